@@ -1,0 +1,441 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference on CPU.
+
+TEST INFRASTRUCTURE.  Runs only in the build container (needs /root/reference,
+which never travels to the GPU box).  Nothing from the reference is copied: this
+script imports it, feeds it seeded inputs and stores inputs' recipes + outputs.
+
+    python oracle/make_goldens.py            # rewrites tests/golden/
+
+Harness = SURVEY.md Appendix C: sys.modules stubs for the missing third-party
+logging/dashboard modules, `.cuda()` -> identity.
+"""
+import json
+import os
+import random
+import shutil
+import sys
+import tempfile
+import types
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parents[1]
+REF = Path(os.environ.get("MASR_REFERENCE", "/root/reference"))
+OUT = REPO / "tests" / "golden"
+sys.path.insert(0, str(REPO))
+
+from oracle import ref_cpu  # noqa: E402  (shared deterministic init + synthetic data recipes)
+
+
+class RunningAvgDict(dict):
+    """Stand-in (true torchexp semantics unknown -> smoothed logs are 'parity unpinned')."""
+    def __init__(self, decay_rate=1.0):
+        super().__init__()
+        self.decay_rate = decay_rate
+        self._n = {}
+    def add(self, info, n=1):
+        for k, v in info.items():
+            v = float(v)
+            if k not in self:
+                self[k] = v
+                self._n[k] = n
+            elif self.decay_rate >= 1.0:
+                tot = self._n[k] + n
+                self[k] = (self[k] * self._n[k] + v * n) / tot
+                self._n[k] = tot
+            else:
+                self[k] = self.decay_rate * self[k] + (1 - self.decay_rate) * v
+
+# --------------------------------------------------------------------------- #
+# stubs (Appendix C)
+# --------------------------------------------------------------------------- #
+def install_stubs():
+    tl = types.ModuleType("tqdmlogger")
+    tl.log = lambda *a, **k: None
+    tl.seclog = lambda *a, **k: None
+    tl.flush = lambda *a, **k: None
+    tl.logger = SimpleNamespace(info=lambda *a, **k: None)
+    an = types.ModuleType("tqdmlogger.ansistyle")
+    an.stylize = lambda s, *a, **k: s
+    an.fg = an.bg = an.attr = lambda *a, **k: ""
+    an.RESET = ""
+    tl.ansistyle = an
+    sys.modules["tqdmlogger"] = tl
+    sys.modules["tqdmlogger.ansistyle"] = an
+
+    te = types.ModuleType("torchexp")
+    tes = types.ModuleType("torchexp.stat")
+    tes.RunningAvgDict = RunningAvgDict
+    te.stat = tes
+    sys.modules["torchexp"] = te
+    sys.modules["torchexp.stat"] = tes
+
+    sys.modules["torch_optimizer"] = types.ModuleType("torch_optimizer")
+
+    cm = types.ModuleType("comet_ml")
+    class _Exp:
+        def __init__(self, *a, **k): self.alive = True
+        def get_key(self): return "stub"
+        def __getattr__(self, name): return lambda *a, **k: None
+    cm.Experiment = cm.ExistingExperiment = _Exp
+    sys.modules["comet_ml"] = cm
+
+    ed = types.ModuleType("editdistance")
+    def _lev(a, b):
+        a, b = list(a), list(b)
+        prev = list(range(len(b) + 1))
+        for i, x in enumerate(a, 1):
+            cur = [i]
+            for j, y in enumerate(b, 1):
+                cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
+            prev = cur
+        return prev[-1]
+    ed.eval = _lev
+    sys.modules["editdistance"] = ed
+    ip = types.ModuleType("IPython")
+    ip.embed = lambda *a, **k: None
+    sys.modules["IPython"] = ip
+
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+
+TINY = {  # tiny transformer used for all model goldens (dropout 0 for parity)
+    "idim": 83, "nheads": 4, "d_model": 64, "d_inner": 128, "dropout": 0.0, "pos_dropout": 0.0,
+    "tgt_share_weight": 1, "encoder": {"nlayers": 2}, "decoder": {"nlayers": 2},
+    "inner_optimizer_cls": "SGD", "inner_optimizer_opt": {"momentum": 0.9, "nesterov": True},
+    "meta_opt_cls": "noam", "meta": {"optimizer_opt": {"k": 1.0, "warmup_steps": 25000}},
+}
+ODIM = 367
+
+
+def synth_batch(seed, ilens, olens, idim=83):
+    """Seeded synthetic batch (shared recipe with tests): feat ~ N(0,1), labels U{1..365}."""
+    g = torch.Generator().manual_seed(seed)
+    B, T = len(ilens), max(ilens)
+    xs = torch.zeros(B, T, idim)
+    for b, n in enumerate(ilens):
+        xs[b, :n] = torch.randn(n, idim, generator=g)
+    ys = [torch.randint(1, 366, (n,), generator=g) for n in olens]
+    return xs, torch.tensor(ilens), ys, torch.tensor(olens)
+
+
+def flat_checks(t):
+    """small fingerprint of a tensor: sum, abs-sum, l2, first/last 4 values."""
+    t = t.detach().double().reshape(-1)
+    return np.array([t.sum(), t.abs().sum(), t.norm(), *t[:4].tolist(), *t[-4:].tolist()])
+
+
+def build_ref_model(cfg, sd):
+    from src.model.transformer_pytorch.mono_transformer_torch import MyTransformer
+    m = MyTransformer(["x"] * ODIM, cfg)
+    missing = m.load_state_dict(sd)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return m
+
+
+def ref_run_batch(model, batch, eps):
+    """The reference's own run_batch arithmetic, by calling its trainer class body:
+    we instantiate the mixin on a minimal Interface so the REAL run_batch code runs."""
+    from src.transformer_torch_trainer import get_trainer
+
+    class _Iface:
+        def __init__(self, config, paras, id2accent):
+            self.global_step = 1          # %500 != 0 -> no probe
+        def load_model(self): pass
+    solver = get_trainer(_Iface, None, None, None)
+    solver.asr_model = model
+    solver.label_smooth_rate = eps
+    solver.asr_opt = SimpleNamespace(zero_grad=lambda: [setattr(p, "grad", None) for p in model.parameters()])
+    xs, il, ys, ol = batch
+    info = solver.run_batch(0, xs, il.clone(), [y.clone() for y in ys], ol.clone(), train=True)
+    return info
+
+
+def gen_model_goldens():
+    cfg = TINY
+    sd = ref_cpu.deterministic_state_dict(cfg, ODIM, seed=7)
+    out = {}
+    cases = {
+        "ragged": ([64, 52, 40, 33], [9, 7, 5, 3]),
+        "same": ([48, 48, 48], [6, 6, 4]),
+        "single": ([37], [5]),
+    }
+    for cname, (ilens, olens) in cases.items():
+        for eps in (0.2, 0.0):
+            model = build_ref_model(cfg, sd)
+            model.train()
+            batch = synth_batch(11, ilens, olens)
+            xs, il, ys, ol = batch
+            with torch.no_grad():
+                logit, gold = model(xs, il.clone(), [y.clone() for y in ys], ol.clone())
+            info = ref_run_batch(model, batch, eps)
+            key = f"{cname}_eps{eps}"
+            out[f"{key}/logit"] = logit.numpy()
+            out[f"{key}/gold"] = gold.numpy()
+            out[f"{key}/loss"] = np.float64(info["loss"])
+            out[f"{key}/acc"] = np.float64(info["acc"])
+            named = dict(model.named_parameters())
+            for n, p in named.items():
+                out[f"{key}/gradfp/{n}"] = flat_checks(p.grad)
+            # a few full gradients (small tensors) for element-wise checks
+            for n in ("feat_extractor.0.weight", "feat_extractor.0.bias", "char_trans.bias",
+                      "encoder.layers.0.norm1.weight", "decoder.layers.1.multihead_attn.in_proj_bias",
+                      "encoder.norm.bias", "decoder.layers.0.self_attn.out_proj.weight"):
+                out[f"{key}/grad/{n}"] = named[n].grad.numpy().copy()
+            if cname == "ragged" and eps == 0.2:
+                # inner step: clip + SGD(nesterov) x2 with the reference's optimizer objects
+                opt = torch.optim.SGD(model.parameters(), lr=ref_cpu.inner_lr(cfg) * 1000, momentum=0.9, nesterov=True)
+                gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 5)
+                opt.step()
+                out["inner/gradnorm0"] = np.float64(gn)
+                batch2 = synth_batch(12, ilens, olens)
+                solver_info = ref_run_batch(model, batch2, eps)
+                gn2 = torch.nn.utils.clip_grad_norm_(model.parameters(), 5)
+                opt.step()
+                out["inner/loss1"] = np.float64(solver_info["loss"])
+                out["inner/gradnorm1"] = np.float64(gn2)
+                for n, p in model.named_parameters():
+                    out[f"inner/paramfp/{n}"] = flat_checks(p)
+                out["inner/param/vgg2enc.bias"] = named["vgg2enc.bias"].detach().numpy().copy()
+                out["inner/param/char_trans.weight"] = named["char_trans.weight"].detach().numpy().copy()
+            if cname == "ragged" and eps == 0.2:
+                model = build_ref_model(cfg, sd)          # fresh weights (the inner steps above moved them)
+                model.eval()
+                with torch.no_grad():
+                    hyp = model.recog(xs, il.clone())
+                out["recog/hyp"] = hyp.numpy()
+                with torch.no_grad():
+                    logit_eval, _ = model(xs, il.clone(), [y.clone() for y in ys], ol.clone())
+                out["eval/logit"] = logit_eval.numpy()
+    np.savez_compressed(OUT / "model_tiny.npz", **out)
+    print("model_tiny.npz", len(out), "arrays")
+
+
+def gen_masks_noam():
+    from src.nets_utils import make_bool_pad_mask, generate_square_subsequent_mask
+    from src.model.transformer_pytorch.optimizer import TransformerOptimizer
+    out = {}
+    out["pad_mask"] = make_bool_pad_mask(torch.tensor([7, 3, 5])).numpy()
+    out["causal5"] = generate_square_subsequent_mask(5).numpy()
+    w = torch.nn.Parameter(torch.zeros(3))
+    opt = TransformerOptimizer(torch.optim.Adam([w], betas=(0.9, 0.98), eps=1e-9), 1.0, 512, 25000)
+    lrs = []
+    for _ in range(12):
+        w.grad = torch.ones(3)
+        opt.step()
+        lrs.append(opt.lr)
+    out["noam_lr_512_25000"] = np.array(lrs)
+    opt = TransformerOptimizer(torch.optim.Adam([w], betas=(0.9, 0.98), eps=1e-9), 0.7, 64, 4)
+    lrs = []
+    for _ in range(12):
+        w.grad = torch.ones(3)
+        opt.step()
+        lrs.append(opt.lr)
+    out["noam_lr_64_4_k0.7"] = np.array(lrs)
+    # Adam trajectory on a fixed gradient sequence (pins beta/eps/bias-correction semantics)
+    g = torch.Generator().manual_seed(3)
+    w = torch.nn.Parameter(torch.randn(16, generator=g))
+    out["adam_w0"] = w.detach().numpy().copy()
+    opt = TransformerOptimizer(torch.optim.Adam([w], betas=(0.9, 0.98), eps=1e-9), 1.0, 64, 4)
+    gs = []
+    for _ in range(5):
+        gr = torch.randn(16, generator=g)
+        gs.append(gr.numpy().copy())
+        w.grad = gr.clone()
+        opt.step()
+    out["adam_grads"] = np.stack(gs)
+    out["adam_w5"] = w.detach().numpy().copy()
+    np.savez_compressed(OUT / "masks_noam.npz", **out)
+    print("masks_noam.npz")
+
+
+def write_toy_shard(root, accent, split, n_utt, seed, idim=83, lo=12, hi=40):
+    """Appendix D layout: feat.dat (NPY format), ilens/olens/label .npy."""
+    from numpy.lib.format import open_memmap
+    rng = np.random.RandomState(seed)
+    d = Path(root) / accent / split
+    d.mkdir(parents=True, exist_ok=True)
+    ilens = rng.randint(lo, hi, size=n_utt).astype(np.int64)
+    olens = rng.randint(2, 6, size=n_utt).astype(np.int64)
+    feat = open_memmap(d / "feat.dat", mode="w+", dtype=np.float32, shape=(int(ilens.sum()), idim))
+    feat[:] = rng.randn(int(ilens.sum()), idim).astype(np.float32)
+    feat.flush()
+    del feat
+    np.save(d / "ilens.npy", ilens)
+    np.save(d / "olens.npy", olens)
+    np.save(d / "label.npy", rng.randint(1, 366, size=int(olens.sum())).astype(np.int64))
+    return ilens, olens
+
+
+def gen_sampler_goldens():
+    from src.io.dataset import BucketSampler
+    out = {}
+    rng = np.random.RandomState(5)
+    ilens = rng.randint(8, 60, size=200)
+    out["ilens"] = ilens
+    random.seed(531)
+    np.random.seed(531)
+    s = BucketSampler(ilens, min_ilen=10, max_ilen=50, half_batch_ilen=30, batch_size=4,
+                      bucket_size=1, bucket_reverse=False, drop_last=False)
+    for ep in range(2):
+        batches = list(iter(s))
+        out[f"epoch{ep}_flat"] = np.array([i for b in batches for i in b])
+        out[f"epoch{ep}_sizes"] = np.array([len(b) for b in batches])
+    out["len"] = np.int64(len(s))
+    np.savez_compressed(OUT / "bucket_sampler.npz", **out)
+    print("bucket_sampler.npz")
+
+
+def gen_fomaml_goldens():
+    """Full reference FOMAML run through get_trainer(FOMetaASRInterface...) on toy shards."""
+    import yaml
+    from src.fo_meta_interface import FOMetaASRInterface
+    from src.transformer_torch_trainer import get_trainer
+    tmp = Path(tempfile.mkdtemp(prefix="masr_gold_"))
+    cwd = os.getcwd()
+    try:
+        (tmp / "data").mkdir()
+        for f in ("accent-code.json", "valid_train_en_unigram150.model", "valid_train_en_unigram150_units.txt"):
+            shutil.copy(REF / "data" / f, tmp / "data" / f)     # runtime copy only, temp dir
+        accents = ["african", "australia"]
+        for ai, a in enumerate(accents):
+            write_toy_shard(tmp / "data", a, "train", 16, seed=100 + ai)
+            write_toy_shard(tmp / "data", a, "dev", 4, seed=200 + ai)
+        cfg = {
+            "asr_model": dict(TINY),
+            "solver": {"setting": "gold", "data_root": "data", "total_steps": 10,
+                       "spm_mapping": "data/valid_train_en_unigram150_units.txt",
+                       "spm_model": "data/valid_train_en_unigram150.model",
+                       "label_smoothing": 0.2, "eval_ival": 2, "log_ival": 1, "save_ival": 2,
+                       "batch_size": 4, "dev_batch_size": 4, "min_ilen": 10, "max_ilen": 50,
+                       "dev_max_ilen": 3000, "half_batch_ilen": 30},
+        }
+        cfg["asr_model"]["meta"]["optimizer_opt"]["warmup_steps"] = 4     # visible meta updates
+        os.chdir(tmp)
+        id2accent = json.load(open("data/accent-code.json"))
+        paras = SimpleNamespace(
+            config="x", pretrain_suffix="g", pretrain_accents=["af", "au"], num_pretrain=2, tgt_accent="ca",
+            runs=0, overwrite=True, seed=531, no_cuda=True, no_memmap=False, no_bucket=False, meta_k=2,
+            meta_batch_size=2, sample_strategy="normal", max_step=3, resume=False, resume_step=-1,
+            use_tensorboard=False, model_name="transformer", algo="fomaml", njobs=0, cuda=False,
+            is_bucket=True, is_memmap=True)
+        random.seed(531); np.random.seed(531); torch.manual_seed(531)
+        solver = get_trainer(FOMetaASRInterface, cfg, paras, id2accent)
+        solver.load_data()
+        solver.set_model()
+        # replace the RNG-order-dependent init by the shared deterministic one
+        sd = ref_cpu.deterministic_state_dict(cfg["asr_model"], ODIM, seed=7)
+        solver.asr_model.load_state_dict(sd)
+        solver.load_model()                       # re-clone _original + fresh meta optimizer
+        # record every batch the reference feeds to run_batch, and the info it returns
+        rec = []
+        orig_run_batch = solver.run_batch
+        def spy(idx, x, ilens, ys, olens, train, accent_idx=None):
+            info = orig_run_batch(idx, x, ilens.clone(), [y.clone() for y in ys], olens.clone(),
+                                  train=train, accent_idx=accent_idx)
+            rec.append((int(idx), x.numpy().copy(), ilens.numpy().copy(),
+                        [y.numpy().copy() for y in ys], olens.numpy().copy(), dict(info)))
+            return info
+        from functools import partial
+        solver._train = partial(spy, train=True)
+        solver.exec()
+        out = {}
+        out["n_calls"] = np.int64(len(rec))
+        for i, (idx, x, il, ys, ol, info) in enumerate(rec):
+            out[f"call{i}/accent"] = np.int64(idx)
+            out[f"call{i}/ilens"] = il
+            out[f"call{i}/olens"] = ol
+            out[f"call{i}/x_fp"] = flat_checks(torch.from_numpy(x))
+            out[f"call{i}/ys"] = np.concatenate(ys)
+            out[f"call{i}/loss"] = np.float64(info["loss"])
+            out[f"call{i}/acc"] = np.float64(info["acc"])
+        for n, p in solver._original.items():
+            out[f"meta/fp/{n}"] = flat_checks(p)
+        out["meta/param/vgg2enc.bias"] = solver._original["vgg2enc.bias"].detach().numpy().copy()
+        out["meta/param/decoder.norm.weight"] = solver._original["decoder.norm.weight"].detach().numpy().copy()
+        out["meta/param/char_trans.bias"] = solver._original["char_trans.bias"].detach().numpy().copy()
+        out["meta/step_num"] = np.int64(solver.meta_opt.step_num)
+        out["meta/lr"] = np.float64(solver.meta_opt.lr)
+        out["global_step"] = np.int64(solver.global_step)
+        out["inner_lr"] = np.float64(solver.inner_lr)
+        snap = torch.load(solver.log_dir / "snapshot.latest") if (solver.log_dir / "snapshot.latest").exists() else None
+        out["files"] = np.array(sorted(p.name for p in solver.log_dir.iterdir()))
+        for f in solver.log_dir.iterdir():
+            if f.name.startswith(("dev_", "train_", "best_")) :
+                out[f"log/{f.name}"] = np.array(open(f).read())
+        for n, t in snap.items():
+            out[f"snap/fp/{n}"] = flat_checks(t)
+        out["state_dict_keys"] = np.array(list(solver.asr_model.state_dict().keys()))
+        np.savez_compressed(OUT / "fomaml_toy.npz", **out)
+        print("fomaml_toy.npz calls:", len(rec), "files:", out["files"])
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def gen_ctc_goldens():
+    """nn.CTCLoss(blank=0, reduction='mean', zero_infinity=True) as called at blstm_trainer.py:22,65-70."""
+    out = {}
+    g = torch.Generator().manual_seed(9)
+    T, B, C = 24, 4, 11
+    logits = torch.randn(T, B, C, generator=g, requires_grad=True)
+    tl = torch.tensor([5, 3, 7, 1])
+    il = torch.tensor([24, 20, 15, 9])
+    tgt = torch.randint(1, C, (int(tl.sum()),), generator=g)
+    tgt[1] = tgt[0]                                   # repeated label case
+    lp = torch.log_softmax(logits, dim=-1)
+    loss = torch.nn.CTCLoss(blank=0, reduction="mean", zero_infinity=True)(lp, tgt, il, tl)
+    loss.backward()
+    out.update(logits=logits.detach().numpy(), targets=tgt.numpy(), il=il.numpy(), tl=tl.numpy(),
+               loss=np.float64(loss.item()), grad_logits=logits.grad.numpy())
+    # infeasible sample (target longer than input) -> zero_infinity
+    logits2 = torch.randn(4, 2, C, generator=g, requires_grad=True)
+    tl2 = torch.tensor([6, 2]); il2 = torch.tensor([4, 4])
+    tgt2 = torch.randint(1, C, (8,), generator=g)
+    loss2 = torch.nn.CTCLoss(blank=0, reduction="mean", zero_infinity=True)(torch.log_softmax(logits2, -1), tgt2, il2, tl2)
+    loss2.backward()
+    out.update(inf_logits=logits2.detach().numpy(), inf_targets=tgt2.numpy(), inf_il=il2.numpy(), inf_tl=tl2.numpy(),
+               inf_loss=np.float64(loss2.item()), inf_grad_logits=logits2.grad.numpy())
+    np.savez_compressed(OUT / "ctc.npz", **out)
+    print("ctc.npz")
+
+
+def gen_init_goldens():
+    """Reference init under torch.manual_seed(531) (RNG-order sensitive; pins our init replay)."""
+    import yaml
+    cfg = yaml.safe_load(open(REF / "config/transformer/pretrain/fometa-hkust.yaml"))["asr_model"]
+    from src.model.transformer_pytorch.mono_transformer_torch import MyTransformer
+    out = {}
+    for tag, c in (("hkust", cfg), ("tiny", TINY)):
+        torch.manual_seed(531)
+        m = MyTransformer(["x"] * ODIM, c)
+        sd = m.state_dict()
+        out[f"{tag}/keys"] = np.array(list(sd.keys()))
+        out[f"{tag}/nparams"] = np.int64(sum(p.numel() for p in m.parameters()))
+        for n, t in sd.items():
+            if n != "pos_encoder.pe":
+                out[f"{tag}/fp/{n}"] = flat_checks(t)
+    np.savez_compressed(OUT / "init.npz", **out)
+    print("init.npz")
+
+
+def main():
+    OUT.mkdir(parents=True, exist_ok=True)
+    install_stubs()
+    sys.path.insert(0, str(REF))
+    torch.set_num_threads(4)
+    gen_masks_noam()
+    gen_sampler_goldens()
+    gen_ctc_goldens()
+    gen_init_goldens()
+    gen_model_goldens()
+    gen_fomaml_goldens()
+
+
+if __name__ == "__main__":
+    main()

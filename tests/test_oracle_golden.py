@@ -1,0 +1,219 @@
+"""The CPU oracle (oracle/ref_cpu.py) against vectors captured from the real reference
+(oracle/make_goldens.py).  CPU only; pins the oracle (prompt section 3 / SURVEY 8c)."""
+import math
+import random
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu
+from oracle.make_goldens import TINY, ODIM, synth_batch, flat_checks
+
+torch.set_num_threads(4)
+
+
+def _fp_close(a, b, rtol=2e-4, atol=1e-6):
+    a, b = np.asarray(a), np.asarray(b)
+    scale = max(np.abs(b[2]), 1e-12)            # l2 norm of the tensor
+    assert np.all(np.abs(a - b) <= rtol * np.abs(b) + atol + 1e-5 * scale), (a, b)
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return np.load(golden_dir / "model_tiny.npz")
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return ref_cpu.deterministic_state_dict(TINY, ODIM, seed=7)
+
+
+CASES = {"ragged": ([64, 52, 40, 33], [9, 7, 5, 3]), "same": ([48, 48, 48], [6, 6, 4]), "single": ([37], [5])}
+
+
+@pytest.mark.parametrize("cname", list(CASES))
+@pytest.mark.parametrize("eps", [0.2, 0.0])
+def test_forward_loss_grads(G, sd, cname, eps):
+    ilens, olens = CASES[cname]
+    batch = synth_batch(11, ilens, olens)
+    p = ref_cpu.leafify(sd, TINY)
+    info, grads, logit, gold = ref_cpu.run_batch_train(p, TINY, batch, eps)
+    key = f"{cname}_eps{eps}"
+    np.testing.assert_allclose(logit.numpy(), G[f"{key}/logit"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_array_equal(gold.numpy(), G[f"{key}/gold"])
+    assert abs(info["loss"] - float(G[f"{key}/loss"])) <= 1e-5 * abs(float(G[f"{key}/loss"]))
+    assert info["acc"] == float(G[f"{key}/acc"])
+    for n, g in grads.items():
+        _fp_close(flat_checks(g), G[f"{key}/gradfp/{n}"])
+    for k in G.files:
+        if k.startswith(f"{key}/grad/"):
+            n = k[len(f"{key}/grad/"):]
+            ref = G[k]
+            np.testing.assert_allclose(grads[n].numpy(), ref, rtol=1e-3, atol=1e-5 * np.abs(ref).max() + 1e-9)
+
+
+def test_inner_steps(G, sd):
+    """two inner steps: run_batch -> clip 5 -> SGD(momentum .9, nesterov) with lr x1000."""
+    ilens, olens = CASES["ragged"]
+    p = ref_cpu.leafify(sd, TINY)
+    bufs = {}
+    lr = ref_cpu.inner_lr(TINY) * 1000
+    i0 = ref_cpu.inner_step(p, TINY, synth_batch(11, ilens, olens), 0.2, bufs, lr)
+    i1 = ref_cpu.inner_step(p, TINY, synth_batch(12, ilens, olens), 0.2, bufs, lr)
+    assert abs(i0["grad_norm"] - float(G["inner/gradnorm0"])) <= 1e-4 * float(G["inner/gradnorm0"])
+    assert abs(i1["grad_norm"] - float(G["inner/gradnorm1"])) <= 1e-4 * float(G["inner/gradnorm1"])
+    assert abs(i1["loss"] - float(G["inner/loss1"])) <= 1e-5 * float(G["inner/loss1"])
+    for n in ref_cpu.grad_param_names(p, TINY):
+        _fp_close(flat_checks(p[n]), G[f"inner/paramfp/{n}"], rtol=1e-5)
+    np.testing.assert_allclose(p["vgg2enc.bias"].detach().numpy(), G["inner/param/vgg2enc.bias"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(p["char_trans.weight"].detach().numpy(), G["inner/param/char_trans.weight"], rtol=1e-5, atol=5e-7)
+
+
+def test_recog_and_eval(G, sd):
+    ilens, olens = CASES["ragged"]
+    xs, il, ys, ol = synth_batch(11, ilens, olens)
+    with torch.no_grad():
+        hyp = ref_cpu.recog_greedy(sd, TINY, xs, il)
+        logit, _ = ref_cpu.model_forward(sd, TINY, xs, il, ys, ol.clone())
+    np.testing.assert_array_equal(hyp.numpy(), G["recog/hyp"])
+    np.testing.assert_allclose(logit.numpy(), G["eval/logit"], rtol=1e-4, atol=2e-5)
+
+
+def test_olens_mutated_in_place(sd):
+    """quirk Q6: preprocess does olens += 1 on the caller's tensor."""
+    xs, il, ys, ol = synth_batch(11, [37], [5])
+    with torch.no_grad():
+        ref_cpu.model_forward(sd, TINY, xs, il, ys, ol)
+    assert ol.tolist() == [6]
+
+
+def test_masks_noam_adam(golden_dir):
+    g = np.load(golden_dir / "masks_noam.npz")
+    np.testing.assert_array_equal(ref_cpu.make_bool_pad_mask(torch.tensor([7, 3, 5])).numpy(), g["pad_mask"])
+    np.testing.assert_array_equal(ref_cpu.generate_square_subsequent_mask(5).numpy(), g["causal5"])
+    lrs = [ref_cpu.noam_lr(t, 1.0, 512, 25000) for t in range(1, 13)]
+    np.testing.assert_allclose(lrs, g["noam_lr_512_25000"], rtol=1e-12)
+    lrs = [ref_cpu.noam_lr(t, 0.7, 64, 4) for t in range(1, 13)]
+    np.testing.assert_allclose(lrs, g["noam_lr_64_4_k0.7"], rtol=1e-12)
+    w = {"w": torch.from_numpy(g["adam_w0"].copy())}
+    st = {}
+    for t, gr in enumerate(g["adam_grads"], 1):
+        ref_cpu.adam_step(w, {"w": torch.from_numpy(gr.copy())}, st, ref_cpu.noam_lr(t, 1.0, 64, 4))
+    np.testing.assert_allclose(w["w"].numpy(), g["adam_w5"], rtol=1e-6, atol=1e-7)
+
+
+def test_bucket_sampler(golden_dir):
+    g = np.load(golden_dir / "bucket_sampler.npz")
+    random.seed(531)
+    np.random.seed(531)
+    plan = ref_cpu.bucket_sampler_plan(g["ilens"], 10, 50, 30, 4)
+    for ep in range(2):
+        batches = list(ref_cpu.bucket_sampler_epoch(plan))
+        np.testing.assert_array_equal(np.array([i for b in batches for i in b]), g[f"epoch{ep}_flat"])
+        np.testing.assert_array_equal(np.array([len(b) for b in batches]), g[f"epoch{ep}_sizes"])
+    assert len(batches) == int(g["len"])
+    # every batch holds utterances of one length (bucket_size 1) and ilen in (min_ilen, max_ilen-2]
+    il = g["ilens"]
+    for b in batches:
+        assert len({int(il[i]) for i in b}) == 1
+        assert 10 < il[b[0]] <= 48
+
+
+def test_ctc(golden_dir):
+    g = np.load(golden_dir / "ctc.npz")
+    for pre in ("", "inf_"):
+        logits = torch.from_numpy(g[pre + "logits"])
+        lp = torch.log_softmax(logits, -1)
+        loss, grad_lp = ref_cpu.ctc_loss_np(lp.numpy(), g[pre + "targets"], g[pre + "il"], g[pre + "tl"])
+        assert abs(loss - float(g[pre + "loss"])) <= 1e-6 * max(1.0, abs(float(g[pre + "loss"])))
+        glp = torch.from_numpy(grad_lp).float()
+        grad_logits = glp - lp.exp() * glp.sum(-1, keepdim=True)       # log_softmax backward
+        np.testing.assert_allclose(grad_logits.numpy(), g[pre + "grad_logits"], rtol=1e-4, atol=1e-6)
+
+
+def test_fomaml_toy(golden_dir, tmp_path):
+    """Replay of the reference's full FOMAML run (2 accents, meta_k=2, 2 meta-steps): same toy
+    shards, same RNG streams -> same batches -> same losses and same final meta weights."""
+    from oracle.make_goldens import write_toy_shard
+    g = np.load(golden_dir / "fomaml_toy.npz")
+    cfg = dict(TINY)
+    cfg["meta"] = {"optimizer_opt": {"k": 1.0, "warmup_steps": 4}}
+    accents = ["african", "australia"]
+    shards = []
+    for ai, a in enumerate(accents):
+        write_toy_shard(tmp_path, a, "train", 16, seed=100 + ai)
+        d = tmp_path / a / "train"
+        feat = np.load(d / "feat.dat", mmap_mode="r")
+        ilens, olens, label = np.load(d / "ilens.npy"), np.load(d / "olens.npy"), np.load(d / "label.npy")
+        iptr = np.concatenate([[0], np.cumsum(ilens)])
+        optr = np.concatenate([[0], np.cumsum(olens)])
+        shards.append((feat, iptr, label, optr, ilens, olens))
+    random.seed(531)
+    np.random.seed(531)
+
+    def new_iter(ai):
+        feat, iptr, label, optr, ilens, olens = shards[ai]
+        plan = ref_cpu.bucket_sampler_plan(ilens, 10, 50, 30, 4)
+        for idxs in ref_cpu.bucket_sampler_epoch(plan):
+            yield ref_cpu.collate(feat, iptr, label, optr, ilens, olens, idxs)
+
+    # DataContainer.__init__ builds train iterators (and samplers) in accent order (dataset.py:223-235)
+    its = []
+    for ai in range(2):
+        feat, iptr, label, optr, ilens, olens = shards[ai]
+        plan = ref_cpu.bucket_sampler_plan(ilens, 10, 50, 30, 4)     # consumes `random` at construction
+        its.append([plan, None])
+
+    def get_item(ai):
+        plan, it = its[ai]
+        feat, iptr, label, optr, ilens, olens = shards[ai]
+        if it is None:
+            it = iter(ref_cpu.bucket_sampler_epoch(plan))            # np.random consumed lazily at first next()
+            its[ai][1] = it
+        try:
+            idxs = next(it)
+        except StopIteration:
+            plan = ref_cpu.bucket_sampler_plan(ilens, 10, 50, 30, 4)
+            it = iter(ref_cpu.bucket_sampler_epoch(plan))
+            its[ai] = [plan, it]
+            idxs = next(it)
+        return ref_cpu.collate(feat, iptr, label, optr, ilens, olens, idxs)
+
+    meta = OrderedDict((n, t.clone()) for n, t in ref_cpu.deterministic_state_dict(cfg, ODIM, 7).items())
+    if cfg["tgt_share_weight"]:
+        meta["pre_embed.weight"] = meta["char_trans.weight"]
+    adam_state = {}
+    task_ids = [0, 1]
+    call = 0
+    for step in (1, 2):
+        random.shuffle(task_ids)
+        tasks = []
+        for ai in task_ids[:2]:
+            tr = [get_item(ai) for _ in range(2)]
+            val = get_item(ai)
+            tasks.append((tr, val))
+            for b in tr + [val]:
+                assert int(g[f"call{call}/accent"]) == ai
+                np.testing.assert_array_equal(b[1].numpy(), g[f"call{call}/ilens"])
+                np.testing.assert_array_equal(np.concatenate([y.numpy() for y in b[2]]), g[f"call{call}/ys"])
+                call += 1
+        infos, lr = ref_cpu.fomaml_meta_step(meta, cfg, tasks, 0.2, adam_state, step)
+        # val losses are the 3rd, 6th call of each meta step
+        base = (step - 1) * 6
+        for ti, info in enumerate(infos):
+            ref = float(g[f"call{base + ti * 3 + 2}/loss"])
+            assert abs(info["loss"] - ref) <= 2e-5 * ref
+    assert call == int(g["n_calls"])
+    assert abs(lr - float(g["meta/lr"])) <= 1e-12
+    # Adam's update is +-lr * m/sqrt(v): a 1e-5 relative wobble in a near-cancelling conv gradient moves the
+    # update by ~1e-4*lr, so weights are compared at 2% of the step size (lr), i.e. far below 1e-3 relative.
+    tol = 0.02 * lr
+    for n in ref_cpu.grad_param_names(meta, cfg):
+        a, b = flat_checks(meta[n]), g[f"meta/fp/{n}"]
+        assert abs(a[2] - b[2]) <= 1e-4 * b[2] + 1e-9, n                 # l2 norm
+        assert np.all(np.abs(a[3:] - b[3:]) <= tol), n                   # first/last 4 values
+    for n in ("vgg2enc.bias", "char_trans.bias", "decoder.norm.weight"):
+        assert np.abs(meta[n].numpy() - g[f"meta/param/{n}"]).max() <= tol, n
+    assert abs(ref_cpu.inner_lr(cfg) - float(g["inner_lr"])) < 1e-15
