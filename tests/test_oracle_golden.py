@@ -212,7 +212,10 @@ def test_fomaml_toy(golden_dir, tmp_path):
     tol = 0.02 * lr
     for n in ref_cpu.grad_param_names(meta, cfg):
         a, b = flat_checks(meta[n]), g[f"meta/fp/{n}"]
-        assert abs(a[2] - b[2]) <= 1e-3 * b[2] + 1e-9, n                 # l2 norm
+        # the key third of every in_proj_bias has an exactly-zero true gradient (softmax is invariant to a
+        # per-query shift), so Adam turns pure rounding noise into +-lr steps there: not comparable.
+        if not n.endswith("in_proj_bias"):
+            assert abs(a[2] - b[2]) <= 1e-3 * b[2] + 1e-9, n             # l2 norm
         assert np.all(np.abs(a[3:] - b[3:]) <= tol), n                   # first/last 4 values
     for n in ("vgg2enc.bias", "char_trans.bias", "decoder.norm.weight"):
         assert np.abs(meta[n].numpy() - g[f"meta/param/{n}"]).max() <= tol, n
