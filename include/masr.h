@@ -1,0 +1,131 @@
+/* libmasr -- C ABI of the MI355X-native meta-ASR training path.
+ *
+ * Drop-in boundary for the hot path of sunprinceS/MetaASR-CrossAccent.
+ * The reference has no native code and no FFI: its "operator boundary" is the Python mixin
+ * contract  get_trainer(cls, config, paras, id2accent) -> solver with
+ * solver.run_batch(idx, x, ilens, ys, olens, train) (src/transformer_torch_trainer.py:13-99)
+ * driven by FOMetaASRInterface.run_task/_partial_meta_update/_final_meta_update
+ * (src/fo_meta_interface.py:128-250).  Each entry point below names the reference code it
+ * replaces.  The Python host mirror (metaasr-crossaccent_amd/) binds these with ctypes; see
+ * INTEGRATION.md for the stub a maintainer of the reference would add.
+ *
+ * Conventions: plain pointers and sizes only (no torch types).  All device pointers are HIP
+ * device memory owned by the caller.  Every call is ordered on the caller's hipStream_t
+ * (passed as void*), allocates nothing and never synchronises unless stated.  Return 0 on
+ * success, <0 on error (text via masr_last_error()).  A handle is not thread-safe.
+ */
+#ifndef MASR_H
+#define MASR_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct masr_model masr_model;
+
+/* asr_model block of the reference YAML (config/transformer/pretrain/fometa-hkust.yaml:13-27)
+ * + odim (= len(id2units), src/pretrain_interface.py:38-43) + solver.label_smoothing. */
+typedef struct masr_config {
+    int32_t idim, odim, d_model, nheads, d_inner, enc_layers, dec_layers;
+    int32_t tie_weights;          /* tgt_share_weight != 0 (mono_transformer_torch.py:66-70) */
+    float dropout, pos_dropout, label_smoothing;
+} masr_config;
+
+#define MASR_TRAIN 1              /* run_batch(train=True): forward + loss + backward            */
+#define MASR_EVAL 0               /* run_batch(train=False): forward + loss only (dropout off)   */
+
+int masr_version(void);
+const char* masr_last_error(void);
+
+/* MyTransformer.__init__ (mono_transformer_torch.py:37-104): builds the parameter table only. */
+masr_model* masr_create(const masr_config* cfg);
+void masr_destroy(masr_model* m);
+
+/* Flat fp32 parameter buffer layout = the reference state_dict order without
+ * the pos_encoder.pe buffer and, when tied, without pre_embed.weight (alias of char_trans.weight). */
+int64_t masr_param_numel(const masr_model* m);
+int masr_param_count(const masr_model* m);
+int masr_param_info(const masr_model* m, int idx, char* name, int name_cap, int64_t shape[4], int* ndim, int64_t* offset);
+
+/* workspace needed for a batch of B utterances x T frames with L = max(olen)+1 target positions */
+int64_t masr_workspace_bytes(const masr_model* m, int B, int T, int L);
+/* params/grads: fp32 [masr_param_numel]; pe: fp32 [3000][d_model] (PositionalEncoding buffer, :16-28) */
+int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void* workspace, int64_t ws_bytes);
+/* rebuild the bf16 operand shadows after ANY change of params (load_state_dict, optimizer step) */
+int masr_refresh(masr_model* m, void* stream);
+void masr_set_seed(masr_model* m, uint64_t seed);      /* dropout stream */
+
+/* TransformerTrainer.run_batch (src/transformer_torch_trainer.py:59-99) = MyTransformer.forward
+ * (:178-208) + label-smoothed CE (:64-84) + (train) zero_grad/backward.  xs: device fp32 [B][T][idim];
+ * ilens/olens/ys_flat: HOST int64 (ys_flat = concatenated labels, sum(olens) entries).  Gradients
+ * are left in `grads`.  olens is NOT mutated (quirk Q6 is reproduced by the Python mirror). */
+int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const int64_t* ys_flat,
+                   const int64_t* olens, int B, int T, int flags, void* stream);
+/* out[0]=loss, out[1]=n_correct, out[2]=n_total, out[3]=last grad norm.  Synchronises the stream. */
+int masr_read_stats(masr_model* m, float out[4], void* stream);
+/* device view of the last forward's logits: fp32 [rows = B*L][ld], first odim columns valid; and gold */
+int masr_last_logits(masr_model* m, const float** logits, const int32_t** gold, int* rows, int* L, int* ld);
+
+/* nn.utils.clip_grad_norm_(parameters, max_norm) (fo_meta_interface.py:148-149,242-243): norm only */
+int masr_grad_norm(masr_model* m, void* stream);
+/* ... followed by `if not isnan(norm): SGD(lr, momentum, nesterov).step()` (fo_meta_interface.py:228-248) */
+int masr_clip_sgd_step(masr_model* m, float* momentum_buf, float max_norm, float lr, float momentum, int nesterov,
+                       int first_step, void* stream);
+/* clip in place (multi_interface.py:108-109, mono fine-tune) */
+int masr_clip_grads(masr_model* m, float max_norm, void* stream);
+/* _partial_meta_update after the val-batch clip (fo_meta_interface.py:148-154,180-198): updates += clip(grads) */
+int masr_clip_accumulate(masr_model* m, float* updates, float max_norm, void* stream);
+
+/* flat helpers on arbitrary device buffers */
+int masr_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                   float beta1, float beta2, float eps, int step, void* stream);      /* torch.optim.Adam, optimizer.py:19-21 */
+int masr_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr, float momentum,
+                  int nesterov, int first_step, void* stream);
+int masr_scale(float* x, int64_t n, float a, void* stream);                           /* _updates /= counter (:201-202) */
+int masr_axpy(float* y, const float* x, int64_t n, float a, void* stream);
+int masr_copy(float* dst, const float* src, int64_t n, void* stream);                 /* load_state_dict(_original) (:226) */
+
+/* MyTransformer.recog (mono_transformer_torch.py:143-176): greedy decode, out int32 [Ldec][B] (device),
+ * Ldec = max(floor(ilens/4)).  Needs workspace for L = Ldec. */
+int masr_recog(masr_model* m, const float* xs, const int64_t* ilens, int B, int T, int32_t* out, void* stream);
+
+/* collate_fn zero-padding of CommonVoiceDataset rows (src/io/dataset.py:21-33,147-153) done on the GPU:
+ * feat fp32 [sum T_i][D] resident in HBM, row_start int64 [B] (device), lens int32 [B] (device). */
+int masr_gather_pad(const float* feat, const int64_t* row_start, const int32_t* lens, float* xs, int B, int Tmax, int D, void* stream);
+
+/* nn.CTCLoss(blank, reduction='mean', zero_infinity=True) on log_softmax(logits) with its gradient wrt the
+ * logits (src/blstm_trainer.py:22,62-70).  logits fp32 [T][B][C] device; targets/tgt_off/in_len/tgt_len int32 device.
+ * nll [B], loss [1], grad [T][B][C] device outputs; work: masr_ctc_work_floats(T,B,maxS) floats. */
+int64_t masr_ctc_work_floats(int T, int B, int maxS);
+int masr_ctc_loss(const float* logits, const int32_t* targets, const int32_t* tgt_off, const int32_t* in_len,
+                  const int32_t* tgt_len, int T, int B, int C, int blank, float* nll, float* loss, float* grad,
+                  float* work, int maxS, void* stream);
+
+/* per-kernel-family device timing (HIP events on the launch stream) for bench.py's roofline block */
+#define MASR_PROF_CONV_FWD 0
+#define MASR_PROF_CONV_DGRAD 1
+#define MASR_PROF_CONV_WGRAD 2
+#define MASR_PROF_GEMM 3
+#define MASR_PROF_ATTN 4
+#define MASR_PROF_OTHER 5
+#define MASR_PROF_N 6
+int masr_profile_enable(masr_model* m, int on);
+/* sums since the last call: ms[MASR_PROF_N], launches[MASR_PROF_N]; synchronises */
+int masr_profile_read(masr_model* m, float* ms, int* launches);
+
+/* standalone kernel entry points used by the parity tests (bf16 passed as uint16_t bit patterns) */
+int masr_test_gemm(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int K, int reduction_major,
+                   const float* bias, int relu, float* C32, int64_t ldc, void* stream);
+int masr_test_conv3x3(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, uint16_t* out,
+                      int B, int H, int W, int CIN, int COUT, void* stream);
+int masr_test_conv3x3_wgrad(const uint16_t* in, const uint16_t* dy, float* dw, float* slab, int64_t slab_floats,
+                            int B, int H, int W, int CIN, int COUT, void* stream);
+int64_t masr_test_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT);
+int masr_test_attention(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* dout, uint16_t* o,
+                        uint16_t* dq, uint16_t* dk, uint16_t* dv, float* lse, float* delta, const int32_t* klens,
+                        int B, int H, int Tq, int Tk, int hd, int causal, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

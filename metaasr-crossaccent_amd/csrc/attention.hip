@@ -1,0 +1,449 @@
+// Fused multi-head attention forward / backward (flash-style, online softmax) for gfx950.
+//
+// Restates torch nn.MultiheadAttention as used by nn.TransformerEncoder/DecoderLayer in
+// src/model/transformer_pytorch/mono_transformer_torch.py:74-98,200-203:
+//   scores = q k^T / sqrt(hd); key-padding mask (encoder self, decoder cross) or causal mask
+//   (decoder self; no target key-padding mask -- quirk Q7); softmax; dropout on the
+//   probabilities; . v
+// q/k/v are read straight out of the packed in_proj GEMM output (row b*T+t, head h at
+// column h*hd), so no head split/merge copies exist.  Score matrices never reach HBM.
+//
+// One workgroup = 4 waves = 64 query rows (fwd, dQ) or 64 key rows (dK/dV); K/V (or Q/dO)
+// tiles of 64 rows live in LDS in their natural [row][dim] layout and serve both MFMA operand
+// forms: 16-byte row reads (contraction over dim) and ds_read_b64_tr_b16 transposing reads
+// (contraction over the row index).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BLK = 64;             // rows per tile
+constexpr int LDP = 72;             // P scratch row stride (elements)
+constexpr float NEG = -1e30f;
+
+template <int HD> struct Cfg {
+    static constexpr int HDP = HD < 32 ? 32 : HD;   // contraction length for q.k (zero padded)
+    static constexpr int KS = HDP / 32;
+    static constexpr int DT = HD / 16;
+    static constexpr int LD = HDP + 16;             // tile row stride: (LD*2 B) == 8 dwords mod 64 for hd 64
+};
+
+typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+
+// B-operand fragment, contraction over the tile's ROW index: rows krow0..krow0+31, columns c0..c0+15.
+// k order inside the fragment is permuted (4g+e | 16+4g+e); the A operand uses frag_a_perm to match.
+template <int LD>
+__device__ __forceinline__ bf16x8 frag_tr(const bf16* tile, int krow0, int c0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const bf16* a0 = tile + (krow0 + 4 * g + q) * LD + c0 + 4 * p;
+    const bf16* a1 = a0 + 16 * LD;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)a0);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)a1);
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+// A-operand fragment from the P scratch ([16 rows][64 cols]) with the same k permutation
+__device__ __forceinline__ bf16x8 frag_a_perm(const bf16* sp, int k0, int lane) {
+    const int g = lane >> 4, row = lane & 15;
+    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(sp + row * LDP + k0 + 4 * g);
+    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(sp + row * LDP + k0 + 16 + 4 * g);
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+// row-read fragment (contraction over dim): rows r0..r0+15, dims ks*32 + 8g..
+template <int LD>
+__device__ __forceinline__ bf16x8 frag_row(const bf16* tile, int r0, int ks, int lane) {
+    return ld8(tile + (r0 + (lane & 15)) * LD + ks * 32 + (lane >> 4) * 8);
+}
+// fragment of 16 rows straight from global memory (rows beyond nrows / dims beyond HD are zero)
+template <int HD>
+__device__ __forceinline__ bf16x8 frag_global(const bf16* base, long ld, int row, int nrows, int ks, int lane) {
+    const int r = row + (lane & 15), dcol = ks * 32 + (lane >> 4) * 8;
+    if (r < nrows && dcol < HD) return ld8(base + (long)r * ld + dcol);
+    return zero8();
+}
+
+// copy a [64][HD] tile (rows row0.. of a [nrows] matrix) into LDS, zero-filling missing rows
+template <int HD>
+__device__ __forceinline__ void load_tile(bf16* dst, const bf16* src, long ld, int row0, int nrows, int tid) {
+    constexpr int LD = Cfg<HD>::LD;
+    constexpr int CPR = HD / 8;                        // chunks per row
+    for (int c = tid; c < BLK * CPR; c += 256) {
+        const int r = c / CPR, dc = (c % CPR) * 8;
+        bf16x8 v = zero8();
+        if (row0 + r < nrows) v = ld8(src + (long)(row0 + r) * ld + dc);
+        st8(dst + r * LD + dc, v);
+    }
+}
+template <int HD>
+__device__ __forceinline__ void zero_tile(bf16* dst, int tid) {
+    constexpr int LD = Cfg<HD>::LD;
+    for (int c = tid; c < BLK * LD / 8; c += 256) st8(dst + c * 8, zero8());
+}
+
+// ---------------------------------------------------------------------------- forward
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    using C = Cfg<HD>;
+    constexpr int LD = C::LD, KS = C::KS, DT = C::DT;
+    __shared__ __attribute__((aligned(16))) bf16 sK[BLK * LD];
+    __shared__ __attribute__((aligned(16))) bf16 sV[BLK * LD];
+    __shared__ __attribute__((aligned(16))) bf16 sP[4][16 * LDP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BLK;
+    const int Tq = a.Tq, Tk = a.Tk;
+    const int klen = a.klens ? a.klens[b] : Tk;
+    const float scale = rsqrtf((float)HD);
+    const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+
+    const bf16* qb = a.q + (long)b * Tq * a.ldq + h * HD;
+    const bf16* kb_ = a.k + (long)b * Tk * a.ldk + h * HD;
+    const bf16* vb = a.v + (long)b * Tk * a.ldv + h * HD;
+
+    zero_tile<HD>(sK, tid);
+    zero_tile<HD>(sV, tid);
+
+    const int qrow0 = q0 + wave * 16;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_global<HD>(qb, a.ldq, qrow0, Tq, ks, lane);
+
+    float m[4], l[4];
+    f32x4 o[DT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m[r] = NEG; l[r] = 0.f; }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int nkb = (Tk + BLK - 1) / BLK;
+    if (a.causal) { const int lim = (q0 + BLK - 1) / BLK + 1; if (lim < nkb) nkb = lim; }
+
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();
+        load_tile<HD>(sK, kb_, a.ldk, kb * BLK, Tk, tid);
+        load_tile<HD>(sV, vb, a.ldv, kb * BLK, Tk, tid);
+        __syncthreads();
+
+        f32x4 s[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            s[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) s[jt] = mma16(qf[ks], frag_row<LD>(sK, jt * 16, ks, lane), s[jt]);
+        }
+        float mx[4] = {NEG, NEG, NEG, NEG};
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            const int kj = kb * BLK + jt * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qi = qrow0 + (lane >> 4) * 4 + r;
+                float v = s[jt][r] * scale;
+                if (kj >= klen || (a.causal && kj > qi)) v = NEG;
+                s[jt][r] = v;
+                mx[r] = fmaxf(mx[r], v);
+            }
+        }
+        float alpha[4], rs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = mx[r];
+            v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64));
+            v = fmaxf(v, __shfl_xor(v, 4, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
+            const float mn = fmaxf(m[r], v);
+            alpha[r] = __expf(m[r] - mn);
+            m[r] = mn;
+            rs[r] = 0.f;
+        }
+        bf16* sp = sP[wave];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            const int kj = kb * BLK + jt * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = (lane >> 4) * 4 + r;
+                float p = __expf(s[jt][r] - m[r]);
+                if (s[jt][r] <= NEG) p = 0.f;
+                rs[r] += p;
+                if (a.drop_p > 0.f) {
+                    const uint32_t idx = (uint32_t)((((long)b * a.H + h) * Tq + (qrow0 + row)) * Tk + kj);
+                    p *= dropout_scale(a.seed, a.site, idx, a.drop_p, inv_keep);
+                }
+                sp[row * LDP + jt * 16 + (lane & 15)] = (bf16)p;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = rs[r];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            l[r] = l[r] * alpha[r] + v;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[dt][r] *= alpha[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+            const bf16x8 pf = frag_a_perm(sp, ks2 * 32, lane);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[dt] = mma16(pf, frag_tr<LD>(sV, ks2 * 32, dt * 16, lane), o[dt]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qi = qrow0 + (lane >> 4) * 4 + r;
+        if (qi >= Tq) continue;
+        const float inv = 1.f / l[r];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+            a.o[((long)b * Tq + qi) * a.ldo + h * HD + dt * 16 + (lane & 15)] = (bf16)(o[dt][r] * inv);
+        if ((lane & 15) == 0) a.lse[((long)b * a.H + h) * Tq + qi] = m[r] + __logf(l[r]);
+    }
+}
+
+// ---------------------------------------------------------------------------- backward
+template <int HD>
+__global__ void attn_delta_kernel(AttnArgs a) {
+    const long n = (long)a.B * a.H * a.Tq;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int qi = (int)(i % a.Tq);
+    const int h = (int)((i / a.Tq) % a.H);
+    const int b = (int)(i / ((long)a.Tq * a.H));
+    const bf16* o = a.o + ((long)b * a.Tq + qi) * a.ldo + h * HD;
+    const bf16* d = a.dout + ((long)b * a.Tq + qi) * a.lddo + h * HD;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; c += 8) {
+        const bf16x8 x = ld8(o + c), y = ld8(d + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (float)x[j] * (float)y[j];
+    }
+    a.delta[i] = s;
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+    using C = Cfg<HD>;
+    constexpr int LD = C::LD, KS = C::KS, DT = C::DT;
+    __shared__ __attribute__((aligned(16))) bf16 sK[BLK * LD];
+    __shared__ __attribute__((aligned(16))) bf16 sV[BLK * LD];
+    __shared__ __attribute__((aligned(16))) bf16 sP[4][16 * LDP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BLK;
+    const int Tq = a.Tq, Tk = a.Tk;
+    const int klen = a.klens ? a.klens[b] : Tk;
+    const float scale = rsqrtf((float)HD);
+    const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const bf16* qb = a.q + (long)b * Tq * a.ldq + h * HD;
+    const bf16* kb_ = a.k + (long)b * Tk * a.ldk + h * HD;
+    const bf16* vb = a.v + (long)b * Tk * a.ldv + h * HD;
+    const bf16* dob = a.dout + (long)b * Tq * a.lddo + h * HD;
+
+    zero_tile<HD>(sK, tid);
+    zero_tile<HD>(sV, tid);
+    const int qrow0 = q0 + wave * 16;
+    bf16x8 qf[KS], dof[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        qf[ks] = frag_global<HD>(qb, a.ldq, qrow0, Tq, ks, lane);
+        dof[ks] = frag_global<HD>(dob, a.lddo, qrow0, Tq, ks, lane);
+    }
+    float lse[4], dl[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qi = qrow0 + (lane >> 4) * 4 + r;
+        const long idx = ((long)b * a.H + h) * Tq + qi;
+        lse[r] = qi < Tq ? a.lse[idx] : 0.f;
+        dl[r] = qi < Tq ? a.delta[idx] : 0.f;
+    }
+    f32x4 dq[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int nkb = (Tk + BLK - 1) / BLK;
+    if (a.causal) { const int lim = (q0 + BLK - 1) / BLK + 1; if (lim < nkb) nkb = lim; }
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();
+        load_tile<HD>(sK, kb_, a.ldk, kb * BLK, Tk, tid);
+        load_tile<HD>(sV, vb, a.ldv, kb * BLK, Tk, tid);
+        __syncthreads();
+        bf16* sp = sP[wave];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s = mma16(qf[ks], frag_row<LD>(sK, jt * 16, ks, lane), s);
+                dp = mma16(dof[ks], frag_row<LD>(sV, jt * 16, ks, lane), dp);
+            }
+            const int kj = kb * BLK + jt * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = (lane >> 4) * 4 + r, qi = qrow0 + row;
+                float p = __expf(s[r] * scale - lse[r]);
+                if (kj >= klen || (a.causal && kj > qi) || qi >= Tq) p = 0.f;
+                float dpv = dp[r];
+                if (a.drop_p > 0.f) {
+                    const uint32_t idx = (uint32_t)((((long)b * a.H + h) * Tq + qi) * Tk + kj);
+                    dpv *= dropout_scale(a.seed, a.site, idx, a.drop_p, inv_keep);
+                }
+                sp[row * LDP + jt * 16 + (lane & 15)] = (bf16)(p * (dpv - dl[r]) * scale);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+            const bf16x8 df = frag_a_perm(sp, ks2 * 32, lane);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) dq[dt] = mma16(df, frag_tr<LD>(sK, ks2 * 32, dt * 16, lane), dq[dt]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qi = qrow0 + (lane >> 4) * 4 + r;
+        if (qi >= Tq) continue;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+            a.dq[((long)b * Tq + qi) * a.lddq + h * HD + dt * 16 + (lane & 15)] = (bf16)dq[dt][r];
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+    using C = Cfg<HD>;
+    constexpr int LD = C::LD, KS = C::KS, DT = C::DT;
+    __shared__ __attribute__((aligned(16))) bf16 sQ[BLK * LD];
+    __shared__ __attribute__((aligned(16))) bf16 sDO[BLK * LD];
+    __shared__ __attribute__((aligned(16))) bf16 sP[4][16 * LDP];
+    __shared__ __attribute__((aligned(16))) bf16 sDS[4][16 * LDP];
+    __shared__ float sLse[BLK], sDl[BLK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * BLK;
+    const int Tq = a.Tq, Tk = a.Tk;
+    const int klen = a.klens ? a.klens[b] : Tk;
+    const float scale = rsqrtf((float)HD);
+    const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const bf16* qb = a.q + (long)b * Tq * a.ldq + h * HD;
+    const bf16* kb_ = a.k + (long)b * Tk * a.ldk + h * HD;
+    const bf16* vb = a.v + (long)b * Tk * a.ldv + h * HD;
+    const bf16* dob = a.dout + (long)b * Tq * a.lddo + h * HD;
+
+    zero_tile<HD>(sQ, tid);
+    zero_tile<HD>(sDO, tid);
+    const int krow0 = k0 + wave * 16;
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = frag_global<HD>(kb_, a.ldk, krow0, Tk, ks, lane);
+        vf[ks] = frag_global<HD>(vb, a.ldv, krow0, Tk, ks, lane);
+    }
+    f32x4 dk[DT], dv[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int nqb = (Tq + BLK - 1) / BLK;
+    const int qb0 = a.causal ? k0 / BLK : 0;
+    for (int qbi = qb0; qbi < nqb; ++qbi) {
+        __syncthreads();
+        load_tile<HD>(sQ, qb, a.ldq, qbi * BLK, Tq, tid);
+        load_tile<HD>(sDO, dob, a.lddo, qbi * BLK, Tq, tid);
+        if (tid < BLK) {
+            const int qi = qbi * BLK + tid;
+            const long idx = ((long)b * a.H + h) * Tq + qi;
+            sLse[tid] = qi < Tq ? a.lse[idx] : 0.f;
+            sDl[tid] = qi < Tq ? a.delta[idx] : 0.f;
+        }
+        __syncthreads();
+        bf16* sp = sP[wave];
+        bf16* sd = sDS[wave];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dpt = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                st = mma16(kf[ks], frag_row<LD>(sQ, jt * 16, ks, lane), st);
+                dpt = mma16(vf[ks], frag_row<LD>(sDO, jt * 16, ks, lane), dpt);
+            }
+            const int ql = jt * 16 + (lane & 15), qi = qbi * BLK + ql;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = (lane >> 4) * 4 + r, kj = krow0 + row;
+                float p = __expf(st[r] * scale - sLse[ql]);
+                if (kj >= klen || (a.causal && kj > qi) || qi >= Tq) p = 0.f;
+                float ms = 1.f;
+                if (a.drop_p > 0.f) {
+                    const uint32_t idx = (uint32_t)((((long)b * a.H + h) * Tq + qi) * Tk + kj);
+                    ms = dropout_scale(a.seed, a.site, idx, a.drop_p, inv_keep);
+                }
+                sp[row * LDP + ql] = (bf16)(p * ms);
+                sd[row * LDP + ql] = (bf16)(p * (dpt[r] * ms - sDl[ql]) * scale);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+            const bf16x8 pf = frag_a_perm(sp, ks2 * 32, lane);
+            const bf16x8 df = frag_a_perm(sd, ks2 * 32, lane);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                dv[dt] = mma16(pf, frag_tr<LD>(sDO, ks2 * 32, dt * 16, lane), dv[dt]);
+                dk[dt] = mma16(df, frag_tr<LD>(sQ, ks2 * 32, dt * 16, lane), dk[dt]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int kj = krow0 + (lane >> 4) * 4 + r;
+        if (kj >= Tk) continue;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const long off = ((long)b * Tk + kj);
+            a.dk[off * a.lddk + h * HD + dt * 16 + (lane & 15)] = (bf16)dk[dt][r];
+            a.dv[off * a.lddv + h * HD + dt * 16 + (lane & 15)] = (bf16)dv[dt][r];
+        }
+    }
+}
+
+template <int HD>
+int launch_fwd(const AttnArgs& a, hipStream_t s) {
+    dim3 grid((a.Tq + BLK - 1) / BLK, a.H, a.B);
+    hipLaunchKernelGGL(attn_fwd_kernel<HD>, grid, dim3(256), 0, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+template <int HD>
+int launch_bwd(const AttnArgs& a, hipStream_t s) {
+    const long n = (long)a.B * a.H * a.Tq;
+    hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, dim3((a.Tq + BLK - 1) / BLK, a.H, a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<HD>, dim3((a.Tk + BLK - 1) / BLK, a.H, a.B), dim3(256), 0, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+bool check(const AttnArgs& a) {
+    if ((a.ldq & 7) || (a.ldk & 7) || (a.ldv & 7)) { mk_set_error("mk_attn", "row strides must be multiples of 8"); return false; }
+    if (a.hd != 16 && a.hd != 32 && a.hd != 64) { mk_set_error("mk_attn", "head dim must be 16, 32 or 64"); return false; }
+    return true;
+}
+
+}  // namespace
+
+int mk_attn_fwd(const AttnArgs& a, hipStream_t s) {
+    if (!check(a)) return -1;
+    if (a.hd == 64) return launch_fwd<64>(a, s);
+    if (a.hd == 32) return launch_fwd<32>(a, s);
+    return launch_fwd<16>(a, s);
+}
+int mk_attn_bwd(const AttnArgs& a, hipStream_t s) {
+    if (!check(a)) return -1;
+    if ((a.lddo & 7)) { mk_set_error("mk_attn_bwd", "lddo must be a multiple of 8"); return -1; }
+    if (a.hd == 64) return launch_bwd<64>(a, s);
+    if (a.hd == 32) return launch_bwd<32>(a, s);
+    return launch_bwd<16>(a, s);
+}

@@ -1,0 +1,68 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of libmasr.
+// Wave = 64 lanes.  One MFMA primitive is used everywhere:
+//   v_mfma_f32_16x16x32_bf16   D[16x16] += A[16x32] * B[32x16]
+//   A fragment: lane l holds A[row = l&15][k = 8*(l>>4) + j], j = 0..7
+//   B fragment: lane l holds B[k = 8*(l>>4) + j][col = l&15]
+//   C/D       : lane l, reg r  ->  row = 4*(l>>4) + r, col = l&15
+// so every operand is staged in LDS as [row-or-col][k contiguous] and read
+// with one 16-byte ds_read per fragment.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define MASR_WAVE 64
+
+__device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (bf16)0.0f;
+    return z;
+}
+
+__device__ __forceinline__ bf16x8 ld8(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void st8(bf16* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Stateless counter-based RNG for dropout: the same (seed, site, index) gives the same
+// bit in forward and backward, so no mask is ever stored.
+__device__ __forceinline__ uint32_t hash_u32(uint32_t seed, uint32_t site, uint32_t idx) {
+    uint32_t x = idx * 0x9E3779B1u ^ (seed + site * 0x85EBCA77u);
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+// keep-scale: 0 (dropped) or 1/(1-p)
+__device__ __forceinline__ float dropout_scale(uint32_t seed, uint32_t site, uint32_t idx, float p, float inv_keep) {
+    // 24-bit uniform in [0,1)
+    float u = (float)(hash_u32(seed, site, idx) >> 8) * (1.0f / 16777216.0f);
+    return u < p ? 0.0f : inv_keep;
+}
+
+#define HIP_CHECK_RET(expr)                                                        \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) { mk_set_error(#expr, hipGetErrorString(_e)); return -1; } \
+    } while (0)
+
+void mk_set_error(const char* what, const char* detail);

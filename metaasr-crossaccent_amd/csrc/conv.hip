@@ -1,0 +1,455 @@
+// VGG front-end of MyTransformer.extract_feat
+// (reference: src/model/transformer_pytorch/mono_transformer_torch.py:49-60,113-116 --
+//  Conv2d(1,64,3,p1)+ReLU, Conv2d(64,64)+ReLU, MaxPool2d(2,2), Conv2d(64,128)+ReLU,
+//  Conv2d(128,128)+ReLU, MaxPool2d(2,2); ~71 % of the path's FLOPs).
+//
+// MI355X layout: activations are NHWC bf16 ([B][T][D][C], channels innermost) so that the
+// 3x3 convolutions become implicit GEMMs whose K index (tap, ci) is contiguous in memory:
+//   out[p][co] = sum_{tap,ci} in[p + off(tap)][ci] * wk[co][tap*CIN + ci]
+// with M = B*T*D pixels, N = COUT, K = 9*CIN on v_mfma_f32_16x16x32_bf16.
+// The same kernel computes dgrad (input = dY, weights = 180-degree-rotated/transposed shadow).
+// wgrad is the reduction-major product dW[co][tap,ci] = sum_p dY[p][co] * in[p+off][ci]
+// (transposing LDS reads), split over pixel ranges with a deterministic slab reduce.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = 40;
+
+// ------------------------------------------------------------------ conv1 (CIN = 1), direct fp32
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, bf16* __restrict__ out,
+                                                        int B, int H, int W) {
+    __shared__ float sw[64 * 9 + 64];
+    for (int i = threadIdx.x; i < 64 * 9 + 64; i += 256) sw[i] = i < 576 ? w[i] : bias[i - 576];
+    __syncthreads();
+    const long P = (long)B * H * W;
+    const long p = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int cg = threadIdx.x & 7;
+    if (p >= P) return;
+    const int d = (int)(p % W);
+    const int t = (int)((p / W) % H);
+    float xv[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int tt = t + tap / 3 - 1, dd = d + tap % 3 - 1;
+        xv[tap] = (tt >= 0 && tt < H && dd >= 0 && dd < W) ? x[p + (long)(tap / 3 - 1) * W + (tap % 3 - 1)] : 0.f;
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int co = cg * 8 + j;
+        float a = sw[576 + co];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) a = fmaf(sw[co * 9 + tap], xv[tap], a);
+        o[j] = (bf16)fmaxf(a, 0.f);
+    }
+    st8(out + p * 64 + cg * 8, o);
+}
+
+constexpr int C1_PIX = 2048;   // pixels per block in conv1 wgrad
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const bf16* __restrict__ dy,
+                                                          float* __restrict__ slab, int B, int H, int W) {
+    const long P = (long)B * H * W;
+    const long p0 = (long)blockIdx.x * C1_PIX;
+    const int pl = threadIdx.x >> 3, cg = threadIdx.x & 7;
+    float acc[8][10];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc[j][k] = 0.f;
+    for (int it = 0; it < C1_PIX / 32; ++it) {
+        const long p = p0 + it * 32 + pl;
+        if (p >= P) break;
+        const int d = (int)(p % W);
+        const int t = (int)((p / W) % H);
+        float xv[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int tt = t + tap / 3 - 1, dd = d + tap % 3 - 1;
+            xv[tap] = (tt >= 0 && tt < H && dd >= 0 && dd < W) ? x[p + (long)(tap / 3 - 1) * W + (tap % 3 - 1)] : 0.f;
+        }
+        const bf16x8 g = ld8(dy + p * 64 + cg * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gj = (float)g[j];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) acc[j][tap] = fmaf(gj, xv[tap], acc[j][tap]);
+            acc[j][9] += gj;
+        }
+    }
+    // reduce over the 8 pixel-lanes of a wave that share cg (lane bits 3..5), then over the 4 waves
+    __shared__ float red[4][8][80];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            float v = acc[j][k];
+            v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 8) red[wave][lane][j * 10 + k] = v;
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 640; i += 256) {
+        const int c = i / 80, e = i % 80;
+        const float v = red[0][c][e] + red[1][c][e] + red[2][c][e] + red[3][c][e];
+        // slab[block][co = c*8 + e/10][k = e%10]
+        slab[(long)blockIdx.x * 640 + (c * 8 + e / 10) * 10 + e % 10] = v;
+    }
+}
+__global__ void conv1_wgrad_reduce(const float* __restrict__ slab, int nblocks, float* __restrict__ dw, float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 640) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += slab[(long)b * 640 + i];
+    const int co = i / 10, k = i % 10;
+    if (k < 9) dw[co * 9 + k] = s; else db[co] = s;
+}
+
+// ------------------------------------------------------------------ implicit GEMM 3x3 (fwd and dgrad)
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
+    constexpr int BM = 128;
+    constexpr int WGN = COUT / 64, WGM = 4 / WGN;        // wave grid
+    constexpr int WM = BM / WGM, WN = 64;
+    constexpr int FM = WM / 16, FN = 4;
+    constexpr int KTOT = 9 * CIN, NK = KTOT / BK;
+    constexpr int BCH = COUT * BK / 8 / 256;              // B chunks per thread (1 or 2)
+    __shared__ __attribute__((aligned(16))) bf16 sA[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) bf16 sB[2][COUT * LDK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const long P = (long)a.B * a.H * a.W;
+    const long m0 = (long)blockIdx.x * BM;
+    const int H = a.H, W = a.W;
+
+    // the two A rows (pixels) this thread stages are fixed over the K loop
+    long pix[2]; int pt[2], pd[2]; bool pv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (tid + i * 256) >> 2;
+        pix[i] = m0 + r;
+        pv[i] = pix[i] < P;
+        pd[i] = (int)(pix[i] % W);
+        pt[i] = (int)((pix[i] / W) % H);
+    }
+    const int kc = (tid & 3) * 8;
+
+    bf16x8 ra[2], rb[BCH];
+    auto load = [&](int kt) {
+        const int tap = (kt * BK) / CIN, ci0 = (kt * BK) % CIN;
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int tt = pt[i] + dy, dd = pd[i] + dx;
+            bf16x8 v = zero8();
+            if (pv[i] && tt >= 0 && tt < H && dd >= 0 && dd < W)
+                v = ld8(a.in + (pix[i] + (long)dy * W + dx) * CIN + ci0 + kc);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            const int c = tid + i * 256;
+            rb[i] = ld8(a.wk + (long)(c >> 2) * KTOT + kt * BK + (c & 3) * 8);
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) st8(&sA[buf][((tid + i * 256) >> 2) * LDK + kc], ra[i]);
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            const int c = tid + i * 256;
+            st8(&sB[buf][(c >> 2) * LDK + (c & 3) * 8], rb[i]);
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int kt = 0; kt < NK; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < NK) load(kt + 1);
+        bf16x8 af[FM], bfr[FN];
+        const int kq = (lane >> 4) * 8, rr = lane & 15;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = ld8(&sA[cur][(wm * WM + i * 16 + rr) * LDK + kq]);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bfr[j] = ld8(&sB[cur][(wn * WN + j * 16 + rr) * LDK + kq]);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
+        if (kt + 1 < NK) store(cur ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long p = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
+            if (p >= P) continue;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int co = wn * WN + j * 16 + (lane & 15);
+                float v = acc[i][j][r];
+                if (a.bias) v += a.bias[co];
+                if (a.relu) v = fmaxf(v, 0.f);
+                if (a.mask) v = ((float)a.mask[p * COUT + co] > 0.f) ? v : 0.f;
+                a.out[p * COUT + co] = (bf16)v;
+            }
+        }
+}
+
+// ------------------------------------------------------------------ wgrad (reduction over pixels)
+template <int LDT>
+__device__ __forceinline__ bf16x8 frag_rm(const bf16* tile, int r0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+    const bf16* a0 = tile + (4 * g + q) * LDT + r0 + 4 * p;
+    const bf16* a1 = a0 + 16 * LDT;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)a0);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)a1);
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(ConvWgradArgs a, long pix_per_split) {
+    constexpr int BM = COUT, BN = 64;
+    constexpr int LDA = BM + 16, LDB = BN + 16;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int ACH = BK * (BM / 8) / 256;              // A chunks per thread (1 or 2)
+    constexpr int KTOT = 9 * CIN;
+    __shared__ __attribute__((aligned(16))) bf16 sA[2][BK * LDA];
+    __shared__ __attribute__((aligned(16))) bf16 sB[2][BK * LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tap = blockIdx.x / (CIN / 64), ci0 = (blockIdx.x % (CIN / 64)) * 64;
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    const long P = (long)a.B * a.H * a.W;
+    const long ps = (long)blockIdx.y * pix_per_split;
+    const long pe = ps + pix_per_split < P ? ps + pix_per_split : P;
+    const int H = a.H, W = a.W;
+
+    bf16x8 ra[ACH], rb;
+    auto load = [&](long p0) {
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const int c = tid + i * 256;
+            const int k = c / (BM / 8), rc = (c % (BM / 8)) * 8;
+            bf16x8 v = zero8();
+            if (p0 + k < pe) v = ld8(a.dy + (p0 + k) * COUT + rc);
+            ra[i] = v;
+        }
+        {
+            const int k = tid >> 3, rc = (tid & 7) * 8;
+            const long p = p0 + k;
+            bf16x8 v = zero8();
+            if (p < pe) {
+                const int d = (int)(p % W), t = (int)((p / W) % H);
+                const int tt = t + dy, dd = d + dx;
+                if (tt >= 0 && tt < H && dd >= 0 && dd < W) v = ld8(a.in + (p + (long)dy * W + dx) * CIN + ci0 + rc);
+            }
+            rb = v;
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const int c = tid + i * 256;
+            st8(&sA[buf][(c / (BM / 8)) * LDA + (c % (BM / 8)) * 8], ra[i]);
+        }
+        st8(&sB[buf][(tid >> 3) * LDB + (tid & 7) * 8], rb);
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (int)((pe - ps + BK - 1) / BK);
+    if (nk > 0) {
+        load(ps);
+        store(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load(ps + (long)(kt + 1) * BK);
+        bf16x8 af[FM], bfr[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = frag_rm<LDA>(sA[cur], wm * WM + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bfr[j] = frag_rm<LDB>(sB[cur], wn * WN + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
+        if (kt + 1 < nk) store(cur ^ 1);
+        __syncthreads();
+    }
+    float* out = a.slab + (long)blockIdx.y * COUT * KTOT;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = wm * WM + i * 16 + (lane >> 4) * 4 + r;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int ci = ci0 + wn * WN + j * 16 + (lane & 15);
+                out[(long)co * KTOT + tap * CIN + ci] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ void conv3x3_wgrad_reduce(const float* __restrict__ slab, int nsplit, float* __restrict__ dw, int CIN, int COUT) {
+    const int KTOT = 9 * CIN;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // co*KTOT + tap*CIN + ci
+    if (i >= COUT * KTOT) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slab[(long)k * COUT * KTOT + i];
+    const int co = i / KTOT, rem = i % KTOT, tap = rem / CIN, ci = rem % CIN;
+    dw[((long)co * CIN + ci) * 9 + tap] = s;
+}
+
+int wgrad_splits(long P, int CIN) {
+    const int col_tiles = 9 * (CIN / 64);
+    int splits = (1536 + col_tiles - 1) / col_tiles;                 // ~1.5k workgroups
+    const long max_splits = (P + 255) / 256;                         // at least 256 pixels per split
+    if (splits > max_splits) splits = (int)max_splits;
+    if (splits < 1) splits = 1;
+    return splits;
+}
+
+// ------------------------------------------------------------------ max-pool 2x2 (floor) NHWC
+__global__ void maxpool_fwd_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int B, int H, int W, int C) {
+    const int H2 = H / 2, W2 = W / 2, C8 = C / 8;
+    const long n = (long)B * H2 * W2 * C8;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c8 = (int)(i % C8);
+    const int d2 = (int)((i / C8) % W2);
+    const int t2 = (int)((i / ((long)C8 * W2)) % H2);
+    const int b = (int)(i / ((long)C8 * W2 * H2));
+    const bf16* base = in + (((long)b * H + 2 * t2) * W + 2 * d2) * C + c8 * 8;
+    const bf16x8 v00 = ld8(base), v01 = ld8(base + C), v10 = ld8(base + (long)W * C), v11 = ld8(base + (long)W * C + C);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        o[j] = (bf16)fmaxf(fmaxf((float)v00[j], (float)v01[j]), fmaxf((float)v10[j], (float)v11[j]));
+    st8(out + i * 8, o);
+}
+
+__global__ void maxpool_relu_bwd_kernel(const bf16* __restrict__ in, const bf16* __restrict__ dout, bf16* __restrict__ din,
+                                        int B, int H, int W, int C) {
+    const int H2 = H / 2, W2 = W / 2, C8 = C / 8;
+    const int H2c = (H + 1) / 2, W2c = (W + 1) / 2;           // cells incl. the cropped edge
+    const long n = (long)B * H2c * W2c * C8;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c8 = (int)(i % C8);
+    const int d2 = (int)((i / C8) % W2c);
+    const int t2 = (int)((i / ((long)C8 * W2c)) % H2c);
+    const int b = (int)(i / ((long)C8 * W2c * H2c));
+    const long base = (((long)b * H + 2 * t2) * W + 2 * d2) * C + c8 * 8;
+    if (t2 < H2 && d2 < W2) {
+        const long offs[4] = {0, (long)C, (long)W * C, (long)W * C + C};
+        bf16x8 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = ld8(in + base + offs[k]);
+        const bf16x8 g = ld8(dout + ((((long)b * H2 + t2) * W2 + d2) * C + c8 * 8));
+        bf16x8 o[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int arg = 0; float mx = (float)v[0][j];            // first max in scan order (strict >), as torch
+#pragma unroll
+            for (int k = 1; k < 4; ++k) if ((float)v[k][j] > mx) { mx = (float)v[k][j]; arg = k; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k][j] = (k == arg && mx > 0.f) ? g[j] : (bf16)0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st8(din + base + offs[k], o[k]);
+    } else {
+        // cells outside every pooling window (odd H or W): gradient is zero
+        for (int dt = 0; dt < 2; ++dt)
+            for (int dd = 0; dd < 2; ++dd)
+                if (2 * t2 + dt < H && 2 * d2 + dd < W) st8(din + base + ((long)dt * W + dd) * C, zero8());
+    }
+}
+
+}  // namespace
+
+int mk_conv1_fwd(const float* x, const float* w, const float* bias, bf16* out, int B, int H, int W, hipStream_t s) {
+    const long P = (long)B * H * W;
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, s, x, w, bias, out, B, H, W);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+long mk_conv1_wgrad_slab_floats(int B, int H, int W) { return (((long)B * H * W + C1_PIX - 1) / C1_PIX) * 640; }
+int mk_conv1_wgrad(const float* x, const bf16* dy, float* dw, float* db, float* slab, int B, int H, int W, hipStream_t s) {
+    const long P = (long)B * H * W;
+    const int nb = (int)((P + C1_PIX - 1) / C1_PIX);
+    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(nb), dim3(256), 0, s, x, dy, slab, B, H, W);
+    hipLaunchKernelGGL(conv1_wgrad_reduce, dim3(3), dim3(256), 0, s, slab, nb, dw, db);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int mk_conv3x3(const ConvArgs& a, hipStream_t s) {
+    const long P = (long)a.B * a.H * a.W;
+    dim3 grid((unsigned)((P + 127) / 128));
+    if (a.CIN == 64 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_kernel<64, 64>), grid, dim3(256), 0, s, a);
+    else if (a.CIN == 64 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_kernel<64, 128>), grid, dim3(256), 0, s, a);
+    else if (a.CIN == 128 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_kernel<128, 128>), grid, dim3(256), 0, s, a);
+    else if (a.CIN == 128 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_kernel<128, 64>), grid, dim3(256), 0, s, a);
+    else { mk_set_error("mk_conv3x3", "unsupported channel counts"); return -1; }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+long mk_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT) {
+    return (long)wgrad_splits((long)B * H * W, CIN) * COUT * 9 * CIN;
+}
+int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s) {
+    const long P = (long)a.B * a.H * a.W;
+    const int splits = wgrad_splits(P, a.CIN);
+    long pps = (P + splits - 1) / splits;
+    pps = (pps + 31) / 32 * 32;
+    dim3 grid(9 * (a.CIN / 64), splits);
+    if (a.CIN == 64 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_wgrad_kernel<64, 64>), grid, dim3(256), 0, s, a, pps);
+    else if (a.CIN == 64 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_wgrad_kernel<64, 128>), grid, dim3(256), 0, s, a, pps);
+    else if (a.CIN == 128 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_wgrad_kernel<128, 128>), grid, dim3(256), 0, s, a, pps);
+    else { mk_set_error("mk_conv3x3_wgrad", "unsupported channel counts"); return -1; }
+    const int n = a.COUT * 9 * a.CIN;
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((n + 255) / 256), dim3(256), 0, s, a.slab, splits, a.dw, a.CIN, a.COUT);
+    if (a.db) {
+        // bias gradient = column sums of dy [P][COUT]; reuse the slab tail is not safe -> caller passes db separately via mk_colsum
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int mk_maxpool_fwd(const bf16* in, bf16* out, int B, int H, int W, int C, hipStream_t s) {
+    const long n = (long)B * (H / 2) * (W / 2) * (C / 8);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, B, H, W, C);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int mk_maxpool_relu_bwd(const bf16* in, const bf16* dout, bf16* din, int B, int H, int W, int C, hipStream_t s) {
+    const long n = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+    hipLaunchKernelGGL(maxpool_relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, dout, din, B, H, W, C);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -1,0 +1,130 @@
+// CTC forward-backward lattice (config 1 / BLSTM path only; reference call site src/blstm_trainer.py:22,62-70:
+// nn.CTCLoss(blank=0, reduction='mean', zero_infinity=True) on log_softmax(pred)).
+// One workgroup per utterance; the alpha/beta rows of the S = 2L+1 lattice live in LDS (double buffered)
+// and are advanced one frame per barrier ("wavefront scan"); alpha is parked in HBM scratch so the beta sweep can
+// form the posteriors and write d loss / d logits = (softmax - posterior) / (L * B) in the same pass.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+constexpr int MAXS = 2048;
+constexpr float NINF = -INFINITY;
+
+__device__ __forceinline__ float lae(float a, float b) {          // log(exp a + exp b)
+    if (a == NINF) return b;
+    if (b == NINF) return a;
+    const float m = fmaxf(a, b);
+    return m + log1pf(__expf(fminf(a, b) - m));
+}
+
+__global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logits, const int* __restrict__ targets,
+                                                  const int* __restrict__ tgt_off, const int* __restrict__ in_len,
+                                                  const int* __restrict__ tgt_len, int T, int B, int C, int blank,
+                                                  float* __restrict__ nll, float* __restrict__ grad,
+                                                  float* __restrict__ work, int Spad) {
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Tb = in_len[b], Lb = tgt_len[b], S = 2 * Lb + 1;
+    const int* tg = targets + tgt_off[b];
+    float* walpha = work + (long)b * T * Spad;                    // [T][Spad]
+    float* wlse = work + (long)B * T * Spad + (long)b * T;        // [T]
+    __shared__ float row[2][MAXS];
+    __shared__ float acc[4096];
+    __shared__ float s_ll;
+
+    // zero the gradient of this utterance (frames >= Tb stay zero)
+    for (long i = tid; i < (long)T * C; i += 256) grad[((i / C) * B + b) * C + (i % C)] = 0.f;
+    // log-softmax normalisers
+    for (int t = wave; t < Tb; t += 4) {
+        const float* z = logits + ((long)t * B + b) * C;
+        float mx = -3.4e38f;
+        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, z[c]);
+        mx = wave_max(mx);
+        float se = 0.f;
+        for (int c = lane; c < C; c += 64) se += __expf(z[c] - mx);
+        se = wave_sum(se);
+        if (lane == 0) wlse[t] = mx + __logf(se);
+    }
+    __syncthreads();
+    auto ext = [&](int s) { return (s & 1) ? tg[s >> 1] : blank; };
+    auto lp = [&](int t, int s) { return logits[((long)t * B + b) * C + ext(s)] - wlse[t]; };
+
+    // alpha sweep
+    for (int s = tid; s < S; s += 256) {
+        const float a = (s < 2) ? lp(0, s) : NINF;
+        row[0][s] = a;
+        walpha[s] = a;
+    }
+    __syncthreads();
+    for (int t = 1; t < Tb; ++t) {
+        const float* prev = row[(t - 1) & 1];
+        float* cur = row[t & 1];
+        for (int s = tid; s < S; s += 256) {
+            float a = prev[s];
+            if (s > 0) a = lae(a, prev[s - 1]);
+            if (s > 1 && (s & 1) && ext(s) != ext(s - 2)) a = lae(a, prev[s - 2]);
+            a = (a == NINF) ? NINF : a + lp(t, s);
+            cur[s] = a;
+            walpha[(long)t * Spad + s] = a;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float* last = row[(Tb - 1) & 1];
+        float ll = last[S - 1];
+        if (S > 1) ll = lae(ll, last[S - 2]);
+        s_ll = ll;
+    }
+    __syncthreads();
+    const float ll = s_ll;
+    if (ll == NINF || ll != ll) {                                   // zero_infinity
+        if (tid == 0) nll[b] = 0.f;
+        return;
+    }
+    if (tid == 0) nll[b] = -ll;
+    const float gscale = 1.f / ((float)(Lb > 0 ? Lb : 1) * (float)B);
+
+    // beta sweep + gradient
+    for (int t = Tb - 1; t >= 0; --t) {
+        float* cur = row[t & 1];
+        const float* nxt = row[(t + 1) & 1];
+        for (int c = tid; c < C; c += 256) acc[c] = 0.f;
+        __syncthreads();
+        for (int s = tid; s < S; s += 256) {
+            float bta;
+            if (t == Tb - 1) bta = (s >= S - 2) ? lp(t, s) : NINF;
+            else {
+                bta = nxt[s];
+                if (s + 1 < S) bta = lae(bta, nxt[s + 1]);
+                if (s + 2 < S && (s & 1) && ext(s + 2) != ext(s)) bta = lae(bta, nxt[s + 2]);
+                bta = (bta == NINF) ? NINF : bta + lp(t, s);
+            }
+            cur[s] = bta;
+            const float al = walpha[(long)t * Spad + s];
+            if (al != NINF && bta != NINF) atomicAdd(&acc[ext(s)], __expf(al + bta - lp(t, s) - ll));
+        }
+        __syncthreads();
+        const float* z = logits + ((long)t * B + b) * C;
+        float* g = grad + ((long)t * B + b) * C;
+        const float lse = wlse[t];
+        for (int c = tid; c < C; c += 256) g[c] = (__expf(z[c] - lse) - acc[c]) * gscale;
+        __syncthreads();
+    }
+}
+__global__ void ctc_mean_kernel(const float* __restrict__ nll, const int* __restrict__ tgt_len, int B, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += nll[b] / (float)(tgt_len[b] > 0 ? tgt_len[b] : 1);
+        out[0] = s / B;
+    }
+}
+}  // namespace
+
+long mk_ctc_work_floats(int T, int B, int maxS) { return (long)B * T * ((maxS + 3) / 4 * 4) + (long)B * T; }
+int mk_ctc_loss(const float* logits, const int* targets, const int* tgt_off, const int* in_len, const int* tgt_len, int T,
+                  int B, int C, int blank, float* nll, float* loss_out, float* grad, float* work, int maxS, hipStream_t s) {
+    if (maxS > MAXS || C > 4096) { mk_set_error("mk_ctc_loss", "lattice wider than 2048 states or > 4096 classes"); return -1; }
+    hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(256), 0, s, logits, targets, tgt_off, in_len, tgt_len, T, B, C, blank, nll, grad,
+                       work, (maxS + 3) / 4 * 4);
+    hipLaunchKernelGGL(ctc_mean_kernel, dim3(1), dim3(64), 0, s, nll, tgt_len, B, loss_out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -1,0 +1,768 @@
+// libmasr engine: the VGG-Transformer encoder-decoder training step of the reference
+// (MyTransformer.forward, src/model/transformer_pytorch/mono_transformer_torch.py:178-208, plus
+// run_batch's loss/backward, src/transformer_torch_trainer.py:59-99) orchestrated as a fixed
+// sequence of hand-written gfx950 kernels on one HIP stream, behind the C ABI of include/masr.h.
+//
+// Memory model (sized for 288 GB HBM3E): ONE flat fp32 parameter buffer and ONE flat gradient buffer
+// (caller-owned; every optimiser / clip / all-reduce is a single streaming pass), bf16 operand shadows
+// of the weights (refreshed after each parameter update), and a bump-allocated activation arena that
+// keeps every activation of the step resident (nothing is recomputed, nothing is re-read through host).
+// Activations are batch-first row matrices [B*T][E]; conv activations are NHWC bf16.
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/masr.h"
+#include "kernels.h"
+
+static thread_local std::string g_err;
+void mk_set_error(const char* what, const char* detail) { g_err = std::string(what) + ": " + detail; }
+
+namespace {
+
+struct PInfo { std::string name; int64_t shape[4]; int ndim; int64_t off; int64_t numel; };
+struct Lin { int64_t w, b; int N, K; bf16 *k16, *t16; };          // weight [N][K]; k16 = bf16 copy, t16 = bf16 [K][Npad]
+struct Norm { int64_t w, b; };
+struct Attn { Lin in, out; };
+struct EncL { Attn sa; Lin l1, l2; Norm n1, n2; };
+struct DecL { Attn sa, ca; Lin l1, l2; Norm n1, n2, n3; };
+struct Conv { int64_t w, b; int CO, CI; bf16 *k16, *d16; };
+
+struct Arena {
+    char* base; int64_t cap, off;
+    template <class T> T* get(int64_t n) {
+        const int64_t bytes = (n * (int64_t)sizeof(T) + 255) & ~(int64_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += bytes;
+        return p;
+    }
+};
+
+struct EncAct { float *s1, *x1_32, *s2, *m1, *r1, *m2, *r2, *lse; bf16 *qkv, *ao, *x1_16, *f; uint32_t site[4]; };
+struct DecAct {
+    float *s1, *y1_32, *s2, *y2_32, *s3, *m1, *r1, *m2, *r2, *m3, *r3, *lse_s, *lse_c;
+    bf16 *qkv, *ao, *y1_16, *q, *kv, *co, *y2_16, *f; uint32_t site[6];
+};
+struct Acts {
+    int B, T, D, H2, W2, Tp, Dp, L, rows_e, rows_d;
+    int *tok_in, *gold, *enc_lens;
+    bf16 *a1, *a2, *p1, *a3, *a4, *p2;
+    std::vector<float*> x32; std::vector<bf16*> x16;        // encoder layer inputs/outputs [NE+1]
+    std::vector<EncAct> enc;
+    float *mf, *rf; bf16* mem16;
+    std::vector<float*> y32; std::vector<bf16*> y16;        // decoder layer inputs/outputs [ND+1]
+    std::vector<DecAct> dec;
+    float *mdf, *rdf; bf16* yf16;
+    float* logits; bf16* dlogits; float* row_loss; int* row_correct;
+    uint32_t site_v2e, site_emb;
+    // backward scratch
+    float *ge_a, *ge_b, *gd_a, *gd_b, *dmem32, *v2e_g32;
+    bf16 *ge16, *gd16, *gqkv_e, *gqkv_d, *gf_e, *gf_d, *gao_e, *gao_d, *gq_d, *gkv_d, *dp2, *da4, *da3, *dp1, *da2, *da1;
+    float *delta_e, *delta_d;
+    float* slab; int64_t slab_floats;
+};
+
+}  // namespace
+
+struct masr_model {
+    masr_config cfg;
+    int E, H, hd, Fi, NE, ND, C, Cp, D, Dp, F;
+    std::vector<PInfo> params; int64_t nparams = 0;
+    Conv conv[4]; Lin v2e, ct; int64_t embed_w; std::vector<EncL> enc; Norm enc_norm; std::vector<DecL> dec; Norm dec_norm;
+    float *P = nullptr, *G = nullptr; const float* pe = nullptr;
+    char* ws = nullptr; int64_t ws_bytes = 0, persist_bytes = 0;
+    bf16 *v2e_k = nullptr;                    // permuted vgg2enc weight (NHWC feature order)
+    float* stats = nullptr;                   // device [8]: loss, n_correct, n_total, grad_norm
+    float* h_stats = nullptr;                 // pinned
+    int* h_stage = nullptr; int64_t stage_ints = 0; int stage_slot = 0; hipEvent_t stage_ev[4];
+    uint64_t seed = 0x1234; uint64_t step = 0;
+    Acts acts; bool have_acts = false;
+    // profiling
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[MASR_PROF_N]; int prof_used[MASR_PROF_N] = {0};
+};
+
+namespace {
+
+int64_t add_param(masr_model* m, const std::string& name, std::initializer_list<int64_t> shape) {
+    PInfo p; p.name = name; p.ndim = (int)shape.size(); p.numel = 1;
+    int i = 0; for (auto s : shape) { p.shape[i++] = s; p.numel *= s; }
+    for (; i < 4; ++i) p.shape[i] = 1;
+    p.off = m->nparams; m->nparams += p.numel;
+    m->params.push_back(p);
+    return p.off;
+}
+Lin add_linear(masr_model* m, const std::string& pre, int N, int K, const char* wname = ".weight", const char* bname = ".bias") {
+    Lin l{}; l.N = N; l.K = K;
+    l.w = add_param(m, pre + wname, {N, K});
+    l.b = add_param(m, pre + bname, {N});
+    return l;
+}
+Norm add_norm(masr_model* m, const std::string& pre) {
+    Norm n; n.w = add_param(m, pre + ".weight", {m->E}); n.b = add_param(m, pre + ".bias", {m->E}); return n;
+}
+Attn add_attn(masr_model* m, const std::string& pre) {
+    Attn a;
+    a.in = add_linear(m, pre, 3 * m->E, m->E, ".in_proj_weight", ".in_proj_bias");
+    a.out = add_linear(m, pre + ".out_proj", m->E, m->E);
+    return a;
+}
+
+// ------------------------------------------------------------------ persistent region (shadows, stats)
+void plan_persistent(masr_model* m, Arena& ar) {
+    for (int i = 1; i < 4; ++i) {
+        m->conv[i].k16 = ar.get<bf16>((int64_t)m->conv[i].CO * 9 * m->conv[i].CI);
+        m->conv[i].d16 = ar.get<bf16>((int64_t)m->conv[i].CO * 9 * m->conv[i].CI);
+    }
+    auto lin = [&](Lin& l) {
+        const int Np = (l.N + 7) / 8 * 8;
+        l.k16 = ar.get<bf16>((int64_t)Np * l.K);
+        l.t16 = ar.get<bf16>((int64_t)l.K * Np);
+    };
+    m->v2e_k = ar.get<bf16>((int64_t)m->E * m->F);
+    m->v2e.t16 = ar.get<bf16>((int64_t)m->F * m->E);
+    m->ct.k16 = ar.get<bf16>((int64_t)m->Cp * m->E);
+    m->ct.t16 = ar.get<bf16>((int64_t)m->E * m->Cp);
+    for (auto& e : m->enc) { lin(e.sa.in); lin(e.sa.out); lin(e.l1); lin(e.l2); }
+    for (auto& d : m->dec) { lin(d.sa.in); lin(d.sa.out); lin(d.ca.in); lin(d.ca.out); lin(d.l1); lin(d.l2); }
+    m->stats = ar.get<float>(64);
+}
+
+// ------------------------------------------------------------------ activation plan
+void plan_acts(const masr_model* m, Arena& ar, Acts& a, int B, int T, int L, bool train) {
+    const int E = m->E, Fi = m->Fi, H = m->H;
+    a.B = B; a.T = T; a.D = m->D; a.H2 = T / 2; a.W2 = m->D / 2; a.Tp = a.H2 / 2; a.Dp = a.W2 / 2; a.L = L;
+    a.rows_e = B * a.Tp; a.rows_d = B * L;
+    const int64_t re = a.rows_e, rd = a.rows_d;
+    a.tok_in = ar.get<int>(rd); a.gold = ar.get<int>(rd); a.enc_lens = ar.get<int>(B);
+    const int64_t P1 = (int64_t)B * T * m->D, P2 = (int64_t)B * a.H2 * a.W2;
+    a.a1 = ar.get<bf16>(P1 * 64); a.a2 = ar.get<bf16>(P1 * 64); a.p1 = ar.get<bf16>(P2 * 64);
+    a.a3 = ar.get<bf16>(P2 * 128); a.a4 = ar.get<bf16>(P2 * 128); a.p2 = ar.get<bf16>(re * m->F);
+    a.x32.resize(m->NE + 1); a.x16.resize(m->NE + 1); a.enc.resize(m->NE);
+    for (int l = 0; l <= m->NE; ++l) { a.x32[l] = ar.get<float>(re * E); a.x16[l] = ar.get<bf16>(re * E); }
+    for (auto& e : a.enc) {
+        e.qkv = ar.get<bf16>(re * 3 * E); e.ao = ar.get<bf16>(re * E); e.lse = ar.get<float>((int64_t)B * H * a.Tp);
+        e.s1 = ar.get<float>(re * E); e.x1_32 = ar.get<float>(re * E); e.x1_16 = ar.get<bf16>(re * E);
+        e.m1 = ar.get<float>(re); e.r1 = ar.get<float>(re); e.f = ar.get<bf16>(re * Fi);
+        e.s2 = ar.get<float>(re * E); e.m2 = ar.get<float>(re); e.r2 = ar.get<float>(re);
+    }
+    a.mf = ar.get<float>(re); a.rf = ar.get<float>(re); a.mem16 = ar.get<bf16>(re * E);
+    a.y32.resize(m->ND + 1); a.y16.resize(m->ND + 1); a.dec.resize(m->ND);
+    for (int l = 0; l <= m->ND; ++l) { a.y32[l] = ar.get<float>(rd * E); a.y16[l] = ar.get<bf16>(rd * E); }
+    for (auto& d : a.dec) {
+        d.qkv = ar.get<bf16>(rd * 3 * E); d.ao = ar.get<bf16>(rd * E); d.lse_s = ar.get<float>((int64_t)B * H * L);
+        d.s1 = ar.get<float>(rd * E); d.y1_32 = ar.get<float>(rd * E); d.y1_16 = ar.get<bf16>(rd * E);
+        d.m1 = ar.get<float>(rd); d.r1 = ar.get<float>(rd);
+        d.q = ar.get<bf16>(rd * E); d.kv = ar.get<bf16>(re * 2 * E); d.co = ar.get<bf16>(rd * E); d.lse_c = ar.get<float>((int64_t)B * H * L);
+        d.s2 = ar.get<float>(rd * E); d.y2_32 = ar.get<float>(rd * E); d.y2_16 = ar.get<bf16>(rd * E);
+        d.m2 = ar.get<float>(rd); d.r2 = ar.get<float>(rd);
+        d.f = ar.get<bf16>(rd * Fi); d.s3 = ar.get<float>(rd * E); d.m3 = ar.get<float>(rd); d.r3 = ar.get<float>(rd);
+    }
+    a.mdf = ar.get<float>(rd); a.rdf = ar.get<float>(rd); a.yf16 = ar.get<bf16>(rd * E);
+    a.logits = ar.get<float>(rd * m->Cp); a.dlogits = ar.get<bf16>(rd * m->Cp);
+    a.row_loss = ar.get<float>(rd); a.row_correct = ar.get<int>(rd);
+    // slab: max over all users
+    int64_t sl = mk_sumsq_slab_floats(m->nparams);
+    auto mx = [&](int64_t v) { if (v > sl) sl = v; };
+    mx(mk_layernorm_bwd_slab_floats((int)(re > rd ? re : rd), E));
+    mx(mk_colsum_slab_floats((int)P1, 64)); mx(mk_colsum_slab_floats((int)P2, 128));
+    mx(mk_colsum_slab_floats((int)(re > rd ? re : rd), 3 * E > Fi ? 3 * E : Fi));
+    mx(mk_conv1_wgrad_slab_floats(B, T, m->D));
+    mx(mk_conv3x3_wgrad_slab_floats(B, T, m->D, 64, 64));
+    mx(mk_conv3x3_wgrad_slab_floats(B, a.H2, a.W2, 64, 128));
+    mx(mk_conv3x3_wgrad_slab_floats(B, a.H2, a.W2, 128, 128));
+    a.slab_floats = sl; a.slab = ar.get<float>(sl);
+    if (train) {
+        a.ge_a = ar.get<float>(re * E); a.ge_b = ar.get<float>(re * E); a.gd_a = ar.get<float>(rd * E); a.gd_b = ar.get<float>(rd * E);
+        a.dmem32 = ar.get<float>(re * E); a.v2e_g32 = ar.get<float>((int64_t)E * m->F);
+        a.ge16 = ar.get<bf16>(re * E); a.gd16 = ar.get<bf16>(rd * E);
+        a.gqkv_e = ar.get<bf16>(re * 3 * E); a.gqkv_d = ar.get<bf16>(rd * 3 * E);
+        a.gf_e = ar.get<bf16>(re * Fi); a.gf_d = ar.get<bf16>(rd * Fi);
+        a.gao_e = ar.get<bf16>(re * E); a.gao_d = ar.get<bf16>(rd * E);
+        a.gq_d = ar.get<bf16>(rd * E); a.gkv_d = ar.get<bf16>(re * 2 * E);
+        a.delta_e = ar.get<float>((int64_t)B * H * a.Tp); a.delta_d = ar.get<float>((int64_t)B * H * L);
+        a.dp2 = ar.get<bf16>(re * m->F); a.da4 = ar.get<bf16>(P2 * 128); a.da3 = ar.get<bf16>(P2 * 128);
+        a.dp1 = ar.get<bf16>(P2 * 64); a.da2 = ar.get<bf16>(P1 * 64); a.da1 = ar.get<bf16>(P1 * 64);
+    }
+}
+
+// ------------------------------------------------------------------ profiling scope
+struct Prof {
+    masr_model* m; int cat; hipStream_t s; bool on;
+    Prof(masr_model* m_, int cat_, hipStream_t s_) : m(m_), cat(cat_), s(s_), on(m_->prof) {
+        if (!on) return;
+        auto& v = m->prof_ev[cat];
+        if (m->prof_used[cat] == (int)v.size()) {
+            hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); v.push_back({a, b});
+        }
+        hipEventRecord(v[m->prof_used[cat]].first, s);
+    }
+    ~Prof() {
+        if (!on) return;
+        hipEventRecord(m->prof_ev[cat][m->prof_used[cat]].second, s);
+        m->prof_used[cat]++;
+    }
+};
+
+#define CK(expr) do { if ((expr) != 0) return -1; } while (0)
+
+// Y = X W^T (+bias ...) with the bf16 shadow of W
+GemmArgs lin_fwd_args(const bf16* x, long ldx, const bf16* wk, int M, int N, int K, const float* bias) {
+    GemmArgs g = gemm_args();
+    g.A = x; g.lda = ldx; g.B = wk; g.ldb = K; g.M = M; g.N = N; g.K = K; g.bias = bias;
+    return g;
+}
+
+struct Ctx { masr_model* m; hipStream_t s; uint32_t seed; bool train; float p_drop, p_pos; };
+
+int gemm(Ctx& c, const GemmArgs& g) { Prof p(c.m, MASR_PROF_GEMM, c.s); return mk_gemm(g, c.s); }
+
+// weight/bias gradients of a Linear: dW[N][K] = dy^T x, db = colsum(dy)
+int lin_wgrad(Ctx& c, const bf16* dy, long lddy, const bf16* x, long ldx, int rows, int N, int K, float* dW, float* db, int accumulate = 0) {
+    GemmArgs g = gemm_args();
+    g.reduction_major = 1; g.A = dy; g.lda = lddy; g.B = x; g.ldb = ldx; g.M = N; g.N = K; g.K = rows;
+    g.C32 = dW; g.ldc = K; g.accumulate = accumulate;
+    CK(gemm(c, g));
+    if (db) { Prof p(c.m, MASR_PROF_OTHER, c.s); CK(mk_colsum(dy, lddy, db, c.m->acts.slab, rows, (N + 7) / 8 * 8, N, c.s)); }
+    return 0;
+}
+// dX = dy W via the transposed shadow t16 [K][ldt]
+GemmArgs lin_dgrad_args(const bf16* dy, long lddy, const bf16* t16, long ldt, int rows, int N, int K) {
+    GemmArgs g = gemm_args();
+    g.A = dy; g.lda = lddy; g.B = t16; g.ldb = ldt; g.M = rows; g.N = K; g.K = N;
+    return g;
+}
+
+int attn_block_fwd(Ctx& c, const Attn& at, const bf16* xq, const bf16* xkv, int rows_q, int rows_kv, int Tq, int Tk, bool self,
+                   bool causal, const int* klens, bf16* qkv_or_q, bf16* kv, bf16* ao, float* lse, const float* resid, float* s_out,
+                   uint32_t site_p, uint32_t site_o) {
+    masr_model* m = c.m; const int E = m->E; const float* P = m->P;
+    AttnArgs a{};
+    if (self) {
+        GemmArgs g = lin_fwd_args(xq, E, at.in.k16, rows_q, 3 * E, E, P + at.in.b); g.C16 = qkv_or_q; g.ldc16 = 3 * E;
+        CK(gemm(c, g));
+        a.q = qkv_or_q; a.k = qkv_or_q + E; a.v = qkv_or_q + 2 * E; a.ldq = a.ldk = a.ldv = 3 * E;
+    } else {
+        GemmArgs g = lin_fwd_args(xq, E, at.in.k16, rows_q, E, E, P + at.in.b); g.C16 = qkv_or_q; g.ldc16 = E;
+        CK(gemm(c, g));
+        GemmArgs h = lin_fwd_args(xkv, E, at.in.k16 + (long)E * E, rows_kv, 2 * E, E, P + at.in.b + E); h.C16 = kv; h.ldc16 = 2 * E;
+        CK(gemm(c, h));
+        a.q = qkv_or_q; a.ldq = E; a.k = kv; a.v = kv + E; a.ldk = a.ldv = 2 * E;
+    }
+    a.o = ao; a.ldo = E; a.lse = lse; a.klens = klens; a.B = m->acts.B; a.H = m->H; a.Tq = Tq; a.Tk = Tk; a.hd = m->hd;
+    a.causal = causal; a.drop_p = c.p_drop; a.seed = c.seed; a.site = site_p;
+    { Prof p(m, MASR_PROF_ATTN, c.s); CK(mk_attn_fwd(a, c.s)); }
+    GemmArgs o = lin_fwd_args(ao, E, at.out.k16, rows_q, E, E, P + at.out.b);
+    o.drop_p = c.p_drop; o.seed = c.seed; o.site = site_o; o.residual = resid; o.ldres = E; o.C32 = s_out; o.ldc = E;
+    CK(gemm(c, o));
+    return 0;
+}
+
+int ffn_fwd(Ctx& c, const Lin& l1, const Lin& l2, const bf16* x16, const float* x32, int rows, bf16* f, float* s_out, uint32_t site_i, uint32_t site_o) {
+    masr_model* m = c.m; const int E = m->E, Fi = m->Fi; const float* P = m->P;
+    GemmArgs g = lin_fwd_args(x16, E, l1.k16, rows, Fi, E, P + l1.b); g.relu = 1; g.drop_p = c.p_drop; g.seed = c.seed; g.site = site_i;
+    g.C16 = f; g.ldc16 = Fi;
+    CK(gemm(c, g));
+    GemmArgs h = lin_fwd_args(f, Fi, l2.k16, rows, E, Fi, P + l2.b); h.drop_p = c.p_drop; h.seed = c.seed; h.site = site_o;
+    h.residual = x32; h.ldres = E; h.C32 = s_out; h.ldc = E;
+    CK(gemm(c, h));
+    return 0;
+}
+int ln_fwd(Ctx& c, const Norm& n, const float* x, float* y32, bf16* y16, float* mean, float* rstd, int rows) {
+    Prof p(c.m, MASR_PROF_OTHER, c.s);
+    return mk_layernorm_fwd(x, c.m->P + n.w, c.m->P + n.b, y32, y16, mean, rstd, rows, c.m->E, c.s);
+}
+int ln_bwd(Ctx& c, const Norm& n, const float* dy, const float* x, const float* mean, const float* rstd, float* dx32, bf16* dx16,
+           uint32_t site, int rows) {
+    Prof p(c.m, MASR_PROF_OTHER, c.s);
+    masr_model* m = c.m;
+    return mk_layernorm_bwd(dy, x, m->P + n.w, mean, rstd, dx32, dx16, dx16 ? c.p_drop : 0.f, c.seed, site, m->G + n.w, m->G + n.b,
+                            m->acts.slab, rows, m->E, c.s);
+}
+
+// backward of  s_out = x + drop(ffn(x16))  given d s_out (gs32 fp32, gs16 bf16 already dropout-masked for the ffn output site)
+// writes d x (fp32) = gs32 + ffn-branch gradient into gout
+int ffn_bwd(Ctx& c, const Lin& l1, const Lin& l2, const bf16* x16, const bf16* f, const float* gs32, const bf16* gs16, int rows,
+            bf16* gf, float* gout) {
+    masr_model* m = c.m; const int E = m->E, Fi = m->Fi;
+    CK(lin_wgrad(c, gs16, E, f, Fi, rows, E, Fi, m->G + l2.w, m->G + l2.b));
+    GemmArgs g = lin_dgrad_args(gs16, E, l2.t16, E, rows, E, Fi);
+    g.mask = f; g.ldmask = Fi; g.mask_scale = c.p_drop > 0.f ? 1.f / (1.f - c.p_drop) : 1.f; g.C16 = gf; g.ldc16 = Fi;
+    CK(gemm(c, g));
+    CK(lin_wgrad(c, gf, Fi, x16, E, rows, Fi, E, m->G + l1.w, m->G + l1.b));
+    GemmArgs h = lin_dgrad_args(gf, Fi, l1.t16, Fi, rows, Fi, E);
+    h.residual = gs32; h.ldres = E; h.C32 = gout; h.ldc = E;
+    CK(gemm(c, h));
+    return 0;
+}
+
+}  // namespace
+
+// =========================================================================== C ABI
+extern "C" {
+
+int masr_version(void) { return 1; }
+const char* masr_last_error(void) { return g_err.c_str(); }
+
+masr_model* masr_create(const masr_config* cfg) {
+    if (!cfg || cfg->d_model % cfg->nheads || cfg->d_model % 8 || cfg->d_inner % 8 || cfg->idim < 4) {
+        mk_set_error("masr_create", "bad config"); return nullptr;
+    }
+    const int hd = cfg->d_model / cfg->nheads;
+    if (hd != 16 && hd != 32 && hd != 64) { mk_set_error("masr_create", "head dim must be 16/32/64"); return nullptr; }
+    if (cfg->d_model > 1024 || cfg->d_inner > 2048 || 3 * cfg->d_model > 2048) {
+        mk_set_error("masr_create", "d_model <= 682, d_inner <= 2048 supported"); return nullptr;
+    }
+    masr_model* m = new masr_model();
+    m->cfg = *cfg; m->E = cfg->d_model; m->H = cfg->nheads; m->hd = hd; m->Fi = cfg->d_inner; m->NE = cfg->enc_layers;
+    m->ND = cfg->dec_layers; m->C = cfg->odim; m->Cp = (cfg->odim + 127) / 128 * 128; m->D = cfg->idim;
+    m->Dp = (cfg->idim / 2) / 2; m->F = 128 * m->Dp;
+    // state_dict order of the reference
+    const int idx[4] = {0, 2, 5, 7}; const int co[4] = {64, 64, 128, 128}, ci[4] = {1, 64, 64, 128};
+    for (int i = 0; i < 4; ++i) {
+        Conv& c = m->conv[i]; c.CO = co[i]; c.CI = ci[i]; c.k16 = c.d16 = nullptr;
+        const std::string pre = "feat_extractor." + std::to_string(idx[i]);
+        c.w = add_param(m, pre + ".weight", {co[i], ci[i], 3, 3});
+        c.b = add_param(m, pre + ".bias", {co[i]});
+    }
+    m->v2e = add_linear(m, "vgg2enc", m->E, 128 * (cfg->idim / 4));
+    m->ct = add_linear(m, "char_trans", m->C, m->E);
+    m->embed_w = cfg->tie_weights ? m->ct.w : add_param(m, "pre_embed.weight", {m->C, m->E});
+    m->enc.resize(m->NE);
+    for (int l = 0; l < m->NE; ++l) {
+        const std::string pre = "encoder.layers." + std::to_string(l);
+        EncL& e = m->enc[l];
+        e.sa = add_attn(m, pre + ".self_attn");
+        e.l1 = add_linear(m, pre + ".linear1", m->Fi, m->E); e.l2 = add_linear(m, pre + ".linear2", m->E, m->Fi);
+        e.n1 = add_norm(m, pre + ".norm1"); e.n2 = add_norm(m, pre + ".norm2");
+    }
+    m->enc_norm = add_norm(m, "encoder.norm");
+    m->dec.resize(m->ND);
+    for (int l = 0; l < m->ND; ++l) {
+        const std::string pre = "decoder.layers." + std::to_string(l);
+        DecL& d = m->dec[l];
+        d.sa = add_attn(m, pre + ".self_attn"); d.ca = add_attn(m, pre + ".multihead_attn");
+        d.l1 = add_linear(m, pre + ".linear1", m->Fi, m->E); d.l2 = add_linear(m, pre + ".linear2", m->E, m->Fi);
+        d.n1 = add_norm(m, pre + ".norm1"); d.n2 = add_norm(m, pre + ".norm2"); d.n3 = add_norm(m, pre + ".norm3");
+    }
+    m->dec_norm = add_norm(m, "decoder.norm");
+    Arena ar{nullptr, 0, 0};
+    plan_persistent(m, ar);
+    m->persist_bytes = ar.off;
+    m->stage_ints = 1 << 16;
+    for (auto& e : m->stage_ev) e = nullptr;
+    return m;
+}
+
+void masr_destroy(masr_model* m) {
+    if (!m) return;
+    if (m->h_stage) hipHostFree(m->h_stage);
+    if (m->h_stats) hipHostFree(m->h_stats);
+    for (auto& e : m->stage_ev) if (e) hipEventDestroy(e);
+    for (auto& v : m->prof_ev) for (auto& p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    delete m;
+}
+
+int64_t masr_param_numel(const masr_model* m) { return m->nparams; }
+int masr_param_count(const masr_model* m) { return (int)m->params.size(); }
+int masr_param_info(const masr_model* m, int idx, char* name, int cap, int64_t shape[4], int* ndim, int64_t* offset) {
+    if (idx < 0 || idx >= (int)m->params.size()) { mk_set_error("masr_param_info", "index out of range"); return -1; }
+    const PInfo& p = m->params[idx];
+    if (name && cap > 0) { std::strncpy(name, p.name.c_str(), cap - 1); name[cap - 1] = 0; }
+    for (int i = 0; i < 4; ++i) shape[i] = p.shape[i];
+    *ndim = p.ndim; *offset = p.off;
+    return 0;
+}
+
+int64_t masr_workspace_bytes(const masr_model* m, int B, int T, int L) {
+    Arena ar{nullptr, 0, 0};
+    Acts a;
+    plan_acts(m, ar, a, B, T, L, true);
+    return m->persist_bytes + ar.off + 4096;
+}
+
+int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void* workspace, int64_t ws_bytes) {
+    if (!params || !grads || !pe || !workspace || ws_bytes < m->persist_bytes) { mk_set_error("masr_bind", "null pointer or workspace too small"); return -1; }
+    if (((uintptr_t)workspace & 255) || ((uintptr_t)params & 15) || ((uintptr_t)grads & 15)) { mk_set_error("masr_bind", "misaligned buffers"); return -1; }
+    m->P = params; m->G = grads; m->pe = pe; m->ws = (char*)workspace; m->ws_bytes = ws_bytes;
+    Arena ar{m->ws, ws_bytes, 0};
+    plan_persistent(m, ar);
+    if (!m->h_stage) {
+        HIP_CHECK_RET(hipHostMalloc((void**)&m->h_stage, sizeof(int) * m->stage_ints * 4, hipHostMallocDefault));
+        HIP_CHECK_RET(hipHostMalloc((void**)&m->h_stats, sizeof(float) * 64, hipHostMallocDefault));
+        for (auto& e : m->stage_ev) HIP_CHECK_RET(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    m->have_acts = false;
+    return 0;
+}
+
+void masr_set_seed(masr_model* m, uint64_t seed) { m->seed = seed; m->step = 0; }
+
+int masr_refresh(masr_model* m, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!m->P) { mk_set_error("masr_refresh", "not bound"); return -1; }
+    Prof p(m, MASR_PROF_OTHER, s);
+    const float* P = m->P;
+    // pads of the char_trans shadows must be zero (rows/cols >= odim)
+    HIP_CHECK_RET(hipMemsetAsync(m->ct.k16, 0, sizeof(bf16) * (size_t)m->Cp * m->E, s));
+    HIP_CHECK_RET(hipMemsetAsync(m->ct.t16, 0, sizeof(bf16) * (size_t)m->E * m->Cp, s));
+    for (int i = 1; i < 4; ++i) CK(mk_conv_weight_shadows(P + m->conv[i].w, m->conv[i].k16, m->conv[i].d16, m->conv[i].CO, m->conv[i].CI, s));
+    CK(mk_vgg2enc_shadows(P + m->v2e.w, m->v2e_k, m->v2e.t16, m->E, 128, m->Dp, s));
+    CK(mk_cast_bf16(P + m->ct.w, m->ct.k16, (long)m->C * m->E, s));
+    CK(mk_transpose_cast_bf16(P + m->ct.w, m->ct.t16, m->C, m->E, m->Cp, s));
+    auto lin = [&](Lin& l) -> int {
+        const int Np = (l.N + 7) / 8 * 8;
+        CK(mk_cast_bf16(P + l.w, l.k16, (long)l.N * l.K, s));
+        CK(mk_transpose_cast_bf16(P + l.w, l.t16, l.N, l.K, Np, s));
+        return 0;
+    };
+    for (auto& e : m->enc) { CK(lin(e.sa.in)); CK(lin(e.sa.out)); CK(lin(e.l1)); CK(lin(e.l2)); }
+    for (auto& d : m->dec) { CK(lin(d.sa.in)); CK(lin(d.sa.out)); CK(lin(d.ca.in)); CK(lin(d.ca.out)); CK(lin(d.l1)); CK(lin(d.l2)); }
+    return 0;
+}
+
+static int forward_encoder(Ctx& c, const float* xs) {
+    masr_model* m = c.m; Acts& a = m->acts; hipStream_t s = c.s; const float* P = m->P;
+    const int B = a.B, T = a.T, D = a.D, E = m->E;
+    uint32_t site = 1;
+    {
+        Prof p(m, MASR_PROF_CONV_FWD, s);
+        CK(mk_conv1_fwd(xs, P + m->conv[0].w, P + m->conv[0].b, a.a1, B, T, D, s));
+    }
+    auto conv = [&](const bf16* in, const Conv& cv, bf16* out, int H, int W) -> int {
+        Prof p(m, MASR_PROF_CONV_FWD, s);
+        ConvArgs ca{}; ca.in = in; ca.wk = cv.k16; ca.bias = P + cv.b; ca.relu = 1; ca.mask = nullptr; ca.out = out;
+        ca.B = B; ca.H = H; ca.W = W; ca.CIN = cv.CI; ca.COUT = cv.CO;
+        return mk_conv3x3(ca, s);
+    };
+    CK(conv(a.a1, m->conv[1], a.a2, T, D));
+    { Prof p(m, MASR_PROF_OTHER, s); CK(mk_maxpool_fwd(a.a2, a.p1, B, T, D, 64, s)); }
+    CK(conv(a.p1, m->conv[2], a.a3, a.H2, a.W2));
+    CK(conv(a.a3, m->conv[3], a.a4, a.H2, a.W2));
+    { Prof p(m, MASR_PROF_OTHER, s); CK(mk_maxpool_fwd(a.a4, a.p2, B, a.H2, a.W2, 128, s)); }
+    // vgg2enc + positional encoding + pos dropout
+    {
+        GemmArgs g = lin_fwd_args(a.p2, m->F, m->v2e_k, a.rows_e, E, m->F, P + m->v2e.b);
+        g.pe = m->pe; g.pe_period = a.Tp; g.drop_p = c.p_pos; g.seed = c.seed; g.site = a.site_v2e = site++;
+        g.C32 = a.x32[0]; g.ldc = E; g.C16 = a.x16[0]; g.ldc16 = E;
+        CK(gemm(c, g));
+    }
+    for (int l = 0; l < m->NE; ++l) {
+        EncAct& e = a.enc[l]; const EncL& w = m->enc[l];
+        for (int i = 0; i < 4; ++i) e.site[i] = site++;
+        CK(attn_block_fwd(c, w.sa, a.x16[l], nullptr, a.rows_e, 0, a.Tp, a.Tp, true, false, a.enc_lens, e.qkv, nullptr, e.ao, e.lse,
+                          a.x32[l], e.s1, e.site[0], e.site[1]));
+        CK(ln_fwd(c, w.n1, e.s1, e.x1_32, e.x1_16, e.m1, e.r1, a.rows_e));
+        CK(ffn_fwd(c, w.l1, w.l2, e.x1_16, e.x1_32, a.rows_e, e.f, e.s2, e.site[2], e.site[3]));
+        CK(ln_fwd(c, w.n2, e.s2, a.x32[l + 1], a.x16[l + 1], e.m2, e.r2, a.rows_e));
+    }
+    CK(ln_fwd(c, m->enc_norm, a.x32[m->NE], nullptr, a.mem16, a.mf, a.rf, a.rows_e));
+    return 0;
+}
+
+static int forward_decoder(Ctx& c) {
+    masr_model* m = c.m; Acts& a = m->acts; hipStream_t s = c.s; const float* P = m->P;
+    const int E = m->E, L = a.L;
+    uint32_t site = 100;
+    a.site_emb = site++;
+    { Prof p(m, MASR_PROF_OTHER, s); CK(mk_embed_fwd(a.tok_in, P + m->embed_w, m->pe, a.y32[0], a.y16[0], a.B, L, E, c.p_pos, c.seed, a.site_emb, s)); }
+    for (int l = 0; l < m->ND; ++l) {
+        DecAct& d = a.dec[l]; const DecL& w = m->dec[l];
+        for (int i = 0; i < 6; ++i) d.site[i] = site++;
+        CK(attn_block_fwd(c, w.sa, a.y16[l], nullptr, a.rows_d, 0, L, L, true, true, nullptr, d.qkv, nullptr, d.ao, d.lse_s, a.y32[l], d.s1,
+                          d.site[0], d.site[1]));
+        CK(ln_fwd(c, w.n1, d.s1, d.y1_32, d.y1_16, d.m1, d.r1, a.rows_d));
+        CK(attn_block_fwd(c, w.ca, d.y1_16, a.mem16, a.rows_d, a.rows_e, L, a.Tp, false, false, a.enc_lens, d.q, d.kv, d.co, d.lse_c, d.y1_32,
+                          d.s2, d.site[2], d.site[3]));
+        CK(ln_fwd(c, w.n2, d.s2, d.y2_32, d.y2_16, d.m2, d.r2, a.rows_d));
+        CK(ffn_fwd(c, w.l1, w.l2, d.y2_16, d.y2_32, a.rows_d, d.f, d.s3, d.site[4], d.site[5]));
+        CK(ln_fwd(c, w.n3, d.s3, a.y32[l + 1], a.y16[l + 1], d.m3, d.r3, a.rows_d));
+    }
+    CK(ln_fwd(c, m->dec_norm, a.y32[m->ND], nullptr, a.yf16, a.mdf, a.rdf, a.rows_d));
+    GemmArgs g = lin_fwd_args(a.yf16, E, m->ct.k16, a.rows_d, m->C, E, P + m->ct.b);
+    g.C32 = a.logits; g.ldc = m->Cp;
+    CK(gemm(c, g));
+    return 0;
+}
+
+// backward of an attention block  s = resid + drop(out_proj(attn(...)))
+//   gs32/gs16: d s (bf16 copy already masked with the out-proj dropout site)
+//   self : writes d x (fp32) = gs32 + qkv-proj dgrad into gout
+//   cross: writes d xq (fp32) = gs32 + q-proj dgrad into gout and accumulates d memory into dmem
+static int attn_block_bwd(Ctx& c, const Attn& at, const bf16* xq16, const bf16* xkv16, int rows_q, int rows_kv, int Tq, int Tk, bool self,
+                          bool causal, const int* klens, const bf16* qkv_or_q, const bf16* kv, const bf16* ao, const float* lse,
+                          const float* gs32, const bf16* gs16, bf16* gao, bf16* gqkv_or_q, bf16* gkv, float* delta, float* gout,
+                          float* dmem, int dmem_accumulate, uint32_t site_p) {
+    masr_model* m = c.m; const int E = m->E; float* G = m->G;
+    CK(lin_wgrad(c, gs16, E, ao, E, rows_q, E, E, G + at.out.w, G + at.out.b));
+    { GemmArgs g = lin_dgrad_args(gs16, E, at.out.t16, E, rows_q, E, E); g.C16 = gao; g.ldc16 = E; CK(gemm(c, g)); }
+    AttnArgs a{};
+    if (self) {
+        a.q = qkv_or_q; a.k = qkv_or_q + E; a.v = qkv_or_q + 2 * E; a.ldq = a.ldk = a.ldv = 3 * E;
+        a.dq = gqkv_or_q; a.dk = gqkv_or_q + E; a.dv = gqkv_or_q + 2 * E; a.lddq = a.lddk = a.lddv = 3 * E;
+    } else {
+        a.q = qkv_or_q; a.ldq = E; a.k = kv; a.v = kv + E; a.ldk = a.ldv = 2 * E;
+        a.dq = gqkv_or_q; a.lddq = E; a.dk = gkv; a.dv = gkv + E; a.lddk = a.lddv = 2 * E;
+    }
+    a.o = const_cast<bf16*>(ao); a.ldo = E; a.lse = const_cast<float*>(lse); a.dout = gao; a.lddo = E; a.delta = delta; a.klens = klens;
+    a.B = m->acts.B; a.H = m->H; a.Tq = Tq; a.Tk = Tk; a.hd = m->hd; a.causal = causal; a.drop_p = c.p_drop; a.seed = c.seed; a.site = site_p;
+    { Prof p(m, MASR_PROF_ATTN, c.s); CK(mk_attn_bwd(a, c.s)); }
+    if (self) {
+        CK(lin_wgrad(c, gqkv_or_q, 3 * E, xq16, E, rows_q, 3 * E, E, G + at.in.w, G + at.in.b));
+        GemmArgs g = lin_dgrad_args(gqkv_or_q, 3 * E, at.in.t16, 3 * E, rows_q, 3 * E, E);
+        g.residual = gs32; g.ldres = E; g.C32 = gout; g.ldc = E;
+        CK(gemm(c, g));
+    } else {
+        CK(lin_wgrad(c, gqkv_or_q, E, xq16, E, rows_q, E, E, G + at.in.w, G + at.in.b));
+        GemmArgs g = lin_dgrad_args(gqkv_or_q, E, at.in.t16, 3 * E, rows_q, E, E);
+        g.residual = gs32; g.ldres = E; g.C32 = gout; g.ldc = E;
+        CK(gemm(c, g));
+        CK(lin_wgrad(c, gkv, 2 * E, xkv16, E, rows_kv, 2 * E, E, G + at.in.w + (long)E * E, G + at.in.b + E));
+        GemmArgs h = lin_dgrad_args(gkv, 2 * E, at.in.t16 + E, 3 * E, rows_kv, 2 * E, E);
+        h.C32 = dmem; h.ldc = E; h.accumulate = dmem_accumulate;
+        CK(gemm(c, h));
+    }
+    return 0;
+}
+
+static int backward(Ctx& c, const float* xs) {
+    masr_model* m = c.m; Acts& a = m->acts; hipStream_t s = c.s; float* G = m->G;
+    const int E = m->E, L = a.L, B = a.B;
+    // ---- output projection
+    CK(lin_wgrad(c, a.dlogits, m->Cp, a.yf16, E, a.rows_d, m->C, E, G + m->ct.w, G + m->ct.b));
+    { GemmArgs g = lin_dgrad_args(a.dlogits, m->Cp, m->ct.t16, m->Cp, a.rows_d, m->Cp, E); g.C32 = a.gd_a; g.ldc = E; CK(gemm(c, g)); }
+    float *gcur = a.gd_b, *gs = a.gd_a;
+    CK(ln_bwd(c, m->dec_norm, a.gd_a, a.y32[m->ND], a.mdf, a.rdf, gcur, nullptr, 0, a.rows_d));
+    // ---- decoder layers
+    for (int l = m->ND - 1; l >= 0; --l) {
+        DecAct& d = a.dec[l]; const DecL& w = m->dec[l];
+        CK(ln_bwd(c, w.n3, gcur, d.s3, d.m3, d.r3, gs, a.gd16, d.site[5], a.rows_d));
+        CK(ffn_bwd(c, w.l1, w.l2, d.y2_16, d.f, gs, a.gd16, a.rows_d, a.gf_d, gcur));
+        CK(ln_bwd(c, w.n2, gcur, d.s2, d.m2, d.r2, gs, a.gd16, d.site[3], a.rows_d));
+        CK(attn_block_bwd(c, w.ca, d.y1_16, a.mem16, a.rows_d, a.rows_e, L, a.Tp, false, false, a.enc_lens, d.q, d.kv, d.co, d.lse_c, gs,
+                          a.gd16, a.gao_d, a.gq_d, a.gkv_d, a.delta_d, gcur, a.dmem32, l == m->ND - 1 ? 0 : 1, d.site[2]));
+        CK(ln_bwd(c, w.n1, gcur, d.s1, d.m1, d.r1, gs, a.gd16, d.site[1], a.rows_d));
+        CK(attn_block_bwd(c, w.sa, a.y16[l], nullptr, a.rows_d, 0, L, L, true, true, nullptr, d.qkv, nullptr, d.ao, d.lse_s, gs, a.gd16,
+                          a.gao_d, a.gqkv_d, nullptr, a.delta_d, gcur, nullptr, 0, d.site[0]));
+    }
+    { Prof p(m, MASR_PROF_OTHER, s);
+      CK(mk_embed_bwd(a.tok_in, gcur, G + m->embed_w, a.rows_d, m->C, E, m->cfg.tie_weights ? 1 : 0, c.p_pos, c.seed, a.site_emb, s)); }
+    // ---- encoder
+    gcur = a.ge_b; gs = a.ge_a;
+    CK(ln_bwd(c, m->enc_norm, a.dmem32, a.x32[m->NE], a.mf, a.rf, gcur, nullptr, 0, a.rows_e));
+    for (int l = m->NE - 1; l >= 0; --l) {
+        EncAct& e = a.enc[l]; const EncL& w = m->enc[l];
+        CK(ln_bwd(c, w.n2, gcur, e.s2, e.m2, e.r2, gs, a.ge16, e.site[3], a.rows_e));
+        CK(ffn_bwd(c, w.l1, w.l2, e.x1_16, e.f, gs, a.ge16, a.rows_e, a.gf_e, gcur));
+        CK(ln_bwd(c, w.n1, gcur, e.s1, e.m1, e.r1, gs, a.ge16, e.site[1], a.rows_e));
+        CK(attn_block_bwd(c, w.sa, a.x16[l], nullptr, a.rows_e, 0, a.Tp, a.Tp, true, false, a.enc_lens, e.qkv, nullptr, e.ao, e.lse, gs, a.ge16,
+                          a.gao_e, a.gqkv_e, nullptr, a.delta_e, gcur, nullptr, 0, e.site[0]));
+    }
+    // ---- vgg2enc (through the positional dropout)
+    { Prof p(m, MASR_PROF_OTHER, s); CK(mk_cast_dropout(gcur, a.ge16, (long)a.rows_e * E, c.p_pos, c.seed, a.site_v2e, s)); }
+    CK(lin_wgrad(c, a.ge16, E, a.p2, m->F, a.rows_e, E, m->F, a.v2e_g32, G + m->v2e.b));
+    { Prof p(m, MASR_PROF_OTHER, s); CK(mk_vgg2enc_grad_unpermute(a.v2e_g32, G + m->v2e.w, E, 128, m->Dp, s)); }
+    { GemmArgs g = lin_dgrad_args(a.ge16, E, m->v2e.t16, E, a.rows_e, E, m->F); g.C16 = a.dp2; g.ldc16 = m->F; CK(gemm(c, g)); }
+    // ---- VGG
+    const int64_t P1 = (int64_t)B * a.T * a.D, P2 = (int64_t)B * a.H2 * a.W2;
+    auto wgrad = [&](const bf16* in, const bf16* dy, const Conv& cv, int H, int W, int64_t P) -> int {
+        { Prof p(m, MASR_PROF_CONV_WGRAD, s);
+          ConvWgradArgs wa{}; wa.in = in; wa.dy = dy; wa.dw = G + cv.w; wa.db = nullptr; wa.slab = a.slab; wa.B = B; wa.H = H; wa.W = W; wa.CIN = cv.CI; wa.COUT = cv.CO;
+          CK(mk_conv3x3_wgrad(wa, s)); }
+        { Prof p(m, MASR_PROF_OTHER, s); CK(mk_colsum(dy, cv.CO, G + cv.b, a.slab, (int)P, cv.CO, cv.CO, s)); }
+        return 0;
+    };
+    auto dgrad = [&](const bf16* dy, const Conv& cv, const bf16* mask, bf16* out, int H, int W) -> int {
+        Prof p(m, MASR_PROF_CONV_DGRAD, s);
+        ConvArgs ca{}; ca.in = dy; ca.wk = cv.d16; ca.bias = nullptr; ca.relu = 0; ca.mask = mask; ca.out = out; ca.B = B; ca.H = H; ca.W = W;
+        ca.CIN = cv.CO; ca.COUT = cv.CI;
+        return mk_conv3x3(ca, s);
+    };
+    { Prof p(m, MASR_PROF_OTHER, s); CK(mk_maxpool_relu_bwd(a.a4, a.dp2, a.da4, B, a.H2, a.W2, 128, s)); }
+    CK(wgrad(a.a3, a.da4, m->conv[3], a.H2, a.W2, P2));
+    CK(dgrad(a.da4, m->conv[3], a.a3, a.da3, a.H2, a.W2));
+    CK(wgrad(a.p1, a.da3, m->conv[2], a.H2, a.W2, P2));
+    CK(dgrad(a.da3, m->conv[2], nullptr, a.dp1, a.H2, a.W2));
+    { Prof p(m, MASR_PROF_OTHER, s); CK(mk_maxpool_relu_bwd(a.a2, a.dp1, a.da2, B, a.T, a.D, 64, s)); }
+    CK(wgrad(a.a1, a.da2, m->conv[1], a.T, a.D, P1));
+    CK(dgrad(a.da2, m->conv[1], a.a1, a.da1, a.T, a.D));
+    { Prof p(m, MASR_PROF_CONV_WGRAD, s); CK(mk_conv1_wgrad(xs, a.da1, G + m->conv[0].w, G + m->conv[0].b, a.slab, B, a.T, a.D, s)); }
+    return 0;
+}
+
+int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const int64_t* ys_flat, const int64_t* olens, int B, int T,
+                   int flags, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!m->P) { mk_set_error("masr_run_batch", "not bound"); return -1; }
+    if (B <= 0 || T < 4) { mk_set_error("masr_run_batch", "need B >= 1 and T >= 4"); return -1; }
+    const bool train = (flags & MASR_TRAIN) != 0;
+    int maxo = 0; int64_t ntot = 0;
+    for (int b = 0; b < B; ++b) { if (olens[b] > maxo) maxo = (int)olens[b]; ntot += olens[b] + 1; }
+    const int L = maxo + 1;
+    Arena ar{m->ws, m->ws_bytes, m->persist_bytes};
+    plan_acts(m, ar, m->acts, B, T, L, train);
+    if (ar.off > m->ws_bytes) { mk_set_error("masr_run_batch", "workspace too small (see masr_workspace_bytes)"); return -2; }
+    Acts& a = m->acts; m->have_acts = true;
+    if ((int64_t)2 * B * L + B > m->stage_ints) { mk_set_error("masr_run_batch", "token staging buffer too small"); return -1; }
+    // ---- MyTransformer.preprocess (:124-141): ys_in = [sos]+y padded with eos, ys_out = y+[eos] padded with -1
+    const int slot = m->stage_slot; m->stage_slot = (slot + 1) & 3;
+    HIP_CHECK_RET(hipEventSynchronize(m->stage_ev[slot]));
+    int* h = m->h_stage + (int64_t)slot * m->stage_ints;
+    int* h_in = h; int* h_out = h + (int64_t)B * L; int* h_len = h + (int64_t)2 * B * L;
+    const int sos = 0, eos = m->C - 1;
+    int64_t off = 0;
+    for (int b = 0; b < B; ++b) {
+        const int n = (int)olens[b];
+        for (int l = 0; l < L; ++l) { h_in[b * L + l] = eos; h_out[b * L + l] = -1; }
+        h_in[b * L] = sos;
+        for (int l = 0; l < n; ++l) {
+            const int tok = (int)ys_flat[off + l];
+            if (tok < 0 || tok >= m->C) { mk_set_error("masr_run_batch", "label out of range"); return -1; }
+            h_in[b * L + l + 1] = tok; h_out[b * L + l] = tok;
+        }
+        h_out[b * L + n] = eos;
+        off += n;
+        h_len[b] = (int)(ilens[b] / 4);                             // enc_lens = floor(ilens/4) (:117)
+        if (h_len[b] < 1 || ilens[b] > T) { mk_set_error("masr_run_batch", "ilens must be in [4, T]"); return -1; }
+    }
+    HIP_CHECK_RET(hipMemcpyAsync(a.tok_in, h_in, sizeof(int) * (size_t)B * L, hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipMemcpyAsync(a.gold, h_out, sizeof(int) * (size_t)B * L, hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipMemcpyAsync(a.enc_lens, h_len, sizeof(int) * (size_t)B, hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipEventRecord(m->stage_ev[slot], s));
+
+    Ctx c{m, s, (uint32_t)(m->seed * 0x9E3779B97F4A7C15ull >> 32) + (uint32_t)m->step * 7919u, train,
+          train ? m->cfg.dropout : 0.f, train ? m->cfg.pos_dropout : 0.f};
+    m->step++;
+    CK(forward_encoder(c, xs));
+    CK(forward_decoder(c));
+    { Prof p(m, MASR_PROF_OTHER, s);
+      CK(mk_ls_ce(a.logits, m->Cp, a.gold, a.rows_d, m->C, m->cfg.label_smoothing, 1.0f / (float)ntot, a.dlogits, a.row_loss, a.row_correct,
+                  m->stats, s)); }
+    if (train) CK(backward(c, xs));
+    return 0;
+}
+
+int masr_read_stats(masr_model* m, float out[4], void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HIP_CHECK_RET(hipMemcpyAsync(m->h_stats, m->stats, sizeof(float) * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK_RET(hipStreamSynchronize(s));
+    for (int i = 0; i < 4; ++i) out[i] = m->h_stats[i];
+    return 0;
+}
+
+int masr_last_logits(masr_model* m, const float** logits, const int32_t** gold, int* rows, int* L, int* ld) {
+    if (!m->have_acts) { mk_set_error("masr_last_logits", "no forward has run"); return -1; }
+    *logits = m->acts.logits; *gold = m->acts.gold; *rows = m->acts.rows_d; *L = m->acts.L; *ld = m->Cp;
+    return 0;
+}
+
+static float* slab_of(masr_model* m) {
+    // optimiser passes may run before any batch: fall back to the tail of the persistent stats block
+    return m->have_acts ? m->acts.slab : nullptr;
+}
+
+int masr_grad_norm(masr_model* m, void* stream) {
+    float* slab = slab_of(m);
+    if (!slab) { mk_set_error("masr_grad_norm", "run a batch first"); return -1; }
+    Prof p(m, MASR_PROF_OTHER, (hipStream_t)stream);
+    return mk_sumsq(m->G, m->nparams, slab, m->stats + 3, (hipStream_t)stream);
+}
+int masr_clip_sgd_step(masr_model* m, float* mom, float max_norm, float lr, float momentum, int nesterov, int first_step, void* stream) {
+    CK(masr_grad_norm(m, stream));
+    { Prof p(m, MASR_PROF_OTHER, (hipStream_t)stream);
+      CK(mk_clip_sgd(m->P, m->G, mom, m->nparams, m->stats + 3, max_norm, lr, momentum, nesterov, first_step, (hipStream_t)stream)); }
+    return masr_refresh(m, stream);
+}
+int masr_clip_grads(masr_model* m, float max_norm, void* stream) {
+    CK(masr_grad_norm(m, stream));
+    return mk_clip_scale(m->G, m->nparams, m->stats + 3, max_norm, (hipStream_t)stream);
+}
+int masr_clip_accumulate(masr_model* m, float* updates, float max_norm, void* stream) {
+    CK(masr_grad_norm(m, stream));
+    return mk_clip_axpy(updates, m->G, m->nparams, m->stats + 3, max_norm, (hipStream_t)stream);
+}
+int masr_adam_step(float* p, const float* g, float* ea, float* eas, int64_t n, float lr, float b1, float b2, float eps, int step, void* stream) {
+    return mk_adam(p, g, ea, eas, n, lr, b1, b2, eps, step, (hipStream_t)stream);
+}
+int masr_sgd_step(float* p, const float* g, float* mom, int64_t n, float lr, float momentum, int nesterov, int first_step, void* stream) {
+    return mk_clip_sgd(p, g, mom, n, nullptr, 0.f, lr, momentum, nesterov, first_step, (hipStream_t)stream);
+}
+int masr_scale(float* x, int64_t n, float a, void* stream) { return mk_scale(x, n, a, (hipStream_t)stream); }
+int masr_axpy(float* y, const float* x, int64_t n, float a, void* stream) { return mk_axpy(y, x, n, a, (hipStream_t)stream); }
+int masr_copy(float* dst, const float* src, int64_t n, void* stream) {
+    HIP_CHECK_RET(hipMemcpyAsync(dst, src, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+int masr_recog(masr_model* m, const float* xs, const int64_t* ilens, int B, int T, int32_t* out, void* stream) {
+    (void)m; (void)xs; (void)ilens; (void)B; (void)T; (void)out; (void)stream;
+    mk_set_error("masr_recog", "greedy decode is a SURVEY 8(f) 'next' row and is not built yet");
+    return -3;
+}
+
+int masr_gather_pad(const float* feat, const int64_t* row_start, const int32_t* lens, float* xs, int B, int Tmax, int D, void* stream) {
+    return mk_gather_pad(feat, (const long*)row_start, lens, xs, B, Tmax, D, (hipStream_t)stream);
+}
+int64_t masr_ctc_work_floats(int T, int B, int maxS) { return mk_ctc_work_floats(T, B, maxS); }
+int masr_ctc_loss(const float* logits, const int32_t* targets, const int32_t* tgt_off, const int32_t* in_len, const int32_t* tgt_len, int T,
+                  int B, int C, int blank, float* nll, float* loss, float* grad, float* work, int maxS, void* stream) {
+    return mk_ctc_loss(logits, targets, tgt_off, in_len, tgt_len, T, B, C, blank, nll, loss, grad, work, maxS, (hipStream_t)stream);
+}
+
+int masr_profile_enable(masr_model* m, int on) {
+    m->prof = on != 0;
+    for (int i = 0; i < MASR_PROF_N; ++i) m->prof_used[i] = 0;
+    return 0;
+}
+int masr_profile_read(masr_model* m, float* ms, int* launches) {
+    HIP_CHECK_RET(hipDeviceSynchronize());
+    for (int i = 0; i < MASR_PROF_N; ++i) {
+        float tot = 0.f;
+        for (int k = 0; k < m->prof_used[i]; ++k) {
+            float t = 0.f;
+            hipEventElapsedTime(&t, m->prof_ev[i][k].first, m->prof_ev[i][k].second);
+            tot += t;
+        }
+        ms[i] = tot; launches[i] = m->prof_used[i]; m->prof_used[i] = 0;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- standalone kernel entry points (parity tests)
+int masr_test_gemm(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int K, int reduction_major, const float* bias,
+                   int relu, float* C32, int64_t ldc, void* stream) {
+    GemmArgs g = gemm_args();
+    g.A = (const bf16*)A; g.lda = lda; g.B = (const bf16*)B; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.reduction_major = reduction_major;
+    g.bias = bias; g.relu = relu; g.C32 = C32; g.ldc = ldc;
+    return mk_gemm(g, (hipStream_t)stream);
+}
+int masr_test_conv3x3(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, uint16_t* out, int B, int H, int W, int CIN,
+                      int COUT, void* stream) {
+    ConvArgs a{}; a.in = (const bf16*)in; a.wk = (const bf16*)wk; a.bias = bias; a.relu = relu; a.out = (bf16*)out;
+    a.B = B; a.H = H; a.W = W; a.CIN = CIN; a.COUT = COUT;
+    return mk_conv3x3(a, (hipStream_t)stream);
+}
+int64_t masr_test_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT) { return mk_conv3x3_wgrad_slab_floats(B, H, W, CIN, COUT); }
+int masr_test_conv3x3_wgrad(const uint16_t* in, const uint16_t* dy, float* dw, float* slab, int64_t slab_floats, int B, int H, int W, int CIN,
+                            int COUT, void* stream) {
+    if (slab_floats < mk_conv3x3_wgrad_slab_floats(B, H, W, CIN, COUT)) { mk_set_error("masr_test_conv3x3_wgrad", "slab too small"); return -1; }
+    ConvWgradArgs a{}; a.in = (const bf16*)in; a.dy = (const bf16*)dy; a.dw = dw; a.slab = slab; a.B = B; a.H = H; a.W = W; a.CIN = CIN; a.COUT = COUT;
+    return mk_conv3x3_wgrad(a, (hipStream_t)stream);
+}
+int masr_test_attention(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* dout, uint16_t* o, uint16_t* dq, uint16_t* dk,
+                        uint16_t* dv, float* lse, float* delta, const int32_t* klens, int B, int H, int Tq, int Tk, int hd, int causal,
+                        void* stream) {
+    const long E = (long)H * hd;
+    AttnArgs a{};
+    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ldq = a.ldk = a.ldv = E; a.o = (bf16*)o; a.ldo = E; a.lse = lse;
+    a.klens = klens; a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.causal = causal;
+    CK(mk_attn_fwd(a, (hipStream_t)stream));
+    if (dout) {
+        a.dout = (const bf16*)dout; a.lddo = E; a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.lddq = a.lddk = a.lddv = E; a.delta = delta;
+        CK(mk_attn_bwd(a, (hipStream_t)stream));
+    }
+    return 0;
+}
+
+}  // extern "C"

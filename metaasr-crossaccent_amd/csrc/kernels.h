@@ -1,0 +1,115 @@
+// Internal launch API of the libmasr kernels (C++ side; the public C ABI is include/masr.h).
+// Every launcher is stream-ordered, allocates nothing, never synchronises (graph-capturable).
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------- GEMM (gemm.hip)
+struct GemmArgs {
+    // C[m][n] = epi( alpha * sum_k A(m,k) B(n,k) )
+    const bf16* A; long lda;      // reduction_major=0: A[m*lda + k]   =1: A[k*lda + m]
+    const bf16* B; long ldb;      // reduction_major=0: B[n*ldb + k]   =1: B[k*ldb + n]
+    int M, N, K;
+    int reduction_major;          // 1 = both operands have the reduction index as the slow index (wgrad)
+    float alpha;
+    const float* bias;            // [N] or null
+    const float* pe; int pe_period;   // add pe[(m % pe_period)*N + n]
+    int relu;
+    const bf16* mask; long ldmask; float mask_scale;   // v = mask>0 ? v*mask_scale : 0
+    float drop_p; uint32_t seed, site;                 // dropout on element index m*N+n
+    const float* residual; long ldres;                 // + residual[m*ldres + n]
+    int accumulate;               // C32 += v
+    float* C32; long ldc;         // fp32 output or null
+    bf16* C16; long ldc16;        // bf16 output or null
+};
+int mk_gemm(const GemmArgs& g, hipStream_t s);
+inline GemmArgs gemm_args() { GemmArgs g{}; g.alpha = 1.f; g.mask_scale = 1.f; return g; }
+
+// ---------------------------------------------------------------- conv front-end (conv.hip)
+// activations NHWC bf16: [B][H][W][C]; x input fp32 [B][H][W] (C=1)
+int mk_conv1_fwd(const float* x, const float* w /*[64][9]*/, const float* bias, bf16* out, int B, int H, int W, hipStream_t s);
+int mk_conv1_wgrad(const float* x, const bf16* dy, float* dw /*[64][9]*/, float* db, float* slab, int B, int H, int W, hipStream_t s);
+long mk_conv1_wgrad_slab_floats(int B, int H, int W);
+// implicit-GEMM 3x3 pad 1: out[p][co] = epi( sum_{tap,ci} in[p+off(tap)][ci] * wk[co][tap*CIN+ci] )
+struct ConvArgs {
+    const bf16* in; const bf16* wk; const float* bias; int relu;
+    const bf16* mask;             // optional ReLU mask source (same shape as out): out = mask>0 ? v : 0
+    bf16* out; int B, H, W, CIN, COUT;
+};
+int mk_conv3x3(const ConvArgs& a, hipStream_t s);
+// wgrad: dw[co][ci][3][3] (+ db[co]) from in (NHWC, CIN) and dy (NHWC, COUT)
+struct ConvWgradArgs { const bf16* in; const bf16* dy; float* dw; float* db; float* slab; int B, H, W, CIN, COUT; };
+int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s);
+long mk_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT);
+int mk_maxpool_fwd(const bf16* in, bf16* out, int B, int H, int W, int C, hipStream_t s);
+// din = (in is the first max of its window && in > 0) ? dout : 0   (ReLU backward fused)
+int mk_maxpool_relu_bwd(const bf16* in, const bf16* dout, bf16* din, int B, int H, int W, int C, hipStream_t s);
+
+// ---------------------------------------------------------------- attention (attention.hip)
+struct AttnArgs {
+    const bf16 *q, *k, *v; long ldq, ldk, ldv;   // row (b*T + t), head h at column h*hd
+    bf16* o; long ldo; float* lse;               // lse [B][H][Tq]
+    const bf16 *dout; long lddo;                 // backward
+    bf16 *dq, *dk, *dv; long lddq, lddk, lddv;
+    float* delta;                                // [B][H][Tq] scratch: rowsum(dO*O)
+    const int* klens;                            // [B] valid keys per batch or null (all Tk)
+    int B, H, Tq, Tk, hd, causal;
+    float drop_p; uint32_t seed, site;
+};
+int mk_attn_fwd(const AttnArgs& a, hipStream_t s);
+int mk_attn_bwd(const AttnArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- row ops (rowops.hip)
+int mk_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y32, bf16* y16,
+                       float* mean, float* rstd, int rows, int E, hipStream_t s);
+// dx32 = LN backward; dx16 = bf16 copy (optionally dropout-masked with (seed,site) for the branch GEMMs)
+int mk_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                       float* dx32, bf16* dx16, float drop_p, uint32_t seed, uint32_t site,
+                       float* dgamma, float* dbeta, float* slab, int rows, int E, hipStream_t s);
+long mk_layernorm_bwd_slab_floats(int rows, int E);
+int mk_embed_fwd(const int* tok, const float* table, const float* pe, float* y32, bf16* y16,
+                   int B, int L, int E, float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
+// dtable[v] (+)= sum over rows with tok==v of dy[row]  (deterministic: one block per vocab row)
+int mk_embed_bwd(const int* tok, const float* dy, float* dtable, int rows, int V, int E, int accumulate,
+                   float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
+// y16 = bf16(x32 * dropout_mask)
+int mk_cast_dropout(const float* x, bf16* y, long n, float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
+// column sums of x[rows][cols] (cols % 8 == 0, ld >= cols); only the first out_cols are written
+int mk_colsum(const bf16* x, long ld, float* out, float* slab, int rows, int cols, int out_cols, hipStream_t s);
+long mk_colsum_slab_floats(int rows, int cols);
+// label-smoothed CE: logits fp32 [rows][ld]; gold int [rows] (-1 ignored); writes dlogits bf16 [rows][ld]
+// stats[0] = loss (already / n_total), stats[1] = n_correct, stats[2] = n_total
+int mk_ls_ce(const float* logits, long ld, const int* gold, int rows, int C, float eps, float inv_ntotal,
+               bf16* dlogits, float* row_loss, int* row_correct, float* stats, hipStream_t s);
+
+// ---------------------------------------------------------------- flat optimiser ops (optim.hip)
+int mk_sumsq(const float* x, long n, float* slab, float* out_norm, hipStream_t s);       // out_norm[0] = sqrt(sum x^2)
+long mk_sumsq_slab_floats(long n);
+// coef = clip(max_norm / (norm+1e-6), <=1) (NaN propagates like torch.clamp)
+// norm == nullptr: plain SGD step without clipping
+int mk_clip_sgd(float* p, const float* g, float* mom, long n, const float* norm, float max_norm, float lr,
+                  float momentum, int nesterov, int first_step, hipStream_t s);     // NaN norm -> step skipped
+int mk_clip_scale(float* g, long n, const float* norm, float max_norm, hipStream_t s);    // g *= coef
+int mk_clip_axpy(float* acc, const float* g, long n, const float* norm, float max_norm, hipStream_t s); // acc += coef*g
+int mk_scale(float* x, long n, float a, hipStream_t s);
+int mk_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int t, hipStream_t s);
+int mk_axpy(float* y, const float* x, long n, float a, hipStream_t s);
+int mk_cast_bf16(const float* x, bf16* y, long n, hipStream_t s);
+int mk_transpose_cast_bf16(const float* x /*[R][C]*/, bf16* y /*[C][ldy]*/, int R, int C, long ldy, hipStream_t s);
+// conv weight shadows: w [CO][CI][3][3] fp32 -> wk [CO][tap*CI+ci] (fwd) and wd [CI][tap'*CO+co] = w[co][ci][8-tap'] (dgrad)
+int mk_conv_weight_shadows(const float* w, bf16* wk, bf16* wd, int CO, int CI, hipStream_t s);
+// vgg2enc weight [E][128*Dp] with reference feature index c*Dp+d  ->  bf16 [E][d*128+c] (NHWC order) and transpose
+int mk_vgg2enc_shadows(const float* w, bf16* wk, bf16* wt, int E, int C, int Dp, hipStream_t s);
+// inverse map for the weight gradient: g_nhwc [E][d*C+c] fp32 -> dw [E][c*Dp+d]
+int mk_vgg2enc_grad_unpermute(const float* g_nhwc, float* dw, int E, int C, int Dp, hipStream_t s);
+
+// ---------------------------------------------------------------- data (data.hip)
+// ragged gather + zero pad: rows of feat [sum T_i][D] -> xs [B][Tmax][D]
+int mk_gather_pad(const float* feat, const long* row_start, const int* lens, float* xs, int B, int Tmax, int D, hipStream_t s);
+
+// ---------------------------------------------------------------- CTC (ctc.hip)
+// logits fp32 [T][B][C] (pre-softmax); targets concatenated int [sum tl]; per-sample offsets tgt_off [B]
+// loss_out[0] = mean_b( nll_b / max(tl_b,1) ), zero_infinity; grad wrt logits [T][B][C]
+int mk_ctc_loss(const float* logits, const int* targets, const int* tgt_off, const int* in_len, const int* tgt_len,
+                  int T, int B, int C, int blank, float* nll /*[B]*/, float* loss_out, float* grad, float* work,
+                  int maxS, hipStream_t s);
+long mk_ctc_work_floats(int T, int B, int maxS);

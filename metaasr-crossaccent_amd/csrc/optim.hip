@@ -1,0 +1,216 @@
+// Flat ("multi-tensor") optimiser kernels over the single fp32 parameter / gradient buffers.
+// All parameters live in ONE contiguous buffer, so clip / SGD / Adam / accumulate / all-reduce
+// are each one streaming pass at HBM rate instead of ~113 small launches
+// (reference call sites: src/fo_meta_interface.py:148-149,180-221,223-250; optimizer.py:19-28).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int SS_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ slab) {
+    double acc = 0.0;
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            const float4 v = *reinterpret_cast<const float4*>(x + i);
+            acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+        } else {
+            for (long j = i; j < n; ++j) acc += (double)x[j] * x[j];
+        }
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) reinterpret_cast<double*>(slab)[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void sumsq_final(const float* __restrict__ slab, int nblocks, float* __restrict__ out) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) acc += reinterpret_cast<const double*>(slab)[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)sqrt(red[0]);
+}
+
+// torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to <= 1; NaN stays NaN
+__device__ __forceinline__ float clip_coef(float norm, float max_norm) {
+    const float c = max_norm / (norm + 1e-6f);
+    return (c != c) ? c : fminf(c, 1.0f);
+}
+
+// inner step of run_task (fo_meta_interface.py:242-248): clip, then (unless the norm is NaN)
+// torch.optim.SGD(momentum, nesterov, dampening 0): buf = first ? g : m*buf + g; p -= lr*(nesterov ? g + m*buf : buf)
+__global__ void clip_sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom, long n,
+                                const float* __restrict__ norm, float max_norm, float lr, float momentum, int nesterov,
+                                int first_step) {
+    float coef = 1.f;
+    if (norm) {
+        const float nv = norm[0];
+        if (nv != nv) return;                               // math.isnan(grad_norm) -> skip the step
+        coef = clip_coef(nv, max_norm);
+    }
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i] * coef;
+        float step = gi;
+        if (momentum != 0.f) {
+            const float b = first_step ? gi : momentum * mom[i] + gi;
+            mom[i] = b;
+            step = nesterov ? gi + momentum * b : b;
+        }
+        p[i] -= lr * step;
+    }
+}
+__global__ void clip_scale_kernel(float* __restrict__ g, long n, const float* __restrict__ norm, float max_norm) {
+    const float coef = clip_coef(norm[0], max_norm);
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] *= coef;
+}
+__global__ void clip_axpy_kernel(float* __restrict__ acc, const float* __restrict__ g, long n, const float* __restrict__ norm,
+                                 float max_norm) {
+    const float coef = clip_coef(norm[0], max_norm);
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc[i] += coef * g[i];
+}
+__global__ void scale_kernel(float* __restrict__ x, long n, float a) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] *= a;
+}
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, long n, float a) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] += a * x[i];
+}
+// torch.optim.Adam (no amsgrad, no weight decay): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= lr/(1-b1^t) * m/denom
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n, float step_size, float b1, float b2, float eps, float inv_sqrt_bc2) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);        // lerp, as torch
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+__global__ void cast_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = (bf16)x[i];
+}
+// y[c][r] = bf16(x[r][c]) via a 32x32 LDS tile
+__global__ void transpose_cast_kernel(const float* __restrict__ x, bf16* __restrict__ y, int R, int C, long ldy) {
+    __shared__ float t[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 256 threads: 8 rows per pass
+    for (int k = ty; k < 32; k += 8)
+        t[k][tx] = (r0 + k < R && c0 + tx < C) ? x[(long)(r0 + k) * C + c0 + tx] : 0.f;
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (c0 + k < C && r0 + tx < R) y[(long)(c0 + k) * ldy + r0 + tx] = (bf16)t[tx][k];
+}
+__global__ void conv_shadow_kernel(const float* __restrict__ w, bf16* __restrict__ wk, bf16* __restrict__ wd, int CO, int CI) {
+    const int n = CO * CI * 9;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int tap = i % 9, ci = (i / 9) % CI, co = i / (9 * CI);
+    const bf16 v = (bf16)w[i];
+    wk[(long)co * 9 * CI + tap * CI + ci] = v;                        // forward: out[co] += in[p+off(tap)][ci] * w
+    if (wd) wd[(long)ci * 9 * CO + (8 - tap) * CO + co] = v;          // dgrad: din[ci] += dy[p-off(tap)][co] * w
+}
+__global__ void vgg2enc_shadow_kernel(const float* __restrict__ w, bf16* __restrict__ wk, bf16* __restrict__ wt, int E, int C, int Dp) {
+    const int F = C * Dp;
+    const long n = (long)E * F;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int f = (int)(i % F), e = (int)(i / F);
+    const int c = f / Dp, d = f % Dp;                                   // reference feature index c*Dp + d
+    const int fn = d * C + c;                                           // NHWC feature index
+    const bf16 v = (bf16)w[i];
+    wk[(long)e * F + fn] = v;
+    wt[(long)fn * E + e] = v;
+}
+__global__ void vgg2enc_unpermute_kernel(const float* __restrict__ g, float* __restrict__ dw, int E, int C, int Dp) {
+    const int F = C * Dp;
+    const long n = (long)E * F;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int f = (int)(i % F), e = (int)(i / F);
+    const int c = f / Dp, d = f % Dp;
+    dw[i] = g[(long)e * F + d * C + c];
+}
+
+inline unsigned flat_blocks(long n) {
+    long b = (n + 255) / 256;
+    return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : (mk_set_error(__func__, "launch failed"), -1))
+
+long mk_sumsq_slab_floats(long) { return SS_BLOCKS * 2; }
+int mk_sumsq(const float* x, long n, float* slab, float* out_norm, hipStream_t s) {
+    hipLaunchKernelGGL(sumsq_kernel, dim3(SS_BLOCKS), dim3(256), 0, s, x, n, slab);
+    hipLaunchKernelGGL(sumsq_final, dim3(1), dim3(256), 0, s, slab, SS_BLOCKS, out_norm);
+    return LAUNCH_OK();
+}
+int mk_clip_sgd(float* p, const float* g, float* mom, long n, const float* norm, float max_norm, float lr, float momentum,
+                  int nesterov, int first_step, hipStream_t s) {
+    hipLaunchKernelGGL(clip_sgd_kernel, dim3(flat_blocks(n)), dim3(256), 0, s, p, g, mom, n, norm, max_norm, lr, momentum, nesterov, first_step);
+    return LAUNCH_OK();
+}
+int mk_clip_scale(float* g, long n, const float* norm, float max_norm, hipStream_t s) {
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(flat_blocks(n)), dim3(256), 0, s, g, n, norm, max_norm);
+    return LAUNCH_OK();
+}
+int mk_clip_axpy(float* acc, const float* g, long n, const float* norm, float max_norm, hipStream_t s) {
+    hipLaunchKernelGGL(clip_axpy_kernel, dim3(flat_blocks(n)), dim3(256), 0, s, acc, g, n, norm, max_norm);
+    return LAUNCH_OK();
+}
+int mk_scale(float* x, long n, float a, hipStream_t s) {
+    hipLaunchKernelGGL(scale_kernel, dim3(flat_blocks(n)), dim3(256), 0, s, x, n, a);
+    return LAUNCH_OK();
+}
+int mk_axpy(float* y, const float* x, long n, float a, hipStream_t s) {
+    hipLaunchKernelGGL(axpy_kernel, dim3(flat_blocks(n)), dim3(256), 0, s, y, x, n, a);
+    return LAUNCH_OK();
+}
+int mk_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int t, hipStream_t s) {
+    const double bc1 = 1.0 - pow((double)b1, t), bc2 = 1.0 - pow((double)b2, t);
+    hipLaunchKernelGGL(adam_kernel, dim3(flat_blocks(n)), dim3(256), 0, s, p, g, m, v, n, (float)(lr / bc1), b1, b2, eps,
+                       (float)(1.0 / sqrt(bc2)));
+    return LAUNCH_OK();
+}
+int mk_cast_bf16(const float* x, bf16* y, long n, hipStream_t s) {
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(flat_blocks(n)), dim3(256), 0, s, x, y, n);
+    return LAUNCH_OK();
+}
+int mk_transpose_cast_bf16(const float* x, bf16* y, int R, int C, long ldy, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_cast_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, s, x, y, R, C, ldy);
+    return LAUNCH_OK();
+}
+int mk_conv_weight_shadows(const float* w, bf16* wk, bf16* wd, int CO, int CI, hipStream_t s) {
+    const int n = CO * CI * 9;
+    hipLaunchKernelGGL(conv_shadow_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, wk, wd, CO, CI);
+    return LAUNCH_OK();
+}
+int mk_vgg2enc_shadows(const float* w, bf16* wk, bf16* wt, int E, int C, int Dp, hipStream_t s) {
+    const long n = (long)E * C * Dp;
+    hipLaunchKernelGGL(vgg2enc_shadow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, wk, wt, E, C, Dp);
+    return LAUNCH_OK();
+}
+int mk_vgg2enc_grad_unpermute(const float* g, float* dw, int E, int C, int Dp, hipStream_t s) {
+    const long n = (long)E * C * Dp;
+    hipLaunchKernelGGL(vgg2enc_unpermute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, dw, E, C, Dp);
+    return LAUNCH_OK();
+}

@@ -1,0 +1,205 @@
+"""MasrEngine: owner of the flat HBM buffers and thin driver of the libmasr C ABI.
+
+PyTorch is used only as plumbing here: device memory (`torch.empty`), the current HIP stream and
+(in parallel.py) `torch.distributed`.  All arithmetic of the hot path runs in libmasr's HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _cabi
+from ._cabi import MasrConfig, check, lib
+
+MASR_TRAIN, MASR_EVAL = 1, 0
+
+
+def sinusoid_pe(max_len: int, E: int) -> torch.Tensor:
+    """PositionalEncoding buffer, formula of mono_transformer_torch.py:21-28 -> [max_len, 1, E]."""
+    pe = torch.zeros(max_len, E)
+    position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, E, 2).float() * (-math.log(10000.0) / E))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe.unsqueeze(1)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class MasrEngine:
+    """One model instance on one GPU: flat fp32 params / grads + activation workspace."""
+
+    def __init__(self, model_para: dict, odim: int, label_smoothing: float = 0.0, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("MasrEngine needs a HIP device (MI355X); there is no CPU path")
+        self.device = torch.device(device)
+        self.model_para = model_para
+        self.odim = odim
+        self.cfg = MasrConfig(
+            idim=model_para["idim"], odim=odim, d_model=model_para["d_model"], nheads=model_para["nheads"],
+            d_inner=model_para["d_inner"], enc_layers=model_para["encoder"]["nlayers"],
+            dec_layers=model_para["decoder"]["nlayers"], tie_weights=int(model_para.get("tgt_share_weight", 0) != 0),
+            dropout=float(model_para.get("dropout", 0.0)), pos_dropout=float(model_para.get("pos_dropout", 0.0)),
+            label_smoothing=float(label_smoothing))
+        self._l = lib()
+        self.h = self._l.masr_create(C.byref(self.cfg))
+        if not self.h:
+            raise _cabi.MasrError("masr_create: " + self._l.masr_last_error().decode())
+        self.numel = int(self._l.masr_param_numel(self.h))
+        self.tied = bool(self.cfg.tie_weights)
+        with torch.cuda.device(self.device):
+            self.params = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+            self.grads = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+            self.pe = sinusoid_pe(3000, self.cfg.d_model).to(self.device).contiguous()
+        self.table = OrderedDict()           # name -> (offset, shape)
+        name = C.create_string_buffer(256)
+        shape = (C.c_int64 * 4)()
+        ndim, off = C.c_int(), C.c_int64()
+        for i in range(self._l.masr_param_count(self.h)):
+            check(self._l.masr_param_info(self.h, i, name, 256, shape, C.byref(ndim), C.byref(off)), "masr_param_info")
+            self.table[name.value.decode()] = (int(off.value), tuple(int(shape[k]) for k in range(ndim.value)))
+        self.ws = None
+        self._ws_key = (0, 0, 0)
+        self._ensure_ws(1, 64, 8)
+        self._dirty = True
+
+    # ------------------------------------------------------------------ buffers
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self._l.masr_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _ensure_ws(self, B, T, L):
+        need = int(self._l.masr_workspace_bytes(self.h, B, T, L))
+        if self.ws is None or self.ws.numel() < need:
+            torch.cuda.synchronize(self.device)
+            self.ws = None
+            self.ws = torch.empty(int(need * 1.05) + 4096, dtype=torch.uint8, device=self.device)
+            check(self._l.masr_bind(self.h, _ptr(self.params), _ptr(self.grads), _ptr(self.pe), _ptr(self.ws), self.ws.numel()), "masr_bind")
+            self._dirty = True
+
+    def view(self, name, flat=None):
+        off, shape = self.table[name]
+        flat = self.params if flat is None else flat
+        return flat[off:off + int(np.prod(shape))].view(shape)
+
+    def state_dict(self, flat=None, clone=True) -> "OrderedDict[str, torch.Tensor]":
+        """Reference key set and order, incl. pos_encoder.pe and the tied alias."""
+        sd = OrderedDict()
+        for n in self.table:
+            v = self.view(n, flat)
+            sd[n] = v.clone() if clone else v
+            if n == "vgg2enc.bias":
+                sd["pos_encoder.pe"] = self.pe.clone() if clone else self.pe
+            if n == "char_trans.bias" and self.tied:
+                sd["pre_embed.weight"] = sd["char_trans.weight"]
+        return sd
+
+    def load_state_dict(self, sd, flat=None):
+        dst = self.params if flat is None else flat
+        for n, (off, shape) in self.table.items():
+            t = sd[n]
+            dst[off:off + t.numel()].copy_(t.detach().reshape(-1).to(torch.float32))
+        if flat is None:
+            self._dirty = True
+
+    def mark_dirty(self):
+        """call after writing self.params outside the C ABI (copy_, all-reduce, ...)"""
+        self._dirty = True
+
+    def refresh(self):
+        if self._dirty:
+            check(self._l.masr_refresh(self.h, self.stream()), "masr_refresh")
+            self._dirty = False
+
+    def set_seed(self, seed: int):
+        self._l.masr_set_seed(self.h, C.c_uint64(seed & (2 ** 64 - 1)))
+
+    # ------------------------------------------------------------------ the operator
+    def run_batch(self, xs: torch.Tensor, ilens, ys, olens, train: bool):
+        """forward + loss (+ backward).  xs: device fp32 [B,T,idim] (host tensors are uploaded);
+        ilens/olens: int64 host tensors; ys: list of int64 host tensors."""
+        if xs.device != self.device:
+            xs = xs.to(self.device, non_blocking=True)
+        xs = xs.contiguous().float()
+        B, T, D = xs.shape
+        assert D == self.cfg.idim, f"idim mismatch {D} vs {self.cfg.idim}"
+        il = torch.as_tensor(ilens, dtype=torch.int64).cpu().contiguous()
+        ol = torch.as_tensor(olens, dtype=torch.int64).cpu().contiguous()
+        yf = torch.cat([torch.as_tensor(y, dtype=torch.int64).reshape(-1) for y in ys]).cpu().contiguous()
+        L = int(ol.max()) + 1
+        self._ensure_ws(B, T, L)
+        self.refresh()
+        check(self._l.masr_run_batch(self.h, _ptr(xs), C.c_void_p(il.data_ptr()), C.c_void_p(yf.data_ptr()),
+                                     C.c_void_p(ol.data_ptr()), B, T, MASR_TRAIN if train else MASR_EVAL, self.stream()),
+              "masr_run_batch")
+        self._last_x = xs          # keep the input alive until the stream has consumed it
+
+    def read_stats(self):
+        out = (C.c_float * 4)()
+        check(self._l.masr_read_stats(self.h, out, self.stream()), "masr_read_stats")
+        return {"loss": float(out[0]), "n_correct": float(out[1]), "n_total": float(out[2]), "grad_norm": float(out[3])}
+
+    def last_logits(self):
+        """[B, L, odim] fp32 view of the last forward's logits and gold [B, L] (int32, -1 = pad)."""
+        lp, gp = C.c_void_p(), C.c_void_p()
+        rows, L, ld = C.c_int(), C.c_int(), C.c_int()
+        check(self._l.masr_last_logits(self.h, C.byref(lp), C.byref(gp), C.byref(rows), C.byref(L), C.byref(ld)), "masr_last_logits")
+        ws_base = self.ws.data_ptr()
+        lo = (lp.value - ws_base)
+        logits = self.ws[lo:lo + rows.value * ld.value * 4].view(torch.float32).view(rows.value // L.value, L.value, ld.value)[..., :self.odim]
+        go = (gp.value - ws_base)
+        gold = self.ws[go:go + rows.value * 4].view(torch.int32).view(rows.value // L.value, L.value)
+        return logits, gold
+
+    # ------------------------------------------------------------------ optimiser passes
+    def clip_sgd_step(self, momentum_buf, max_norm, lr, momentum, nesterov, first_step):
+        check(self._l.masr_clip_sgd_step(self.h, _ptr(momentum_buf), max_norm, lr, momentum, int(nesterov), int(first_step), self.stream()),
+              "masr_clip_sgd_step")
+        self._dirty = False            # the C call refreshes the shadows itself
+
+    def clip_grads(self, max_norm):
+        check(self._l.masr_clip_grads(self.h, max_norm, self.stream()), "masr_clip_grads")
+
+    def clip_accumulate(self, updates, max_norm):
+        check(self._l.masr_clip_accumulate(self.h, _ptr(updates), max_norm, self.stream()), "masr_clip_accumulate")
+
+    def grad_norm(self):
+        check(self._l.masr_grad_norm(self.h, self.stream()), "masr_grad_norm")
+
+    def adam_step(self, params, grads, m, v, lr, b1, b2, eps, step):
+        check(self._l.masr_adam_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, b1, b2, eps, step, self.stream()), "masr_adam_step")
+
+    def sgd_step(self, params, grads, mom, lr, momentum, nesterov, first_step):
+        check(self._l.masr_sgd_step(_ptr(params), _ptr(grads), _ptr(mom), params.numel(), lr, momentum, int(nesterov), int(first_step), self.stream()), "masr_sgd_step")
+
+    def scale(self, x, a):
+        check(self._l.masr_scale(_ptr(x), x.numel(), a, self.stream()), "masr_scale")
+
+    def axpy(self, y, x, a):
+        check(self._l.masr_axpy(_ptr(y), _ptr(x), x.numel(), a, self.stream()), "masr_axpy")
+
+    def copy(self, dst, src):
+        check(self._l.masr_copy(_ptr(dst), _ptr(src), src.numel(), self.stream()), "masr_copy")
+
+    # ------------------------------------------------------------------ profiling
+    def profile(self, on: bool):
+        check(self._l.masr_profile_enable(self.h, int(on)), "masr_profile_enable")
+
+    def profile_read(self):
+        ms = (C.c_float * 6)()
+        n = (C.c_int * 6)()
+        check(self._l.masr_profile_read(self.h, ms, n), "masr_profile_read")
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(_cabi.PROF_NAMES)}

@@ -1,0 +1,140 @@
+"""Per-kernel parity through the C ABI (GPU).  References are plain torch fp32 ops on the SAME
+bf16-rounded operands, so only the fp32 accumulation order differs (tight tolerances)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import masr_amd  # noqa: E402
+from masr_amd import _cabi  # noqa: E402
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def bits(t):
+    """bf16 tensor -> its storage viewed as int16 (what the C ABI takes)"""
+    return t.view(torch.int16)
+
+
+@pytest.fixture(scope="module")
+def L():
+    return _cabi.lib()
+
+
+def S():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 367, 512), (4000, 512, 2560), (37, 24, 8), (513, 2048, 512)])
+def test_gemm_nt(L, M, N, K):
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    B = torch.randn(N, K, device="cuda", generator=g).bfloat16()
+    bias = torch.randn(N, device="cuda", generator=g)
+    Cc = torch.full((M, N + 3), 7.0, device="cuda")
+    _cabi.check(L.masr_test_gemm(P(A), K, P(B), K, M, N, K, 0, P(bias), 1, P(Cc), N + 3, S()))
+    ref = torch.relu(A.float() @ B.float().t() + bias)
+    torch.testing.assert_close(Cc[:, :N], ref, rtol=2e-4, atol=2e-3)
+    assert torch.all(Cc[:, N:] == 7.0)          # no write outside the N columns
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (128, 256, 1000), (367, 512, 500), (1536, 512, 4000), (8, 16, 5)])
+def test_gemm_reduction_major(L, M, N, K):
+    """wgrad form: C[m][n] = sum_k A[k][m] B[k][n] (transposing LDS reads)."""
+    g = torch.Generator(device="cuda").manual_seed(M * 3 + N + K)
+    lda, ldb = (M + 7) // 8 * 8 + 8, (N + 7) // 8 * 8
+    A = torch.zeros(K, lda, device="cuda").bfloat16()
+    A[:, :M] = torch.randn(K, M, device="cuda", generator=g).bfloat16()
+    B = torch.zeros(K, ldb, device="cuda").bfloat16()
+    B[:, :N] = torch.randn(K, N, device="cuda", generator=g).bfloat16()
+    Cc = torch.zeros(M, N, device="cuda")
+    _cabi.check(L.masr_test_gemm(P(A), lda, P(B), ldb, M, N, K, 1, None, 0, P(Cc), N, S()))
+    ref = A[:, :M].float().t() @ B[:, :N].float()
+    torch.testing.assert_close(Cc, ref, rtol=2e-4, atol=2e-3 * (K ** 0.5) / 8)
+
+
+def test_gemm_exact_integers(L):
+    """A = I check with an asymmetric B (catches transposed fragment maps exactly)."""
+    M = N = K = 64
+    A = torch.eye(M, device="cuda").bfloat16()
+    B = (torch.arange(N * K, device="cuda").reshape(N, K) % 61).float().bfloat16()
+    Cc = torch.zeros(M, N, device="cuda")
+    _cabi.check(L.masr_test_gemm(P(A), K, P(B), K, M, N, K, 0, None, 0, P(Cc), N, S()))
+    assert torch.equal(Cc, B.float().t())
+    Cc.zero_()
+    _cabi.check(L.masr_test_gemm(P(A), M, P(B.t().contiguous()), N, M, N, K, 1, None, 0, P(Cc), N, S()))
+    assert torch.equal(Cc, B.float().t())       # A^T = I, B given as [k][n]
+
+
+@pytest.mark.parametrize("B_,H,W,CIN,COUT", [(2, 10, 9, 64, 64), (1, 33, 21, 64, 128), (3, 16, 20, 128, 128), (2, 7, 5, 128, 64)])
+def test_conv3x3(L, B_, H, W, CIN, COUT):
+    g = torch.Generator(device="cuda").manual_seed(CIN + COUT + H)
+    x = torch.randn(B_, H, W, CIN, device="cuda", generator=g).bfloat16()           # NHWC
+    w = (torch.randn(COUT, CIN, 3, 3, device="cuda", generator=g) * 0.05).bfloat16()
+    bias = torch.randn(COUT, device="cuda", generator=g)
+    wk = w.permute(0, 2, 3, 1).reshape(COUT, 9 * CIN).contiguous()                   # [co][tap*CIN+ci]
+    out = torch.zeros(B_, H, W, COUT, device="cuda").bfloat16()
+    _cabi.check(L.masr_test_conv3x3(P(x), P(wk), P(bias), 1, P(out), B_, H, W, CIN, COUT, S()))
+    ref = torch.relu(torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias, padding=1)).permute(0, 2, 3, 1)
+    torch.testing.assert_close(out.float(), ref, rtol=1e-2, atol=1e-2)              # bf16 output rounding
+
+
+@pytest.mark.parametrize("B_,H,W,CIN,COUT", [(2, 10, 9, 64, 64), (1, 33, 21, 64, 128), (2, 40, 20, 128, 128)])
+def test_conv3x3_wgrad(L, B_, H, W, CIN, COUT):
+    g = torch.Generator(device="cuda").manual_seed(CIN + COUT + H + 1)
+    x = torch.randn(B_, H, W, CIN, device="cuda", generator=g).bfloat16()
+    dy = torch.randn(B_, H, W, COUT, device="cuda", generator=g).bfloat16()
+    n = int(L.masr_test_conv3x3_wgrad_slab_floats(B_, H, W, CIN, COUT))
+    slab = torch.zeros(n, device="cuda")
+    dw = torch.zeros(COUT, CIN, 3, 3, device="cuda")
+    _cabi.check(L.masr_test_conv3x3_wgrad(P(x), P(dy), P(dw), P(slab), n, B_, H, W, CIN, COUT, S()))
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(False)
+    wref = torch.zeros(COUT, CIN, 3, 3, device="cuda", requires_grad=True)
+    y = torch.nn.functional.conv2d(xr, wref, None, padding=1)
+    y.backward(dy.float().permute(0, 3, 1, 2))
+    torch.testing.assert_close(dw, wref.grad, rtol=1e-3, atol=2e-2)
+
+
+def _attn_ref(q, k, v, klens, causal, dout):
+    B_, Tq, H, hd = q.shape
+    Tk = k.shape[1]
+    q, k, v = (t.float().permute(0, 2, 1, 3).requires_grad_(True) for t in (q, k, v))
+    s = q @ k.transpose(-1, -2) / hd ** 0.5
+    if causal:
+        s = s + torch.triu(torch.full((Tq, Tk), float("-inf"), device=q.device), 1)
+    if klens is not None:
+        pad = torch.arange(Tk, device=q.device)[None, :] >= klens[:, None]
+        s = s.masked_fill(pad[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, -1)
+    o = p @ v
+    o.backward(dout.float().permute(0, 2, 1, 3))
+    return o.permute(0, 2, 1, 3), q.grad.permute(0, 2, 1, 3), k.grad.permute(0, 2, 1, 3), v.grad.permute(0, 2, 1, 3)
+
+
+@pytest.mark.parametrize("B_,H,Tq,Tk,hd,causal,masked", [
+    (2, 2, 31, 31, 64, 1, False), (3, 4, 250, 250, 64, 0, True), (2, 8, 31, 250, 64, 0, True),
+    (2, 4, 12, 16, 16, 0, True), (2, 4, 10, 10, 16, 1, False), (1, 2, 70, 130, 32, 0, True), (2, 2, 100, 100, 32, 1, False)])
+def test_attention(L, B_, H, Tq, Tk, hd, causal, masked):
+    g = torch.Generator(device="cuda").manual_seed(Tq * 7 + Tk + hd)
+    q = torch.randn(B_, Tq, H, hd, device="cuda", generator=g).bfloat16()
+    k = torch.randn(B_, Tk, H, hd, device="cuda", generator=g).bfloat16()
+    v = torch.randn(B_, Tk, H, hd, device="cuda", generator=g).bfloat16()
+    dout = torch.randn(B_, Tq, H, hd, device="cuda", generator=g).bfloat16()
+    klens = torch.randint(max(1, Tk // 2), Tk + 1, (B_,), device="cuda", generator=g).int() if masked else None
+    o = torch.zeros_like(q); dq = torch.zeros_like(q); dk = torch.zeros_like(k); dv = torch.zeros_like(v)
+    lse = torch.zeros(B_, H, Tq, device="cuda"); delta = torch.zeros(B_, H, Tq, device="cuda")
+    _cabi.check(L.masr_test_attention(P(q), P(k), P(v), P(dout), P(o), P(dq), P(dk), P(dv), P(lse), P(delta),
+                                      P(klens) if masked else None, B_, H, Tq, Tk, hd, causal, S()))
+    ro, rdq, rdk, rdv = _attn_ref(q, k, v, klens.long() if masked else None, causal, dout)
+    torch.testing.assert_close(o.float(), ro, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(dq.float(), rdq, rtol=3e-2, atol=4e-2)
+    torch.testing.assert_close(dk.float(), rdk, rtol=3e-2, atol=4e-2)
+    torch.testing.assert_close(dv.float(), rdv, rtol=3e-2, atol=4e-2)
+    if masked:                                   # masked keys receive exactly zero gradient
+        for b in range(B_):
+            assert torch.all(dk[b, int(klens[b]):] == 0) and torch.all(dv[b, int(klens[b]):] == 0)
