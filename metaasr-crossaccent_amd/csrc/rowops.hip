@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void ls_ce_reduce(const float* __restrict__ ro
         if (threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { stats[0] = sl[0] * inv_ntotal; stats[1] = (float)sc[0]; stats[2] = 1.f / inv_ntotal; }
+    if (threadIdx.x == 0) { stats[0] = sl[0] * inv_ntotal; stats[1] = (float)sc[0]; stats[2] = rintf(1.f / inv_ntotal); }
 }
 
 }  // namespace

@@ -133,21 +133,47 @@ def generate_square_subsequent_mask(sz: int) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- #
+# optional bf16 emulation (checker aid, NOT reference behaviour)
+# --------------------------------------------------------------------------- #
+# The HIP engine feeds bf16 operands to the MFMA units (fp32 accumulate, fp32 residual stream /
+# LayerNorm / softmax / loss).  With QUANT[0] = True the oracle rounds the same tensors to bf16
+# (straight-through gradient), so that ReLU / max-pool decisions coincide and the comparison is
+# tight enough (~1e-2 -> ~1e-3) to expose real kernel bugs.  Default False = the reference's fp32.
+QUANT = [False]
+
+
+def _q(x):
+    if not QUANT[0]:
+        return x
+    return x + (x.detach().bfloat16().float() - x.detach())
+
+
+class bf16_emulation:
+    def __enter__(self):
+        self.prev = QUANT[0]
+        QUANT[0] = True
+        return self
+
+    def __exit__(self, *a):
+        QUANT[0] = self.prev
+
+
+# --------------------------------------------------------------------------- #
 # model forward (mono_transformer_torch.py)
 # --------------------------------------------------------------------------- #
 def extract_feat(p, xs_pad, ilens):
     """VGG front-end + Linear (mono_transformer_torch.py:113-122; Appendix A.1-2)."""
     x = xs_pad.unsqueeze(1)                                        # [B,1,T,D]
-    x = F.relu(F.conv2d(x, p["feat_extractor.0.weight"], p["feat_extractor.0.bias"], padding=1))
-    x = F.relu(F.conv2d(x, p["feat_extractor.2.weight"], p["feat_extractor.2.bias"], padding=1))
+    x = _q(F.relu(F.conv2d(x, p["feat_extractor.0.weight"], p["feat_extractor.0.bias"], padding=1)))
+    x = _q(F.relu(F.conv2d(x, _q(p["feat_extractor.2.weight"]), p["feat_extractor.2.bias"], padding=1)))
     x = F.max_pool2d(x, 2, stride=2)                                # floor
-    x = F.relu(F.conv2d(x, p["feat_extractor.5.weight"], p["feat_extractor.5.bias"], padding=1))
-    x = F.relu(F.conv2d(x, p["feat_extractor.7.weight"], p["feat_extractor.7.bias"], padding=1))
+    x = _q(F.relu(F.conv2d(x, _q(p["feat_extractor.5.weight"]), p["feat_extractor.5.bias"], padding=1)))
+    x = _q(F.relu(F.conv2d(x, _q(p["feat_extractor.7.weight"]), p["feat_extractor.7.bias"], padding=1)))
     x = F.max_pool2d(x, 2, stride=2)                                # [B,128,T',D']
     enc_lens = torch.floor(ilens.to(torch.float32) / 4).to(torch.int64)   # :117
     B, C, Tp, Dp = x.shape
     x = x.transpose(1, 2).contiguous().view(B, Tp, C * Dp)          # feature = c*D'+d (:118-119)
-    x = x @ p["vgg2enc.weight"].t() + p["vgg2enc.bias"]
+    x = x @ _q(p["vgg2enc.weight"]).t() + p["vgg2enc.bias"]
     return x, enc_lens
 
 
@@ -160,10 +186,11 @@ def _mha(p, prefix, q_in, kv_in, nheads, attn_mask=None, key_padding_mask=None):
     Tq, B, E = q_in.shape
     Tk = kv_in.shape[0]
     hd = E // nheads
-    W, b = p[f"{prefix}.in_proj_weight"], p[f"{prefix}.in_proj_bias"]
-    q = q_in @ W[:E].t() + b[:E]
-    k = kv_in @ W[E:2 * E].t() + b[E:2 * E]
-    v = kv_in @ W[2 * E:].t() + b[2 * E:]
+    W, b = _q(p[f"{prefix}.in_proj_weight"]), p[f"{prefix}.in_proj_bias"]
+    q_in, kv_in = _q(q_in), _q(kv_in)
+    q = _q(q_in @ W[:E].t() + b[:E])
+    k = _q(kv_in @ W[E:2 * E].t() + b[E:2 * E])
+    v = _q(kv_in @ W[2 * E:].t() + b[2 * E:])
     q = q.reshape(Tq, B, nheads, hd).permute(1, 2, 0, 3)            # [B,H,Tq,hd]
     k = k.reshape(Tk, B, nheads, hd).permute(1, 2, 0, 3)
     v = v.reshape(Tk, B, nheads, hd).permute(1, 2, 0, 3)
@@ -173,8 +200,12 @@ def _mha(p, prefix, q_in, kv_in, nheads, attn_mask=None, key_padding_mask=None):
     if key_padding_mask is not None:
         s = s.masked_fill(key_padding_mask.view(B, 1, 1, Tk), float("-inf"))
     a = torch.softmax(s, dim=-1)
-    o = (a @ v).permute(2, 0, 1, 3).reshape(Tq, B, E)
-    return o @ p[f"{prefix}.out_proj.weight"].t() + p[f"{prefix}.out_proj.bias"]
+    if QUANT[0]:        # the engine normalises after P.V: o = (bf16(exp(s-m)) @ v) / l
+        mx = s.detach().amax(dim=-1, keepdim=True)
+        l = torch.exp(s - mx).sum(-1, keepdim=True)
+        a = _q(a * l) / l
+    o = _q((a @ v).permute(2, 0, 1, 3).reshape(Tq, B, E))
+    return o @ _q(p[f"{prefix}.out_proj.weight"]).t() + p[f"{prefix}.out_proj.bias"]
 
 
 def _ln(p, prefix, x):
@@ -182,8 +213,8 @@ def _ln(p, prefix, x):
 
 
 def _ffn(p, prefix, x):
-    h = F.relu(x @ p[f"{prefix}.linear1.weight"].t() + p[f"{prefix}.linear1.bias"])
-    return h @ p[f"{prefix}.linear2.weight"].t() + p[f"{prefix}.linear2.bias"]
+    h = _q(F.relu(_q(x) @ _q(p[f"{prefix}.linear1.weight"]).t() + p[f"{prefix}.linear1.bias"]))
+    return h @ _q(p[f"{prefix}.linear2.weight"]).t() + p[f"{prefix}.linear2.bias"]
 
 
 def encoder_forward(p, cfg, x, pad_mask):
@@ -241,7 +272,7 @@ def model_forward(p, cfg, xs_pad, ilens, ys, olens):
     memory = encoder_forward(p, cfg, enc, pad_mask)
     out = decoder_forward(p, cfg, ys_in, memory, causal, pad_mask)
     out = out.transpose(0, 1)                                        # [B,L,E]
-    logit = out @ p["char_trans.weight"].t() + p["char_trans.bias"]
+    logit = _q(out) @ _q(p["char_trans.weight"]).t() + p["char_trans.bias"]
     return logit, ys_out
 
 

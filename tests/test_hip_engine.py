@@ -51,18 +51,32 @@ def test_run_batch_vs_oracle_and_golden(sd, G, cname, eps):
     lg, gd = eng.last_logits()
     np.testing.assert_array_equal(gd.cpu().numpy(), G[f"{key}/gold"])
     assert rel_l2(lg.cpu(), torch.from_numpy(G[f"{key}/logit"])) < 2e-2
-    # gradients: direction and size per tensor (bf16 operands -> ~1e-2 relative)
+    # gradients vs the fp32 oracle: bf16 operands flip ~0.3 % of the ReLU / max-pool decisions, which alone moves
+    # gradients by 3-10 % (the oracle shows the same drift when IT is run with bf16 emulation), so this check is loose
     g_all = eng.state_dict(flat=eng.grads)
-    worst = 0.0
-    for n in ref_cpu.grad_param_names(p, TINY):
-        a, b = g_all[n].cpu(), grads[n]
+    names = ref_cpu.grad_param_names(p, TINY)
+
+    def cmp(a, b, n):
+        a, b = a.cpu(), b
         if n.endswith("in_proj_bias"):
             E = TINY["d_model"]                              # key-bias third has zero true gradient
             a = torch.cat([a[:E], a[2 * E:]]); b = torch.cat([b[:E], b[2 * E:]])
-        r = rel_l2(a, b)
+        return rel_l2(a, b)
+    worst32 = max(cmp(g_all[n], grads[n], n) for n in names)
+    assert worst32 < 0.15, worst32
+    # ... and tight against the oracle with the same bf16 rounding points (same ReLU / pool decisions)
+    with ref_cpu.bf16_emulation():
+        pq = ref_cpu.leafify(sd, TINY)
+        infoq, gradsq, logitq, _ = ref_cpu.run_batch_train(pq, TINY, (xs, il, ys, ol.clone()), eps)
+    assert abs(st["loss"] - infoq["loss"]) <= 2e-4 * infoq["loss"], (st["loss"], infoq["loss"])
+    assert rel_l2(lg.cpu(), logitq) < 4e-3
+    worst = 0.0
+    for n in names:
+        r = cmp(g_all[n], gradsq[n], n)
         worst = max(worst, r)
-        assert r < 6e-2, (n, r)
-    print(f"{key}: loss {st['loss']:.6f} vs {ref_loss:.6f}; worst grad rel-l2 {worst:.4f}")
+        # conv gradients additionally pass through five bf16-rounded dY tensors and sum ~10^4 near-cancelling terms
+        assert r < (6e-2 if n.startswith("feat_extractor") else 4e-2), (n, r)
+    print(f"{key}: loss {st['loss']:.6f} ref {ref_loss:.6f} bf16-oracle {infoq['loss']:.6f}; worst grad rel-l2 {worst:.4f} (fp32 oracle {worst32:.4f})")
 
 
 def test_inner_steps_vs_oracle(sd, G):
