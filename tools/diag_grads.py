@@ -8,14 +8,18 @@ from masr_amd.engine import MasrEngine
 from oracle import ref_cpu
 from oracle.make_goldens import TINY, ODIM, synth_batch
 
+case = sys.argv[1] if len(sys.argv) > 1 else "ragged"
+CASES = {"ragged": ([64, 52, 40, 33], [9, 7, 5, 3]), "same": ([48, 48, 48], [6, 6, 4]), "single": ([37], [5]),
+         "ragged_same_olen": ([64, 52, 40, 33], [7, 7, 7, 7]), "same_ilen_ragged_olen": ([64, 64, 64, 64], [9, 7, 5, 3])}
 sd = ref_cpu.deterministic_state_dict(TINY, ODIM, seed=7)
-xs, il, ys, ol = synth_batch(11, [64, 52, 40, 33], [9, 7, 5, 3])
+xs, il, ys, ol = synth_batch(11, *CASES[case])
 eng = MasrEngine(TINY, ODIM, label_smoothing=0.2)
 eng.load_state_dict(sd)
 eng.run_batch(xs, il, ys, ol, train=True)
 print(eng.read_stats())
-p = ref_cpu.leafify(sd, TINY)
-info, grads, logit, gold = ref_cpu.run_batch_train(p, TINY, (xs, il, ys, ol.clone()), 0.2)
+with ref_cpu.bf16_emulation():
+    p = ref_cpu.leafify(sd, TINY)
+    info, grads, logit, gold = ref_cpu.run_batch_train(p, TINY, (xs, il, ys, ol.clone()), 0.2)
 print(info)
 g_all = eng.state_dict(flat=eng.grads)
 for n in ref_cpu.grad_param_names(p, TINY):
