@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- inner-step utterances/sec of the MI355X-native meta-ASR path (BASELINE.json metric).
+
+A "step" is ONE inner-loop step of FOMetaASRInterface.run_task (src/fo_meta_interface.py:238-250):
+run_batch(train=True) [forward + label-smoothed CE + backward] -> clip_grad_norm_(5) -> SGD(momentum .9,
+nesterov) step, on one synthetic batch of 10 s x 80-dim fbank utterances that is already resident in
+HBM when the timed region starts.  Model = config/transformer/pretrain/fometa-hkust.yaml geometry
+(d_model 512, 8 heads, d_inner 2048, 2 enc / 4 dec, odim 367, dropout 0.1), random-init weights.
+
+    python bench.py [--gpus N --steps K --warmup W]          # N>1 via torch.distributed.run, one rank per GPU
+
+N ranks = N independent accent-tasks (FOMAML shards tasks one per GPU; the inner step has no exchange),
+so scaling is "weak": value = N * B * K / max-over-ranks time.  The meta-gradient all-reduce of the OUTER
+step is measured separately (field "meta_step") because the metric counts inner steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np
+import torch
+
+HKUST = {
+    "idim": 80, "nheads": 8, "d_model": 512, "d_inner": 2048, "dropout": 0.1, "pos_dropout": 0.1,
+    "tgt_share_weight": 1, "encoder": {"nlayers": 2}, "decoder": {"nlayers": 4},
+    "inner_optimizer_cls": "SGD", "inner_optimizer_opt": {"momentum": 0.9, "nesterov": True},
+    "meta_opt_cls": "noam", "meta": {"optimizer_opt": {"k": 1.0, "warmup_steps": 25000}},
+}
+ODIM = 367
+PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """progress to stderr (stdout carries only the one JSON line)"""
+    print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def synth_batch(B, T, D, seed):
+    """feat ~ N(0,1), ilens = T, olens ~ U{10..40}, labels ~ U{1..365}."""
+    rng = np.random.RandomState(seed)
+    xs = torch.from_numpy(rng.randn(B, T, D).astype(np.float32))
+    olens = rng.randint(10, 41, size=B)
+    ys = [torch.from_numpy(rng.randint(1, 366, size=int(n)).astype(np.int64)) for n in olens]
+    return xs, torch.full((B,), T, dtype=torch.int64), ys, torch.from_numpy(olens.astype(np.int64))
+
+
+def fwd_flops_per_utt(T, D, L=31, E=512, F=2048, NE=2, ND=4, C=367):
+    """SURVEY 8(d) algorithmic forward FLOPs per utterance (multiply-add = 2)."""
+    H2, W2 = T // 2, D // 2
+    Tp, Dp = H2 // 2, W2 // 2
+    conv = 2 * 9 * (1 * 64 * T * D + 64 * 64 * T * D + 64 * 128 * H2 * W2 + 128 * 128 * H2 * W2)
+    v2e = 2 * Tp * (128 * Dp) * E
+    enc = NE * (2 * Tp * E * 3 * E + 2 * Tp * E * E + 4 * Tp * Tp * E + 4 * Tp * E * F)
+    dec = ND * ((2 * L * E * 3 * E + 2 * L * E * E + 4 * L * L * E) + (2 * L * E * E + 2 * Tp * E * 2 * E + 2 * L * E * E + 4 * L * Tp * E) + 4 * L * E * F)
+    return conv + v2e + enc + dec + 2 * L * E * C
+
+
+def cpu_baseline(cfg, B, T, D, steps=2):
+    """The oracle's inner step (fp32 torch on the host cores) on a bounded sample of the same workload."""
+    from oracle import ref_cpu
+    n = len(os.sched_getaffinity(0))
+    torch.set_num_threads(n)
+    c = dict(cfg)
+    c["dropout"] = c["pos_dropout"] = 0.0            # the oracle is the dropout-free restatement
+    sd = ref_cpu.deterministic_state_dict(c, ODIM, seed=1)
+    p = ref_cpu.leafify(sd, c)
+    bufs = {}
+    batch = synth_batch(B, T, D, 0)
+    lr = ref_cpu.inner_lr(c)
+    ref_cpu.inner_step(p, c, (batch[0], batch[1], batch[2], batch[3].clone()), 0.2, bufs, lr)      # warm-up
+    log(f"cpu warm-up step done ({n} threads)")
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ref_cpu.inner_step(p, c, (batch[0], batch[1], batch[2], batch[3].clone()), 0.2, bufs, lr)
+        log("cpu step done")
+    dt = time.perf_counter() - t0
+    return {"value": B * steps / dt, "unit": "utt/s", "cores": n, "kind": "port",
+            "sample": f"{steps} timed + 1 warm-up inner steps, B={B} x T={T} x D={D}, same model/config, fp32 torch CPU oracle, dropout 0"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="utterances per inner step per GPU (16 = what the shipped half_batch_ilen rule yields at 1000 frames)")
+    ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--idim", type=int, default=80)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+
+    import masr_amd
+    from masr_amd.engine import MasrEngine
+    from oracle import ref_cpu                                   # deterministic init recipe only (host side)
+
+    cfg = dict(HKUST)
+    cfg["idim"] = args.idim
+    B, T, D = args.batch, args.frames, args.idim
+    eng = MasrEngine(cfg, ODIM, label_smoothing=0.2, device=dev)
+    eng.load_state_dict(ref_cpu.deterministic_state_dict(cfg, ODIM, seed=1))
+    eng.set_seed(531 + rank)
+    xs, il, ys, ol = synth_batch(B, T, D, seed=rank)             # numpy seed 0 + accent index
+    xs = xs.to(dev)
+    mom = torch.zeros_like(eng.params)
+    lr = ref_cpu.inner_lr(cfg)
+
+    def step(i):
+        eng.run_batch(xs, il, ys, ol, train=True)
+        eng.clip_sgd_step(mom, 5.0, lr, 0.9, True, first_step=(i == 0))
+
+    log(f"rank {rank}: engine ready, workspace will be {eng._l.masr_workspace_bytes(eng.h, B, T, 42) / 1e9:.2f} GB")
+    for i in range(args.warmup):
+        step(i)
+        if i == 0:
+            torch.cuda.synchronize(dev)
+            log("first step done")
+    st = eng.read_stats()
+    log(f"warm-up done: loss {st['loss']:.4f} grad_norm {st['grad_norm']:.4f}")
+    assert np.isfinite(st["loss"]) and np.isfinite(st["grad_norm"]), st
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = eng.read_stats()
+    log(f"timed region: {dt:.3f} s for {args.steps} steps")
+
+    # ---- one FOMAML meta-step's exchange (all-reduce of the flat meta-gradient) for information
+    meta = None
+    if dist is not None:
+        upd = torch.zeros_like(eng.params)
+        eng.clip_accumulate(upd, 5.0)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            dist.all_reduce(upd)
+        torch.cuda.synchronize(dev)
+        meta = {"allreduce_ms": (time.perf_counter() - t1) / 5 * 1e3, "payload_mb": upd.numel() * 4 / 1e6}
+
+    # ---- roofline of the dominant kernel, timed live with HIP events on the launch stream
+    roof = None
+    prof_all = None
+    if rank == 0 and not args.no_profile:
+        eng.profile(True)
+        nprof = 5
+        for i in range(nprof):
+            step(args.warmup + args.steps + i)
+        prof_all = eng.profile_read()
+        eng.profile(False)
+        ms, n = prof_all["conv2_fwd"]
+        flops = 2.0 * 9 * 64 * 64 * B * T * D                    # algorithmic FLOPs of one conv 64->64 launch
+        achieved = flops / (ms / n * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "conv3x3_kernel<64,64> (conv2 forward, implicit GEMM)", "achieved": achieved,
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                "avg_launch_ms": ms / n, "flops_per_launch": flops}
+
+    if rank == 0:
+        utt = world * B * args.steps
+        value = utt / dt
+        F = fwd_flops_per_utt(T, D)
+        out = {
+            "metric": "inner-step utterances/sec (10s x 80-dim fbank)", "value": value, "unit": "utt/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "pretrain.py --algo fomaml inner step (run_batch + clip 5 + SGD nesterov), "
+                                   "config/transformer/pretrain/fometa-hkust.yaml geometry, synthetic 10s x %d-dim fbank" % D,
+                       "batch_per_gpu": B, "frames": T, "idim": D, "dropout": cfg["dropout"], "tasks": world,
+                       "parallelism": f"task-per-gpu x{world}"},
+            "algorithmic_gflop_per_utt_fwd_bwd": 3 * F / 1e9,
+            "model_tflops": value * 3 * F / 1e12, "model_frac_of_bf16_peak": value * 3 * F / 1e12 / (PEAK_BF16_TFLOPS * world),
+            "loss": st["loss"], "grad_norm": st["grad_norm"],
+        }
+        if roof:
+            out["roofline"] = roof
+            out["kernel_ms_per_step"] = {k: v[0] / 5 for k, v in prof_all.items()}
+        if meta:
+            out["meta_step"] = meta
+        if not args.no_cpu_baseline and world == 1:
+            log("cpu baseline (oracle on host cores) ...")
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch, T, D)
+            log("cpu baseline done")
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -108,7 +108,8 @@ int masr_ctc_loss(const float* logits, const int32_t* targets, const int32_t* tg
 #define MASR_PROF_GEMM 3
 #define MASR_PROF_ATTN 4
 #define MASR_PROF_OTHER 5
-#define MASR_PROF_N 6
+#define MASR_PROF_CONV2_FWD 6   /* the single largest launch: conv 64->64 forward on the full-resolution map */
+#define MASR_PROF_N 7
 int masr_profile_enable(masr_model* m, int on);
 /* sums since the last call: ms[MASR_PROF_N], launches[MASR_PROF_N]; synchronises */
 int masr_profile_read(masr_model* m, float* ms, int* launches);

@@ -53,7 +53,7 @@ _SIGS = {
     "masr_test_attention": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
 }
 EXPORTS = tuple(_SIGS)
-PROF_NAMES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "gemm", "attn", "other")
+PROF_NAMES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "gemm", "attn", "other", "conv2_fwd")
 
 _lib = None
 

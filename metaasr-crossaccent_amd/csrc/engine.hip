@@ -431,7 +431,7 @@ static int forward_encoder(Ctx& c, const float* xs) {
         CK(mk_conv1_fwd(xs, P + m->conv[0].w, P + m->conv[0].b, a.a1, B, T, D, s));
     }
     auto conv = [&](const bf16* in, const Conv& cv, bf16* out, int H, int W) -> int {
-        Prof p(m, MASR_PROF_CONV_FWD, s);
+        Prof p(m, &cv == &m->conv[1] ? MASR_PROF_CONV2_FWD : MASR_PROF_CONV_FWD, s);
         ConvArgs ca{}; ca.in = in; ca.wk = cv.k16; ca.bias = P + cv.b; ca.relu = 1; ca.mask = nullptr; ca.out = out;
         ca.B = B; ca.H = H; ca.W = W; ca.CIN = cv.CI; ca.COUT = cv.CO;
         return mk_conv3x3(ca, s);

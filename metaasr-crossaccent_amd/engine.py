@@ -199,7 +199,7 @@ class MasrEngine:
         check(self._l.masr_profile_enable(self.h, int(on)), "masr_profile_enable")
 
     def profile_read(self):
-        ms = (C.c_float * 6)()
-        n = (C.c_int * 6)()
+        ms = (C.c_float * len(_cabi.PROF_NAMES))()
+        n = (C.c_int * len(_cabi.PROF_NAMES))()
         check(self._l.masr_profile_read(self.h, ms, n), "masr_profile_read")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(_cabi.PROF_NAMES)}
