@@ -101,13 +101,16 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
         slab[(long)blockIdx.x * 640 + (c * 8 + e / 10) * 10 + e % 10] = v;
     }
 }
-__global__ void conv1_wgrad_reduce(const float* __restrict__ slab, int nblocks, float* __restrict__ dw, float* __restrict__ db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per output element: lanes stride over the per-block partials, fixed-order tree -> deterministic
+__global__ __launch_bounds__(256) void conv1_wgrad_reduce(const float* __restrict__ slab, int nblocks, float* __restrict__ dw,
+                                                          float* __restrict__ db) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= 640) return;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += slab[(long)b * 640 + i];
+    for (int b = lane; b < nblocks; b += 64) s += slab[(long)b * 640 + i];
+    s = wave_sum(s);
     const int co = i / 10, k = i % 10;
-    if (k < 9) dw[co * 9 + k] = s; else db[co] = s;
+    if (lane == 0) { if (k < 9) dw[co * 9 + k] = s; else db[co] = s; }
 }
 
 // ------------------------------------------------------------------ implicit GEMM 3x3 (fwd and dgrad)
@@ -284,15 +287,26 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(ConvWgradArgs a, lon
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // fused bias gradient: db[co] = sum_p dy[p][co], accumulated by the column-tile-0 workgroup of each split
+    const bool do_db = a.db != nullptr && blockIdx.x == 0;
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto accumulate = [&]() {
+#pragma unroll
+        for (int i = 0; i < ACH; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) csum[j] += (float)ra[i][j];
+    };
+
     const int nk = (int)((pe - ps + BK - 1) / BK);
     if (nk > 0) {
         load(ps);
+        if (do_db) accumulate();
         store(0);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) load(ps + (long)(kt + 1) * BK);
+        if (kt + 1 < nk) { load(ps + (long)(kt + 1) * BK); if (do_db) accumulate(); }
         bf16x8 af[FM], bfr[FN];
 #pragma unroll
         for (int i = 0; i < FM; ++i) af[i] = frag_rm<LDA>(sA[cur], wm * WM + i * 16, lane);
@@ -304,6 +318,20 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(ConvWgradArgs a, lon
             for (int j = 0; j < FN; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
         if (kt + 1 < nk) store(cur ^ 1);
         __syncthreads();
+    }
+    if (do_db) {
+        constexpr int RC = BM / 8;
+        float* red = reinterpret_cast<float*>(sA[0]);                 // [256][8] floats (tile buffers are free now)
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid * 8 + j] = csum[j];
+        __syncthreads();
+        if (tid < BM) {
+            const int rc = tid / 8, j = tid % 8;
+            float sum = 0.f;
+            for (int t = rc; t < 256; t += RC) sum += red[t * 8 + j];
+            a.slab[(long)gridDim.y * COUT * KTOT + (long)blockIdx.y * COUT + tid] = sum;
+        }
     }
     float* out = a.slab + (long)blockIdx.y * COUT * KTOT;
 #pragma unroll
@@ -319,10 +347,19 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(ConvWgradArgs a, lon
         }
 }
 
-__global__ void conv3x3_wgrad_reduce(const float* __restrict__ slab, int nsplit, float* __restrict__ dw, int CIN, int COUT) {
+__global__ void conv3x3_wgrad_reduce(const float* __restrict__ slab, int nsplit, float* __restrict__ dw, float* __restrict__ db,
+                                     int CIN, int COUT) {
     const int KTOT = 9 * CIN;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;       // co*KTOT + tap*CIN + ci
-    if (i >= COUT * KTOT) return;
+    if (i >= COUT * KTOT) {
+        const int co = i - COUT * KTOT;
+        if (db && co < COUT) {
+            float s = 0.f;
+            for (int k = 0; k < nsplit; ++k) s += slab[(long)nsplit * COUT * KTOT + (long)k * COUT + co];
+            db[co] = s;
+        }
+        return;
+    }
     float s = 0.f;
     for (int k = 0; k < nsplit; ++k) s += slab[(long)k * COUT * KTOT + i];
     const int co = i / KTOT, rem = i % KTOT, tap = rem / CIN, ci = rem % CIN;
@@ -406,7 +443,7 @@ int mk_conv1_wgrad(const float* x, const bf16* dy, float* dw, float* db, float* 
     const long P = (long)B * H * W;
     const int nb = (int)((P + C1_PIX - 1) / C1_PIX);
     hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(nb), dim3(256), 0, s, x, dy, slab, B, H, W);
-    hipLaunchKernelGGL(conv1_wgrad_reduce, dim3(3), dim3(256), 0, s, slab, nb, dw, db);
+    hipLaunchKernelGGL(conv1_wgrad_reduce, dim3(160), dim3(256), 0, s, slab, nb, dw, db);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -422,7 +459,7 @@ int mk_conv3x3(const ConvArgs& a, hipStream_t s) {
 }
 
 long mk_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT) {
-    return (long)wgrad_splits((long)B * H * W, CIN) * COUT * 9 * CIN;
+    return (long)wgrad_splits((long)B * H * W, CIN) * (COUT * 9 * CIN + COUT);
 }
 int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s) {
     const long P = (long)a.B * a.H * a.W;
@@ -434,11 +471,8 @@ int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s) {
     else if (a.CIN == 64 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_wgrad_kernel<64, 128>), grid, dim3(256), 0, s, a, pps);
     else if (a.CIN == 128 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_wgrad_kernel<128, 128>), grid, dim3(256), 0, s, a, pps);
     else { mk_set_error("mk_conv3x3_wgrad", "unsupported channel counts"); return -1; }
-    const int n = a.COUT * 9 * a.CIN;
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((n + 255) / 256), dim3(256), 0, s, a.slab, splits, a.dw, a.CIN, a.COUT);
-    if (a.db) {
-        // bias gradient = column sums of dy [P][COUT]; reuse the slab tail is not safe -> caller passes db separately via mk_colsum
-    }
+    const int n = a.COUT * 9 * a.CIN + a.COUT;
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((n + 255) / 256), dim3(256), 0, s, a.slab, splits, a.dw, a.db, a.CIN, a.COUT);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

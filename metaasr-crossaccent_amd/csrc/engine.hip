@@ -222,9 +222,8 @@ int gemm(Ctx& c, const GemmArgs& g) { Prof p(c.m, MASR_PROF_GEMM, c.s); return m
 int lin_wgrad(Ctx& c, const bf16* dy, long lddy, const bf16* x, long ldx, int rows, int N, int K, float* dW, float* db, int accumulate = 0) {
     GemmArgs g = gemm_args();
     g.reduction_major = 1; g.A = dy; g.lda = lddy; g.B = x; g.ldb = ldx; g.M = N; g.N = K; g.K = rows;
-    g.C32 = dW; g.ldc = K; g.accumulate = accumulate;
+    g.C32 = dW; g.ldc = K; g.accumulate = accumulate; g.colsum = db;
     CK(gemm(c, g));
-    if (db) { Prof p(c.m, MASR_PROF_OTHER, c.s); CK(mk_colsum(dy, lddy, db, c.m->acts.slab, rows, (N + 7) / 8 * 8, N, c.s)); }
     return 0;
 }
 // dX = dy W via the transposed shadow t16 [K][ldt]
@@ -568,9 +567,9 @@ static int backward(Ctx& c, const float* xs) {
     const int64_t P1 = (int64_t)B * a.T * a.D, P2 = (int64_t)B * a.H2 * a.W2;
     auto wgrad = [&](const bf16* in, const bf16* dy, const Conv& cv, int H, int W, int64_t P) -> int {
         { Prof p(m, MASR_PROF_CONV_WGRAD, s);
-          ConvWgradArgs wa{}; wa.in = in; wa.dy = dy; wa.dw = G + cv.w; wa.db = nullptr; wa.slab = a.slab; wa.B = B; wa.H = H; wa.W = W; wa.CIN = cv.CI; wa.COUT = cv.CO;
+          ConvWgradArgs wa{}; wa.in = in; wa.dy = dy; wa.dw = G + cv.w; wa.db = G + cv.b; wa.slab = a.slab; wa.B = B; wa.H = H; wa.W = W; wa.CIN = cv.CI; wa.COUT = cv.CO;
           CK(mk_conv3x3_wgrad(wa, s)); }
-        { Prof p(m, MASR_PROF_OTHER, s); CK(mk_colsum(dy, cv.CO, G + cv.b, a.slab, (int)P, cv.CO, cv.CO, s)); }
+        (void)P;
         return 0;
     };
     auto dgrad = [&](const bf16* dy, const Conv& cv, const bf16* mask, bf16* out, int H, int W) -> int {

@@ -80,6 +80,13 @@ struct StagerRM {
             if (c < CHUNKS) st8(dst + k * LDT + rc, regs[i]);
         }
     }
+    // running column sums of the staged tile (each thread always owns the same 8 rows: 256 % RC == 0)
+    __device__ __forceinline__ void accumulate(float (&acc)[8]) {
+#pragma unroll
+        for (int i = 0; i < PT; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)regs[i][j];
+    }
 };
 
 // fragment of 16 rows starting at r0 from a reduction-major tile (k permuted, see header)
@@ -119,9 +126,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // fused bias gradient (wgrad form only): colsum[m] = sum_k A(m,k), produced by the n-tile-0 workgroups
+    const bool do_colsum = RM && g.colsum && blockIdx.x == 0;
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
     const int nk = (g.K + BK - 1) / BK;
     sa.load(g.A, g.lda, m0, 0, g.M, g.K, tid);
     sb.load(g.B, g.ldb, n0, 0, g.N, g.K, tid);
+    if constexpr (RM) { if (do_colsum) sa.accumulate(csum); }
     sa.store(sa_[0].d, tid);
     sb.store(sb_[0].d, tid);
     __syncthreads();
@@ -150,10 +162,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
         if (kt + 1 < nk) {
+            if constexpr (RM) { if (do_colsum) sa.accumulate(csum); }
             sa.store(sa_[cur ^ 1].d, tid);
             sb.store(sb_[cur ^ 1].d, tid);
         }
         __syncthreads();
+    }
+    if constexpr (RM) {
+        if (do_colsum) {
+            // threads tid, tid + RC, tid + 2RC ... own the same 8 rows: reduce through LDS (tile buffers are free now)
+            constexpr int RC = BM / 8;
+            float* red = reinterpret_cast<float*>(sa_[0].d);          // [256][8] floats = 8 KB <= tile size
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[tid * 8 + j] = csum[j];
+            __syncthreads();
+            if (tid < BM) {
+                const int rc = tid / 8, j = tid % 8;
+                float sum = 0.f;
+                for (int t = rc; t < 256; t += RC) sum += red[t * 8 + j];
+                if (m0 + tid < g.M) g.colsum[m0 + tid] = sum;
+            }
+            __syncthreads();
+        }
     }
 
     // epilogue: alpha -> bias -> pe -> relu -> mask -> dropout -> residual -> (accumulate) -> store

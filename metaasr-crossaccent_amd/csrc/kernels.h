@@ -17,6 +17,7 @@ struct GemmArgs {
     const bf16* mask; long ldmask; float mask_scale;   // v = mask>0 ? v*mask_scale : 0
     float drop_p; uint32_t seed, site;                 // dropout on element index m*N+n
     const float* residual; long ldres;                 // + residual[m*ldres + n]
+    float* colsum;                // reduction-major only: colsum[m] = sum_k A(m,k) (fused bias gradient) or null
     int accumulate;               // C32 += v
     float* C32; long ldc;         // fp32 output or null
     bf16* C16; long ldc16;        // bf16 output or null

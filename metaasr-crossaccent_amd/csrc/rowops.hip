@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // backward: each block handles LN_ROWS rows (one wave per row, looping), accumulating dgamma/dbeta
 // partials per thread-column, written to slab[block][2][E]; reduced by ln_bwd_reduce.
-constexpr int LN_ROWS = 32;
+constexpr int LN_ROWS = 8;
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx32,
@@ -105,14 +105,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         slab[((long)blockIdx.x * 2 + 1) * E + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
     }
 }
-__global__ void ln_bwd_reduce(const float* __restrict__ slab, int nblocks, float* __restrict__ dgamma,
-                              float* __restrict__ dbeta, int E) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * E) return;
-    const int which = c / E, col = c % E;
+// 64 columns x 4 block-lanes per workgroup; fixed-order -> deterministic
+__global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ slab, int nblocks, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int E) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    __shared__ float red[4][64];
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += slab[((long)b * 2 + which) * E + col];
-    (which == 0 ? dgamma : dbeta)[col] = s;
+    if (c < 2 * E) {
+        const int which = c / E, col = c % E;
+        for (int b = part; b < nblocks; b += 4) s += slab[((long)b * 2 + which) * E + col];
+    }
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && c < 2 * E) {
+        const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        (c / E == 0 ? dgamma : dbeta)[c % E] = t;
+    }
 }
 
 // ---------------------------------------------------------------- embedding + positional encoding
@@ -136,15 +144,35 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ 
                                                         float drop_p, uint32_t seed, uint32_t site) {
     const int v = blockIdx.x;
     const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    for (int e = threadIdx.x; e < E; e += 256) {
-        float s = 0.f;
-        for (int r = 0; r < rows; ++r)
-            if (tok[r] == v) {
-                float g = dy[(long)r * E + e];
-                if (drop_p > 0.f) g *= dropout_scale(seed, site, (uint32_t)((long)r * E + e), drop_p, inv_keep);
-                s += g;
+    // rows holding token v, gathered in order (deterministic sum); most vocabulary rows have none
+    __shared__ int hit[1024]; __shared__ int nhit;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};                                  // E <= 1024 -> <= 4 columns per thread
+    for (int r0 = 0; r0 < rows; r0 += 1024) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int n = 0;
+            const int r1 = r0 + 1024 < rows ? r0 + 1024 : rows;
+            for (int r = r0; r < r1; ++r) if (tok[r] == v) hit[n++] = r;
+            nhit = n;
+        }
+        __syncthreads();
+        for (int h = 0; h < nhit; ++h) {
+            const int r = hit[h];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = threadIdx.x + i * 256;
+                if (e < E) {
+                    float g = dy[(long)r * E + e];
+                    if (drop_p > 0.f) g *= dropout_scale(seed, site, (uint32_t)((long)r * E + e), drop_p, inv_keep);
+                    s[i] += g;
+                }
             }
-        if (accumulate) dtable[(long)v * E + e] += s; else dtable[(long)v * E + e] = s;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = threadIdx.x + i * 256;
+        if (e < E) { if (accumulate) dtable[(long)v * E + e] += s[i]; else dtable[(long)v * E + e] = s[i]; }
     }
 }
 
@@ -275,7 +303,7 @@ int mk_layernorm_bwd(const float* dy, const float* x, const float* gamma, const 
     if (E > 64 * LN_MAXPT) { mk_set_error("mk_layernorm_bwd", "d_model > 1024 unsupported"); return -1; }
     const int nb = (rows + LN_ROWS - 1) / LN_ROWS;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx32, dx16, drop_p, seed, site, slab, rows, E);
-    hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * E + 255) / 256), dim3(256), 0, s, slab, nb, dgamma, dbeta, E);
+    hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * E + 63) / 64), dim3(256), 0, s, slab, nb, dgamma, dbeta, E);
     return LAUNCH_OK();
 }
 int mk_embed_fwd(const int* tok, const float* table, const float* pe, float* y32, bf16* y16, int B, int L, int E,
