@@ -1,0 +1,226 @@
+"""Data path of the reference (src/io/dataset.py) re-built for the MI355X path.
+
+On-disk format is unchanged: `<dir>/feat.dat` is an NPY-format [sum T_i, idim] float
+array opened with np.load(mmap_mode='r'); ilens.npy / olens.npy / label.npy.  Batching semantics
+(BucketSampler's 1-frame buckets, half-batch rule, RNG consumption order; collate's sort + zero pad) are
+the reference's, bit for bit (pinned by tests/golden/bucket_sampler.npz and fomaml_toy.npz).
+
+What is different: no DataLoader worker processes.  A shard can be made HBM-resident
+(`CommonVoiceDataset.to_device`): with 288 GB per GPU a whole accent shard fits, and collate becomes
+one coalesced gather+pad kernel (masr_gather_pad) instead of a host memcpy + pinned upload.
+"""
+import random
+from pathlib import Path
+
+import numpy as np
+import torch
+
+BUCKET_SIZE = 1
+ILEN_MIN = 2
+ILEN_MAX = 10000
+
+
+def collate_fn(batch):
+    """dataset.py:21-33: sort by ilen (desc, stable), zero-pad features, keep labels as a list."""
+    batch.sort(key=lambda d: d['ilen'], reverse=True)
+    tmax = int(batch[0]['ilen'])
+    xs_pad = torch.zeros(len(batch), tmax, batch[0]['feat'].shape[1])
+    for b, d in enumerate(batch):
+        xs_pad[b, :d['feat'].shape[0]] = d['feat']
+    ilens = torch.stack([d['ilen'] for d in batch])
+    ys = [d['label'] for d in batch]
+    olens = torch.stack([d['olen'] for d in batch])
+    return xs_pad, ilens, ys, olens
+
+
+class BucketSampler:
+    """dataset.py:35-110.  Buckets are 1 frame wide; python `random` orders the buckets once at construction,
+    np.random shuffles inside a bucket lazily when iteration reaches it; batch size is halved for buckets
+    beyond half_batch_ilen."""
+
+    def __init__(self, ilens, min_ilen, max_ilen, half_batch_ilen, batch_size, bucket_size=BUCKET_SIZE,
+                 bucket_reverse=False, drop_last=False):
+        self.ilens = np.asarray(ilens)
+        self.batch_size, self.drop_last, self.bucket_reverse = batch_size, drop_last, bucket_reverse
+        lo = min(ILEN_MIN, bucket_size) if not min_ilen else min_ilen
+        hi = max(ILEN_MAX, int(self.ilens.max())) if not max_ilen else max_ilen
+        half = half_batch_ilen if half_batch_ilen else ILEN_MAX
+        bins = np.arange(hi, lo, -bucket_size) if bucket_reverse else np.arange(lo, hi, bucket_size)
+        which = np.digitize(self.ilens, bins, right=True)
+        self.half_idx = np.digitize(half, bins, right=True)
+        self.buckets = []
+        for b in range(1, len(bins) - 1):                     # first and last bin are dropped, as in the reference
+            members = np.where(which == b)[0]
+            if len(members):
+                self.buckets.append((b, members))
+        random.shuffle(self.buckets)
+
+    def _bs(self, bin_idx):
+        halved = bin_idx < self.half_idx if self.bucket_reverse else bin_idx > self.half_idx
+        return max(1, self.batch_size // 2) if halved else self.batch_size
+
+    def __iter__(self):
+        for bin_idx, members in self.buckets:
+            bs = self._bs(bin_idx)
+            np.random.shuffle(members)
+            cur = []
+            for i in members:
+                cur.append(int(i))
+                if len(cur) == bs:
+                    yield cur
+                    cur = []
+            if cur and not self.drop_last:
+                yield cur
+
+    def __len__(self):
+        n = 0
+        for bin_idx, members in self.buckets:
+            bs = self._bs(bin_idx)
+            n += len(members) // bs if self.drop_last else (len(members) + bs - 1) // bs
+        return n
+
+
+class CommonVoiceDataset:
+    """dataset.py:116-153: ragged rows of one NPY array + cumulative pointers."""
+
+    def __init__(self, data_dir, is_memmap):
+        data_dir = Path(data_dir)
+        if is_memmap:
+            self.feat = np.load(data_dir / 'feat.dat', mmap_mode='r')
+        else:
+            self.feat = np.load(data_dir / 'feat.npy')
+        self.ilens = np.load(data_dir / 'ilens.npy')
+        self.olens = np.load(data_dir / 'olens.npy')
+        self.label = np.load(data_dir / 'label.npy')
+        assert len(self.ilens) == len(self.olens), "Number of samples should be the same in features and labels"
+        self.iptr = np.concatenate([[0], np.cumsum(self.ilens)]).astype(np.int64)
+        self.optr = np.concatenate([[0], np.cumsum(self.olens)]).astype(np.int64)
+        self.dev_feat = None
+
+    def __len__(self):
+        return len(self.ilens)
+
+    def __getitem__(self, idx):
+        return {
+            'feat': torch.from_numpy(np.array(self.feat[self.iptr[idx]:self.iptr[idx + 1], :], dtype=np.float32)),
+            'ilen': torch.as_tensor(self.ilens[idx]),
+            'label': torch.from_numpy(np.asarray(self.label[self.optr[idx]:self.optr[idx + 1]]).astype(np.int64)),
+            'olen': torch.as_tensor(self.olens[idx]),
+        }
+
+    # ---- HBM-resident shard -------------------------------------------------------------
+    def to_device(self, device):
+        """Upload the whole shard once (coalesced HBM reads afterwards; SURVEY 8(d) 'ragged gather')."""
+        self.dev_feat = torch.from_numpy(np.ascontiguousarray(self.feat, dtype=np.float32)).to(device)
+        return self
+
+    def gather_batch(self, idxs):
+        """collate on the GPU: same sort / pad semantics as collate_fn, features never leave HBM."""
+        import ctypes as C
+        from .._cabi import lib, check
+        assert self.dev_feat is not None, "call to_device() first"
+        idxs = sorted(idxs, key=lambda i: int(self.ilens[i]), reverse=True)
+        dev = self.dev_feat.device
+        lens = torch.tensor([int(self.ilens[i]) for i in idxs], dtype=torch.int32)
+        rows = torch.tensor([int(self.iptr[i]) for i in idxs], dtype=torch.int64)
+        B, tmax, D = len(idxs), int(lens.max()), self.dev_feat.shape[1]
+        xs = torch.empty(B, tmax, D, device=dev)
+        rows_d, lens_d = rows.to(dev), lens.to(dev)
+        s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        check(lib().masr_gather_pad(C.c_void_p(self.dev_feat.data_ptr()), C.c_void_p(rows_d.data_ptr()),
+                                    C.c_void_p(lens_d.data_ptr()), C.c_void_p(xs.data_ptr()), B, tmax, D, s), "masr_gather_pad")
+        ys = [torch.from_numpy(np.asarray(self.label[self.optr[i]:self.optr[i + 1]]).astype(np.int64)) for i in idxs]
+        olens = torch.tensor([int(self.olens[i]) for i in idxs], dtype=torch.int64)
+        return xs, lens.to(torch.int64), ys, olens
+
+
+class Loader:
+    """In-process stand-in for the reference's DataLoader(batch_sampler=..., collate_fn=...)."""
+
+    def __init__(self, dset, batch_sampler=None, batch_size=1, shuffle=False, drop_last=False, indices=None):
+        self.dset, self.batch_sampler, self.batch_size = dset, batch_sampler, batch_size
+        self.shuffle, self.drop_last = shuffle, drop_last
+        self.indices = list(range(len(dset))) if indices is None else list(indices)
+
+    def _batches(self):
+        if self.batch_sampler is not None:
+            yield from self.batch_sampler
+            return
+        order = list(self.indices)
+        if self.shuffle:
+            # torch.utils.data.RandomSampler: draw a seed from the default generator, permute with a private one
+            g = torch.Generator()
+            g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
+            order = [order[i] for i in torch.randperm(len(order), generator=g).tolist()]
+        for i in range(0, len(order), self.batch_size):
+            chunk = order[i:i + self.batch_size]
+            if len(chunk) == self.batch_size or not self.drop_last:
+                yield chunk
+
+    def __iter__(self):
+        for idxs in self._batches():
+            if self.dset.dev_feat is not None:
+                yield self.dset.gather_batch(idxs)
+            else:
+                yield collate_fn([self.dset[i] for i in idxs])
+
+    def __len__(self):
+        if self.batch_sampler is not None:
+            return len(self.batch_sampler)
+        n = len(self.indices)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+
+def get_loader(data_dir, batch_size, is_memmap, is_bucket, num_workers=0, split_rate=1.0, split_seed=531,
+               min_ilen=None, max_ilen=None, half_batch_ilen=None, bucket_reverse=False, shuffle=True,
+               read_file=False, drop_last=False, pin_memory=True, device=None):
+    """dataset.py:156-198.  num_workers / pin_memory are accepted for signature parity and ignored."""
+    assert not read_file, "Load from Kaldi ark haven't been implemented yet"
+    dset = CommonVoiceDataset(data_dir, is_memmap)
+    if device is not None:
+        dset.to_device(device)
+    indices = None
+    if split_rate < 1.0:
+        n_tr = int(len(dset) * split_rate)
+        perm = torch.randperm(len(dset), generator=torch.Generator().manual_seed(split_seed)).tolist()
+        indices = perm[:n_tr]                                  # random_split's first subset
+    if is_bucket and split_rate == 1.0:
+        sampler = BucketSampler(dset.ilens, min_ilen=min_ilen, max_ilen=max_ilen, half_batch_ilen=half_batch_ilen,
+                                batch_size=batch_size, bucket_size=BUCKET_SIZE, bucket_reverse=bucket_reverse,
+                                drop_last=drop_last)
+        return Loader(dset, batch_sampler=sampler)
+    return Loader(dset, batch_size=batch_size, shuffle=shuffle, drop_last=drop_last, indices=indices)
+
+
+class DataContainer:
+    """dataset.py:200-277: one endless train iterator per accent + dev loaders."""
+
+    def __init__(self, data_dirs, batch_size, dev_batch_size, is_memmap, is_bucket, num_workers=0, min_ilen=None,
+                 max_ilen=None, half_batch_ilen=None, bucket_reverse=False, shuffle=True, read_file=False,
+                 drop_last=False, pin_memory=True, device=None, accent_filter=None):
+        self.data_dirs = [Path(d) for d in data_dirs]
+        self.num_datasets = len(self.data_dirs)
+        self.kw = dict(batch_size=batch_size, is_memmap=is_memmap, is_bucket=is_bucket, num_workers=num_workers,
+                       min_ilen=min_ilen, max_ilen=max_ilen, half_batch_ilen=half_batch_ilen,
+                       bucket_reverse=bucket_reverse, shuffle=shuffle, read_file=read_file, device=device)
+        self.reload_cnt = 0
+        self.loader_iters, self.dev_loaders = [], []
+        for i, d in enumerate(self.data_dirs):
+            # accent_filter (multi-GPU): a rank only opens the shards of the tasks it owns
+            mine = accent_filter is None or i in accent_filter
+            self.loader_iters.append(iter(get_loader(d / 'train', **self.kw)) if mine else None)
+            self.dev_loaders.append(get_loader(d / 'dev', batch_size=dev_batch_size, is_memmap=is_memmap, is_bucket=False,
+                                               num_workers=num_workers, shuffle=False, device=device))
+
+    def get_item(self, accent_idx=None, num=1):
+        out = []
+        ids = np.random.randint(self.num_datasets, size=num) if accent_idx is None else np.repeat(accent_idx, num)
+        for a in ids:
+            try:
+                batch = next(self.loader_iters[a])
+            except StopIteration:
+                self.loader_iters[a] = iter(get_loader(self.data_dirs[a] / 'train', **self.kw))
+                self.reload_cnt += 1
+                batch = next(self.loader_iters[a])
+            out.append((a, batch))
+        return out

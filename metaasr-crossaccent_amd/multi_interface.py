@@ -1,0 +1,121 @@
+"""MultiASRInterface: multi-task pretraining (reference: src/multi_interface.py:17-192) -- one random-accent batch per
+step, clip 5, NaN-skip / optimiser step.  With N ranks this is plain data parallelism over N random-accent batches
+with a gradient all-reduce(mean), which changes the effective batch (parity holds at world_size 1 only)."""
+import math
+import pickle
+from functools import partial
+
+import torch
+
+from .marcos import *  # noqa: F401,F403
+from .monitor import logger
+from .monitor.stat import RunningAvgDict
+from .optimizer import TransformerOptimizer
+from .pretrain_interface import PretrainInterface
+
+
+class MultiASRInterface(PretrainInterface):
+    def __init__(self, config, paras, id2accent):
+        super().__init__(config, paras, id2accent)
+        self.asr_model = self.asr_opt = None
+        assert self.sample_strategy == 'normal', "Multi-task training only support normal sampling strategy"
+        self.dashboard.set_status('pretraining')
+        self._train = partial(self.run_batch, train=True)
+        self._eval = partial(self.run_batch, train=False)
+
+    def _sd_cpu(self):
+        return {k: v.cpu() for k, v in self.asr_model.engine.state_dict(clone=False).items()}
+
+    def save_best_model(self, tpe='wer', only_stat=False):
+        if self.sharder.rank != 0:
+            return
+        if not only_stat:
+            torch.save(self._sd_cpu(), self.log_dir.joinpath(f'model.{tpe}.best'))
+        with open(self.log_dir.joinpath(f'best_{tpe}'), 'w') as fout:
+            print('{} {}'.format(self.global_step, getattr(self, f'best_{tpe}')), file=fout)
+
+    def save_per_steps(self):
+        if self.sharder.rank != 0:
+            return
+        sd = self._sd_cpu()
+        torch.save(sd, self.log_dir.joinpath("snapshot.latest"))
+        with open(self.log_dir.joinpath("info_dict.latest"), 'wb') as f:
+            pickle.dump(self.train_info, f)
+        with open(self.log_dir.joinpath("global_step"), 'w') as f:
+            print(self.global_step, file=f)
+        torch.save(sd, self.log_dir.joinpath(f"snapshot.step.{self.global_step}"))
+        self.dashboard.log_step()
+
+    def load_model(self):
+        if self.paras.resume:
+            self.asr_model.load_state_dict(torch.load(self.resume_model_path))
+            self.dashboard.set_step(self.global_step)
+
+    def write_tr_logs(self):
+        for k, v in self.train_info.items():
+            self.write_log(f"train_{k}", float(v))
+
+    def write_dev_logs(self, prefix, info):
+        for k, v in info.items():
+            self.write_log(f"{prefix}_{k}", float(v))
+
+    def check_evaluate(self):
+        if self.global_step % self.eval_ival == 0:
+            self.evaluate()
+
+    def train(self):
+        eng = self.asr_model.engine
+        try:
+            while self.global_step < self.max_step:
+                for _ in range(self.eval_ival):
+                    idx, (x, ilens, ys, olens) = self.data_container.get_item()[0]
+                    info = self._train(idx, x, ilens, ys, olens, accent_idx=idx)
+                    self.train_info.add(info, len(ys))
+                    if self.sharder.world > 1:                            # DP: mean gradient over ranks
+                        self.sharder.all_reduce(eng.grads)
+                        eng.scale(eng.grads, 1.0 / self.sharder.world)
+                    grad_norm = self.clip_grad_norm_(GRAD_CLIP)
+                    if math.isnan(grad_norm):
+                        logger.warning(f"grad norm NaN @ step {self.global_step}")
+                    else:
+                        self.opt_step()
+                    self.log_msg(self.asr_opt.lr if isinstance(self.asr_opt, TransformerOptimizer) else None)
+                    self.check_evaluate()
+                    self.global_step += 1
+                    self.dashboard.step()
+                    if self.global_step % self.save_ival == 0:
+                        self.save_per_steps()
+        except KeyboardInterrupt:
+            logger.warning("Pretraining stopped")
+            self.save_per_steps()
+            self.dashboard.set_status('pretrained(SIGINT)')
+        else:
+            logger.notice("Pretraining completed")
+            self.dashboard.set_status('pretrained')
+
+    def evaluate(self):
+        self.asr_model.eval()
+        self.write_tr_logs()
+        dev_info_ls = [RunningAvgDict(decay_rate=1.) for _ in range(self.num_pretrain)]
+        for idx, dev_loader in enumerate(self.data_container.dev_loaders):
+            for x, ilens, ys, olens in dev_loader:
+                if ilens.max() > self.dev_max_ilen:
+                    continue
+                dev_info_ls[idx].add(self._eval(idx, x, ilens, ys, olens), len(ys))
+            self.dashboard.log_info(f"dev_{self.accents[idx]}", dev_info_ls[idx])
+            self.write_dev_logs(f"dev_{self.accents[idx]}", dev_info_ls[idx])
+        dev_avg = RunningAvgDict(decay_rate=1.0)
+        for d in dev_info_ls:
+            dev_avg.add({k: float(v) for k, v in d.items()})
+        self.dashboard.log_info("dev", dev_avg)
+        self.write_dev_logs("dev_avg", dev_avg)
+        if float(dev_avg['wer']) < self.best_wer:
+            self.best_wer = float(dev_avg['wer'])
+            self.save_best_model()
+        if float(dev_avg['cer']) < self.best_cer:
+            self.best_cer = float(dev_avg['cer'])
+            self.save_best_model('cer', only_stat=True)
+        self.asr_model.train()
+
+    def run_batch(self, idx, x, ilens, ys, olens, train):
+        raise NotImplementedError

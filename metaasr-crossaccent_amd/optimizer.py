@@ -1,0 +1,104 @@
+"""Optimisers over the engine's flat fp32 buffers.
+
+TransformerOptimizer restates src/model/transformer_pytorch/optimizer.py:5-37 (Noam schedule around Adam);
+FlatAdam / FlatSGD replace torch.optim.Adam(betas=(0.9, 0.98), eps=1e-9) and torch.optim.SGD(momentum,
+nesterov) (call sites src/fo_meta_interface.py:105,228-236; src/transformer_torch_trainer.py:28-35) with one
+streaming HIP kernel over all parameters (masr_adam_step / masr_clip_sgd_step)."""
+import torch
+
+
+class FlatAdam:
+    def __init__(self, engine, params_flat, betas=(0.9, 0.98), eps=1e-9, lr=1e-3):
+        self.engine, self.params = engine, params_flat
+        self.betas, self.eps = betas, eps
+        self.param_groups = [{'lr': lr}]
+        self.exp_avg = torch.zeros_like(params_flat)
+        self.exp_avg_sq = torch.zeros_like(params_flat)
+        self.t = 0
+        self.grad = None                      # set by the caller before step()
+
+    def zero_grad(self):
+        self.grad = None
+
+    def step(self):
+        assert self.grad is not None, "FlatAdam.step(): no gradient attached"
+        self.t += 1
+        self.engine.adam_step(self.params, self.grad, self.exp_avg, self.exp_avg_sq, self.param_groups[0]['lr'],
+                              self.betas[0], self.betas[1], self.eps, self.t)
+        if self.params.data_ptr() == self.engine.params.data_ptr():
+            self.engine.mark_dirty()
+
+    def state_dict(self):
+        return {'t': self.t, 'exp_avg': self.exp_avg.cpu(), 'exp_avg_sq': self.exp_avg_sq.cpu(), 'lr': self.param_groups[0]['lr']}
+
+    def load_state_dict(self, sd):
+        self.t = sd['t']
+        self.exp_avg.copy_(sd['exp_avg'])
+        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        self.param_groups[0]['lr'] = sd['lr']
+
+
+class FlatSGD:
+    """torch.optim.SGD(lr, momentum, nesterov) on the engine's own params/grads; `clip` fuses clip_grad_norm_."""
+
+    def __init__(self, engine, lr, momentum=0.0, nesterov=False):
+        self.engine, self.lr, self.momentum, self.nesterov = engine, lr, momentum, nesterov
+        self.param_groups = [{'lr': lr}]
+        self.buf = torch.zeros_like(engine.params) if momentum != 0 else None
+        self.first = True
+
+    def zero_grad(self):
+        pass                                   # run_batch overwrites every gradient
+
+    def step(self):
+        e = self.engine
+        e.sgd_step(e.params, e.grads, self.buf, self.param_groups[0]['lr'], self.momentum, self.nesterov, self.first)
+        self.first = False
+        e.mark_dirty()
+
+    def clip_and_step(self, max_norm):
+        """clip_grad_norm_(max_norm) + `if not isnan(norm): step()` in one pass (fo_meta_interface.py:242-248)."""
+        e = self.engine
+        e.clip_sgd_step(self.buf, max_norm, self.param_groups[0]['lr'], self.momentum, self.nesterov, self.first)
+        self.first = False
+
+    def state_dict(self):
+        return {'buf': None if self.buf is None else self.buf.cpu(), 'first': self.first, 'lr': self.param_groups[0]['lr']}
+
+    def load_state_dict(self, sd):
+        if sd['buf'] is not None:
+            self.buf.copy_(sd['buf'])
+        self.first, self.param_groups[0]['lr'] = sd['first'], sd['lr']
+
+
+class TransformerOptimizer:
+    """Noam learning-rate wrapper (optimizer.py:5-37): lr = k * d_model^-0.5 * min(step^-0.5, step * warmup^-1.5)."""
+
+    def __init__(self, optimizer, k, d_model, warmup_steps=25000):
+        self.optimizer, self.k = optimizer, k
+        self.init_lr = d_model ** (-0.5)
+        self.warmup_steps = warmup_steps
+        self.step_num = 0
+        self.lr = self.init_lr
+
+    def zero_grad(self):
+        self.optimizer.zero_grad()
+
+    def step(self):
+        self._update_lr()
+        self.optimizer.step()
+
+    def _update_lr(self):
+        self.step_num += 1
+        self.lr = self.k * self.init_lr * min(self.step_num ** (-0.5), self.step_num * (self.warmup_steps ** (-1.5)))
+        for g in self.optimizer.param_groups:
+            g['lr'] = self.lr
+
+    def load_state_dict(self, state_dict):
+        self.optimizer.load_state_dict(state_dict)
+
+    def state_dict(self):
+        return self.optimizer.state_dict()
+
+    def set_k(self, k):
+        self.k = k

@@ -1,0 +1,110 @@
+"""Multi-GPU meta-training: accent-tasks sharded one-per-GPU, meta-gradient reduced with RCCL.
+
+The reference is single-process.  FOMAML's tasks inside one meta-step are independent given the
+meta weights (src/fo_meta_interface.py:139-156), so rank r runs the tasks  task_ids[r::world]  of the meta-batch
+and the only exchange is ONE all-reduce(sum) of the flat meta-gradient (24.88 M fp32 = 99.5 MB for hkust), after
+which every rank applies the identical Noam-Adam step (replicated state, no broadcast).
+
+Overlap (SURVEY 8(e) option (i)): when a rank owns >= 2 tasks of a meta-step, each task's clipped gradient is
+all-reduced on a side HIP stream while the next task's inner loop runs on the main stream -- all tasks of a
+meta-step read the same meta weights, so nothing is stale.  xGMI is point-to-point, so the payload goes out as a
+few large chunks (ring all-reduce is per-link bound) rather than per-tensor buckets.
+
+Backends: "nccl" (= RCCL on ROCm) on GPUs, "gloo" on CPU tensors (tests, world_size 2).
+"""
+import os
+import random
+
+import torch
+
+
+class TaskSharder:
+    def __init__(self, rank=0, world=1, backend=None):
+        self.rank, self.world, self.backend = rank, world, backend
+        self._side = None
+        self._pending = []
+
+    @classmethod
+    def from_env(cls):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return cls(dist.get_rank(), dist.get_world_size(), dist.get_backend())
+        return cls()
+
+    @staticmethod
+    def init_process_group(backend=None):
+        """one process per GPU; reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment."""
+        import torch.distributed as dist
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world <= 1 or dist.is_initialized():
+            return
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            local = int(os.environ.get("LOCAL_RANK", "0"))
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
+
+    # ------------------------------------------------------------------ task assignment
+    def task_rng(self, seed):
+        """Task order must be identical on every rank.  The reference shuffles with the global `random` stream
+        (fo_meta_interface.py:136), which data-loader re-creation also consumes at rank-dependent times, so in
+        multi-rank runs a dedicated generator is used; world_size 1 keeps the global stream (bit parity)."""
+        return random if self.world == 1 else random.Random(seed)
+
+    def my_tasks(self, meta_batch):
+        """tasks of this meta-step owned by this rank: round-robin over the (rank-identical) shuffled list"""
+        return list(meta_batch[self.rank::self.world])
+
+    def owned_accents(self, num_tasks, meta_batch_size):
+        """with meta_batch_size == num_tasks every accent can land on any rank over time -> all shards stay open"""
+        return None
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    # ------------------------------------------------------------------ meta-gradient exchange
+    def _side_stream(self, device):
+        if self._side is None and device.type == "cuda":
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
+
+    def reduce_async(self, buf):
+        """all-reduce(sum) `buf` in place, overlapped with whatever the caller enqueues next on the main stream.
+        The caller must not touch `buf` until wait_all()."""
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        if buf.device.type == "cuda":
+            side = self._side_stream(buf.device)
+            side.wait_stream(torch.cuda.current_stream(buf.device))
+            with torch.cuda.stream(side):
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+            self._pending.append((work, side))
+        else:
+            self._pending.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), None))
+
+    def wait_all(self):
+        for work, side in self._pending:
+            work.wait()
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+        self._pending = []
+
+    def all_reduce(self, buf):
+        self.reduce_async(buf)
+        self.wait_all()
+
+    def all_reduce_scalar_sum(self, x: float) -> float:
+        if self.world == 1:
+            return x
+        import torch.distributed as dist
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        return float(t.item())

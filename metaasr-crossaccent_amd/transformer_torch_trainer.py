@@ -1,0 +1,86 @@
+"""get_trainer(cls, config, paras, id2accent): the Trainer mixin of the reference
+(src/transformer_torch_trainer.py:13-107) over the HIP engine.  Same contract: builds
+`class TransformerTrainer(cls)` at run time, provides set_model / exec / run_batch / probe_model."""
+import torch
+
+from .marcos import IGNORE_ID
+from .model import MyTransformer
+from .optimizer import FlatAdam, FlatSGD, TransformerOptimizer
+from .monitor import logger
+
+
+def get_trainer(cls, config, paras, id2accent):
+    logger.notice("Transformer Trainer Init...")
+
+    class TransformerTrainer(cls):
+        def __init__(self, config, paras, id2accent):
+            super().__init__(config, paras, id2accent)
+
+        def set_model(self):
+            mp = self.config['asr_model']
+            self.label_smooth_rate = self.config['solver']['label_smoothing']
+            device = getattr(self.paras, 'device', None) or "cuda:0"
+            self.asr_model = MyTransformer(self.id2ch, mp, self.label_smooth_rate, device=device).cuda()
+            eng = self.asr_model.engine
+            eng.set_seed(getattr(self.paras, 'seed', 531))
+            if 'inner_optimizer_cls' not in mp:                              # multi-task or mono (:27)
+                cls_name = mp['optimizer_cls']
+                if cls_name == 'noam':
+                    self.asr_opt = TransformerOptimizer(FlatAdam(eng, eng.params, betas=(0.9, 0.98), eps=1e-09),
+                                                        mp['optimizer_opt']['k'], mp['d_model'], mp['optimizer_opt']['warmup_steps'])
+                elif cls_name == 'SGD':
+                    o = mp['optimizer_opt']
+                    self.asr_opt = FlatSGD(eng, o['lr'], o.get('momentum', 0.0), o.get('nesterov', False))
+                elif cls_name in ('Adam', 'AdamW'):
+                    o = mp['optimizer_opt']
+                    if cls_name == 'AdamW' or o.get('weight_decay', 0):
+                        raise NotImplementedError("weight decay is not built into the flat Adam kernel yet")
+                    opt = FlatAdam(eng, eng.params, betas=tuple(o.get('betas', (0.9, 0.999))), eps=o.get('eps', 1e-8), lr=o.get('lr', 1e-3))
+                    self.asr_opt = opt
+                else:
+                    raise NotImplementedError(f"optimizer_cls {cls_name} (reference: getattr(torch.optim, cls) / torch_optimizer.RAdam)")
+            else:
+                logger.notice("During meta-training, model optimizer will reset after running each task")
+            self.sos_id, self.eos_id = self.asr_model.sos_id, self.asr_model.eos_id
+            super().load_model()
+
+        def exec(self):
+            self.train()
+
+        def run_batch(self, cur_b, x, ilens, ys, olens, train, accent_idx=None):
+            """forward + label-smoothed CE + (train) backward, gradients left in engine.grads
+            (reference :59-99).  One host sync (read_stats) instead of the reference's three .item() calls."""
+            eng = self.asr_model.engine
+            eng.run_batch(x, ilens, ys, olens, train=train)
+            olens += 1                                                        # quirk Q6 (mono_transformer_torch.py:139)
+            st = eng.read_stats()
+            info = {'loss': st['loss'], 'acc': st['n_correct'] / st['n_total']}
+            if train:
+                if self.global_step % 500 == 0:
+                    self.probe_model(accent_idx)
+            else:
+                pred, gold = eng.last_logits()
+                pred, gold = pred.cpu(), gold.cpu().to(torch.int64)
+                info['cer'] = self.metric_observer.batch_cal_er(pred, gold, ['att'], ['cer'])['att_cer']
+                info['wer'] = self.metric_observer.batch_cal_er(pred, gold, ['att'], ['wer'])['att_wer']
+            return info
+
+        def opt_step(self):
+            """asr_opt.step() with the engine's flat gradient attached (torch optimisers read p.grad implicitly)"""
+            inner = self.asr_opt.optimizer if isinstance(self.asr_opt, TransformerOptimizer) else self.asr_opt
+            if isinstance(inner, FlatAdam):
+                inner.grad = self.asr_model.engine.grads
+            self.asr_opt.step()
+
+        def clip_grad_norm_(self, max_norm):
+            """nn.utils.clip_grad_norm_(self.asr_model.parameters(), max_norm) -> python float (host sync)."""
+            eng = self.asr_model.engine
+            eng.clip_grads(max_norm)
+            return eng.read_stats()['grad_norm']
+
+        def probe_model(self, accent_idx):
+            pred, gold = self.asr_model.engine.last_logits()
+            p0, g0 = torch.argmax(pred[0].cpu(), dim=-1), gold[0].cpu().to(torch.int64)
+            logger.log(f"probe cer {self.metric_observer.cal_att_cer(p0, g0):.2f} wer {self.metric_observer.cal_att_wer(p0, g0):.2f}", prefix='debug')
+
+    return TransformerTrainer(config, paras, id2accent)

@@ -1,0 +1,138 @@
+"""CPU tests of the host mirror (no GPU): data path vs goldens captured from the reference, Noam schedule,
+init replay, masks, metric, parameter table, and that libmasr.so exports every symbol of include/masr.h."""
+import ctypes
+import random
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import masr_amd
+from masr_amd import _cabi
+from masr_amd.io.dataset import BucketSampler, DataContainer, collate_fn, get_loader
+from masr_amd.model import reference_init_state_dict
+from masr_amd.monitor.metric import levenshtein
+from masr_amd.nets_utils import generate_square_subsequent_mask, make_bool_pad_mask
+from masr_amd.optimizer import TransformerOptimizer
+from oracle.make_goldens import TINY, flat_checks, write_toy_shard
+
+REPO = Path(__file__).resolve().parents[1]
+HK = dict(idim=83, nheads=8, d_model=512, d_inner=2048, dropout=0.1, pos_dropout=0.1, tgt_share_weight=1,
+          encoder=dict(nlayers=2), decoder=dict(nlayers=4))
+
+
+def test_cabi_exports_every_declared_symbol():
+    """include/masr.h <-> libmasr.so <-> ctypes table (load + symbol lookup only, no compute)."""
+    hdr = (REPO / "include" / "masr.h").read_text()
+    declared = set(re.findall(r"\b(masr_[a-z0-9_]+)\s*\(", hdr))
+    lib = ctypes.CDLL(str(_cabi.LIB_PATH))
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in masr.h but not exported"
+    assert declared == set(_cabi.EXPORTS), declared ^ set(_cabi.EXPORTS)
+    assert _cabi.lib().masr_version() >= 1
+
+
+def test_param_table_matches_reference_state_dict(golden_dir):
+    g = np.load(golden_dir / "init.npz")
+    l = _cabi.lib()
+    for tag, cfg in (("tiny", TINY), ("hkust", HK)):
+        c = _cabi.MasrConfig(cfg["idim"], 367, cfg["d_model"], cfg["nheads"], cfg["d_inner"], cfg["encoder"]["nlayers"],
+                             cfg["decoder"]["nlayers"], 1, 0.0, 0.0, 0.0)
+        h = l.masr_create(ctypes.byref(c))
+        names = []
+        name = ctypes.create_string_buffer(256); shape = (ctypes.c_int64 * 4)(); nd = ctypes.c_int(); off = ctypes.c_int64()
+        for i in range(l.masr_param_count(h)):
+            assert l.masr_param_info(h, i, name, 256, shape, ctypes.byref(nd), ctypes.byref(off)) == 0
+            names.append(name.value.decode())
+        ref = [k for k in g[f"{tag}/keys"] if k not in ("pos_encoder.pe", "pre_embed.weight")]
+        assert names == ref
+        assert int(l.masr_param_numel(h)) == int(g[f"{tag}/nparams"])
+        l.masr_destroy(h)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "hkust"])
+def test_init_replay_matches_reference_seed_531(golden_dir, tag):
+    g = np.load(golden_dir / "init.npz")
+    torch.manual_seed(531)
+    sd = reference_init_state_dict(TINY if tag == "tiny" else HK, 367)
+    for n, t in sd.items():
+        np.testing.assert_allclose(flat_checks(t), g[f"{tag}/fp/{n}"], rtol=1e-6, atol=1e-9, err_msg=n)
+
+
+def test_masks_and_noam(golden_dir):
+    g = np.load(golden_dir / "masks_noam.npz")
+    np.testing.assert_array_equal(make_bool_pad_mask(torch.tensor([7, 3, 5])).numpy(), g["pad_mask"])
+    np.testing.assert_array_equal(generate_square_subsequent_mask(5).numpy(), g["causal5"])
+
+    class _Opt:
+        param_groups = [{"lr": 0.0}]
+        def step(self): pass
+        def zero_grad(self): pass
+    for key, (k, d, w) in {"noam_lr_512_25000": (1.0, 512, 25000), "noam_lr_64_4_k0.7": (0.7, 64, 4)}.items():
+        o = TransformerOptimizer(_Opt(), k, d, w)
+        lrs = []
+        for _ in range(12):
+            o.step()
+            lrs.append(o.lr)
+        np.testing.assert_allclose(lrs, g[key], rtol=1e-12)
+
+
+def test_bucket_sampler_matches_reference(golden_dir):
+    g = np.load(golden_dir / "bucket_sampler.npz")
+    random.seed(531); np.random.seed(531)
+    s = BucketSampler(g["ilens"], min_ilen=10, max_ilen=50, half_batch_ilen=30, batch_size=4)
+    for ep in range(2):
+        batches = list(iter(s))
+        np.testing.assert_array_equal(np.array([i for b in batches for i in b]), g[f"epoch{ep}_flat"])
+        np.testing.assert_array_equal(np.array([len(b) for b in batches]), g[f"epoch{ep}_sizes"])
+    assert len(s) == int(g["len"])
+
+
+def test_data_container_replays_reference_batches(golden_dir, tmp_path):
+    """DataContainer + get_loader + BucketSampler + collate_fn feed the FOMAML loop the same batches, in the same
+    order, as the reference did in the golden run (2 accents, meta_k 2, 2 meta-steps)."""
+    g = np.load(golden_dir / "fomaml_toy.npz")
+    for ai, a in enumerate(["african", "australia"]):
+        write_toy_shard(tmp_path, a, "train", 16, seed=100 + ai)
+        write_toy_shard(tmp_path, a, "dev", 4, seed=200 + ai)
+    random.seed(531); np.random.seed(531)
+    dc = DataContainer([tmp_path / "african", tmp_path / "australia"], batch_size=4, dev_batch_size=4, is_memmap=True,
+                       is_bucket=True, min_ilen=10, max_ilen=50, half_batch_ilen=30)
+    task_ids = [0, 1]
+    call = 0
+    for _ in range(2):
+        random.shuffle(task_ids)
+        for ai in task_ids[:2]:
+            for acc, (x, il, ys, ol) in dc.get_item(ai, 2) + dc.get_item(ai):
+                assert int(acc) == int(g[f"call{call}/accent"])
+                np.testing.assert_array_equal(il.numpy(), g[f"call{call}/ilens"])
+                np.testing.assert_array_equal(ol.numpy(), g[f"call{call}/olens"])
+                np.testing.assert_array_equal(np.concatenate([y.numpy() for y in ys]), g[f"call{call}/ys"])
+                np.testing.assert_allclose(flat_checks(x), g[f"call{call}/x_fp"], rtol=1e-6)
+                call += 1
+    assert call == int(g["n_calls"])
+
+
+def test_collate_sorts_and_pads():
+    items = [{"feat": torch.ones(n, 3) * n, "ilen": torch.tensor(n), "label": torch.arange(n % 4 + 1), "olen": torch.tensor(n % 4 + 1)}
+             for n in (5, 9, 7)]
+    xs, il, ys, ol = collate_fn(items)
+    assert il.tolist() == [9, 7, 5] and xs.shape == (3, 9, 3)
+    assert torch.all(xs[1, 7:] == 0) and torch.all(xs[1, :7] == 7)
+    assert [len(y) for y in ys] == ol.tolist()
+
+
+def test_edge_buckets_are_dropped_like_the_reference():
+    # utterances at/below min_ilen or above max_ilen-2 fall in the first/last bin, which the reference never iterates
+    random.seed(0); np.random.seed(0)
+    s = BucketSampler(np.array([10, 11, 48, 49, 50, 200]), min_ilen=10, max_ilen=50, half_batch_ilen=30, batch_size=4)
+    kept = sorted(i for b in s for i in b)
+    assert kept == [1, 2]
+
+
+def test_levenshtein():
+    assert levenshtein("kitten", "sitting") == 3
+    assert levenshtein([], [1, 2]) == 2
+    assert levenshtein(["a", "b"], ["a", "b"]) == 0
