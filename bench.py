@@ -64,10 +64,23 @@ def fwd_flops_per_utt(T, D, L=31, E=512, F=2048, NE=2, ND=4, C=367):
     return conv + v2e + enc + dec + 2 * L * E * C
 
 
+def host_cores():
+    """cores this job may actually use: affinity mask capped by the cgroup CPU quota (a GPU box hands one GPU's job
+    a 16-core share of a much larger host; spawning one thread per visible core thrashes)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("MASR_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(cfg, B, T, D, steps=2):
     """The oracle's inner step (fp32 torch on the host cores) on a bounded sample of the same workload."""
     from oracle import ref_cpu
-    n = len(os.sched_getaffinity(0))
+    n = host_cores()
     torch.set_num_threads(n)
     c = dict(cfg)
     c["dropout"] = c["pos_dropout"] = 0.0            # the oracle is the dropout-free restatement
