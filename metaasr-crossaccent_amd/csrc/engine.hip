@@ -61,7 +61,9 @@ struct Acts {
     bf16 *ge16, *gd16, *gqkv_e, *gqkv_d, *gf_e, *gf_d, *gao_e, *gao_d, *gq_d, *gkv_d, *dp2, *da4, *da3, *dp1, *da2, *da1;
     float *delta_e, *delta_d;
     float* slab; int64_t slab_floats;
+    float* wg_slab;                                        // split-K partials: (WG_SPLIT-1) x nparams
 };
+constexpr int WG_SPLIT = 4;
 
 }  // namespace
 
@@ -73,6 +75,8 @@ struct masr_model {
     float *P = nullptr, *G = nullptr; const float* pe = nullptr;
     char* ws = nullptr; int64_t ws_bytes = 0, persist_bytes = 0;
     bf16 *v2e_k = nullptr;                    // permuted vgg2enc weight (NHWC feature order)
+    long* d_ranges = nullptr; int nranges = 0;            // split-K combine table: (offset, length) of every Linear weight / bias
+    ShadowDesc* d_sdesc = nullptr; bf16** d_sptrs = nullptr; int nsdesc = 0, shadow_tiles = 0;
     float* stats = nullptr;                   // device [8]: loss, n_correct, n_total, grad_norm
     float* h_stats = nullptr;                 // pinned
     int* h_stage = nullptr; int64_t stage_ints = 0; int stage_slot = 0; hipEvent_t stage_ev[4];
@@ -127,6 +131,10 @@ void plan_persistent(masr_model* m, Arena& ar) {
     for (auto& e : m->enc) { lin(e.sa.in); lin(e.sa.out); lin(e.l1); lin(e.l2); }
     for (auto& d : m->dec) { lin(d.sa.in); lin(d.sa.out); lin(d.ca.in); lin(d.ca.out); lin(d.l1); lin(d.l2); }
     m->stats = ar.get<float>(64);
+    const int nlin = (int)(m->enc.size() * 4 + m->dec.size() * 6);
+    m->d_ranges = ar.get<long>(2 * (2 * nlin + 2));
+    m->d_sdesc = ar.get<ShadowDesc>(nlin);
+    m->d_sptrs = ar.get<bf16*>(2 * nlin);
 }
 
 // ------------------------------------------------------------------ activation plan
@@ -174,6 +182,7 @@ void plan_acts(const masr_model* m, Arena& ar, Acts& a, int B, int T, int L, boo
     mx(mk_conv3x3_wgrad_slab_floats(B, a.H2, a.W2, 128, 128));
     a.slab_floats = sl; a.slab = ar.get<float>(sl);
     if (train) {
+        a.wg_slab = ar.get<float>((int64_t)(WG_SPLIT - 1) * m->nparams);
         a.ge_a = ar.get<float>(re * E); a.ge_b = ar.get<float>(re * E); a.gd_a = ar.get<float>(rd * E); a.gd_b = ar.get<float>(rd * E);
         a.dmem32 = ar.get<float>(re * E); a.v2e_g32 = ar.get<float>((int64_t)E * m->F);
         a.ge16 = ar.get<bf16>(re * E); a.gd16 = ar.get<bf16>(rd * E);
@@ -223,6 +232,10 @@ int lin_wgrad(Ctx& c, const bf16* dy, long lddy, const bf16* x, long ldx, int ro
     GemmArgs g = gemm_args();
     g.reduction_major = 1; g.A = dy; g.lda = lddy; g.B = x; g.ldb = ldx; g.M = N; g.N = K; g.K = rows;
     g.C32 = dW; g.ldc = K; g.accumulate = accumulate; g.colsum = db;
+    masr_model* m = c.m;
+    if (dW >= m->G && dW < m->G + m->nparams) {           // gradient lives in the flat buffer -> split-K with slab partials
+        g.split_k = WG_SPLIT; g.split_delta = m->acts.wg_slab - m->G; g.split_stride = m->nparams;
+    }
     CK(gemm(c, g));
     return 0;
 }
@@ -392,6 +405,25 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
         HIP_CHECK_RET(hipHostMalloc((void**)&m->h_stats, sizeof(float) * 64, hipHostMallocDefault));
         for (auto& e : m->stage_ev) HIP_CHECK_RET(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
+    {   // device tables: split-K combine ranges and the fused shadow-refresh descriptors
+        std::vector<long> ranges; std::vector<ShadowDesc> desc; std::vector<bf16*> ptrs;
+        int tiles = 0;
+        auto lin = [&](const Lin& l) {
+            ranges.push_back(l.w); ranges.push_back((long)l.N * l.K);
+            ranges.push_back(l.b); ranges.push_back(l.N);
+            ShadowDesc d; d.src = l.w; d.N = l.N; d.K = l.K; d.Np = (l.N + 7) / 8 * 8; d.tile_start = tiles;
+            tiles += ((l.N + 31) / 32) * ((l.K + 31) / 32);
+            desc.push_back(d); ptrs.push_back(l.k16); ptrs.push_back(l.t16);
+        };
+        for (auto& e : m->enc) { lin(e.sa.in); lin(e.sa.out); lin(e.l1); lin(e.l2); }
+        for (auto& d : m->dec) { lin(d.sa.in); lin(d.sa.out); lin(d.ca.in); lin(d.ca.out); lin(d.l1); lin(d.l2); }
+        ranges.push_back(m->ct.w); ranges.push_back((long)m->C * m->E);
+        ranges.push_back(m->ct.b); ranges.push_back(m->C);
+        m->nranges = (int)ranges.size() / 2; m->nsdesc = (int)desc.size(); m->shadow_tiles = tiles;
+        HIP_CHECK_RET(hipMemcpy(m->d_ranges, ranges.data(), sizeof(long) * ranges.size(), hipMemcpyHostToDevice));
+        HIP_CHECK_RET(hipMemcpy(m->d_sdesc, desc.data(), sizeof(ShadowDesc) * desc.size(), hipMemcpyHostToDevice));
+        HIP_CHECK_RET(hipMemcpy(m->d_sptrs, ptrs.data(), sizeof(bf16*) * ptrs.size(), hipMemcpyHostToDevice));
+    }
     m->have_acts = false;
     return 0;
 }
@@ -410,14 +442,7 @@ int masr_refresh(masr_model* m, void* stream) {
     CK(mk_vgg2enc_shadows(P + m->v2e.w, m->v2e_k, m->v2e.t16, m->E, 128, m->Dp, s));
     CK(mk_cast_bf16(P + m->ct.w, m->ct.k16, (long)m->C * m->E, s));
     CK(mk_transpose_cast_bf16(P + m->ct.w, m->ct.t16, m->C, m->E, m->Cp, s));
-    auto lin = [&](Lin& l) -> int {
-        const int Np = (l.N + 7) / 8 * 8;
-        CK(mk_cast_bf16(P + l.w, l.k16, (long)l.N * l.K, s));
-        CK(mk_transpose_cast_bf16(P + l.w, l.t16, l.N, l.K, Np, s));
-        return 0;
-    };
-    for (auto& e : m->enc) { CK(lin(e.sa.in)); CK(lin(e.sa.out)); CK(lin(e.l1)); CK(lin(e.l2)); }
-    for (auto& d : m->dec) { CK(lin(d.sa.in)); CK(lin(d.sa.out)); CK(lin(d.ca.in)); CK(lin(d.ca.out)); CK(lin(d.l1)); CK(lin(d.l2)); }
+    CK(mk_linear_shadows(P, m->d_sdesc, m->d_sptrs, m->nsdesc, m->shadow_tiles, s));
     return 0;
 }
 
@@ -545,8 +570,7 @@ static int backward(Ctx& c, const float* xs) {
         CK(attn_block_bwd(c, w.sa, a.y16[l], nullptr, a.rows_d, 0, L, L, true, true, nullptr, d.qkv, nullptr, d.ao, d.lse_s, gs, a.gd16,
                           a.gao_d, a.gqkv_d, nullptr, a.delta_d, gcur, nullptr, 0, d.site[0]));
     }
-    { Prof p(m, MASR_PROF_OTHER, s);
-      CK(mk_embed_bwd(a.tok_in, gcur, G + m->embed_w, a.rows_d, m->C, E, m->cfg.tie_weights ? 1 : 0, c.p_pos, c.seed, a.site_emb, s)); }
+    float* g_dec_in = gcur;                                  // d(decoder input): consumed by embed_bwd after the split-K combine
     // ---- encoder
     gcur = a.ge_b; gs = a.ge_a;
     CK(ln_bwd(c, m->enc_norm, a.dmem32, a.x32[m->NE], a.mf, a.rf, gcur, nullptr, 0, a.rows_e));
@@ -587,6 +611,10 @@ static int backward(Ctx& c, const float* xs) {
     CK(wgrad(a.a1, a.da2, m->conv[1], a.T, a.D, P1));
     CK(dgrad(a.da2, m->conv[1], a.a1, a.da1, a.T, a.D));
     { Prof p(m, MASR_PROF_CONV_WGRAD, s); CK(mk_conv1_wgrad(xs, a.da1, G + m->conv[0].w, G + m->conv[0].b, a.slab, B, a.T, a.D, s)); }
+    // ---- combine the split-K partials of all Linear gradients, then add the embedding rows into the (tied) table
+    { Prof p(m, MASR_PROF_OTHER, s);
+      CK(mk_split_reduce(G, a.wg_slab, WG_SPLIT - 1, m->nparams, m->d_ranges, m->nranges, s));
+      CK(mk_embed_bwd(a.tok_in, g_dec_in, G + m->embed_w, a.rows_d, m->C, E, m->cfg.tie_weights ? 1 : 0, c.p_pos, c.seed, a.site_emb, s)); }
     return 0;
 }
 

@@ -130,9 +130,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const bool do_colsum = RM && g.colsum && blockIdx.x == 0;
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (g.K + BK - 1) / BK;
-    sa.load(g.A, g.lda, m0, 0, g.M, g.K, tid);
-    sb.load(g.B, g.ldb, n0, 0, g.N, g.K, tid);
+    // split-K (wgrad form): this workgroup reduces rows [kbeg, kend) of the reduction index
+    int kbeg = 0, kend = g.K;
+    long out_delta = 0;
+    if (RM && g.split_k > 1) {
+        const int per = ((g.K + g.split_k - 1) / g.split_k + BK - 1) / BK * BK;
+        kbeg = blockIdx.z * per;
+        kend = kbeg + per < g.K ? kbeg + per : g.K;
+        if (blockIdx.z > 0) out_delta = g.split_delta + (long)(blockIdx.z - 1) * g.split_stride;
+    }
+    const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+    sa.load(g.A, g.lda, m0, kbeg, g.M, kend, tid);
+    sb.load(g.B, g.ldb, n0, kbeg, g.N, kend, tid);
     if constexpr (RM) { if (do_colsum) sa.accumulate(csum); }
     sa.store(sa_[0].d, tid);
     sb.store(sb_[0].d, tid);
@@ -141,8 +150,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            sa.load(g.A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid);
-            sb.load(g.B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid);
+            sa.load(g.A, g.lda, m0, kbeg + (kt + 1) * BK, g.M, kend, tid);
+            sb.load(g.B, g.ldb, n0, kbeg + (kt + 1) * BK, g.N, kend, tid);
         }
         bf16x8 af[FM], bfr[FN];
         if (RM) {
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 const int rc = tid / 8, j = tid % 8;
                 float sum = 0.f;
                 for (int t = rc; t < 256; t += RC) sum += red[t * 8 + j];
-                if (m0 + tid < g.M) g.colsum[m0 + tid] = sum;
+                if (m0 + tid < g.M) g.colsum[out_delta + m0 + tid] = sum;
             }
             __syncthreads();
         }
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 if (g.drop_p > 0.f) v *= dropout_scale(g.seed, g.site, (uint32_t)((long)m * g.N + n), g.drop_p, inv_keep);
                 if (g.residual) v += g.residual[(long)m * g.ldres + n];
                 if (g.C32) {
-                    float* p = g.C32 + (long)m * g.ldc + n;
+                    float* p = g.C32 + out_delta + (long)m * g.ldc + n;
                     if (g.accumulate) v += *p;
                     *p = v;
                 }
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
 template <int BM, int BN>
 int launch_tile(const GemmArgs& g, hipStream_t s) {
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, (g.reduction_major && g.split_k > 1) ? g.split_k : 1);
     if (g.reduction_major)
         hipLaunchKernelGGL((gemm_kernel<BM, BN, true>), grid, dim3(256), 0, s, g);
     else
@@ -243,7 +252,10 @@ int mk_gemm(const GemmArgs& g, hipStream_t s) {
         mk_set_error("mk_gemm", "reduction-major form needs lda >= roundup8(M), ldb >= roundup8(N)");
         return -1;
     }
-    const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    if (tiles128 >= 192) return launch_tile<128, 128>(g, s);
+    // largest tile that still yields roughly one workgroup per CU (256 CUs)
+    const long z = (g.reduction_major && g.split_k > 1) ? g.split_k : 1;
+    auto wgs = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * z; };
+    if (wgs(128, 128) >= 192) return launch_tile<128, 128>(g, s);
+    if (wgs(128, 64) >= 192) return launch_tile<128, 64>(g, s);
     return launch_tile<64, 64>(g, s);
 }

@@ -18,6 +18,8 @@ struct GemmArgs {
     float drop_p; uint32_t seed, site;                 // dropout on element index m*N+n
     const float* residual; long ldres;                 // + residual[m*ldres + n]
     float* colsum;                // reduction-major only: colsum[m] = sum_k A(m,k) (fused bias gradient) or null
+    int split_k;                  // reduction-major only: >1 splits the reduction over gridDim.z workgroups; split 0 writes
+    long split_delta, split_stride;   // C32/colsum, split z>0 writes the same addresses + split_delta + (z-1)*split_stride
     int accumulate;               // C32 += v
     float* C32; long ldc;         // fp32 output or null
     bf16* C16; long ldc16;        // bf16 output or null
@@ -97,6 +99,11 @@ int mk_axpy(float* y, const float* x, long n, float a, hipStream_t s);
 int mk_cast_bf16(const float* x, bf16* y, long n, hipStream_t s);
 int mk_transpose_cast_bf16(const float* x /*[R][C]*/, bf16* y /*[C][ldy]*/, int R, int C, long ldy, hipStream_t s);
 // conv weight shadows: w [CO][CI][3][3] fp32 -> wk [CO][tap*CI+ci] (fwd) and wd [CI][tap'*CO+co] = w[co][ci][8-tap'] (dgrad)
+// G[i] += sum_{s<nslab} slab[s*stride + i] over the listed (offset, length) ranges (deterministic split-K combine)
+int mk_split_reduce(float* G, const float* slab, int nslab, long stride, const long* ranges, int nranges, hipStream_t s);
+// all Linear-layer shadows in one launch: desc[i] = {src offset, N, K, Np, tile_start}, ptrs[2i] = k16, ptrs[2i+1] = t16
+struct ShadowDesc { long src; int N, K, Np, tile_start; };
+int mk_linear_shadows(const float* P, const ShadowDesc* desc, bf16* const* ptrs, int ndesc, int total_tiles, hipStream_t s);
 int mk_conv_weight_shadows(const float* w, bf16* wk, bf16* wd, int CO, int CI, hipStream_t s);
 // vgg2enc weight [E][128*Dp] with reference feature index c*Dp+d  ->  bf16 [E][d*128+c] (NHWC order) and transpose
 int mk_vgg2enc_shadows(const float* w, bf16* wk, bf16* wt, int E, int C, int Dp, hipStream_t s);

@@ -149,6 +149,38 @@ __global__ void vgg2enc_unpermute_kernel(const float* __restrict__ g, float* __r
     dw[i] = g[(long)e * F + d * C + c];
 }
 
+__global__ void split_reduce_kernel(float* __restrict__ G, const float* __restrict__ slab, int nslab, long stride,
+                                    const long* __restrict__ ranges) {
+    const long off = ranges[2 * blockIdx.y], len = ranges[2 * blockIdx.y + 1];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (long)gridDim.x * blockDim.x) {
+        float v = G[off + i];
+        for (int s = 0; s < nslab; ++s) v += slab[(long)s * stride + off + i];
+        G[off + i] = v;
+    }
+}
+// every Linear weight -> bf16 copy [N][K] and bf16 transpose [K][Np], one 32x32 tile per workgroup
+__global__ __launch_bounds__(256) void linear_shadows_kernel(const float* __restrict__ P, const ShadowDesc* __restrict__ desc,
+                                                             bf16* const* __restrict__ ptrs, int ndesc) {
+    int e = 0;
+    while (e + 1 < ndesc && (int)blockIdx.x >= desc[e + 1].tile_start) ++e;
+    const ShadowDesc d = desc[e];
+    const int tile = blockIdx.x - d.tile_start, tc = (d.K + 31) / 32;
+    const int r0 = (tile / tc) * 32, c0 = (tile % tc) * 32;
+    const float* x = P + d.src;
+    bf16* k16 = ptrs[2 * e]; bf16* t16 = ptrs[2 * e + 1];
+    __shared__ float t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const bool ok = r0 + k < d.N && c0 + tx < d.K;
+        const float v = ok ? x[(long)(r0 + k) * d.K + c0 + tx] : 0.f;
+        t[k][tx] = v;
+        if (ok) k16[(long)(r0 + k) * d.K + c0 + tx] = (bf16)v;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (c0 + k < d.K && r0 + tx < d.N) t16[(long)(c0 + k) * d.Np + r0 + tx] = (bf16)t[tx][k];
+}
+
 inline unsigned flat_blocks(long n) {
     long b = (n + 255) / 256;
     return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -197,6 +229,15 @@ int mk_cast_bf16(const float* x, bf16* y, long n, hipStream_t s) {
 }
 int mk_transpose_cast_bf16(const float* x, bf16* y, int R, int C, long ldy, hipStream_t s) {
     hipLaunchKernelGGL(transpose_cast_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, s, x, y, R, C, ldy);
+    return LAUNCH_OK();
+}
+int mk_split_reduce(float* G, const float* slab, int nslab, long stride, const long* ranges, int nranges, hipStream_t s) {
+    if (nslab <= 0 || nranges <= 0) return 0;
+    hipLaunchKernelGGL(split_reduce_kernel, dim3(64, nranges), dim3(256), 0, s, G, slab, nslab, stride, ranges);
+    return LAUNCH_OK();
+}
+int mk_linear_shadows(const float* P, const ShadowDesc* desc, bf16* const* ptrs, int ndesc, int total_tiles, hipStream_t s) {
+    hipLaunchKernelGGL(linear_shadows_kernel, dim3(total_tiles), dim3(256), 0, s, P, desc, ptrs, ndesc);
     return LAUNCH_OK();
 }
 int mk_conv_weight_shadows(const float* w, bf16* wk, bf16* wd, int CO, int CI, hipStream_t s) {
