@@ -21,36 +21,41 @@
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDK = 40;   // NT form: padded LDS row (elements), 80-byte stride
+constexpr int BK = 64;    // k-tile: halves the barrier / LDS round trips per FLOP of the 32-deep version
+constexpr int LDK = 72;   // NT form: padded LDS row (elements), 144-byte stride (16 rows -> 16 distinct 16-byte slots)
 
 template <int ROWS>
 struct TileNT { bf16 d[ROWS * LDK]; };
 template <int ROWS>
 struct TileRM { bf16 d[BK * (ROWS + 16)]; };   // [k][row], row stride (ROWS+16)*2 B == 8 dwords mod 64
 
+// Loads are UNCONDITIONAL (addresses clamped into the matrix) and the zero-fill of out-of-range chunks is applied
+// when the registers are written to LDS: a branch around a global load makes hipcc fall back to s_waitcnt vmcnt(0)
+// at every join, which serialises the whole prefetch ring.
 // ---- NT stager: element (r,k) at src[r*ld + k]
 template <int ROWS>
 struct StagerNT {
     static constexpr int CHUNKS = ROWS * BK / 8;
-    static constexpr int PT = CHUNKS / 256 > 0 ? CHUNKS / 256 : 1;
+    static constexpr int PT = CHUNKS / 256;
+    static_assert(CHUNKS % 256 == 0, "tile must be a multiple of 256 chunks");
     bf16x8 regs[PT];
+    unsigned ok;
     __device__ __forceinline__ void load(const bf16* __restrict__ src, long ld, int r0, int k0, int nrows, int nk, int tid) {
+        ok = 0;
 #pragma unroll
         for (int i = 0; i < PT; ++i) {
-            int c = tid + i * 256;
-            int r = c >> 2, kc = (c & 3) * 8;
-            bf16x8 v = zero8();
-            if (c < CHUNKS && r0 + r < nrows && k0 + kc < nk) v = ld8(src + (long)(r0 + r) * ld + k0 + kc);
-            regs[i] = v;
+            const int c = tid + i * 256;
+            const int r = r0 + c / (BK / 8), k = k0 + (c % (BK / 8)) * 8;
+            if (r < nrows && k < nk) ok |= 1u << i;
+            const int rc = r < nrows ? r : nrows - 1, kc = k < nk ? k : nk - 8;
+            regs[i] = ld8(src + (long)rc * ld + kc);
         }
     }
     __device__ __forceinline__ void store(bf16* __restrict__ dst, int tid) {
 #pragma unroll
         for (int i = 0; i < PT; ++i) {
-            int c = tid + i * 256;
-            int r = c >> 2, kc = (c & 3) * 8;
-            if (c < CHUNKS) st8(dst + r * LDK + kc, regs[i]);
+            const int c = tid + i * 256;
+            st8(dst + (c / (BK / 8)) * LDK + (c % (BK / 8)) * 8, (ok >> i) & 1 ? regs[i] : zero8());
         }
     }
 };
@@ -60,41 +65,46 @@ struct StagerRM {
     static constexpr int LDT = ROWS + 16;
     static constexpr int RC = ROWS / 8;
     static constexpr int CHUNKS = BK * RC;
-    static constexpr int PT = CHUNKS / 256 > 0 ? CHUNKS / 256 : 1;
+    static constexpr int PT = CHUNKS / 256;
+    static_assert(CHUNKS % 256 == 0, "tile must be a multiple of 256 chunks");
     bf16x8 regs[PT];
+    unsigned ok;
     __device__ __forceinline__ void load(const bf16* __restrict__ src, long ld, int r0, int k0, int nrows, int nk, int tid) {
+        ok = 0;
+        const int rmax = (nrows + 7) / 8 * 8 - 8;              // last 8-row chunk (the padded row exists, see mk_gemm)
 #pragma unroll
         for (int i = 0; i < PT; ++i) {
-            int c = tid + i * 256;
-            int k = c / RC, rc = (c % RC) * 8;
-            bf16x8 v = zero8();
-            if (c < CHUNKS && k0 + k < nk && r0 + rc < nrows) v = ld8(src + (long)(k0 + k) * ld + r0 + rc);
-            regs[i] = v;
+            const int c = tid + i * 256;
+            const int k = k0 + c / RC, r = r0 + (c % RC) * 8;
+            if (k < nk && r < nrows) ok |= 1u << i;
+            const int kc = k < nk ? k : nk - 1, rc = r < nrows ? r : rmax;
+            regs[i] = ld8(src + (long)kc * ld + rc);
         }
     }
     __device__ __forceinline__ void store(bf16* __restrict__ dst, int tid) {
 #pragma unroll
         for (int i = 0; i < PT; ++i) {
-            int c = tid + i * 256;
-            int k = c / RC, rc = (c % RC) * 8;
-            if (c < CHUNKS) st8(dst + k * LDT + rc, regs[i]);
+            const int c = tid + i * 256;
+            st8(dst + (c / RC) * LDT + (c % RC) * 8, (ok >> i) & 1 ? regs[i] : zero8());
         }
     }
     // running column sums of the staged tile (each thread always owns the same 8 rows: 256 % RC == 0)
     __device__ __forceinline__ void accumulate(float (&acc)[8]) {
 #pragma unroll
         for (int i = 0; i < PT; ++i)
+            if ((ok >> i) & 1) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += (float)regs[i][j];
+                for (int j = 0; j < 8; ++j) acc[j] += (float)regs[i][j];
+            }
     }
 };
 
 // fragment of 16 rows starting at r0 from a reduction-major tile (k permuted, see header)
 template <int LDT>
-__device__ __forceinline__ bf16x8 frag_rm(const bf16* tile, int r0, int lane) {
+__device__ __forceinline__ bf16x8 frag_rm(const bf16* tile, int r0, int lane, int k0 = 0) {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
     typedef __attribute__((address_space(3))) bf16x4 lds_b4;
-    const bf16* a0 = tile + (4 * g + q) * LDT + r0 + 4 * p;
+    const bf16* a0 = tile + (k0 + 4 * g + q) * LDT + r0 + 4 * p;
     const bf16* a1 = a0 + 16 * LDT;
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)a0);
     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)a1);
@@ -104,7 +114,12 @@ __device__ __forceinline__ bf16x8 frag_rm(const bf16* tile, int r0, int lane) {
     return f;
 }
 
-template <int BM, int BN, bool RM>
+// EPI >= 0: the set of epilogue features is a compile-time constant (dead paths vanish: the fully generic epilogue is
+// ~2000 instructions, which alone cost ~8 us per launch on the small decoder GEMMs); EPI < 0: decided at run time.
+enum { E_BIAS = 1, E_PE = 2, E_RELU = 4, E_MASK = 8, E_DROP = 16, E_RES = 32, E_ACC = 64, E_C32 = 128, E_C16 = 256 };
+#define HAS(flag, runtime) (EPI >= 0 ? bool(EPI & (flag)) : bool(runtime))
+
+template <int BM, int BN, bool RM, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int FM = WM / 16, FN = WN / 16;
@@ -112,14 +127,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     using TB = typename std::conditional<RM, TileRM<BN>, TileNT<BN>>::type;
     using SA = typename std::conditional<RM, StagerRM<BM>, StagerNT<BM>>::type;
     using SB = typename std::conditional<RM, StagerRM<BN>, StagerNT<BN>>::type;
-    __shared__ __attribute__((aligned(16))) TA sa_[2];
-    __shared__ __attribute__((aligned(16))) TB sb_[2];
+    constexpr int LDC = BN + 4;                                // fp32 output tile row stride (epilogue staging)
+    constexpr size_t TILE_BYTES = 2 * sizeof(TA) + 2 * sizeof(TB), OUT_BYTES = sizeof(float) * BM * LDC;
+    __shared__ __attribute__((aligned(16))) char smem[TILE_BYTES > OUT_BYTES ? TILE_BYTES : OUT_BYTES];
+    TA* sa_ = reinterpret_cast<TA*>(smem);
+    TB* sb_ = reinterpret_cast<TB*>(smem + 2 * sizeof(TA));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
-    SA sa; SB sb;
+    // register ring of DEPTH k-tiles: global loads run DEPTH tiles ahead of the MFMAs (a lone workgroup on a CU has
+    // nothing else to hide the L2/HBM latency with -- this is what the small-M decoder GEMMs are made of)
+    constexpr int DEPTH = 2;
+    SA sa[DEPTH]; SB sb[DEPTH];
     f32x4 acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -140,48 +161,59 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         if (blockIdx.z > 0) out_delta = g.split_delta + (long)(blockIdx.z - 1) * g.split_stride;
     }
     const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
-    sa.load(g.A, g.lda, m0, kbeg, g.M, kend, tid);
-    sb.load(g.B, g.ldb, n0, kbeg, g.N, kend, tid);
-    if constexpr (RM) { if (do_colsum) sa.accumulate(csum); }
-    sa.store(sa_[0].d, tid);
-    sb.store(sb_[0].d, tid);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {                       // (tiles past the end are clamped reads, never stored)
+        sa[d].load(g.A, g.lda, m0, kbeg + d * BK, g.M, kend, tid);
+        sb[d].load(g.B, g.ldb, n0, kbeg + d * BK, g.N, kend, tid);
+    }
+    if constexpr (RM) { if (do_colsum) sa[0].accumulate(csum); }
+    sa[0].store(sa_[0].d, tid);
+    sb[0].store(sb_[0].d, tid);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            sa.load(g.A, g.lda, m0, kbeg + (kt + 1) * BK, g.M, kend, tid);
-            sb.load(g.B, g.ldb, n0, kbeg + (kt + 1) * BK, g.N, kend, tid);
+    for (int kt0 = 0; kt0 < nk; kt0 += DEPTH) {
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            const int kt = kt0 + u;
+            if (kt >= nk) break;
+            const int cur = kt & 1;
+            // tile kt already sits in LDS, so ring slot u is free: refill it with tile kt + DEPTH
+            sa[u].load(g.A, g.lda, m0, kbeg + (kt + DEPTH) * BK, g.M, kend, tid);
+            sb[u].load(g.B, g.ldb, n0, kbeg + (kt + DEPTH) * BK, g.N, kend, tid);
+#pragma unroll
+            for (int kc = 0; kc < BK / 32; ++kc) {
+                bf16x8 af[FM], bfr[FN];
+                if (RM) {
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) af[i] = frag_rm<BM + 16>(sa_[cur].d, wm * WM + i * 16, lane, kc * 32);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) bfr[j] = frag_rm<BN + 16>(sb_[cur].d, wn * WN + j * 16, lane, kc * 32);
+                } else {
+                    const int kq = kc * 32 + (lane >> 4) * 8, rr = lane & 15;
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) af[i] = ld8(&sa_[cur].d[(wm * WM + i * 16 + rr) * LDK + kq]);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) bfr[j] = ld8(&sb_[cur].d[(wn * WN + j * 16 + rr) * LDK + kq]);
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
+            }
+            if (kt + 1 < nk) {
+                const int nx = (u + 1) % DEPTH;        // static after the full unroll
+                if constexpr (RM) { if (do_colsum) sa[nx].accumulate(csum); }
+                sa[nx].store(sa_[cur ^ 1].d, tid);
+                sb[nx].store(sb_[cur ^ 1].d, tid);
+            }
+            __syncthreads();
         }
-        bf16x8 af[FM], bfr[FN];
-        if (RM) {
-#pragma unroll
-            for (int i = 0; i < FM; ++i) af[i] = frag_rm<BM + 16>(sa_[cur].d, wm * WM + i * 16, lane);
-#pragma unroll
-            for (int j = 0; j < FN; ++j) bfr[j] = frag_rm<BN + 16>(sb_[cur].d, wn * WN + j * 16, lane);
-        } else {
-            const int kq = (lane >> 4) * 8, rr = lane & 15;
-#pragma unroll
-            for (int i = 0; i < FM; ++i) af[i] = ld8(&sa_[cur].d[(wm * WM + i * 16 + rr) * LDK + kq]);
-#pragma unroll
-            for (int j = 0; j < FN; ++j) bfr[j] = ld8(&sb_[cur].d[(wn * WN + j * 16 + rr) * LDK + kq]);
-        }
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
-        if (kt + 1 < nk) {
-            if constexpr (RM) { if (do_colsum) sa.accumulate(csum); }
-            sa.store(sa_[cur ^ 1].d, tid);
-            sb.store(sb_[cur ^ 1].d, tid);
-        }
-        __syncthreads();
     }
     if constexpr (RM) {
         if (do_colsum) {
             // threads tid, tid + RC, tid + 2RC ... own the same 8 rows: reduce through LDS (tile buffers are free now)
             constexpr int RC = BM / 8;
-            float* red = reinterpret_cast<float*>(sa_[0].d);          // [256][8] floats = 8 KB <= tile size
+            float* red = reinterpret_cast<float*>(smem);          // [256][8] floats = 8 KB <= tile size
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < 8; ++j) red[tid * 8 + j] = csum[j];
@@ -196,43 +228,121 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         }
     }
 
-    // epilogue: alpha -> bias -> pe -> relu -> mask -> dropout -> residual -> (accumulate) -> store
-    const float inv_keep = g.drop_p > 0.f ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+    // epilogue: alpha -> bias -> pe -> relu -> mask -> dropout -> residual -> (accumulate) -> store.
+    // The accumulators go through an fp32 LDS tile so that every global access of the epilogue is a 16-byte (fp32) or
+    // 8-byte (bf16) row segment, and each optional input is fetched with ONE batched load per 4 outputs (per-element
+    // branches around loads serialise on s_waitcnt vmcnt(0) and used to dominate the small decoder GEMMs).
+    float* ct = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
-            if (m >= g.M) continue;
+        for (int j = 0; j < FN; ++j)
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int n = n0 + wn * WN + j * 16 + (lane & 15);
-                if (n >= g.N) continue;
-                float v = acc[i][j][r] * g.alpha;
-                if (g.bias) v += g.bias[n];
-                if (g.pe) v += g.pe[(long)(m % g.pe_period) * g.N + n];
-                if (g.relu) v = fmaxf(v, 0.f);
-                if (g.mask) v = ((float)g.mask[(long)m * g.ldmask + n] > 0.f) ? v * g.mask_scale : 0.f;
-                if (g.drop_p > 0.f) v *= dropout_scale(g.seed, g.site, (uint32_t)((long)m * g.N + n), g.drop_p, inv_keep);
-                if (g.residual) v += g.residual[(long)m * g.ldres + n];
-                if (g.C32) {
-                    float* p = g.C32 + out_delta + (long)m * g.ldc + n;
-                    if (g.accumulate) v += *p;
-                    *p = v;
-                }
-                if (g.C16) g.C16[(long)m * g.ldc16 + n] = (bf16)v;
-            }
+            for (int r = 0; r < 4; ++r)
+                ct[(wm * WM + i * 16 + (lane >> 4) * 4 + r) * LDC + wn * WN + j * 16 + (lane & 15)] = acc[i][j][r] * g.alpha;
+    __syncthreads();
+    constexpr int C4 = BN / 4, NCH = BM * C4 / 256;
+    const int c4 = (tid % C4) * 4, n = n0 + c4;
+    if (n >= g.N) return;
+    const bool f_bias = HAS(E_BIAS, g.bias), f_pe = HAS(E_PE, g.pe), f_relu = HAS(E_RELU, g.relu), f_mask = HAS(E_MASK, g.mask);
+    const bool f_drop = HAS(E_DROP, g.drop_p > 0.f) && g.drop_p > 0.f, f_res = HAS(E_RES, g.residual);
+    const bool f_acc = HAS(E_ACC, g.accumulate), f_c32 = HAS(E_C32, g.C32), f_c16 = HAS(E_C16, g.C16);
+    const int nv = g.N - n < 4 ? g.N - n : 4;                   // valid columns of this thread's 4-column strip
+    const float inv_keep = f_drop ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (f_bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[n + e];
+    }
+    // 16-byte paths need 4 valid columns and 4-float-aligned rows (n is a multiple of 4 by construction)
+    const bool v_c32 = nv == 4 && f_c32 && !((g.ldc | out_delta) & 3) && !((uintptr_t)g.C32 & 15);
+    const bool v_res = nv == 4 && f_res && !(g.ldres & 3) && !((uintptr_t)g.residual & 15);
+    const bool v_c16 = nv == 4 && f_c16 && !(g.ldc16 & 3) && !((uintptr_t)g.C16 & 7);
+    const bool v_msk = nv == 4 && f_mask && !(g.ldmask & 3) && !((uintptr_t)g.mask & 7);
+    const bool v_pe = nv == 4 && f_pe && !(g.N & 3) && !((uintptr_t)g.pe & 15);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int row = (tid + i * 256) / C4, m = m0 + row;
+        if (m >= g.M) continue;
+        const f32x4 cv = *reinterpret_cast<const f32x4*>(ct + row * LDC + c4);
+        float v[4] = {cv[0] + bv[0], cv[1] + bv[1], cv[2] + bv[2], cv[3] + bv[3]};
+        float rs[4] = {0.f, 0.f, 0.f, 0.f}, old[4] = {0.f, 0.f, 0.f, 0.f}, pev[4] = {0.f, 0.f, 0.f, 0.f};
+        float mk[4] = {1.f, 1.f, 1.f, 1.f};
+        // ---- batched loads of the optional inputs
+        if (f_res) {
+            const float* p = g.residual + (long)m * g.ldres + n;
+            if (v_res) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); rs[0] = t[0]; rs[1] = t[1]; rs[2] = t[2]; rs[3] = t[3]; }
+            else { for (int e = 0; e < nv; ++e) rs[e] = p[e]; }
+        }
+        if (f_pe) {
+            const float* p = g.pe + (long)(m % g.pe_period) * g.N + n;
+            if (v_pe) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); pev[0] = t[0]; pev[1] = t[1]; pev[2] = t[2]; pev[3] = t[3]; }
+            else { for (int e = 0; e < nv; ++e) pev[e] = p[e]; }
+        }
+        if (f_mask) {
+            const bf16* p = g.mask + (long)m * g.ldmask + n;
+            if (v_msk) { const bf16x4 t = *reinterpret_cast<const bf16x4*>(p); for (int e = 0; e < 4; ++e) mk[e] = (float)t[e]; }
+            else { for (int e = 0; e < nv; ++e) mk[e] = (float)p[e]; }
+        }
+        float* c32 = f_c32 ? g.C32 + out_delta + (long)m * g.ldc + n : nullptr;
+        if (f_c32 && f_acc) {
+            if (v_c32) { const f32x4 t = *reinterpret_cast<const f32x4*>(c32); old[0] = t[0]; old[1] = t[1]; old[2] = t[2]; old[3] = t[3]; }
+            else { for (int e = 0; e < nv; ++e) old[e] = c32[e]; }
+        }
+        // ---- arithmetic
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = v[e] + pev[e];
+            if (f_relu) x = fmaxf(x, 0.f);
+            if (f_mask) x = mk[e] > 0.f ? x * g.mask_scale : 0.f;
+            if (f_drop) x *= dropout_scale(g.seed, g.site, (uint32_t)((long)m * g.N + n + e), g.drop_p, inv_keep);
+            v[e] = x + rs[e] + old[e];
+        }
+        // ---- stores
+        if (f_c32) {
+            if (v_c32) *reinterpret_cast<f32x4*>(c32) = f32x4{v[0], v[1], v[2], v[3]};
+            else { for (int e = 0; e < nv; ++e) c32[e] = v[e]; }
+        }
+        if (f_c16) {
+            bf16* p = g.C16 + (long)m * g.ldc16 + n;
+            if (v_c16) { bf16x4 t; t[0] = (bf16)v[0]; t[1] = (bf16)v[1]; t[2] = (bf16)v[2]; t[3] = (bf16)v[3]; *reinterpret_cast<bf16x4*>(p) = t; }
+            else { for (int e = 0; e < nv; ++e) p[e] = (bf16)v[e]; }
         }
     }
+}
+#undef HAS
+
+template <int BM, int BN, bool RM, int EPI>
+void launch_epi(const GemmArgs& g, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, RM, EPI>), grid, dim3(256), 0, s, g);
 }
 
 template <int BM, int BN>
 int launch_tile(const GemmArgs& g, hipStream_t s) {
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, (g.reduction_major && g.split_k > 1) ? g.split_k : 1);
-    if (g.reduction_major)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, true>), grid, dim3(256), 0, s, g);
-    else
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, false>), grid, dim3(256), 0, s, g);
+    const int epi = (g.bias ? E_BIAS : 0) | (g.pe ? E_PE : 0) | (g.relu ? E_RELU : 0) | (g.mask ? E_MASK : 0) |
+                    (g.drop_p > 0.f ? E_DROP : 0) | (g.residual ? E_RES : 0) | (g.accumulate ? E_ACC : 0) |
+                    (g.C32 ? E_C32 : 0) | (g.C16 ? E_C16 : 0);
+    if (g.reduction_major) {
+        if (epi == E_C32) launch_epi<BM, BN, true, E_C32>(g, grid, s);
+        else launch_epi<BM, BN, true, -1>(g, grid, s);
+    } else {
+        switch (epi & ~E_DROP) {                       // dropout stays a run-time test inside the specialised kernels
+#define CASE(mask) case (mask): launch_epi<BM, BN, false, (mask) | E_DROP>(g, grid, s); break;
+            CASE(E_BIAS | E_C16)                       // q/k/v projections
+            CASE(E_BIAS | E_RES | E_C32)               // attention out-proj, FFN second layer
+            CASE(E_BIAS | E_RELU | E_C16)              // FFN first layer
+            CASE(E_BIAS | E_PE | E_C32 | E_C16)        // vgg2enc + positional encoding
+            CASE(E_BIAS | E_C32)                       // output projection
+            CASE(E_C16)                                // plain dgrad
+            CASE(E_MASK | E_C16)                       // dgrad through ReLU (+dropout) mask
+            CASE(E_RES | E_C32)                        // dgrad joined with the residual gradient
+            CASE(E_ACC | E_C32)                        // memory gradient accumulated over decoder layers
+            CASE(E_C32)
+#undef CASE
+            default: launch_epi<BM, BN, false, -1>(g, grid, s);
+        }
+    }
     if (hipGetLastError() != hipSuccess) { mk_set_error("mk_gemm", "launch failed"); return -1; }
     return 0;
 }
