@@ -375,14 +375,16 @@ __device__ __forceinline__ bf16x8 frag_rm(const bf16* tile, int r0, int lane) {
 
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(ConvWgradArgs a, long pix_per_split) {
+    constexpr int WBK = 64;                               // pixels per k-tile
     constexpr int BM = COUT, BN = 64;
     constexpr int LDA = BM + 16, LDB = BN + 16;
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int FM = WM / 16, FN = WN / 16;
-    constexpr int ACH = BK * (BM / 8) / 256;              // A chunks per thread (1 or 2)
+    constexpr int ACH = WBK * (BM / 8) / 256;             // A chunks per thread (2 or 4)
+    constexpr int BCH = WBK * (BN / 8) / 256;             // B chunks per thread (2)
     constexpr int KTOT = 9 * CIN;
-    __shared__ __attribute__((aligned(16))) bf16 sA[2][BK * LDA];
-    __shared__ __attribute__((aligned(16))) bf16 sB[2][BK * LDB];
+    __shared__ __attribute__((aligned(16))) bf16 sA[2][WBK * LDA];
+    __shared__ __attribute__((aligned(16))) bf16 sB[2][WBK * LDB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -393,35 +395,53 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(ConvWgradArgs a, lon
     const long pe = ps + pix_per_split < P ? ps + pix_per_split : P;
     const int H = a.H, W = a.W;
 
-    bf16x8 ra[ACH], rb;
-    auto load = [&](long p0) {
+    // register ring (depth 2) with UNCONDITIONAL loads: out-of-range pixels / taps read a clamped valid address and
+    // are zeroed when written to LDS (a branch around a global load costs an s_waitcnt vmcnt(0) per k-tile)
+    struct Stage { bf16x8 ra[ACH], rb[BCH]; unsigned oka, okb; };
+    Stage st[2];
+    auto load = [&](Stage& g, long p0) {
+        g.oka = 0; g.okb = 0;
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
             const int c = tid + i * 256;
-            const int k = c / (BM / 8), rc = (c % (BM / 8)) * 8;
-            bf16x8 v = zero8();
-            if (p0 + k < pe) v = ld8(a.dy + (p0 + k) * COUT + rc);
-            ra[i] = v;
+            const long p = p0 + c / (BM / 8);
+            if (p < pe) g.oka |= 1u << i;
+            g.ra[i] = ld8(a.dy + (p < P ? p : P - 1) * COUT + (c % (BM / 8)) * 8);
         }
-        {
-            const int k = tid >> 3, rc = (tid & 7) * 8;
-            const long p = p0 + k;
-            bf16x8 v = zero8();
-            if (p < pe) {
-                const int d = (int)(p % W), t = (int)((p / W) % H);
-                const int tt = t + dy, dd = d + dx;
-                if (tt >= 0 && tt < H && dd >= 0 && dd < W) v = ld8(a.in + (p + (long)dy * W + dx) * CIN + ci0 + rc);
-            }
-            rb = v;
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            const int c = tid + i * 256;
+            const long p = p0 + (c >> 3);
+            const long pc = p < P ? p : P - 1;
+            const int d = (int)(pc % W), t = (int)((pc / W) % H);
+            const int tt = t + dy, dd = d + dx;
+            const bool ok = p < pe && tt >= 0 && tt < H && dd >= 0 && dd < W;
+            if (ok) g.okb |= 1u << i;
+            g.rb[i] = ld8(a.in + (ok ? pc + (long)dy * W + dx : pc) * CIN + ci0 + (c & 7) * 8);
         }
     };
-    auto store = [&](int buf) {
+    auto store = [&](const Stage& g, int buf) {
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
             const int c = tid + i * 256;
-            st8(&sA[buf][(c / (BM / 8)) * LDA + (c % (BM / 8)) * 8], ra[i]);
+            st8(&sA[buf][(c / (BM / 8)) * LDA + (c % (BM / 8)) * 8], (g.oka >> i) & 1 ? g.ra[i] : zero8());
         }
-        st8(&sB[buf][(tid >> 3) * LDB + (tid & 7) * 8], rb);
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            const int c = tid + i * 256;
+            st8(&sB[buf][(c >> 3) * LDB + (c & 7) * 8], (g.okb >> i) & 1 ? g.rb[i] : zero8());
+        }
+    };
+    // fused bias gradient: db[co] = sum_p dy[p][co], accumulated by the column-tile-0 workgroup of each split
+    const bool do_db = a.db != nullptr && blockIdx.x == 0;
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto accumulate = [&](const Stage& g) {
+#pragma unroll
+        for (int i = 0; i < ACH; ++i)
+            if ((g.oka >> i) & 1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) csum[j] += (float)g.ra[i][j];
+            }
     };
 
     f32x4 acc[FM][FN];
@@ -430,42 +450,41 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(ConvWgradArgs a, lon
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // fused bias gradient: db[co] = sum_p dy[p][co], accumulated by the column-tile-0 workgroup of each split
-    const bool do_db = a.db != nullptr && blockIdx.x == 0;
-    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto accumulate = [&]() {
-#pragma unroll
-        for (int i = 0; i < ACH; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) csum[j] += (float)ra[i][j];
-    };
-
-    const int nk = (int)((pe - ps + BK - 1) / BK);
-    if (nk > 0) {
-        load(ps);
-        if (do_db) accumulate();
-        store(0);
-    }
+    const int nk = pe > ps ? (int)((pe - ps + WBK - 1) / WBK) : 0;
+    load(st[0], ps);
+    load(st[1], ps + WBK);
+    if (do_db) accumulate(st[0]);
+    store(st[0], 0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) { load(ps + (long)(kt + 1) * BK); if (do_db) accumulate(); }
-        bf16x8 af[FM], bfr[FN];
+    for (int kt0 = 0; kt0 < nk; kt0 += 2) {
 #pragma unroll
-        for (int i = 0; i < FM; ++i) af[i] = frag_rm<LDA>(sA[cur], wm * WM + i * 16, lane);
+        for (int u = 0; u < 2; ++u) {
+            const int kt = kt0 + u;
+            if (kt >= nk) break;
+            const int cur = kt & 1;
+            load(st[u], ps + (long)(kt + 2) * WBK);          // slot u is free: tile kt already sits in LDS
 #pragma unroll
-        for (int j = 0; j < FN; ++j) bfr[j] = frag_rm<LDB>(sB[cur], wn * WN + j * 16, lane);
+            for (int kc = 0; kc < WBK / 32; ++kc) {
+                bf16x8 af[FM], bfr[FN];
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+                for (int i = 0; i < FM; ++i) af[i] = frag_rm<LDA>(sA[cur] + kc * 32 * LDA, wm * WM + i * 16, lane);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
-        if (kt + 1 < nk) store(cur ^ 1);
-        __syncthreads();
+                for (int j = 0; j < FN; ++j) bfr[j] = frag_rm<LDB>(sB[cur] + kc * 32 * LDB, wn * WN + j * 16, lane);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
+            }
+            if (kt + 1 < nk) {
+                if (do_db) accumulate(st[u ^ 1]);
+                store(st[u ^ 1], cur ^ 1);
+            }
+            __syncthreads();
+        }
     }
     if (do_db) {
         constexpr int RC = BM / 8;
         float* red = reinterpret_cast<float*>(sA[0]);                 // [256][8] floats (tile buffers are free now)
-        __syncthreads();
 #pragma unroll
         for (int j = 0; j < 8; ++j) red[tid * 8 + j] = csum[j];
         __syncthreads();
@@ -617,7 +636,7 @@ int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s) {
     const long P = (long)a.B * a.H * a.W;
     const int splits = wgrad_splits(P, a.CIN);
     long pps = (P + splits - 1) / splits;
-    pps = (pps + 31) / 32 * 32;
+    pps = (pps + 63) / 64 * 64;
     dim3 grid(9 * (a.CIN / 64), splits);
     if (a.CIN == 64 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_wgrad_kernel<64, 64>), grid, dim3(256), 0, s, a, pps);
     else if (a.CIN == 64 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_wgrad_kernel<64, 128>), grid, dim3(256), 0, s, a, pps);

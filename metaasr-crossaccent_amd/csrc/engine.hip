@@ -323,6 +323,7 @@ masr_model* masr_create(const masr_config* cfg) {
     }
     const int hd = cfg->d_model / cfg->nheads;
     if (hd != 16 && hd != 32 && hd != 64) { mk_set_error("masr_create", "head dim must be 16/32/64"); return nullptr; }
+    if (cfg->d_model % 64) { mk_set_error("masr_create", "d_model must be a multiple of 64"); return nullptr; }
     if (cfg->d_model > 1024 || cfg->d_inner > 2048 || 3 * cfg->d_model > 2048) {
         mk_set_error("masr_create", "d_model <= 682, d_inner <= 2048 supported"); return nullptr;
     }

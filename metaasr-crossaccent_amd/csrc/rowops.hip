@@ -6,119 +6,114 @@
 namespace {
 
 // ---------------------------------------------------------------- LayerNorm (eps 1e-5, torch semantics)
-// one wave per row; E <= 64*16
-constexpr int LN_MAXPT = 16;
+// one wave per row, E = 64 * PT exactly (compile-time): every load of a row is issued unconditionally and up front --
+// a bounds check around the loads makes hipcc serialise them on s_waitcnt vmcnt(0).
+template <int PT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ y32,
                                                      bf16* __restrict__ y16, float* __restrict__ mean,
-                                                     float* __restrict__ rstd, int rows, int E) {
+                                                     float* __restrict__ rstd, int rows) {
+    constexpr int E = 64 * PT;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + (long)row * E;
-    float v[LN_MAXPT];
+    float v[PT], gm[PT], bt[PT];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXPT; ++i) {
-        const int c = lane + i * 64;
-        v[i] = c < E ? xr[c] : 0.f;
-        s += v[i];
-    }
+    for (int i = 0; i < PT; ++i) { v[i] = xr[lane + i * 64]; gm[i] = gamma[lane + i * 64]; bt[i] = beta[lane + i * 64]; }
+#pragma unroll
+    for (int i = 0; i < PT; ++i) s += v[i];
     const float mu = wave_sum(s) / E;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXPT; ++i) {
-        const int c = lane + i * 64;
-        const float d = c < E ? v[i] - mu : 0.f;
-        q += d * d;
-    }
+    for (int i = 0; i < PT; ++i) { const float d = v[i] - mu; q += d * d; }
     const float rs = rsqrtf(wave_sum(q) / E + 1e-5f);
 #pragma unroll
-    for (int i = 0; i < LN_MAXPT; ++i) {
-        const int c = lane + i * 64;
-        if (c < E) {
-            const float o = (v[i] - mu) * rs * gamma[c] + beta[c];
-            if (y32) y32[(long)row * E + c] = o;
-            if (y16) y16[(long)row * E + c] = (bf16)o;
-        }
+    for (int i = 0; i < PT; ++i) {
+        const float o = (v[i] - mu) * rs * gm[i] + bt[i];
+        if (y32) y32[(long)row * E + lane + i * 64] = o;
+        if (y16) y16[(long)row * E + lane + i * 64] = (bf16)o;
     }
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
 // backward: each block handles LN_ROWS rows (one wave per row, looping), accumulating dgamma/dbeta
 // partials per thread-column, written to slab[block][2][E]; reduced by ln_bwd_reduce.
-constexpr int LN_ROWS = 8;
+constexpr int LN_ROWS = 16;
+template <int PT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx32,
                                                      bf16* __restrict__ dx16, float drop_p, uint32_t seed, uint32_t site,
-                                                     float* __restrict__ slab, int rows, int E) {
+                                                     float* __restrict__ slab, int rows) {
+    constexpr int E = 64 * PT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float dg[LN_MAXPT], db[LN_MAXPT];
+    float dg[PT], db[PT], gm[PT];
 #pragma unroll
-    for (int i = 0; i < LN_MAXPT; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+    for (int i = 0; i < PT; ++i) { dg[i] = 0.f; db[i] = 0.f; gm[i] = gamma[lane + i * 64]; }
     const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     for (int rr = wave; rr < LN_ROWS; rr += 4) {
         const int row = blockIdx.x * LN_ROWS + rr;
         if (row >= rows) break;
         const float mu = mean[row], rs = rstd[row];
-        float g[LN_MAXPT], xh[LN_MAXPT];
+        float d[PT], xv[PT];
+#pragma unroll
+        for (int i = 0; i < PT; ++i) { d[i] = dy[(long)row * E + lane + i * 64]; xv[i] = x[(long)row * E + lane + i * 64]; }
+        float g[PT], xh[PT];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXPT; ++i) {
-            const int c = lane + i * 64;
-            if (c < E) {
-                const float d = dy[(long)row * E + c];
-                xh[i] = (x[(long)row * E + c] - mu) * rs;
-                g[i] = d * gamma[c];
-                dg[i] += d * xh[i];
-                db[i] += d;
-                s1 += g[i];
-                s2 += g[i] * xh[i];
-            } else { g[i] = 0.f; xh[i] = 0.f; }
+        for (int i = 0; i < PT; ++i) {
+            xh[i] = (xv[i] - mu) * rs;
+            g[i] = d[i] * gm[i];
+            dg[i] += d[i] * xh[i];
+            db[i] += d[i];
+            s1 += g[i];
+            s2 += g[i] * xh[i];
         }
         s1 = wave_sum(s1) / E;
         s2 = wave_sum(s2) / E;
 #pragma unroll
-        for (int i = 0; i < LN_MAXPT; ++i) {
-            const int c = lane + i * 64;
-            if (c < E) {
-                const float o = (g[i] - s1 - xh[i] * s2) * rs;
-                const long idx = (long)row * E + c;
-                if (dx32) dx32[idx] = o;
-                if (dx16) {
-                    float od = o;
-                    if (drop_p > 0.f) od *= dropout_scale(seed, site, (uint32_t)idx, drop_p, inv_keep);
-                    dx16[idx] = (bf16)od;
-                }
+        for (int i = 0; i < PT; ++i) {
+            const float o = (g[i] - s1 - xh[i] * s2) * rs;
+            const long idx = (long)row * E + lane + i * 64;
+            if (dx32) dx32[idx] = o;
+            if (dx16) {
+                float od = o;
+                if (drop_p > 0.f) od *= dropout_scale(seed, site, (uint32_t)idx, drop_p, inv_keep);
+                dx16[idx] = (bf16)od;
             }
         }
     }
-    __shared__ float red[4][2][64 * LN_MAXPT];
+    __shared__ float red[4][2][E];
 #pragma unroll
-    for (int i = 0; i < LN_MAXPT; ++i) {
-        const int c = lane + i * 64;
-        if (c < E) { red[wave][0][c] = dg[i]; red[wave][1][c] = db[i]; }
-    }
+    for (int i = 0; i < PT; ++i) { red[wave][0][lane + i * 64] = dg[i]; red[wave][1][lane + i * 64] = db[i]; }
     __syncthreads();
     for (int c = threadIdx.x; c < E; c += 256) {
         slab[((long)blockIdx.x * 2 + 0) * E + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
         slab[((long)blockIdx.x * 2 + 1) * E + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
     }
 }
-// 64 columns x 4 block-lanes per workgroup; fixed-order -> deterministic
+// 32 columns x 8 block-lanes per workgroup, 4 independent partial sums per thread; fixed order -> deterministic
 __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ slab, int nblocks, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int E) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-    __shared__ float red[4][64];
-    float s = 0.f;
+    const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    __shared__ float red[8][32];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < 2 * E) {
-        const int which = c / E, col = c % E;
-        for (int b = part; b < nblocks; b += 4) s += slab[((long)b * 2 + which) * E + col];
+        const float* p = slab + (long)(c / E) * E + c % E;
+        int b = part;
+        for (; b + 24 < nblocks; b += 32) {
+            s0 += p[(long)b * 2 * E]; s1 += p[(long)(b + 8) * 2 * E]; s2 += p[(long)(b + 16) * 2 * E]; s3 += p[(long)(b + 24) * 2 * E];
+        }
+        for (; b < nblocks; b += 8) s0 += p[(long)b * 2 * E];
     }
-    red[part][threadIdx.x & 63] = s;
+    red[part][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (part == 0 && c < 2 * E) {
-        const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][cl];
         (c / E == 0 ? dgamma : dbeta)[c % E] = t;
     }
 }
@@ -144,18 +139,27 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ 
                                                         float drop_p, uint32_t seed, uint32_t site) {
     const int v = blockIdx.x;
     const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    // rows holding token v, gathered in order (deterministic sum); most vocabulary rows have none
-    __shared__ int hit[1024]; __shared__ int nhit;
+    // rows holding token v, compacted IN ORDER (deterministic sum) with a ballot prefix; most vocabulary rows have none
+    __shared__ int hit[1024]; __shared__ int wcnt[4]; __shared__ int nhit;
     float s[4] = {0.f, 0.f, 0.f, 0.f};                                  // E <= 1024 -> <= 4 columns per thread
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int r0 = 0; r0 < rows; r0 += 1024) {
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int n = 0;
-            const int r1 = r0 + 1024 < rows ? r0 + 1024 : rows;
-            for (int r = r0; r < r1; ++r) if (tok[r] == v) hit[n++] = r;
-            nhit = n;
-        }
+        if (threadIdx.x == 0) nhit = 0;
         __syncthreads();
+        for (int sub = 0; sub < 1024; sub += 256) {                      // 256 consecutive rows per pass, wave w owns 64 of them
+            const int r = r0 + sub + threadIdx.x;
+            const bool h = r < rows && tok[r] == v;
+            const unsigned long long m = __ballot(h);
+            if (lane == 0) wcnt[wave] = __popcll(m);
+            __syncthreads();
+            int base = nhit;
+            for (int w = 0; w < wave; ++w) base += wcnt[w];
+            if (h) hit[base + __popcll(m & ((1ull << lane) - 1))] = r;
+            __syncthreads();
+            if (threadIdx.x == 0) nhit += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            __syncthreads();
+        }
         for (int h = 0; h < nhit; ++h) {
             const int r = hit[h];
 #pragma unroll
@@ -290,20 +294,39 @@ __global__ __launch_bounds__(256) void ls_ce_reduce(const float* __restrict__ ro
 
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : (mk_set_error(__func__, "launch failed"), -1))
 
+template <int PT>
+static void ln_fwd_launch(const float* x, const float* gamma, const float* beta, float* y32, bf16* y16, float* mean, float* rstd, int rows, hipStream_t s) {
+    hipLaunchKernelGGL(ln_fwd_kernel<PT>, dim3((rows + 3) / 4), dim3(256), 0, s, x, gamma, beta, y32, y16, mean, rstd, rows);
+}
+template <int PT>
+static void ln_bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx32, bf16* dx16,
+                          float drop_p, uint32_t seed, uint32_t site, float* slab, int rows, int nb, hipStream_t s) {
+    hipLaunchKernelGGL(ln_bwd_kernel<PT>, dim3(nb), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx32, dx16, drop_p, seed, site, slab, rows);
+}
+#define LN_DISPATCH(E, CALL)                                                                      \
+    switch ((E) / 64) {                                                                           \
+        case 1: CALL(1); break; case 2: CALL(2); break; case 4: CALL(4); break; case 6: CALL(6); break;   \
+        case 8: CALL(8); break; case 12: CALL(12); break; case 16: CALL(16); break;              \
+        default: mk_set_error("layernorm", "d_model must be 64 x {1,2,4,6,8,12,16}"); return -1; \
+    }
 int mk_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y32, bf16* y16, float* mean,
                        float* rstd, int rows, int E, hipStream_t s) {
-    if (E > 64 * LN_MAXPT) { mk_set_error("mk_layernorm_fwd", "d_model > 1024 unsupported"); return -1; }
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, gamma, beta, y32, y16, mean, rstd, rows, E);
+    if (E % 64) { mk_set_error("mk_layernorm_fwd", "d_model must be a multiple of 64"); return -1; }
+#define CALL(P) ln_fwd_launch<P>(x, gamma, beta, y32, y16, mean, rstd, rows, s)
+    LN_DISPATCH(E, CALL)
+#undef CALL
     return LAUNCH_OK();
 }
 long mk_layernorm_bwd_slab_floats(int rows, int E) { return (long)((rows + LN_ROWS - 1) / LN_ROWS) * 2 * E; }
 int mk_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        float* dx32, bf16* dx16, float drop_p, uint32_t seed, uint32_t site, float* dgamma, float* dbeta,
                        float* slab, int rows, int E, hipStream_t s) {
-    if (E > 64 * LN_MAXPT) { mk_set_error("mk_layernorm_bwd", "d_model > 1024 unsupported"); return -1; }
+    if (E % 64) { mk_set_error("mk_layernorm_bwd", "d_model must be a multiple of 64"); return -1; }
     const int nb = (rows + LN_ROWS - 1) / LN_ROWS;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx32, dx16, drop_p, seed, site, slab, rows, E);
-    hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * E + 63) / 64), dim3(256), 0, s, slab, nb, dgamma, dbeta, E);
+#define CALL(P) ln_bwd_launch<P>(dy, x, gamma, mean, rstd, dx32, dx16, drop_p, seed, site, slab, rows, nb, s)
+    LN_DISPATCH(E, CALL)
+#undef CALL
+    hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * E + 31) / 32), dim3(256), 0, s, slab, nb, dgamma, dbeta, E);
     return LAUNCH_OK();
 }
 int mk_embed_fwd(const int* tok, const float* table, const float* pe, float* y32, bf16* y16, int B, int L, int E,
