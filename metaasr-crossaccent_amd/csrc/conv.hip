@@ -509,6 +509,153 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(ConvWgradArgs a, lon
         }
 }
 
+// ------------------------------------------------------------------ wgrad v2: patch-tiled, persistent, all 9 taps per workgroup
+// dW[co][tap][ci] = sum_pixels dy[pix][co] * x[pix + off(tap)][ci].  A workgroup owns one (64-ci slab, 64-co half) and walks
+// over 8x16-pixel tiles of the batch: the x patch (10x18 pixels, zero outside the image) and the dy tile go to LDS once
+// and feed ALL 9 taps (both operands via ds_read_b64_tr_b16, contraction over the pixel index), so L2/HBM traffic per
+// FLOP is 9x lower than one-tap-per-workgroup.  The 9 x 64 x 64 fp32 partial stays in registers (144 VGPRs/lane) across
+// all tiles of the workgroup and is written once; a fixed-order slab reduce makes the result deterministic.
+constexpr int W2_TH = 8, W2_TW = 16, W2_PH = W2_TH + 2, W2_PW = W2_TW + 2, W2_PS = 72, W2_LDY = 80;
+constexpr int W2_TOTAL_WG = 256;    // one persistent workgroup per CU (144 accumulator VGPRs -> one wave per SIMD, no spills)
+
+template <int CIN, int COUT, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs a, int nwg, int ntiles, int tiles_x, int tiles_y) {
+    constexpr int KTOT = 9 * CIN;
+    constexpr int NPCH = (W2_PH * W2_PW * 8 + 255) / 256;   // patch chunks per thread (6)
+    constexpr int NDCH = W2_TH * W2_TW * 8 / 256;           // dy chunks per thread (4)
+    __shared__ __attribute__((aligned(16))) bf16 patch[W2_PH * W2_PW * W2_PS];
+    __shared__ __attribute__((aligned(16))) bf16 dyt[W2_TH * W2_TW * W2_LDY];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int cs = blockIdx.y % (CIN / 64), ch = blockIdx.y / (CIN / 64);
+    const int H = a.H, W = a.W;
+
+    bf16x8 pr[NPCH], dr[NDCH];
+    unsigned okp = 0, okd = 0;
+    auto load_tile = [&](int tile) {
+        const int tc = tile < ntiles ? tile : ntiles - 1;
+        const int tx = tc % tiles_x, ty = (tc / tiles_x) % tiles_y, b = tc / (tiles_x * tiles_y);
+        const int t0 = ty * W2_TH, d0 = tx * W2_TW;
+        const bf16* in_b = a.in + (long)b * H * W * CIN + cs * 64;
+        const bf16* dy_b = a.dy + (long)b * H * W * COUT + ch * 64;
+        okp = 0; okd = 0;
+#pragma unroll
+        for (int i = 0; i < NPCH; ++i) {
+            const int c = tid + i * 256;
+            const int pix = c >> 3, pi = pix / W2_PW, pj = pix % W2_PW;
+            const int t = t0 + pi - 1, d = d0 + pj - 1;
+            const bool ok = c < W2_PH * W2_PW * 8 && t >= 0 && t < H && d >= 0 && d < W;
+            if (ok) okp |= 1u << i;
+            pr[i] = ld8(in_b + (ok ? ((long)t * W + d) : 0) * CIN + (c & 7) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NDCH; ++i) {
+            const int c = tid + i * 256;
+            const int pix = c >> 3, t = t0 + pix / W2_TW, d = d0 + pix % W2_TW;
+            const bool ok = t < H && d < W;
+            if (ok) okd |= 1u << i;
+            dr[i] = ld8(dy_b + (ok ? ((long)t * W + d) : 0) * COUT + (c & 7) * 8);
+        }
+    };
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool do_db = a.db != nullptr && cs == 0;
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPCH; ++i) {
+            const int c = tid + i * 256;
+            if (c < W2_PH * W2_PW * 8) st8(patch + (c >> 3) * W2_PS + (c & 7) * 8, (okp >> i) & 1 ? pr[i] : zero8());
+        }
+#pragma unroll
+        for (int i = 0; i < NDCH; ++i) {
+            const int c = tid + i * 256;
+            const bf16x8 v = (okd >> i) & 1 ? dr[i] : zero8();
+            st8(dyt + (c >> 3) * W2_LDY + (c & 7) * 8, v);
+            if (do_db) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) csum[j] += (float)v[j];
+            }
+        }
+    };
+
+    f32x4 acc[9][2][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+    const int g = lane >> 4, q = (lane & 15) >> 2, p4 = (lane & 3) * 4;
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) { load_tile(tile); store_tile(); }
+    __syncthreads();
+    for (; tile < ntiles; tile += nwg) {
+        const bool has_next = tile + nwg < ntiles;
+        load_tile(tile + nwg);                                   // in flight during the MFMAs (clamped when past the end)
+#pragma unroll
+        for (int kc = 0; kc < W2_TH / 2; ++kc) {                 // 32 pixels = pixel rows 2kc, 2kc+1
+            bf16x8 af[2];
+#pragma unroll
+            for (int fm = 0; fm < 2; ++fm) {
+                const bf16* a0 = dyt + (kc * 32 + 4 * g + q) * W2_LDY + wm * 32 + fm * 16 + p4;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)a0);
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(a0 + 16 * W2_LDY));
+                af[fm][0] = lo[0]; af[fm][1] = lo[1]; af[fm][2] = lo[2]; af[fm][3] = lo[3];
+                af[fm][4] = hi[0]; af[fm][5] = hi[1]; af[fm][6] = hi[2]; af[fm][7] = hi[3];
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dyi = tap / 3, dxj = tap % 3;
+#pragma unroll
+                for (int fn = 0; fn < 2; ++fn) {
+                    const bf16* b0 = patch + ((2 * kc + dyi) * W2_PW + 4 * g + q + dxj) * W2_PS + wn * 32 + fn * 16 + p4;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)b0);
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(b0 + W2_PW * W2_PS));
+                    bf16x8 bfr;
+                    bfr[0] = lo[0]; bfr[1] = lo[1]; bfr[2] = lo[2]; bfr[3] = lo[3];
+                    bfr[4] = hi[0]; bfr[5] = hi[1]; bfr[6] = hi[2]; bfr[7] = hi[3];
+                    acc[tap][0][fn] = mma16(af[0], bfr, acc[tap][0][fn]);
+                    acc[tap][1][fn] = mma16(af[1], bfr, acc[tap][1][fn]);
+                }
+            }
+        }
+        __syncthreads();
+        if (has_next) store_tile();
+        __syncthreads();
+    }
+
+    float* out = a.slab + (long)blockIdx.x * COUT * KTOT;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = ch * 64 + wm * 32 + fm * 16 + (lane >> 4) * 4 + r;
+#pragma unroll
+                for (int fn = 0; fn < 2; ++fn) {
+                    const int ci = cs * 64 + wn * 32 + fn * 16 + (lane & 15);
+                    out[(long)co * KTOT + tap * CIN + ci] = acc[tap][fm][fn][r];
+                }
+            }
+    if (do_db) {
+        // threads with equal tid % 8 own the same 8 output channels
+        float* red = reinterpret_cast<float*>(patch);                 // [256][8] floats = 8 KB
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid * 8 + j] = csum[j];
+        __syncthreads();
+        if (tid < 64) {
+            const int rc = tid / 8, j = tid % 8;
+            float sum = 0.f;
+            for (int t = rc; t < 256; t += 8) sum += red[t * 8 + j];
+            a.slab[(long)nwg * COUT * KTOT + (long)blockIdx.x * COUT + ch * 64 + tid] = sum;
+        }
+    }
+}
+
 __global__ void conv3x3_wgrad_reduce(const float* __restrict__ slab, int nsplit, float* __restrict__ dw, float* __restrict__ db,
                                      int CIN, int COUT) {
     const int KTOT = 9 * CIN;
@@ -629,19 +776,44 @@ int mk_conv3x3(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+static int wgrad2_nwg(int CIN, int COUT) {
+    static const int total = getenv("MASR_WGRAD_WGS") ? atoi(getenv("MASR_WGRAD_WGS")) : W2_TOTAL_WG;
+    return total / ((CIN / 64) * (COUT / 64));
+}
 long mk_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT) {
-    return (long)wgrad_splits((long)B * H * W, CIN) * (COUT * 9 * CIN + COUT);
+    const long v1 = (long)wgrad_splits((long)B * H * W, CIN) * (COUT * 9 * CIN + COUT);
+    const long v2 = (long)wgrad2_nwg(CIN, COUT) * (COUT * 9 * CIN + COUT);
+    return v1 > v2 ? v1 : v2;
 }
 int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s) {
     const long P = (long)a.B * a.H * a.W;
-    const int splits = wgrad_splits(P, a.CIN);
-    long pps = (P + splits - 1) / splits;
-    pps = (pps + 63) / 64 * 64;
-    dim3 grid(9 * (a.CIN / 64), splits);
-    if (a.CIN == 64 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_wgrad_kernel<64, 64>), grid, dim3(256), 0, s, a, pps);
-    else if (a.CIN == 64 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_wgrad_kernel<64, 128>), grid, dim3(256), 0, s, a, pps);
-    else if (a.CIN == 128 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_wgrad_kernel<128, 128>), grid, dim3(256), 0, s, a, pps);
-    else { mk_set_error("mk_conv3x3_wgrad", "unsupported channel counts"); return -1; }
+    int splits;
+    if (getenv("MASR_WGRAD_V1")) {                         // first-generation one-tap-per-workgroup kernel (kept for A/B runs)
+        splits = wgrad_splits(P, a.CIN);
+        long pps = (P + splits - 1) / splits;
+        pps = (pps + 63) / 64 * 64;
+        dim3 grid(9 * (a.CIN / 64), splits);
+        if (a.CIN == 64 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_wgrad_kernel<64, 64>), grid, dim3(256), 0, s, a, pps);
+        else if (a.CIN == 64 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_wgrad_kernel<64, 128>), grid, dim3(256), 0, s, a, pps);
+        else if (a.CIN == 128 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_wgrad_kernel<128, 128>), grid, dim3(256), 0, s, a, pps);
+        else { mk_set_error("mk_conv3x3_wgrad", "unsupported channel counts"); return -1; }
+    } else {
+        const int tiles_x = (a.W + W2_TW - 1) / W2_TW, tiles_y = (a.H + W2_TH - 1) / W2_TH;
+        const int ntiles = tiles_x * tiles_y * a.B;
+        int nwg = wgrad2_nwg(a.CIN, a.COUT);
+        if (nwg > ntiles) nwg = ntiles;
+        splits = nwg;
+        dim3 grid(nwg, (a.CIN / 64) * (a.COUT / 64));
+        static const int occ = getenv("MASR_WGRAD_OCC") ? atoi(getenv("MASR_WGRAD_OCC")) : 1;
+#define W2(CI, CO) \
+        if (occ == 1) hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CI, CO, 1>), grid, dim3(256), 0, s, a, nwg, ntiles, tiles_x, tiles_y); \
+        else hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CI, CO, 2>), grid, dim3(256), 0, s, a, nwg, ntiles, tiles_x, tiles_y);
+        if (a.CIN == 64 && a.COUT == 64) { W2(64, 64) }
+        else if (a.CIN == 64 && a.COUT == 128) { W2(64, 128) }
+        else if (a.CIN == 128 && a.COUT == 128) { W2(128, 128) }
+        else { mk_set_error("mk_conv3x3_wgrad", "unsupported channel counts"); return -1; }
+#undef W2
+    }
     const int n = a.COUT * 9 * a.CIN + a.COUT;
     hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((n + 255) / 256), dim3(256), 0, s, a.slab, splits, a.dw, a.db, a.CIN, a.COUT);
     return hipGetLastError() == hipSuccess ? 0 : -1;
