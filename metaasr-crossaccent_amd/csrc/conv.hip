@@ -293,6 +293,9 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
         for (int tap = 0; tap < 9; ++tap, ++step) {
             const bf16* wcur = wbuf0 + (step & 1) * W_EL;
             if (tap + 1 < 9) load_w(slab, tap + 1);
+            // keep the weight prefetch HERE: hipcc otherwise sinks the global loads to just before their LDS store,
+            // exposing one L2 round trip per tap (9 per slab, longer than the tap's 32 MFMAs)
+            __builtin_amdgcn_sched_barrier(0);
             const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) {
@@ -595,6 +598,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs 
     for (; tile < ntiles; tile += nwg) {
         const bool has_next = tile + nwg < ntiles;
         load_tile(tile + nwg);                                   // in flight during the MFMAs (clamped when past the end)
+        __builtin_amdgcn_sched_barrier(0);                       // keep the prefetch ahead of the MFMAs (hipcc would sink it)
 #pragma unroll
         for (int kc = 0; kc < W2_TH / 2; ++kc) {                 // 32 pixels = pixel rows 2kc, 2kc+1
             bf16x8 af[2];

@@ -160,17 +160,24 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ 
             if (threadIdx.x == 0) nhit += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
             __syncthreads();
         }
-        for (int h = 0; h < nhit; ++h) {
-            const int r = hit[h];
+        // eight rows in flight per step (independent loads), added in row order
+        for (int h0 = 0; h0 < nhit; h0 += 8) {
+            float gv[8][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int e = threadIdx.x + i * 256;
-                if (e < E) {
-                    float g = dy[(long)r * E + e];
+            for (int u = 0; u < 8; ++u) {
+                const int r = hit[h0 + u < nhit ? h0 + u : nhit - 1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = threadIdx.x + i * 256;
+                    float g = dy[(long)r * E + (e < E ? e : 0)];
                     if (drop_p > 0.f) g *= dropout_scale(seed, site, (uint32_t)((long)r * E + e), drop_p, inv_keep);
-                    s[i] += g;
+                    gv[u][i] = (h0 + u < nhit && e < E) ? g : 0.f;
                 }
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i] += gv[u][i];
         }
     }
 #pragma unroll
