@@ -133,21 +133,22 @@ __global__ void embed_fwd_kernel(const int* __restrict__ tok, const float* __res
     y32[i] = v;
     y16[i] = (bf16)v;
 }
-// one block per vocabulary row: deterministic sum over the (few hundred) token rows
+// dtable[v][:] (+)= sum of dy rows whose token is v.  Workgroup = (vocabulary row v, 64-column slice); the rows holding v
+// are compacted IN ORDER with a ballot prefix and summed by 4 waves (wave w takes hits w, w+4, ...; fixed order ->
+// deterministic).  Most vocabulary rows have no hit; the padding token (</s>) has hundreds, hence the 2-D split.
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ tok, const float* __restrict__ dy,
                                                         float* __restrict__ dtable, int rows, int E, int accumulate,
                                                         float drop_p, uint32_t seed, uint32_t site) {
-    const int v = blockIdx.x;
-    const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    // rows holding token v, compacted IN ORDER (deterministic sum) with a ballot prefix; most vocabulary rows have none
-    __shared__ int hit[1024]; __shared__ int wcnt[4]; __shared__ int nhit;
-    float s[4] = {0.f, 0.f, 0.f, 0.f};                                  // E <= 1024 -> <= 4 columns per thread
+    const int v = blockIdx.x, col = blockIdx.y * 64 + (threadIdx.x & 63);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    __shared__ int hit[1024]; __shared__ int wcnt[4]; __shared__ int nhit; __shared__ float part[4][64];
+    float s = 0.f;
     for (int r0 = 0; r0 < rows; r0 += 1024) {
         __syncthreads();
         if (threadIdx.x == 0) nhit = 0;
         __syncthreads();
-        for (int sub = 0; sub < 1024; sub += 256) {                      // 256 consecutive rows per pass, wave w owns 64 of them
+        for (int sub = 0; sub < 1024 && r0 + sub < rows; sub += 256) {
             const int r = r0 + sub + threadIdx.x;
             const bool h = r < rows && tok[r] == v;
             const unsigned long long m = __ballot(h);
@@ -160,30 +161,26 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ 
             if (threadIdx.x == 0) nhit += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
             __syncthreads();
         }
-        // eight rows in flight per step (independent loads), added in row order
-        for (int h0 = 0; h0 < nhit; h0 += 8) {
-            float gv[8][4];
+        const int n = nhit;
+        for (int h0 = wave; h0 < n; h0 += 32) {                         // 8 independent row loads in flight per wave
+            float gv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int r = hit[h0 + u < nhit ? h0 + u : nhit - 1];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int e = threadIdx.x + i * 256;
-                    float g = dy[(long)r * E + (e < E ? e : 0)];
-                    if (drop_p > 0.f) g *= dropout_scale(seed, site, (uint32_t)((long)r * E + e), drop_p, inv_keep);
-                    gv[u][i] = (h0 + u < nhit && e < E) ? g : 0.f;
-                }
+                const int h = h0 + 4 * u;
+                const int r = hit[h < n ? h : n - 1];
+                float g = dy[(long)r * E + col];
+                if (drop_p > 0.f) g *= dropout_scale(seed, site, (uint32_t)((long)r * E + col), drop_p, inv_keep);
+                gv[u] = h < n ? g : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) s[i] += gv[u][i];
+            for (int u = 0; u < 8; ++u) s += gv[u];
         }
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int e = threadIdx.x + i * 256;
-        if (e < E) { if (accumulate) dtable[(long)v * E + e] += s[i]; else dtable[(long)v * E + e] = s[i]; }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0) {
+        const float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        if (accumulate) dtable[(long)v * E + col] += t; else dtable[(long)v * E + col] = t;
     }
 }
 
@@ -344,7 +341,8 @@ int mk_embed_fwd(const int* tok, const float* table, const float* pe, float* y32
 }
 int mk_embed_bwd(const int* tok, const float* dy, float* dtable, int rows, int V, int E, int accumulate, float drop_p,
                    uint32_t seed, uint32_t site, hipStream_t s) {
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), 0, s, tok, dy, dtable, rows, E, accumulate, drop_p, seed, site);
+    if (E % 64) { mk_set_error("mk_embed_bwd", "d_model must be a multiple of 64"); return -1; }
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(V, E / 64), dim3(256), 0, s, tok, dy, dtable, rows, E, accumulate, drop_p, seed, site);
     return LAUNCH_OK();
 }
 int mk_cast_dropout(const float* x, bf16* y, long n, float drop_p, uint32_t seed, uint32_t site, hipStream_t s) {
