@@ -201,8 +201,16 @@ def main():
         ms, n = prof_all["conv2_fwd"]
         flops = 2.0 * 9 * 64 * 64 * B * T * D                    # algorithmic FLOPs of one conv 64->64 launch
         achieved = flops / (ms / n * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "conv3x3_kernel<64,64> (conv2 forward, implicit GEMM)", "achieved": achieved,
-                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+        traffic = None                                           # HBM bytes per launch from the committed PMC passes (same workload)
+        try:
+            pmc = json.load(open(ROOT / "profiles" / "pmc_traffic.json"))
+            if pmc["workload"] == {"batch": B, "frames": T, "idim": D}:
+                traffic = pmc["traffic_bytes"]
+        except Exception:
+            pass
+        roof = {"bound": "mfma", "kernel": "conv3x3_patch_kernel<64,64,16> (conv2 forward, patch-tiled implicit GEMM)", "achieved": achieved,
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                "algorithmic_bytes": 2 * B * T * D * 64 * 2,
                 "avg_launch_ms": ms / n, "flops_per_launch": flops}
 
     if rank == 0:

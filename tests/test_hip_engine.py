@@ -127,3 +127,46 @@ def test_state_dict_layout(sd):
     for k in sd:
         assert out[k].shape == sd[k].shape
         torch.testing.assert_close(out[k].cpu(), sd[k], rtol=0, atol=1e-6 if k == "pos_encoder.pe" else 0)
+
+
+def _flat_dot(eng, a, b):
+    return float((a.double() * b.double()).sum())
+
+
+def test_dropout_forward_backward_consistency(sd):
+    """Dropout masks are regenerated (not stored) in the backward from a stateless hash of (seed, site, index).
+    For a fixed seed the loss is a deterministic function of the weights, so the analytic gradient must match a
+    central finite difference along the gradient direction -- this fails if any forward/backward mask pair disagrees."""
+    cfg = dict(TINY); cfg["dropout"] = 0.2; cfg["pos_dropout"] = 0.1
+    xs, il, ys, ol = synth_batch(11, *CASES["ragged"])
+    eng = MasrEngine(cfg, ODIM, label_smoothing=0.2)
+    eng.load_state_dict(sd)
+
+    def loss_at(params, seed=77):
+        eng.params.copy_(params); eng.mark_dirty(); eng.set_seed(seed)
+        eng.run_batch(xs, il, ys, ol, train=True)
+        return eng.read_stats()["loss"], eng.grads.clone()
+
+    p0 = eng.params.clone()
+    l0, g0 = loss_at(p0)
+    l0b, g0b = loss_at(p0)
+    assert l0 == l0b and torch.equal(g0, g0b), "same seed must reproduce the same masks"
+    l_other, _ = loss_at(p0, seed=78)
+    assert l_other != l0, "a different seed must draw different masks"
+    eng.cfg_eval = None
+    # eval mode ignores dropout
+    eng.params.copy_(p0); eng.mark_dirty()
+    eng.run_batch(xs, il, ys, ol, train=False)
+    l_eval = eng.read_stats()["loss"]
+    eng0 = MasrEngine(TINY, ODIM, label_smoothing=0.2); eng0.load_state_dict(sd)
+    eng0.run_batch(xs, il, ys, ol, train=False)
+    assert abs(l_eval - eng0.read_stats()["loss"]) < 1e-6
+    assert abs(l0 - l_eval) < 0.15 * l_eval                      # dropout perturbs, it does not destroy, the loss
+    # directional derivative along the gradient
+    v = g0 / g0.norm()
+    eps = 0.02
+    lp, _ = loss_at(p0 + eps * v)
+    lm, _ = loss_at(p0 - eps * v)
+    fd = (lp - lm) / (2 * eps)
+    an = float(g0.norm())
+    assert abs(fd - an) < 0.08 * an, (fd, an)
