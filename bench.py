@@ -9,14 +9,19 @@ HBM when the timed region starts.  Model = config/transformer/pretrain/fometa-hk
 
     python bench.py [--gpus N --steps K --warmup W]          # N>1 via torch.distributed.run, one rank per GPU
 
-N ranks = N independent accent-tasks (FOMAML shards tasks one per GPU; the inner step has no exchange),
-so scaling is "weak": value = N * B * K / max-over-ranks time.  The meta-gradient all-reduce of the OUTER
-step is measured separately (field "meta_step") because the metric counts inner steps.
+N ranks = N groups of independent accent-tasks (FOMAML shards tasks over GPUs; the inner step has no exchange),
+so scaling is "weak": value = N * tasks_per_gpu * B * K / max-over-ranks time.  The meta-gradient all-reduce of
+the OUTER step is measured separately (field "meta_step") because the metric counts inner steps.
+
+--tasks-per-gpu (default 3): tasks of one meta-step are independent, so each GPU runs several of them concurrently
+(one model replica + HIP stream + host thread per task; `--tasks_per_gpu` of pretrain.py).  Every task still performs
+full B-utterance inner steps; "single_task" in the output is the same measurement with one task per GPU.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -111,19 +116,38 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--tasks-per-gpu", type=int, default=3, help="concurrent independent accent-tasks per GPU (1 = reference order)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    backend = os.environ.get("MASR_BENCH_BACKEND", "nccl")       # "gloo": rehearsal of the N>1 path on a 1-GPU box
+    ndev = torch.cuda.device_count()
+    if backend != "nccl":
+        local = local % max(ndev, 1)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
+
+    def all_reduce_(t, op=None):
+        """in-place all-reduce of a device tensor (RCCL), or through host memory for the gloo rehearsal"""
+        if backend == "nccl":
+            dist.all_reduce(t, op=op or dist.ReduceOp.SUM)
+        else:
+            c = t.cpu()
+            dist.all_reduce(c, op=op or dist.ReduceOp.SUM)
+            t.copy_(c)
 
     import masr_amd
     from masr_amd.engine import MasrEngine
@@ -132,27 +156,29 @@ def main():
     cfg = dict(HKUST)
     cfg["idim"] = args.idim
     B, T, D = args.batch, args.frames, args.idim
-    eng = MasrEngine(cfg, ODIM, label_smoothing=0.2, device=dev)
-    eng.load_state_dict(ref_cpu.deterministic_state_dict(cfg, ODIM, seed=1))
-    eng.set_seed(531 + rank)
-    xs, il, ys, ol = synth_batch(B, T, D, seed=rank)             # numpy seed 0 + accent index
-    xs = xs.to(dev)
-    mom = torch.zeros_like(eng.params)
+    K = max(1, args.tasks_per_gpu)
     lr = ref_cpu.inner_lr(cfg)
+    sd0 = ref_cpu.deterministic_state_dict(cfg, ODIM, seed=1)
 
-    def step(i):
-        eng.run_batch(xs, il, ys, ol, train=True)
-        eng.clip_sgd_step(mom, 5.0, lr, 0.9, True, first_step=(i == 0))
+    class Task:                                                  # one accent-task slot: replica + stream + resident batch
+        def __init__(self, k):
+            self.eng = MasrEngine(cfg, ODIM, label_smoothing=0.2, device=dev)
+            self.eng.load_state_dict(sd0)
+            self.eng.set_seed(531 + rank * 64 + k)
+            xs, self.il, self.ys, self.ol = synth_batch(B, T, D, seed=rank * 64 + k)   # numpy seed 0 + task index
+            self.xs = xs.to(dev)
+            self.mom = torch.zeros_like(self.eng.params)
+            self.stream = torch.cuda.Stream(device=dev)
+            self.i = 0
 
-    log(f"rank {rank}: engine ready, workspace will be {eng._l.masr_workspace_bytes(eng.h, B, T, 42) / 1e9:.2f} GB")
-    for i in range(args.warmup):
-        step(i)
-        if i == 0:
-            torch.cuda.synchronize(dev)
-            log("first step done")
-    st = eng.read_stats()
-    log(f"warm-up done: loss {st['loss']:.4f} grad_norm {st['grad_norm']:.4f}")
-    assert np.isfinite(st["loss"]) and np.isfinite(st["grad_norm"]), st
+        def step(self):
+            self.eng.run_batch(self.xs, self.il, self.ys, self.ol, train=True)
+            self.eng.clip_sgd_step(self.mom, 5.0, lr, 0.9, True, first_step=(self.i == 0))
+            self.i += 1
+
+    tasks = [Task(k) for k in range(K)]
+    eng = tasks[0].eng
+    log(f"rank {rank}: {K} task slot(s) ready, workspace {eng._l.masr_workspace_bytes(eng.h, B, T, 42) / 1e9:.2f} GB each")
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -160,21 +186,53 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(active, nsteps, nwarm):
+        """nwarm untimed + nsteps timed inner steps on every task of `active`, one host thread + HIP stream per task"""
+        gate = threading.Barrier(len(active) + 1)
+
+        def body(t):
+            with torch.cuda.stream(t.stream):
+                for _ in range(nwarm):
+                    t.step()
+                t.stream.synchronize()
+                gate.wait()                                      # (1) warm-up done everywhere
+                gate.wait()                                      # (2) timed region starts
+                for _ in range(nsteps):
+                    t.step()
+                t.stream.synchronize()
+        ths = [threading.Thread(target=body, args=(t,)) for t in active]
+        for th in ths:
+            th.start()
+        gate.wait()
+        barrier()
+        t0 = time.perf_counter()
+        gate.wait()
+        for th in ths:
+            th.join()
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    single = None
+    if K > 1:
+        n1 = max(5, args.steps // 3)
+        dt1 = timed(tasks[:1], n1, args.warmup)
+        single = {"value": world * B * n1 / dt1, "ms_per_step": dt1 / n1 * 1e3, "steps": n1}
+        log(f"single task per GPU: {single['value']:.1f} utt/s")
+    dt = timed(tasks, args.steps, args.warmup)
     st = eng.read_stats()
-    log(f"timed region: {dt:.3f} s for {args.steps} steps")
+    assert np.isfinite(st["loss"]) and np.isfinite(st["grad_norm"]), st
+    log(f"timed region: {dt:.3f} s for {args.steps} steps x {K} task(s); loss {st['loss']:.4f}")
+
+    def step(i):
+        tasks[0].step()
 
     # ---- one FOMAML meta-step's exchange (all-reduce of the flat meta-gradient) for information
     meta = None
@@ -184,7 +242,7 @@ def main():
         barrier()
         t1 = time.perf_counter()
         for _ in range(5):
-            dist.all_reduce(upd)
+            all_reduce_(upd)
         torch.cuda.synchronize(dev)
         meta = {"allreduce_ms": (time.perf_counter() - t1) / 5 * 1e3, "payload_mb": upd.numel() * 4 / 1e6}
 
@@ -195,7 +253,7 @@ def main():
         eng.profile(True)
         nprof = 5
         for i in range(nprof):
-            step(args.warmup + args.steps + i)
+            step(i)
         prof_all = eng.profile_read()
         eng.profile(False)
         ms, n = prof_all["conv2_fwd"]
@@ -214,7 +272,7 @@ def main():
                 "avg_launch_ms": ms / n, "flops_per_launch": flops}
 
     if rank == 0:
-        utt = world * B * args.steps
+        utt = world * K * B * args.steps
         value = utt / dt
         F = fwd_flops_per_utt(T, D)
         out = {
@@ -223,10 +281,11 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "pretrain.py --algo fomaml inner step (run_batch + clip 5 + SGD nesterov), "
                                    "config/transformer/pretrain/fometa-hkust.yaml geometry, synthetic 10s x %d-dim fbank" % D,
-                       "batch_per_gpu": B, "frames": T, "idim": D, "dropout": cfg["dropout"], "tasks": world,
-                       "parallelism": f"task-per-gpu x{world}"},
+                       "batch_per_task": B, "tasks_per_gpu": K, "frames": T, "idim": D, "dropout": cfg["dropout"],
+                       "tasks": world * K, "parallelism": f"{K} concurrent task(s) per GPU x {world} GPU(s)"},
             "algorithmic_gflop_per_utt_fwd_bwd": 3 * F / 1e9,
             "model_tflops": value * 3 * F / 1e12, "model_frac_of_bf16_peak": value * 3 * F / 1e12 / (PEAK_BF16_TFLOPS * world),
+            "single_task": single,
             "loss": st["loss"], "grad_norm": st["grad_norm"],
         }
         if roof:

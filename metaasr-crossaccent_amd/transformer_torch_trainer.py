@@ -47,16 +47,17 @@ def get_trainer(cls, config, paras, id2accent):
         def exec(self):
             self.train()
 
-        def run_batch(self, cur_b, x, ilens, ys, olens, train, accent_idx=None):
+        def run_batch(self, cur_b, x, ilens, ys, olens, train, accent_idx=None, engine=None):
             """forward + label-smoothed CE + (train) backward, gradients left in engine.grads
-            (reference :59-99).  One host sync (read_stats) instead of the reference's three .item() calls."""
-            eng = self.asr_model.engine
+            (reference :59-99).  One host sync (read_stats) instead of the reference's three .item() calls.
+            `engine` selects a task slot's replica (concurrent tasks per GPU); default = self.asr_model."""
+            eng = engine if engine is not None else self.asr_model.engine
             eng.run_batch(x, ilens, ys, olens, train=train)
             olens += 1                                                        # quirk Q6 (mono_transformer_torch.py:139)
             st = eng.read_stats()
             info = {'loss': st['loss'], 'acc': st['n_correct'] / st['n_total']}
             if train:
-                if self.global_step % 500 == 0:
+                if self.global_step % 500 == 0 and engine is None:
                     self.probe_model(accent_idx)
             else:
                 pred, gold = eng.last_logits()
@@ -72,9 +73,9 @@ def get_trainer(cls, config, paras, id2accent):
                 inner.grad = self.asr_model.engine.grads
             self.asr_opt.step()
 
-        def clip_grad_norm_(self, max_norm):
+        def clip_grad_norm_(self, max_norm, engine=None):
             """nn.utils.clip_grad_norm_(self.asr_model.parameters(), max_norm) -> python float (host sync)."""
-            eng = self.asr_model.engine
+            eng = engine if engine is not None else self.asr_model.engine
             eng.clip_grads(max_norm)
             return eng.read_stats()['grad_norm']
 

@@ -45,6 +45,8 @@ def build_parser():
     p.add_argument('--njobs', default=-1, type=int)
     # MI355X-path extras (all default to the reference's behaviour)
     p.add_argument('--hbm_shards', action='store_true', help='keep the fbank shards resident in HBM (GPU gather+pad)')
+    p.add_argument('--tasks_per_gpu', type=int, default=1, help='FOMAML: accent-tasks of a meta-step run concurrently on one GPU '
+                   '(replica + HIP stream + host thread each); results are identical to 1 (tasks are independent)')
     p.add_argument('--fix_snapshot_meta_weights', action='store_true', help='save the META weights in snapshots (reference saves the last task\'s adapted weights)')
     return p
 

@@ -20,9 +20,9 @@ from oracle import ref_cpu  # noqa: E402
 from oracle.make_goldens import TINY, ODIM, write_toy_shard  # noqa: E402
 
 
-def make_run(tmp_path, algo="fomaml", max_step=3):
+def make_run(tmp_path, algo="fomaml", max_step=3, tasks_per_gpu=1):
     data = tmp_path / "data"
-    data.mkdir()
+    data.mkdir(exist_ok=True)
     for ai, a in enumerate(["african", "australia"]):
         write_toy_shard(data, a, "train", 16, seed=100 + ai)
         write_toy_shard(data, a, "dev", 4, seed=200 + ai)
@@ -36,7 +36,8 @@ def make_run(tmp_path, algo="fomaml", max_step=3):
     paras = SimpleNamespace(config="x", pretrain_suffix="g", pretrain_accents=["af", "au"], num_pretrain=2, tgt_accent="ca", runs=0,
                             overwrite=True, seed=531, no_cuda=False, no_memmap=False, no_bucket=False, meta_k=2, meta_batch_size=2,
                             sample_strategy="normal", max_step=max_step, resume=False, resume_step=-1, use_tensorboard=False,
-                            model_name="transformer", algo=algo, njobs=0, cuda=True, is_bucket=True, is_memmap=True, device="cuda:0")
+                            model_name="transformer", algo=algo, njobs=0, cuda=True, is_bucket=True, is_memmap=True, device="cuda:0",
+                            tasks_per_gpu=tasks_per_gpu)
     id2accent = {"af": "african", "au": "australia", "ca": "canada"}
     return cfg, paras, id2accent
 
@@ -107,3 +108,23 @@ def test_reptile_and_maml_are_rejected_like_the_reference(tmp_path, monkeypatch)
     solver.load_data(); solver.set_model()
     with pytest.raises(ValueError, match="Not support meta algo"):
         solver.exec()
+
+
+def test_concurrent_task_slots_reproduce_sequential_run(tmp_path, monkeypatch):
+    """--tasks_per_gpu 2: the two tasks of each meta-step run concurrently (replica + stream + thread each); the meta
+    weights must come out bit-identical to the sequential run (same batches, same kernels, same accumulation order)."""
+    monkeypatch.chdir(tmp_path)
+    finals = []
+    for k in (1, 2):
+        cfg, paras, id2accent = make_run(tmp_path, tasks_per_gpu=k)
+        random.seed(531); np.random.seed(531); torch.manual_seed(531)
+        solver = get_trainer(FOMetaASRInterface, cfg, paras, id2accent)
+        solver.load_data(); solver.set_model()
+        solver.asr_model.load_state_dict(ref_cpu.deterministic_state_dict(cfg["asr_model"], ODIM, seed=7))
+        solver.load_model()
+        solver.evaluate = lambda: None
+        solver.exec()
+        torch.cuda.synchronize()
+        finals.append((solver._original.clone(), dict(solver.train_info)))
+    assert torch.equal(finals[0][0], finals[1][0])
+    assert finals[0][1] == finals[1][1]
