@@ -724,9 +724,37 @@ int masr_copy(float* dst, const float* src, int64_t n, void* stream) {
 }
 
 int masr_recog(masr_model* m, const float* xs, const int64_t* ilens, int B, int T, int32_t* out, void* stream) {
-    (void)m; (void)xs; (void)ilens; (void)B; (void)T; (void)out; (void)stream;
-    mk_set_error("masr_recog", "greedy decode is a SURVEY 8(f) 'next' row and is not built yet");
-    return -3;
+    // MyTransformer.recog (mono_transformer_torch.py:143-176): the encoder runs once; then, for step = 1 .. max(enc_lens),
+    // the WHOLE prefix [sos, out_0 .. out_{step-2}] is decoded again (no KV cache, exactly as the reference) and every
+    // position's arg-max becomes the new `out`.  The result after the last step is out[Ldec][B].
+    hipStream_t s = (hipStream_t)stream;
+    if (!m->P) { mk_set_error("masr_recog", "not bound"); return -1; }
+    if (B <= 0 || T < 4) { mk_set_error("masr_recog", "need B >= 1 and T >= 4"); return -1; }
+    int Ldec = 0;
+    for (int b = 0; b < B; ++b) {
+        if (ilens[b] < 4 || ilens[b] > T) { mk_set_error("masr_recog", "ilens must be in [4, T]"); return -1; }
+        if ((int)(ilens[b] / 4) > Ldec) Ldec = (int)(ilens[b] / 4);
+    }
+    Arena ar{m->ws, m->ws_bytes, m->persist_bytes};
+    plan_acts(m, ar, m->acts, B, T, Ldec, false);
+    if (ar.off > m->ws_bytes) { mk_set_error("masr_recog", "workspace too small (masr_workspace_bytes(B, T, max(ilens)/4))"); return -2; }
+    Acts& a = m->acts; m->have_acts = true;
+    const int slot = m->stage_slot; m->stage_slot = (slot + 1) & 3;
+    HIP_CHECK_RET(hipEventSynchronize(m->stage_ev[slot]));
+    int* h_len = m->h_stage + (int64_t)slot * m->stage_ints;
+    for (int b = 0; b < B; ++b) h_len[b] = (int)(ilens[b] / 4);
+    HIP_CHECK_RET(hipMemcpyAsync(a.enc_lens, h_len, sizeof(int) * (size_t)B, hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipEventRecord(m->stage_ev[slot], s));
+    Ctx c{m, s, 0u, false, 0.f, 0.f};
+    CK(forward_encoder(c, xs));
+    for (int step = 1; step <= Ldec; ++step) {
+        a.L = step; a.rows_d = B * step;
+        CK(mk_recog_build_tok(a.tok_in, out, B, step, 0, s));
+        CK(forward_decoder(c));
+        CK(mk_recog_argmax(a.logits, m->Cp, out, B, step, m->C, s));
+    }
+    m->have_acts = false;                                   // logits/gold views are not meaningful after a decode
+    return 0;
 }
 
 int masr_gather_pad(const float* feat, const int64_t* row_start, const int32_t* lens, float* xs, int B, int Tmax, int D, void* stream) {

@@ -74,6 +74,9 @@ int mk_embed_fwd(const int* tok, const float* table, const float* pe, float* y32
 // dtable[v] (+)= sum over rows with tok==v of dy[row]  (deterministic: one block per vocab row)
 int mk_embed_bwd(const int* tok, const float* dy, float* dtable, int rows, int V, int E, int accumulate,
                    float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
+// greedy decode: build the next decoder input from the previous step's tokens; arg-max of every logits row
+int mk_recog_build_tok(int* tok, const int* out, int B, int L, int sos, hipStream_t s);
+int mk_recog_argmax(const float* logits, long ld, int* out, int B, int L, int C, hipStream_t s);
 // y16 = bf16(x32 * dropout_mask)
 int mk_cast_dropout(const float* x, bf16* y, long n, float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
 // column sums of x[rows][cols] (cols % 8 == 0, ld >= cols); only the first out_cols are written

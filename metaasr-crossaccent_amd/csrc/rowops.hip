@@ -233,6 +233,29 @@ __global__ void colsum_reduce(const float* __restrict__ slab, int nblocks, float
     out[c] = s;
 }
 
+// ---------------------------------------------------------------- greedy decode helpers (MyTransformer.recog, :143-176)
+// decoder input of step `L`: tok[b][0] = sos, tok[b][l] = previous step's output token at position l-1
+__global__ void recog_build_tok_kernel(int* __restrict__ tok, const int* __restrict__ out, int B, int L, int sos) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * L) return;
+    const int b = i / L, l = i % L;
+    tok[i] = l == 0 ? sos : out[(l - 1) * B + b];
+}
+// out[l][b] = argmax_c logits[b*L + l][c]  (first maximal index, as torch.argmax); one wave per row
+__global__ __launch_bounds__(256) void recog_argmax_kernel(const float* __restrict__ logits, long ld, int* __restrict__ out, int B, int L, int C) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B * L) return;
+    const float* z = logits + (long)row * ld;
+    float mx = -3.4e38f; int am = 0;
+    for (int c = lane; c < C; c += 64) { const float v = z[c]; if (v > mx) { mx = v; am = c; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(mx, o, 64); const int oa = __shfl_xor(am, o, 64);
+        if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
+    }
+    if (lane == 0) out[(row % L) * B + row / L] = am;
+}
+
 // ---------------------------------------------------------------- label-smoothed CE
 // reference: src/transformer_torch_trainer.py:64-84 -- q = onehot*(1-eps) + (1-onehot)*eps/C (note /C),
 // loss_i = -sum_c q_c logp_c, masked mean over gold != -1; eps == 0 -> plain CE(ignore_index=-1).
@@ -343,6 +366,14 @@ int mk_embed_bwd(const int* tok, const float* dy, float* dtable, int rows, int V
                    uint32_t seed, uint32_t site, hipStream_t s) {
     if (E % 64) { mk_set_error("mk_embed_bwd", "d_model must be a multiple of 64"); return -1; }
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(V, E / 64), dim3(256), 0, s, tok, dy, dtable, rows, E, accumulate, drop_p, seed, site);
+    return LAUNCH_OK();
+}
+int mk_recog_build_tok(int* tok, const int* out, int B, int L, int sos, hipStream_t s) {
+    hipLaunchKernelGGL(recog_build_tok_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, tok, out, B, L, sos);
+    return LAUNCH_OK();
+}
+int mk_recog_argmax(const float* logits, long ld, int* out, int B, int L, int C, hipStream_t s) {
+    hipLaunchKernelGGL(recog_argmax_kernel, dim3((B * L + 3) / 4), dim3(256), 0, s, logits, ld, out, B, L, C);
     return LAUNCH_OK();
 }
 int mk_cast_dropout(const float* x, bf16* y, long n, float drop_p, uint32_t seed, uint32_t site, hipStream_t s) {

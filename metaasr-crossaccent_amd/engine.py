@@ -147,6 +147,21 @@ class MasrEngine:
               "masr_run_batch")
         self._last_x = xs          # keep the input alive until the stream has consumed it
 
+    def recog(self, xs: torch.Tensor, ilens):
+        """greedy decode (MyTransformer.recog): returns int64 [Ldec, B] on the device, Ldec = max(ilens // 4)"""
+        if xs.device != self.device:
+            xs = xs.to(self.device, non_blocking=True)
+        xs = xs.contiguous().float()
+        B, T, D = xs.shape
+        il = torch.as_tensor(ilens, dtype=torch.int64).cpu().contiguous()
+        Ldec = int(il.max()) // 4
+        self._ensure_ws(B, T, Ldec)
+        self.refresh()
+        out = torch.zeros(Ldec, B, dtype=torch.int32, device=self.device)
+        check(self._l.masr_recog(self.h, _ptr(xs), C.c_void_p(il.data_ptr()), B, T, _ptr(out), self.stream()), "masr_recog")
+        self._last_x = xs
+        return out.to(torch.int64)
+
     def read_stats(self):
         out = (C.c_float * 4)()
         check(self._l.masr_read_stats(self.h, out, self.stream()), "masr_read_stats")

@@ -97,4 +97,6 @@ class MyTransformer:
     __call__ = forward
 
     def recog(self, xs_pad, ilens):
-        raise NotImplementedError("greedy decode (SURVEY 8(f) row 1) is not built in this round")
+        """greedy decode (:143-176): encoder once, max(enc_lens) full re-decodes, arg-max of every position -> [Ldec, B]"""
+        assert xs_pad.size(0) == ilens.size(0), "Batch size mismatch"
+        return self.engine.recog(xs_pad, ilens)

@@ -170,3 +170,24 @@ def test_dropout_forward_backward_consistency(sd):
     fd = (lp - lm) / (2 * eps)
     an = float(g0.norm())
     assert abs(fd - an) < 0.08 * an, (fd, an)
+
+
+def test_recog_matches_reference_tokens(sd, G):
+    """greedy decode (masr_recog) vs the reference's MyTransformer.recog tokens (golden).  The tiny random model has
+    near-flat logits, so bf16 rounding can flip an arg-max; once a token differs the rest of that utterance diverges
+    (autoregressive), so agreement is checked on the leading tokens and against the bf16-emulated oracle."""
+    ilens, olens = CASES["ragged"]
+    xs, il, ys, ol = synth_batch(11, ilens, olens)
+    eng = MasrEngine(TINY, ODIM)
+    eng.load_state_dict(sd)
+    hyp = eng.recog(xs, il).cpu()
+    ref = torch.from_numpy(G["recog/hyp"])
+    assert hyp.shape == ref.shape == (max(ilens) // 4, len(ilens))
+    with ref_cpu.bf16_emulation(), torch.no_grad():
+        hq = ref_cpu.recog_greedy(sd, TINY, xs, il)
+    agree_ref = float((hyp == ref).float().mean())
+    agree_q = float((hyp == hq).float().mean())
+    first = int((hyp[0] == ref[0]).sum())
+    print(f"recog agreement: reference {agree_ref:.3f}, bf16-emulated oracle {agree_q:.3f}, first tokens {first}/{len(ilens)}")
+    assert first == len(ilens)
+    assert agree_ref >= 0.9 and agree_q >= 0.9

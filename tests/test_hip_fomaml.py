@@ -128,3 +128,31 @@ def test_concurrent_task_slots_reproduce_sequential_run(tmp_path, monkeypatch):
         finals.append((solver._original.clone(), dict(solver.train_info)))
     assert torch.equal(finals[0][0], finals[1][0])
     assert finals[0][1] == finals[1][1]
+
+
+def test_tester_writes_best_hyp_like_the_reference(tmp_path, monkeypatch):
+    """train.py --test path: Tester loads model.wer.best (reference state_dict layout), greedy-decodes the test shard and
+    appends "<ref ids> TAB <hyp ids>" lines with the reference's trim rule."""
+    from masr_amd.tester import Tester
+    monkeypatch.chdir(tmp_path)
+    cfg, paras, id2accent = make_run(tmp_path)
+    write_toy_shard(tmp_path / "data", "african", "test", 6, seed=300)
+    paras.accent, paras.eval_suffix, paras.pretrain_suffix, paras.algo = "af", "ev", None, "no"
+    paras.test_model, paras.decode_suffix, paras.decode_mode, paras.decode_batch_size = "model.wer.best", "greedy_decode", "greedy", 4
+    log_dir = tmp_path / "testing-logs" / "evaluation" / "gold" / "no" / "ev" / "ev" / "african" / "0"
+    log_dir.mkdir(parents=True)
+    sd = ref_cpu.deterministic_state_dict(cfg["asr_model"], ODIM, seed=7)
+    torch.save(sd, log_dir / "model.wer.best")
+    t = Tester(cfg, paras, id2accent)
+    t.load_data(); t.set_model(); t.exec()
+    lines = (log_dir / "greedy_decode" / "best-hyp").read_text().splitlines()
+    labels = np.load(tmp_path / "data" / "african" / "test" / "label.npy")
+    olens = np.load(tmp_path / "data" / "african" / "test" / "olens.npy")
+    assert len(lines) == 6
+    refs = sorted(l.split("\t")[0] for l in lines)
+    optr = np.concatenate([[0], np.cumsum(olens)])
+    assert refs == sorted(" ".join(str(int(x)) for x in labels[optr[i]:optr[i + 1]]) for i in range(6))
+    for l in lines:
+        hyp = [int(x) for x in l.split("\t")[1].split()] if "\t" in l and l.split("\t")[1] else []
+        assert ODIM - 1 not in hyp[1:]                       # nothing after (and including) the first </s> survives trim
+    assert t.trim([5, 366, 7]) == [5] and t.trim([366, 4, 366, 9]) == [366, 4] and t.trim([3]) == [] and t.trim([1, 2, 3]) == [1, 2, 3]

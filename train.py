@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """train.py -- drop-in CLI of the reference's train.py:22-127 (mono-accent training / fine-tuning) on the
-MI355X-native path.  `--test` (greedy decode) is not built in this round."""
+MI355X-native path.  `--test` runs the greedy decoder (masr_recog) and writes best-hyp like src/tester.py."""
 import argparse
 import json
 import os
@@ -65,7 +65,11 @@ def main(argv=None):
     with open(Path('data', 'accent-code.json')) as fin:
         id2accent = json.load(fin)
     if paras.test:
-        raise NotImplementedError("--test (greedy decode + best-hyp) is SURVEY 8(f) row 1: not built in this round")
+        from masr_amd.tester import Tester
+        paras.decode_suffix = f"{paras.decode_mode}_decode" + (f"_{paras.decode_suffix}" if paras.decode_suffix else "")   # train.py:83
+        solver = Tester(config, paras, id2accent)
+        solver.load_data(); solver.set_model(); solver.exec()
+        return
     if paras.model_name != 'transformer':
         raise NotImplementedError("only the transformer trainer is on the MI355X path (BLSTM/CTC: masr_ctc_loss kernel only)")
     from masr_amd.mono_interface import MonoASRInterface
