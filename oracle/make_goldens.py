@@ -424,6 +424,33 @@ def gen_init_goldens():
     print("init.npz")
 
 
+def gen_metric_goldens():
+    """Metric.batch_cal_er (src/monitor/metric.py:36-87) on seeded logits with the reference's sentencepiece model."""
+    from src.monitor.metric import Metric
+    units = ['<s>'] + [l.rstrip().split(' ')[0] for l in open(REF / "data" / "valid_train_en_unigram150_units.txt")] + ['</s>']
+    m = Metric(str(REF / "data" / "valid_train_en_unigram150.model"), units, 0, len(units) - 1)
+    g = torch.Generator().manual_seed(21)
+    B, L = 6, 12
+    gold = torch.full((B, L), -1, dtype=torch.int64)
+    pred_ids = torch.randint(1, 366, (B, L), generator=g)
+    for b in range(B):
+        n = int(torch.randint(3, L - 1, (1,), generator=g))
+        gold[b, :n] = torch.randint(1, 366, (n,), generator=g)
+        gold[b, n] = 366
+        keep = torch.rand(n, generator=g) < 0.6                     # hypotheses share ~60 % of the reference tokens
+        pred_ids[b, :n] = torch.where(keep, gold[b, :n], pred_ids[b, :n])
+        pred_ids[b, n + int(torch.randint(0, 2, (1,), generator=g))] = 366
+    pred_ids[5, 0] = 366                                            # leading </s>: not a stop (discard_ch_after_eos quirk)
+    logits = torch.nn.functional.one_hot(pred_ids, 367).float()
+    out = {"pred_ids": pred_ids.numpy(), "gold": gold.numpy()}
+    out["cer"] = np.float64(m.batch_cal_er(logits, gold, ['att'], ['cer'])['att_cer'])
+    out["wer"] = np.float64(m.batch_cal_er(logits, gold, ['att'], ['wer'])['att_wer'])
+    out["per_cer"] = np.array([m.cal_att_cer(pred_ids[b], gold[b]) for b in range(B)])
+    out["per_wer"] = np.array([m.cal_att_wer(pred_ids[b], gold[b]) for b in range(B)])
+    np.savez_compressed(OUT / "metric.npz", **out)
+    print("metric.npz", out["cer"], out["wer"])
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     install_stubs()
@@ -433,6 +460,7 @@ def main():
     gen_sampler_goldens()
     gen_ctc_goldens()
     gen_init_goldens()
+    gen_metric_goldens()
     gen_model_goldens()
     gen_fomaml_goldens()
 

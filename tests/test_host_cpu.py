@@ -136,3 +136,22 @@ def test_levenshtein():
     assert levenshtein("kitten", "sitting") == 3
     assert levenshtein([], [1, 2]) == 2
     assert levenshtein(["a", "b"], ["a", "b"]) == 0
+
+
+SPM = Path("/root/reference/data/valid_train_en_unigram150.model")
+
+
+@pytest.mark.skipif(not SPM.exists(), reason="needs the reference's sentencepiece model (build container only)")
+def test_metric_matches_reference(golden_dir):
+    """eval metric path: teacher-forced argmax -> trim -> DecodePieces -> Levenshtein."""
+    from masr_amd.monitor.metric import Metric
+    g = np.load(golden_dir / "metric.npz")
+    units = ['<s>'] + [l.rstrip().split(' ')[0] for l in open(SPM.parent / "valid_train_en_unigram150_units.txt")] + ['</s>']
+    m = Metric(SPM, units, 0, len(units) - 1)
+    pred_ids, gold = torch.from_numpy(g["pred_ids"]), torch.from_numpy(g["gold"])
+    logits = torch.nn.functional.one_hot(pred_ids, 367).float()
+    assert abs(m.batch_cal_er(logits, gold, ['att'], ['cer'])['att_cer'] - float(g["cer"])) < 1e-9
+    assert abs(m.batch_cal_er(logits, gold, ['att'], ['wer'])['att_wer'] - float(g["wer"])) < 1e-9
+    for b in range(len(gold)):
+        assert abs(m.cal_att_cer(pred_ids[b], gold[b]) - g["per_cer"][b]) < 1e-9
+        assert abs(m.cal_att_wer(pred_ids[b], gold[b]) - g["per_wer"][b]) < 1e-9
