@@ -221,12 +221,12 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 // (64-channel slab) is brought into LDS ONCE and all 9 taps read their A fragments straight out of it (no im2col
 // re-fetch: HBM/L2 traffic per output pixel drops from 9x to ~1.3x the input bytes); the per-tap weight slice
 // [COUT][64] is double-buffered through registers.  4 waves, wave w owns TH/4 pixel rows x all COUT.
-// LDS: patch pixel stride 72 elements (144 B: 16 pixels of a fragment land on 16 distinct 16-byte slots).
+// LDS: patch pixel / weight row stride 80 elements (160 B), conflict-free for the four 16-lane groups of ds_read_b128.
 template <int CIN, int COUT, int TH>
 __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
     constexpr int TW = 16, PW = TW + 2, PH = TH + 2;
-    constexpr int PS = 72;                                 // patch pixel stride (elements)
-    constexpr int WS = 72;                                 // weight row stride (elements)
+    constexpr int PS = 80;                                 // patch pixel stride (elements): 160 B is conflict-free for the
+    constexpr int WS = 80;                                 // ds_read_b128 lane groups (144 B measured 39 % conflict cycles)
     constexpr int MF = TH / 4, NF = COUT / 16;
     constexpr int KTOT = 9 * CIN, NSLAB = CIN / 64;
     constexpr int PATCH_EL = PH * PW * PS, W_EL = COUT * WS;
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(ConvWgradArgs a, lon
 // and feed ALL 9 taps (both operands via ds_read_b64_tr_b16, contraction over the pixel index), so L2/HBM traffic per
 // FLOP is 9x lower than one-tap-per-workgroup.  The 9 x 64 x 64 fp32 partial stays in registers (144 VGPRs/lane) across
 // all tiles of the workgroup and is written once; a fixed-order slab reduce makes the result deterministic.
-constexpr int W2_TH = 8, W2_TW = 16, W2_PH = W2_TH + 2, W2_PW = W2_TW + 2, W2_PS = 72, W2_LDY = 80;
+constexpr int W2_TH = 8, W2_TW = 16, W2_PH = W2_TH + 2, W2_PW = W2_TW + 2, W2_PS = 80, W2_LDY = 80;   // 160-B rows: tr-reads conflict-free
 constexpr int W2_TOTAL_WG = 256;    // one persistent workgroup per CU (144 accumulator VGPRs -> one wave per SIMD, no spills)
 
 template <int CIN, int COUT, int OCC>

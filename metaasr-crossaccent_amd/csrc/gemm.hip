@@ -22,7 +22,7 @@
 namespace {
 
 constexpr int BK = 64;    // k-tile: halves the barrier / LDS round trips per FLOP of the 32-deep version
-constexpr int LDK = 72;   // NT form: padded LDS row (elements), 144-byte stride (16 rows -> 16 distinct 16-byte slots)
+constexpr int LDK = 80;   // NT form: padded LDS row (elements); 160-byte stride is conflict-free for ds_read_b128 lane groups (144 B is 2-way)
 
 template <int ROWS>
 struct TileNT { bf16 d[ROWS * LDK]; };
