@@ -78,8 +78,8 @@ def test_run_batch_vs_oracle_and_golden(sd, G, cname, eps):
         # forward disagreement of two different bf16 implementations (each flipped unit moves a whole row/column
         # of a weight gradient): a few percent on this 30-token batch.  Structure errors show up as >> 10 %.
         assert r < 8e-2, (n, r)
-    flat_a = torch.cat([g_all[n].cpu().reshape(-1) for n in names if not n.endswith("in_proj_bias")])
-    flat_b = torch.cat([gradsq[n].reshape(-1) for n in names if not n.endswith("in_proj_bias")])
+    flat_a = torch.cat([g_all[n].cpu().reshape(-1) for n in names if not n.endswith("in_proj_bias")]).double()
+    flat_b = torch.cat([gradsq[n].reshape(-1) for n in names if not n.endswith("in_proj_bias")]).double()
     cos = float((flat_a * flat_b).sum() / (flat_a.norm() * flat_b.norm()))
     assert cos > 0.999, cos
     assert abs(float(flat_a.norm()) - float(flat_b.norm())) < 1e-2 * float(flat_b.norm())
@@ -191,3 +191,43 @@ def test_recog_matches_reference_tokens(sd, G):
     print(f"recog agreement: reference {agree_ref:.3f}, bf16-emulated oracle {agree_q:.3f}, first tokens {first}/{len(ilens)}")
     assert first == len(ilens)
     assert agree_ref >= 0.9 and agree_q >= 0.9
+
+
+HKUST = {"idim": 83, "nheads": 8, "d_model": 512, "d_inner": 2048, "dropout": 0.0, "pos_dropout": 0.0, "tgt_share_weight": 1,
+         "encoder": {"nlayers": 2}, "decoder": {"nlayers": 4},
+         "meta": {"optimizer_opt": {"k": 1.0, "warmup_steps": 25000}}}
+
+
+def test_hkust_geometry_inner_steps_vs_oracle():
+    """The shipped fometa-hkust.yaml geometry (24.88 M parameters, head dim 64, idim 83 -> odd widths in the VGG) on a
+    ragged batch: loss of two consecutive inner steps (run_batch + clip 5 + Nesterov SGD at the shipped inner lr) against
+    the fp32 oracle within the north-star 1e-3, and the flat gradient's direction / size against the bf16-emulated oracle."""
+    sd = ref_cpu.deterministic_state_dict(HKUST, ODIM, seed=3)
+    assert sum(v.numel() for k, v in sd.items() if k not in ("pos_encoder.pe", "pre_embed.weight")) == 24881455
+    ilens, olens = [203, 160, 121], [12, 9, 7]
+    b1, b2 = synth_batch(5, ilens, olens), synth_batch(6, ilens, olens)
+    eng = MasrEngine(HKUST, ODIM, label_smoothing=0.2)
+    eng.load_state_dict(sd)
+    mom = torch.zeros_like(eng.params)
+    lr = ref_cpu.inner_lr(HKUST)
+    got, g_first = [], None
+    for i, b in enumerate((b1, b2)):
+        eng.run_batch(b[0], b[1], b[2], b[3], train=True)
+        if i == 0:
+            g_first = eng.state_dict(flat=eng.grads)
+        eng.clip_sgd_step(mom, 5.0, lr, 0.9, True, first_step=(i == 0))
+        got.append(eng.read_stats())
+    p = ref_cpu.leafify(sd, HKUST)
+    bufs = {}
+    ref = [ref_cpu.inner_step(p, HKUST, (b[0], b[1], b[2], b[3].clone()), 0.2, bufs, lr) for b in (b1, b2)]
+    for g, r in zip(got, ref):
+        assert abs(g["loss"] - r["loss"]) <= 1e-3 * r["loss"], (g["loss"], r["loss"])
+        assert abs(g["grad_norm"] - r["grad_norm"]) <= 3e-2 * r["grad_norm"], (g["grad_norm"], r["grad_norm"])
+    with ref_cpu.bf16_emulation():
+        pq = ref_cpu.leafify(sd, HKUST)
+        _, gq, _, _ = ref_cpu.run_batch_train(pq, HKUST, (b1[0], b1[1], b1[2], b1[3].clone()), 0.2)
+    names = [n for n in ref_cpu.grad_param_names(pq, HKUST) if not n.endswith("in_proj_bias")]
+    a = torch.cat([g_first[n].cpu().reshape(-1) for n in names]).double(); bq = torch.cat([gq[n].reshape(-1) for n in names]).double()
+    cos = float((a * bq).sum() / (a.norm() * bq.norm()))
+    print(f"hkust: losses {[round(g['loss'], 5) for g in got]} vs {[round(r['loss'], 5) for r in ref]}; grad cos {cos:.5f}")
+    assert cos > 0.995 and abs(float(a.norm() / bq.norm()) - 1) < 2e-2
