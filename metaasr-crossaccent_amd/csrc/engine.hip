@@ -132,7 +132,7 @@ void plan_persistent(masr_model* m, Arena& ar) {
     for (auto& d : m->dec) { lin(d.sa.in); lin(d.sa.out); lin(d.ca.in); lin(d.ca.out); lin(d.l1); lin(d.l2); }
     m->stats = ar.get<float>(64);
     const int nlin = (int)(m->enc.size() * 4 + m->dec.size() * 6);
-    m->d_ranges = ar.get<long>(2 * (2 * nlin + 2));
+    m->d_ranges = ar.get<long>(2 * (2 * nlin + 2 * (int)m->dec.size() + 2));
     m->d_sdesc = ar.get<ShadowDesc>(nlin);
     m->d_sptrs = ar.get<bf16*>(2 * nlin);
 }
@@ -228,12 +228,15 @@ struct Ctx { masr_model* m; hipStream_t s; uint32_t seed; bool train; float p_dr
 int gemm(Ctx& c, const GemmArgs& g) { Prof p(c.m, MASR_PROF_GEMM, c.s); return mk_gemm(g, c.s); }
 
 // weight/bias gradients of a Linear: dW[N][K] = dy^T x, db = colsum(dy)
-int lin_wgrad(Ctx& c, const bf16* dy, long lddy, const bf16* x, long ldx, int rows, int N, int K, float* dW, float* db, int accumulate = 0) {
+int lin_wgrad(Ctx& c, const bf16* dy, long lddy, const bf16* x, long ldx, int rows, int N, int K, float* dW, float* db, bool split = false,
+              int accumulate = 0) {
     GemmArgs g = gemm_args();
     g.reduction_major = 1; g.A = dy; g.lda = lddy; g.B = x; g.ldb = ldx; g.M = N; g.N = K; g.K = rows;
     g.C32 = dW; g.ldc = K; g.accumulate = accumulate; g.colsum = db;
     masr_model* m = c.m;
-    if (dW >= m->G && dW < m->G + m->nparams) {           // gradient lives in the flat buffer -> split-K with slab partials
+    // long reductions (encoder rows B*T') are split over WG_SPLIT workgroups with slab partials that
+    // mk_split_reduce combines in fixed order; decoder-row reductions (B*L) are short and stay whole
+    if (split && dW >= m->G && dW < m->G + m->nparams) {
         g.split_k = WG_SPLIT; g.split_delta = m->acts.wg_slab - m->G; g.split_stride = m->nparams;
     }
     CK(gemm(c, g));
@@ -296,13 +299,13 @@ int ln_bwd(Ctx& c, const Norm& n, const float* dy, const float* x, const float* 
 // backward of  s_out = x + drop(ffn(x16))  given d s_out (gs32 fp32, gs16 bf16 already dropout-masked for the ffn output site)
 // writes d x (fp32) = gs32 + ffn-branch gradient into gout
 int ffn_bwd(Ctx& c, const Lin& l1, const Lin& l2, const bf16* x16, const bf16* f, const float* gs32, const bf16* gs16, int rows,
-            bf16* gf, float* gout) {
+            bf16* gf, float* gout, bool split) {
     masr_model* m = c.m; const int E = m->E, Fi = m->Fi;
-    CK(lin_wgrad(c, gs16, E, f, Fi, rows, E, Fi, m->G + l2.w, m->G + l2.b));
+    CK(lin_wgrad(c, gs16, E, f, Fi, rows, E, Fi, m->G + l2.w, m->G + l2.b, split));
     GemmArgs g = lin_dgrad_args(gs16, E, l2.t16, E, rows, E, Fi);
     g.mask = f; g.ldmask = Fi; g.mask_scale = c.p_drop > 0.f ? 1.f / (1.f - c.p_drop) : 1.f; g.C16 = gf; g.ldc16 = Fi;
     CK(gemm(c, g));
-    CK(lin_wgrad(c, gf, Fi, x16, E, rows, Fi, E, m->G + l1.w, m->G + l1.b));
+    CK(lin_wgrad(c, gf, Fi, x16, E, rows, Fi, E, m->G + l1.w, m->G + l1.b, split));
     GemmArgs h = lin_dgrad_args(gf, Fi, l1.t16, Fi, rows, Fi, E);
     h.residual = gs32; h.ldres = E; h.C32 = gout; h.ldc = E;
     CK(gemm(c, h));
@@ -409,17 +412,21 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
     {   // device tables: split-K combine ranges and the fused shadow-refresh descriptors
         std::vector<long> ranges; std::vector<ShadowDesc> desc; std::vector<bf16*> ptrs;
         int tiles = 0;
-        auto lin = [&](const Lin& l) {
-            ranges.push_back(l.w); ranges.push_back((long)l.N * l.K);
-            ranges.push_back(l.b); ranges.push_back(l.N);
+        auto lin = [&](const Lin& l, bool split) {
+            if (split) {                                           // split-K partials exist only for the encoder-row wgrads
+                ranges.push_back(l.w); ranges.push_back((long)l.N * l.K);
+                ranges.push_back(l.b); ranges.push_back(l.N);
+            }
             ShadowDesc d; d.src = l.w; d.N = l.N; d.K = l.K; d.Np = (l.N + 7) / 8 * 8; d.tile_start = tiles;
             tiles += ((l.N + 31) / 32) * ((l.K + 31) / 32);
             desc.push_back(d); ptrs.push_back(l.k16); ptrs.push_back(l.t16);
         };
-        for (auto& e : m->enc) { lin(e.sa.in); lin(e.sa.out); lin(e.l1); lin(e.l2); }
-        for (auto& d : m->dec) { lin(d.sa.in); lin(d.sa.out); lin(d.ca.in); lin(d.ca.out); lin(d.l1); lin(d.l2); }
-        ranges.push_back(m->ct.w); ranges.push_back((long)m->C * m->E);
-        ranges.push_back(m->ct.b); ranges.push_back(m->C);
+        for (auto& e : m->enc) { lin(e.sa.in, true); lin(e.sa.out, true); lin(e.l1, true); lin(e.l2, true); }
+        for (auto& d : m->dec) { lin(d.sa.in, false); lin(d.sa.out, false); lin(d.ca.in, false); lin(d.ca.out, false); lin(d.l1, false); lin(d.l2, false); }
+        for (auto& d : m->dec) {                                   // cross-attention K/V projection: reduction over encoder rows
+            ranges.push_back(d.ca.in.w + (long)m->E * m->E); ranges.push_back(2L * m->E * m->E);
+            ranges.push_back(d.ca.in.b + m->E); ranges.push_back(2L * m->E);
+        }
         m->nranges = (int)ranges.size() / 2; m->nsdesc = (int)desc.size(); m->shadow_tiles = tiles;
         HIP_CHECK_RET(hipMemcpy(m->d_ranges, ranges.data(), sizeof(long) * ranges.size(), hipMemcpyHostToDevice));
         HIP_CHECK_RET(hipMemcpy(m->d_sdesc, desc.data(), sizeof(ShadowDesc) * desc.size(), hipMemcpyHostToDevice));
@@ -518,9 +525,9 @@ static int forward_decoder(Ctx& c) {
 static int attn_block_bwd(Ctx& c, const Attn& at, const bf16* xq16, const bf16* xkv16, int rows_q, int rows_kv, int Tq, int Tk, bool self,
                           bool causal, const int* klens, const bf16* qkv_or_q, const bf16* kv, const bf16* ao, const float* lse,
                           const float* gs32, const bf16* gs16, bf16* gao, bf16* gqkv_or_q, bf16* gkv, float* delta, float* gout,
-                          float* dmem, int dmem_accumulate, uint32_t site_p) {
+                          float* dmem, int dmem_accumulate, uint32_t site_p, bool split) {
     masr_model* m = c.m; const int E = m->E; float* G = m->G;
-    CK(lin_wgrad(c, gs16, E, ao, E, rows_q, E, E, G + at.out.w, G + at.out.b));
+    CK(lin_wgrad(c, gs16, E, ao, E, rows_q, E, E, G + at.out.w, G + at.out.b, split));
     { GemmArgs g = lin_dgrad_args(gs16, E, at.out.t16, E, rows_q, E, E); g.C16 = gao; g.ldc16 = E; CK(gemm(c, g)); }
     AttnArgs a{};
     if (self) {
@@ -534,7 +541,7 @@ static int attn_block_bwd(Ctx& c, const Attn& at, const bf16* xq16, const bf16* 
     a.B = m->acts.B; a.H = m->H; a.Tq = Tq; a.Tk = Tk; a.hd = m->hd; a.causal = causal; a.drop_p = c.p_drop; a.seed = c.seed; a.site = site_p;
     { Prof p(m, MASR_PROF_ATTN, c.s); CK(mk_attn_bwd(a, c.s)); }
     if (self) {
-        CK(lin_wgrad(c, gqkv_or_q, 3 * E, xq16, E, rows_q, 3 * E, E, G + at.in.w, G + at.in.b));
+        CK(lin_wgrad(c, gqkv_or_q, 3 * E, xq16, E, rows_q, 3 * E, E, G + at.in.w, G + at.in.b, split));
         GemmArgs g = lin_dgrad_args(gqkv_or_q, 3 * E, at.in.t16, 3 * E, rows_q, 3 * E, E);
         g.residual = gs32; g.ldres = E; g.C32 = gout; g.ldc = E;
         CK(gemm(c, g));
@@ -543,7 +550,7 @@ static int attn_block_bwd(Ctx& c, const Attn& at, const bf16* xq16, const bf16* 
         GemmArgs g = lin_dgrad_args(gqkv_or_q, E, at.in.t16, 3 * E, rows_q, E, E);
         g.residual = gs32; g.ldres = E; g.C32 = gout; g.ldc = E;
         CK(gemm(c, g));
-        CK(lin_wgrad(c, gkv, 2 * E, xkv16, E, rows_kv, 2 * E, E, G + at.in.w + (long)E * E, G + at.in.b + E));
+        CK(lin_wgrad(c, gkv, 2 * E, xkv16, E, rows_kv, 2 * E, E, G + at.in.w + (long)E * E, G + at.in.b + E, true));   // encoder rows
         GemmArgs h = lin_dgrad_args(gkv, 2 * E, at.in.t16 + E, 3 * E, rows_kv, 2 * E, E);
         h.C32 = dmem; h.ldc = E; h.accumulate = dmem_accumulate;
         CK(gemm(c, h));
@@ -563,13 +570,13 @@ static int backward(Ctx& c, const float* xs) {
     for (int l = m->ND - 1; l >= 0; --l) {
         DecAct& d = a.dec[l]; const DecL& w = m->dec[l];
         CK(ln_bwd(c, w.n3, gcur, d.s3, d.m3, d.r3, gs, a.gd16, d.site[5], a.rows_d));
-        CK(ffn_bwd(c, w.l1, w.l2, d.y2_16, d.f, gs, a.gd16, a.rows_d, a.gf_d, gcur));
+        CK(ffn_bwd(c, w.l1, w.l2, d.y2_16, d.f, gs, a.gd16, a.rows_d, a.gf_d, gcur, false));
         CK(ln_bwd(c, w.n2, gcur, d.s2, d.m2, d.r2, gs, a.gd16, d.site[3], a.rows_d));
         CK(attn_block_bwd(c, w.ca, d.y1_16, a.mem16, a.rows_d, a.rows_e, L, a.Tp, false, false, a.enc_lens, d.q, d.kv, d.co, d.lse_c, gs,
-                          a.gd16, a.gao_d, a.gq_d, a.gkv_d, a.delta_d, gcur, a.dmem32, l == m->ND - 1 ? 0 : 1, d.site[2]));
+                          a.gd16, a.gao_d, a.gq_d, a.gkv_d, a.delta_d, gcur, a.dmem32, l == m->ND - 1 ? 0 : 1, d.site[2], false));
         CK(ln_bwd(c, w.n1, gcur, d.s1, d.m1, d.r1, gs, a.gd16, d.site[1], a.rows_d));
         CK(attn_block_bwd(c, w.sa, a.y16[l], nullptr, a.rows_d, 0, L, L, true, true, nullptr, d.qkv, nullptr, d.ao, d.lse_s, gs, a.gd16,
-                          a.gao_d, a.gqkv_d, nullptr, a.delta_d, gcur, nullptr, 0, d.site[0]));
+                          a.gao_d, a.gqkv_d, nullptr, a.delta_d, gcur, nullptr, 0, d.site[0], false));
     }
     float* g_dec_in = gcur;                                  // d(decoder input): consumed by embed_bwd after the split-K combine
     // ---- encoder
@@ -578,10 +585,10 @@ static int backward(Ctx& c, const float* xs) {
     for (int l = m->NE - 1; l >= 0; --l) {
         EncAct& e = a.enc[l]; const EncL& w = m->enc[l];
         CK(ln_bwd(c, w.n2, gcur, e.s2, e.m2, e.r2, gs, a.ge16, e.site[3], a.rows_e));
-        CK(ffn_bwd(c, w.l1, w.l2, e.x1_16, e.f, gs, a.ge16, a.rows_e, a.gf_e, gcur));
+        CK(ffn_bwd(c, w.l1, w.l2, e.x1_16, e.f, gs, a.ge16, a.rows_e, a.gf_e, gcur, true));
         CK(ln_bwd(c, w.n1, gcur, e.s1, e.m1, e.r1, gs, a.ge16, e.site[1], a.rows_e));
         CK(attn_block_bwd(c, w.sa, a.x16[l], nullptr, a.rows_e, 0, a.Tp, a.Tp, true, false, a.enc_lens, e.qkv, nullptr, e.ao, e.lse, gs, a.ge16,
-                          a.gao_e, a.gqkv_e, nullptr, a.delta_e, gcur, nullptr, 0, e.site[0]));
+                          a.gao_e, a.gqkv_e, nullptr, a.delta_e, gcur, nullptr, 0, e.site[0], true));
     }
     // ---- vgg2enc (through the positional dropout)
     { Prof p(m, MASR_PROF_OTHER, s); CK(mk_cast_dropout(gcur, a.ge16, (long)a.rows_e * E, c.p_pos, c.seed, a.site_v2e, s)); }
