@@ -660,23 +660,35 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs 
     }
 }
 
-__global__ void conv3x3_wgrad_reduce(const float* __restrict__ slab, int nsplit, float* __restrict__ dw, float* __restrict__ db,
-                                     int CIN, int COUT) {
-    const int KTOT = 9 * CIN;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // co*KTOT + tap*CIN + ci
-    if (i >= COUT * KTOT) {
-        const int co = i - COUT * KTOT;
-        if (db && co < COUT) {
-            float s = 0.f;
-            for (int k = 0; k < nsplit; ++k) s += slab[(long)nsplit * COUT * KTOT + (long)k * COUT + co];
-            db[co] = s;
+// dw[co][ci][3][3] = sum over the per-workgroup partial slabs; 64 outputs x 4 slab-lanes per workgroup, four independent
+// partial sums per thread (fixed order -> deterministic); the trailing COUT entries are the bias gradient
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce(const float* __restrict__ slab, int nsplit, float* __restrict__ dw,
+                                                            float* __restrict__ db, int CIN, int COUT) {
+    const int KTOT = 9 * CIN, NW = COUT * KTOT;
+    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + cl;                       // co*KTOT + tap*CIN + ci, then NW + co for the bias
+    __shared__ float red[4][64];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < NW + COUT) {
+        const bool is_b = i >= NW;
+        const float* p = is_b ? slab + (long)nsplit * NW + (i - NW) : slab + i;
+        const long stride = is_b ? COUT : NW;
+        int k = part;
+        for (; k + 12 < nsplit; k += 16) {
+            s0 += p[(long)k * stride]; s1 += p[(long)(k + 4) * stride]; s2 += p[(long)(k + 8) * stride]; s3 += p[(long)(k + 12) * stride];
         }
-        return;
+        for (; k < nsplit; k += 4) s0 += p[(long)k * stride];
     }
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += slab[(long)k * COUT * KTOT + i];
-    const int co = i / KTOT, rem = i % KTOT, tap = rem / CIN, ci = rem % CIN;
-    dw[((long)co * CIN + ci) * 9 + tap] = s;
+    red[part][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (part == 0 && i < NW + COUT) {
+        const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        if (i >= NW) { if (db) db[i - NW] = t; }
+        else {
+            const int co = i / KTOT, rem = i % KTOT, tap = rem / CIN, ci = rem % CIN;
+            dw[((long)co * CIN + ci) * 9 + tap] = t;
+        }
+    }
 }
 
 int wgrad_splits(long P, int CIN) {
@@ -819,7 +831,7 @@ int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s) {
 #undef W2
     }
     const int n = a.COUT * 9 * a.CIN + a.COUT;
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((n + 255) / 256), dim3(256), 0, s, a.slab, splits, a.dw, a.db, a.CIN, a.COUT);
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((n + 63) / 64), dim3(256), 0, s, a.slab, splits, a.dw, a.db, a.CIN, a.COUT);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
