@@ -17,6 +17,7 @@
 // Tile: BM x BN x 32, 256 threads = 4 waves in a 2x2 grid, register-staged double buffer.
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -118,6 +119,97 @@ __device__ __forceinline__ bf16x8 frag_rm(const bf16* tile, int r0, int lane, in
 // ~2000 instructions, which alone cost ~8 us per launch on the small decoder GEMMs); EPI < 0: decided at run time.
 enum { E_BIAS = 1, E_PE = 2, E_RELU = 4, E_MASK = 8, E_DROP = 16, E_RES = 32, E_ACC = 64, E_C32 = 128, E_C16 = 256 };
 #define HAS(flag, runtime) (EPI >= 0 ? bool(EPI & (flag)) : bool(runtime))
+
+// ---- shared epilogue (see the comment inside): consumes the accumulators of one BM x BN tile
+template <int BM, int BN, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM / 32][BN / 32], char* smem, int m0, int n0, long out_delta) {
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int LDC = BN + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // epilogue: alpha -> bias -> pe -> relu -> mask -> dropout -> residual -> (accumulate) -> store.
+    // The accumulators go through an fp32 LDS tile so that every global access of the epilogue is a 16-byte (fp32) or
+    // 8-byte (bf16) row segment, and each optional input is fetched with ONE batched load per 4 outputs (per-element
+    // branches around loads serialise on s_waitcnt vmcnt(0) and used to dominate the small decoder GEMMs).
+    float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                ct[(wm * WM + i * 16 + (lane >> 4) * 4 + r) * LDC + wn * WN + j * 16 + (lane & 15)] = acc[i][j][r] * g.alpha;
+    __syncthreads();
+    constexpr int C4 = BN / 4, NCH = BM * C4 / 256;
+    const int c4 = (tid % C4) * 4, n = n0 + c4;
+    if (n >= g.N) return;
+    const bool f_bias = HAS(E_BIAS, g.bias), f_pe = HAS(E_PE, g.pe), f_relu = HAS(E_RELU, g.relu), f_mask = HAS(E_MASK, g.mask);
+    const bool f_drop = HAS(E_DROP, g.drop_p > 0.f) && g.drop_p > 0.f, f_res = HAS(E_RES, g.residual);
+    const bool f_acc = HAS(E_ACC, g.accumulate), f_c32 = HAS(E_C32, g.C32), f_c16 = HAS(E_C16, g.C16);
+    const int nv = g.N - n < 4 ? g.N - n : 4;                   // valid columns of this thread's 4-column strip
+    const float inv_keep = f_drop ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (f_bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[n + e];
+    }
+    // 16-byte paths need 4 valid columns and 4-float-aligned rows (n is a multiple of 4 by construction)
+    const bool v_c32 = nv == 4 && f_c32 && !((g.ldc | out_delta) & 3) && !((uintptr_t)g.C32 & 15);
+    const bool v_res = nv == 4 && f_res && !(g.ldres & 3) && !((uintptr_t)g.residual & 15);
+    const bool v_c16 = nv == 4 && f_c16 && !(g.ldc16 & 3) && !((uintptr_t)g.C16 & 7);
+    const bool v_msk = nv == 4 && f_mask && !(g.ldmask & 3) && !((uintptr_t)g.mask & 7);
+    const bool v_pe = nv == 4 && f_pe && !(g.N & 3) && !((uintptr_t)g.pe & 15);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int row = (tid + i * 256) / C4, m = m0 + row;
+        if (m >= g.M) continue;
+        const f32x4 cv = *reinterpret_cast<const f32x4*>(ct + row * LDC + c4);
+        float v[4] = {cv[0] + bv[0], cv[1] + bv[1], cv[2] + bv[2], cv[3] + bv[3]};
+        float rs[4] = {0.f, 0.f, 0.f, 0.f}, old[4] = {0.f, 0.f, 0.f, 0.f}, pev[4] = {0.f, 0.f, 0.f, 0.f};
+        float mk[4] = {1.f, 1.f, 1.f, 1.f};
+        // ---- batched loads of the optional inputs
+        if (f_res) {
+            const float* p = g.residual + (long)m * g.ldres + n;
+            if (v_res) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); rs[0] = t[0]; rs[1] = t[1]; rs[2] = t[2]; rs[3] = t[3]; }
+            else { for (int e = 0; e < nv; ++e) rs[e] = p[e]; }
+        }
+        if (f_pe) {
+            const float* p = g.pe + (long)(m % g.pe_period) * g.N + n;
+            if (v_pe) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); pev[0] = t[0]; pev[1] = t[1]; pev[2] = t[2]; pev[3] = t[3]; }
+            else { for (int e = 0; e < nv; ++e) pev[e] = p[e]; }
+        }
+        if (f_mask) {
+            const bf16* p = g.mask + (long)m * g.ldmask + n;
+            if (v_msk) { const bf16x4 t = *reinterpret_cast<const bf16x4*>(p); for (int e = 0; e < 4; ++e) mk[e] = (float)t[e]; }
+            else { for (int e = 0; e < nv; ++e) mk[e] = (float)p[e]; }
+        }
+        float* c32 = f_c32 ? g.C32 + out_delta + (long)m * g.ldc + n : nullptr;
+        if (f_c32 && f_acc) {
+            if (v_c32) { const f32x4 t = *reinterpret_cast<const f32x4*>(c32); old[0] = t[0]; old[1] = t[1]; old[2] = t[2]; old[3] = t[3]; }
+            else { for (int e = 0; e < nv; ++e) old[e] = c32[e]; }
+        }
+        // ---- arithmetic
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = v[e] + pev[e];
+            if (f_relu) x = fmaxf(x, 0.f);
+            if (f_mask) x = mk[e] > 0.f ? x * g.mask_scale : 0.f;
+            if (f_drop) x *= dropout_scale(g.seed, g.site, (uint32_t)((long)m * g.N + n + e), g.drop_p, inv_keep);
+            v[e] = x + rs[e] + old[e];
+        }
+        // ---- stores
+        if (f_c32) {
+            if (v_c32) *reinterpret_cast<f32x4*>(c32) = f32x4{v[0], v[1], v[2], v[3]};
+            else { for (int e = 0; e < nv; ++e) c32[e] = v[e]; }
+        }
+        if (f_c16) {
+            bf16* p = g.C16 + (long)m * g.ldc16 + n;
+            if (v_c16) { bf16x4 t; t[0] = (bf16)v[0]; t[1] = (bf16)v[1]; t[2] = (bf16)v[2]; t[3] = (bf16)v[3]; *reinterpret_cast<bf16x4*>(p) = t; }
+            else { for (int e = 0; e < nv; ++e) p[e] = (bf16)v[e]; }
+        }
+    }
+}
 
 template <int BM, int BN, bool RM, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
@@ -228,89 +320,127 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         }
     }
 
-    // epilogue: alpha -> bias -> pe -> relu -> mask -> dropout -> residual -> (accumulate) -> store.
-    // The accumulators go through an fp32 LDS tile so that every global access of the epilogue is a 16-byte (fp32) or
-    // 8-byte (bf16) row segment, and each optional input is fetched with ONE batched load per 4 outputs (per-element
-    // branches around loads serialise on s_waitcnt vmcnt(0) and used to dominate the small decoder GEMMs).
-    float* ct = reinterpret_cast<float*>(smem);
+    gemm_epilogue<BM, BN, EPI>(g, acc, smem, m0, n0, out_delta);
+}
+#undef HAS
+
+// ---- NT form with LDS-DMA staging (global_load_lds_dwordx4): tiles go HBM/L2 -> LDS without touching VGPRs, the next
+// k-tile lands while the current one feeds the MFMAs, and no prefetch ring / vmcnt bookkeeping is left to the compiler.
+// The LDS image must be lane-linear per wave-instruction (1 KiB contiguous), so rows are unpadded (128 B) and the
+// bank-conflict fix is an XOR swizzle applied to the SOURCE address and to the fragment read: 16-byte chunk c of tile
+// row r sits at chunk position c ^ (r & 7).  Needs K % 64 == 0 (out-of-range rows are clamped, never read back).
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int LDC = BN + 4;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
+    constexpr int NBUF = (BM * BN >= 128 * 128) ? 2 : 3;   // 128x128: 2 x 32 KB keeps two workgroups per CU
+    constexpr size_t OUT_BYTES = sizeof(float) * BM * LDC;
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF > OUT_BYTES ? NBUF * BUF : OUT_BYTES];
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    // per-thread source rows are fixed over the k loop
+    constexpr int ACH = BM * 8 / 256, BCH = BN * 8 / 256;
+    const bf16* asrc[ACH]; const bf16* bsrc[BCH];
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+        const int c = tid + i * 256, r = c >> 3, ch = (c & 7) ^ (r & 7);
+        const int row = m0 + r < g.M ? m0 + r : g.M - 1;
+        asrc[i] = g.A + (long)row * g.lda + ch * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+        const int c = tid + i * 256, r = c >> 3, ch = (c & 7) ^ (r & 7);
+        const int row = n0 + r < g.N ? n0 + r : g.N - 1;
+        bsrc[i] = g.B + (long)row * g.ldb + ch * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* ab = smem + buf * BUF;
+        char* bb = ab + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < ACH; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(asrc[i] + kt * 64), (lptr_t*)(ab + (wave * 64 + i * 256) * 16), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BCH; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(bsrc[i] + kt * 64), (lptr_t*)(bb + (wave * 64 + i * 256) * 16), 16, 0, 0);
+    };
+
+    f32x4 acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / 64;
+    const int rr = lane & 15, q = lane >> 4;
+    auto compute = [&](int buf) {
+        const bf16* ab = reinterpret_cast<const bf16*>(smem + buf * BUF);
+        const bf16* bb = reinterpret_cast<const bf16*>(smem + buf * BUF + A_BYTES);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                ct[(wm * WM + i * 16 + (lane >> 4) * 4 + r) * LDC + wn * WN + j * 16 + (lane & 15)] = acc[i][j][r] * g.alpha;
-    __syncthreads();
-    constexpr int C4 = BN / 4, NCH = BM * C4 / 256;
-    const int c4 = (tid % C4) * 4, n = n0 + c4;
-    if (n >= g.N) return;
-    const bool f_bias = HAS(E_BIAS, g.bias), f_pe = HAS(E_PE, g.pe), f_relu = HAS(E_RELU, g.relu), f_mask = HAS(E_MASK, g.mask);
-    const bool f_drop = HAS(E_DROP, g.drop_p > 0.f) && g.drop_p > 0.f, f_res = HAS(E_RES, g.residual);
-    const bool f_acc = HAS(E_ACC, g.accumulate), f_c32 = HAS(E_C32, g.C32), f_c16 = HAS(E_C16, g.C16);
-    const int nv = g.N - n < 4 ? g.N - n : 4;                   // valid columns of this thread's 4-column strip
-    const float inv_keep = f_drop ? 1.0f / (1.0f - g.drop_p) : 1.0f;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (f_bias) {
+        for (int kc = 0; kc < 2; ++kc) {
+            bf16x8 af[FM], bfr[FN];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[n + e];
+            for (int i = 0; i < FM; ++i) {
+                const int row = wm * WM + i * 16 + rr;
+                af[i] = ld8(ab + row * 64 + (((kc * 4 + q) ^ (row & 7)) * 8));
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int row = wn * WN + j * 16 + rr;
+                bfr[j] = ld8(bb + row * 64 + (((kc * 4 + q) ^ (row & 7)) * 8));
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
+        }
+    };
+    if constexpr (NBUF == 2) {
+        stage(0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+            compute(cur);
+            __syncthreads();                               // (emits vmcnt(0): the next tile has landed) + everyone is done reading
+        }
+    } else {
+        // three LDS buffers, two tiles in flight: a COUNTED wait leaves tile kt+1's DMAs outstanding across the (raw)
+        // barrier; __syncthreads() would drain them (its fence emits vmcnt(0) while an LDS-DMA is pending)
+        constexpr int LT = ACH + BCH;                      // DMA instructions per thread per tile
+        static_assert(LT == 4 || LT == 6, "unexpected tile geometry");
+        stage(0, 0);
+        if (nk > 1) stage(1, 1);
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) {
+                if constexpr (LT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();                  // tile kt landed for every wave; buffer (kt-1)%3 is no longer read
+            if (kt + 2 < nk) stage(cur == 0 ? 2 : cur - 1, kt + 2);
+            compute(cur);
+            cur = cur == 2 ? 0 : cur + 1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // all fragment reads done before the epilogue reuses the LDS
     }
-    // 16-byte paths need 4 valid columns and 4-float-aligned rows (n is a multiple of 4 by construction)
-    const bool v_c32 = nv == 4 && f_c32 && !((g.ldc | out_delta) & 3) && !((uintptr_t)g.C32 & 15);
-    const bool v_res = nv == 4 && f_res && !(g.ldres & 3) && !((uintptr_t)g.residual & 15);
-    const bool v_c16 = nv == 4 && f_c16 && !(g.ldc16 & 3) && !((uintptr_t)g.C16 & 7);
-    const bool v_msk = nv == 4 && f_mask && !(g.ldmask & 3) && !((uintptr_t)g.mask & 7);
-    const bool v_pe = nv == 4 && f_pe && !(g.N & 3) && !((uintptr_t)g.pe & 15);
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int row = (tid + i * 256) / C4, m = m0 + row;
-        if (m >= g.M) continue;
-        const f32x4 cv = *reinterpret_cast<const f32x4*>(ct + row * LDC + c4);
-        float v[4] = {cv[0] + bv[0], cv[1] + bv[1], cv[2] + bv[2], cv[3] + bv[3]};
-        float rs[4] = {0.f, 0.f, 0.f, 0.f}, old[4] = {0.f, 0.f, 0.f, 0.f}, pev[4] = {0.f, 0.f, 0.f, 0.f};
-        float mk[4] = {1.f, 1.f, 1.f, 1.f};
-        // ---- batched loads of the optional inputs
-        if (f_res) {
-            const float* p = g.residual + (long)m * g.ldres + n;
-            if (v_res) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); rs[0] = t[0]; rs[1] = t[1]; rs[2] = t[2]; rs[3] = t[3]; }
-            else { for (int e = 0; e < nv; ++e) rs[e] = p[e]; }
-        }
-        if (f_pe) {
-            const float* p = g.pe + (long)(m % g.pe_period) * g.N + n;
-            if (v_pe) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); pev[0] = t[0]; pev[1] = t[1]; pev[2] = t[2]; pev[3] = t[3]; }
-            else { for (int e = 0; e < nv; ++e) pev[e] = p[e]; }
-        }
-        if (f_mask) {
-            const bf16* p = g.mask + (long)m * g.ldmask + n;
-            if (v_msk) { const bf16x4 t = *reinterpret_cast<const bf16x4*>(p); for (int e = 0; e < 4; ++e) mk[e] = (float)t[e]; }
-            else { for (int e = 0; e < nv; ++e) mk[e] = (float)p[e]; }
-        }
-        float* c32 = f_c32 ? g.C32 + out_delta + (long)m * g.ldc + n : nullptr;
-        if (f_c32 && f_acc) {
-            if (v_c32) { const f32x4 t = *reinterpret_cast<const f32x4*>(c32); old[0] = t[0]; old[1] = t[1]; old[2] = t[2]; old[3] = t[3]; }
-            else { for (int e = 0; e < nv; ++e) old[e] = c32[e]; }
-        }
-        // ---- arithmetic
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float x = v[e] + pev[e];
-            if (f_relu) x = fmaxf(x, 0.f);
-            if (f_mask) x = mk[e] > 0.f ? x * g.mask_scale : 0.f;
-            if (f_drop) x *= dropout_scale(g.seed, g.site, (uint32_t)((long)m * g.N + n + e), g.drop_p, inv_keep);
-            v[e] = x + rs[e] + old[e];
-        }
-        // ---- stores
-        if (f_c32) {
-            if (v_c32) *reinterpret_cast<f32x4*>(c32) = f32x4{v[0], v[1], v[2], v[3]};
-            else { for (int e = 0; e < nv; ++e) c32[e] = v[e]; }
-        }
-        if (f_c16) {
-            bf16* p = g.C16 + (long)m * g.ldc16 + n;
-            if (v_c16) { bf16x4 t; t[0] = (bf16)v[0]; t[1] = (bf16)v[1]; t[2] = (bf16)v[2]; t[3] = (bf16)v[3]; *reinterpret_cast<bf16x4*>(p) = t; }
-            else { for (int e = 0; e < nv; ++e) p[e] = (bf16)v[e]; }
-        }
-    }
+    gemm_epilogue<BM, BN, EPI>(g, acc, smem, m0, n0, 0);
 }
-#undef HAS
+
+template <int BM, int BN, int EPI>
+void launch_glds(const GemmArgs& g, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, EPI>), grid, dim3(256), 0, s, g);
+}
 
 template <int BM, int BN, bool RM, int EPI>
 void launch_epi(const GemmArgs& g, dim3 grid, hipStream_t s) {
@@ -327,8 +457,10 @@ int launch_tile(const GemmArgs& g, hipStream_t s) {
         if (epi == E_C32) launch_epi<BM, BN, true, E_C32>(g, grid, s);
         else launch_epi<BM, BN, true, -1>(g, grid, s);
     } else {
+        static const bool use_glds = !getenv("MASR_GEMM_NO_GLDS");
+        const bool glds = use_glds && (g.K % 64 == 0);
         switch (epi & ~E_DROP) {                       // dropout stays a run-time test inside the specialised kernels
-#define CASE(mask) case (mask): launch_epi<BM, BN, false, (mask) | E_DROP>(g, grid, s); break;
+#define CASE(mask) case (mask): if (glds) launch_glds<BM, BN, (mask) | E_DROP>(g, grid, s); else launch_epi<BM, BN, false, (mask) | E_DROP>(g, grid, s); break;
             CASE(E_BIAS | E_C16)                       // q/k/v projections
             CASE(E_BIAS | E_RES | E_C32)               // attention out-proj, FFN second layer
             CASE(E_BIAS | E_RELU | E_C16)              // FFN first layer
