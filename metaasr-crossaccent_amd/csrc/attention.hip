@@ -63,26 +63,40 @@ __device__ __forceinline__ bf16x8 frag_row(const bf16* tile, int r0, int ks, int
 template <int HD>
 __device__ __forceinline__ bf16x8 frag_global(const bf16* base, long ld, int row, int nrows, int ks, int lane) {
     const int r = row + (lane & 15), dcol = ks * 32 + (lane >> 4) * 8;
-    if (r < nrows && dcol < HD) return ld8(base + (long)r * ld + dcol);
-    return zero8();
+    const bool ok = r < nrows && dcol < HD;
+    const bf16x8 v = ld8(base + (long)(r < nrows ? r : nrows - 1) * ld + (dcol < HD ? dcol : 0));
+    return ok ? v : zero8();
 }
 
-// copy a [64][HD] tile (rows row0.. of a [nrows] matrix) into LDS, zero-filling missing rows
+// copy a [64][HD] tile (rows row0.. of a [nrows] matrix) into LDS, zero-filling missing rows.  All loads are issued
+// unconditionally (clamped row) before the first LDS store: a branch around a global load costs an s_waitcnt vmcnt(0).
 template <int HD>
 __device__ __forceinline__ void load_tile(bf16* dst, const bf16* src, long ld, int row0, int nrows, int tid) {
     constexpr int LD = Cfg<HD>::LD;
     constexpr int CPR = HD / 8;                        // chunks per row
-    for (int c = tid; c < BLK * CPR; c += 256) {
+    constexpr int N = (BLK * CPR + 255) / 256;         // chunks per thread
+    bf16x8 v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int c = tid + i * 256;
+        const int r = (c / CPR) % BLK, dc = (c % CPR) * 8;
+        const int row = row0 + r < nrows ? row0 + r : nrows - 1;
+        v[i] = ld8(src + (long)row * ld + dc);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int c = tid + i * 256;
         const int r = c / CPR, dc = (c % CPR) * 8;
-        bf16x8 v = zero8();
-        if (row0 + r < nrows) v = ld8(src + (long)(row0 + r) * ld + dc);
-        st8(dst + r * LD + dc, v);
+        if (c < BLK * CPR) st8(dst + r * LD + dc, row0 + r < nrows ? v[i] : zero8());
     }
 }
+// only head dims < 32 have padding columns (dims HD..31) that must read as zero
 template <int HD>
 __device__ __forceinline__ void zero_tile(bf16* dst, int tid) {
     constexpr int LD = Cfg<HD>::LD;
-    for (int c = tid; c < BLK * LD / 8; c += 256) st8(dst + c * 8, zero8());
+    if constexpr (Cfg<HD>::HDP != HD) {
+        for (int c = tid; c < BLK * LD / 8; c += 256) st8(dst + c * 8, zero8());
+    }
 }
 
 // ---------------------------------------------------------------------------- forward
