@@ -151,14 +151,16 @@ def main():
 
     import masr_amd
     from masr_amd.engine import MasrEngine
-    from oracle import ref_cpu                                   # deterministic init recipe only (host side)
+    from masr_amd.model import reference_init_state_dict        # the product's own seed-exact init (no oracle in the GPU leg)
 
     cfg = dict(HKUST)
     cfg["idim"] = args.idim
     B, T, D = args.batch, args.frames, args.idim
     K = max(1, args.tasks_per_gpu)
-    lr = ref_cpu.inner_lr(cfg)
-    sd0 = ref_cpu.deterministic_state_dict(cfg, ODIM, seed=1)
+    o = cfg["meta"]["optimizer_opt"]
+    lr = cfg["d_model"] ** (-0.5) * o["k"] * o["warmup_steps"] ** (-0.5)      # inner lr, fo_meta_interface.py:41-45
+    torch.manual_seed(531)                                       # CLI seed of the reference (pretrain.py:29)
+    sd0 = reference_init_state_dict(cfg, ODIM)                   # random-init weights exactly as the reference draws them
 
     class Task:                                                  # one accent-task slot: replica + stream + resident batch
         def __init__(self, k):
