@@ -86,8 +86,16 @@ int masr_axpy(float* y, const float* x, int64_t n, float a, void* stream);
 int masr_copy(float* dst, const float* src, int64_t n, void* stream);                 /* load_state_dict(_original) (:226) */
 
 /* MyTransformer.recog (mono_transformer_torch.py:143-176): greedy decode, out int32 [Ldec][B] (device),
- * Ldec = max(floor(ilens/4)).  Needs workspace for L = Ldec. */
+ * Ldec = max(floor(ilens/4)).  Needs workspace for L = Ldec.
+ * masr_recog      : KV-cached incremental decode (one new position per step, the step replayed as a hipGraph);
+ * masr_recog_full : the reference's literal schedule (the whole prefix is decoded again at every step).
+ * Both emit the same token sequences (the target mask is causal). */
 int masr_recog(masr_model* m, const float* xs, const int64_t* ilens, int B, int T, int32_t* out, void* stream);
+int masr_recog_full(masr_model* m, const float* xs, const int64_t* ilens, int B, int T, int32_t* out, void* stream);
+
+/* Levenshtein distance of two id sequences (host-side; replaces the `editdistance` extension the reference's metric
+ * imports, src/monitor/metric.py:4,66,87).  Returns the distance, < 0 on bad arguments. */
+int64_t masr_edit_distance(const int32_t* a, int na, const int32_t* b, int nb);
 
 /* collate_fn zero-padding of CommonVoiceDataset rows (src/io/dataset.py:21-33,147-153) done on the GPU:
  * feat fp32 [sum T_i][D] resident in HBM, row_start int64 [B] (device), lens int32 [B] (device). */

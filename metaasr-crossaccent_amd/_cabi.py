@@ -41,6 +41,8 @@ _SIGS = {
     "masr_axpy": (i32, [vp, vp, i64, f32, vp]),
     "masr_copy": (i32, [vp, vp, i64, vp]),
     "masr_recog": (i32, [vp, vp, vp, i32, i32, vp, vp]),
+    "masr_recog_full": (i32, [vp, vp, vp, i32, i32, vp, vp]),
+    "masr_edit_distance": (i64, [vp, i32, vp, i32]),
     "masr_gather_pad": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "masr_ctc_work_floats": (i64, [i32, i32, i32]),
     "masr_ctc_loss": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]),

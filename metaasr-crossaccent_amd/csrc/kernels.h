@@ -61,6 +61,31 @@ struct AttnArgs {
 int mk_attn_fwd(const AttnArgs& a, hipStream_t s);
 int mk_attn_bwd(const AttnArgs& a, hipStream_t s);
 
+// ---------------------------------------------------------------- incremental greedy decode (decode.hip)
+// C[m][n] = epi(sum_k A[m][k] W[n][k]) for a handful of rows (one per utterance): bias, ReLU, fp32 residual
+struct SkinnyArgs {
+    const bf16* A; long lda; const bf16* W; long ldw; int M, N, K;
+    const float* bias; int relu; const float* residual; long ldres;
+    float* C32; long ldc; bf16* C16; long ldc16;
+};
+int mk_skinny_gemm(const SkinnyArgs& g, hipStream_t s);
+// one query row per (utterance, head) against cached keys/values; see decode.hip
+struct AttnDecodeArgs {
+    const bf16* q; long ldq;                   // [B][ldq], head h at column h*hd
+    const bf16 *k, *v; long ldk, kv_batch_stride;   // cache rows: k + b*kv_batch_stride + j*ldk + h*hd
+    const bf16 *knew, *vnew; long ldnew;       // self-attention: newest row (appended to the cache at slot *step-1) or null
+    const int* step;                           // device scalar: number of valid keys (self-attention) or null
+    const int* klens;                          // [B] valid keys (cross-attention) when step == null
+    bf16* o; long ldo;
+    int B, H, hd, Tk_cap;                      // Tk_cap bounds the key count (sizes the LDS score row)
+};
+int mk_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
+int mk_recog_embed_step(const int* step, const int* out, const float* table, const float* pe, float* y32, bf16* y16, int B, int E, int sos,
+                        hipStream_t s);
+// also advances step[0] once all B rows are done (ticket counter in step[1])
+int mk_recog_argmax_step(int* step, const float* logits, long ld, int* out, int B, int C, hipStream_t s);
+int mk_recog_step_set(int* step, int value, int inc, hipStream_t s);     // inc ? *step += 1 : *step = value
+
 // ---------------------------------------------------------------- row ops (rowops.hip)
 int mk_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y32, bf16* y16,
                        float* mean, float* rstd, int rows, int E, hipStream_t s);

@@ -147,8 +147,9 @@ class MasrEngine:
               "masr_run_batch")
         self._last_x = xs          # keep the input alive until the stream has consumed it
 
-    def recog(self, xs: torch.Tensor, ilens):
-        """greedy decode (MyTransformer.recog): returns int64 [Ldec, B] on the device, Ldec = max(ilens // 4)"""
+    def recog(self, xs: torch.Tensor, ilens, full: bool = False):
+        """greedy decode (MyTransformer.recog): returns int64 [Ldec, B] on the device, Ldec = max(ilens // 4).
+        Default = KV-cached incremental decode; full=True = the reference's literal whole-prefix re-decode per step."""
         if xs.device != self.device:
             xs = xs.to(self.device, non_blocking=True)
         xs = xs.contiguous().float()
@@ -158,7 +159,8 @@ class MasrEngine:
         self._ensure_ws(B, T, Ldec)
         self.refresh()
         out = torch.zeros(Ldec, B, dtype=torch.int32, device=self.device)
-        check(self._l.masr_recog(self.h, _ptr(xs), C.c_void_p(il.data_ptr()), B, T, _ptr(out), self.stream()), "masr_recog")
+        fn = self._l.masr_recog_full if full else self._l.masr_recog
+        check(fn(self.h, _ptr(xs), C.c_void_p(il.data_ptr()), B, T, _ptr(out), self.stream()), "masr_recog")
         self._last_x = xs
         return out.to(torch.int64)
 

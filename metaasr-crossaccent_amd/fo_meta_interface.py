@@ -38,6 +38,9 @@ class FOMetaASRInterface(PretrainInterface):
         o = mp['meta']['optimizer_opt']
         self.inner_lr = mp['d_model'] ** (-0.5) * o['k'] * (o['warmup_steps'] ** (-0.5))         # :41-45
         self.fix_snapshot = bool(getattr(paras, 'fix_snapshot_meta_weights', False))
+        # --fix_reptile: the reference's `--algo reptile` dies with ValueError in _partial_meta_update (:197-198);
+        # with the flag the published Reptile pseudo-gradient (theta_meta - theta_k) is used instead (parity unpinned)
+        self.fix_reptile = bool(getattr(paras, 'fix_reptile', False))
         # MI355X extension: tasks of one meta-step are independent, so several of them can run CONCURRENTLY on one GPU
         # (one model replica + HIP stream + host thread per slot).  A B=16 inner step leaves ~40 % of the 256 CUs idle
         # (small decoder GEMMs, kernel tails); three concurrent tasks raise the throughput ~1.6x.  1 = reference order.
@@ -203,16 +206,25 @@ class FOMetaASRInterface(PretrainInterface):
         """_updates[n] += p.grad for every parameter (:180-198) == one flat axpy.  With several ranks the freshly
         accumulated task gradient is all-reduced on the side stream while the next task runs."""
         eng = engine if engine is not None else self.asr_model.engine
-        if self.paras.algo != 'fomaml':
+        reptile = self.paras.algo == 'reptile' and self.fix_reptile
+        if self.paras.algo != 'fomaml' and not reptile:
             raise ValueError(f"Not support meta algo {self.paras.algo}")    # reptile/maml: no reference implementation (SURVEY F4)
         if self.sharder.world == 1:
             if self._updates is None:
                 self._updates = torch.zeros_like(eng.params)
-            eng.axpy(self._updates, eng.grads, 1.0)
+            if reptile:                                                    # pseudo-gradient theta_meta - theta_k
+                eng.axpy(self._updates, self._original, 1.0)
+                eng.axpy(self._updates, eng.params, -1.0)
+            else:
+                eng.axpy(self._updates, eng.grads, 1.0)
             return
         if self._updates is None:
             self._updates = []
-        contrib = eng.grads.clone()                                       # per-task buffer handed to the side stream
+        if reptile:
+            contrib = self._original.clone()
+            eng.axpy(contrib, eng.params, -1.0)
+        else:
+            contrib = eng.grads.clone()                                   # per-task buffer handed to the side stream
         self.sharder.reduce_async(contrib)
         self._updates.append(contrib)
 

@@ -1,20 +1,24 @@
 """Eval metric path (reference: src/monitor/metric.py:24-87): teacher-forced argmax -> trim at the first
 </s> -> sentencepiece DecodePieces -> Levenshtein / reference length * 100.  `editdistance` (C extension the
-reference imports) is replaced by the small DP below."""
+reference imports) is replaced by libmasr's masr_edit_distance (host C++)."""
+import ctypes as C
+
 import torch
 
+from .. import _cabi
 from ..marcos import BLANK_SYMBOL, IGNORE_ID
 
 
 def levenshtein(a, b):
-    a, b = list(a), list(b)
-    prev = list(range(len(b) + 1))
-    for i, x in enumerate(a, 1):
-        cur = [i]
-        for j, y in enumerate(b, 1):
-            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
-        prev = cur
-    return prev[-1]
+    """edit distance of two sequences of hashables (characters, words, ids) through the C ABI"""
+    ids = {}
+    ia = [ids.setdefault(x, len(ids)) for x in a]
+    ib = [ids.setdefault(x, len(ids)) for x in b]
+    aa, bb = (C.c_int32 * max(len(ia), 1))(*ia), (C.c_int32 * max(len(ib), 1))(*ib)
+    d = _cabi.lib().masr_edit_distance(aa, len(ia), bb, len(ib))
+    if d < 0:
+        raise _cabi.MasrError("masr_edit_distance: " + _cabi.lib().masr_last_error().decode())
+    return int(d)
 
 
 class Metric:

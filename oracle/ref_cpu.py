@@ -451,6 +451,34 @@ def fomaml_meta_step(meta, cfg, tasks, eps, adam_state, meta_step_num, momentum=
     return infos, lr
 
 
+def reptile_meta_step(meta, cfg, tasks, eps, adam_state, meta_step_num, momentum=0.9, nesterov=True):
+    """Reptile outer step.  NOT in the reference: `--algo reptile` reaches `raise ValueError` in
+    fo_meta_interface.py:197-198, so this restates the published algorithm (Nichol et al. 2018, eq. 5) inside
+    the reference's loop structure and is "parity unpinned": per task the pseudo-gradient is
+    theta_meta - theta_k (k inner SGD steps as in run_task); the val batch is still evaluated at theta_k for the logged
+    loss/acc but contributes no gradient; mean over tasks; Noam-Adam on the pseudo-gradient.
+    """
+    names = grad_param_names(meta, cfg)
+    updates = {n: torch.zeros_like(meta[n]) for n in names}
+    infos = []
+    lr_in = inner_lr(cfg)
+    for tr_batches, val_batch in tasks:
+        p = leafify(meta, cfg)
+        bufs = {}
+        for b in tr_batches:
+            inner_step(p, cfg, b, eps, bufs, lr_in, momentum, nesterov)
+        info, _, _, _ = run_batch_train(p, cfg, val_batch, eps)
+        for n in names:
+            updates[n] += meta[n].detach() - p[n].detach()
+        infos.append(info)
+    for n in names:
+        updates[n] /= len(tasks)
+    o = cfg["meta"]["optimizer_opt"]
+    lr = noam_lr(meta_step_num, o["k"], cfg["d_model"], o["warmup_steps"])
+    adam_step(meta, updates, adam_state, lr)
+    return infos, lr
+
+
 # --------------------------------------------------------------------------- #
 # data (src/io/dataset.py)
 # --------------------------------------------------------------------------- #

@@ -110,6 +110,48 @@ def test_reptile_and_maml_are_rejected_like_the_reference(tmp_path, monkeypatch)
         solver.exec()
 
 
+def test_reptile_behind_fix_flag_matches_oracle(tmp_path, monkeypatch):
+    """--algo reptile --fix_reptile (parity unpinned by the reference): the first meta-step through
+    get_trainer(...).exec() against oracle.reptile_meta_step fed the very batches the run drew."""
+    monkeypatch.chdir(tmp_path)
+    cfg, paras, id2accent = make_run(tmp_path, algo="reptile", max_step=2)     # global_step starts at 1
+    paras.fix_reptile = True
+    cfg["solver"]["eval_ival"] = 1; cfg["solver"]["save_ival"] = 1
+    random.seed(531); np.random.seed(531); torch.manual_seed(531)
+    solver = get_trainer(FOMetaASRInterface, cfg, paras, id2accent)
+    solver.load_data(); solver.set_model()
+    sd0 = ref_cpu.deterministic_state_dict(cfg["asr_model"], ODIM, seed=7)
+    solver.asr_model.load_state_dict(sd0)
+    solver.load_model()
+    solver.evaluate = lambda: None
+    rec = []
+    orig = solver.run_batch
+
+    def spy(idx, x, ilens, ys, olens, train, accent_idx=None):
+        batch = (x.clone().cpu(), ilens.clone(), [y.clone() for y in ys], olens.clone())
+        info = orig(idx, x, ilens, ys, olens, train=train, accent_idx=accent_idx)
+        rec.append((batch, dict(info)))
+        return info
+    solver._train = partial(spy, train=True)
+    solver.exec()
+    assert len(rec) == 6 and solver.meta_opt.step_num == 1          # 2 tasks x (2 inner + 1 val)
+    tasks = [([rec[0][0], rec[1][0]], rec[2][0]), ([rec[3][0], rec[4][0]], rec[5][0])]
+    mcfg = cfg["asr_model"]
+    with ref_cpu.bf16_emulation():
+        meta = OrderedDict((k, v.clone()) for k, v in sd0.items())
+        infos, lr = ref_cpu.reptile_meta_step(meta, mcfg, tasks, 0.2, {}, 1)
+    assert abs(lr - solver.meta_opt.lr) < 1e-12
+    for (b, got), want in zip([rec[2], rec[5]], infos):
+        assert abs(got["loss"] - want["loss"]) < 3e-3 * want["loss"], (got, want)
+    got = solver.asr_model.engine.state_dict(flat=solver._original)
+    # Adam's first step is lr * sign(g): compare the direction of the meta update on tensors with a clear signal
+    for n in ("vgg2enc.bias", "char_trans.bias", "decoder.norm.weight", "encoder.layers.0.linear1.bias"):
+        du = (got[n].cpu() - sd0[n]).double(); dr = (meta[n] - sd0[n]).double()
+        agree = float((torch.sign(du) == torch.sign(dr)).double().mean())
+        print(n, "sign agreement of the reptile update", agree)
+        assert agree > 0.9
+
+
 def test_concurrent_task_slots_reproduce_sequential_run(tmp_path, monkeypatch):
     """--tasks_per_gpu 2: the two tasks of each meta-step run concurrently (replica + stream + thread each); the meta
     weights must come out bit-identical to the sequential run (same batches, same kernels, same accumulation order)."""

@@ -136,6 +136,21 @@ def test_levenshtein():
     assert levenshtein("kitten", "sitting") == 3
     assert levenshtein([], [1, 2]) == 2
     assert levenshtein(["a", "b"], ["a", "b"]) == 0
+    assert levenshtein("abc", "") == 3 and levenshtein("", "") == 0
+
+    def dp(a, b):                                    # textbook DP as the checker
+        prev = list(range(len(b) + 1))
+        for i, x in enumerate(a, 1):
+            cur = [i]
+            for j, y in enumerate(b, 1):
+                cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
+            prev = cur
+        return prev[-1]
+    rng = random.Random(3)
+    for _ in range(200):
+        a = [rng.randrange(6) for _ in range(rng.randrange(0, 40))]
+        b = [rng.randrange(6) for _ in range(rng.randrange(0, 40))]
+        assert levenshtein(a, b) == dp(a, b)
 
 
 SPM = Path("/root/reference/data/valid_train_en_unigram150.model")
