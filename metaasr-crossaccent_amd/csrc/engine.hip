@@ -117,6 +117,20 @@ Attn add_attn(masr_model* m, const std::string& pre) {
     return a;
 }
 
+// split-K combine table: the Linear weight / bias ranges whose gradients have partial sums in the slab (encoder-row
+// reductions: encoder layers, cross-attention K/V projections), cut into chunks of <= SPLIT_CHUNK floats = one workgroup each
+constexpr long SPLIT_CHUNK = 2048;
+std::vector<long> split_chunks(const masr_model* m) {
+    std::vector<long> c;
+    auto add = [&](long off, long len) {
+        for (long o = 0; o < len; o += SPLIT_CHUNK) { c.push_back(off + o); c.push_back(len - o < SPLIT_CHUNK ? len - o : SPLIT_CHUNK); }
+    };
+    auto lin = [&](const Lin& l) { add(l.w, (long)l.N * l.K); add(l.b, l.N); };
+    for (auto& e : m->enc) { lin(e.sa.in); lin(e.sa.out); lin(e.l1); lin(e.l2); }
+    for (auto& d : m->dec) { add(d.ca.in.w + (long)m->E * m->E, 2L * m->E * m->E); add(d.ca.in.b + m->E, 2L * m->E); }
+    return c;
+}
+
 // ------------------------------------------------------------------ persistent region (shadows, stats)
 void plan_persistent(masr_model* m, Arena& ar) {
     for (int i = 1; i < 4; ++i) {
@@ -136,7 +150,7 @@ void plan_persistent(masr_model* m, Arena& ar) {
     for (auto& d : m->dec) { lin(d.sa.in); lin(d.sa.out); lin(d.ca.in); lin(d.ca.out); lin(d.l1); lin(d.l2); }
     m->stats = ar.get<float>(64);
     const int nlin = (int)(m->enc.size() * 4 + m->dec.size() * 6);
-    m->d_ranges = ar.get<long>(2 * (2 * nlin + 2 * (int)m->dec.size() + 2));
+    m->d_ranges = ar.get<long>((int64_t)split_chunks(m).size());
     m->d_sdesc = ar.get<ShadowDesc>(nlin);
     m->d_sptrs = ar.get<bf16*>(2 * nlin);
 }
@@ -419,23 +433,15 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
         for (auto& e : m->stage_ev) HIP_CHECK_RET(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     {   // device tables: split-K combine ranges and the fused shadow-refresh descriptors
-        std::vector<long> ranges; std::vector<ShadowDesc> desc; std::vector<bf16*> ptrs;
+        std::vector<long> ranges = split_chunks(m); std::vector<ShadowDesc> desc; std::vector<bf16*> ptrs;
         int tiles = 0;
-        auto lin = [&](const Lin& l, bool split) {
-            if (split) {                                           // split-K partials exist only for the encoder-row wgrads
-                ranges.push_back(l.w); ranges.push_back((long)l.N * l.K);
-                ranges.push_back(l.b); ranges.push_back(l.N);
-            }
+        auto lin = [&](const Lin& l, bool) {
             ShadowDesc d; d.src = l.w; d.N = l.N; d.K = l.K; d.Np = (l.N + 7) / 8 * 8; d.tile_start = tiles;
             tiles += ((l.N + 31) / 32) * ((l.K + 31) / 32);
             desc.push_back(d); ptrs.push_back(l.k16); ptrs.push_back(l.t16);
         };
         for (auto& e : m->enc) { lin(e.sa.in, true); lin(e.sa.out, true); lin(e.l1, true); lin(e.l2, true); }
         for (auto& d : m->dec) { lin(d.sa.in, false); lin(d.sa.out, false); lin(d.ca.in, false); lin(d.ca.out, false); lin(d.l1, false); lin(d.l2, false); }
-        for (auto& d : m->dec) {                                   // cross-attention K/V projection: reduction over encoder rows
-            ranges.push_back(d.ca.in.w + (long)m->E * m->E); ranges.push_back(2L * m->E * m->E);
-            ranges.push_back(d.ca.in.b + m->E); ranges.push_back(2L * m->E);
-        }
         m->nranges = (int)ranges.size() / 2; m->nsdesc = (int)desc.size(); m->shadow_tiles = tiles;
         HIP_CHECK_RET(hipMemcpy(m->d_ranges, ranges.data(), sizeof(long) * ranges.size(), hipMemcpyHostToDevice));
         HIP_CHECK_RET(hipMemcpy(m->d_sdesc, desc.data(), sizeof(ShadowDesc) * desc.size(), hipMemcpyHostToDevice));

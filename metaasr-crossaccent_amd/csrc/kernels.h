@@ -127,7 +127,7 @@ int mk_axpy(float* y, const float* x, long n, float a, hipStream_t s);
 int mk_cast_bf16(const float* x, bf16* y, long n, hipStream_t s);
 int mk_transpose_cast_bf16(const float* x /*[R][C]*/, bf16* y /*[C][ldy]*/, int R, int C, long ldy, hipStream_t s);
 // conv weight shadows: w [CO][CI][3][3] fp32 -> wk [CO][tap*CI+ci] (fwd) and wd [CI][tap'*CO+co] = w[co][ci][8-tap'] (dgrad)
-// G[i] += sum_{s<nslab} slab[s*stride + i] over the listed (offset, length) ranges (deterministic split-K combine)
+// G[i] += sum_{s<nslab} slab[s*stride + i] over the listed (offset, length <= 2048) chunks (deterministic split-K combine)
 int mk_split_reduce(float* G, const float* slab, int nslab, long stride, const long* ranges, int nranges, hipStream_t s);
 // all Linear-layer shadows in one launch: desc[i] = {src offset, N, K, Np, tile_start}, ptrs[2i] = k16, ptrs[2i+1] = t16
 struct ShadowDesc { long src; int N, K, Np, tile_start; };

@@ -149,14 +149,20 @@ __global__ void vgg2enc_unpermute_kernel(const float* __restrict__ g, float* __r
     dw[i] = g[(long)e * F + d * C + c];
 }
 
-__global__ void split_reduce_kernel(float* __restrict__ G, const float* __restrict__ slab, int nslab, long stride,
-                                    const long* __restrict__ ranges) {
-    const long off = ranges[2 * blockIdx.y], len = ranges[2 * blockIdx.y + 1];
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (long)gridDim.x * blockDim.x) {
-        float v = G[off + i];
-        for (int s = 0; s < nslab; ++s) v += slab[(long)s * stride + off + i];
-        G[off + i] = v;
+// one workgroup per (offset, length <= 2048) chunk; 8 independent elements per thread in flight
+__global__ __launch_bounds__(256) void split_reduce_kernel(float* __restrict__ G, const float* __restrict__ slab, int nslab, long stride,
+                                                           const long* __restrict__ chunks) {
+    const long off = chunks[2 * blockIdx.x]; const int len = (int)chunks[2 * blockIdx.x + 1];
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const int i = threadIdx.x + e * 256; v[e] = i < len ? G[off + i] : 0.f; }
+    for (int s = 0; s < nslab; ++s) {
+        const float* sp = slab + (long)s * stride + off;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const int i = threadIdx.x + e * 256; if (i < len) v[e] += sp[i]; }
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const int i = threadIdx.x + e * 256; if (i < len) G[off + i] = v[e]; }
 }
 // every Linear weight -> bf16 copy [N][K] and bf16 transpose [K][Np], one 32x32 tile per workgroup
 __global__ __launch_bounds__(256) void linear_shadows_kernel(const float* __restrict__ P, const ShadowDesc* __restrict__ desc,
@@ -233,7 +239,7 @@ int mk_transpose_cast_bf16(const float* x, bf16* y, int R, int C, long ldy, hipS
 }
 int mk_split_reduce(float* G, const float* slab, int nslab, long stride, const long* ranges, int nranges, hipStream_t s) {
     if (nslab <= 0 || nranges <= 0) return 0;
-    hipLaunchKernelGGL(split_reduce_kernel, dim3(64, nranges), dim3(256), 0, s, G, slab, nslab, stride, ranges);
+    hipLaunchKernelGGL(split_reduce_kernel, dim3(nranges), dim3(256), 0, s, G, slab, nslab, stride, ranges);
     return LAUNCH_OK();
 }
 int mk_linear_shadows(const float* P, const ShadowDesc* desc, bf16* const* ptrs, int ndesc, int total_tiles, hipStream_t s) {
