@@ -241,7 +241,7 @@ __global__ void attn_delta_kernel(AttnArgs a) {
 }
 
 template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx) {
     using C = Cfg<HD>;
     constexpr int LD = C::LD, KS = C::KS, DT = C::DT;
     __shared__ __attribute__((aligned(16))) bf16 sK[BLK * LD];
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16 sP[4][16 * LDP];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BLK;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = bx * BLK;
     const int Tq = a.Tq, Tk = a.Tk;
     const int klen = a.klens ? a.klens[b] : Tk;
     const float scale = rsqrtf((float)HD);
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 }
 
 template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int bx) {
     using C = Cfg<HD>;
     constexpr int LD = C::LD, KS = C::KS, DT = C::DT;
     __shared__ __attribute__((aligned(16))) bf16 sQ[BLK * LD];
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     __shared__ float sLse[BLK], sDl[BLK];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * BLK;
+    const int b = blockIdx.z, h = blockIdx.y, k0 = bx * BLK;
     const int Tq = a.Tq, Tk = a.Tk;
     const int klen = a.klens ? a.klens[b] : Tk;
     const float scale = rsqrtf((float)HD);
@@ -425,6 +425,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
 }
 
+// dQ and dK/dV of one attention as ONE grid: blocks [0, nqb) own 64 query rows each, the rest 64 key rows each.  The two
+// halves are independent given delta, so they overlap instead of queueing as two launch-latency-bound kernels.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a, int nqb) {
+    if ((int)blockIdx.x < nqb) attn_bwd_dq_body<HD>(a, blockIdx.x);
+    else attn_bwd_dkv_body<HD>(a, blockIdx.x - nqb);
+}
+
 template <int HD>
 int launch_fwd(const AttnArgs& a, hipStream_t s) {
     dim3 grid((a.Tq + BLK - 1) / BLK, a.H, a.B);
@@ -435,8 +443,8 @@ template <int HD>
 int launch_bwd(const AttnArgs& a, hipStream_t s) {
     const long n = (long)a.B * a.H * a.Tq;
     hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, dim3((a.Tq + BLK - 1) / BLK, a.H, a.B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<HD>, dim3((a.Tk + BLK - 1) / BLK, a.H, a.B), dim3(256), 0, s, a);
+    const int nqb = (a.Tq + BLK - 1) / BLK, nkb = (a.Tk + BLK - 1) / BLK;
+    hipLaunchKernelGGL(attn_bwd_kernel<HD>, dim3(nqb + nkb, a.H, a.B), dim3(256), 0, s, a, nqb);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

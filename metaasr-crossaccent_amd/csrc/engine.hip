@@ -44,6 +44,8 @@ struct DecAct {
     float *s1, *y1_32, *s2, *y2_32, *s3, *m1, *r1, *m2, *r2, *m3, *r3, *lse_s, *lse_c;
     bf16 *qkv, *ao, *y1_16, *q, *kv, *co, *y2_16, *f; uint32_t site[6];
 };
+// per-decoder-layer bf16 gradient operands of the deferred (grouped) weight-gradient launch
+struct DecGrad { bf16 *g3, *g2, *g1, *gf, *gq, *gqkv; };
 struct Acts {
     int B, T, D, H2, W2, Tp, Dp, L, rows_e, rows_d;
     int *tok_in, *gold, *enc_lens, *step_dev;
@@ -59,9 +61,11 @@ struct Acts {
     uint32_t site_v2e, site_emb;
     // backward scratch
     float *ge_a, *ge_b, *gd_a, *gd_b, *dmem32, *v2e_g32;
-    bf16 *ge16, *gd16, *gqkv_e, *gqkv_d, *gf_e, *gf_d, *gao_e, *gao_d, *gq_d, *gkv_d, *dp2, *da4, *da3, *dp1, *da2, *da1;
+    bf16 *ge16, *gqkv_e, *gf_e, *gao_e, *gao_d, *gkv_d, *dp2, *da4, *da3, *dp1, *da2, *da1;
     float *delta_e, *delta_d;
+    std::vector<DecGrad> dgr;
     float* slab; int64_t slab_floats;
+    float* ln_slab; int64_t ln_slab_floats;                // one region per LayerNorm backward (grouped reduce)
     float* wg_slab;                                        // split-K partials: (WG_SPLIT-1) x nparams
 };
 constexpr int WG_SPLIT = 4;
@@ -83,6 +87,8 @@ struct masr_model {
     int* h_stage = nullptr; int64_t stage_ints = 0; int stage_slot = 0; hipEvent_t stage_ev[4];
     uint64_t seed = 0x1234; uint64_t step = 0;
     Acts acts; bool have_acts = false;
+    LnReduceGroup lng; int64_t ln_slab_used = 0;           // LayerNorm dgamma/dbeta partials, folded by one grouped launch
+    WgradGroup wg; bool wg_defer = false;                  // decoder-row weight gradients collected for one grouped launch
     // cached hipGraph of one incremental decode step (masr_recog)
     hipGraphExec_t dec_exec = nullptr; hipGraph_t dec_graph = nullptr; hipEvent_t dec_done = nullptr;
     int dec_key[3] = {0, 0, 0}; const void* dec_key_ptr[3] = {nullptr, nullptr, nullptr};
@@ -201,15 +207,24 @@ void plan_acts(const masr_model* m, Arena& ar, Acts& a, int B, int T, int L, boo
     mx(mk_conv3x3_wgrad_slab_floats(B, a.H2, a.W2, 128, 128));
     a.slab_floats = sl; a.slab = ar.get<float>(sl);
     if (train) {
+        const int nln = 2 * m->NE + 1 + 3 * m->ND + 1;
+        a.ln_slab_floats = 0;
+        for (int i = 0; i < nln; ++i) a.ln_slab_floats += mk_layernorm_bwd_slab_floats((int)(i < 2 * m->NE + 1 ? re : rd), E);
+        a.ln_slab = ar.get<float>(a.ln_slab_floats);
         a.wg_slab = ar.get<float>((int64_t)(WG_SPLIT - 1) * m->nparams);
         a.ge_a = ar.get<float>(re * E); a.ge_b = ar.get<float>(re * E); a.gd_a = ar.get<float>(rd * E); a.gd_b = ar.get<float>(rd * E);
         a.dmem32 = ar.get<float>(re * E); a.v2e_g32 = ar.get<float>((int64_t)E * m->F);
-        a.ge16 = ar.get<bf16>(re * E); a.gd16 = ar.get<bf16>(rd * E);
-        a.gqkv_e = ar.get<bf16>(re * 3 * E); a.gqkv_d = ar.get<bf16>(rd * 3 * E);
-        a.gf_e = ar.get<bf16>(re * Fi); a.gf_d = ar.get<bf16>(rd * Fi);
+        a.ge16 = ar.get<bf16>(re * E);
+        a.gqkv_e = ar.get<bf16>(re * 3 * E);
+        a.gf_e = ar.get<bf16>(re * Fi);
         a.gao_e = ar.get<bf16>(re * E); a.gao_d = ar.get<bf16>(rd * E);
-        a.gq_d = ar.get<bf16>(rd * E); a.gkv_d = ar.get<bf16>(re * 2 * E);
+        a.gkv_d = ar.get<bf16>(re * 2 * E);
         a.delta_e = ar.get<float>((int64_t)B * H * a.Tp); a.delta_d = ar.get<float>((int64_t)B * H * L);
+        a.dgr.resize(m->ND);
+        for (auto& g : a.dgr) {
+            g.g3 = ar.get<bf16>(rd * E); g.g2 = ar.get<bf16>(rd * E); g.g1 = ar.get<bf16>(rd * E);
+            g.gf = ar.get<bf16>(rd * Fi); g.gq = ar.get<bf16>(rd * E); g.gqkv = ar.get<bf16>(rd * 3 * E);
+        }
         a.dp2 = ar.get<bf16>(re * m->F); a.da4 = ar.get<bf16>(P2 * 128); a.da3 = ar.get<bf16>(P2 * 128);
         a.dp1 = ar.get<bf16>(P2 * 64); a.da2 = ar.get<bf16>(P1 * 64); a.da1 = ar.get<bf16>(P1 * 64);
     }
@@ -249,10 +264,15 @@ int gemm(Ctx& c, const GemmArgs& g) { Prof p(c.m, MASR_PROF_GEMM, c.s); return m
 // weight/bias gradients of a Linear: dW[N][K] = dy^T x, db = colsum(dy)
 int lin_wgrad(Ctx& c, const bf16* dy, long lddy, const bf16* x, long ldx, int rows, int N, int K, float* dW, float* db, bool split = false,
               int accumulate = 0) {
+    masr_model* m = c.m;
+    if (m->wg_defer && !split && !accumulate && m->wg.n < WGRAD_GROUP_MAX) {      // joins the grouped launch (flush_wgrads)
+        WgradDesc& d = m->wg.p[m->wg.n++];
+        d.dy = dy; d.x = x; d.dW = dW; d.db = db; d.lddy = (int)lddy; d.ldx = (int)ldx; d.rows = rows; d.N = N; d.K = K; d.tile_start = 0;
+        return 0;
+    }
     GemmArgs g = gemm_args();
     g.reduction_major = 1; g.A = dy; g.lda = lddy; g.B = x; g.ldb = ldx; g.M = N; g.N = K; g.K = rows;
     g.C32 = dW; g.ldc = K; g.accumulate = accumulate; g.colsum = db;
-    masr_model* m = c.m;
     // long reductions (encoder rows B*T') are split over WG_SPLIT workgroups with slab partials that
     // mk_split_reduce combines in fixed order; decoder-row reductions (B*L) are short and stay whole
     if (split && dW >= m->G && dW < m->G + m->nparams) {
@@ -260,6 +280,15 @@ int lin_wgrad(Ctx& c, const bf16* dy, long lddy, const bf16* x, long ldx, int ro
     }
     CK(gemm(c, g));
     return 0;
+}
+int flush_wgrads(Ctx& c) {
+    masr_model* m = c.m;
+    m->wg_defer = false;
+    if (m->wg.n == 0) return 0;
+    Prof p(m, MASR_PROF_GEMM, c.s);
+    const int rc = mk_gemm_wgrad_grouped(m->wg, c.s);
+    m->wg.n = 0;
+    return rc;
 }
 // dX = dy W via the transposed shadow t16 [K][ldt]
 GemmArgs lin_dgrad_args(const bf16* dy, long lddy, const bf16* t16, long ldt, int rows, int N, int K) {
@@ -311,8 +340,25 @@ int ln_bwd(Ctx& c, const Norm& n, const float* dy, const float* x, const float* 
            uint32_t site, int rows) {
     Prof p(c.m, MASR_PROF_OTHER, c.s);
     masr_model* m = c.m;
+    // the dgamma/dbeta partials of every LayerNorm go to their own slab region; flush_ln_reduce folds them all at once
+    const int64_t need = mk_layernorm_bwd_slab_floats(rows, m->E);
+    if (m->lng.n < LN_GROUP_MAX && m->ln_slab_used + need <= m->acts.ln_slab_floats) {
+        float* slab = m->acts.ln_slab + m->ln_slab_used;
+        m->ln_slab_used += need;
+        LnReduceDesc& d = m->lng.p[m->lng.n++];
+        d.slab = slab; d.dgamma = m->G + n.w; d.dbeta = m->G + n.b; d.nblocks = (int)(need / (2 * m->E));
+        return mk_layernorm_bwd(dy, x, m->P + n.w, mean, rstd, dx32, dx16, dx16 ? c.p_drop : 0.f, c.seed, site, nullptr, nullptr, slab, rows,
+                                m->E, c.s);
+    }
     return mk_layernorm_bwd(dy, x, m->P + n.w, mean, rstd, dx32, dx16, dx16 ? c.p_drop : 0.f, c.seed, site, m->G + n.w, m->G + n.b,
                             m->acts.slab, rows, m->E, c.s);
+}
+int flush_ln_reduce(Ctx& c) {
+    masr_model* m = c.m;
+    Prof p(m, MASR_PROF_OTHER, c.s);
+    const int rc = mk_layernorm_bwd_reduce_grouped(m->lng, m->E, c.s);
+    m->lng.n = 0; m->ln_slab_used = 0;
+    return rc;
 }
 
 // backward of  s_out = x + drop(ffn(x16))  given d s_out (gs32 fp32, gs16 bf16 already dropout-masked for the ffn output site)
@@ -576,23 +622,28 @@ static int attn_block_bwd(Ctx& c, const Attn& at, const bf16* xq16, const bf16* 
 static int backward(Ctx& c, const float* xs) {
     masr_model* m = c.m; Acts& a = m->acts; hipStream_t s = c.s; float* G = m->G;
     const int E = m->E, L = a.L, B = a.B;
-    // ---- output projection
+    // ---- output projection.  The weight gradients of the decoder-row Linears (reduction over only B*L rows) are not
+    // launched one by one: their operands are kept per layer and ONE grouped launch computes them after the layer loop
+    static const bool group_wgrads = !getenv("MASR_NO_GROUPED_WGRAD");
+    m->wg.n = 0; m->wg_defer = group_wgrads;
+    m->lng.n = 0; m->ln_slab_used = 0;
     CK(lin_wgrad(c, a.dlogits, m->Cp, a.yf16, E, a.rows_d, m->C, E, G + m->ct.w, G + m->ct.b));
     { GemmArgs g = lin_dgrad_args(a.dlogits, m->Cp, m->ct.t16, m->Cp, a.rows_d, m->Cp, E); g.C32 = a.gd_a; g.ldc = E; CK(gemm(c, g)); }
     float *gcur = a.gd_b, *gs = a.gd_a;
     CK(ln_bwd(c, m->dec_norm, a.gd_a, a.y32[m->ND], a.mdf, a.rdf, gcur, nullptr, 0, a.rows_d));
     // ---- decoder layers
     for (int l = m->ND - 1; l >= 0; --l) {
-        DecAct& d = a.dec[l]; const DecL& w = m->dec[l];
-        CK(ln_bwd(c, w.n3, gcur, d.s3, d.m3, d.r3, gs, a.gd16, d.site[5], a.rows_d));
-        CK(ffn_bwd(c, w.l1, w.l2, d.y2_16, d.f, gs, a.gd16, a.rows_d, a.gf_d, gcur, false));
-        CK(ln_bwd(c, w.n2, gcur, d.s2, d.m2, d.r2, gs, a.gd16, d.site[3], a.rows_d));
+        DecAct& d = a.dec[l]; const DecL& w = m->dec[l]; const DecGrad& dg = a.dgr[l];
+        CK(ln_bwd(c, w.n3, gcur, d.s3, d.m3, d.r3, gs, dg.g3, d.site[5], a.rows_d));
+        CK(ffn_bwd(c, w.l1, w.l2, d.y2_16, d.f, gs, dg.g3, a.rows_d, dg.gf, gcur, false));
+        CK(ln_bwd(c, w.n2, gcur, d.s2, d.m2, d.r2, gs, dg.g2, d.site[3], a.rows_d));
         CK(attn_block_bwd(c, w.ca, d.y1_16, a.mem16, a.rows_d, a.rows_e, L, a.Tp, false, false, a.enc_lens, d.q, d.kv, d.co, d.lse_c, gs,
-                          a.gd16, a.gao_d, a.gq_d, a.gkv_d, a.delta_d, gcur, a.dmem32, l == m->ND - 1 ? 0 : 1, d.site[2], false));
-        CK(ln_bwd(c, w.n1, gcur, d.s1, d.m1, d.r1, gs, a.gd16, d.site[1], a.rows_d));
-        CK(attn_block_bwd(c, w.sa, a.y16[l], nullptr, a.rows_d, 0, L, L, true, true, nullptr, d.qkv, nullptr, d.ao, d.lse_s, gs, a.gd16,
-                          a.gao_d, a.gqkv_d, nullptr, a.delta_d, gcur, nullptr, 0, d.site[0], false));
+                          dg.g2, a.gao_d, dg.gq, a.gkv_d, a.delta_d, gcur, a.dmem32, l == m->ND - 1 ? 0 : 1, d.site[2], false));
+        CK(ln_bwd(c, w.n1, gcur, d.s1, d.m1, d.r1, gs, dg.g1, d.site[1], a.rows_d));
+        CK(attn_block_bwd(c, w.sa, a.y16[l], nullptr, a.rows_d, 0, L, L, true, true, nullptr, d.qkv, nullptr, d.ao, d.lse_s, gs, dg.g1,
+                          a.gao_d, dg.gqkv, nullptr, a.delta_d, gcur, nullptr, 0, d.site[0], false));
     }
+    CK(flush_wgrads(c));
     float* g_dec_in = gcur;                                  // d(decoder input): consumed by embed_bwd after the split-K combine
     // ---- encoder
     gcur = a.ge_b; gs = a.ge_a;
@@ -634,6 +685,7 @@ static int backward(Ctx& c, const float* xs) {
     CK(wgrad(a.a1, a.da2, m->conv[1], a.T, a.D, P1));
     CK(dgrad(a.da2, m->conv[1], a.a1, a.da1, a.T, a.D));
     { Prof p(m, MASR_PROF_CONV_WGRAD, s); CK(mk_conv1_wgrad(xs, a.da1, G + m->conv[0].w, G + m->conv[0].b, a.slab, B, a.T, a.D, s)); }
+    CK(flush_ln_reduce(c));
     // ---- combine the split-K partials of all Linear gradients, then add the embedding rows into the (tied) table
     { Prof p(m, MASR_PROF_OTHER, s);
       CK(mk_split_reduce(G, a.wg_slab, WG_SPLIT - 1, m->nparams, m->d_ranges, m->nranges, s));

@@ -212,7 +212,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
 }
 
 template <int BM, int BN, bool RM, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int bz) {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int FM = WM / 16, FN = WN / 16;
     using TA = typename std::conditional<RM, TileRM<BM>, TileNT<BM>>::type;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = by * BM, n0 = bx * BN;
 
     // register ring of DEPTH k-tiles: global loads run DEPTH tiles ahead of the MFMAs (a lone workgroup on a CU has
     // nothing else to hide the L2/HBM latency with -- this is what the small-M decoder GEMMs are made of)
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // fused bias gradient (wgrad form only): colsum[m] = sum_k A(m,k), produced by the n-tile-0 workgroups
-    const bool do_colsum = RM && g.colsum && blockIdx.x == 0;
+    const bool do_colsum = RM && g.colsum && bx == 0;
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // split-K (wgrad form): this workgroup reduces rows [kbeg, kend) of the reduction index
@@ -248,9 +248,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     long out_delta = 0;
     if (RM && g.split_k > 1) {
         const int per = ((g.K + g.split_k - 1) / g.split_k + BK - 1) / BK * BK;
-        kbeg = blockIdx.z * per;
+        kbeg = bz * per;
         kend = kbeg + per < g.K ? kbeg + per : g.K;
-        if (blockIdx.z > 0) out_delta = g.split_delta + (long)(blockIdx.z - 1) * g.split_stride;
+        if (bz > 0) out_delta = g.split_delta + (long)(bz - 1) * g.split_stride;
     }
     const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
 #pragma unroll
@@ -321,6 +321,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 
     gemm_epilogue<BM, BN, EPI>(g, acc, smem, m0, n0, out_delta);
+}
+template <int BM, int BN, bool RM, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    gemm_body<BM, BN, RM, EPI>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// ---- grouped weight-gradient launch: many small reduction-major GEMMs (dW = dY^T X of the decoder Linears, reduction
+// over only B*L rows) as ONE grid.  Each of them alone is 16-256 workgroups and ~12 us of mostly launch latency; together
+// they fill the chip.  The descriptors travel in the kernel-argument segment (uniform scalar loads, no table upload).
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_wgrad_grouped_kernel(WgradGroup grp) {
+    int p = 0;
+    while (p + 1 < grp.n && (int)blockIdx.x >= grp.p[p + 1].tile_start) ++p;
+    const WgradDesc& d = grp.p[p];
+    GemmArgs g{};
+    g.A = d.dy; g.lda = d.lddy; g.B = d.x; g.ldb = d.ldx; g.M = d.N; g.N = d.K; g.K = d.rows; g.reduction_major = 1;
+    g.alpha = 1.f; g.mask_scale = 1.f; g.C32 = d.dW; g.ldc = d.K; g.colsum = d.db;
+    const int t = blockIdx.x - d.tile_start, tiles_x = (d.K + BN - 1) / BN;
+    gemm_body<BM, BN, true, E_C32>(g, t % tiles_x, t / tiles_x, 0);
 }
 #undef HAS
 
@@ -480,6 +499,22 @@ int launch_tile(const GemmArgs& g, hipStream_t s) {
 }
 
 }  // namespace
+
+int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s) {
+    if (grp.n <= 0) return 0;
+    int tiles = 0;
+    for (int i = 0; i < grp.n; ++i) {
+        WgradDesc& d = grp.p[i];
+        if ((d.lddy & 7) || (d.ldx & 7) || ((uintptr_t)d.dy & 15) || ((uintptr_t)d.x & 15) || d.lddy < (d.N + 7) / 8 * 8 || d.ldx < (d.K + 7) / 8 * 8) {
+            mk_set_error("mk_gemm_wgrad_grouped", "operands must be 16-byte aligned with padded rows"); return -1;
+        }
+        d.tile_start = tiles;
+        tiles += ((d.N + 63) / 64) * ((d.K + 63) / 64);
+    }
+    hipLaunchKernelGGL((gemm_wgrad_grouped_kernel<64, 64>), dim3(tiles), dim3(256), 0, s, grp);
+    if (hipGetLastError() != hipSuccess) { mk_set_error("mk_gemm_wgrad_grouped", "launch failed"); return -1; }
+    return 0;
+}
 
 int mk_gemm(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return 0;

@@ -25,6 +25,11 @@ struct GemmArgs {
     bf16* C16; long ldc16;        // bf16 output or null
 };
 int mk_gemm(const GemmArgs& g, hipStream_t s);
+// Linear weight gradients as one grouped launch: dW[N][K] = dy[rows][N]^T x[rows][K], db[N] = column sums of dy (or null)
+struct WgradDesc { const bf16* dy; const bf16* x; float* dW; float* db; int lddy, ldx, rows, N, K, tile_start; };
+constexpr int WGRAD_GROUP_MAX = 40;
+struct WgradGroup { int n; WgradDesc p[WGRAD_GROUP_MAX]; };
+int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s);       // fills tile_start
 inline GemmArgs gemm_args() { GemmArgs g{}; g.alpha = 1.f; g.mask_scale = 1.f; return g; }
 
 // ---------------------------------------------------------------- conv front-end (conv.hip)
@@ -94,6 +99,12 @@ int mk_layernorm_bwd(const float* dy, const float* x, const float* gamma, const 
                        float* dx32, bf16* dx16, float drop_p, uint32_t seed, uint32_t site,
                        float* dgamma, float* dbeta, float* slab, int rows, int E, hipStream_t s);
 long mk_layernorm_bwd_slab_floats(int rows, int E);
+// dgamma == null: only the per-block partials are written to `slab` (each LayerNorm its own region) and
+// mk_layernorm_bwd_reduce_grouped folds all of them in one launch at the end of the backward pass
+struct LnReduceDesc { const float* slab; float* dgamma; float* dbeta; int nblocks; };
+constexpr int LN_GROUP_MAX = 64;
+struct LnReduceGroup { int n; LnReduceDesc p[LN_GROUP_MAX]; };
+int mk_layernorm_bwd_reduce_grouped(const LnReduceGroup& grp, int E, hipStream_t s);
 int mk_embed_fwd(const int* tok, const float* table, const float* pe, float* y32, bf16* y16,
                    int B, int L, int E, float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
 // dtable[v] (+)= sum over rows with tok==v of dy[row]  (deterministic: one block per vocab row)

@@ -94,10 +94,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 // 32 columns x 8 block-lanes per workgroup, 4 independent partial sums per thread; fixed order -> deterministic
-__global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ slab, int nblocks, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int E) {
+__device__ __forceinline__ void ln_bwd_reduce_body(const float* __restrict__ slab, int nblocks, float* __restrict__ dgamma,
+                                                   float* __restrict__ dbeta, int E, int bx) {
     const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    const int c = bx * 32 + cl;
     __shared__ float red[8][32];
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < 2 * E) {
@@ -116,6 +116,15 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ s
         for (int k = 0; k < 8; ++k) t += red[k][cl];
         (c / E == 0 ? dgamma : dbeta)[c % E] = t;
     }
+}
+__global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ slab, int nblocks, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int E) {
+    ln_bwd_reduce_body(slab, nblocks, dgamma, dbeta, E, blockIdx.x);
+}
+// all LayerNorms of a backward pass at once: blockIdx.y = which LayerNorm (descriptors in the kernel-argument segment)
+__global__ __launch_bounds__(256) void ln_bwd_reduce_grouped(LnReduceGroup grp, int E) {
+    const LnReduceDesc& d = grp.p[blockIdx.y];
+    ln_bwd_reduce_body(d.slab, d.nblocks, d.dgamma, d.dbeta, E, blockIdx.x);
 }
 
 // ---------------------------------------------------------------- embedding + positional encoding
@@ -353,7 +362,12 @@ int mk_layernorm_bwd(const float* dy, const float* x, const float* gamma, const 
 #define CALL(P) ln_bwd_launch<P>(dy, x, gamma, mean, rstd, dx32, dx16, drop_p, seed, site, slab, rows, nb, s)
     LN_DISPATCH(E, CALL)
 #undef CALL
-    hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * E + 31) / 32), dim3(256), 0, s, slab, nb, dgamma, dbeta, E);
+    if (dgamma) hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * E + 31) / 32), dim3(256), 0, s, slab, nb, dgamma, dbeta, E);
+    return LAUNCH_OK();
+}
+int mk_layernorm_bwd_reduce_grouped(const LnReduceGroup& grp, int E, hipStream_t s) {
+    if (grp.n <= 0) return 0;
+    hipLaunchKernelGGL(ln_bwd_reduce_grouped, dim3((2 * E + 31) / 32, grp.n), dim3(256), 0, s, grp, E);
     return LAUNCH_OK();
 }
 int mk_embed_fwd(const int* tok, const float* table, const float* pe, float* y32, bf16* y16, int B, int L, int E,
