@@ -11,6 +11,8 @@ import os
 import random
 from pathlib import Path
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")            # --tasks_per_gpu > 3 needs more than the default 4 HIP hardware queues
+
 import numpy as np
 import torch
 import yaml
