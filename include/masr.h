@@ -97,6 +97,15 @@ int masr_recog_full(masr_model* m, const float* xs, const int64_t* ilens, int B,
  * imports, src/monitor/metric.py:4,66,87).  Returns the distance, < 0 on bad arguments. */
 int64_t masr_edit_distance(const int32_t* a, int na, const int32_t* b, int nb);
 
+/* Log-mel filterbank features on the GPU, written in the layout of the reference's feat.dat shards
+ * (src/io/dataset.py:123-139: one [sum T_b][idim] float matrix per split).  The reference has no extraction code; the
+ * algorithm is Kaldi's compute-fbank-feats with the recipe's options (16 kHz, 25 ms / 10 ms, povey window, 512-point FFT,
+ * mel bins over 20 Hz - 8 kHz, log) -- oracle/fbank_np.py.  wav: device fp32 on the 16-bit PCM scale, utterances
+ * concatenated; wav_off: device int64 [B+1]; row_off: device int64 [B] first output row of each utterance;
+ * frames of utterance b: T_b = 1 + (n_b - 400) / 160 (0 if n_b < 400); max_frames >= max T_b; feat: device [sum T_b][n_mel]. */
+int masr_fbank(const float* wav, const int64_t* wav_off, const int64_t* row_off, int B, int max_frames, int n_mel,
+               float* feat, void* stream);
+
 /* collate_fn zero-padding of CommonVoiceDataset rows (src/io/dataset.py:21-33,147-153) done on the GPU:
  * feat fp32 [sum T_i][D] resident in HBM, row_start int64 [B] (device), lens int32 [B] (device). */
 int masr_gather_pad(const float* feat, const int64_t* row_start, const int32_t* lens, float* xs, int B, int Tmax, int D, void* stream);

@@ -43,6 +43,7 @@ _SIGS = {
     "masr_recog": (i32, [vp, vp, vp, i32, i32, vp, vp]),
     "masr_recog_full": (i32, [vp, vp, vp, i32, i32, vp, vp]),
     "masr_edit_distance": (i64, [vp, i32, vp, i32]),
+    "masr_fbank": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
     "masr_gather_pad": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "masr_ctc_work_floats": (i64, [i32, i32, i32]),
     "masr_ctc_loss": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]),

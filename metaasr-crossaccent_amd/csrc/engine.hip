@@ -953,6 +953,9 @@ int64_t masr_edit_distance(const int32_t* a, int na, const int32_t* b, int nb) {
 int masr_gather_pad(const float* feat, const int64_t* row_start, const int32_t* lens, float* xs, int B, int Tmax, int D, void* stream) {
     return mk_gather_pad(feat, (const long*)row_start, lens, xs, B, Tmax, D, (hipStream_t)stream);
 }
+int masr_fbank(const float* wav, const int64_t* wav_off, const int64_t* row_off, int B, int max_frames, int n_mel, float* feat, void* stream) {
+    return mk_fbank(wav, (const long*)wav_off, (const long*)row_off, B, max_frames, n_mel, feat, (hipStream_t)stream);
+}
 int64_t masr_ctc_work_floats(int T, int B, int maxS) { return mk_ctc_work_floats(T, B, maxS); }
 int masr_ctc_loss(const float* logits, const int32_t* targets, const int32_t* tgt_off, const int32_t* in_len, const int32_t* tgt_len, int T,
                   int B, int C, int blank, float* nll, float* loss, float* grad, float* work, int maxS, void* stream) {

@@ -153,6 +153,11 @@ int mk_vgg2enc_grad_unpermute(const float* g_nhwc, float* dw, int E, int C, int 
 // ragged gather + zero pad: rows of feat [sum T_i][D] -> xs [B][Tmax][D]
 int mk_gather_pad(const float* feat, const long* row_start, const int* lens, float* xs, int B, int Tmax, int D, hipStream_t s);
 
+// ---------------------------------------------------------------- features (fbank.hip)
+// Kaldi-style log-mel filterbank: wav fp32 (PCM scale, utterances concatenated), wav_off [B+1], row_off [B] (first output
+// row of each utterance), feat [sum T_b][n_mel]; T_b = 1 + (n_b - 400) / 160; grid covers max_frames frames per utterance
+int mk_fbank(const float* wav, const long* wav_off, const long* row_off, int B, int max_frames, int n_mel, float* feat, hipStream_t s);
+
 // ---------------------------------------------------------------- CTC (ctc.hip)
 // logits fp32 [T][B][C] (pre-softmax); targets concatenated int [sum tl]; per-sample offsets tgt_off [B]
 // loss_out[0] = mean_b( nll_b / max(tl_b,1) ), zero_infinity; grad wrt logits [T][B][C]

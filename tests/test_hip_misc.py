@@ -174,3 +174,32 @@ def test_mono_interface_finetunes_from_pretrain_snapshot(tmp_path, monkeypatch):
     files = {p.name for p in s.log_dir.iterdir()}
     assert {"snapshot.latest", "optimizer.latest", "info_dict.latest", "epoch", "global_step"} <= files
     assert (s.log_dir / "epoch").read_text().strip() == "2"
+
+
+def test_fbank_matches_kaldi_style_oracle(tmp_path):
+    """masr_fbank (the reference has no extraction code -> oracle/fbank_np.py restates Kaldi's published
+    compute-fbank-feats, parity unpinned): ragged utterances incl. one shorter than a frame, rows land in feat.dat order."""
+    from masr_amd.io import fbank as gf
+    from oracle import fbank_np as F
+    rng = np.random.default_rng(5)
+    lens = [16000, 399, 8123, 400, 24000]
+    wavs = []
+    for i, n in enumerate(lens):
+        t = np.arange(n) / 16000.0
+        w = 6000 * np.sin(2 * np.pi * (220 + 310 * i) * t) + 2500 * np.sin(2 * np.pi * 3100 * t + i) + 800 * rng.standard_normal(n) + 150.0
+        wavs.append(np.round(w).astype(np.float32))                       # PCM-like integers with a DC offset
+    feat, ilens = gf.extract(wavs, n_mel=80)
+    assert ilens.tolist() == [F.num_frames(n) for n in lens] == [98, 0, 49, 1, 148]
+    ref = np.concatenate([F.fbank(w, 80) for w in wavs])
+    got = feat.cpu().numpy().astype(np.float64)
+    assert got.shape == ref.shape == (int(ilens.sum()), 80)
+    err = np.abs(got - ref)
+    print(f"fbank: max |log-mel diff| {err.max():.2e}, mean {err.mean():.2e} (values {ref.min():.1f} .. {ref.max():.1f})")
+    assert err.max() < 2e-3                                               # fp32 FFT / window vs float64, log domain
+    # 40 mel bins and the shard writer (feat.dat = NPY header + matrix, readable the way the reference reads it)
+    f40, il40 = gf.extract(wavs[:1], n_mel=40)
+    assert np.abs(f40.cpu().numpy() - F.fbank(wavs[0], 40)).max() < 2e-3
+    gf.write_feat_shard(tmp_path / "us" / "train", feat, ilens)
+    back = np.load(tmp_path / "us" / "train" / "feat.dat", mmap_mode="r")
+    assert back.shape == got.shape and np.array_equal(np.asarray(back), feat.cpu().numpy())
+    assert np.load(tmp_path / "us" / "train" / "ilens.npy").tolist() == ilens.tolist()

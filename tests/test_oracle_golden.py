@@ -220,3 +220,19 @@ def test_fomaml_toy(golden_dir, tmp_path):
     for n in ("vgg2enc.bias", "char_trans.bias", "decoder.norm.weight"):
         assert np.abs(meta[n].numpy() - g[f"meta/param/{n}"]).max() <= tol, n
     assert abs(ref_cpu.inner_lr(cfg) - float(g["inner_lr"])) < 1e-15
+
+
+def test_fbank_oracle_properties():
+    """oracle/fbank_np.py has no reference fixture to pin it (the reference ships no extraction code): check the
+    published algorithm's invariants instead -- frame count, scale law, DC invariance, tone localisation."""
+    from oracle import fbank_np as F
+    assert [F.num_frames(n) for n in (0, 399, 400, 559, 560, 16000)] == [0, 0, 1, 1, 2, 98]
+    banks = F.mel_banks(80)
+    assert banks.shape == (80, 256) and banks.min() >= 0 and banks.max() <= 1 and (banks.sum(1) > 0).all()
+    t = np.arange(8000) / 16000.0
+    tone = 5000 * np.sin(2 * np.pi * 1000.0 * t)
+    f = F.fbank(tone, 80)
+    centre = F.mel(F.LOW) + (np.arange(80) + 1) * (F.mel(8000.0) - F.mel(F.LOW)) / 81
+    assert abs(int(f.mean(0).argmax()) - int(np.abs(centre - F.mel(1000.0)).argmin())) <= 1      # energy sits at the 1 kHz filter
+    np.testing.assert_allclose(F.fbank(2 * tone, 80), f + 2 * np.log(2.0), atol=1e-9)            # power scales with amplitude^2
+    np.testing.assert_allclose(F.fbank(tone + 1234.0, 80), f, atol=1e-6)                         # remove_dc_offset
