@@ -532,6 +532,9 @@ int mk_gemm(const GemmArgs& g, hipStream_t s) {
     // largest tile that still yields roughly one workgroup per CU (256 CUs)
     const long z = (g.reduction_major && g.split_k > 1) ? g.split_k : 1;
     auto wgs = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * z; };
+    static const int rm_tile = getenv("MASR_GEMM_RM_TILE") ? atoi(getenv("MASR_GEMM_RM_TILE")) : 0;     // A/B switch: 1 = 64x64, 2 = 128x64
+    if (g.reduction_major && rm_tile == 1) return launch_tile<64, 64>(g, s);
+    if (g.reduction_major && rm_tile == 2) return launch_tile<128, 64>(g, s);
     if (wgs(128, 128) >= 192) return launch_tile<128, 128>(g, s);
     if (wgs(128, 64) >= 192) return launch_tile<128, 64>(g, s);
     return launch_tile<64, 64>(g, s);
