@@ -322,9 +322,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 
     gemm_epilogue<BM, BN, EPI>(g, acc, smem, m0, n0, out_delta);
 }
+// XCD-aware tile order (bijective for any grid): workgroup ids are dealt round-robin to the 8 XCDs, each with a private
+// L2; every XCD gets a CONTIGUOUS run of tiles (x fastest), so tiles that share an A row-block / B column-block meet in
+// one L2 instead of eight.
+__device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz) {
+    const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * (int)gridDim.z;
+    const int l = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int c = l & 7, q = total >> 3, r = total & 7;
+    const int t = c * q + (c < r ? c : r) + (l >> 3);
+    bx = t % gx; by = (t / gx) % gy; bz = t / (gx * gy);
+}
 template <int BM, int BN, bool RM, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    gemm_body<BM, BN, RM, EPI>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (g.xcd_order) xcd_tile(bx, by, bz);
+    gemm_body<BM, BN, RM, EPI>(g, bx, by, bz);
 }
 
 // ---- grouped weight-gradient launch: many small reduction-major GEMMs (dW = dY^T X of the decoder Linears, reduction
@@ -363,7 +375,9 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int bx_ = blockIdx.x, by_ = blockIdx.y, bz_ = 0;
+    if (g.xcd_order) xcd_tile(bx_, by_, bz_);
+    const int m0 = by_ * BM, n0 = bx_ * BN;
 
     // per-thread source rows are fixed over the k loop
     constexpr int ACH = BM * 8 / 256, BCH = BN * 8 / 256;
@@ -467,8 +481,11 @@ void launch_epi(const GemmArgs& g, dim3 grid, hipStream_t s) {
 }
 
 template <int BM, int BN>
-int launch_tile(const GemmArgs& g, hipStream_t s) {
+int launch_tile(const GemmArgs& g_in, hipStream_t s) {
+    static const bool xcd = !getenv("MASR_GEMM_NO_XCD");
+    GemmArgs g = g_in;
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, (g.reduction_major && g.split_k > 1) ? g.split_k : 1);
+    g.xcd_order = xcd && (long)grid.x * grid.y * grid.z >= 64;
     const int epi = (g.bias ? E_BIAS : 0) | (g.pe ? E_PE : 0) | (g.relu ? E_RELU : 0) | (g.mask ? E_MASK : 0) |
                     (g.drop_p > 0.f ? E_DROP : 0) | (g.residual ? E_RES : 0) | (g.accumulate ? E_ACC : 0) |
                     (g.C32 ? E_C32 : 0) | (g.C16 ? E_C16 : 0);

@@ -21,6 +21,7 @@ struct GemmArgs {
     int split_k;                  // reduction-major only: >1 splits the reduction over gridDim.z workgroups; split 0 writes
     long split_delta, split_stride;   // C32/colsum, split z>0 writes the same addresses + split_delta + (z-1)*split_stride
     int accumulate;               // C32 += v
+    int xcd_order;                // set by mk_gemm: XCD-contiguous tile order
     float* C32; long ldc;         // fp32 output or null
     bf16* C16; long ldc16;        // bf16 output or null
 };
