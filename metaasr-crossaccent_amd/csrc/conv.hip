@@ -216,13 +216,33 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
         }
 }
 
+// fragment of a reduction-major LDS tile [k][m] (row stride LDT): 32 k-rows x columns r0..r0+15 through two transposing reads
+template <int LDT>
+__device__ __forceinline__ bf16x8 frag_rm(const bf16* tile, int r0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+    const bf16* a0 = tile + (4 * g + q) * LDT + r0 + 4 * p;
+    const bf16* a1 = a0 + 16 * LDT;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)a0);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)a1);
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
 // ------------------------------------------------------------------ patch-tiled 3x3 (fwd and dgrad), v2
 // One workgroup = a TH x 16 tile of output pixels of one image, all COUT channels.  The (TH+2) x 18 input patch
 // (64-channel slab) is brought into LDS ONCE and all 9 taps read their A fragments straight out of it (no im2col
 // re-fetch: HBM/L2 traffic per output pixel drops from 9x to ~1.3x the input bytes); the per-tap weight slice
 // [COUT][64] is double-buffered through registers.  4 waves, wave w owns TH/4 pixel rows x all COUT.
 // LDS: patch pixel / weight row stride 80 elements (160 B), conflict-free for the four 16-lane groups of ds_read_b128.
-template <int CIN, int COUT, int TH>
+// W1 = true (dgrad of the second conv only): the tile of d(conv1 output) never goes to HBM.  Its only consumer is the
+// weight gradient of conv1 (the network input needs no gradient), so the epilogue contracts the masked tile in LDS with
+// the 3x3 neighbourhoods of the 1-channel input on the MFMA -- [64 channels] x [9 taps + a column of ones for the bias
+// gradient] over the 256 pixels of the tile -- and writes 640 partial sums per workgroup (folded by conv1_wgrad_reduce).
+// This removes the 164 MB store, the 164 MB re-read and the whole conv1_wgrad launch.
+template <int CIN, int COUT, int TH, bool W1 = false>
 __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
     constexpr int TW = 16, PW = TW + 2, PH = TH + 2;
     constexpr int PS = 80;                                 // patch pixel stride (elements): 160 B is conflict-free for the
@@ -241,6 +261,19 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
     const int H = a.H, W = a.W;
     const int d0 = blockIdx.x * TW, t0 = blockIdx.y * TH, b = blockIdx.z;
     const bf16* in_b = a.in + (long)b * H * W * CIN;
+
+    // W1: the (TH+2) x 18 neighbourhood of the 1-channel network input, fetched now, used in the epilogue
+    float x1v[2] = {0.f, 0.f};
+    if constexpr (W1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + i * 256;
+            const int pi = c / PW, pj = c % PW, t = t0 + pi - 1, d = d0 + pj - 1;
+            const int tc = t < 0 ? 0 : (t > H - 1 ? H - 1 : t), dc = d < 0 ? 0 : (d > W - 1 ? W - 1 : d);
+            const float v = a.x1[((long)b * H + tc) * W + dc];
+            x1v[i] = (c < PH * PW && t == tc && d == dc) ? v : 0.f;
+        }
+    }
 
     f32x4 acc[MF][NF];
 #pragma unroll
@@ -350,31 +383,60 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
         const int c = tid + i * 256;
         const int pix = c / (COUT / 8), ch = (c % (COUT / 8)) * 8;
         const int t = t0 + pix / TW, d = d0 + pix % TW;
+        bf16x8 v = ov[i];
         if (t < H && d < W) {
-            bf16x8 v = ov[i];
             if (mask_b) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) if (!((float)mv[i][k] > 0.f)) v[k] = (bf16)0.f;
             }
-            st8(out_b + ((long)t * W + d) * COUT + ch, v);
+            if constexpr (!W1) st8(out_b + ((long)t * W + d) * COUT + ch, v);
+        } else {
+            v = zero8();
+        }
+        if constexpr (W1) st8(otile + pix * OS + ch, v);        // masked tile (zeros outside the image) stays in LDS
+    }
+    if constexpr (W1) {
+        static_assert(!W1 || (COUT == 64 && TH == 16), "fused conv1 wgrad: 64 channels, 16 x 16 pixel tile");
+        constexpr int XS = 256 + 8;                               // row stride of the tap-major input image
+        bf16* sxt = lds + OUT_EL;                                 // [16 taps][XS]: taps 0..8, 9 = ones (bias), 10..15 = 0
+        float* sxp = reinterpret_cast<float*>(sxt + 16 * XS);     // [(TH+2) * 18] input neighbourhood
+        static_assert(!W1 || (OUT_EL + 16 * XS) * 2 + PH * PW * 4 <= LDS_EL * 2, "LDS budget of the fused epilogue");
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int c = tid + i * 256; if (c < PH * PW) sxp[c] = x1v[i]; }
+        __syncthreads();
+        {   // thread = pixel: its 9 neighbours + 1 go to column kappa(pixel) of the tap-major image.  kappa undoes the
+            // k-permutation of frag_rm (MFMA k index 8g+j <-> tile row 4g+j for j < 4, 16+4g+(j-4) for j >= 4).
+            const int pr = tid >> 4, pc = tid & 15;
+            const int rho = tid & 31, slab = tid >> 5;
+            const int kap = rho < 16 ? 8 * (rho >> 2) + (rho & 3) : 8 * ((rho - 16) >> 2) + 4 + (rho & 3);
+            const bool in_img = t0 + pr < H && d0 + pc < W;
+#pragma unroll
+            for (int tap = 0; tap < 16; ++tap) {
+                float v = 0.f;
+                if (tap < 9) v = sxp[(pr + tap / 3) * PW + pc + tap % 3];
+                else if (tap == 9) v = 1.f;
+                sxt[tap * XS + slab * 32 + kap] = (bf16)(in_img ? v : 0.f);
+            }
+        }
+        __syncthreads();
+        // wave w: output channels 16w .. 16w+15 x 16 taps, contraction over the 256 pixels (8 slabs of 32)
+        f32x4 cw = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) {
+            const bf16x8 af = frag_rm<OS>(otile + sl * 32 * OS, wave * 16, lane);
+            const bf16x8 bf = ld8(sxt + (lane & 15) * XS + sl * 32 + (lane >> 4) * 8);
+            cw = mma16(af, bf, cw);
+        }
+        const int tap = lane & 15;
+        if (tap < 10) {
+            const long wg = ((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.w1_slab[wg * 640 + (wave * 16 + 4 * (lane >> 4) + r) * 10 + tap] = cw[r];
         }
     }
 }
 
 // ------------------------------------------------------------------ wgrad (reduction over pixels)
-template <int LDT>
-__device__ __forceinline__ bf16x8 frag_rm(const bf16* tile, int r0, int lane) {
-    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-    typedef __attribute__((address_space(3))) bf16x4 lds_b4;
-    const bf16* a0 = tile + (4 * g + q) * LDT + r0 + 4 * p;
-    const bf16* a1 = a0 + 16 * LDT;
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)a0);
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)a1);
-    bf16x8 f;
-    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-    return f;
-}
 
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(ConvWgradArgs a, long pix_per_split) {
@@ -772,6 +834,13 @@ int mk_conv1_wgrad(const float* x, const bf16* dy, float* dw, float* db, float* 
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+long mk_conv1_wgrad_fused_slab_floats(int B, int H, int W) { return (long)B * ((H + 15) / 16) * ((W + 15) / 16) * 640; }
+int mk_conv1_wgrad_fused_reduce(const float* slab, int B, int H, int W, float* dw, float* db, hipStream_t s) {
+    const int nb = B * ((H + 15) / 16) * ((W + 15) / 16);
+    hipLaunchKernelGGL(conv1_wgrad_reduce, dim3(160), dim3(256), 0, s, slab, nb, dw, db);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int mk_conv3x3(const ConvArgs& a, hipStream_t s) {
     if (getenv("MASR_CONV_V1")) {                          // first-generation im2col-on-the-fly kernel (kept for A/B runs)
         const long P = (long)a.B * a.H * a.W;
@@ -784,7 +853,10 @@ int mk_conv3x3(const ConvArgs& a, hipStream_t s) {
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     auto grid = [&](int TH) { return dim3((a.W + 15) / 16, (a.H + TH - 1) / TH, a.B); };
-    if (a.CIN == 64 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<64, 64, 16>), grid(16), dim3(256), 0, s, a);
+    if (a.x1) {
+        if (!(a.CIN == 64 && a.COUT == 64) || !a.w1_slab || !a.mask) { mk_set_error("mk_conv3x3", "fused conv1 wgrad needs the 64->64 dgrad with a mask"); return -1; }
+        hipLaunchKernelGGL((conv3x3_patch_kernel<64, 64, 16, true>), grid(16), dim3(256), 0, s, a);
+    } else if (a.CIN == 64 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<64, 64, 16>), grid(16), dim3(256), 0, s, a);
     else if (a.CIN == 64 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<64, 128, 8>), grid(8), dim3(256), 0, s, a);
     else if (a.CIN == 128 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 128, 8>), grid(8), dim3(256), 0, s, a);
     else if (a.CIN == 128 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 64, 16>), grid(16), dim3(256), 0, s, a);

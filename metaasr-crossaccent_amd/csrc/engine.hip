@@ -201,7 +201,7 @@ void plan_acts(const masr_model* m, Arena& ar, Acts& a, int B, int T, int L, boo
     mx(mk_layernorm_bwd_slab_floats((int)(re > rd ? re : rd), E));
     mx(mk_colsum_slab_floats((int)P1, 64)); mx(mk_colsum_slab_floats((int)P2, 128));
     mx(mk_colsum_slab_floats((int)(re > rd ? re : rd), 3 * E > Fi ? 3 * E : Fi));
-    mx(mk_conv1_wgrad_slab_floats(B, T, m->D));
+    mx(mk_conv1_wgrad_slab_floats(B, T, m->D)); mx(mk_conv1_wgrad_fused_slab_floats(B, T, m->D));
     mx(mk_conv3x3_wgrad_slab_floats(B, T, m->D, 64, 64));
     mx(mk_conv3x3_wgrad_slab_floats(B, a.H2, a.W2, 64, 128));
     mx(mk_conv3x3_wgrad_slab_floats(B, a.H2, a.W2, 128, 128));
@@ -683,8 +683,18 @@ static int backward(Ctx& c, const float* xs) {
     CK(dgrad(a.da3, m->conv[2], nullptr, a.dp1, a.H2, a.W2));
     { Prof p(m, MASR_PROF_OTHER, s); CK(mk_maxpool_relu_bwd(a.a2, a.dp1, a.da2, B, a.T, a.D, 64, s)); }
     CK(wgrad(a.a1, a.da2, m->conv[1], a.T, a.D, P1));
-    CK(dgrad(a.da2, m->conv[1], a.a1, a.da1, a.T, a.D));
-    { Prof p(m, MASR_PROF_CONV_WGRAD, s); CK(mk_conv1_wgrad(xs, a.da1, G + m->conv[0].w, G + m->conv[0].b, a.slab, B, a.T, a.D, s)); }
+    static const bool fuse_w1 = !getenv("MASR_NO_FUSED_CONV1_WGRAD");
+    if (fuse_w1) {
+        // d(conv1 output) is consumed only by conv1's weight gradient: contract it inside the dgrad epilogue, never store it
+        { Prof p(m, MASR_PROF_CONV_DGRAD, s);
+          ConvArgs ca{}; ca.in = a.da2; ca.wk = m->conv[1].d16; ca.mask = a.a1; ca.out = a.da1; ca.B = B; ca.H = a.T; ca.W = a.D;
+          ca.CIN = 64; ca.COUT = 64; ca.x1 = xs; ca.w1_slab = a.slab;
+          CK(mk_conv3x3(ca, s)); }
+        { Prof p(m, MASR_PROF_CONV_WGRAD, s); CK(mk_conv1_wgrad_fused_reduce(a.slab, B, a.T, a.D, G + m->conv[0].w, G + m->conv[0].b, s)); }
+    } else {
+        CK(dgrad(a.da2, m->conv[1], a.a1, a.da1, a.T, a.D));
+        { Prof p(m, MASR_PROF_CONV_WGRAD, s); CK(mk_conv1_wgrad(xs, a.da1, G + m->conv[0].w, G + m->conv[0].b, a.slab, B, a.T, a.D, s)); }
+    }
     CK(flush_ln_reduce(c));
     // ---- combine the split-K partials of all Linear gradients, then add the embedding rows into the (tied) table
     { Prof p(m, MASR_PROF_OTHER, s);

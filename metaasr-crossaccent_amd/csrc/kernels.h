@@ -43,8 +43,13 @@ struct ConvArgs {
     const bf16* in; const bf16* wk; const float* bias; int relu;
     const bf16* mask;             // optional ReLU mask source (same shape as out): out = mask>0 ? v : 0
     bf16* out; int B, H, W, CIN, COUT;
+    // 64->64 dgrad of the second conv only: fuse the weight gradient of conv1 (x1 = fp32 network input [B][H][W]) into the
+    // epilogue; `out` is then never written, w1_slab receives 640 partial sums per workgroup (mk_conv1_wgrad_fused_reduce)
+    const float* x1; float* w1_slab;
 };
 int mk_conv3x3(const ConvArgs& a, hipStream_t s);
+long mk_conv1_wgrad_fused_slab_floats(int B, int H, int W);
+int mk_conv1_wgrad_fused_reduce(const float* slab, int B, int H, int W, float* dw, float* db, hipStream_t s);
 // wgrad: dw[co][ci][3][3] (+ db[co]) from in (NHWC, CIN) and dy (NHWC, COUT)
 struct ConvWgradArgs { const bf16* in; const bf16* dy; float* dw; float* db; float* slab; int B, H, W, CIN, COUT; };
 int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s);
