@@ -242,12 +242,14 @@ __device__ __forceinline__ bf16x8 frag_rm(const bf16* tile, int r0, int lane) {
 // the 3x3 neighbourhoods of the 1-channel input on the MFMA -- [64 channels] x [9 taps + a column of ones for the bias
 // gradient] over the 256 pixels of the tile -- and writes 640 partial sums per workgroup (folded by conv1_wgrad_reduce).
 // This removes the 164 MB store, the 164 MB re-read and the whole conv1_wgrad launch.
-template <int CIN, int COUT, int TH, bool W1 = false>
+// TW = 8 (tile 8 pixels wide, an MFMA pixel tile = 2 rows x 8 columns) exists for maps whose width is not a multiple
+// of 16: the 40-column maps behind the first pool would waste 8 of every 48 columns (17 % of the MFMAs) with TW = 16.
+template <int CIN, int COUT, int TH, bool W1 = false, int TW = 16>
 __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
-    constexpr int TW = 16, PW = TW + 2, PH = TH + 2;
+    constexpr int PW = TW + 2, PH = TH + 2, RPT = 16 / TW;     // RPT = pixel rows per 16-pixel MFMA tile
     constexpr int PS = 80;                                 // patch pixel stride (elements): 160 B is conflict-free for the
     constexpr int WS = 80;                                 // ds_read_b128 lane groups (144 B measured 39 % conflict cycles)
-    constexpr int MF = TH / 4, NF = COUT / 16;
+    constexpr int MF = TH * TW / 64, NF = COUT / 16;
     constexpr int KTOT = 9 * CIN, NSLAB = CIN / 64;
     constexpr int PATCH_EL = PH * PW * PS, W_EL = COUT * WS;
     constexpr int OUT_EL = TH * TW * (COUT + 8);
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
                 bf16x8 af[MF], bfr[NF];
 #pragma unroll
                 for (int i = 0; i < MF; ++i)
-                    af[i] = ld8(patch + ((wave * MF + i + dy) * PW + rr + dx) * PS + kc * 32 + kq);
+                    af[i] = ld8(patch + (((wave * MF + i) * RPT + rr / TW + dy) * PW + rr % TW + dx) * PS + kc * 32 + kq);
 #pragma unroll
                 for (int j = 0; j < NF; ++j) bfr[j] = ld8(wcur + (j * 16 + rr) * WS + kc * 32 + kq);
 #pragma unroll
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
                 float v = acc[i][j][r] + bv;
                 if (a.relu) v = fmaxf(v, 0.f);
                 const int pj = (lane >> 4) * 4 + r;
-                otile[((wave * MF + i) * TW + pj) * OS + co] = (bf16)v;
+                otile[((wave * MF + i) * 16 + pj) * OS + co] = (bf16)v;
             }
         }
     __syncthreads();
@@ -580,11 +582,13 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(ConvWgradArgs a, lon
 // and feed ALL 9 taps (both operands via ds_read_b64_tr_b16, contraction over the pixel index), so L2/HBM traffic per
 // FLOP is 9x lower than one-tap-per-workgroup.  The 9 x 64 x 64 fp32 partial stays in registers (144 VGPRs/lane) across
 // all tiles of the workgroup and is written once; a fixed-order slab reduce makes the result deterministic.
-constexpr int W2_TH = 8, W2_TW = 16, W2_PH = W2_TH + 2, W2_PW = W2_TW + 2, W2_PS = 80, W2_LDY = 80;   // 160-B rows: tr-reads conflict-free
-constexpr int W2_TOTAL_WG = 256;    // one persistent workgroup per CU (144 accumulator VGPRs -> one wave per SIMD, no spills)
+constexpr int W2_PS = 80, W2_LDY = 80;   // 160-B rows: tr-reads conflict-free
+constexpr int W2_TOTAL_WG = 512;    // two persistent workgroups per CU: one multiplies while the other loads / stages its next tile
 
-template <int CIN, int COUT, int OCC>
+// W2_TW: tile width in pixels (16, or 8 for maps whose width pads badly to 16 -- see conv3x3_patch_kernel); tile = 128 pixels
+template <int CIN, int COUT, int OCC, int W2_TW>
 __global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs a, int nwg, int ntiles, int tiles_x, int tiles_y) {
+    constexpr int W2_TH = 128 / W2_TW, W2_PH = W2_TH + 2, W2_PW = W2_TW + 2, RPS = 32 / W2_TW;      // RPS = pixel rows per 32-pixel slab
     constexpr int KTOT = 9 * CIN;
     constexpr int NPCH = (W2_PH * W2_PW * 8 + 255) / 256;   // patch chunks per thread (6)
     constexpr int NDCH = W2_TH * W2_TW * 8 / 256;           // dy chunks per thread (4)
@@ -592,7 +596,6 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs 
     __shared__ __attribute__((aligned(16))) bf16 dyt[W2_TH * W2_TW * W2_LDY];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
     const int cs = blockIdx.y % (CIN / 64), ch = blockIdx.y / (CIN / 64);
     const int H = a.H, W = a.W;
 
@@ -643,30 +646,38 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs 
         }
     };
 
-    f32x4 acc[9][2][2];
+    // wave w owns input channels 16w .. 16w+15 x all 64 output channels x 9 taps: the four dy fragments of a pixel slab are
+    // tap-independent (read once per slab), only ONE x fragment is read per tap: 26 transposing reads per 36 MFMAs
+    // (the 2 x 2 wave grid needed 40)
+    f32x4 acc[9][4];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     typedef __attribute__((address_space(3))) bf16x4 lds_b4;
     const int g = lane >> 4, q = (lane & 15) >> 2, p4 = (lane & 3) * 4;
 
     int tile = blockIdx.x;
-    if (tile < ntiles) { load_tile(tile); store_tile(); }
+    if (OCC == 1 && tile < ntiles) { load_tile(tile); store_tile(); }
     __syncthreads();
     for (; tile < ntiles; tile += nwg) {
         const bool has_next = tile + nwg < ntiles;
-        load_tile(tile + nwg);                                   // in flight during the MFMAs (clamped when past the end)
-        __builtin_amdgcn_sched_barrier(0);                       // keep the prefetch ahead of the MFMAs (hipcc would sink it)
+        if constexpr (OCC == 1) {
+            load_tile(tile + nwg);                               // in flight during the MFMAs (clamped when past the end)
+            __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch ahead of the MFMAs (hipcc would sink it)
+        } else {
+            // two workgroups per CU: no register prefetch (it would spill at 256 VGPRs); the co-resident workgroup's MFMA
+            // phase covers this one's load + staging
+            load_tile(tile); store_tile();
+            __syncthreads();
+        }
 #pragma unroll
-        for (int kc = 0; kc < W2_TH / 2; ++kc) {                 // 32 pixels = pixel rows 2kc, 2kc+1
-            bf16x8 af[2];
+        for (int kc = 0; kc < 4; ++kc) {                         // slab of 32 pixels = RPS pixel rows
+            bf16x8 af[4];
 #pragma unroll
-            for (int fm = 0; fm < 2; ++fm) {
-                const bf16* a0 = dyt + (kc * 32 + 4 * g + q) * W2_LDY + wm * 32 + fm * 16 + p4;
+            for (int fm = 0; fm < 4; ++fm) {
+                const bf16* a0 = dyt + (kc * 32 + 4 * g + q) * W2_LDY + fm * 16 + p4;
                 const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)a0);
                 const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(a0 + 16 * W2_LDY));
                 af[fm][0] = lo[0]; af[fm][1] = lo[1]; af[fm][2] = lo[2]; af[fm][3] = lo[3];
@@ -675,37 +686,36 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs 
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int dyi = tap / 3, dxj = tap % 3;
-#pragma unroll
-                for (int fn = 0; fn < 2; ++fn) {
-                    const bf16* b0 = patch + ((2 * kc + dyi) * W2_PW + 4 * g + q + dxj) * W2_PS + wn * 32 + fn * 16 + p4;
+                {
+                    const int pi = 4 * g + q;                   // pixel of the slab's first half this lane addresses
+                    const bf16* b0 = patch + ((RPS * kc + pi / W2_TW + dyi) * W2_PW + pi % W2_TW + dxj) * W2_PS + wave * 16 + p4;
                     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)b0);
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(b0 + W2_PW * W2_PS));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(b0 + (16 / W2_TW) * W2_PW * W2_PS));
                     bf16x8 bfr;
                     bfr[0] = lo[0]; bfr[1] = lo[1]; bfr[2] = lo[2]; bfr[3] = lo[3];
                     bfr[4] = hi[0]; bfr[5] = hi[1]; bfr[6] = hi[2]; bfr[7] = hi[3];
-                    acc[tap][0][fn] = mma16(af[0], bfr, acc[tap][0][fn]);
-                    acc[tap][1][fn] = mma16(af[1], bfr, acc[tap][1][fn]);
+#pragma unroll
+                    for (int fm = 0; fm < 4; ++fm) acc[tap][fm] = mma16(af[fm], bfr, acc[tap][fm]);
                 }
             }
         }
         __syncthreads();
-        if (has_next) store_tile();
-        __syncthreads();
+        if constexpr (OCC == 1) {
+            if (has_next) store_tile();
+            __syncthreads();
+        }
     }
 
     float* out = a.slab + (long)blockIdx.x * COUT * KTOT;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-        for (int fm = 0; fm < 2; ++fm)
+        for (int fm = 0; fm < 4; ++fm)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = ch * 64 + wm * 32 + fm * 16 + (lane >> 4) * 4 + r;
-#pragma unroll
-                for (int fn = 0; fn < 2; ++fn) {
-                    const int ci = cs * 64 + wn * 32 + fn * 16 + (lane & 15);
-                    out[(long)co * KTOT + tap * CIN + ci] = acc[tap][fm][fn][r];
-                }
+                const int co = ch * 64 + fm * 16 + (lane >> 4) * 4 + r;
+                const int ci = cs * 64 + wave * 16 + (lane & 15);
+                out[(long)co * KTOT + tap * CIN + ci] = acc[tap][fm][r];
             }
     if (do_db) {
         // threads with equal tid % 8 own the same 8 output channels
@@ -853,10 +863,20 @@ int mk_conv3x3(const ConvArgs& a, hipStream_t s) {
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     auto grid = [&](int TH) { return dim3((a.W + 15) / 16, (a.H + TH - 1) / TH, a.B); };
+    // 8-wide tiles when they cover the width with fewer padded columns than 16-wide ones (e.g. W = 40: 40 vs 48)
+    static const bool allow_narrow = !getenv("MASR_CONV_NO_TW8");
+    const bool narrow = allow_narrow && (a.W + 7) / 8 * 8 < (a.W + 15) / 16 * 16;
     if (a.x1) {
         if (!(a.CIN == 64 && a.COUT == 64) || !a.w1_slab || !a.mask) { mk_set_error("mk_conv3x3", "fused conv1 wgrad needs the 64->64 dgrad with a mask"); return -1; }
         hipLaunchKernelGGL((conv3x3_patch_kernel<64, 64, 16, true>), grid(16), dim3(256), 0, s, a);
     } else if (a.CIN == 64 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<64, 64, 16>), grid(16), dim3(256), 0, s, a);
+    else if (narrow) {                                     // same pixels per workgroup, tile 8 columns wide and twice as tall
+        auto grid8 = [&](int TH) { return dim3((a.W + 7) / 8, (a.H + TH - 1) / TH, a.B); };
+        if (a.CIN == 64 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<64, 128, 16, false, 8>), grid8(16), dim3(256), 0, s, a);
+        else if (a.CIN == 128 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 128, 16, false, 8>), grid8(16), dim3(256), 0, s, a);
+        else if (a.CIN == 128 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 64, 16, false, 8>), grid8(16), dim3(256), 0, s, a);
+        else { mk_set_error("mk_conv3x3", "unsupported channel counts"); return -1; }
+    }
     else if (a.CIN == 64 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<64, 128, 8>), grid(8), dim3(256), 0, s, a);
     else if (a.CIN == 128 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 128, 8>), grid(8), dim3(256), 0, s, a);
     else if (a.CIN == 128 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 64, 16>), grid(16), dim3(256), 0, s, a);
@@ -886,20 +906,25 @@ int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s) {
         else if (a.CIN == 128 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_wgrad_kernel<128, 128>), grid, dim3(256), 0, s, a, pps);
         else { mk_set_error("mk_conv3x3_wgrad", "unsupported channel counts"); return -1; }
     } else {
-        const int tiles_x = (a.W + W2_TW - 1) / W2_TW, tiles_y = (a.H + W2_TH - 1) / W2_TH;
+        static const bool allow_narrow = getenv("MASR_WGRAD_TW8") != nullptr;
+        const bool narrow = allow_narrow && (a.W + 7) / 8 * 8 < (a.W + 15) / 16 * 16;
+        const int tw = narrow ? 8 : 16, th = 128 / tw;
+        const int tiles_x = (a.W + tw - 1) / tw, tiles_y = (a.H + th - 1) / th;
         const int ntiles = tiles_x * tiles_y * a.B;
         int nwg = wgrad2_nwg(a.CIN, a.COUT);
         if (nwg > ntiles) nwg = ntiles;
         splits = nwg;
         dim3 grid(nwg, (a.CIN / 64) * (a.COUT / 64));
-        static const int occ = getenv("MASR_WGRAD_OCC") ? atoi(getenv("MASR_WGRAD_OCC")) : 1;
+        static const int occ = getenv("MASR_WGRAD_OCC") ? atoi(getenv("MASR_WGRAD_OCC")) : 2;
+#define W2T(CI, CO, OC, TWV) hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CI, CO, OC, TWV>), grid, dim3(256), 0, s, a, nwg, ntiles, tiles_x, tiles_y)
 #define W2(CI, CO) \
-        if (occ == 1) hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CI, CO, 1>), grid, dim3(256), 0, s, a, nwg, ntiles, tiles_x, tiles_y); \
-        else hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CI, CO, 2>), grid, dim3(256), 0, s, a, nwg, ntiles, tiles_x, tiles_y);
+        if (occ == 1) { if (narrow) W2T(CI, CO, 1, 8); else W2T(CI, CO, 1, 16); } \
+        else { if (narrow) W2T(CI, CO, 2, 8); else W2T(CI, CO, 2, 16); }
         if (a.CIN == 64 && a.COUT == 64) { W2(64, 64) }
         else if (a.CIN == 64 && a.COUT == 128) { W2(64, 128) }
         else if (a.CIN == 128 && a.COUT == 128) { W2(128, 128) }
         else { mk_set_error("mk_conv3x3_wgrad", "unsupported channel counts"); return -1; }
+#undef W2T
 #undef W2
     }
     const int n = a.COUT * 9 * a.CIN + a.COUT;

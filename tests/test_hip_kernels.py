@@ -71,7 +71,9 @@ def test_gemm_exact_integers(L):
     assert torch.equal(Cc, B.float().t())       # A^T = I, B given as [k][n]
 
 
-@pytest.mark.parametrize("B_,H,W,CIN,COUT", [(2, 10, 9, 64, 64), (1, 33, 21, 64, 128), (3, 16, 20, 128, 128), (2, 7, 5, 128, 64)])
+# widths 9 / 21 / 20 / 5 take the 8-pixel-wide tiles, 48 / 32 / 16 / 80 the 16-wide ones
+@pytest.mark.parametrize("B_,H,W,CIN,COUT", [(2, 10, 9, 64, 64), (1, 33, 21, 64, 128), (3, 16, 20, 128, 128), (2, 7, 5, 128, 64),
+                                             (1, 12, 48, 128, 128), (1, 9, 32, 64, 128), (1, 20, 16, 128, 64), (1, 19, 80, 64, 64)])
 def test_conv3x3(L, B_, H, W, CIN, COUT):
     g = torch.Generator(device="cuda").manual_seed(CIN + COUT + H)
     x = torch.randn(B_, H, W, CIN, device="cuda", generator=g).bfloat16()           # NHWC
@@ -84,7 +86,7 @@ def test_conv3x3(L, B_, H, W, CIN, COUT):
     torch.testing.assert_close(out.float(), ref, rtol=1e-2, atol=1e-2)              # bf16 output rounding
 
 
-@pytest.mark.parametrize("B_,H,W,CIN,COUT", [(2, 10, 9, 64, 64), (1, 33, 21, 64, 128), (2, 40, 20, 128, 128)])
+@pytest.mark.parametrize("B_,H,W,CIN,COUT", [(2, 10, 9, 64, 64), (1, 33, 21, 64, 128), (2, 40, 20, 128, 128), (1, 21, 48, 128, 128), (1, 17, 80, 64, 64)])
 def test_conv3x3_wgrad(L, B_, H, W, CIN, COUT):
     g = torch.Generator(device="cuda").manual_seed(CIN + COUT + H + 1)
     x = torch.randn(B_, H, W, CIN, device="cuda", generator=g).bfloat16()
