@@ -92,11 +92,11 @@ struct StagerRM {
     // running column sums of the staged tile (each thread always owns the same 8 rows: 256 % RC == 0)
     __device__ __forceinline__ void accumulate(float (&acc)[8]) {
 #pragma unroll
-        for (int i = 0; i < PT; ++i)
-            if ((ok >> i) & 1) {
+        for (int i = 0; i < PT; ++i) {
+            const float m = (ok >> i) & 1 ? 1.f : 0.f;             // branch-free (a divergent branch here costs exec-mask juggling per chunk)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += (float)regs[i][j];
-            }
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(m, (float)regs[i][j], acc[j]);
+        }
     }
 };
 
@@ -231,7 +231,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 
     // register ring of DEPTH k-tiles: global loads run DEPTH tiles ahead of the MFMAs (a lone workgroup on a CU has
     // nothing else to hide the L2/HBM latency with -- this is what the small-M decoder GEMMs are made of)
-    constexpr int DEPTH = 2;
+    constexpr int DEPTH = RM ? 4 : 2;                          // weight-gradient form: one workgroup per CU and 16+ k-tiles -> deeper ring
     SA sa[DEPTH]; SB sb[DEPTH];
     f32x4 acc[FM][FN];
 #pragma unroll
@@ -268,7 +268,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
         for (int u = 0; u < DEPTH; ++u) {
             const int kt = kt0 + u;
             if (kt >= nk) break;
-            const int cur = kt & 1;
+            static_assert(DEPTH % 2 == 0, "kt0 is a multiple of DEPTH: the LDS buffer parity must be static");
+            const int cur = u & 1;                     // == kt & 1, but a compile-time constant (fragment addresses fold to immediates)
             // tile kt already sits in LDS, so ring slot u is free: refill it with tile kt + DEPTH
             sa[u].load(g.A, g.lda, m0, kbeg + (kt + DEPTH) * BK, g.M, kend, tid);
             sb[u].load(g.B, g.ldb, n0, kbeg + (kt + DEPTH) * BK, g.N, kend, tid);
