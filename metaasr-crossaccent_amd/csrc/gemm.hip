@@ -231,7 +231,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 
     // register ring of DEPTH k-tiles: global loads run DEPTH tiles ahead of the MFMAs (a lone workgroup on a CU has
     // nothing else to hide the L2/HBM latency with -- this is what the small-M decoder GEMMs are made of)
-    constexpr int DEPTH = RM ? 4 : 2;                          // weight-gradient form: one workgroup per CU and 16+ k-tiles -> deeper ring
+    constexpr int DEPTH = 2;
     SA sa[DEPTH]; SB sb[DEPTH];
     f32x4 acc[FM][FN];
 #pragma unroll
