@@ -78,7 +78,12 @@ int masr_clip_accumulate(masr_model* m, float* updates, float max_norm, void* st
 
 /* flat helpers on arbitrary device buffers */
 int masr_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                   float beta1, float beta2, float eps, int step, void* stream);      /* torch.optim.Adam, optimizer.py:19-21 */
+                   float beta1, float beta2, float eps, int step, void* stream);
+/* torch.optim.AdamW (decoupled != 0: p *= 1 - lr*weight_decay, then the Adam update) or torch.optim.Adam with its L2
+ * weight_decay (decoupled == 0: g += weight_decay*p) -- config/transformer/adapt/hkust-adamw.yaml through
+ * getattr(torch.optim, cls) (src/transformer_torch_trainer.py:44-46) */
+int masr_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int decoupled, int step, void* stream);      /* torch.optim.Adam, optimizer.py:19-21 */
 int masr_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr, float momentum,
                   int nesterov, int first_step, void* stream);
 int masr_scale(float* x, int64_t n, float a, void* stream);                           /* _updates /= counter (:201-202) */

@@ -795,7 +795,11 @@ int masr_clip_accumulate(masr_model* m, float* updates, float max_norm, void* st
     return mk_clip_axpy(updates, m->G, m->nparams, m->stats + 3, max_norm, (hipStream_t)stream);
 }
 int masr_adam_step(float* p, const float* g, float* ea, float* eas, int64_t n, float lr, float b1, float b2, float eps, int step, void* stream) {
-    return mk_adam(p, g, ea, eas, n, lr, b1, b2, eps, step, (hipStream_t)stream);
+    return mk_adam(p, g, ea, eas, n, lr, b1, b2, eps, step, 0.f, 0, (hipStream_t)stream);
+}
+int masr_adamw_step(float* p, const float* g, float* ea, float* eas, int64_t n, float lr, float b1, float b2, float eps, float weight_decay,
+                    int decoupled, int step, void* stream) {
+    return mk_adam(p, g, ea, eas, n, lr, b1, b2, eps, step, weight_decay, decoupled, (hipStream_t)stream);
 }
 int masr_sgd_step(float* p, const float* g, float* mom, int64_t n, float lr, float momentum, int nesterov, int first_step, void* stream) {
     return mk_clip_sgd(p, g, mom, n, nullptr, 0.f, lr, momentum, nesterov, first_step, (hipStream_t)stream);

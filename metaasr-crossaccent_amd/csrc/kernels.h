@@ -139,7 +139,9 @@ int mk_clip_sgd(float* p, const float* g, float* mom, long n, const float* norm,
 int mk_clip_scale(float* g, long n, const float* norm, float max_norm, hipStream_t s);    // g *= coef
 int mk_clip_axpy(float* acc, const float* g, long n, const float* norm, float max_norm, hipStream_t s); // acc += coef*g
 int mk_scale(float* x, long n, float a, hipStream_t s);
-int mk_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int t, hipStream_t s);
+// weight_decay: decoupled != 0 -> AdamW (p *= 1 - lr*wd first), else torch.optim.Adam's L2 term (g += wd*p); 0 = plain Adam
+int mk_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int t, float weight_decay,
+            int decoupled, hipStream_t s);
 int mk_axpy(float* y, const float* x, long n, float a, hipStream_t s);
 int mk_cast_bf16(const float* x, bf16* y, long n, hipStream_t s);
 int mk_transpose_cast_bf16(const float* x /*[R][C]*/, bf16* y /*[C][ldy]*/, int R, int C, long ldy, hipStream_t s);

@@ -92,15 +92,18 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
 }
 // torch.optim.Adam (no amsgrad, no weight decay): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= lr/(1-b1^t) * m/denom
+// decay_mul = 1 - lr * weight_decay (AdamW: decoupled, applied to the weight first, as torch.optim.AdamW) or 1;
+// l2 = weight_decay of torch.optim.Adam (added to the gradient) or 0
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            long n, float step_size, float b1, float b2, float eps, float inv_sqrt_bc2) {
+                            long n, float step_size, float b1, float b2, float eps, float inv_sqrt_bc2, float decay_mul, float l2) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float gi = g[i];
+        const float pi = p[i] * decay_mul;
+        const float gi = g[i] + l2 * pi;
         const float mi = m[i] + (gi - m[i]) * (1.f - b1);        // lerp, as torch
         const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
         m[i] = mi; v[i] = vi;
-        p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+        p[i] = pi - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
     }
 }
 __global__ void cast_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, long n) {
@@ -223,10 +226,10 @@ int mk_axpy(float* y, const float* x, long n, float a, hipStream_t s) {
     hipLaunchKernelGGL(axpy_kernel, dim3(flat_blocks(n)), dim3(256), 0, s, y, x, n, a);
     return LAUNCH_OK();
 }
-int mk_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int t, hipStream_t s) {
+int mk_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int t, float weight_decay, int decoupled, hipStream_t s) {
     const double bc1 = 1.0 - pow((double)b1, t), bc2 = 1.0 - pow((double)b2, t);
     hipLaunchKernelGGL(adam_kernel, dim3(flat_blocks(n)), dim3(256), 0, s, p, g, m, v, n, (float)(lr / bc1), b1, b2, eps,
-                       (float)(1.0 / sqrt(bc2)));
+                       (float)(1.0 / sqrt(bc2)), decoupled ? 1.f - lr * weight_decay : 1.f, decoupled ? 0.f : weight_decay);
     return LAUNCH_OK();
 }
 int mk_cast_bf16(const float* x, bf16* y, long n, hipStream_t s) {

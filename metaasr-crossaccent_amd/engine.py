@@ -196,8 +196,12 @@ class MasrEngine:
     def grad_norm(self):
         check(self._l.masr_grad_norm(self.h, self.stream()), "masr_grad_norm")
 
-    def adam_step(self, params, grads, m, v, lr, b1, b2, eps, step):
-        check(self._l.masr_adam_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, b1, b2, eps, step, self.stream()), "masr_adam_step")
+    def adam_step(self, params, grads, m, v, lr, b1, b2, eps, step, weight_decay=0.0, decoupled=False):
+        if weight_decay:
+            check(self._l.masr_adamw_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, b1, b2, eps, weight_decay,
+                                          int(decoupled), step, self.stream()), "masr_adamw_step")
+        else:
+            check(self._l.masr_adam_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, b1, b2, eps, step, self.stream()), "masr_adam_step")
 
     def sgd_step(self, params, grads, mom, lr, momentum, nesterov, first_step):
         check(self._l.masr_sgd_step(_ptr(params), _ptr(grads), _ptr(mom), params.numel(), lr, momentum, int(nesterov), int(first_step), self.stream()), "masr_sgd_step")

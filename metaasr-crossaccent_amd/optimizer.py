@@ -8,9 +8,10 @@ import torch
 
 
 class FlatAdam:
-    def __init__(self, engine, params_flat, betas=(0.9, 0.98), eps=1e-9, lr=1e-3):
+    def __init__(self, engine, params_flat, betas=(0.9, 0.98), eps=1e-9, lr=1e-3, weight_decay=0.0, decoupled=False):
         self.engine, self.params = engine, params_flat
         self.betas, self.eps = betas, eps
+        self.weight_decay, self.decoupled = weight_decay, decoupled      # decoupled = torch.optim.AdamW, else Adam's L2 term
         self.param_groups = [{'lr': lr}]
         self.exp_avg = torch.zeros_like(params_flat)
         self.exp_avg_sq = torch.zeros_like(params_flat)
@@ -24,7 +25,7 @@ class FlatAdam:
         assert self.grad is not None, "FlatAdam.step(): no gradient attached"
         self.t += 1
         self.engine.adam_step(self.params, self.grad, self.exp_avg, self.exp_avg_sq, self.param_groups[0]['lr'],
-                              self.betas[0], self.betas[1], self.eps, self.t)
+                              self.betas[0], self.betas[1], self.eps, self.t, self.weight_decay, self.decoupled)
         if self.params.data_ptr() == self.engine.params.data_ptr():
             self.engine.mark_dirty()
 

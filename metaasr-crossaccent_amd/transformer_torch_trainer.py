@@ -32,11 +32,12 @@ def get_trainer(cls, config, paras, id2accent):
                     o = mp['optimizer_opt']
                     self.asr_opt = FlatSGD(eng, o['lr'], o.get('momentum', 0.0), o.get('nesterov', False))
                 elif cls_name in ('Adam', 'AdamW'):
-                    o = mp['optimizer_opt']
-                    if cls_name == 'AdamW' or o.get('weight_decay', 0):
-                        raise NotImplementedError("weight decay is not built into the flat Adam kernel yet")
-                    opt = FlatAdam(eng, eng.params, betas=tuple(o.get('betas', (0.9, 0.999))), eps=o.get('eps', 1e-8), lr=o.get('lr', 1e-3))
-                    self.asr_opt = opt
+                    o = mp['optimizer_opt']                                  # torch defaults: Adam wd 0 (L2), AdamW wd 1e-2 (decoupled)
+                    if o.get('amsgrad', False):
+                        raise NotImplementedError("amsgrad")
+                    wd = o.get('weight_decay', 1e-2 if cls_name == 'AdamW' else 0.0)
+                    self.asr_opt = FlatAdam(eng, eng.params, betas=tuple(o.get('betas', (0.9, 0.999))), eps=o.get('eps', 1e-8),
+                                            lr=o.get('lr', 1e-3), weight_decay=wd, decoupled=(cls_name == 'AdamW'))
                 else:
                     raise NotImplementedError(f"optimizer_cls {cls_name} (reference: getattr(torch.optim, cls) / torch_optimizer.RAdam)")
             else:

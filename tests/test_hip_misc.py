@@ -102,6 +102,18 @@ def test_flat_adam_and_sgd_match_oracle():
         eng.sgd_step(q, gr.cuda(), buf, 0.05, 0.9, True, first_step=(t == 0))
         ref_cpu.sgd_nesterov_step(rq, {"w": gr}, rb, 0.05, 0.9, True)
     torch.testing.assert_close(q.cpu(), rq["w"], rtol=2e-6, atol=2e-7)
+    # AdamW (config/transformer/adapt/hkust-adamw.yaml: getattr(torch.optim, 'AdamW')(lr=0.00028)) and Adam with an L2 term,
+    # against torch.optim itself on the CPU
+    for decoupled, cls in ((True, torch.optim.AdamW), (False, torch.optim.Adam)):
+        w = torch.nn.Parameter(p0.clone())
+        opt = cls([w], lr=2.8e-4, weight_decay=1e-2)
+        p, m, v = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        for t in range(1, 5):
+            gr = torch.randn(n, generator=g)
+            w.grad = gr.clone()
+            opt.step()
+            eng.adam_step(p, gr.cuda(), m, v, 2.8e-4, 0.9, 0.999, 1e-8, t, weight_decay=1e-2, decoupled=decoupled)
+        torch.testing.assert_close(p.cpu(), w.detach(), rtol=2e-6, atol=2e-7)
 
 
 def _common(tmp_path, extra_model):

@@ -55,7 +55,8 @@ class FakeEngine:
             buf.mul_(momentum).add_(g)
         self.params.sub_(lr * (g + momentum * buf if nesterov else buf))
 
-    def adam_step(self, p, g, m, v, lr, b1, b2, eps, t):
+    def adam_step(self, p, g, m, v, lr, b1, b2, eps, t, weight_decay=0.0, decoupled=False):
+        assert weight_decay == 0.0
         m.mul_(b1).add_(g, alpha=1 - b1)
         v.mul_(b2).addcmul_(g, g, value=1 - b2)
         p.addcdiv_(m, (v.sqrt() / math.sqrt(1 - b2 ** t)).add_(eps), value=-lr / (1 - b1 ** t))
