@@ -170,6 +170,10 @@ class MonoASRInterface(TrainInterface):
             freeze = self.config['solver'].get('freeze_module')
             if freeze:
                 # requires_grad = False in the reference == a 0/1 mask on the flat gradient here
+                inner = self.asr_opt.optimizer if isinstance(self.asr_opt, TransformerOptimizer) else self.asr_opt
+                if getattr(inner, 'weight_decay', 0.0):
+                    # torch skips parameters without a gradient entirely (no decay either); the flat pass would decay them
+                    raise NotImplementedError("frozen modules together with weight decay")
                 self.frozen_mask = torch.ones_like(eng.params)
                 for n in eng.table:
                     if n.split('.')[0] in freeze:
