@@ -368,6 +368,28 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
             }
         }
     __syncthreads();
+    if (a.pool_out) {
+        // fused MaxPool2d(2, 2) (floor): the ReLU'd tile is in LDS, tile origin and size are even -> each pooled pixel's
+        // 2 x 2 window lies inside this tile; saves the separate pool launch and its re-read of the full-resolution map
+        const int H2 = H / 2, W2 = W / 2;
+        constexpr int NPOOL = (TH / 2) * (TW / 2) * (COUT / 8);
+#pragma unroll
+        for (int i = 0; i < (NPOOL + 255) / 256; ++i) {
+            const int c = tid + i * 256;
+            const int pp = c / (COUT / 8), ch = (c % (COUT / 8)) * 8;
+            const int pr = pp / (TW / 2), pc = pp % (TW / 2);
+            const int t2 = t0 / 2 + pr, d2 = d0 / 2 + pc;
+            if (c < NPOOL && t2 < H2 && d2 < W2) {
+                const bf16* o00 = otile + ((2 * pr) * TW + 2 * pc) * OS + ch;
+                const bf16x8 v00 = ld8(o00), v01 = ld8(o00 + OS), v10 = ld8(o00 + TW * OS), v11 = ld8(o00 + TW * OS + OS);
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    o[j] = (bf16)fmaxf(fmaxf((float)v00[j], (float)v01[j]), fmaxf((float)v10[j], (float)v11[j]));
+                st8(a.pool_out + (((long)b * H2 + t2) * W2 + d2) * COUT + ch, o);
+            }
+        }
+    }
     bf16* out_b = a.out + (long)b * H * W * COUT;
     const bf16* mask_b = a.mask ? a.mask + (long)b * H * W * COUT : nullptr;
     constexpr int NOCH = TH * TW * (COUT / 8) / 256;
@@ -860,6 +882,7 @@ int mk_conv3x3(const ConvArgs& a, hipStream_t s) {
         else if (a.CIN == 128 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_kernel<128, 128>), grid, dim3(256), 0, s, a);
         else if (a.CIN == 128 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_kernel<128, 64>), grid, dim3(256), 0, s, a);
         else { mk_set_error("mk_conv3x3", "unsupported channel counts"); return -1; }
+        if (a.pool_out && mk_maxpool_fwd(a.out, a.pool_out, a.B, a.H, a.W, a.COUT, s)) return -1;     // (no fused pool in v1)
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     auto grid = [&](int TH) { return dim3((a.W + 15) / 16, (a.H + TH - 1) / TH, a.B); };

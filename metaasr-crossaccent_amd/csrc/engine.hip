@@ -523,17 +523,18 @@ static int forward_encoder(Ctx& c, const float* xs) {
         Prof p(m, MASR_PROF_CONV_FWD, s);
         CK(mk_conv1_fwd(xs, P + m->conv[0].w, P + m->conv[0].b, a.a1, B, T, D, s));
     }
-    auto conv = [&](const bf16* in, const Conv& cv, bf16* out, int H, int W) -> int {
+    static const bool fuse_pool = !getenv("MASR_NO_FUSED_POOL");      // MaxPool2d written by the producing conv's epilogue
+    auto conv = [&](const bf16* in, const Conv& cv, bf16* out, int H, int W, bf16* pooled) -> int {
         Prof p(m, &cv == &m->conv[1] ? MASR_PROF_CONV2_FWD : MASR_PROF_CONV_FWD, s);
         ConvArgs ca{}; ca.in = in; ca.wk = cv.k16; ca.bias = P + cv.b; ca.relu = 1; ca.mask = nullptr; ca.out = out;
-        ca.B = B; ca.H = H; ca.W = W; ca.CIN = cv.CI; ca.COUT = cv.CO;
+        ca.B = B; ca.H = H; ca.W = W; ca.CIN = cv.CI; ca.COUT = cv.CO; ca.pool_out = fuse_pool ? pooled : nullptr;
         return mk_conv3x3(ca, s);
     };
-    CK(conv(a.a1, m->conv[1], a.a2, T, D));
-    { Prof p(m, MASR_PROF_OTHER, s); CK(mk_maxpool_fwd(a.a2, a.p1, B, T, D, 64, s)); }
-    CK(conv(a.p1, m->conv[2], a.a3, a.H2, a.W2));
-    CK(conv(a.a3, m->conv[3], a.a4, a.H2, a.W2));
-    { Prof p(m, MASR_PROF_OTHER, s); CK(mk_maxpool_fwd(a.a4, a.p2, B, a.H2, a.W2, 128, s)); }
+    CK(conv(a.a1, m->conv[1], a.a2, T, D, a.p1));
+    if (!fuse_pool) { Prof p(m, MASR_PROF_OTHER, s); CK(mk_maxpool_fwd(a.a2, a.p1, B, T, D, 64, s)); }
+    CK(conv(a.p1, m->conv[2], a.a3, a.H2, a.W2, nullptr));
+    CK(conv(a.a3, m->conv[3], a.a4, a.H2, a.W2, a.p2));
+    if (!fuse_pool) { Prof p(m, MASR_PROF_OTHER, s); CK(mk_maxpool_fwd(a.a4, a.p2, B, a.H2, a.W2, 128, s)); }
     // vgg2enc + positional encoding + pos dropout
     {
         GemmArgs g = lin_fwd_args(a.p2, m->F, m->v2e_k, a.rows_e, E, m->F, P + m->v2e.b);
