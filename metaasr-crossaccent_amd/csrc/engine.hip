@@ -167,7 +167,8 @@ void plan_acts(const masr_model* m, Arena& ar, Acts& a, int B, int T, int L, boo
     a.B = B; a.T = T; a.D = m->D; a.H2 = T / 2; a.W2 = m->D / 2; a.Tp = a.H2 / 2; a.Dp = a.W2 / 2; a.L = L;
     a.rows_e = B * a.Tp; a.rows_d = B * L;
     const int64_t re = a.rows_e, rd = a.rows_d;
-    a.tok_in = ar.get<int>(rd); a.gold = ar.get<int>(rd); a.enc_lens = ar.get<int>(B); a.step_dev = ar.get<int>(4);
+    a.tok_in = ar.get<int>(2 * rd + B); a.gold = a.tok_in + rd; a.enc_lens = a.gold + rd;   // one block: one H2D copy per step
+    a.step_dev = ar.get<int>(4);
     a.step_qkv = ar.get<bf16>((int64_t)B * 3 * E);
     const int64_t P1 = (int64_t)B * T * m->D, P2 = (int64_t)B * a.H2 * a.W2;
     a.a1 = ar.get<bf16>(P1 * 64); a.a2 = ar.get<bf16>(P1 * 64); a.p1 = ar.get<bf16>(P2 * 64);
@@ -493,6 +494,9 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
         HIP_CHECK_RET(hipMemcpy(m->d_sdesc, desc.data(), sizeof(ShadowDesc) * desc.size(), hipMemcpyHostToDevice));
         HIP_CHECK_RET(hipMemcpy(m->d_sptrs, ptrs.data(), sizeof(bf16*) * ptrs.size(), hipMemcpyHostToDevice));
     }
+    // pads of the char_trans shadows must be zero (rows/cols >= odim); the refresh kernels only write the odim part
+    HIP_CHECK_RET(hipMemset(m->ct.k16, 0, sizeof(bf16) * (size_t)m->Cp * m->E));
+    HIP_CHECK_RET(hipMemset(m->ct.t16, 0, sizeof(bf16) * (size_t)m->E * m->Cp));
     m->have_acts = false;
     return 0;
 }
@@ -504,9 +508,7 @@ int masr_refresh(masr_model* m, void* stream) {
     if (!m->P) { mk_set_error("masr_refresh", "not bound"); return -1; }
     Prof p(m, MASR_PROF_OTHER, s);
     const float* P = m->P;
-    // pads of the char_trans shadows must be zero (rows/cols >= odim)
-    HIP_CHECK_RET(hipMemsetAsync(m->ct.k16, 0, sizeof(bf16) * (size_t)m->Cp * m->E, s));
-    HIP_CHECK_RET(hipMemsetAsync(m->ct.t16, 0, sizeof(bf16) * (size_t)m->E * m->Cp, s));
+    // (the pads of the char_trans shadows -- rows / columns >= odim -- are zeroed once in masr_bind and never written)
     for (int i = 1; i < 4; ++i) CK(mk_conv_weight_shadows(P + m->conv[i].w, m->conv[i].k16, m->conv[i].d16, m->conv[i].CO, m->conv[i].CI, s));
     CK(mk_vgg2enc_shadows(P + m->v2e.w, m->v2e_k, m->v2e.t16, m->E, 128, m->Dp, s));
     CK(mk_cast_bf16(P + m->ct.w, m->ct.k16, (long)m->C * m->E, s));
@@ -739,9 +741,7 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
         h_len[b] = (int)(ilens[b] / 4);                             // enc_lens = floor(ilens/4) (:117)
         if (h_len[b] < 1 || ilens[b] > T) { mk_set_error("masr_run_batch", "ilens must be in [4, T]"); return -1; }
     }
-    HIP_CHECK_RET(hipMemcpyAsync(a.tok_in, h_in, sizeof(int) * (size_t)B * L, hipMemcpyHostToDevice, s));
-    HIP_CHECK_RET(hipMemcpyAsync(a.gold, h_out, sizeof(int) * (size_t)B * L, hipMemcpyHostToDevice, s));
-    HIP_CHECK_RET(hipMemcpyAsync(a.enc_lens, h_len, sizeof(int) * (size_t)B, hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipMemcpyAsync(a.tok_in, h, sizeof(int) * ((size_t)2 * B * L + B), hipMemcpyHostToDevice, s));   // tok_in | gold | enc_lens
     HIP_CHECK_RET(hipEventRecord(m->stage_ev[slot], s));
 
     Ctx c{m, s, (uint32_t)(m->seed * 0x9E3779B97F4A7C15ull >> 32) + (uint32_t)m->step * 7919u, train,
