@@ -43,7 +43,8 @@ def test_gemm_nt(L, M, N, K):
     assert torch.all(Cc[:, N:] == 7.0)          # no write outside the N columns
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (128, 256, 1000), (367, 512, 500), (1536, 512, 4000), (8, 16, 5)])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (128, 256, 1000), (367, 512, 500), (1536, 512, 4000), (8, 16, 5),
+                                   (2048, 2048, 1000), (2000, 1800, 777), (2048, 1536, 64)])     # the last three take the LDS-DMA 128x128 kernel
 def test_gemm_reduction_major(L, M, N, K):
     """wgrad form: C[m][n] = sum_k A[k][m] B[k][n] (transposing LDS reads)."""
     g = torch.Generator(device="cuda").manual_seed(M * 3 + N + K)

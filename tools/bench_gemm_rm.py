@@ -8,7 +8,7 @@ from masr_amd import _cabi
 L = _cabi.lib()
 P = lambda t: C.c_void_p(t.data_ptr())
 S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
-for (M, N, K) in [(2048, 2048, 1024)]:
+for (M, N, K) in [(2048, 2048, 1024), (2048, 2048, 4000), (4096, 4096, 4096)]:
     A = torch.randn(K, M, device="cuda").bfloat16(); B = torch.randn(K, N, device="cuda").bfloat16()
     Cc = torch.zeros(M, N, device="cuda")
     for _ in range(3):
