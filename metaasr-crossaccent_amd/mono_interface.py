@@ -187,9 +187,11 @@ class MonoASRInterface(TrainInterface):
         eng = self.asr_model.engine
         self.evaluate()
         try:
+            if self.save_verbose:                                            # save_init (:124-127)
+                torch.save(self._sd_cpu(), self.log_dir.joinpath("snapshot.init"))
             while self.ep < self.max_epoch:
-                for x, ilens, ys, olens in self.train_set:
-                    info = self._train(self.global_step, x, ilens, ys, olens)
+                for cur_b, (x, ilens, ys, olens) in enumerate(self.train_set):
+                    info = self._train(cur_b, x, ilens, ys, olens)
                     self.train_info.add(info, len(ys))
                     if self.frozen_mask is not None:
                         eng.grads.mul_(self.frozen_mask)
@@ -204,6 +206,8 @@ class MonoASRInterface(TrainInterface):
                     self.dashboard.step()
                 self.ep += 1
                 self.save_per_epoch()
+                if getattr(self.paras, 'eval_every_epoch', False):           # train.py --eval_every_epoch (:169-170)
+                    self.evaluate()
         except KeyboardInterrupt:
             logger.warning("Training stopped")
             self.evaluate()

@@ -378,6 +378,131 @@ def gen_fomaml_goldens():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def _toy_workspace(tmp):
+    (tmp / "data").mkdir()
+    for f in ("accent-code.json", "valid_train_en_unigram150.model", "valid_train_en_unigram150_units.txt"):
+        shutil.copy(REF / "data" / f, tmp / "data" / f)     # runtime copy only, temp dir
+    for ai, a in enumerate(["african", "australia"]):
+        write_toy_shard(tmp / "data", a, "train", 16, seed=100 + ai)
+        write_toy_shard(tmp / "data", a, "dev", 4, seed=200 + ai)
+    return {"setting": "gold", "data_root": "data", "total_steps": 10, "total_epochs": 2,
+            "spm_mapping": "data/valid_train_en_unigram150_units.txt", "spm_model": "data/valid_train_en_unigram150.model",
+            "label_smoothing": 0.2, "eval_ival": 3, "log_ival": 1, "save_ival": 3, "batch_size": 4, "dev_batch_size": 4,
+            "min_ilen": 10, "max_ilen": 50, "dev_max_ilen": 3000, "half_batch_ilen": 30}
+
+
+def _record_calls(solver):
+    rec = []
+    orig = solver.run_batch
+    def spy(idx, x, ilens, ys, olens, train, accent_idx=None):
+        info = orig(idx, x, ilens.clone(), [y.clone() for y in ys], olens.clone(), train=train, accent_idx=accent_idx)
+        rec.append((int(idx), x.numpy().copy(), ilens.numpy().copy(), [y.numpy().copy() for y in ys], olens.numpy().copy(), dict(info)))
+        return info
+    from functools import partial
+    solver._train = partial(spy, train=True)
+    return rec
+
+
+def _dump_calls(out, rec):
+    out["n_calls"] = np.int64(len(rec))
+    for i, (idx, x, il, ys, ol, info) in enumerate(rec):
+        out[f"call{i}/accent"] = np.int64(idx)
+        out[f"call{i}/ilens"] = il
+        out[f"call{i}/x_fp"] = flat_checks(torch.from_numpy(x))
+        out[f"call{i}/ys"] = np.concatenate(ys)
+        out[f"call{i}/loss"] = np.float64(info["loss"])
+        out[f"call{i}/acc"] = np.float64(info["acc"])
+
+
+def gen_multi_goldens():
+    """Reference multi-task pretraining (src/multi_interface.py:94-140) through get_trainer(MultiASRInterface...):
+    7 steps of random-accent batches, clip 5, Noam-Adam on the model itself."""
+    from src.multi_interface import MultiASRInterface
+    from src.transformer_torch_trainer import get_trainer
+    tmp = Path(tempfile.mkdtemp(prefix="masr_gold_"))
+    cwd = os.getcwd()
+    try:
+        solver_cfg = _toy_workspace(tmp)
+        model = {k: v for k, v in TINY.items() if k not in ("inner_optimizer_cls", "inner_optimizer_opt", "meta_opt_cls", "meta")}
+        model.update({"optimizer_cls": "noam", "optimizer_opt": {"k": 1.0, "warmup_steps": 20}})
+        cfg = {"asr_model": model, "solver": solver_cfg}
+        os.chdir(tmp)
+        id2accent = json.load(open("data/accent-code.json"))
+        paras = SimpleNamespace(config="x", pretrain_suffix="m", pretrain_accents=["af", "au"], num_pretrain=2, tgt_accent="ca",
+                                runs=0, overwrite=True, seed=531, no_cuda=True, no_memmap=False, no_bucket=False, meta_k=None,
+                                meta_batch_size=None, sample_strategy="normal", max_step=7, resume=False, resume_step=-1,
+                                use_tensorboard=False, model_name="transformer", algo="multi", njobs=0, cuda=False,
+                                is_bucket=True, is_memmap=True)
+        random.seed(531); np.random.seed(531); torch.manual_seed(531)
+        solver = get_trainer(MultiASRInterface, cfg, paras, id2accent)
+        solver.load_data()
+        solver.set_model()
+        sd = ref_cpu.deterministic_state_dict(cfg["asr_model"], ODIM, seed=7)
+        solver.asr_model.load_state_dict(sd)
+        solver.evaluate = lambda: None                      # (the dev pass is covered by the FOMAML golden run)
+        rec = _record_calls(solver)
+        solver.exec()
+        out = {}
+        _dump_calls(out, rec)
+        out["global_step"] = np.int64(solver.global_step)
+        out["step_num"] = np.int64(solver.asr_opt.step_num)
+        out["lr"] = np.float64(solver.asr_opt.lr)
+        for n in ("vgg2enc.bias", "decoder.norm.weight", "char_trans.bias", "encoder.layers.0.linear1.bias"):
+            out[f"param/{n}"] = solver.asr_model.state_dict()[n].detach().numpy().copy()
+        out["files"] = np.array(sorted(p.name for p in solver.log_dir.iterdir()))
+        np.savez_compressed(OUT / "multi_toy.npz", **out)
+        print("multi_toy.npz calls:", len(rec), "global_step", solver.global_step, "files:", out["files"])
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def gen_mono_goldens():
+    """Reference fine-tuning (train.py path: src/train_interface.py + src/mono_interface.py) through
+    get_trainer(MonoASRInterface...): initialised from a pretraining snapshot, feat_extractor frozen, SGD(nesterov),
+    two epochs over the toy shard."""
+    from src.mono_interface import MonoASRInterface
+    from src.transformer_torch_trainer import get_trainer
+    tmp = Path(tempfile.mkdtemp(prefix="masr_gold_"))
+    cwd = os.getcwd()
+    try:
+        solver_cfg = _toy_workspace(tmp)
+        solver_cfg.update({"eval_ival": 1000, "log_ival": 1000, "save_ival": 3, "freeze_module": ["feat_extractor"],
+                           "pretrain_module": ["encoder", "decoder", "feat_extractor", "vgg2enc", "char_trans", "pre_embed"]})
+        model = {k: v for k, v in TINY.items() if k not in ("inner_optimizer_cls", "inner_optimizer_opt", "meta_opt_cls", "meta")}
+        model.update({"optimizer_cls": "SGD", "optimizer_opt": {"lr": 0.05, "momentum": 0.9, "nesterov": True}})
+        cfg = {"asr_model": model, "solver": solver_cfg}
+        os.chdir(tmp)
+        id2accent = json.load(open("data/accent-code.json"))
+        sd = ref_cpu.deterministic_state_dict(cfg["asr_model"], ODIM, seed=7)
+        torch.save(sd, tmp / "pre.snapshot")
+        paras = SimpleNamespace(config="x", accent="af", algo="fomaml", model_name="transformer", eval_suffix="e", runs=0, overwrite=True,
+                                seed=531, resume=False, use_tensorboard=False, save_verbose=False, split_rate=1.0, freeze_layer=None,
+                                pretrain=True, pretrain_suffix="p", pretrain_setting=None, pretrain_runs=0, pretrain_step=0,
+                                pretrain_tgt_accent="ca", pretrain_model_path=str(tmp / "pre.snapshot"), njobs=0, is_bucket=True,
+                                is_memmap=True, no_cuda=True, cuda=False, test=False, eval_every_epoch=False)
+        random.seed(531); np.random.seed(531); torch.manual_seed(531)
+        solver = get_trainer(MonoASRInterface, cfg, paras, id2accent)
+        solver.load_data()
+        solver.set_model()
+        solver.evaluate = lambda: None
+        rec = _record_calls(solver)
+        solver.exec()
+        out = {}
+        _dump_calls(out, rec)
+        out["global_step"] = np.int64(solver.global_step)
+        out["ep"] = np.int64(solver.ep)
+        st = solver.asr_model.state_dict()
+        for n in ("vgg2enc.bias", "decoder.norm.weight", "char_trans.bias", "encoder.layers.0.linear1.bias", "feat_extractor.2.bias"):
+            out[f"param/{n}"] = st[n].detach().numpy().copy()
+        out["files"] = np.array(sorted(p.name for p in solver.log_dir.iterdir()))
+        np.savez_compressed(OUT / "mono_toy.npz", **out)
+        print("mono_toy.npz calls:", len(rec), "global_step", solver.global_step, "ep", solver.ep, "files:", out["files"])
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def gen_ctc_goldens():
     """nn.CTCLoss(blank=0, reduction='mean', zero_infinity=True) as called at blstm_trainer.py:22,65-70."""
     out = {}
@@ -463,6 +588,8 @@ def main():
     gen_metric_goldens()
     gen_model_goldens()
     gen_fomaml_goldens()
+    gen_multi_goldens()
+    gen_mono_goldens()
 
 
 if __name__ == "__main__":
