@@ -503,6 +503,44 @@ def gen_mono_goldens():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def gen_tester_goldens():
+    """Reference decode path (train.py --test: src/tester.py Tester.load_data/set_model/exec, greedy, batch 4) on a toy
+    test shard with the deterministic tiny model: the best-hyp file, line by line."""
+    from src.tester import Tester
+    tmp = Path(tempfile.mkdtemp(prefix="masr_gold_"))
+    cwd = os.getcwd()
+    try:
+        solver_cfg = _toy_workspace(tmp)
+        solver_cfg["beam_decode"] = {"beam_size": 1}
+        write_toy_shard(tmp / "data", "african", "test", 6, seed=300)
+        model = dict(TINY)
+        cfg = {"asr_model": model, "solver": solver_cfg}
+        os.chdir(tmp)
+        id2accent = json.load(open("data/accent-code.json"))
+        log_dir = tmp / "testing-logs" / "evaluation" / "gold" / "no" / "ev" / "ev" / "african" / "0"
+        log_dir.mkdir(parents=True)
+        (log_dir / "exp_key").write_text("stub\n")
+        sd = ref_cpu.deterministic_state_dict(model, ODIM, seed=7)
+        torch.save(sd, log_dir / "model.wer.best")
+        paras = SimpleNamespace(accent="af", algo="no", pretrain_suffix=None, eval_suffix="ev", runs=0, model_name="transformer",
+                                test_model="model.wer.best", decode_suffix="greedy_decode", decode_mode="greedy", decode_batch_size=4,
+                                cuda=False, njobs=1, resume=False, overwrite=True, is_memmap=True, lm_model_path=None)
+        t = Tester(cfg, paras, id2accent)
+        t.load_data()
+        # in-process loading (the reference hard-codes num_workers=1; a worker process adds nothing to the result)
+        from src.io.dataset import get_loader
+        t.eval_set = get_loader(t.data_dir.joinpath("test"), batch_size=4, half_batch_ilen=512, is_memmap=True, is_bucket=False,
+                                shuffle=False, num_workers=0)
+        t.set_model()
+        t.exec()
+        lines = (log_dir / "greedy_decode" / "best-hyp").read_text().splitlines()
+        np.savez_compressed(OUT / "tester_toy.npz", lines=np.array(lines))
+        print("tester_toy.npz", len(lines), "lines; first:", lines[0][:80])
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def gen_ctc_goldens():
     """nn.CTCLoss(blank=0, reduction='mean', zero_infinity=True) as called at blstm_trainer.py:22,65-70."""
     out = {}
@@ -590,6 +628,7 @@ def main():
     gen_fomaml_goldens()
     gen_multi_goldens()
     gen_mono_goldens()
+    gen_tester_goldens()
 
 
 if __name__ == "__main__":

@@ -172,9 +172,10 @@ def test_concurrent_task_slots_reproduce_sequential_run(tmp_path, monkeypatch):
     assert finals[0][1] == finals[1][1]
 
 
-def test_tester_writes_best_hyp_like_the_reference(tmp_path, monkeypatch):
+def test_tester_writes_best_hyp_like_the_reference(golden_dir, tmp_path, monkeypatch):
     """train.py --test path: Tester loads model.wer.best (reference state_dict layout), greedy-decodes the test shard and
-    appends "<ref ids> TAB <hyp ids>" lines with the reference's trim rule."""
+    appends "<ref ids> TAB <hyp ids>" lines with the reference's trim rule.  The file is compared line by line with the one
+    the reference's own Tester wrote for the same shard and weights (tests/golden/tester_toy.npz)."""
     from masr_amd.tester import Tester
     monkeypatch.chdir(tmp_path)
     cfg, paras, id2accent = make_run(tmp_path)
@@ -188,6 +189,14 @@ def test_tester_writes_best_hyp_like_the_reference(tmp_path, monkeypatch):
     t = Tester(cfg, paras, id2accent)
     t.load_data(); t.set_model(); t.exec()
     lines = (log_dir / "greedy_decode" / "best-hyp").read_text().splitlines()
+    gold = np.load(golden_dir / "tester_toy.npz")["lines"].tolist()
+    assert [l.split("\t")[0] for l in lines] == [l.split("\t")[0] for l in gold]           # same utterances in the same order
+    same = sum(a == b for a, b in zip(lines, gold))
+    tok = [(a.split("\t")[1].split(), b.split("\t")[1].split()) for a, b in zip(lines, gold)]
+    agree = np.mean([np.mean([x == y for x, y in zip(h, r)]) if len(h) == len(r) and r else float(h == r) for h, r in tok])
+    print(f"best-hyp: {same}/{len(gold)} lines identical to the reference's file, token agreement {agree:.3f}")
+    # the tiny random model's logits are nearly flat: allow a bf16 arg-max flip in at most one utterance
+    assert same >= len(gold) - 1 and agree > 0.9
     labels = np.load(tmp_path / "data" / "african" / "test" / "label.npy")
     olens = np.load(tmp_path / "data" / "african" / "test" / "olens.npy")
     assert len(lines) == 6
