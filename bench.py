@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--mixed", action="store_true", help="also time a mixed-length leg (ilens ~ U{200..1500}), reported as \"mixed_lengths\"")
     ap.add_argument("--no-stagger", action="store_true", help="start all concurrent tasks at the same instant (lock-step)")
     ap.add_argument("--tasks-per-gpu", type=int, default=4, help="concurrent independent accent-tasks per GPU (1 = reference order)")
     args = ap.parse_args()
@@ -246,6 +247,40 @@ def main():
     assert np.isfinite(st["loss"]) and np.isfinite(st["grad_norm"]), st
     log(f"timed region: {dt:.3f} s for {args.steps} steps x {K} task(s); loss {st['loss']:.4f}")
 
+    # ---- mixed-length leg (ilens ~ U{200..1500}): every task cycles through 8 batches of its own; all
+    # utterances of a batch share one length (what the reference's BucketSampler yields) and the half-batch rule applies
+    # above 512 frames (B/1 or B*2 utterances, batch_size 32 of the shipped configs = 2 * B here)
+    mixed = None
+    if args.mixed:
+        rng = np.random.RandomState(1234 + rank)
+        pools = []
+        for t in tasks:
+            pool = []
+            for j in range(8):
+                Tm = int(rng.randint(200, 1501))
+                Bm = B if Tm > 512 else 2 * B
+                xs, il, ys, ol = synth_batch(Bm, Tm, D, seed=rank * 1000 + len(pools) * 8 + j)
+                pool.append((xs.to(dev), il, ys, ol))
+            pools.append(pool)
+        for t, pool in zip(tasks, pools):
+            t.pool, t.j = pool, 0
+
+            def mstep(t=t):
+                xs, il, ys, ol = t.pool[t.j % 8]
+                t.j += 1
+                t.eng.run_batch(xs, il, ys, ol, train=True)
+                t.eng.clip_sgd_step(t.mom, 5.0, lr, 0.9, True, first_step=False)
+            t.step = mstep
+        nm = max(8, args.steps // 2 // 8 * 8)                    # whole cycles of the pool
+        dtm = timed(tasks, nm, 8, stagger)
+        utt = sum(sum(p[j % 8][1].numel() for j in range(nm)) for p in pools)
+        frames = sum(sum(int(p[j % 8][1].sum()) for j in range(nm)) for p in pools)
+        mixed = {"value": world * utt / dtm, "unit": "utt/s", "frames_per_s": world * frames / dtm, "steps": nm,
+                 "ilens": "U{200..1500}, one length per batch; B utterances above 512 frames, 2B below (half-batch rule)"}
+        log(f"mixed lengths: {mixed['value']:.1f} utt/s, {mixed['frames_per_s'] / 1e6:.2f} M frames/s")
+        for t in tasks:
+            del t.step                                           # back to the fixed-shape step of the class
+
     def step(i):
         tasks[0].step()
 
@@ -302,6 +337,7 @@ def main():
             "algorithmic_gflop_per_utt_fwd_bwd": 3 * F / 1e9,
             "model_tflops": value * 3 * F / 1e12, "model_frac_of_bf16_peak": value * 3 * F / 1e12 / (PEAK_BF16_TFLOPS * world),
             "single_task": single,
+            "mixed_lengths": mixed,
             "loss": st["loss"], "grad_norm": st["grad_norm"],
         }
         if roof:
