@@ -102,6 +102,40 @@ int masr_recog_full(masr_model* m, const float* xs, const int64_t* ilens, int B,
  * imports, src/monitor/metric.py:4,66,87).  Returns the distance, < 0 on bad arguments. */
 int64_t masr_edit_distance(const int32_t* a, int na, const int32_t* b, int nb);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * BLSTM-CTC model of config/blstm: MonoBLSTM.forward (src/model/blstm/mono_blstm.py:77-92) =
+ * BlstmEncoder (src/modules/encoder.py:215-298: VGG 1->128->128 pool(ceil) ->256->256 pool(ceil), RNNP = nlayers x
+ * {packed bidirectional LSTM(enc_dim), Linear(2 enc_dim -> proj_dim | enc_odim), tanh}, pad frames zeroed) + Linear head,
+ * with BLSTMTrainer.run_batch's loss (src/blstm_trainer.py:55-85): targets [sos] + y + [eos] (sos = eos = odim - 1),
+ * log_softmax + CTCLoss(blank 0, mean, zero_infinity).  sample_rate 1 / dropout 0 per layer (the shipped settings).
+ * Same conventions as the masr_* calls above: flat fp32 params / grads in the reference's state_dict order (each tensor
+ * starts on a 4-float boundary), caller-owned workspace, stream-ordered, int return codes. */
+typedef struct masr_blstm masr_blstm;
+typedef struct masr_blstm_config {
+    int32_t idim, odim;          /* feature width (83), vocabulary incl. <blank> and <eos> (367) */
+    int32_t enc_dim, proj_dim;   /* LSTM hidden size per direction, projection width between layers */
+    int32_t enc_odim;            /* projection width of the last layer (encoder.odim) */
+    int32_t nlayers;
+} masr_blstm_config;
+masr_blstm* masr_blstm_create(const masr_blstm_config* cfg);
+void masr_blstm_destroy(masr_blstm* m);
+int64_t masr_blstm_param_numel(const masr_blstm* m);
+int masr_blstm_param_count(const masr_blstm* m);
+int masr_blstm_param_info(const masr_blstm* m, int idx, char* name, int name_cap, int64_t shape[4], int* ndim, int64_t* offset);
+int64_t masr_blstm_workspace_bytes(const masr_blstm* m, int B, int T, int max_target_len);
+int masr_blstm_bind(masr_blstm* m, float* params, float* grads, void* workspace, int64_t ws_bytes);
+int masr_blstm_refresh(masr_blstm* m, void* stream);
+/* xs: device fp32 [B][T][idim]; ilens / olens: host int64 [B]; ys_flat: host int64 (labels without sos/eos, concatenated).
+ * MASR_TRAIN leaves d loss / d params in the bound gradient buffer. */
+int masr_blstm_run_batch(masr_blstm* m, const float* xs, const int64_t* ilens, const int64_t* ys_flat, const int64_t* olens,
+                         int B, int T, int flags, void* stream);
+int masr_blstm_read_stats(masr_blstm* m, float out[4], void* stream);            /* out[0] = CTC loss, out[3] = grad norm */
+/* head output (pre-softmax) [B][Tp][odim] fp32 and enc_lens int32 [B] on the device, Tp = ceil(ceil(T/2)/2) */
+int masr_blstm_last_logits(masr_blstm* m, float** logits, int32_t** enc_lens, int* B, int* Tp, int* C);
+/* clip_grad_norm_(max_norm) + SGD(momentum, nesterov) step + shadow refresh (mono_interface.py:141-148) */
+int masr_blstm_clip_sgd_step(masr_blstm* m, float* momentum_buf, float max_norm, float lr, float momentum, int nesterov,
+                             int first_step, void* stream);
+
 /* Log-mel filterbank features on the GPU, written in the layout of the reference's feat.dat shards
  * (src/io/dataset.py:123-139: one [sum T_b][idim] float matrix per split).  The reference has no extraction code; the
  * algorithm is Kaldi's compute-fbank-feats with the recipe's options (16 kHz, 25 ms / 10 ms, povey window, 512-point FFT,

@@ -44,6 +44,18 @@ _SIGS = {
     "masr_recog": (i32, [vp, vp, vp, i32, i32, vp, vp]),
     "masr_recog_full": (i32, [vp, vp, vp, i32, i32, vp, vp]),
     "masr_edit_distance": (i64, [vp, i32, vp, i32]),
+    "masr_blstm_create": (vp, [vp]),
+    "masr_blstm_destroy": (None, [vp]),
+    "masr_blstm_param_numel": (i64, [vp]),
+    "masr_blstm_param_count": (i32, [vp]),
+    "masr_blstm_param_info": (i32, [vp, i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64)]),
+    "masr_blstm_workspace_bytes": (i64, [vp, i32, i32, i32]),
+    "masr_blstm_bind": (i32, [vp, vp, vp, vp, i64]),
+    "masr_blstm_refresh": (i32, [vp, vp]),
+    "masr_blstm_run_batch": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "masr_blstm_read_stats": (i32, [vp, C.POINTER(f32), vp]),
+    "masr_blstm_last_logits": (i32, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+    "masr_blstm_clip_sgd_step": (i32, [vp, vp, f32, f32, f32, i32, i32, vp]),
     "masr_fbank": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
     "masr_gather_pad": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "masr_ctc_work_floats": (i64, [i32, i32, i32]),

@@ -22,7 +22,8 @@ constexpr int LDK = 40;
 // ------------------------------------------------------------------ conv1 (CIN = 1), direct fp32
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, bf16* __restrict__ out,
-                                                        int B, int H, int W) {
+                                                        int B, int H, int W, int cstride) {
+    // one launch = 64 output channels of a map with `cstride` channels (w, bias, out pre-offset by the caller)
     __shared__ float sw[64 * 9 + 64];
     for (int i = threadIdx.x; i < 64 * 9 + 64; i += 256) sw[i] = i < 576 ? w[i] : bias[i - 576];
     __syncthreads();
@@ -47,12 +48,12 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
         for (int tap = 0; tap < 9; ++tap) a = fmaf(sw[co * 9 + tap], xv[tap], a);
         o[j] = (bf16)fmaxf(a, 0.f);
     }
-    st8(out + p * 64 + cg * 8, o);
+    st8(out + p * cstride + cg * 8, o);
 }
 
 constexpr int C1_PIX = 2048;   // pixels per block in conv1 wgrad
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const bf16* __restrict__ dy,
-                                                          float* __restrict__ slab, int B, int H, int W) {
+                                                          float* __restrict__ slab, int B, int H, int W, int cstride) {
     const long P = (long)B * H * W;
     const long p0 = (long)blockIdx.x * C1_PIX;
     const int pl = threadIdx.x >> 3, cg = threadIdx.x & 7;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
             const int tt = t + tap / 3 - 1, dd = d + tap % 3 - 1;
             xv[tap] = (tt >= 0 && tt < H && dd >= 0 && dd < W) ? x[p + (long)(tap / 3 - 1) * W + (tap % 3 - 1)] : 0.f;
         }
-        const bf16x8 g = ld8(dy + p * 64 + cg * 8);
+        const bf16x8 g = ld8(dy + p * cstride + cg * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float gj = (float)g[j];
@@ -795,8 +796,9 @@ int wgrad_splits(long P, int CIN) {
 }
 
 // ------------------------------------------------------------------ max-pool 2x2 (floor) NHWC
-__global__ void maxpool_fwd_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int B, int H, int W, int C) {
-    const int H2 = H / 2, W2 = W / 2, C8 = C / 8;
+// ceil_mode: output (H+1)/2 x (W+1)/2, windows clipped at the map edge (MaxPool2d(2, 2, ceil_mode=True) of the BLSTM front-end)
+__global__ void maxpool_fwd_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int B, int H, int W, int C, int ceil_mode) {
+    const int H2 = ceil_mode ? (H + 1) / 2 : H / 2, W2 = ceil_mode ? (W + 1) / 2 : W / 2, C8 = C / 8;
     const long n = (long)B * H2 * W2 * C8;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -805,17 +807,18 @@ __global__ void maxpool_fwd_kernel(const bf16* __restrict__ in, bf16* __restrict
     const int t2 = (int)((i / ((long)C8 * W2)) % H2);
     const int b = (int)(i / ((long)C8 * W2 * H2));
     const bf16* base = in + (((long)b * H + 2 * t2) * W + 2 * d2) * C + c8 * 8;
-    const bf16x8 v00 = ld8(base), v01 = ld8(base + C), v10 = ld8(base + (long)W * C), v11 = ld8(base + (long)W * C + C);
+    const bool r1 = 2 * t2 + 1 < H, c1 = 2 * d2 + 1 < W;     // second row / column of the window exists
+    const bf16x8 v00 = ld8(base), v01 = c1 ? ld8(base + C) : v00, v10 = r1 ? ld8(base + (long)W * C) : v00,
+                 v11 = (r1 && c1) ? ld8(base + (long)W * C + C) : v00;
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
         o[j] = (bf16)fmaxf(fmaxf((float)v00[j], (float)v01[j]), fmaxf((float)v10[j], (float)v11[j]));
     st8(out + i * 8, o);
 }
-
 __global__ void maxpool_relu_bwd_kernel(const bf16* __restrict__ in, const bf16* __restrict__ dout, bf16* __restrict__ din,
-                                        int B, int H, int W, int C) {
-    const int H2 = H / 2, W2 = W / 2, C8 = C / 8;
+                                        int B, int H, int W, int C, int ceil_mode) {
+    const int H2 = ceil_mode ? (H + 1) / 2 : H / 2, W2 = ceil_mode ? (W + 1) / 2 : W / 2, C8 = C / 8;
     const int H2c = (H + 1) / 2, W2c = (W + 1) / 2;           // cells incl. the cropped edge
     const long n = (long)B * H2c * W2c * C8;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -825,7 +828,21 @@ __global__ void maxpool_relu_bwd_kernel(const bf16* __restrict__ in, const bf16*
     const int t2 = (int)((i / ((long)C8 * W2c)) % H2c);
     const int b = (int)(i / ((long)C8 * W2c * H2c));
     const long base = (((long)b * H + 2 * t2) * W + 2 * d2) * C + c8 * 8;
-    if (t2 < H2 && d2 < W2) {
+    if (t2 < H2 && d2 < W2 && !(2 * t2 + 1 < H && 2 * d2 + 1 < W)) {
+        // ceil_mode window clipped by the map edge: arg-max over the elements that exist
+        const bool ex[4] = {true, 2 * d2 + 1 < W, 2 * t2 + 1 < H, 2 * t2 + 1 < H && 2 * d2 + 1 < W};
+        const long offs[4] = {0, (long)C, (long)W * C, (long)W * C + C};
+        bf16x8 v[4];
+        for (int k = 0; k < 4; ++k) v[k] = ex[k] ? ld8(in + base + offs[k]) : zero8();
+        const bf16x8 g = ld8(dout + ((((long)b * H2 + t2) * W2 + d2) * C + c8 * 8));
+        bf16x8 o[4];
+        for (int j = 0; j < 8; ++j) {
+            int arg = 0; float mx = (float)v[0][j];
+            for (int k = 1; k < 4; ++k) if (ex[k] && (float)v[k][j] > mx) { mx = (float)v[k][j]; arg = k; }
+            for (int k = 0; k < 4; ++k) o[k][j] = (k == arg && mx > 0.f) ? g[j] : (bf16)0.f;
+        }
+        for (int k = 0; k < 4; ++k) if (ex[k]) st8(din + base + offs[k], o[k]);
+    } else if (t2 < H2 && d2 < W2) {
         const long offs[4] = {0, (long)C, (long)W * C, (long)W * C + C};
         bf16x8 v[4];
 #pragma unroll
@@ -854,15 +871,34 @@ __global__ void maxpool_relu_bwd_kernel(const bf16* __restrict__ in, const bf16*
 
 int mk_conv1_fwd(const float* x, const float* w, const float* bias, bf16* out, int B, int H, int W, hipStream_t s) {
     const long P = (long)B * H * W;
-    hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, s, x, w, bias, out, B, H, W);
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, s, x, w, bias, out, B, H, W, 64);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 long mk_conv1_wgrad_slab_floats(int B, int H, int W) { return (((long)B * H * W + C1_PIX - 1) / C1_PIX) * 640; }
 int mk_conv1_wgrad(const float* x, const bf16* dy, float* dw, float* db, float* slab, int B, int H, int W, hipStream_t s) {
     const long P = (long)B * H * W;
     const int nb = (int)((P + C1_PIX - 1) / C1_PIX);
-    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(nb), dim3(256), 0, s, x, dy, slab, B, H, W);
+    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(nb), dim3(256), 0, s, x, dy, slab, B, H, W, 64);
     hipLaunchKernelGGL(conv1_wgrad_reduce, dim3(160), dim3(256), 0, s, slab, nb, dw, db);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// CIN = 1 conv with COUT = 64 * n channels (the BLSTM front-end has 128): n launches of the 64-channel kernels
+int mk_conv1_fwd_n(const float* x, const float* w, const float* bias, bf16* out, int B, int H, int W, int COUT, hipStream_t s) {
+    if (COUT % 64) { mk_set_error("mk_conv1_fwd_n", "COUT must be a multiple of 64"); return -1; }
+    const long P = (long)B * H * W;
+    for (int c0 = 0; c0 < COUT; c0 += 64)
+        hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, s, x, w + c0 * 9, bias + c0, out + c0, B, H, W, COUT);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int mk_conv1_wgrad_n(const float* x, const bf16* dy, float* dw, float* db, float* slab, int B, int H, int W, int COUT, hipStream_t s) {
+    if (COUT % 64) { mk_set_error("mk_conv1_wgrad_n", "COUT must be a multiple of 64"); return -1; }
+    const long P = (long)B * H * W;
+    const int nb = (int)((P + C1_PIX - 1) / C1_PIX);
+    for (int c0 = 0; c0 < COUT; c0 += 64) {
+        hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(nb), dim3(256), 0, s, x, dy + c0, slab, B, H, W, COUT);
+        hipLaunchKernelGGL(conv1_wgrad_reduce, dim3(160), dim3(256), 0, s, slab, nb, dw + c0 * 9, db + c0);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -888,7 +924,7 @@ int mk_conv3x3(const ConvArgs& a, hipStream_t s) {
     auto grid = [&](int TH) { return dim3((a.W + 15) / 16, (a.H + TH - 1) / TH, a.B); };
     // 8-wide tiles when they cover the width with fewer padded columns than 16-wide ones (e.g. W = 40: 40 vs 48)
     static const bool allow_narrow = !getenv("MASR_CONV_NO_TW8");
-    const bool narrow = allow_narrow && (a.W + 7) / 8 * 8 < (a.W + 15) / 16 * 16;
+    const bool narrow = allow_narrow && (a.W + 7) / 8 * 8 < (a.W + 15) / 16 * 16 && a.CIN <= 128 && a.COUT <= 128;
     if (a.x1) {
         if (!(a.CIN == 64 && a.COUT == 64) || !a.w1_slab || !a.mask) { mk_set_error("mk_conv3x3", "fused conv1 wgrad needs the 64->64 dgrad with a mask"); return -1; }
         hipLaunchKernelGGL((conv3x3_patch_kernel<64, 64, 16, true>), grid(16), dim3(256), 0, s, a);
@@ -900,6 +936,9 @@ int mk_conv3x3(const ConvArgs& a, hipStream_t s) {
         else if (a.CIN == 128 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 64, 16, false, 8>), grid8(16), dim3(256), 0, s, a);
         else { mk_set_error("mk_conv3x3", "unsupported channel counts"); return -1; }
     }
+    else if (a.CIN == 128 && a.COUT == 256) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 256, 8>), grid(8), dim3(256), 0, s, a);   // BLSTM front-end
+    else if (a.CIN == 256 && a.COUT == 256) hipLaunchKernelGGL((conv3x3_patch_kernel<256, 256, 8>), grid(8), dim3(256), 0, s, a);
+    else if (a.CIN == 256 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<256, 128, 8>), grid(8), dim3(256), 0, s, a);
     else if (a.CIN == 64 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<64, 128, 8>), grid(8), dim3(256), 0, s, a);
     else if (a.CIN == 128 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 128, 8>), grid(8), dim3(256), 0, s, a);
     else if (a.CIN == 128 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 64, 16>), grid(16), dim3(256), 0, s, a);
@@ -946,6 +985,8 @@ int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s) {
         if (a.CIN == 64 && a.COUT == 64) { W2(64, 64) }
         else if (a.CIN == 64 && a.COUT == 128) { W2(64, 128) }
         else if (a.CIN == 128 && a.COUT == 128) { W2(128, 128) }
+        else if (a.CIN == 128 && a.COUT == 256) { W2(128, 256) }
+        else if (a.CIN == 256 && a.COUT == 256) { W2(256, 256) }
         else { mk_set_error("mk_conv3x3_wgrad", "unsupported channel counts"); return -1; }
 #undef W2T
 #undef W2
@@ -955,14 +996,14 @@ int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int mk_maxpool_fwd(const bf16* in, bf16* out, int B, int H, int W, int C, hipStream_t s) {
-    const long n = (long)B * (H / 2) * (W / 2) * (C / 8);
+int mk_maxpool_fwd(const bf16* in, bf16* out, int B, int H, int W, int C, hipStream_t s, int ceil_mode) {
+    const long n = ceil_mode ? (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8) : (long)B * (H / 2) * (W / 2) * (C / 8);
     if (n == 0) return 0;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, B, H, W, C);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, B, H, W, C, ceil_mode);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-int mk_maxpool_relu_bwd(const bf16* in, const bf16* dout, bf16* din, int B, int H, int W, int C, hipStream_t s) {
+int mk_maxpool_relu_bwd(const bf16* in, const bf16* dout, bf16* din, int B, int H, int W, int C, hipStream_t s, int ceil_mode) {
     const long n = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
-    hipLaunchKernelGGL(maxpool_relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, dout, din, B, H, W, C);
+    hipLaunchKernelGGL(maxpool_relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, dout, din, B, H, W, C, ceil_mode);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

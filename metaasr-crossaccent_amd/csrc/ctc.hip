@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
                                                   const int* __restrict__ tgt_off, const int* __restrict__ in_len,
                                                   const int* __restrict__ tgt_len, int T, int B, int C, int blank,
                                                   float* __restrict__ nll, float* __restrict__ grad,
-                                                  float* __restrict__ work, int Spad) {
+                                                  float* __restrict__ work, int Spad, long st_t, long st_b) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Tb = in_len[b], Lb = tgt_len[b], S = 2 * Lb + 1;
     const int* tg = targets + tgt_off[b];
@@ -32,10 +32,11 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
     __shared__ float s_ll;
 
     // zero the gradient of this utterance (frames >= Tb stay zero)
-    for (long i = tid; i < (long)T * C; i += 256) grad[((i / C) * B + b) * C + (i % C)] = 0.f;
+    // element (t, b, c) of logits / grad sits at ((t * st_t + b * st_b) * C + c): time-major [T][B][C] or batch-first [B][T][C]
+    for (long i = tid; i < (long)T * C; i += 256) grad[((i / C) * st_t + b * st_b) * C + (i % C)] = 0.f;
     // log-softmax normalisers
     for (int t = wave; t < Tb; t += 4) {
-        const float* z = logits + ((long)t * B + b) * C;
+        const float* z = logits + ((long)t * st_t + b * st_b) * C;
         float mx = -3.4e38f;
         for (int c = lane; c < C; c += 64) mx = fmaxf(mx, z[c]);
         mx = wave_max(mx);
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
     }
     __syncthreads();
     auto ext = [&](int s) { return (s & 1) ? tg[s >> 1] : blank; };
-    auto lp = [&](int t, int s) { return logits[((long)t * B + b) * C + ext(s)] - wlse[t]; };
+    auto lp = [&](int t, int s) { return logits[((long)t * st_t + b * st_b) * C + ext(s)] - wlse[t]; };
 
     // alpha sweep
     for (int s = tid; s < S; s += 256) {
@@ -103,8 +104,8 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
             if (al != NINF && bta != NINF) atomicAdd(&acc[ext(s)], __expf(al + bta - lp(t, s) - ll));
         }
         __syncthreads();
-        const float* z = logits + ((long)t * B + b) * C;
-        float* g = grad + ((long)t * B + b) * C;
+        const float* z = logits + ((long)t * st_t + b * st_b) * C;
+        float* g = grad + ((long)t * st_t + b * st_b) * C;
         const float lse = wlse[t];
         for (int c = tid; c < C; c += 256) g[c] = (__expf(z[c] - lse) - acc[c]) * gscale;
         __syncthreads();
@@ -121,10 +122,10 @@ __global__ void ctc_mean_kernel(const float* __restrict__ nll, const int* __rest
 
 long mk_ctc_work_floats(int T, int B, int maxS) { return (long)B * T * ((maxS + 3) / 4 * 4) + (long)B * T; }
 int mk_ctc_loss(const float* logits, const int* targets, const int* tgt_off, const int* in_len, const int* tgt_len, int T,
-                  int B, int C, int blank, float* nll, float* loss_out, float* grad, float* work, int maxS, hipStream_t s) {
+                  int B, int C, int blank, float* nll, float* loss_out, float* grad, float* work, int maxS, hipStream_t s, int batch_first) {
     if (maxS > MAXS || C > 4096) { mk_set_error("mk_ctc_loss", "lattice wider than 2048 states or > 4096 classes"); return -1; }
     hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(256), 0, s, logits, targets, tgt_off, in_len, tgt_len, T, B, C, blank, nll, grad,
-                       work, (maxS + 3) / 4 * 4);
+                       work, (maxS + 3) / 4 * 4, batch_first ? 1L : (long)B, batch_first ? (long)T : 1L);
     hipLaunchKernelGGL(ctc_mean_kernel, dim3(1), dim3(64), 0, s, nll, tgt_len, B, loss_out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

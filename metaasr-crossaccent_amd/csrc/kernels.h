@@ -55,9 +55,12 @@ int mk_conv1_wgrad_fused_reduce(const float* slab, int B, int H, int W, float* d
 struct ConvWgradArgs { const bf16* in; const bf16* dy; float* dw; float* db; float* slab; int B, H, W, CIN, COUT; };
 int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s);
 long mk_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT);
-int mk_maxpool_fwd(const bf16* in, bf16* out, int B, int H, int W, int C, hipStream_t s);
+int mk_maxpool_fwd(const bf16* in, bf16* out, int B, int H, int W, int C, hipStream_t s, int ceil_mode = 0);
 // din = (in is the first max of its window && in > 0) ? dout : 0   (ReLU backward fused)
-int mk_maxpool_relu_bwd(const bf16* in, const bf16* dout, bf16* din, int B, int H, int W, int C, hipStream_t s);
+int mk_maxpool_relu_bwd(const bf16* in, const bf16* dout, bf16* din, int B, int H, int W, int C, hipStream_t s, int ceil_mode = 0);
+// CIN = 1 convs with COUT = 64 n channels
+int mk_conv1_fwd_n(const float* x, const float* w, const float* bias, bf16* out, int B, int H, int W, int COUT, hipStream_t s);
+int mk_conv1_wgrad_n(const float* x, const bf16* dy, float* dw, float* db, float* slab, int B, int H, int W, int COUT, hipStream_t s);
 
 // ---------------------------------------------------------------- attention (attention.hip)
 struct AttnArgs {
@@ -162,6 +165,35 @@ int mk_vgg2enc_grad_unpermute(const float* g_nhwc, float* dw, int E, int C, int 
 // ragged gather + zero pad: rows of feat [sum T_i][D] -> xs [B][Tmax][D]
 int mk_gather_pad(const float* feat, const long* row_start, const int* lens, float* xs, int B, int Tmax, int D, hipStream_t s);
 
+// ---------------------------------------------------------------- bidirectional LSTM (lstm.hip) -- BLSTM-P encoder of the CTC config
+// rows are batch-first (b*T + t); the gate axis is unit-major (u*4 + g, g in torch order i,f,g,o); index [2] = direction
+struct LstmStepArgs {
+    int B, T, H, KP;                  // KP = H rounded up to a multiple of 32 (zero-padded bf16 recurrent operands)
+    const int* lens;                  // [B] valid frames per sequence (device)
+    bf16* h16[2][2];                  // [B][KP] hidden state ping-pong
+    const bf16* whh16[2];             // [4H][KP]  W_hh, rows unit-major
+    const bf16* whhT16[2];            // [H][4H]   W_hh^T (columns unit-major)
+    const float* gx[2];               // [B*T][4H] input contribution + biases
+    float* act[2];                    // [B*T][4H] gate activations (saved for backward)
+    float* c[2];                      // [B*T][H]  cell states
+    float* cstate[2];                 // [B][H]    running cell state (forward) / dL/dc carry (backward)
+    bf16* y16;                        // [B*T][2H] layer output (fwd | bwd halves), 0 at padded frames
+    const float* dy;                  // [B*T][2H] gradient wrt y (backward)
+    bf16* dz16[2];                    // [B*T][4H] gradient wrt the gate pre-activations (backward output)
+};
+int mk_lstm_fwd_steps(const LstmStepArgs& a, hipStream_t s);
+int mk_lstm_bwd_steps(const LstmStepArgs& a, hipStream_t s);
+// W_ih [4H][K], W_hh [4H][H], biases in torch order -> unit-major bf16 shadows (+ transposes for the dgrad GEMMs)
+int mk_lstm_shadows(const float* wih, const float* whh, const float* bih, const float* bhh, int H, int K, int KP_in, int KP_h,
+                    bf16* wih16, bf16* wihT16, bf16* whh16, bf16* whhT16, float* bias, int pc, int pd, hipStream_t s);
+// (pc, pd) != 0: the input features are an NHWC conv map [pd][pc]; torch's weight columns are c*pd + d
+int mk_lstm_unperm(const float* src, float* dst, float* dst2, int H, int K, int pc, int pd, hipStream_t s);   // unit-major rows -> torch rows
+int mk_lstm_hprev(const bf16* y16, bf16* hp0, bf16* hp1, int B, int T, int H, int KP, hipStream_t s);
+int mk_cast_rows_pad(const float* x, bf16* y, long rows, int C, int Cp, hipStream_t s);
+int mk_tanh_fwd(const float* x, float* y32, bf16* y16, long n, hipStream_t s);
+int mk_tanh_bwd(const float* dy, const float* y, bf16* dx16, long n, hipStream_t s);
+int mk_mask_rows(float* x32, bf16* x16, const int* lens, int B, int T, int C, hipStream_t s);
+
 // ---------------------------------------------------------------- features (fbank.hip)
 // Kaldi-style log-mel filterbank: wav fp32 (PCM scale, utterances concatenated), wav_off [B+1], row_off [B] (first output
 // row of each utterance), feat [sum T_b][n_mel]; T_b = 1 + (n_b - 400) / 160; grid covers max_frames frames per utterance
@@ -172,5 +204,5 @@ int mk_fbank(const float* wav, const long* wav_off, const long* row_off, int B, 
 // loss_out[0] = mean_b( nll_b / max(tl_b,1) ), zero_infinity; grad wrt logits [T][B][C]
 int mk_ctc_loss(const float* logits, const int* targets, const int* tgt_off, const int* in_len, const int* tgt_len,
                   int T, int B, int C, int blank, float* nll /*[B]*/, float* loss_out, float* grad, float* work,
-                  int maxS, hipStream_t s);
+                  int maxS, hipStream_t s, int batch_first = 0);      // batch_first: logits / grad are [B][T][C]
 long mk_ctc_work_floats(int T, int B, int maxS);

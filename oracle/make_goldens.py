@@ -541,6 +541,45 @@ def gen_tester_goldens():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+BLSTM_TINY = {"optimizer": {"type": "SGD"}, "optimizer_opt": {"lr": 0.01, "momentum": 0.9, "nesterov": True},
+              "encoder": {"idim": 83, "enc_dim": 40, "proj_dim": 40, "odim": 40, "sample_rate": "1_1", "dropout": "0_0"}}
+
+
+def gen_blstm_goldens():
+    """Reference MonoBLSTM (config/blstm geometry, small widths) + the loss of BLSTMTrainer.run_batch on a ragged batch."""
+    from oracle import blstm_cpu
+    from src.model.blstm.mono_blstm import MonoBLSTM
+    id2char = ["<blank>"] + [f"u{i}" for i in range(1, 366)] + ["</s>"]
+    model = MonoBLSTM(id2char, BLSTM_TINY)
+    sd = blstm_cpu.deterministic_state_dict(BLSTM_TINY, ODIM, seed=11)
+    assert list(model.state_dict().keys()) == list(sd.keys()), (list(model.state_dict().keys()), list(sd.keys()))
+    model.load_state_dict(sd)
+    model.train()
+    out = {"state_dict_keys": np.array(list(sd.keys()))}
+    for tag, (ilens, olens) in {"ragged": ([61, 50, 38, 30], [7, 5, 4, 3]), "single": ([45], [6])}.items():
+        xs, il, ys, ol = synth_batch(21, ilens, olens)
+        # BLSTMTrainer.run_batch (src/blstm_trainer.py:55-70), executed verbatim on the reference model
+        sos = ys[0].new([model.sos_id]); eos = ys[0].new([model.eos_id])
+        y_true = torch.cat([torch.cat([sos, y, eos], dim=0) for y in ys])
+        pred, enc_lens = model(xs, il)
+        logp = torch.nn.functional.log_softmax(pred, dim=-1)
+        loss = torch.nn.CTCLoss(blank=0, reduction='mean', zero_infinity=True)(logp.transpose(0, 1).contiguous(), y_true, enc_lens.cpu().long(), (ol + 2).long())
+        model.zero_grad()
+        loss.backward()
+        out[f"{tag}/loss"] = np.float64(loss.item())
+        out[f"{tag}/logits"] = pred.detach().numpy().copy()
+        out[f"{tag}/enc_lens"] = enc_lens.numpy().copy()
+        for n, prm in model.named_parameters():
+            out[f"{tag}/grad/{n}"] = flat_checks(prm.grad)
+        out[f"{tag}/gradfull/head.bias"] = model.head.bias.grad.numpy().copy()
+        out[f"{tag}/gradfull/encoder.vgg.0.weight"] = model.encoder.vgg[0].weight.grad.numpy().copy()
+        out[f"{tag}/gradfull/encoder.blstm.rnn0.weight_hh_l0_reverse"] = model.encoder.blstm.rnn0.weight_hh_l0_reverse.grad.numpy().copy()
+        gn = torch.sqrt(sum((prm.grad ** 2).sum() for prm in model.parameters()))
+        out[f"{tag}/grad_norm"] = np.float64(gn.item())
+    np.savez_compressed(OUT / "blstm_tiny.npz", **out)
+    print("blstm_tiny.npz loss", out["ragged/loss"], "grad norm", out["ragged/grad_norm"])
+
+
 def gen_ctc_goldens():
     """nn.CTCLoss(blank=0, reduction='mean', zero_infinity=True) as called at blstm_trainer.py:22,65-70."""
     out = {}
@@ -629,6 +668,7 @@ def main():
     gen_multi_goldens()
     gen_mono_goldens()
     gen_tester_goldens()
+    gen_blstm_goldens()
 
 
 if __name__ == "__main__":

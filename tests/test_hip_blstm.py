@@ -1,0 +1,97 @@
+"""BLSTM-CTC path on the GPU through the C ABI (masr_blstm_*): forward logits, CTC loss and every
+parameter gradient against the reference's golden (tests/golden/blstm_tiny.npz, real MonoBLSTM) and the CPU oracle with
+and without bf16 emulation of the MFMA operands."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import masr_amd  # noqa: E402
+from masr_amd.blstm_engine import BlstmEngine  # noqa: E402
+from oracle import blstm_cpu  # noqa: E402
+from oracle.make_goldens import BLSTM_TINY, ODIM, synth_batch  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return blstm_cpu.deterministic_state_dict(BLSTM_TINY, ODIM, seed=11)
+
+
+def test_param_table_is_the_reference_state_dict(sd, golden_dir):
+    eng = BlstmEngine(BLSTM_TINY, ODIM)
+    g = np.load(golden_dir / "blstm_tiny.npz")
+    assert list(eng.table) == g["state_dict_keys"].tolist() == list(sd)
+    for n, (off, shape) in eng.table.items():
+        assert tuple(sd[n].shape) == shape and off % 4 == 0
+    eng.load_state_dict(sd)
+    back = eng.state_dict()
+    assert all(torch.equal(back[n].cpu(), sd[n]) for n in sd)
+
+
+@pytest.mark.parametrize("tag,ilens,olens", [("ragged", [61, 50, 38, 30], [7, 5, 4, 3]), ("single", [45], [6])])
+def test_run_batch_vs_reference_golden(sd, golden_dir, tag, ilens, olens):
+    g = np.load(golden_dir / "blstm_tiny.npz")
+    xs, il, ys, ol = synth_batch(21, ilens, olens)
+    eng = BlstmEngine(BLSTM_TINY, ODIM)
+    eng.load_state_dict(sd)
+    eng.run_batch(xs, il, ys, ol, train=True)
+    st = eng.read_stats()
+    logits, lens = eng.last_logits()
+    ref_logits = torch.from_numpy(g[f"{tag}/logits"])
+    assert lens.cpu().tolist() == g[f"{tag}/enc_lens"].tolist()
+    rel_logits = float((logits.cpu() - ref_logits).norm() / ref_logits.norm())
+    rel_loss = abs(st["loss"] - float(g[f"{tag}/loss"])) / float(g[f"{tag}/loss"])
+    print(f"{tag}: loss {st['loss']:.5f} vs reference {float(g[f'{tag}/loss']):.5f} (rel {rel_loss:.1e}); logits rel-L2 {rel_logits:.1e}")
+    assert rel_loss < 1e-3 and rel_logits < 2e-2                      # north-star tolerance on the loss; bf16 operands on the logits
+    got = eng.state_dict(flat=eng.grads)
+    # full-tensor gradient checks where the golden stores them, norms everywhere
+    for n in ("head.bias", "encoder.vgg.0.weight", "encoder.blstm.rnn0.weight_hh_l0_reverse"):
+        ref = torch.from_numpy(g[f"{tag}/gradfull/{n}"])
+        rel = float((got[n].cpu() - ref).norm() / ref.norm())
+        print(f"   grad {n}: rel-L2 {rel:.2e}")
+        assert rel < 0.15
+    worst = 0.0
+    for n in sd:
+        ref_l2 = float(g[f"{tag}/grad/{n}"][2])
+        mine = float(got[n].double().norm())
+        if ref_l2 > 1e-6:
+            worst = max(worst, abs(mine / ref_l2 - 1))
+            assert abs(mine / ref_l2 - 1) < 0.15, (n, mine, ref_l2)
+    gn = float(torch.cat([got[n].reshape(-1) for n in sd]).double().norm())
+    print(f"   worst per-tensor gradient-norm deviation {worst:.2e}; total grad norm {gn:.4f} vs {float(g[f'{tag}/grad_norm']):.4f}")
+    assert abs(gn / float(g[f"{tag}/grad_norm"]) - 1) < 3e-2
+
+
+def test_gradients_vs_oracle_per_tensor(sd):
+    """every parameter gradient against the CPU oracle (fp32): cosine and norm per tensor"""
+    xs, il, ys, ol = synth_batch(21, [61, 50, 38, 30], [7, 5, 4, 3])
+    eng = BlstmEngine(BLSTM_TINY, ODIM)
+    eng.load_state_dict(sd)
+    eng.run_batch(xs, il, ys, ol, train=True)
+    got = eng.state_dict(flat=eng.grads)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss, _, _ = blstm_cpu.run_batch(p, BLSTM_TINY, (xs, il, ys, ol), ODIM)
+    loss.backward()
+    a = torch.cat([got[n].cpu().reshape(-1) for n in sd]).double(); b = torch.cat([p[n].grad.reshape(-1) for n in sd]).double()
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    print(f"global gradient cosine vs oracle {cos:.5f}, norm ratio {float(a.norm() / b.norm()):.4f}")
+    assert cos > 0.995
+    for n in sd:
+        x, y = got[n].cpu().double().reshape(-1), p[n].grad.double().reshape(-1)
+        c = float((x * y).sum() / (x.norm() * y.norm() + 1e-30))
+        assert c > 0.97, (n, c)
+
+
+def test_sgd_steps_reduce_the_loss(sd):
+    xs, il, ys, ol = synth_batch(21, [61, 50, 38, 30], [7, 5, 4, 3])
+    eng = BlstmEngine(BLSTM_TINY, ODIM)
+    eng.load_state_dict(sd)
+    mom = torch.zeros_like(eng.params)
+    losses = []
+    for i in range(6):
+        eng.run_batch(xs, il, ys, ol, train=True)
+        eng.clip_sgd_step(mom, 5.0, 0.01, 0.9, True, first_step=(i == 0))
+        losses.append(eng.read_stats()["loss"])
+    print("CTC loss over 6 SGD steps on one batch:", [round(l, 4) for l in losses])
+    assert losses[-1] < losses[0] and all(np.isfinite(l) for l in losses)

@@ -236,3 +236,26 @@ def test_fbank_oracle_properties():
     assert abs(int(f.mean(0).argmax()) - int(np.abs(centre - F.mel(1000.0)).argmin())) <= 1      # energy sits at the 1 kHz filter
     np.testing.assert_allclose(F.fbank(2 * tone, 80), f + 2 * np.log(2.0), atol=1e-9)            # power scales with amplitude^2
     np.testing.assert_allclose(F.fbank(tone + 1234.0, 80), f, atol=1e-6)                         # remove_dc_offset
+
+
+@pytest.mark.parametrize("tag,ilens,olens", [("ragged", [61, 50, 38, 30], [7, 5, 4, 3]), ("single", [45], [6])])
+def test_blstm_oracle_matches_reference(golden_dir, tag, ilens, olens):
+    """oracle/blstm_cpu.py (explicit LSTM recurrence with own packed-sequence handling) vs the real MonoBLSTM +
+    BLSTMTrainer.run_batch loss: logits, CTC loss, every parameter gradient."""
+    from oracle import blstm_cpu
+    from oracle.make_goldens import BLSTM_TINY, ODIM, flat_checks, synth_batch
+    g = np.load(golden_dir / "blstm_tiny.npz")
+    sd = blstm_cpu.deterministic_state_dict(BLSTM_TINY, ODIM, seed=11)
+    assert list(sd.keys()) == g["state_dict_keys"].tolist()
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xs, il, ys, ol = synth_batch(21, ilens, olens)
+    loss, logits, lens = blstm_cpu.run_batch(p, BLSTM_TINY, (xs, il, ys, ol), ODIM)
+    loss.backward()
+    assert lens.tolist() == g[f"{tag}/enc_lens"].tolist()
+    np.testing.assert_allclose(logits.detach().numpy(), g[f"{tag}/logits"], rtol=1e-4, atol=2e-5)
+    assert abs(float(loss) - float(g[f"{tag}/loss"])) < 1e-5 * float(g[f"{tag}/loss"])
+    for n in sd:
+        np.testing.assert_allclose(flat_checks(p[n].grad), g[f"{tag}/grad/{n}"], rtol=2e-3, atol=1e-6, err_msg=n)
+    np.testing.assert_allclose(p["head.bias"].grad.numpy(), g[f"{tag}/gradfull/head.bias"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(p["encoder.blstm.rnn0.weight_hh_l0_reverse"].grad.numpy(),
+                               g[f"{tag}/gradfull/encoder.blstm.rnn0.weight_hh_l0_reverse"], rtol=1e-3, atol=1e-7)
