@@ -132,6 +132,8 @@ int masr_blstm_run_batch(masr_blstm* m, const float* xs, const int64_t* ilens, c
 int masr_blstm_read_stats(masr_blstm* m, float out[4], void* stream);            /* out[0] = CTC loss, out[3] = grad norm */
 /* head output (pre-softmax) [B][Tp][odim] fp32 and enc_lens int32 [B] on the device, Tp = ceil(ceil(T/2)/2) */
 int masr_blstm_last_logits(masr_blstm* m, float** logits, int32_t** enc_lens, int* B, int* Tp, int* C);
+/* nn.utils.clip_grad_norm_(parameters, max_norm) on the flat gradient; the norm is read with masr_blstm_read_stats */
+int masr_blstm_clip_grads(masr_blstm* m, float max_norm, void* stream);
 /* clip_grad_norm_(max_norm) + SGD(momentum, nesterov) step + shadow refresh (mono_interface.py:141-148) */
 int masr_blstm_clip_sgd_step(masr_blstm* m, float* momentum_buf, float max_norm, float lr, float momentum, int nesterov,
                              int first_step, void* stream);

@@ -127,7 +127,90 @@ class BlstmEngine:
         lens = self.ws[eo:eo + B.value * 4].view(torch.int32)
         return logits, lens
 
+    def clip_grads(self, max_norm):
+        check(self._l.masr_blstm_clip_grads(self.h, max_norm, self.stream()), "masr_blstm_clip_grads")
+
+    def sgd_step(self, params, grads, mom, lr, momentum, nesterov, first_step):
+        check(self._l.masr_sgd_step(_ptr(params), _ptr(grads), _ptr(mom), params.numel(), lr, momentum, int(nesterov), int(first_step), self.stream()),
+              "masr_sgd_step")
+
     def clip_sgd_step(self, momentum_buf, max_norm, lr, momentum, nesterov, first_step):
         check(self._l.masr_blstm_clip_sgd_step(self.h, _ptr(momentum_buf), max_norm, lr, momentum, int(nesterov), int(first_step), self.stream()),
               "masr_blstm_clip_sgd_step")
         self._dirty = False
+
+
+def reference_init_state_dict(model_para: dict, odim: int):
+    """Initial weights identical to the reference's for the same torch seed: replays MonoBLSTM.__init__'s RNG consumption
+    (module construction order of src/modules/encoder.py:230-248 and mono_blstm.py:36-38) with throw-away torch.nn modules
+    on the host, then lecun_normal_init_parameters (src/nets_utils.py:293-318: biases 0, matrices N(0, 1/sqrt(fan_in)))
+    over encoder.parameters() and head.parameters()."""
+    import math
+    from torch import nn
+    e = model_para["encoder"]
+    H, proj, eodim = e["enc_dim"], e["proj_dim"], e["odim"]
+    rates = e["sample_rate"].split("_")
+    vgg = nn.Sequential(nn.Conv2d(1, 128, 3, 1, 1), nn.ReLU(), nn.Conv2d(128, 128, 3, 1, 1), nn.ReLU(), nn.MaxPool2d(2, 2, ceil_mode=True),
+                        nn.Conv2d(128, 256, 3, 1, 1), nn.ReLU(), nn.Conv2d(256, 256, 3, 1, 1), nn.ReLU(), nn.MaxPool2d(2, 2, ceil_mode=True))
+    vgg_o = int(np.ceil(np.ceil(np.array(e["idim"], dtype=np.float32) / 2) / 2)) * 256
+    mods = OrderedDict()
+    mods["encoder.vgg"] = vgg
+    nl = len(rates)
+    order = []
+    rnn0 = nn.LSTM(vgg_o, H, num_layers=1, bidirectional=True, batch_first=True); bt0 = nn.Linear(2 * H, proj)
+    order += [("encoder.blstm.rnn0", rnn0), ("encoder.blstm.bt0", bt0)]
+    for i in range(1, nl):
+        rnn = nn.LSTM(proj, H, num_layers=1, bidirectional=True, batch_first=True)
+        bt = nn.Linear(2 * H, eodim if i == nl - 1 else proj)
+        order += [(f"encoder.blstm.rnn{i}", rnn), (f"encoder.blstm.bt{i}", bt)]
+    head = nn.Linear(eodim, odim)
+    allmods = [("encoder.vgg", vgg)] + order + [("head", head)]
+    with torch.no_grad():
+        for _, mod in allmods:                       # init_encoder() walks encoder.parameters() (vgg, then blstm), then the head
+            for prm in mod.parameters():
+                if prm.dim() == 1:
+                    prm.zero_()
+                else:
+                    n = prm.size(1)
+                    for k in prm.size()[2:]:
+                        n *= k
+                    prm.normal_(0, 1.0 / math.sqrt(n))
+    sd = OrderedDict()
+    for name, mod in allmods:
+        for n, t in mod.state_dict().items():
+            sd[f"{name}.{n}"] = t.detach()
+    return sd
+
+
+class MonoBLSTM:
+    """Facade with the surface the Interface / Trainer code touches (reference: src/model/blstm/mono_blstm.py:23-92)."""
+
+    def __init__(self, id2char, model_para, device="cuda:0", init=True):
+        from .marcos import BLANK_SYMBOL
+        self.idim = model_para["encoder"]["idim"]
+        self.odim = len(id2char)
+        self.sos_id = self.eos_id = len(id2char) - 1
+        self.blank_id = id2char.index(BLANK_SYMBOL)
+        self.engine = BlstmEngine(model_para, self.odim, device=device)
+        self.training = True
+        if init:
+            self.engine.load_state_dict(reference_init_state_dict(model_para, self.odim))
+
+    def cuda(self):
+        return self
+
+    def train(self):
+        self.training = True
+
+    def eval(self):
+        self.training = False
+
+    def state_dict(self):
+        return self.engine.state_dict()
+
+    def load_state_dict(self, sd):
+        self.engine.load_state_dict(sd)
+
+    @property
+    def device(self):
+        return self.engine.device

@@ -382,6 +382,12 @@ int masr_blstm_last_logits(masr_blstm* m, float** logits, int32_t** enc_lens, in
     *logits = m->logits; *enc_lens = m->lens; *B = m->B; *Tp = m->Tp; *C = m->C;
     return 0;
 }
+int masr_blstm_clip_grads(masr_blstm* m, float max_norm, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!m->have) { mk_set_error("masr_blstm_clip_grads", "run a batch first"); return -1; }
+    CK(mk_sumsq(m->G, m->nparams, m->slab, m->stats + 3, s));
+    return mk_clip_scale(m->G, m->nparams, m->stats + 3, max_norm, s);
+}
 int masr_blstm_clip_sgd_step(masr_blstm* m, float* mom, float max_norm, float lr, float momentum, int nesterov, int first_step, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!m->have) { mk_set_error("masr_blstm_clip_sgd_step", "run a batch first"); return -1; }

@@ -55,6 +55,23 @@ class Metric:
         h, r = self._texts(pred, y)
         return float(levenshtein(h, r)) / len(r) * 100
 
+    def _ctc_texts(self, pred, y):
+        """metric.py:89-135: collapse repeats, drop sos/eos/blank, DecodePieces"""
+        from itertools import groupby
+        assert self.blank_id is not None
+        hyp = [x[0] for x in groupby(pred.tolist())]
+        hyp = [x for x in hyp if x != self.sos_id and x != self.eos_id and x != self.blank_id]
+        return self.spm.DecodePieces([self.id2units[x] for x in hyp]), self.spm.DecodePieces([self.id2units[x] for x in y.tolist()])
+
+    def cal_ctc_wer(self, pred, y, show=False, show_decode=False):
+        h, r = self._ctc_texts(pred, y)
+        h, r = h.split(' '), r.split(' ')
+        return float(levenshtein(h, r)) / len(r) * 100
+
+    def cal_ctc_cer(self, pred, y, show=False, show_decode=False):
+        h, r = self._ctc_texts(pred, y)
+        return float(levenshtein(h, r)) / len(r) * 100
+
     def batch_cal_er(self, preds, ys, modes, er_modes):
         pred = torch.argmax(preds, dim=-1)
         out = {}

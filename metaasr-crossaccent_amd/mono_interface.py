@@ -231,6 +231,8 @@ class MonoASRInterface(TrainInterface):
         if float(dev_info['cer']) < self.best_cer:
             self.best_cer = float(dev_info['cer'])
             self.save_best_model('cer', only_stat=True)
+        if getattr(self, 'lr_scheduler', None) is not None:                  # mono_interface.py:220-221 (BLSTM: ReduceLROnPlateau)
+            self.lr_scheduler.step(float(dev_info['loss']))
         self.asr_model.train()
 
     def run_batch(self, cur_b, x, ilens, ys, olens, train):

@@ -580,6 +580,68 @@ def gen_blstm_goldens():
     print("blstm_tiny.npz loss", out["ragged/loss"], "grad norm", out["ragged/grad_norm"])
 
 
+def gen_blstm_mono_goldens():
+    """BASELINE configs[0]: train.py mono-accent, config/blstm CTC on a toy memmap shard -- the reference's
+    get_trainer(MonoASRInterface...) from src/blstm_trainer.py, two epochs of clip-5 + SGD(nesterov) steps."""
+    import torch.optim.lr_scheduler as lrs
+    _orig = lrs.ReduceLROnPlateau
+    class _RLROP(_orig):                                    # torch >= 2.7 dropped the `verbose` kwarg the reference passes
+        def __init__(self, *a, verbose=None, **k): super().__init__(*a, **k)
+    lrs.ReduceLROnPlateau = _RLROP
+    from oracle import blstm_cpu
+    from src.mono_interface import MonoASRInterface
+    from src.blstm_trainer import get_trainer
+    tmp = Path(tempfile.mkdtemp(prefix="masr_gold_"))
+    cwd = os.getcwd()
+    try:
+        solver_cfg = _toy_workspace(tmp)
+        solver_cfg.update({"eval_ival": 1000, "log_ival": 1000})
+        cfg = {"asr_model": dict(BLSTM_TINY), "solver": solver_cfg}
+        os.chdir(tmp)
+        id2accent = json.load(open("data/accent-code.json"))
+        paras = SimpleNamespace(config="x", accent="af", algo="no", model_name="blstm", eval_suffix="e", runs=0, overwrite=True,
+                                seed=531, resume=False, use_tensorboard=False, save_verbose=False, split_rate=1.0, freeze_layer=None,
+                                pretrain=False, pretrain_suffix=None, pretrain_setting=None, pretrain_runs=0, pretrain_step=0,
+                                pretrain_tgt_accent="ca", pretrain_model_path=None, njobs=0, is_bucket=True, is_memmap=True,
+                                no_cuda=True, cuda=False, test=False, eval_every_epoch=False)
+        random.seed(531); np.random.seed(531); torch.manual_seed(531)
+        solver = get_trainer(MonoASRInterface, cfg, paras, id2accent)
+        solver.load_data()
+        solver.set_model()
+        sd = blstm_cpu.deterministic_state_dict(BLSTM_TINY, ODIM, seed=11)
+        solver.asr_model.load_state_dict(sd)
+        solver.evaluate = lambda: None
+        rec = []
+        orig = solver.run_batch
+        def spy(cur_b, x, ilens, ys, olens, train):
+            info = orig(cur_b, x, ilens.clone(), [y.clone() for y in ys], olens.clone(), train=train)
+            rec.append((int(cur_b), x.numpy().copy(), ilens.numpy().copy(), [y.numpy().copy() for y in ys], olens.numpy().copy(), dict(info)))
+            return info
+        from functools import partial
+        solver._train = partial(spy, train=True)
+        solver.exec()
+        out = {}
+        out["n_calls"] = np.int64(len(rec))
+        for i, (idx, x, il, ys, ol, info) in enumerate(rec):
+            out[f"call{i}/accent"] = np.int64(idx)
+            out[f"call{i}/ilens"] = il
+            out[f"call{i}/ys"] = np.concatenate(ys)
+            out[f"call{i}/loss"] = np.float64(info["loss"])
+        out["global_step"] = np.int64(solver.global_step)
+        out["ep"] = np.int64(solver.ep)
+        st = solver.asr_model.state_dict()
+        for n in ("head.bias", "encoder.blstm.bt1.bias", "encoder.blstm.rnn0.bias_hh_l0_reverse", "encoder.vgg.7.bias"):
+            out[f"param/{n}"] = st[n].detach().numpy().copy()
+        out["files"] = np.array(sorted(p.name for p in solver.log_dir.iterdir()))
+        np.savez_compressed(OUT / "blstm_mono_toy.npz", **out)
+        print("blstm_mono_toy.npz calls:", len(rec), "losses", [round(r[5]["loss"], 4) for r in rec[:3]], "...", round(rec[-1][5]["loss"], 4),
+              "files:", out["files"])
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+        lrs.ReduceLROnPlateau = _orig
+
+
 def gen_ctc_goldens():
     """nn.CTCLoss(blank=0, reduction='mean', zero_infinity=True) as called at blstm_trainer.py:22,65-70."""
     out = {}
@@ -669,6 +731,7 @@ def main():
     gen_mono_goldens()
     gen_tester_goldens()
     gen_blstm_goldens()
+    gen_blstm_mono_goldens()
 
 
 if __name__ == "__main__":

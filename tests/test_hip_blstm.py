@@ -95,3 +95,67 @@ def test_sgd_steps_reduce_the_loss(sd):
         losses.append(eng.read_stats()["loss"])
     print("CTC loss over 6 SGD steps on one batch:", [round(l, 4) for l in losses])
     assert losses[-1] < losses[0] and all(np.isfinite(l) for l in losses)
+
+
+def test_mono_blstm_training_matches_reference_golden(golden_dir, tmp_path, monkeypatch):
+    """BASELINE configs[0] (train.py mono-accent, config/blstm CTC, toy memmap shard) through
+    get_trainer(MonoASRInterface, ...) of blstm_trainer: the 26 batches of two epochs in the reference's order, per-step
+    CTC losses (incl. the batches whose targets do not fit the 4x-subsampled input: zero_infinity -> 0), files."""
+    import random
+    from functools import partial
+    from types import SimpleNamespace
+    from masr_amd.blstm_trainer import get_trainer
+    from masr_amd.mono_interface import MonoASRInterface
+    from oracle.make_goldens import write_toy_shard
+    g = np.load(golden_dir / "blstm_mono_toy.npz")
+    monkeypatch.chdir(tmp_path)
+    data = tmp_path / "data"
+    data.mkdir()
+    for ai, a in enumerate(["african", "australia"]):
+        write_toy_shard(data, a, "train", 16, seed=100 + ai)
+        write_toy_shard(data, a, "dev", 4, seed=200 + ai)
+    (data / "units.txt").write_text("".join(f"u{i} {i}\n" for i in range(1, 366)))
+    cfg = {"asr_model": dict(BLSTM_TINY),
+           "solver": {"setting": "gold", "data_root": str(data), "total_steps": 10, "total_epochs": 2, "spm_mapping": str(data / "units.txt"),
+                      "spm_model": "unused", "label_smoothing": 0.2, "eval_ival": 1000, "log_ival": 1000, "save_ival": 3, "batch_size": 4,
+                      "dev_batch_size": 4, "min_ilen": 10, "max_ilen": 50, "dev_max_ilen": 3000, "half_batch_ilen": 30}}
+    paras = SimpleNamespace(accent="af", algo="no", model_name="blstm", eval_suffix="e", runs=0, overwrite=True, seed=531, resume=False,
+                            use_tensorboard=False, save_verbose=False, split_rate=1.0, freeze_layer=None, pretrain=False,
+                            pretrain_suffix=None, pretrain_setting=None, pretrain_runs=0, pretrain_step=0, pretrain_tgt_accent="ca",
+                            pretrain_model_path=None, njobs=0, is_bucket=True, is_memmap=True, device="cuda:0", eval_every_epoch=False)
+    random.seed(531); np.random.seed(531); torch.manual_seed(531)
+    s = get_trainer(MonoASRInterface, cfg, paras, {"af": "african", "au": "australia", "ca": "canada"})
+    s.load_data(); s.set_model()
+    s.asr_model.load_state_dict(blstm_cpu.deterministic_state_dict(BLSTM_TINY, ODIM, seed=11))
+    s.evaluate = lambda: None
+    rec = []
+    orig = s.run_batch
+
+    def spy(cur_b, x, ilens, ys, olens, train, accent_idx=None):
+        info = orig(cur_b, x, ilens, ys, olens, train=train)
+        rec.append((int(cur_b), ilens.clone(), [y.clone() for y in ys], dict(info)))
+        return info
+    s._train = partial(spy, train=True)
+    s.exec()
+    assert len(rec) == int(g["n_calls"]) == 26 and s.global_step == int(g["global_step"]) and s.ep == int(g["ep"])
+    worst = 0.0
+    for i, (idx, il, ys, info) in enumerate(rec):
+        assert idx == int(g[f"call{i}/accent"])
+        np.testing.assert_array_equal(il.numpy(), g[f"call{i}/ilens"])
+        np.testing.assert_array_equal(np.concatenate([y.numpy() for y in ys]), g[f"call{i}/ys"])
+        ref = float(g[f"call{i}/loss"])
+        if ref == 0.0:
+            assert info["loss"] == 0.0                                # every target of the batch is infeasible: zero_infinity
+            continue
+        rel = abs(info["loss"] - ref) / ref
+        worst = max(worst, rel)
+        assert rel < (1e-3 if i == 0 else 5e-3), (i, info["loss"], ref)             # measured worst 1.1e-3 after 25 SGD steps
+    print(f"BLSTM mono run: worst per-batch CTC loss rel err over 26 steps {worst:.2e}; last {rec[-1][3]['loss']:.4f} vs {float(g['call25/loss']):.4f}")
+    got = s.asr_model.engine.state_dict()
+    sd0 = blstm_cpu.deterministic_state_dict(BLSTM_TINY, ODIM, seed=11)
+    for n in ("head.bias", "encoder.blstm.bt1.bias", "encoder.blstm.rnn0.bias_hh_l0_reverse", "encoder.vgg.7.bias"):
+        du = (got[n].cpu() - sd0[n]).double(); dr = (torch.from_numpy(g[f"param/{n}"]) - sd0[n]).double()
+        cos = float((du * dr).sum() / (du.norm() * dr.norm()))
+        print(f"   {n}: update cosine vs reference {cos:.4f}, norm ratio {float(du.norm() / dr.norm()):.4f}")
+        assert cos > 0.9
+    assert {p.name for p in s.log_dir.iterdir()} >= set(g["files"].tolist()) - {"exp_key"}

@@ -70,10 +70,13 @@ def main(argv=None):
         solver = Tester(config, paras, id2accent)
         solver.load_data(); solver.set_model(); solver.exec()
         return
-    if paras.model_name != 'transformer':
-        raise NotImplementedError("only the transformer trainer is on the MI355X path (BLSTM/CTC: masr_ctc_loss kernel only)")
     from masr_amd.mono_interface import MonoASRInterface
-    from masr_amd.transformer_torch_trainer import get_trainer
+    if paras.model_name == 'blstm':                               # train.py:112-113 of the reference
+        from masr_amd.blstm_trainer import get_trainer
+    elif paras.model_name == 'transformer':
+        from masr_amd.transformer_torch_trainer import get_trainer
+    else:
+        raise NotImplementedError(f"model_name {paras.model_name} (LAS is not on the MI355X path)")
     solver = get_trainer(MonoASRInterface, config, paras, id2accent)
     solver.load_data()
     solver.set_model()
