@@ -576,6 +576,11 @@ def gen_blstm_goldens():
         out[f"{tag}/gradfull/encoder.blstm.rnn0.weight_hh_l0_reverse"] = model.encoder.blstm.rnn0.weight_hh_l0_reverse.grad.numpy().copy()
         gn = torch.sqrt(sum((prm.grad ** 2).sum() for prm in model.parameters()))
         out[f"{tag}/grad_norm"] = np.float64(gn.item())
+    # the reference's own initialisation (seed 531 of the CLIs), fingerprinted per tensor, for the init replay of the build
+    torch.manual_seed(531)
+    m2 = MonoBLSTM(id2char, BLSTM_TINY)
+    for n, t in m2.state_dict().items():
+        out[f"init/{n}"] = flat_checks(t)
     np.savez_compressed(OUT / "blstm_tiny.npz", **out)
     print("blstm_tiny.npz loss", out["ragged/loss"], "grad norm", out["ragged/grad_norm"])
 

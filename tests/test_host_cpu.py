@@ -170,3 +170,15 @@ def test_metric_matches_reference(golden_dir):
     for b in range(len(gold)):
         assert abs(m.cal_att_cer(pred_ids[b], gold[b]) - g["per_cer"][b]) < 1e-9
         assert abs(m.cal_att_wer(pred_ids[b], gold[b]) - g["per_wer"][b]) < 1e-9
+
+
+def test_blstm_init_replay_matches_reference_seed_531(golden_dir):
+    """MonoBLSTM's initial weights (module construction order + lecun_normal_init_parameters) for torch.manual_seed(531)"""
+    from masr_amd.blstm_engine import reference_init_state_dict as blstm_init
+    from oracle.make_goldens import BLSTM_TINY
+    g = np.load(golden_dir / "blstm_tiny.npz")
+    torch.manual_seed(531)
+    sd = blstm_init(BLSTM_TINY, 367)
+    assert list(sd.keys()) == g["state_dict_keys"].tolist()
+    for n, t in sd.items():
+        np.testing.assert_allclose(flat_checks(t), g[f"init/{n}"], rtol=1e-6, atol=1e-7, err_msg=n)
