@@ -129,6 +129,8 @@ int masr_blstm_refresh(masr_blstm* m, void* stream);
  * MASR_TRAIN leaves d loss / d params in the bound gradient buffer. */
 int masr_blstm_run_batch(masr_blstm* m, const float* xs, const int64_t* ilens, const int64_t* ys_flat, const int64_t* olens,
                          int B, int T, int flags, void* stream);
+/* forward only (MonoBLSTM.forward / greedy_decode, mono_blstm.py:63-92): head output readable through masr_blstm_last_logits */
+int masr_blstm_forward(masr_blstm* m, const float* xs, const int64_t* ilens, int B, int T, void* stream);
 int masr_blstm_read_stats(masr_blstm* m, float out[4], void* stream);            /* out[0] = CTC loss, out[3] = grad norm */
 /* head output (pre-softmax) [B][Tp][odim] fp32 and enc_lens int32 [B] on the device, Tp = ceil(ceil(T/2)/2) */
 int masr_blstm_last_logits(masr_blstm* m, float** logits, int32_t** enc_lens, int* B, int* Tp, int* C);

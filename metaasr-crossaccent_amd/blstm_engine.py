@@ -111,6 +111,19 @@ class BlstmEngine:
                                            B, T, MASR_TRAIN if train else MASR_EVAL, self.stream()), "masr_blstm_run_batch")
         self._last_x = xs
 
+    def forward(self, xs, ilens):
+        """MonoBLSTM.forward: -> (logits fp32 [B, T', odim], enc_lens int32 [B]) (views into the workspace)"""
+        if xs.device != self.device:
+            xs = xs.to(self.device, non_blocking=True)
+        xs = xs.contiguous().float()
+        B, T, D = xs.shape
+        il = torch.as_tensor(ilens, dtype=torch.int64).cpu().contiguous()
+        self._ensure_ws(B, T, 4)
+        self.refresh()
+        check(self._l.masr_blstm_forward(self.h, _ptr(xs), C.c_void_p(il.data_ptr()), B, T, self.stream()), "masr_blstm_forward")
+        self._last_x = xs
+        return self.last_logits()
+
     def read_stats(self):
         out = (C.c_float * 4)()
         check(self._l.masr_blstm_read_stats(self.h, out, self.stream()), "masr_blstm_read_stats")
@@ -198,6 +211,13 @@ class MonoBLSTM:
 
     def cuda(self):
         return self
+
+    def __call__(self, xs_pad, ilens):
+        """forward(xs_pad, ilens) -> (out [B, T', odim], enc_lens)"""
+        logits, lens = self.engine.forward(xs_pad, ilens)
+        return logits, lens.to(torch.int64)
+
+    greedy_decode = __call__                                  # mono_blstm.py:63-64
 
     def train(self):
         self.training = True

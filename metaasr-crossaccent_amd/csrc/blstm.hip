@@ -370,6 +370,24 @@ int masr_blstm_run_batch(masr_blstm* m, const float* xs, const int64_t* ilens, c
     if (flags & MASR_TRAIN) CK(backward(m, xs, s));
     return 0;
 }
+int masr_blstm_forward(masr_blstm* m, const float* xs, const int64_t* ilens, int B, int T, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!m->P) { mk_set_error("masr_blstm_forward", "not bound"); return -1; }
+    if (B <= 0 || T <= 0 || B > 4096) { mk_set_error("masr_blstm_forward", "bad batch"); return -1; }
+    Arena ar{m->ws, m->ws_bytes, m->persist_bytes};
+    plan_acts(m, ar, B, T, 2 * (1 + 2) + 1);
+    if (ar.off > m->ws_bytes) { mk_set_error("masr_blstm_forward", "workspace too small (masr_blstm_workspace_bytes)"); return -2; }
+    HIP_CHECK_RET(hipEventSynchronize(m->stage_ev));
+    for (int b = 0; b < B; ++b) {
+        if (ilens[b] < 1 || ilens[b] > T) { mk_set_error("masr_blstm_forward", "ilens must be in [1, T]"); return -1; }
+        m->h_stage[b] = (int)(((ilens[b] + 1) / 2 + 1) / 2);
+    }
+    HIP_CHECK_RET(hipMemcpyAsync(m->lens, m->h_stage, sizeof(int) * B, hipMemcpyHostToDevice, s));
+    HIP_CHECK_RET(hipEventRecord(m->stage_ev, s));
+    CK(forward(m, xs, s));
+    m->have = true;
+    return 0;
+}
 int masr_blstm_read_stats(masr_blstm* m, float out[4], void* stream) {
     hipStream_t s = (hipStream_t)stream;
     HIP_CHECK_RET(hipMemcpyAsync(m->h_stats, m->stats, sizeof(float) * 4, hipMemcpyDeviceToHost, s));

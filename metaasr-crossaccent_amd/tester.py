@@ -40,7 +40,7 @@ class Tester:
                 self.prev_decode_step = sum(1 for _ in f)
 
     def load_data(self):
-        if self.model_name != 'transformer':
+        if self.model_name not in ('transformer', 'blstm'):
             raise NotImplementedError
         self.id2ch = load_units(self.config, self.model_name)
         self.eval_set = get_loader(self.data_dir.joinpath('test'), batch_size=self.batch_size,
@@ -49,6 +49,14 @@ class Tester:
 
     def set_model(self):
         device = getattr(self.paras, 'device', None) or "cuda:0"
+        if self.model_name == 'blstm':
+            from .blstm_engine import MonoBLSTM
+            self.asr_model = MonoBLSTM(self.id2ch, self.config['asr_model'], device=device, init=False)
+            self.asr_model.load_state_dict(torch.load(self.model_path, map_location='cpu'))
+            self.asr_model.eval()
+            self.sos_id, self.eos_id, self.blank_id = self.asr_model.sos_id, self.asr_model.eos_id, self.asr_model.blank_id
+            return
+        self.blank_id = None
         self.asr_model = MyTransformer(self.id2ch, self.config['asr_model'], device=device, init=False)
         self.asr_model.load_state_dict(torch.load(self.model_path, map_location='cpu'))
         self.asr_model.eval()
@@ -58,6 +66,8 @@ class Tester:
         """tester.py:189-207 (transformer): everything from the first </s> at position >= 1 is dropped; a
         hypothesis of length <= 1 becomes empty."""
         assert isinstance(hyp, list)
+        if self.model_name == 'blstm':                         # tester.py:191-193
+            return [i for i in hyp if i < self.eos_id]
         if len(hyp) <= 1:
             return []
         for pos in range(1, len(hyp)):
@@ -66,6 +76,16 @@ class Tester:
         return hyp
 
     def batch_greedy_decode(self, xs, ilens, ys, olens):
+        if self.model_name == 'blstm':
+            # tester.py:216-225: arg-max over ALL T' frames of the padded batch (frames past enc_lens included, as the
+            # reference does), trim, collapse repeats, drop blanks
+            from itertools import groupby
+            logits, _ = self.asr_model(xs, ilens)
+            preds = torch.argmax(logits, dim=-1).cpu()
+            for pred, y in zip(preds, ys):
+                hyp = [x[0] for x in groupby(self.trim(pred.tolist()))]
+                self.write_hyp(y.tolist(), [x for x in hyp if x != self.blank_id])
+            return True
         preds = self.asr_model.recog(xs, ilens).transpose(0, 1).cpu()
         for pred, y in zip(preds, ys):
             self.write_hyp(y.tolist(), self.trim(pred.tolist()))

@@ -647,6 +647,41 @@ def gen_blstm_mono_goldens():
         lrs.ReduceLROnPlateau = _orig
 
 
+def gen_blstm_tester_goldens():
+    """Reference decode path for the BLSTM model (src/tester.py batch_greedy_decode, blstm branch): best-hyp lines."""
+    from oracle import blstm_cpu
+    from src.tester import Tester
+    tmp = Path(tempfile.mkdtemp(prefix="masr_gold_"))
+    cwd = os.getcwd()
+    try:
+        solver_cfg = _toy_workspace(tmp)
+        solver_cfg["beam_decode"] = {"beam_size": 1}
+        write_toy_shard(tmp / "data", "african", "test", 6, seed=300)
+        cfg = {"asr_model": dict(BLSTM_TINY), "solver": solver_cfg}
+        os.chdir(tmp)
+        id2accent = json.load(open("data/accent-code.json"))
+        log_dir = tmp / "testing-logs" / "evaluation" / "gold" / "no" / "ev" / "ev" / "african" / "0"
+        log_dir.mkdir(parents=True)
+        (log_dir / "exp_key").write_text("stub\n")
+        torch.save(blstm_cpu.deterministic_state_dict(BLSTM_TINY, ODIM, seed=11), log_dir / "model.wer.best")
+        paras = SimpleNamespace(accent="af", algo="no", pretrain_suffix=None, eval_suffix="ev", runs=0, model_name="blstm",
+                                test_model="model.wer.best", decode_suffix="greedy_decode", decode_mode="greedy", decode_batch_size=4,
+                                cuda=False, njobs=1, resume=False, overwrite=True, is_memmap=True, lm_model_path=None)
+        t = Tester(cfg, paras, id2accent)
+        t.load_data()
+        from src.io.dataset import get_loader
+        t.eval_set = get_loader(t.data_dir.joinpath("test"), batch_size=4, half_batch_ilen=512, is_memmap=True, is_bucket=False,
+                                shuffle=False, num_workers=0)
+        t.set_model()
+        t.exec()
+        lines = (log_dir / "greedy_decode" / "best-hyp").read_text().splitlines()
+        np.savez_compressed(OUT / "blstm_tester_toy.npz", lines=np.array(lines))
+        print("blstm_tester_toy.npz", len(lines), "lines; first:", lines[0][:100])
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def gen_ctc_goldens():
     """nn.CTCLoss(blank=0, reduction='mean', zero_infinity=True) as called at blstm_trainer.py:22,65-70."""
     out = {}
@@ -737,6 +772,7 @@ def main():
     gen_tester_goldens()
     gen_blstm_goldens()
     gen_blstm_mono_goldens()
+    gen_blstm_tester_goldens()
 
 
 if __name__ == "__main__":

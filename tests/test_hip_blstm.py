@@ -194,3 +194,31 @@ def test_shipped_geometry_runs_deterministically():
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
     print(f"shipped BLSTM geometry, B=8 x 400 frames: {dt * 1e3:.1f} ms per training step; CTC loss {[round(l, 3) for l in losses]}")
     assert losses[-1] < losses[0]
+
+
+def test_tester_best_hyp_matches_reference(golden_dir, tmp_path, monkeypatch):
+    """train.py --test --model_name blstm: the best-hyp file of the reference's Tester (arg-max over all frames, trim,
+    collapse repeats, drop blanks) for the deterministic tiny model, line by line."""
+    from types import SimpleNamespace
+    from masr_amd.tester import Tester
+    from oracle.make_goldens import write_toy_shard
+    monkeypatch.chdir(tmp_path)
+    data = tmp_path / "data"
+    data.mkdir()
+    write_toy_shard(data, "african", "test", 6, seed=300)
+    (data / "units.txt").write_text("".join(f"u{i} {i}\n" for i in range(1, 366)))
+    cfg = {"asr_model": dict(BLSTM_TINY), "solver": {"setting": "gold", "data_root": str(data), "spm_mapping": str(data / "units.txt"),
+                                                     "spm_model": "unused", "beam_decode": {"beam_size": 1}}}
+    log_dir = tmp_path / "testing-logs" / "evaluation" / "gold" / "no" / "ev" / "ev" / "african" / "0"
+    log_dir.mkdir(parents=True)
+    torch.save(blstm_cpu.deterministic_state_dict(BLSTM_TINY, ODIM, seed=11), log_dir / "model.wer.best")
+    paras = SimpleNamespace(accent="af", algo="no", pretrain_suffix=None, eval_suffix="ev", runs=0, model_name="blstm", test_model="model.wer.best",
+                            decode_suffix="greedy_decode", decode_mode="greedy", decode_batch_size=4, njobs=1, resume=False, overwrite=True,
+                            is_memmap=True, device="cuda:0")
+    t = Tester(cfg, paras, {"af": "african"})
+    t.load_data(); t.set_model(); t.exec()
+    lines = (log_dir / "greedy_decode" / "best-hyp").read_text().splitlines()
+    gold = np.load(golden_dir / "blstm_tester_toy.npz")["lines"].tolist()
+    print("ours :", lines[:2]); print("ref  :", gold[:2])
+    same = sum(a.rstrip() == b.rstrip() for a, b in zip(lines, gold))
+    assert len(lines) == len(gold) and same >= len(gold) - 1, (lines, gold)
