@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < MF; ++i)
 #pragma unroll
-                    for (int j = 0; j < NF; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
+                    for (int j = 0; j < NF; ++j) acc[i][j] = mma16(bfr[j], af[i], acc[i][j]);   // weights as A: a lane ends up with 4 consecutive channels
             }
             if (tap + 1 < 9) store_w(wbuf0 + ((step + 1) & 1) * W_EL);
             __syncthreads();
@@ -354,20 +354,28 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
     // epilogue: bias / ReLU in registers -> bf16 tile in LDS [pixel][COUT+8] -> coalesced 16-byte stores (+ ReLU mask)
     constexpr int OS = COUT + 8;
     bf16* otile = lds;
+    // (operands are swapped in the MFMA -- weights are the A operand -- so acc[i][j][r] is pixel lane&15 of pixel tile i,
+    // channel j*16 + 4*(lane>>4) + r: four consecutive channels per lane = one 8-byte LDS store instead of four 2-byte ones)
+    const int cq = 4 * (lane >> 4);
 #pragma unroll
-    for (int i = 0; i < MF; ++i)
+    for (int j = 0; j < NF; ++j) {
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
 #pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            const int co = j * 16 + rr;
-            const float bv = a.bias ? a.bias[co] : 0.f;
+            for (int r = 0; r < 4; ++r) bv[r] = a.bias[j * 16 + cq + r];
+        }
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            bf16x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = acc[i][j][r] + bv;
+                float v = acc[i][j][r] + bv[r];
                 if (a.relu) v = fmaxf(v, 0.f);
-                const int pj = (lane >> 4) * 4 + r;
-                otile[((wave * MF + i) * 16 + pj) * OS + co] = (bf16)v;
+                o[r] = (bf16)v;
             }
+            *reinterpret_cast<bf16x4*>(otile + ((wave * MF + i) * 16 + rr) * OS + j * 16 + cq) = o;
         }
+    }
     __syncthreads();
     if (a.pool_out) {
         // fused MaxPool2d(2, 2) (floor): the ReLU'd tile is in LDS, tile origin and size are even -> each pooled pixel's
