@@ -1,0 +1,79 @@
+"""Error behaviour of the C ABI and the NaN guard of the inner step (GPU).  The reference raises Python exceptions /
+asserts and skips the optimiser step when the gradient norm is NaN (fo_meta_interface.py:242-248, multi_interface.py:108-112);
+libmasr returns non-zero codes with a message in masr_last_error and decides the skip on the device."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import masr_amd  # noqa: E402
+from masr_amd import _cabi  # noqa: E402
+from masr_amd.engine import MasrEngine  # noqa: E402
+from oracle import ref_cpu  # noqa: E402
+from oracle.make_goldens import TINY, ODIM, synth_batch  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = MasrEngine(TINY, ODIM, label_smoothing=0.2)
+    e.load_state_dict(ref_cpu.deterministic_state_dict(TINY, ODIM, seed=7))
+    return e
+
+
+def test_bad_arguments_are_reported_not_executed(eng):
+    L = _cabi.lib()
+    xs, il, ys, ol = synth_batch(3, [40, 32], [5, 4])
+    # label outside the vocabulary
+    bad = [ys[0].clone(), ys[1].clone()]
+    bad[0][0] = ODIM + 3
+    with pytest.raises(Exception, match="label out of range"):
+        eng.run_batch(xs, il, bad, ol, train=True)
+    # an utterance longer than the padded batch / shorter than one encoder frame
+    with pytest.raises(Exception, match="ilens"):
+        eng.run_batch(xs, torch.tensor([41, 32]), ys, ol, train=True)
+    with pytest.raises(Exception, match="ilens"):
+        eng.run_batch(xs, torch.tensor([40, 3]), ys, ol, train=True)
+    # feature width must match the model
+    with pytest.raises(AssertionError, match="idim"):
+        eng.run_batch(torch.zeros(2, 40, 80), il, ys, ol, train=True)
+    # a config the kernels do not cover is refused at creation
+    cfg = _cabi.MasrConfig(idim=83, odim=367, d_model=96, nheads=4, d_inner=128, enc_layers=1, dec_layers=1, tie_weights=1,
+                           dropout=0.0, pos_dropout=0.0, label_smoothing=0.0)
+    assert not L.masr_create(C.byref(cfg)) and b"masr_create" in L.masr_last_error()
+    # binding an undersized workspace
+    small = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    rc = L.masr_bind(eng.h, C.c_void_p(eng.params.data_ptr()), C.c_void_p(eng.grads.data_ptr()), C.c_void_p(eng.pe.data_ptr()),
+                     C.c_void_p(small.data_ptr()), small.numel())
+    assert rc != 0 and b"masr_bind" in L.masr_last_error()
+    # the engine is still usable afterwards (nothing was launched by the failed calls)
+    eng._ensure_ws(4, 64, 16)
+    _cabi.check(L.masr_bind(eng.h, C.c_void_p(eng.params.data_ptr()), C.c_void_p(eng.grads.data_ptr()), C.c_void_p(eng.pe.data_ptr()),
+                            C.c_void_p(eng.ws.data_ptr()), eng.ws.numel()), "masr_bind")
+    eng.mark_dirty()
+    eng.run_batch(xs, il, ys, ol, train=True)
+    assert np.isfinite(eng.read_stats()["loss"])
+
+
+def test_nan_gradient_skips_the_inner_step(eng):
+    """`if math.isnan(grad_norm): warn else: opt.step()`: a batch with an inf feature gives a NaN norm; the fused
+    clip + SGD kernel must leave parameters and momentum untouched and report the NaN norm."""
+    xs, il, ys, ol = synth_batch(3, [40, 32], [5, 4])
+    xs = xs.clone()
+    xs[0, 5, 7] = float("inf")
+    before = eng.params.clone()
+    mom = torch.full_like(eng.params, 0.25)
+    eng.run_batch(xs, il, ys, ol, train=True)
+    eng.clip_sgd_step(mom, 5.0, 0.1, 0.9, True, first_step=False)
+    st = eng.read_stats()
+    assert np.isnan(st["grad_norm"])
+    assert torch.equal(eng.params, before) and bool((mom == 0.25).all())
+    # a clean batch afterwards trains normally
+    xs2, il2, ys2, ol2 = synth_batch(4, [40, 32], [5, 4])
+    eng.run_batch(xs2, il2, ys2, ol2, train=True)
+    eng.clip_sgd_step(mom, 5.0, 0.1, 0.9, True, first_step=False)
+    st = eng.read_stats()
+    assert np.isfinite(st["grad_norm"]) and not torch.equal(eng.params, before)
+    eng.load_state_dict(ref_cpu.deterministic_state_dict(TINY, ODIM, seed=7))
