@@ -316,7 +316,7 @@ def main():
                 traffic = pmc["traffic_bytes"]
         except Exception:
             pass
-        roof = {"bound": "mfma", "kernel": "conv3x3_patch_kernel<64,64,16> (conv2 forward + fused 2x2 max-pool, patch-tiled implicit GEMM)",
+        roof = {"bound": "mfma", "kernel": "conv3x3_resw_kernel<16,16> (conv2 forward + fused 2x2 max-pool; persistent, LDS-resident weights, LDS-DMA patches)",
                 "achieved": achieved,
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                 "algorithmic_bytes": 2 * B * T * D * 64 * 2 + B * (T // 2) * (D // 2) * 64 * 2,   # in + out + pooled out (bf16)

@@ -179,6 +179,13 @@ int masr_test_gemm(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ld
                    const float* bias, int relu, float* C32, int64_t ldc, void* stream);
 int masr_test_conv3x3(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, uint16_t* out,
                       int B, int H, int W, int CIN, int COUT, void* stream);
+/* dgrad/fused-pool flavours of the same kernel: mask (optional, same shape as out) zeroes outputs where mask <= 0;
+   pool_out (optional, [B][H/2][W/2][COUT]) receives MaxPool2d(2,2) of the ReLU'd output */
+int masr_test_conv3x3_ex(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, const uint16_t* mask, uint16_t* out,
+                         uint16_t* pool_out, int B, int H, int W, int CIN, int COUT, void* stream);
+/* same launch with per-workgroup phase timing: prof receives 6 cycle counts per workgroup (tools/prof_conv_phases.py) */
+int masr_test_conv3x3_prof(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, uint16_t* out,
+                           int B, int H, int W, int CIN, int COUT, int64_t* prof, void* stream);
 int masr_test_conv3x3_wgrad(const uint16_t* in, const uint16_t* dy, float* dw, float* slab, int64_t slab_floats,
                             int B, int H, int W, int CIN, int COUT, void* stream);
 int64_t masr_test_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT);

@@ -66,6 +66,8 @@ _SIGS = {
     "masr_profile_read": (i32, [vp, C.POINTER(f32), C.POINTER(i32)]),
     "masr_test_gemm": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, vp, i32, vp, i64, vp]),
     "masr_test_conv3x3": (i32, [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+    "masr_test_conv3x3_ex": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "masr_test_conv3x3_prof": (i32, [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp]),
     "masr_test_conv3x3_wgrad": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     "masr_test_conv3x3_wgrad_slab_floats": (i64, [i32, i32, i32, i32, i32]),
     "masr_test_attention": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -41,6 +41,7 @@ struct masr_blstm {
     std::vector<PInfo> params; int64_t nparams = 0;
     ConvP conv[4]; std::vector<Layer> layers; int64_t headw, headb; bf16 *head16 = nullptr, *headT16 = nullptr;
     float *P = nullptr, *G = nullptr; char* ws = nullptr; int64_t ws_bytes = 0, persist_bytes = 0;
+    unsigned* conv_sched = nullptr;
     float* stats = nullptr; float* h_stats = nullptr; int* h_stage = nullptr; hipEvent_t stage_ev = nullptr;
     // activations of the last batch
     int B = 0, T = 0, H2 = 0, W2 = 0, Tp = 0, Dp = 0, F = 0; int64_t rows = 0;
@@ -85,6 +86,7 @@ void plan_persistent(masr_blstm* m, Arena& ar) {
     m->head16 = ar.get<bf16>((int64_t)m->Cp8 * m->layers.back().N);
     m->headT16 = ar.get<bf16>((int64_t)m->layers.back().N * m->Cp8);
     m->stats = ar.get<float>(64);
+    m->conv_sched = ar.get<unsigned>(64);
 }
 
 void plan_acts(masr_blstm* m, Arena& ar, int B, int T, int maxS) {
@@ -135,7 +137,7 @@ int forward(masr_blstm* m, const float* xs, hipStream_t s) {
     const float* P = m->P; const int B = m->B, T = m->T, D = m->D, H = m->H, G = 4 * H; const int R = (int)m->rows;
     CK(mk_conv1_fwd_n(xs, P + m->conv[0].w, P + m->conv[0].b, m->c1, B, T, D, 128, s));
     auto conv = [&](const bf16* in, const ConvP& cv, bf16* out, int Hh, int Ww) -> int {
-        ConvArgs ca{}; ca.in = in; ca.wk = cv.k16; ca.bias = P + cv.b; ca.relu = 1; ca.out = out; ca.B = B; ca.H = Hh; ca.W = Ww; ca.CIN = cv.CI; ca.COUT = cv.CO;
+        ConvArgs ca{}; ca.sched = m->conv_sched; ca.in = in; ca.wk = cv.k16; ca.bias = P + cv.b; ca.relu = 1; ca.out = out; ca.B = B; ca.H = Hh; ca.W = Ww; ca.CIN = cv.CI; ca.COUT = cv.CO;
         return mk_conv3x3(ca, s);
     };
     CK(conv(m->c1, m->conv[1], m->c2, T, D));
@@ -215,7 +217,7 @@ int backward(masr_blstm* m, const float* xs, hipStream_t s) {
         return mk_conv3x3_wgrad(wa, s);
     };
     auto dgrad = [&](const bf16* dy, const ConvP& cv, const bf16* mask, bf16* out, int Hh, int Ww) -> int {
-        ConvArgs ca{}; ca.in = dy; ca.wk = cv.d16; ca.mask = mask; ca.out = out; ca.B = B; ca.H = Hh; ca.W = Ww; ca.CIN = cv.CO; ca.COUT = cv.CI;
+        ConvArgs ca{}; ca.sched = m->conv_sched; ca.in = dy; ca.wk = cv.d16; ca.mask = mask; ca.out = out; ca.B = B; ca.H = Hh; ca.W = Ww; ca.CIN = cv.CO; ca.COUT = cv.CI;
         return mk_conv3x3(ca, s);
     };
     CK(mk_maxpool_relu_bwd(m->c4, m->dp2, m->dc4, B, m->H2, m->W2, 256, s, 1));
@@ -305,6 +307,7 @@ int masr_blstm_bind(masr_blstm* m, float* params, float* grads, void* workspace,
         HIP_CHECK_RET(hipHostMalloc((void**)&m->h_stats, sizeof(float) * 64, hipHostMallocDefault));
         HIP_CHECK_RET(hipEventCreateWithFlags(&m->stage_ev, hipEventDisableTiming));
     }
+    HIP_CHECK_RET(hipMemset(m->conv_sched, 0, sizeof(unsigned) * 64));
     HIP_CHECK_RET(hipMemset(m->head16, 0, sizeof(bf16) * (size_t)m->Cp8 * m->layers.back().N));
     HIP_CHECK_RET(hipMemset(m->headT16, 0, sizeof(bf16) * (size_t)m->layers.back().N * m->Cp8));
     m->have = false;

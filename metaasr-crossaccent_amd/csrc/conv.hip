@@ -245,7 +245,7 @@ __device__ __forceinline__ bf16x8 frag_rm(const bf16* tile, int r0, int lane) {
 // This removes the 164 MB store, the 164 MB re-read and the whole conv1_wgrad launch.
 // TW = 8 (tile 8 pixels wide, an MFMA pixel tile = 2 rows x 8 columns) exists for maps whose width is not a multiple
 // of 16: the 40-column maps behind the first pool would waste 8 of every 48 columns (17 % of the MFMAs) with TW = 16.
-template <int CIN, int COUT, int TH, bool W1 = false, int TW = 16>
+template <int CIN, int COUT, int TH, bool W1 = false, int TW = 16, bool PROF = false>
 __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
     constexpr int PW = TW + 2, PH = TH + 2, RPT = 16 / TW;     // RPT = pixel rows per 16-pixel MFMA tile
     constexpr int PS = 80;                                 // patch pixel stride (elements): 160 B is conflict-free for the
@@ -283,6 +283,12 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
     for (int i = 0; i < MF; ++i)
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // PROF instances only (tools/prof_conv_phases.py): cycles wave 0 spends in
+    // [0] patch load+stage  [1] weight-prefetch issue  [2] fragment reads + MFMAs  [3] weight stage  [4] barrier  [5] epilogue
+    long pt[6] = {0, 0, 0, 0, 0, 0};
+    long tprev = PROF ? clock64() : 0;
+    auto stamp = [&](int k) { if constexpr (PROF) { const long now = clock64(); pt[k] += now - tprev; tprev = now; } };
 
     bf16x8 rw[WCH];
     auto load_w = [&](int slab, int tap) {
@@ -326,9 +332,11 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
         load_w(slab, 0);
         store_w(wbuf0 + (step & 1) * W_EL);
         __syncthreads();
+        stamp(0);
         for (int tap = 0; tap < 9; ++tap, ++step) {
             const bf16* wcur = wbuf0 + (step & 1) * W_EL;
             if (tap + 1 < 9) load_w(slab, tap + 1);
+            stamp(1);
             // keep the weight prefetch HERE: hipcc otherwise sinks the global loads to just before their LDS store,
             // exposing one L2 round trip per tap (9 per slab, longer than the tap's 32 MFMAs)
             __builtin_amdgcn_sched_barrier(0);
@@ -346,8 +354,11 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
 #pragma unroll
                     for (int j = 0; j < NF; ++j) acc[i][j] = mma16(bfr[j], af[i], acc[i][j]);   // weights as A: a lane ends up with 4 consecutive channels
             }
+            stamp(2);
             if (tap + 1 < 9) store_w(wbuf0 + ((step + 1) & 1) * W_EL);
+            stamp(3);
             __syncthreads();
+            stamp(4);
         }
     }
 
@@ -466,6 +477,661 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) a.w1_slab[wg * 640 + (wave * 16 + 4 * (lane >> 4) + r) * 10 + tap] = cw[r];
         }
+    }
+    if constexpr (PROF) {
+        stamp(5);
+        if (tid == 0) {
+            const long wg = ((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) a.prof[wg * 6 + k] = pt[k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ streaming 3x3 (fwd and dgrad), v3
+// Phase timing of the patch kernel above (tools/prof_conv_phases.py) shows a workgroup spends a quarter of its life
+// waiting for its input patch, a quarter pushing its output tile out and a third in the MFMA loop, and the one other
+// workgroup on the CU is rarely in the complementary phase.  This kernel keeps the tile geometry and the MFMA loop
+// and takes the memory phases off the MFMA waves' timeline:
+//   * persistent workgroups (one per CU) walk the tiles; a stage = (tile, 64-channel input slab)
+//   * 6 waves: waves 0-3 only read LDS, issue MFMAs and store their accumulators; wave 4 streams the per-tap weight slices
+//     and wave 5 the input patches, both by LDS-DMA (global_load_lds, no VGPR staging).  vmcnt is per wave and counts
+//     in issue order, so giving each stream its own wave is what lets the next PATCH stay in flight for a whole stage
+//     (9 taps) while the weight slices are waited on tap by tap, and keeps the MFMA waves' own stores out of both waits.
+//   * one s_barrier per tap is the only synchronisation: passing barrier u means "tap u's weights (and, at tap 0, the
+//     stage's patch) have landed" and "everybody is done with tap u-1's buffers".
+//   * LDS images are unpadded 128-byte rows (a DMA wave-instruction writes 1 KiB linearly); the bank-conflict fix is an
+//     XOR of the 16-byte chunk index with (patch column & 7) / (weight row & 7), applied to the DMA source address and to
+//     the fragment reads.  Halo pixels outside the image are fetched from a zero line.
+//   * weight rows are permuted on their way into LDS so that a lane's accumulators of two adjacent 16-channel blocks are 8
+//     CONSECUTIVE output channels: the epilogue is bias/ReLU in registers and one 16-byte global store per (pixel
+//     tile, 32-channel group) -- no LDS round trip, no barrier; the 2x2 max-pool is taken across registers and lanes.
+__device__ __attribute__((aligned(128))) bf16 g_zero_line[64];
+__device__ unsigned g_conv_sched[2];                      // tile counter of launches that bring none (single-stream tools and tests)
+
+template <int CIN, int COUT, int TH, int TW, bool PROF = false>
+__global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int ntiles, int tiles_x, int tiles_y, int chunk) {
+    constexpr int PW = TW + 2, PH = TH + 2, RPT = 16 / TW;
+    constexpr int MF = TH * TW / 64, NF = COUT / 16, NH = NF / 2;
+    constexpr int KTOT = 9 * CIN, NSLAB = CIN / 64;
+    constexpr int D = 4;                                   // weight ring: slices u+1 (being read ahead), u, and two in flight
+    constexpr int PPIECES = (PH * PW + 7) / 8;             // 1 KiB DMA pieces per patch (8 pixels x 128 B)
+    constexpr int PCHUNK = (PPIECES + 5) / 6;              // the next patch is issued over taps 0..5, PCHUNK pieces after each barrier
+    constexpr int PBYTES = PPIECES * 1024, WPIECES = COUT / 8, WBYTES = COUT * 128;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * PBYTES + D * WBYTES];
+    __shared__ int tileq[4];                               // tile ids of this workgroup's k-th, k+1-th, ... tile (-1 = none)
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    typedef __attribute__((ext_vector_type(2))) short short2_t;
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    char* const pbuf = lds;
+    char* const wbuf = lds + 2 * PBYTES;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int H = a.H, W = a.W;
+    // Tiles are handed out by an atomic counter (a.sched[0]), not by a static stride: under concurrent streams some of the
+    // "resident" workgroups start late, and with a static split the launch would last until those had walked their full
+    // share.  The patch wave fetches two tiles ahead and publishes the ids through tileq; every wave derives the same
+    // sequence of stages = (tile, 64-channel slab) from it.  The last workgroup to run dry re-arms the counter.
+    // Barrier protocol (every wave executes 1 + 9 x stages barriers): passing the opening barrier means slice 0, patch 0 and
+    // tileq[0..1] are in; passing barrier u (in the MIDDLE of tap u) means slice u+1 -- and at the last tap of a stage the next
+    // stage's patch -- have landed, and that every MFMA wave is done with tap u-1's slice (and, at the first tap of a
+    // stage, with the previous stage's patch).  The MFMA waves read the fragments of the next half-tap before issuing the
+    // MFMAs of the current one, so the barrier wait and the LDS latency sit under 16 MFMAs already in the pipe.
+    // PROF instances (tools/prof_conv_phases.py), cycles per workgroup: MFMA wave 0 [0] start-up [1] tap loops (reads, MFMAs,
+    // barriers) [2] epilogues; weight wave [3] waiting for slices; patch wave [4] issuing DMAs [5] waiting for the patch
+    // PROF instances also take ablation bits in a.relu >> 8: 1 = no patch DMA after the first, 2 = no weight DMA after the
+    // first ring fill, 4 = no epilogue (results are then garbage; timing only)
+    const int dbg = PROF ? a.relu >> 8 : 0;
+    long pt[3] = {0, 0, 0};
+    long tprev = PROF ? clock64() : 0;
+    auto stamp = [&](int k) { if constexpr (PROF) { const long now = clock64(); pt[k] += now - tprev; tprev = now; } };
+    auto read_tileq = [&](int k) { return __builtin_amdgcn_readfirstlane(*(volatile int*)&tileq[k & 3]); };
+
+    if (wave == 4) {
+        // ---------------- weight stream: slice (slab, tap) = [COUT rows][64 ci], LDS row r holds channel perm(r).
+        // Slices do not depend on the tile, so the stream simply runs three ahead and is drained at the end.
+        const int sub = lane >> 3, sl = lane & 7;
+        const bf16* wsrc[WPIECES];
+#pragma unroll
+        for (int i = 0; i < WPIECES; ++i) {
+            const int r = i * 8 + sub, j = r >> 4, m = r & 15;
+            const int co = (j >> 1) * 32 + (m >> 2) * 8 + (j & 1) * 4 + (m & 3);
+            wsrc[i] = a.wk + (long)co * KTOT + ((sl ^ (r & 7)) * 8);
+        }
+        int is = 0, it = 0, islot = 0;
+        auto issue_next = [&]() {
+            const int off = it * CIN + is * 64;
+#pragma unroll
+            for (int i = 0; i < WPIECES; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t*)(wsrc[i] + off), (lptr_t*)(wbuf + islot * WBYTES + i * 1024), 16, 0, 0);
+            islot = (islot + 1) & (D - 1);
+            if (++it == 9) { it = 0; if (++is == NSLAB) is = 0; }
+        };
+        for (int k = 0; k < D - 1; ++k) issue_next();
+        stamp(1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WPIECES) : "memory");
+        stamp(0);
+        asm volatile("s_barrier" ::: "memory");           // opening barrier: slice 0 is in
+        for (int k = 0; read_tileq(k) >= 0; ++k) {
+            for (int u = 0; u < 9 * NSLAB; ++u) {
+                stamp(1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPIECES) : "memory");   // slice u+1 is in, u+2 may be in flight
+                stamp(0);
+                asm volatile("s_barrier" ::: "memory");
+                if (!(dbg & 2)) issue_next();              // slice u+3 -> the slot of tap u-1
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the read-ahead past the last tile lands before the LDS is released
+        if constexpr (PROF) { if (lane == 0) a.prof[blockIdx.x * 6 + 3] = pt[0]; }
+        return;
+    }
+    if (wave == 5) {
+        // ---------------- patch stream.  Per-piece source offsets relative to the tile origin are fixed for the launch.
+        const int sub = lane >> 3, sl = lane & 7;
+        int rel[PPIECES], pij[PPIECES];
+#pragma unroll
+        for (int i = 0; i < PPIECES; ++i) {
+            int p = i * 8 + sub;
+            if (p >= PH * PW) p = PH * PW - 1;             // tail lanes of the last piece: any valid pixel (never read back)
+            const int pi = p / PW, pj = p % PW;
+            rel[i] = ((pi - 1) * W + (pj - 1)) * CIN + (sl ^ (pj & 7)) * 8;
+            pij[i] = pi << 8 | pj;
+        }
+        const bf16* zsrc = g_zero_line + sl * 8;
+        const bf16* org = nullptr;                         // in + image b + tile origin + slab, of the patch being issued
+        int t0 = 0, d0 = 0;
+        bool interior = false;
+        auto begin_patch = [&](int tile, int slab) {
+            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+            d0 = tx * TW; t0 = ty * TH;
+            org = a.in + ((long)b * H * W + (long)t0 * W + d0) * CIN + slab * 64;
+            interior = t0 >= 1 && t0 + TH + 1 <= H && d0 >= 1 && d0 + TW + 1 <= W;
+        };
+        auto issue_pieces = [&](int g, int first, int count) {
+            char* dst = pbuf + (g & 1) * PBYTES;
+            if (interior) {
+#pragma unroll
+                for (int i = 0; i < PPIECES; ++i)
+                    if (i >= first && i < first + count)
+                        __builtin_amdgcn_global_load_lds((gptr_t*)(org + rel[i]), (lptr_t*)(dst + i * 1024), 16, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < PPIECES; ++i)
+                    if (i >= first && i < first + count) {
+                        const int t = t0 + (pij[i] >> 8) - 1, d = d0 + (pij[i] & 255) - 1;
+                        const bf16* src = (t >= 0 && t < H && d >= 0 && d < W) ? org + rel[i] : zsrc;
+                        __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(dst + i * 1024), 16, 0, 0);
+                    }
+            }
+        };
+        // tile fetch: the counter value comes back through vmcnt like any load, so a fetch is issued at the first tap of a
+        // tile and only looked at (resolve) at its last one.  `dry`: a workgroup reports running dry exactly once.
+        bool dry = false;
+        // chunk > 0: no counter, workgroup w owns tiles [w * chunk, (w + 1) * chunk) -- short-lived workgroups that give the CU
+        // back every few tiles, for runs where other streams' kernels should be able to slip in between
+        unsigned own = blockIdx.x * (unsigned)chunk;
+        const unsigned lim = chunk > 0 ? (own + chunk < (unsigned)ntiles ? own + chunk : (unsigned)ntiles) : (unsigned)ntiles;
+        auto issue_fetch = [&](unsigned n) -> unsigned {
+            unsigned t = 0;
+            if (chunk > 0) { t = own; own += n; }
+            else if (!dry && lane == 0) t = atomicAdd(&a.sched[0], n);
+            return t;
+        };
+        auto went_dry = [&]() {
+            dry = true;
+            if (chunk == 0 && lane == 0 && atomicAdd(&a.sched[1], 1u) == gridDim.x - 1) { atomicExch(&a.sched[0], 0u); atomicExch(&a.sched[1], 0u); }
+        };
+        auto resolve = [&](unsigned raw) -> int {
+            if (dry) return -1;
+            const unsigned t = __builtin_amdgcn_readfirstlane(raw);
+            if (t >= lim) { went_dry(); return -1; }
+            return (int)t;
+        };
+        int cur, nxt;
+        {   // the first two tiles come from one fetch of 2
+            const unsigned t = __builtin_amdgcn_readfirstlane(issue_fetch(2u));
+            cur = t < lim ? (int)t : -1;
+            nxt = t + 1 < lim ? (int)t + 1 : -1;
+            if (nxt < 0) went_dry();
+        }
+        if (lane == 0) { tileq[0] = cur; tileq[1] = nxt; }
+        if (cur >= 0) { begin_patch(cur, 0); issue_pieces(0, 0, PPIECES); }
+        stamp(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        stamp(1);
+        asm volatile("s_barrier" ::: "memory");           // opening barrier: patch 0 and tileq[0..1] are in
+        int g = 0;
+        for (int k = 0; cur >= 0; ++k) {
+            int nn = -1;
+            unsigned raw = 0;
+#pragma unroll 1
+            for (int slab = 0; slab < NSLAB; ++slab, ++g) {
+                const bool last_slab = slab == NSLAB - 1;
+                const bool more = !last_slab || nxt >= 0;
+                if (more) begin_patch(last_slab ? nxt : cur, last_slab ? 0 : slab + 1);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    stamp(2);
+                    if (tap == 8) {
+                        if (slab == 0) {
+                            nn = resolve(raw);
+                            if (lane == 0) tileq[(k + 2) & 3] = nn;
+                        }
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the next stage's patch (and tile id) is in
+                    }
+                    stamp(1);
+                    asm volatile("s_barrier" ::: "memory");
+                    stamp(2);
+                    if (tap == 0 && slab == 0) raw = issue_fetch(1u);                  // the tile after next, two tiles ahead
+                    if (tap < 6 && more && !(dbg & 1)) issue_pieces(g + 1, tap * PCHUNK, PCHUNK);
+                    stamp(0);
+                }
+            }
+            cur = nxt; nxt = nn;
+        }
+        if constexpr (PROF) { if (lane == 0) { a.prof[blockIdx.x * 6 + 4] = pt[0]; a.prof[blockIdx.x * 6 + 5] = pt[1]; } }
+        return;
+    }
+
+    // ---------------- MFMA waves
+    const int rr = lane & 15, q = lane >> 4;
+    const int pcol0 = rr % TW, prow0 = wave * MF * RPT + rr / TW;
+    int poff[3][2], woff[2];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+        woff[kc] = rr * 128 + (((kc * 4 + q) ^ (rr & 7)) * 16);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) poff[dx][kc] = (prow0 * PW + pcol0 + dx) * 128 + (((kc * 4 + q) ^ ((pcol0 + dx) & 7)) * 16);
+    }
+    // lane (rr, q) ends up with channels h*32 + q*8 .. +7 of pixel rr of each pixel tile
+    f32x2 bv[NH][4];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bv[h][k][0] = a.bias ? a.bias[h * 32 + q * 8 + 2 * k] : 0.f;
+            bv[h][k][1] = a.bias ? a.bias[h * 32 + q * 8 + 2 * k + 1] : 0.f;
+        }
+
+    // One half-tap = MF*NF MFMAs on one fragment set while the reads of the NEXT set are issued in their shadow, one read
+    // after each of the first MF+NF MFMAs (an MFMA holds the pipe for 16 cycles, the wave is free to issue in between; with
+    // all the reads issued up front the pipe idles for their issue time every half-tap).  sched_barrier(0) after every
+    // instruction pins exactly this order.  The reads are inline asm waited on by hand: the compiler's own bookkeeping would
+    // put a full lgkmcnt(0) between a set's reads and the MFMAs of the previous set, an exposed LDS round trip per half-tap.
+    struct Frags { bf16x8 a[MF], b[NF]; };
+    typedef __attribute__((address_space(3))) const char lds_cchar;
+    f32x4 acc[MF][NF];
+    auto half_tap = [&](const Frags& use, Frags& ld, const char* pl, const char* wl, int tap, int kc) {
+        const int dy = tap / 3, dx = tap % 3;
+        const unsigned pa = (unsigned)(size_t)((lds_cchar*)pl) + poff[dx][kc];
+        const unsigned wa = (unsigned)(size_t)((lds_cchar*)wl) + woff[kc];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MF * NF; ++m) {
+            const int i = m / NF, j = m % NF;
+            acc[i][j] = mma16(use.b[j], use.a[i], acc[i][j]);   // weights as A: a lane ends up with 4 consecutive channels
+            __builtin_amdgcn_sched_barrier(0);
+            if (m < MF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ld.a[m < MF ? m : 0]) : "v"(pa), "n"(((m < MF ? m : 0) * RPT + dy) * PW * 128));
+            else if (m < MF + NF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ld.b[m < MF + NF ? m - MF : 0]) : "v"(wa), "n"((m < MF + NF ? m - MF : 0) * 2048));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto load_frags = [&](Frags& f, const char* pcur, const char* wcur, int tap, int kc) {
+        const int dy = tap / 3, dx = tap % 3;
+        const unsigned pa = (unsigned)(size_t)((lds_cchar*)pcur) + poff[dx][kc];
+        const unsigned wa = (unsigned)(size_t)((lds_cchar*)wcur) + woff[kc];
+#pragma unroll
+        for (int i = 0; i < MF; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.a[i]) : "v"(pa), "n"((i * RPT + dy) * PW * 128));
+#pragma unroll
+        for (int j = 0; j < NF; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.b[j]) : "v"(wa), "n"(j * 2048));
+    };
+
+    Frags f0, f1;
+    stamp(2);
+    asm volatile("s_barrier" ::: "memory");               // opening barrier
+    int tile = read_tileq(0);
+    if (tile >= 0) load_frags(f0, pbuf, wbuf, 0, 0);
+    stamp(0);
+    int g = 0;
+    for (int k = 0; tile >= 0; ++k) {
+        // this lane's output addressing for the tile
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int d0 = tx * TW, t0 = ty * TH;
+        const int tl = t0 + prow0, dl = d0 + pcol0;        // this lane's pixel of pixel tile 0
+        const unsigned voff = (unsigned)((tl * W + dl) * COUT + q * 8) * 2u;
+        char* out_b = reinterpret_cast<char*>(a.out) + (long)b * H * W * COUT * 2;
+        auto row_ok = [&](int i) { return tl + i * RPT < H && dl < W; };
+        auto row_off = [&](int i) { return voff + (unsigned)(i * RPT) * (unsigned)(W * COUT * 2); };
+        int next_tile = -1;
+#pragma unroll 1
+        for (int slab = 0; slab < NSLAB; ++slab, ++g) {
+            if (slab == 0) {
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            const char* pcur = pbuf + (g & 1) * PBYTES;
+            const char* pnext = pbuf + ((g + 1) & 1) * PBYTES;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const char* wcur = wbuf + ((g + tap) & (D - 1)) * WBYTES;          // 9 g + tap = g + tap (mod 4)
+                const char* wnext = wbuf + ((g + tap + 1) & (D - 1)) * WBYTES;
+                // first half: MFMAs on f0 (read during the previous half-tap), reads of this tap's second k-half into f1
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                half_tap(f0, f1, pcur, wcur, tap, 1);
+                // barrier u: slice u+1 (and at tap 8 the next patch) is in.  lgkmcnt(0): every LDS read this wave has issued is
+                // complete before the producers may overwrite tap u-1's buffers, and f1 is ready
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                // second half: MFMAs on f1, reads of the next tap's first k-half into f0 (after the very last tap of the
+                // workgroup these read stale LDS and are never used)
+                if (tap < 8) half_tap(f1, f0, pcur, wnext, tap + 1, 0);
+                else half_tap(f1, f0, pnext, wnext, 0, 0);
+            }
+            if (slab == NSLAB - 1) next_tile = read_tileq(k + 1);
+        }
+        stamp(1);
+        tile = next_tile;
+        if (dbg & 4) continue;
+
+        // epilogue of the tile, straight from the accumulators: bias in fp32, round to bf16, then ReLU / pool as
+        // packed 16-bit integer ops (for bf16 bit patterns max(x, 0) is max_i16(x, 0), and non-negative values order like integers)
+        const int H2 = H / 2, W2 = W / 2;
+        constexpr int IP = (TW == 16) ? 2 : 1;             // pixel tiles per pooling group (TW = 16: two rows = two tiles)
+        const short fl = (a.relu & 255) ? (short)0 : (short)-32768;
+        const short2_t floor2 = {fl, fl};
+        short2_t pm[NH][4];
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const bool ok = row_ok(i);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const unsigned o = row_off(i) + h * 64;
+                short2_t pk[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const f32x4& c = acc[i][2 * h + (kk >> 1)];
+                    f32x2 v = {c[2 * (kk & 1)], c[2 * (kk & 1) + 1]};
+                    v += bv[h][kk];
+                    unsigned r;
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(v[0]), "v"(v[1]));
+                    pk[kk] = __builtin_elementwise_max(__builtin_bit_cast(short2_t, r), floor2);   // ReLU (or a no-op)
+                }
+                if (ok) {
+                    u32x4 ov;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) ov[kk] = __builtin_bit_cast(unsigned, pk[kk]);
+                    *reinterpret_cast<u32x4*>(out_b + o) = ov;
+                }
+                if (a.pool_out) {
+                    // 2 x 2 window (ReLU'd values only): the row pair is (tile i, tile i+1) for TW = 16 and (lane, lane ^ 8)
+                    // for TW = 8; the column pair is (lane, lane ^ 1)
+                    if (IP == 2 && (i & 1) == 0) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) pm[h][kk] = pk[kk];
+                    } else {
+                        u32x4 po;
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            short2_t x = IP == 2 ? __builtin_elementwise_max(pm[h][kk], pk[kk]) : pk[kk];
+                            if constexpr (TW == 8) {
+                                const int o8 = __shfl_xor(__builtin_bit_cast(int, x), 8);
+                                x = __builtin_elementwise_max(x, __builtin_bit_cast(short2_t, o8));
+                            }
+                            const int o1 = __shfl_xor(__builtin_bit_cast(int, x), 1);
+                            x = __builtin_elementwise_max(x, __builtin_bit_cast(short2_t, o1));
+                            po[kk] = __builtin_bit_cast(unsigned, x);
+                        }
+                        const int t2 = (tl + (i - (IP - 1)) * RPT) >> 1, d2 = dl >> 1;
+                        const bool owner = (rr & 1) == 0 && (TW == 16 || rr < 8);
+                        if (owner && t2 < H2 && d2 < W2)
+                            *reinterpret_cast<u32x4*>(a.pool_out + (((long)b * H2 + t2) * W2 + d2) * COUT + h * 32 + q * 8) = po;
+                    }
+                }
+            }
+        }
+        stamp(2);
+    }
+    if constexpr (PROF) {
+        if (wave == 0 && lane == 0) { a.prof[blockIdx.x * 6 + 0] = pt[0]; a.prof[blockIdx.x * 6 + 1] = pt[1]; a.prof[blockIdx.x * 6 + 2] = pt[2]; }
+    }
+}
+
+// ------------------------------------------------------------------ streaming 3x3, 64 -> 64 channels: weights resident in LDS
+// The streaming kernel above is bound by the CU's vector-memory issue rate, not by bytes: every 1 KiB wave-instruction
+// (LDS-DMA piece or 16-byte-per-lane store) costs the texture addresser ~65 cycles, and a 16 x 16 tile needs 41 (patch)
+// + 72 (nine 8 KiB weight slices) + 32 (stores) of them against 4.6k cycles of MFMA.  With 64 input and 64 output
+// channels the whole filter bank is 72 KiB: a persistent workgroup loads it ONCE, which halves the instruction count per
+// tile, removes the weight wave and leaves one barrier per tile (patch hand-over) instead of nine.
+// LDS: 9 x [64 rows][128 B] weights (rows permuted, chunks XOR-swizzled as above) + two patches = 154 KiB.
+template <int TH, int TW, bool PROF = false>
+__global__ __launch_bounds__(320) void conv3x3_resw_kernel(ConvArgs a, int ntiles, int tiles_x, int tiles_y, int chunk) {
+    constexpr int CIN = 64, COUT = 64;
+    constexpr int PW = TW + 2, PH = TH + 2, RPT = 16 / TW;
+    constexpr int MF = TH * TW / 64, NF = COUT / 16, NH = NF / 2;
+    constexpr int KTOT = 9 * CIN;
+    constexpr int PPIECES = (PH * PW + 7) / 8;             // 1 KiB DMA pieces per patch (8 pixels x 128 B)
+    constexpr int PBYTES = PPIECES * 1024, WBYTES = COUT * 128;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * PBYTES + 9 * WBYTES];
+    __shared__ int tileq[4];
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    typedef __attribute__((ext_vector_type(2))) short short2_t;
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    char* const pbuf = lds;
+    char* const wres = lds + 2 * PBYTES;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int H = a.H, W = a.W;
+    const int dbg = PROF ? a.relu >> 8 : 0;                // ablation bits as in the streaming kernel (1, 4)
+    long pt[3] = {0, 0, 0};
+    long tprev = PROF ? clock64() : 0;
+    auto stamp = [&](int k) { if constexpr (PROF) { const long now = clock64(); pt[k] += now - tprev; tprev = now; } };
+    auto read_tileq = [&](int k) { return __builtin_amdgcn_readfirstlane(*(volatile int*)&tileq[k & 3]); };
+
+    {   // the filter bank: 72 pieces of 8 rows, dealt round-robin to the 5 waves
+        const int sub = lane >> 3, sl = lane & 7;
+#pragma unroll
+        for (int n = 0; n < (72 + 4) / 5; ++n) {
+            const int pc = n * 5 + wave;
+            if (pc < 72) {
+                const int tap = pc >> 3, i = pc & 7;
+                const int r = i * 8 + sub, j = r >> 4, m = r & 15;
+                const int co = (j >> 1) * 32 + (m >> 2) * 8 + (j & 1) * 4 + (m & 3);
+                const bf16* src = a.wk + (long)co * KTOT + tap * CIN + ((sl ^ (r & 7)) * 8);
+                __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(wres + pc * 1024), 16, 0, 0);
+            }
+        }
+    }
+
+    if (wave == 4) {
+        // ---------------- patch stream (see the streaming kernel); barrier g hands patch g over and frees patch g-1's buffer
+        const int sub = lane >> 3, sl = lane & 7;
+        int rel[PPIECES], pij[PPIECES];
+#pragma unroll
+        for (int i = 0; i < PPIECES; ++i) {
+            int p = i * 8 + sub;
+            if (p >= PH * PW) p = PH * PW - 1;
+            const int pi = p / PW, pj = p % PW;
+            rel[i] = ((pi - 1) * W + (pj - 1)) * CIN + (sl ^ (pj & 7)) * 8;
+            pij[i] = pi << 8 | pj;
+        }
+        const bf16* zsrc = g_zero_line + sl * 8;
+        auto issue_patch = [&](int tile, int g) {
+            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+            const int d0 = tx * TW, t0 = ty * TH;
+            const bf16* org = a.in + ((long)b * H * W + (long)t0 * W + d0) * CIN;
+            const bool interior = t0 >= 1 && t0 + TH + 1 <= H && d0 >= 1 && d0 + TW + 1 <= W;
+            char* dst = pbuf + (g & 1) * PBYTES;
+            if (interior) {
+#pragma unroll
+                for (int i = 0; i < PPIECES; ++i)
+                    __builtin_amdgcn_global_load_lds((gptr_t*)(org + rel[i]), (lptr_t*)(dst + i * 1024), 16, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < PPIECES; ++i) {
+                    const int t = t0 + (pij[i] >> 8) - 1, d = d0 + (pij[i] & 255) - 1;
+                    const bf16* src = (t >= 0 && t < H && d >= 0 && d < W) ? org + rel[i] : zsrc;
+                    __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(dst + i * 1024), 16, 0, 0);
+                }
+            }
+        };
+        bool dry = false;
+        // chunk > 0: no counter, workgroup w owns tiles [w * chunk, (w + 1) * chunk) -- short-lived workgroups that give the CU
+        // back every few tiles, for runs where other streams' kernels should be able to slip in between
+        unsigned own = blockIdx.x * (unsigned)chunk;
+        const unsigned lim = chunk > 0 ? (own + chunk < (unsigned)ntiles ? own + chunk : (unsigned)ntiles) : (unsigned)ntiles;
+        auto issue_fetch = [&](unsigned n) -> unsigned {
+            unsigned t = 0;
+            if (chunk > 0) { t = own; own += n; }
+            else if (!dry && lane == 0) t = atomicAdd(&a.sched[0], n);
+            return t;
+        };
+        auto went_dry = [&]() {
+            dry = true;
+            if (chunk == 0 && lane == 0 && atomicAdd(&a.sched[1], 1u) == gridDim.x - 1) { atomicExch(&a.sched[0], 0u); atomicExch(&a.sched[1], 0u); }
+        };
+        int cur, nxt;
+        {
+            const unsigned t = __builtin_amdgcn_readfirstlane(issue_fetch(2u));
+            cur = t < lim ? (int)t : -1;
+            nxt = t + 1 < lim ? (int)t + 1 : -1;
+            if (nxt < 0) went_dry();
+        }
+        if (lane == 0) { tileq[0] = cur; tileq[1] = nxt; }
+        if (cur >= 0) issue_patch(cur, 0);
+        stamp(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        stamp(1);
+        asm volatile("s_barrier" ::: "memory");           // opening barrier: weights (every wave's share), patch 0, tileq[0..1]
+        for (int k = 0; cur >= 0; ++k) {
+            // tile k is being computed: fetch the id of tile k+2, stream tile k+1's patch, publish, hand over
+            const unsigned raw = issue_fetch(1u);
+            stamp(2);
+            if (nxt >= 0 && !(dbg & 1)) issue_patch(nxt, k + 1);
+            stamp(0);
+            int nn = -1;
+            if (!dry) {
+                const unsigned t = __builtin_amdgcn_readfirstlane(raw);
+                if (t >= lim) went_dry(); else nn = (int)t;
+            }
+            if (lane == 0) tileq[(k + 2) & 3] = nn;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            stamp(1);
+            asm volatile("s_barrier" ::: "memory");       // barrier k (middle of tile k's last tap)
+            cur = nxt; nxt = nn;
+        }
+        if constexpr (PROF) { if (lane == 0) { a.prof[blockIdx.x * 6 + 4] = pt[0]; a.prof[blockIdx.x * 6 + 5] = pt[1]; } }
+        return;
+    }
+
+    // ---------------- MFMA waves
+    const int rr = lane & 15, q = lane >> 4;
+    const int pcol0 = rr % TW, prow0 = wave * MF * RPT + rr / TW;
+    int poff[3][2], woff[2];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+        woff[kc] = rr * 128 + (((kc * 4 + q) ^ (rr & 7)) * 16);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) poff[dx][kc] = (prow0 * PW + pcol0 + dx) * 128 + (((kc * 4 + q) ^ ((pcol0 + dx) & 7)) * 16);
+    }
+    f32x2 bv[NH][4];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bv[h][k][0] = a.bias ? a.bias[h * 32 + q * 8 + 2 * k] : 0.f;
+            bv[h][k][1] = a.bias ? a.bias[h * 32 + q * 8 + 2 * k + 1] : 0.f;
+        }
+    struct Frags { bf16x8 a[MF], b[NF]; };
+    typedef __attribute__((address_space(3))) const char lds_cchar;
+    const unsigned wbase = (unsigned)(size_t)((lds_cchar*)wres);
+    f32x4 acc[MF][NF];
+    // half_tap: MF*NF MFMAs on `use`, the reads of `ld` issued in their shadow (see the streaming kernel)
+    auto half_tap = [&](const Frags& use, Frags& ld, const char* pl, int tap, int kc) {
+        const int dy = tap / 3, dx = tap % 3;
+        const unsigned pa = (unsigned)(size_t)((lds_cchar*)pl) + poff[dx][kc];
+        const unsigned wa = wbase + woff[kc] + tap * WBYTES;   // (the DS offset field is 16 bits: the tap's 8 KiB stride goes here)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MF * NF; ++m) {
+            const int i = m / NF, j = m % NF;
+            acc[i][j] = mma16(use.b[j], use.a[i], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (m < MF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ld.a[m < MF ? m : 0]) : "v"(pa), "n"(((m < MF ? m : 0) * RPT + dy) * PW * 128));
+            else if (m < MF + NF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ld.b[m < MF + NF ? m - MF : 0]) : "v"(wa), "n"((m < MF + NF ? m - MF : 0) * 2048));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    Frags f0, f1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of the weights
+    stamp(2);
+    asm volatile("s_barrier" ::: "memory");               // opening barrier
+    int tile = read_tileq(0);
+    {   // fragments of (tap 0, first k-half)
+        const unsigned pa = (unsigned)(size_t)((lds_cchar*)pbuf) + poff[0][0];
+        const unsigned wa = wbase + woff[0];
+#pragma unroll
+        for (int i = 0; i < MF; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f0.a[i]) : "v"(pa), "n"(i * RPT * PW * 128));
+#pragma unroll
+        for (int j = 0; j < NF; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f0.b[j]) : "v"(wa), "n"(j * 2048));
+    }
+    stamp(0);
+    for (int k = 0; tile >= 0; ++k) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int d0 = tx * TW, t0 = ty * TH;
+        const int tl = t0 + prow0, dl = d0 + pcol0;
+        const unsigned voff = (unsigned)((tl * W + dl) * COUT + q * 8) * 2u;
+        char* out_b = reinterpret_cast<char*>(a.out) + (long)b * H * W * COUT * 2;
+        auto row_ok = [&](int i) { return tl + i * RPT < H && dl < W; };
+        auto row_off = [&](int i) { return voff + (unsigned)(i * RPT) * (unsigned)(W * COUT * 2); };
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* pcur = pbuf + (k & 1) * PBYTES;
+        const char* pnext = pbuf + ((k + 1) & 1) * PBYTES;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            half_tap(f0, f1, pcur, tap, 1);
+            if (tap < 8) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                half_tap(f1, f0, pcur, tap + 1, 0);
+            } else {
+                // barrier k: the next tile's patch and tileq[k+1..k+2] are in; this wave will not read patch k again
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                half_tap(f1, f0, pnext, 0, 0);            // (after the last tile: stale LDS, never used)
+            }
+        }
+        const int next_tile = read_tileq(k + 1);
+        stamp(1);
+        tile = next_tile;
+        if (dbg & 4) continue;
+
+        // epilogue as in the streaming kernel
+        const int H2 = H / 2, W2 = W / 2;
+        constexpr int IP = (TW == 16) ? 2 : 1;
+        const short fl = (a.relu & 255) ? (short)0 : (short)-32768;
+        const short2_t floor2 = {fl, fl};
+        short2_t pm[NH][4];
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const bool ok = row_ok(i);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const unsigned o = row_off(i) + h * 64;
+                short2_t pk[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const f32x4& c = acc[i][2 * h + (kk >> 1)];
+                    f32x2 v = {c[2 * (kk & 1)], c[2 * (kk & 1) + 1]};
+                    v += bv[h][kk];
+                    unsigned r;
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(v[0]), "v"(v[1]));
+                    pk[kk] = __builtin_elementwise_max(__builtin_bit_cast(short2_t, r), floor2);
+                }
+                if (ok) {
+                    u32x4 ov;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) ov[kk] = __builtin_bit_cast(unsigned, pk[kk]);
+                    *reinterpret_cast<u32x4*>(out_b + o) = ov;
+                }
+                if (a.pool_out) {
+                    if (IP == 2 && (i & 1) == 0) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) pm[h][kk] = pk[kk];
+                    } else {
+                        u32x4 po;
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            short2_t x = IP == 2 ? __builtin_elementwise_max(pm[h][kk], pk[kk]) : pk[kk];
+                            if constexpr (TW == 8) {
+                                const int o8 = __shfl_xor(__builtin_bit_cast(int, x), 8);
+                                x = __builtin_elementwise_max(x, __builtin_bit_cast(short2_t, o8));
+                            }
+                            const int o1 = __shfl_xor(__builtin_bit_cast(int, x), 1);
+                            x = __builtin_elementwise_max(x, __builtin_bit_cast(short2_t, o1));
+                            po[kk] = __builtin_bit_cast(unsigned, x);
+                        }
+                        const int t2 = (tl + (i - (IP - 1)) * RPT) >> 1, d2 = dl >> 1;
+                        const bool owner = (rr & 1) == 0 && (TW == 16 || rr < 8);
+                        if (owner && t2 < H2 && d2 < W2)
+                            *reinterpret_cast<u32x4*>(a.pool_out + (((long)b * H2 + t2) * W2 + d2) * COUT + h * 32 + q * 8) = po;
+                    }
+                }
+            }
+        }
+        stamp(2);
+    }
+    if constexpr (PROF) {
+        if (wave == 0 && lane == 0) { a.prof[blockIdx.x * 6 + 0] = pt[0]; a.prof[blockIdx.x * 6 + 1] = pt[1]; a.prof[blockIdx.x * 6 + 2] = pt[2]; }
     }
 }
 
@@ -917,6 +1583,56 @@ int mk_conv1_wgrad_fused_reduce(const float* slab, int B, int H, int W, float* d
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// persistent grid of the streaming kernel: as many workgroups as fit on the chip at once (1 or 2 per CU)
+// tiles per workgroup of the streaming kernels: 0 = persistent workgroups fed by the tile counter
+static int stream_chunk() {
+    static const int c = getenv("MASR_CONV_CHUNK") ? atoi(getenv("MASR_CONV_CHUNK")) : 0;
+    return c;
+}
+template <bool PROF = false>
+static void launch_resw(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
+    static int resident = 0;
+    if (!resident) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&resident, hipDeviceAttributeMultiprocessorCount, dev);
+        if (resident <= 0) resident = 256;
+    }
+    const int ntiles = tiles_x * tiles_y * a.B;
+    ConvArgs b = a;
+    if (!b.sched) {
+        static unsigned* fallback = nullptr;
+        if (!fallback) hipGetSymbolAddress((void**)&fallback, HIP_SYMBOL(g_conv_sched));
+        b.sched = fallback;
+    }
+    const int chunk = stream_chunk();
+    const int grid = chunk > 0 ? (ntiles + chunk - 1) / chunk : (ntiles < resident ? ntiles : resident);
+    hipLaunchKernelGGL((conv3x3_resw_kernel<16, 16, PROF>), dim3((unsigned)grid), dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, chunk);
+}
+template <int CI, int CO, int TWV, bool PROF = false>
+static void launch_stream(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
+    static int resident = 0;
+    if (!resident) {
+        int dev = 0, ncu = 0, per_cu = 0;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3x3_stream_kernel<CI, CO, 16, TWV, PROF>, 384, 0);
+        if (ncu <= 0) ncu = 256;
+        if (per_cu <= 0) per_cu = 1;
+        static const int cap = getenv("MASR_CONV_STREAM_WGPC") ? atoi(getenv("MASR_CONV_STREAM_WGPC")) : 2;
+        resident = ncu * (per_cu < cap ? per_cu : cap);
+    }
+    const int ntiles = tiles_x * tiles_y * a.B;
+    ConvArgs b = a;
+    if (!b.sched) {
+        static unsigned* fallback = nullptr;
+        if (!fallback) hipGetSymbolAddress((void**)&fallback, HIP_SYMBOL(g_conv_sched));
+        b.sched = fallback;
+    }
+    const int chunk = stream_chunk();
+    const int grid = chunk > 0 ? (ntiles + chunk - 1) / chunk : (ntiles < resident ? ntiles : resident);
+    hipLaunchKernelGGL((conv3x3_stream_kernel<CI, CO, 16, TWV, PROF>), dim3((unsigned)grid), dim3(384), 0, s, b, ntiles, tiles_x, tiles_y, chunk);
+}
 int mk_conv3x3(const ConvArgs& a, hipStream_t s) {
     if (getenv("MASR_CONV_V1")) {                          // first-generation im2col-on-the-fly kernel (kept for A/B runs)
         const long P = (long)a.B * a.H * a.W;
@@ -930,14 +1646,50 @@ int mk_conv3x3(const ConvArgs& a, hipStream_t s) {
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     auto grid = [&](int TH) { return dim3((a.W + 15) / 16, (a.H + TH - 1) / TH, a.B); };
+    if (a.prof) {                                          // phase-timing instances of the four Transformer front-end shapes
+        const bool nar = a.W % 16 != 0;
+        const int TWv = nar ? 8 : 16;
+        const int tiles_x = (a.W + TWv - 1) / TWv, tiles_y = (a.H + 15) / 16;
+        if (getenv("MASR_CONV_STREAM") && atoi(getenv("MASR_CONV_STREAM")) == 0) {
+            auto grid8 = [&](int TH) { return dim3((a.W + 7) / 8, (a.H + TH - 1) / TH, a.B); };
+            if (a.CIN == 64 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<64, 64, 16, false, 16, true>), grid(16), dim3(256), 0, s, a);
+            else if (a.CIN == 64 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<64, 128, 16, false, 8, true>), grid8(16), dim3(256), 0, s, a);
+            else if (a.CIN == 128 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 128, 16, false, 8, true>), grid8(16), dim3(256), 0, s, a);
+            else if (a.CIN == 128 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 64, 16, false, 8, true>), grid8(16), dim3(256), 0, s, a);
+            else { mk_set_error("mk_conv3x3", "no phase-timing instance for this shape"); return -1; }
+        } else if (a.CIN == 64 && a.COUT == 64 && !nar && !(getenv("MASR_CONV_RESW") && atoi(getenv("MASR_CONV_RESW")) == 0)) launch_resw<true>(a, tiles_x, tiles_y, s);
+        else if (a.CIN == 64 && a.COUT == 64 && !nar) launch_stream<64, 64, 16, true>(a, tiles_x, tiles_y, s);
+        else if (a.CIN == 64 && a.COUT == 128 && nar) launch_stream<64, 128, 8, true>(a, tiles_x, tiles_y, s);
+        else if (a.CIN == 128 && a.COUT == 128 && nar) launch_stream<128, 128, 8, true>(a, tiles_x, tiles_y, s);
+        else if (a.CIN == 128 && a.COUT == 64 && nar) launch_stream<128, 64, 8, true>(a, tiles_x, tiles_y, s);
+        else { mk_set_error("mk_conv3x3", "no phase-timing instance for this shape"); return -1; }
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     // 8-wide tiles when they cover the width with fewer padded columns than 16-wide ones (e.g. W = 40: 40 vs 48)
     static const bool allow_narrow = !getenv("MASR_CONV_NO_TW8");
     const bool narrow = allow_narrow && (a.W + 7) / 8 * 8 < (a.W + 15) / 16 * 16 && a.CIN <= 128 && a.COUT <= 128;
+    static const bool stream = !(getenv("MASR_CONV_STREAM") && atoi(getenv("MASR_CONV_STREAM")) == 0);
+    // (forward launches only: the dgrad epilogue needs the ReLU-mask tile, which would have to be streamed in as well)
+    if (stream && !a.x1 && !a.mask && a.CIN <= 128 && a.COUT <= 128 && (narrow || (a.CIN == 64 && a.COUT == 64))) {
+        const int TWv = narrow ? 8 : 16;
+        const int tiles_x = (a.W + TWv - 1) / TWv, tiles_y = (a.H + 15) / 16;
+        static const bool resw = !(getenv("MASR_CONV_RESW") && atoi(getenv("MASR_CONV_RESW")) == 0);
+        if (!narrow && resw) launch_resw<false>(a, tiles_x, tiles_y, s);
+        else if (!narrow) launch_stream<64, 64, 16>(a, tiles_x, tiles_y, s);
+        else if (a.CIN == 64 && a.COUT == 64) launch_stream<64, 64, 8>(a, tiles_x, tiles_y, s);
+        else if (a.CIN == 64 && a.COUT == 128) launch_stream<64, 128, 8>(a, tiles_x, tiles_y, s);
+        else if (a.CIN == 128 && a.COUT == 128) launch_stream<128, 128, 8>(a, tiles_x, tiles_y, s);
+        else launch_stream<128, 64, 8>(a, tiles_x, tiles_y, s);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     if (a.x1) {
         if (!(a.CIN == 64 && a.COUT == 64) || !a.w1_slab || !a.mask) { mk_set_error("mk_conv3x3", "fused conv1 wgrad needs the 64->64 dgrad with a mask"); return -1; }
         hipLaunchKernelGGL((conv3x3_patch_kernel<64, 64, 16, true>), grid(16), dim3(256), 0, s, a);
-    } else if (a.CIN == 64 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<64, 64, 16>), grid(16), dim3(256), 0, s, a);
-    else if (narrow) {                                     // same pixels per workgroup, tile 8 columns wide and twice as tall
+    } else if (a.CIN == 64 && a.COUT == 64) {
+        static const bool th8 = getenv("MASR_CONV_TH8") != nullptr;
+        if (th8) hipLaunchKernelGGL((conv3x3_patch_kernel<64, 64, 8>), grid(8), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_patch_kernel<64, 64, 16>), grid(16), dim3(256), 0, s, a);
+    } else if (narrow) {                                     // same pixels per workgroup, tile 8 columns wide and twice as tall
         auto grid8 = [&](int TH) { return dim3((a.W + 7) / 8, (a.H + TH - 1) / TH, a.B); };
         if (a.CIN == 64 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<64, 128, 16, false, 8>), grid8(16), dim3(256), 0, s, a);
         else if (a.CIN == 128 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 128, 16, false, 8>), grid8(16), dim3(256), 0, s, a);

@@ -83,6 +83,7 @@ struct masr_model {
     long* d_ranges = nullptr; int nranges = 0;            // split-K combine table: (offset, length) of every Linear weight / bias
     ShadowDesc* d_sdesc = nullptr; bf16** d_sptrs = nullptr; int nsdesc = 0, shadow_tiles = 0;
     float* stats = nullptr;                   // device [8]: loss, n_correct, n_total, grad_norm
+    unsigned* conv_sched = nullptr;           // tile counters of the streaming conv kernel (this model's stream only)
     float* h_stats = nullptr;                 // pinned
     int* h_stage = nullptr; int64_t stage_ints = 0; int stage_slot = 0; hipEvent_t stage_ev[4];
     uint64_t seed = 0x1234; uint64_t step = 0;
@@ -155,6 +156,7 @@ void plan_persistent(masr_model* m, Arena& ar) {
     for (auto& e : m->enc) { lin(e.sa.in); lin(e.sa.out); lin(e.l1); lin(e.l2); }
     for (auto& d : m->dec) { lin(d.sa.in); lin(d.sa.out); lin(d.ca.in); lin(d.ca.out); lin(d.l1); lin(d.l2); }
     m->stats = ar.get<float>(64);
+    m->conv_sched = ar.get<unsigned>(64);
     const int nlin = (int)(m->enc.size() * 4 + m->dec.size() * 6);
     m->d_ranges = ar.get<long>((int64_t)split_chunks(m).size());
     m->d_sdesc = ar.get<ShadowDesc>(nlin);
@@ -495,6 +497,7 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
         HIP_CHECK_RET(hipMemcpy(m->d_sptrs, ptrs.data(), sizeof(bf16*) * ptrs.size(), hipMemcpyHostToDevice));
     }
     // pads of the char_trans shadows must be zero (rows/cols >= odim); the refresh kernels only write the odim part
+    HIP_CHECK_RET(hipMemset(m->conv_sched, 0, sizeof(unsigned) * 64));   // tile counters of the streaming conv (re-armed by the kernel itself)
     HIP_CHECK_RET(hipMemset(m->ct.k16, 0, sizeof(bf16) * (size_t)m->Cp * m->E));
     HIP_CHECK_RET(hipMemset(m->ct.t16, 0, sizeof(bf16) * (size_t)m->E * m->Cp));
     m->have_acts = false;
@@ -528,7 +531,7 @@ static int forward_encoder(Ctx& c, const float* xs) {
     static const bool fuse_pool = !getenv("MASR_NO_FUSED_POOL");      // MaxPool2d written by the producing conv's epilogue
     auto conv = [&](const bf16* in, const Conv& cv, bf16* out, int H, int W, bf16* pooled) -> int {
         Prof p(m, &cv == &m->conv[1] ? MASR_PROF_CONV2_FWD : MASR_PROF_CONV_FWD, s);
-        ConvArgs ca{}; ca.in = in; ca.wk = cv.k16; ca.bias = P + cv.b; ca.relu = 1; ca.mask = nullptr; ca.out = out;
+        ConvArgs ca{}; ca.sched = m->conv_sched; ca.in = in; ca.wk = cv.k16; ca.bias = P + cv.b; ca.relu = 1; ca.mask = nullptr; ca.out = out;
         ca.B = B; ca.H = H; ca.W = W; ca.CIN = cv.CI; ca.COUT = cv.CO; ca.pool_out = fuse_pool ? pooled : nullptr;
         return mk_conv3x3(ca, s);
     };
@@ -675,7 +678,7 @@ static int backward(Ctx& c, const float* xs) {
     };
     auto dgrad = [&](const bf16* dy, const Conv& cv, const bf16* mask, bf16* out, int H, int W) -> int {
         Prof p(m, MASR_PROF_CONV_DGRAD, s);
-        ConvArgs ca{}; ca.in = dy; ca.wk = cv.d16; ca.bias = nullptr; ca.relu = 0; ca.mask = mask; ca.out = out; ca.B = B; ca.H = H; ca.W = W;
+        ConvArgs ca{}; ca.sched = m->conv_sched; ca.in = dy; ca.wk = cv.d16; ca.bias = nullptr; ca.relu = 0; ca.mask = mask; ca.out = out; ca.B = B; ca.H = H; ca.W = W;
         ca.CIN = cv.CO; ca.COUT = cv.CI;
         return mk_conv3x3(ca, s);
     };
@@ -690,7 +693,7 @@ static int backward(Ctx& c, const float* xs) {
     if (fuse_w1) {
         // d(conv1 output) is consumed only by conv1's weight gradient: contract it inside the dgrad epilogue, never store it
         { Prof p(m, MASR_PROF_CONV_DGRAD, s);
-          ConvArgs ca{}; ca.in = a.da2; ca.wk = m->conv[1].d16; ca.mask = a.a1; ca.out = a.da1; ca.B = B; ca.H = a.T; ca.W = a.D;
+          ConvArgs ca{}; ca.sched = m->conv_sched; ca.in = a.da2; ca.wk = m->conv[1].d16; ca.mask = a.a1; ca.out = a.da1; ca.B = B; ca.H = a.T; ca.W = a.D;
           ca.CIN = 64; ca.COUT = 64; ca.x1 = xs; ca.w1_slab = a.slab;
           CK(mk_conv3x3(ca, s)); }
         { Prof p(m, MASR_PROF_CONV_WGRAD, s); CK(mk_conv1_wgrad_fused_reduce(a.slab, B, a.T, a.D, G + m->conv[0].w, G + m->conv[0].b, s)); }
@@ -1008,6 +1011,18 @@ int masr_test_conv3x3(const uint16_t* in, const uint16_t* wk, const float* bias,
                       int COUT, void* stream) {
     ConvArgs a{}; a.in = (const bf16*)in; a.wk = (const bf16*)wk; a.bias = bias; a.relu = relu; a.out = (bf16*)out;
     a.B = B; a.H = H; a.W = W; a.CIN = CIN; a.COUT = COUT;
+    return mk_conv3x3(a, (hipStream_t)stream);
+}
+int masr_test_conv3x3_ex(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, const uint16_t* mask, uint16_t* out,
+                         uint16_t* pool_out, int B, int H, int W, int CIN, int COUT, void* stream) {
+    ConvArgs a{}; a.in = (const bf16*)in; a.wk = (const bf16*)wk; a.bias = bias; a.relu = relu; a.mask = (const bf16*)mask; a.out = (bf16*)out;
+    a.pool_out = (bf16*)pool_out; a.B = B; a.H = H; a.W = W; a.CIN = CIN; a.COUT = COUT;
+    return mk_conv3x3(a, (hipStream_t)stream);
+}
+int masr_test_conv3x3_prof(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, uint16_t* out, int B, int H, int W, int CIN,
+                           int COUT, int64_t* prof, void* stream) {
+    ConvArgs a{}; a.in = (const bf16*)in; a.wk = (const bf16*)wk; a.bias = bias; a.relu = relu; a.out = (bf16*)out;
+    a.B = B; a.H = H; a.W = W; a.CIN = CIN; a.COUT = COUT; a.prof = (long*)prof;
     return mk_conv3x3(a, (hipStream_t)stream);
 }
 int64_t masr_test_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT) { return mk_conv3x3_wgrad_slab_floats(B, H, W, CIN, COUT); }

@@ -46,6 +46,8 @@ struct ConvArgs {
     // 64->64 dgrad of the second conv only: fuse the weight gradient of conv1 (x1 = fp32 network input [B][H][W]) into the
     // epilogue; `out` is then never written, w1_slab receives 640 partial sums per workgroup (mk_conv1_wgrad_fused_reduce)
     const float* x1; float* w1_slab;
+    unsigned* sched;              // streaming kernel: 2 zero-initialised counters owned by the calling stream (null: a process-wide pair)
+    long* prof;                   // optional phase-timing output, 6 cycle counts per workgroup (see conv3x3_patch_kernel)
     bf16* pool_out;               // optional: MaxPool2d(2,2) (floor) of the ReLU'd output, [B][H/2][W/2][COUT], written by the same launch
 };
 int mk_conv3x3(const ConvArgs& a, hipStream_t s);

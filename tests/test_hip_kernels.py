@@ -74,7 +74,8 @@ def test_gemm_exact_integers(L):
 
 # widths 9 / 21 / 20 / 5 take the 8-pixel-wide tiles, 48 / 32 / 16 / 80 the 16-wide ones
 @pytest.mark.parametrize("B_,H,W,CIN,COUT", [(2, 10, 9, 64, 64), (1, 33, 21, 64, 128), (3, 16, 20, 128, 128), (2, 7, 5, 128, 64),
-                                             (1, 12, 48, 128, 128), (1, 9, 32, 64, 128), (1, 20, 16, 128, 64), (1, 19, 80, 64, 64)])
+                                             (1, 12, 48, 128, 128), (1, 9, 32, 64, 128), (1, 20, 16, 128, 64), (1, 19, 80, 64, 64),
+                                             (4, 500, 80, 64, 64), (5, 250, 40, 128, 128), (3, 301, 37, 64, 128)])   # more tiles than resident workgroups
 def test_conv3x3(L, B_, H, W, CIN, COUT):
     g = torch.Generator(device="cuda").manual_seed(CIN + COUT + H)
     x = torch.randn(B_, H, W, CIN, device="cuda", generator=g).bfloat16()           # NHWC
@@ -85,6 +86,32 @@ def test_conv3x3(L, B_, H, W, CIN, COUT):
     _cabi.check(L.masr_test_conv3x3(P(x), P(wk), P(bias), 1, P(out), B_, H, W, CIN, COUT, S()))
     ref = torch.relu(torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias, padding=1)).permute(0, 2, 3, 1)
     torch.testing.assert_close(out.float(), ref, rtol=1e-2, atol=1e-2)              # bf16 output rounding
+
+
+@pytest.mark.parametrize("B_,H,W,CIN,COUT", [(2, 38, 80, 64, 64), (3, 50, 40, 128, 128), (1, 33, 21, 128, 64), (2, 301, 80, 64, 64), (1, 17, 48, 128, 128)])
+def test_conv3x3_mask_and_pool(L, B_, H, W, CIN, COUT):
+    """the two epilogue flavours of the engine: dgrad (no bias, output zeroed where the ReLU mask is <= 0) and
+    forward with the fused 2x2 max-pool (floor mode, odd H / W drop the last row / column)"""
+    g = torch.Generator(device="cuda").manual_seed(7 * CIN + COUT + H)
+    x = torch.randn(B_, H, W, CIN, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(COUT, CIN, 3, 3, device="cuda", generator=g) * 0.05).bfloat16()
+    bias = torch.randn(COUT, device="cuda", generator=g)
+    wk = w.permute(0, 2, 3, 1).reshape(COUT, 9 * CIN).contiguous()
+    conv = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float(), None, padding=1).permute(0, 2, 3, 1)
+    # dgrad flavour
+    mask = torch.relu(torch.randn(B_, H, W, COUT, device="cuda", generator=g)).bfloat16()
+    out = torch.full((B_, H, W, COUT), 7.0, device="cuda").bfloat16()
+    _cabi.check(L.masr_test_conv3x3_ex(P(x), P(wk), None, 0, P(mask), P(out), None, B_, H, W, CIN, COUT, S()))
+    ref = torch.where(mask.float() > 0, conv, torch.zeros_like(conv))
+    torch.testing.assert_close(out.float(), ref, rtol=1e-2, atol=1e-2)
+    assert torch.equal(out.float() == 0, ref.bfloat16().float() == 0) or ((out.float() == 0) ^ (mask.float() <= 0)).sum() < 1e-3 * out.numel()
+    # forward + pool flavour
+    pool = torch.full((B_, H // 2, W // 2, COUT), -1.0, device="cuda").bfloat16()
+    _cabi.check(L.masr_test_conv3x3_ex(P(x), P(wk), P(bias), 1, None, P(out), P(pool), B_, H, W, CIN, COUT, S()))
+    ref = torch.relu(conv + bias)
+    torch.testing.assert_close(out.float(), ref, rtol=1e-2, atol=1e-2)
+    pref = torch.nn.functional.max_pool2d(out.float().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    assert torch.equal(pool.float(), pref)                       # pooling the stored map is exact
 
 
 @pytest.mark.parametrize("B_,H,W,CIN,COUT", [(2, 10, 9, 64, 64), (1, 33, 21, 64, 128), (2, 40, 20, 128, 128), (1, 21, 48, 128, 128), (1, 17, 80, 64, 64)])
