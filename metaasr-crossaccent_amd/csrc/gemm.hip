@@ -141,73 +141,104 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
             for (int r = 0; r < 4; ++r)
                 ct[(wm * WM + i * 16 + (lane >> 4) * 4 + r) * LDC + wn * WN + j * 16 + (lane & 15)] = acc[i][j][r] * g.alpha;
     __syncthreads();
-    constexpr int C4 = BN / 4, NCH = BM * C4 / 256;
-    const int c4 = (tid % C4) * 4, n = n0 + c4;
+    // A thread owns strips of SW columns.  The epilogue is bound by the NUMBER of vector-memory wave-instructions (one
+    // texture addresser per CU, ~70 cycles each whatever their width), so epilogues with 16-bit streams (bf16 output, ReLU
+    // mask) use 8-column strips = 16 bytes per lane; pure fp32 epilogues keep 4 columns (same instruction count, fewer LDS
+    // bank conflicts on the staged tile).  All optional inputs of a thread's strips are fetched BEFORE the first store:
+    // a load after a store may alias it as far as the compiler knows, so a load-compute-store loop pays one full memory
+    // round trip per strip (8 to 16 per tile; the masked dgrad GEMMs ran 3x longer than their unmasked twins).  Strips are
+    // therefore handled in batches of four: loads of the batch, then its arithmetic and stores.
+    constexpr int SW = (EPI >= 0 && (EPI & (E_C16 | E_MASK))) ? 8 : 4;
+    constexpr int CS = BN / SW, NCH = BM * CS / 256;
+    const int cs = (tid % CS) * SW, n = n0 + cs;
     if (n >= g.N) return;
     const bool f_bias = HAS(E_BIAS, g.bias), f_pe = HAS(E_PE, g.pe), f_relu = HAS(E_RELU, g.relu), f_mask = HAS(E_MASK, g.mask);
     const bool f_drop = HAS(E_DROP, g.drop_p > 0.f) && g.drop_p > 0.f, f_res = HAS(E_RES, g.residual);
     const bool f_acc = HAS(E_ACC, g.accumulate), f_c32 = HAS(E_C32, g.C32), f_c16 = HAS(E_C16, g.C16);
-    const int nv = g.N - n < 4 ? g.N - n : 4;                   // valid columns of this thread's 4-column strip
+    const int nv = g.N - n < SW ? g.N - n : SW;                 // valid columns of this thread's strip
     const float inv_keep = f_drop ? 1.0f / (1.0f - g.drop_p) : 1.0f;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (f_bias) {
+    float bv[SW];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[n + e];
-    }
-    // 16-byte paths need 4 valid columns and 4-float-aligned rows (n is a multiple of 4 by construction)
-    const bool v_c32 = nv == 4 && f_c32 && !((g.ldc | out_delta) & 3) && !((uintptr_t)g.C32 & 15);
-    const bool v_res = nv == 4 && f_res && !(g.ldres & 3) && !((uintptr_t)g.residual & 15);
-    const bool v_c16 = nv == 4 && f_c16 && !(g.ldc16 & 3) && !((uintptr_t)g.C16 & 7);
-    const bool v_msk = nv == 4 && f_mask && !(g.ldmask & 3) && !((uintptr_t)g.mask & 7);
-    const bool v_pe = nv == 4 && f_pe && !(g.N & 3) && !((uintptr_t)g.pe & 15);
+    for (int e = 0; e < SW; ++e) bv[e] = (f_bias && e < nv) ? g.bias[n + e] : 0.f;
+    // vector paths need a full strip and aligned rows (n is a multiple of SW by construction)
+    constexpr int A16 = SW - 1;                                  // bf16 strip = SW * 2 bytes: leading dimension multiple of SW
+    const bool v_c32 = nv == SW && f_c32 && !((g.ldc | out_delta) & 3) && !((uintptr_t)g.C32 & 15);
+    const bool v_res = nv == SW && f_res && !(g.ldres & 3) && !((uintptr_t)g.residual & 15);
+    const bool v_c16 = nv == SW && f_c16 && !(g.ldc16 & A16) && !((uintptr_t)g.C16 & (2 * SW - 1));
+    const bool v_msk = nv == SW && f_mask && !(g.ldmask & A16) && !((uintptr_t)g.mask & (2 * SW - 1));
+    const bool v_pe = nv == SW && f_pe && !(g.N & 3) && !((uintptr_t)g.pe & 15);
+    auto ldf = [](const float* p, float (&o)[SW]) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int row = (tid + i * 256) / C4, m = m0 + row;
+        for (int h = 0; h < SW / 4; ++h) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * h);
+            o[4 * h] = t[0]; o[4 * h + 1] = t[1]; o[4 * h + 2] = t[2]; o[4 * h + 3] = t[3];
+        }
+    };
+    // strips are handled NB at a time (the batch's inputs must fit the registers the accumulators just vacated)
+    constexpr int NB = NCH < 4 ? NCH : 4;
+#pragma unroll
+    for (int i0 = 0; i0 < NCH; i0 += NB) {
+    // ---- phase 1: every optional input of the batch
+    float rs[NB][SW], old[NB][SW], pev[NB][SW], mk[NB][SW];
+#pragma unroll
+    for (int ii = 0; ii < NB; ++ii) {
+        const int i = ii, row = (tid + (i0 + ii) * 256) / CS, m = m0 + row;
+#pragma unroll
+        for (int e = 0; e < SW; ++e) { rs[i][e] = 0.f; old[i][e] = 0.f; pev[i][e] = 0.f; mk[i][e] = 1.f; }
         if (m >= g.M) continue;
-        const f32x4 cv = *reinterpret_cast<const f32x4*>(ct + row * LDC + c4);
-        float v[4] = {cv[0] + bv[0], cv[1] + bv[1], cv[2] + bv[2], cv[3] + bv[3]};
-        float rs[4] = {0.f, 0.f, 0.f, 0.f}, old[4] = {0.f, 0.f, 0.f, 0.f}, pev[4] = {0.f, 0.f, 0.f, 0.f};
-        float mk[4] = {1.f, 1.f, 1.f, 1.f};
-        // ---- batched loads of the optional inputs
         if (f_res) {
             const float* p = g.residual + (long)m * g.ldres + n;
-            if (v_res) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); rs[0] = t[0]; rs[1] = t[1]; rs[2] = t[2]; rs[3] = t[3]; }
-            else { for (int e = 0; e < nv; ++e) rs[e] = p[e]; }
+            if (v_res) ldf(p, rs[i]);
+            else { for (int e = 0; e < nv; ++e) rs[i][e] = p[e]; }
         }
         if (f_pe) {
             const float* p = g.pe + (long)(m % g.pe_period) * g.N + n;
-            if (v_pe) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); pev[0] = t[0]; pev[1] = t[1]; pev[2] = t[2]; pev[3] = t[3]; }
-            else { for (int e = 0; e < nv; ++e) pev[e] = p[e]; }
+            if (v_pe) ldf(p, pev[i]);
+            else { for (int e = 0; e < nv; ++e) pev[i][e] = p[e]; }
         }
         if (f_mask) {
             const bf16* p = g.mask + (long)m * g.ldmask + n;
-            if (v_msk) { const bf16x4 t = *reinterpret_cast<const bf16x4*>(p); for (int e = 0; e < 4; ++e) mk[e] = (float)t[e]; }
-            else { for (int e = 0; e < nv; ++e) mk[e] = (float)p[e]; }
+            if (v_msk) {
+                if constexpr (SW == 8) { const bf16x8 t = ld8(p); for (int e = 0; e < 8; ++e) mk[i][e] = (float)t[e]; }
+                else { const bf16x4 t = *reinterpret_cast<const bf16x4*>(p); for (int e = 0; e < 4; ++e) mk[i][e] = (float)t[e]; }
+            } else { for (int e = 0; e < nv; ++e) mk[i][e] = (float)p[e]; }
         }
-        float* c32 = f_c32 ? g.C32 + out_delta + (long)m * g.ldc + n : nullptr;
         if (f_c32 && f_acc) {
-            if (v_c32) { const f32x4 t = *reinterpret_cast<const f32x4*>(c32); old[0] = t[0]; old[1] = t[1]; old[2] = t[2]; old[3] = t[3]; }
-            else { for (int e = 0; e < nv; ++e) old[e] = c32[e]; }
+            const float* c32 = g.C32 + out_delta + (long)m * g.ldc + n;
+            if (v_c32) ldf(c32, old[i]);
+            else { for (int e = 0; e < nv; ++e) old[i][e] = c32[e]; }
         }
-        // ---- arithmetic
+    }
+    // ---- phase 2: arithmetic and stores
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float x = v[e] + pev[e];
+    for (int ii = 0; ii < NB; ++ii) {
+        const int i = ii, row = (tid + (i0 + ii) * 256) / CS, m = m0 + row;
+        if (m >= g.M) continue;
+        float v[SW];
+        ldf(ct + row * LDC + cs, v);
+#pragma unroll
+        for (int e = 0; e < SW; ++e) {
+            float x = v[e] + bv[e] + pev[i][e];
             if (f_relu) x = fmaxf(x, 0.f);
-            if (f_mask) x = mk[e] > 0.f ? x * g.mask_scale : 0.f;
+            if (f_mask) x = mk[i][e] > 0.f ? x * g.mask_scale : 0.f;
             if (f_drop) x *= dropout_scale(g.seed, g.site, (uint32_t)((long)m * g.N + n + e), g.drop_p, inv_keep);
-            v[e] = x + rs[e] + old[e];
+            v[e] = x + rs[i][e] + old[i][e];
         }
-        // ---- stores
         if (f_c32) {
-            if (v_c32) *reinterpret_cast<f32x4*>(c32) = f32x4{v[0], v[1], v[2], v[3]};
-            else { for (int e = 0; e < nv; ++e) c32[e] = v[e]; }
+            float* c32 = g.C32 + out_delta + (long)m * g.ldc + n;
+            if (v_c32) {
+#pragma unroll
+                for (int h = 0; h < SW / 4; ++h) *reinterpret_cast<f32x4*>(c32 + 4 * h) = f32x4{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+            } else { for (int e = 0; e < nv; ++e) c32[e] = v[e]; }
         }
         if (f_c16) {
             bf16* p = g.C16 + (long)m * g.ldc16 + n;
-            if (v_c16) { bf16x4 t; t[0] = (bf16)v[0]; t[1] = (bf16)v[1]; t[2] = (bf16)v[2]; t[3] = (bf16)v[3]; *reinterpret_cast<bf16x4*>(p) = t; }
-            else { for (int e = 0; e < nv; ++e) p[e] = (bf16)v[e]; }
+            if (v_c16) {
+                if constexpr (SW == 8) { bf16x8 t; for (int e = 0; e < 8; ++e) t[e] = (bf16)v[e]; st8(p, t); }
+                else { bf16x4 t; for (int e = 0; e < 4; ++e) t[e] = (bf16)v[e]; *reinterpret_cast<bf16x4*>(p) = t; }
+            } else { for (int e = 0; e < nv; ++e) p[e] = (bf16)v[e]; }
         }
+    }
     }
 }
 
