@@ -103,16 +103,41 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
         slab[(long)blockIdx.x * 640 + (c * 8 + e / 10) * 10 + e % 10] = v;
     }
 }
-// one wave per output element: lanes stride over the per-block partials, fixed-order tree -> deterministic
+// workgroup = 16 consecutive outputs x 16 strided walks over a range of the per-block partials (64-byte row segments
+// instead of one float per cache line), then a fixed-order fold in LDS -> deterministic.  Two passes: C1_RSPLIT row
+// ranges in parallel into `part` (a single pass of 40 workgroups spent 31 us on 13 MB: latency-bound), then those rows.
+constexpr int C1_RSPLIT = 16;
 __global__ __launch_bounds__(256) void conv1_wgrad_reduce(const float* __restrict__ slab, int nblocks, float* __restrict__ dw,
-                                                          float* __restrict__ db) {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (i >= 640) return;
-    float s = 0.f;
-    for (int b = lane; b < nblocks; b += 64) s += slab[(long)b * 640 + i];
-    s = wave_sum(s);
-    const int co = i / 10, k = i % 10;
-    if (lane == 0) { if (k < 9) dw[co * 9 + k] = s; else db[co] = s; }
+                                                          float* __restrict__ db, float* __restrict__ part_out) {
+    __shared__ float part[16][17];
+    const int o = threadIdx.x & 15, l = threadIdx.x >> 4, i = blockIdx.x * 16 + o;
+    const int rows = (nblocks + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * rows, b1 = b0 + rows < nblocks ? b0 + rows : nblocks;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = b0 + l;
+    for (; b + 48 < b1; b += 64) {                          // four independent chains keep 4 loads in flight per thread
+        s0 += slab[(long)b * 640 + i]; s1 += slab[(long)(b + 16) * 640 + i];
+        s2 += slab[(long)(b + 32) * 640 + i]; s3 += slab[(long)(b + 48) * 640 + i];
+    }
+    for (; b < b1; b += 16) s0 += slab[(long)b * 640 + i];
+    part[l][o] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += part[k][threadIdx.x];
+        if (part_out) part_out[blockIdx.y * 640 + i] = s;
+        else {
+            const int co = i / 10, k = i % 10;
+            if (k < 9) dw[co * 9 + k] = s; else db[co] = s;
+        }
+    }
+}
+// slab rows [nblocks, nblocks + C1_RSPLIT) hold the first pass's partials
+static void launch_conv1_reduce(float* slab, int nb, float* dw, float* db, hipStream_t s) {
+    float* part = slab + (long)nb * 640;
+    hipLaunchKernelGGL(conv1_wgrad_reduce, dim3(40, C1_RSPLIT), dim3(256), 0, s, slab, nb, nullptr, nullptr, part);
+    hipLaunchKernelGGL(conv1_wgrad_reduce, dim3(40, 1), dim3(256), 0, s, part, C1_RSPLIT, dw, db, nullptr);
 }
 
 // ------------------------------------------------------------------ implicit GEMM 3x3 (fwd and dgrad)
@@ -1548,12 +1573,12 @@ int mk_conv1_fwd(const float* x, const float* w, const float* bias, bf16* out, i
     hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, s, x, w, bias, out, B, H, W, 64);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-long mk_conv1_wgrad_slab_floats(int B, int H, int W) { return (((long)B * H * W + C1_PIX - 1) / C1_PIX) * 640; }
+long mk_conv1_wgrad_slab_floats(int B, int H, int W) { return (((long)B * H * W + C1_PIX - 1) / C1_PIX + C1_RSPLIT) * 640; }
 int mk_conv1_wgrad(const float* x, const bf16* dy, float* dw, float* db, float* slab, int B, int H, int W, hipStream_t s) {
     const long P = (long)B * H * W;
     const int nb = (int)((P + C1_PIX - 1) / C1_PIX);
     hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(nb), dim3(256), 0, s, x, dy, slab, B, H, W, 64);
-    hipLaunchKernelGGL(conv1_wgrad_reduce, dim3(160), dim3(256), 0, s, slab, nb, dw, db);
+    launch_conv1_reduce(slab, nb, dw, db, s);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -1571,15 +1596,15 @@ int mk_conv1_wgrad_n(const float* x, const bf16* dy, float* dw, float* db, float
     const int nb = (int)((P + C1_PIX - 1) / C1_PIX);
     for (int c0 = 0; c0 < COUT; c0 += 64) {
         hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(nb), dim3(256), 0, s, x, dy + c0, slab, B, H, W, COUT);
-        hipLaunchKernelGGL(conv1_wgrad_reduce, dim3(160), dim3(256), 0, s, slab, nb, dw + c0 * 9, db + c0);
+        launch_conv1_reduce(slab, nb, dw + c0 * 9, db + c0, s);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-long mk_conv1_wgrad_fused_slab_floats(int B, int H, int W) { return (long)B * ((H + 15) / 16) * ((W + 15) / 16) * 640; }
-int mk_conv1_wgrad_fused_reduce(const float* slab, int B, int H, int W, float* dw, float* db, hipStream_t s) {
+long mk_conv1_wgrad_fused_slab_floats(int B, int H, int W) { return ((long)B * ((H + 15) / 16) * ((W + 15) / 16) + C1_RSPLIT) * 640; }
+int mk_conv1_wgrad_fused_reduce(float* slab, int B, int H, int W, float* dw, float* db, hipStream_t s) {
     const int nb = B * ((H + 15) / 16) * ((W + 15) / 16);
-    hipLaunchKernelGGL(conv1_wgrad_reduce, dim3(160), dim3(256), 0, s, slab, nb, dw, db);
+    launch_conv1_reduce(slab, nb, dw, db, s);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -52,7 +52,7 @@ struct ConvArgs {
 };
 int mk_conv3x3(const ConvArgs& a, hipStream_t s);
 long mk_conv1_wgrad_fused_slab_floats(int B, int H, int W);
-int mk_conv1_wgrad_fused_reduce(const float* slab, int B, int H, int W, float* dw, float* db, hipStream_t s);
+int mk_conv1_wgrad_fused_reduce(float* slab, int B, int H, int W, float* dw, float* db, hipStream_t s);
 // wgrad: dw[co][ci][3][3] (+ db[co]) from in (NHWC, CIN) and dy (NHWC, COUT)
 struct ConvWgradArgs { const bf16* in; const bf16* dy; float* dw; float* db; float* slab; int B, H, W, CIN, COUT; };
 int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s);
