@@ -1160,6 +1160,295 @@ __global__ __launch_bounds__(320) void conv3x3_resw_kernel(ConvArgs a, int ntile
     }
 }
 
+// ------------------------------------------------------------------ 64 -> 64 dgrad of the second conv with the conv1 weight gradient fused
+// Same skeleton as the resident-weight kernel (persistent workgroups, filter bank in LDS, patch stream by LDS-DMA), tiles of
+// 8 x 16 pixels so that the epilogue's staging fits next to the 72 KiB of weights: the accumulators are masked with the
+// ReLU mask of conv1's output (fetched three taps ahead), written to LDS as a bf16 tile and contracted on the MFMA with the
+// 3 x 3 neighbourhoods of the 1-channel network input (streamed in with the patch) -- d(conv1 output) is never stored.
+// Each wave keeps its 16 channels x 16 taps partial in registers over ALL tiles of the workgroup: one row of 640 sums
+// per workgroup instead of one per tile.  Two extra barriers per tile (tile staged / tap image built) include the patch wave.
+template <bool PROF = false>
+__global__ __launch_bounds__(320) void conv3x3_resw_w1_kernel(ConvArgs a, int ntiles, int tiles_x, int tiles_y, int chunk) {
+    constexpr int CIN = 64, COUT = 64, TH = 8, TW = 16;
+    constexpr int PW = TW + 2, PH = TH + 2, RPT = 16 / TW;
+    constexpr int MF = TH * TW / 64, NF = COUT / 16, NH = NF / 2;
+    constexpr int KTOT = 9 * CIN;
+    constexpr int PPIECES = (PH * PW + 7) / 8;             // 1 KiB DMA pieces per patch (8 pixels x 128 B)
+    constexpr int PBYTES = PPIECES * 1024, WBYTES = COUT * 128;
+    constexpr int OS = COUT + 8;                           // row stride of the masked bf16 tile [pixel][channel] (frag_rm reads)
+    constexpr int NPIX = TH * TW, XS = NPIX + 8;           // tap-major input image [16 taps][XS]
+    constexpr int OT_BYTES = NPIX * OS * 2, XT_BYTES = 16 * XS * 2, XP_BYTES = 192 * 4;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * PBYTES + 9 * WBYTES + OT_BYTES + XT_BYTES + 2 * XP_BYTES];
+    __shared__ int tileq[4];
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    typedef __attribute__((ext_vector_type(2))) short short2_t;
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    char* const pbuf = lds;
+    char* const wres = lds + 2 * PBYTES;
+    bf16* const otile = reinterpret_cast<bf16*>(wres + 9 * WBYTES);
+    bf16* const sxt = reinterpret_cast<bf16*>(wres + 9 * WBYTES + OT_BYTES);
+    float* const sxp = reinterpret_cast<float*>(wres + 9 * WBYTES + OT_BYTES + XT_BYTES);   // two buffers of 192 floats
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int H = a.H, W = a.W;
+    const int dbg = PROF ? a.relu >> 8 : 0;                // ablation bits as in the streaming kernel (1, 4)
+    long pt[3] = {0, 0, 0};
+    long tprev = PROF ? clock64() : 0;
+    auto stamp = [&](int k) { if constexpr (PROF) { const long now = clock64(); pt[k] += now - tprev; tprev = now; } };
+    auto read_tileq = [&](int k) { return __builtin_amdgcn_readfirstlane(*(volatile int*)&tileq[k & 3]); };
+
+    {   // the filter bank: 72 pieces of 8 rows, dealt round-robin to the 5 waves
+        const int sub = lane >> 3, sl = lane & 7;
+#pragma unroll
+        for (int n = 0; n < (72 + 4) / 5; ++n) {
+            const int pc = n * 5 + wave;
+            if (pc < 72) {
+                const int tap = pc >> 3, i = pc & 7;
+                const int r = i * 8 + sub, j = r >> 4, m = r & 15;
+                const int co = (j >> 1) * 32 + (m >> 2) * 8 + (j & 1) * 4 + (m & 3);
+                const bf16* src = a.wk + (long)co * KTOT + tap * CIN + ((sl ^ (r & 7)) * 8);
+                __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(wres + pc * 1024), 16, 0, 0);
+            }
+        }
+    }
+
+    if (wave == 4) {
+        // ---------------- patch stream (see the streaming kernel); barrier g hands patch g over and frees patch g-1's buffer
+        const int sub = lane >> 3, sl = lane & 7;
+        int rel[PPIECES], pij[PPIECES];
+#pragma unroll
+        for (int i = 0; i < PPIECES; ++i) {
+            int p = i * 8 + sub;
+            if (p >= PH * PW) p = PH * PW - 1;
+            const int pi = p / PW, pj = p % PW;
+            rel[i] = ((pi - 1) * W + (pj - 1)) * CIN + (sl ^ (pj & 7)) * 8;
+            pij[i] = pi << 8 | pj;
+        }
+        const bf16* zsrc = g_zero_line + sl * 8;
+        // the (TH+2) x 18 neighbourhood of the 1-channel network input travels with the patch (4-byte LDS-DMA, zeros outside)
+        const float* zx = reinterpret_cast<const float*>(g_zero_line);
+        auto issue_patch = [&](int tile, int g) {
+            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+            const int d0 = tx * TW, t0 = ty * TH;
+            {
+                const float* x_b = a.x1 + (long)b * H * W;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int e = i * 64 + lane, pi = e / PW, pj = e % PW;
+                    const int t = t0 + pi - 1, d = d0 + pj - 1;
+                    const float* src = (e < PH * PW && t >= 0 && t < H && d >= 0 && d < W) ? x_b + (long)t * W + d : zx;
+                    __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(sxp + (g & 1) * 192 + i * 64), 4, 0, 0);
+                }
+            }
+            const bf16* org = a.in + ((long)b * H * W + (long)t0 * W + d0) * CIN;
+            const bool interior = t0 >= 1 && t0 + TH + 1 <= H && d0 >= 1 && d0 + TW + 1 <= W;
+            char* dst = pbuf + (g & 1) * PBYTES;
+            if (interior) {
+#pragma unroll
+                for (int i = 0; i < PPIECES; ++i)
+                    __builtin_amdgcn_global_load_lds((gptr_t*)(org + rel[i]), (lptr_t*)(dst + i * 1024), 16, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < PPIECES; ++i) {
+                    const int t = t0 + (pij[i] >> 8) - 1, d = d0 + (pij[i] & 255) - 1;
+                    const bf16* src = (t >= 0 && t < H && d >= 0 && d < W) ? org + rel[i] : zsrc;
+                    __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(dst + i * 1024), 16, 0, 0);
+                }
+            }
+        };
+        bool dry = false;
+        // Tiles are dealt by a STATIC stride here (workgroup w: tiles w, w + G, ...), not by the tile counter: the wave-level
+        // partial sums run over all tiles of a workgroup, so the assignment fixes the summation order -- the gradient must
+        // be bit-reproducible from run to run.
+        unsigned own = blockIdx.x;
+        const unsigned lim = (unsigned)ntiles;
+        auto issue_fetch = [&](unsigned) -> unsigned { const unsigned t = own; own += gridDim.x; return t; };
+        auto went_dry = [&]() { dry = true; };
+        int cur, nxt;
+        {
+            const unsigned t0f = issue_fetch(1u), t1f = issue_fetch(1u);
+            cur = t0f < lim ? (int)t0f : -1;
+            nxt = t1f < lim ? (int)t1f : -1;
+            if (nxt < 0) went_dry();
+        }
+        if (lane == 0) { tileq[0] = cur; tileq[1] = nxt; }
+        if (cur >= 0) issue_patch(cur, 0);
+        stamp(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        stamp(1);
+        asm volatile("s_barrier" ::: "memory");           // opening barrier: weights (every wave's share), patch 0, tileq[0..1]
+        for (int k = 0; cur >= 0; ++k) {
+            // tile k is being computed: fetch the id of tile k+2, stream tile k+1's patch, publish, hand over
+            const unsigned raw = issue_fetch(1u);
+            stamp(2);
+            if (nxt >= 0 && !(dbg & 1)) issue_patch(nxt, k + 1);
+            stamp(0);
+            int nn = -1;
+            if (!dry) {
+                const unsigned t = __builtin_amdgcn_readfirstlane(raw);
+                if (t >= lim) went_dry(); else nn = (int)t;
+            }
+            if (lane == 0) tileq[(k + 2) & 3] = nn;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            stamp(1);
+            asm volatile("s_barrier" ::: "memory");       // barrier k (middle of tile k's last tap)
+            asm volatile("s_barrier" ::: "memory");       // E1, E2: the MFMA waves' epilogue barriers (masked tile staged; tap image built)
+            asm volatile("s_barrier" ::: "memory");
+            cur = nxt; nxt = nn;
+        }
+        if constexpr (PROF) { if (lane == 0) { a.prof[blockIdx.x * 6 + 4] = pt[0]; a.prof[blockIdx.x * 6 + 5] = pt[1]; } }
+        return;
+    }
+
+    // ---------------- MFMA waves
+    const int rr = lane & 15, q = lane >> 4;
+    const int pcol0 = rr % TW, prow0 = wave * MF * RPT + rr / TW;
+    int poff[3][2], woff[2];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+        woff[kc] = rr * 128 + (((kc * 4 + q) ^ (rr & 7)) * 16);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) poff[dx][kc] = (prow0 * PW + pcol0 + dx) * 128 + (((kc * 4 + q) ^ ((pcol0 + dx) & 7)) * 16);
+    }
+    struct Frags { bf16x8 a[MF], b[NF]; };
+    typedef __attribute__((address_space(3))) const char lds_cchar;
+    const unsigned wbase = (unsigned)(size_t)((lds_cchar*)wres);
+    f32x4 acc[MF][NF];
+    // half_tap: MF*NF MFMAs on `use`, the reads of `ld` issued in their shadow (see the streaming kernel)
+    auto half_tap = [&](const Frags& use, Frags& ld, const char* pl, int tap, int kc) {
+        const int dy = tap / 3, dx = tap % 3;
+        const unsigned pa = (unsigned)(size_t)((lds_cchar*)pl) + poff[dx][kc];
+        const unsigned wa = wbase + woff[kc] + tap * WBYTES;   // (the DS offset field is 16 bits: the tap's 8 KiB stride goes here)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MF * NF; ++m) {
+            const int i = m / NF, j = m % NF;
+            acc[i][j] = mma16(use.b[j], use.a[i], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (m < MF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ld.a[m < MF ? m : 0]) : "v"(pa), "n"(((m < MF ? m : 0) * RPT + dy) * PW * 128));
+            else if (m < MF + NF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ld.b[m < MF + NF ? m - MF : 0]) : "v"(wa), "n"((m < MF + NF ? m - MF : 0) * 2048));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    Frags f0, f1;
+    f32x4 cw = {0.f, 0.f, 0.f, 0.f};                    // conv1 weight-gradient partial of this wave over all its tiles
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of the weights
+    stamp(2);
+    asm volatile("s_barrier" ::: "memory");               // opening barrier
+    int tile = read_tileq(0);
+    {   // fragments of (tap 0, first k-half)
+        const unsigned pa = (unsigned)(size_t)((lds_cchar*)pbuf) + poff[0][0];
+        const unsigned wa = wbase + woff[0];
+#pragma unroll
+        for (int i = 0; i < MF; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f0.a[i]) : "v"(pa), "n"(i * RPT * PW * 128));
+#pragma unroll
+        for (int j = 0; j < NF; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f0.b[j]) : "v"(wa), "n"(j * 2048));
+    }
+    stamp(0);
+    for (int k = 0; tile >= 0; ++k) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int d0 = tx * TW, t0 = ty * TH;
+        const int tl = t0 + prow0, dl = d0 + pcol0;
+        const unsigned voff = (unsigned)((tl * W + dl) * COUT + q * 8) * 2u;
+        const char* mask_b = reinterpret_cast<const char*>(a.mask) + (long)b * H * W * COUT * 2;
+        auto row_ok = [&](int i) { return tl + i * RPT < H && dl < W; };
+        auto row_off = [&](int i) { return voff + (unsigned)(i * RPT) * (unsigned)(W * COUT * 2); };
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* pcur = pbuf + (k & 1) * PBYTES;
+        const char* pnext = pbuf + ((k + 1) & 1) * PBYTES;
+        u32x4 mk[MF][NH];                                 // ReLU mask of this lane's outputs, requested three taps before use
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap == 6) {
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) {
+                        const u32x4 z = {0u, 0u, 0u, 0u};
+                        mk[i][h] = row_ok(i) ? *reinterpret_cast<const u32x4*>(mask_b + row_off(i) + h * 64) : z;
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            half_tap(f0, f1, pcur, tap, 1);
+            if (tap < 8) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                half_tap(f1, f0, pcur, tap + 1, 0);
+            } else {
+                // barrier k: the next tile's patch and tileq[k+1..k+2] are in; this wave will not read patch k again
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                half_tap(f1, f0, pnext, 0, 0);            // (after the last tile: stale LDS, never used)
+            }
+        }
+        const int next_tile = read_tileq(k + 1);
+        stamp(1);
+        tile = next_tile;
+
+        // epilogue: the masked bf16 tile (zeros outside the image) goes to LDS and is contracted there with the 3 x 3
+        // neighbourhoods of the network input: [64 channels] x [9 taps + ones] over the tile's pixels, on the MFMA
+        const short2_t zero2 = {0, 0}, one2 = {1, 1};
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const bool ok = row_ok(i);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                u32x4 ov;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const f32x4& c = acc[i][2 * h + (kk >> 1)];
+                    unsigned r;
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(c[2 * (kk & 1)]), "v"(c[2 * (kk & 1) + 1]));
+                    const unsigned mw = mk[i][h][kk];       // (bit_cast straight from a vector element reads element 0: clang 22)
+                    short2_t m = __builtin_bit_cast(short2_t, mw);
+                    m = __builtin_elementwise_min(__builtin_elementwise_max(m, zero2), one2);   // 1 where mask > 0
+                    const short2_t pk = __builtin_bit_cast(short2_t, r) & (zero2 - m);
+                    ov[kk] = ok ? __builtin_bit_cast(unsigned, pk) : 0u;
+                }
+                *reinterpret_cast<u32x4*>(otile + ((wave * MF + i) * 16 + rr) * OS + h * 32 + q * 8) = ov;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // E1
+        if (threadIdx.x < NPIX) {
+            // thread = pixel: its 9 neighbours + 1 go to column kappa(pixel) of the tap-major image.  kappa undoes the
+            // k-permutation of frag_rm (MFMA k index 8g+j <-> tile row 4g+j for j < 4, 16+4g+(j-4) for j >= 4).
+            const int tid = threadIdx.x, pr = tid >> 4, pc = tid & 15;
+            const int rho = tid & 31, sl = tid >> 5;
+            const int kap = rho < 16 ? 8 * (rho >> 2) + (rho & 3) : 8 * ((rho - 16) >> 2) + 4 + (rho & 3);
+            const bool in_img = t0 + pr < H && d0 + pc < W;
+            const float* xp = sxp + (k & 1) * 192;
+#pragma unroll
+            for (int tap = 0; tap < 16; ++tap) {
+                float v = 0.f;
+                if (tap < 9) v = xp[(pr + tap / 3) * PW + pc + tap % 3];
+                else if (tap == 9) v = 1.f;
+                sxt[tap * XS + sl * 32 + kap] = (bf16)(in_img ? v : 0.f);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // E2
+        // wave w: output channels 16w .. 16w+15 x 16 taps, contraction over the tile's pixels (slabs of 32)
+#pragma unroll
+        for (int sl = 0; sl < NPIX / 32; ++sl) {
+            const bf16x8 af = frag_rm<OS>(otile + sl * 32 * OS, wave * 16, lane);
+            const bf16x8 bf = ld8(sxt + (lane & 15) * XS + sl * 32 + (lane >> 4) * 8);
+            cw = mma16(af, bf, cw);
+        }
+        stamp(2);
+    }
+    if ((lane & 15) < 10) {                                // one row of 640 partial sums per workgroup (mk_conv1_wgrad_fused_reduce)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.w1_slab[(long)blockIdx.x * 640 + (wave * 16 + 4 * (lane >> 4) + r) * 10 + (lane & 15)] = cw[r];
+    }
+    if constexpr (PROF) {
+        if (wave == 0 && lane == 0) { a.prof[blockIdx.x * 6 + 0] = pt[0]; a.prof[blockIdx.x * 6 + 1] = pt[1]; a.prof[blockIdx.x * 6 + 2] = pt[2]; }
+    }
+}
+
 // ------------------------------------------------------------------ wgrad (reduction over pixels)
 
 template <int CIN, int COUT>
@@ -1601,9 +1890,28 @@ int mk_conv1_wgrad_n(const float* x, const bf16* dy, float* dw, float* db, float
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-long mk_conv1_wgrad_fused_slab_floats(int B, int H, int W) { return ((long)B * ((H + 15) / 16) * ((W + 15) / 16) + C1_RSPLIT) * 640; }
+static int conv_ncu() {
+    static int ncu = 0;
+    if (!ncu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); if (ncu <= 0) ncu = 256; }
+    return ncu;
+}
+// the fused conv1-wgrad dgrad: resident-weight kernel unless switched off (then the patch kernel, one slab row per tile)
+static bool use_resw_w1() {
+    static const bool on = !(getenv("MASR_CONV_STREAM") && atoi(getenv("MASR_CONV_STREAM")) == 0) &&
+                           !(getenv("MASR_CONV_RESW") && atoi(getenv("MASR_CONV_RESW")) == 0) &&
+                           !(getenv("MASR_CONV_RESW_W1") && atoi(getenv("MASR_CONV_RESW_W1")) == 0);
+    return on;
+}
+static int resw_w1_rows(int B, int H, int W) {
+    const long ntiles = (long)B * ((H + 7) / 8) * ((W + 15) / 16);
+    return (int)(ntiles < conv_ncu() ? ntiles : conv_ncu());
+}
+long mk_conv1_wgrad_fused_slab_floats(int B, int H, int W) {
+    const long per_tile = (long)B * ((H + 15) / 16) * ((W + 15) / 16), per_wg = resw_w1_rows(B, H, W);
+    return ((per_tile > per_wg ? per_tile : per_wg) + C1_RSPLIT) * 640;
+}
 int mk_conv1_wgrad_fused_reduce(float* slab, int B, int H, int W, float* dw, float* db, hipStream_t s) {
-    const int nb = B * ((H + 15) / 16) * ((W + 15) / 16);
+    const int nb = use_resw_w1() ? resw_w1_rows(B, H, W) : B * ((H + 15) / 16) * ((W + 15) / 16);
     launch_conv1_reduce(slab, nb, dw, db, s);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -1613,6 +1921,16 @@ int mk_conv1_wgrad_fused_reduce(float* slab, int B, int H, int W, float* dw, flo
 static int stream_chunk() {
     static const int c = getenv("MASR_CONV_CHUNK") ? atoi(getenv("MASR_CONV_CHUNK")) : 0;
     return c;
+}
+static void launch_resw_w1(const ConvArgs& a, hipStream_t s) {
+    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 7) / 8, ntiles = tiles_x * tiles_y * a.B;
+    ConvArgs b = a;
+    if (!b.sched) {
+        static unsigned* fallback = nullptr;
+        if (!fallback) hipGetSymbolAddress((void**)&fallback, HIP_SYMBOL(g_conv_sched));
+        b.sched = fallback;
+    }
+    hipLaunchKernelGGL((conv3x3_resw_w1_kernel<false>), dim3((unsigned)resw_w1_rows(a.B, a.H, a.W)), dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, 0);
 }
 template <bool PROF = false>
 static void launch_resw(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
@@ -1711,6 +2029,7 @@ int mk_conv3x3(const ConvArgs& a, hipStream_t s) {
     }
     if (a.x1) {
         if (!(a.CIN == 64 && a.COUT == 64) || !a.w1_slab || !a.mask) { mk_set_error("mk_conv3x3", "fused conv1 wgrad needs the 64->64 dgrad with a mask"); return -1; }
+        if (use_resw_w1()) { launch_resw_w1(a, s); return hipGetLastError() == hipSuccess ? 0 : -1; }
         hipLaunchKernelGGL((conv3x3_patch_kernel<64, 64, 16, true>), grid(16), dim3(256), 0, s, a);
     } else if (a.CIN == 64 && a.COUT == 64) {
         static const bool th8 = getenv("MASR_CONV_TH8") != nullptr;
