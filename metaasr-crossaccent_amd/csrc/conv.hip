@@ -534,7 +534,9 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
 __device__ __attribute__((aligned(128))) bf16 g_zero_line[64];
 __device__ unsigned g_conv_sched[2];                      // tile counter of launches that bring none (single-stream tools and tests)
 
-template <int CIN, int COUT, int TH, int TW, bool PROF = false>
+// MASK = false: forward flavour (bias, ReLU flag, optional fused pool); MASK = true: dgrad flavour (outputs zeroed where
+// a.mask <= 0; no bias / ReLU / pool)
+template <int CIN, int COUT, int TH, int TW, bool MASK, bool PROF = false>
 __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int ntiles, int tiles_x, int tiles_y, int chunk) {
     constexpr int PW = TW + 2, PH = TH + 2, RPT = 16 / TW;
     constexpr int MF = TH * TW / 64, NF = COUT / 16, NH = NF / 2;
@@ -737,8 +739,8 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
     for (int h = 0; h < NH; ++h)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            bv[h][k][0] = a.bias ? a.bias[h * 32 + q * 8 + 2 * k] : 0.f;
-            bv[h][k][1] = a.bias ? a.bias[h * 32 + q * 8 + 2 * k + 1] : 0.f;
+            bv[h][k][0] = (!MASK && a.bias) ? a.bias[h * 32 + q * 8 + 2 * k] : 0.f;
+            bv[h][k][1] = (!MASK && a.bias) ? a.bias[h * 32 + q * 8 + 2 * k + 1] : 0.f;
         }
 
     // One half-tap = MF*NF MFMAs on one fragment set while the reads of the NEXT set are issued in their shadow, one read
@@ -790,6 +792,8 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
         char* out_b = reinterpret_cast<char*>(a.out) + (long)b * H * W * COUT * 2;
         auto row_ok = [&](int i) { return tl + i * RPT < H && dl < W; };
         auto row_off = [&](int i) { return voff + (unsigned)(i * RPT) * (unsigned)(W * COUT * 2); };
+        const char* mask_b = MASK ? reinterpret_cast<const char*>(a.mask) + (long)b * H * W * COUT * 2 : nullptr;
+        u32x4 mk[MASK ? MF : 1][MASK ? NH : 1];           // ReLU mask of this lane's outputs, requested three taps before the epilogue
         int next_tile = -1;
 #pragma unroll 1
         for (int slab = 0; slab < NSLAB; ++slab, ++g) {
@@ -803,6 +807,17 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
             const char* pnext = pbuf + ((g + 1) & 1) * PBYTES;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
+                if constexpr (MASK) {
+                    if (tap == 6 && slab == NSLAB - 1) {
+#pragma unroll
+                        for (int i = 0; i < MF; ++i)
+#pragma unroll
+                            for (int h = 0; h < NH; ++h) {
+                                const u32x4 z = {0u, 0u, 0u, 0u};
+                                mk[i][h] = row_ok(i) ? *reinterpret_cast<const u32x4*>(mask_b + row_off(i) + h * 64) : z;
+                            }
+                    }
+                }
                 const char* wcur = wbuf + ((g + tap) & (D - 1)) * WBYTES;          // 9 g + tap = g + tap (mod 4)
                 const char* wnext = wbuf + ((g + tap + 1) & (D - 1)) * WBYTES;
                 // first half: MFMAs on f0 (read during the previous half-tap), reads of this tap's second k-half into f1
@@ -826,7 +841,7 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
         // packed 16-bit integer ops (for bf16 bit patterns max(x, 0) is max_i16(x, 0), and non-negative values order like integers)
         const int H2 = H / 2, W2 = W / 2;
         constexpr int IP = (TW == 16) ? 2 : 1;             // pixel tiles per pooling group (TW = 16: two rows = two tiles)
-        const short fl = (a.relu & 255) ? (short)0 : (short)-32768;
+        const short fl = (!MASK && (a.relu & 255)) ? (short)0 : (short)-32768;
         const short2_t floor2 = {fl, fl};
         short2_t pm[NH][4];
 #pragma unroll
@@ -845,13 +860,23 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
                     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(v[0]), "v"(v[1]));
                     pk[kk] = __builtin_elementwise_max(__builtin_bit_cast(short2_t, r), floor2);   // ReLU (or a no-op)
                 }
+                if constexpr (MASK) {
+                    const short2_t zero2 = {0, 0}, one2 = {1, 1};
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const unsigned mw = mk[i][h][kk];      // (bit_cast straight from a vector element reads element 0: clang 22)
+                        short2_t m = __builtin_bit_cast(short2_t, mw);
+                        m = __builtin_elementwise_min(__builtin_elementwise_max(m, zero2), one2);   // 1 where mask > 0
+                        pk[kk] = pk[kk] & (zero2 - m);
+                    }
+                }
                 if (ok) {
                     u32x4 ov;
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) ov[kk] = __builtin_bit_cast(unsigned, pk[kk]);
                     *reinterpret_cast<u32x4*>(out_b + o) = ov;
                 }
-                if (a.pool_out) {
+                if (!MASK && a.pool_out) {
                     // 2 x 2 window (ReLU'd values only): the row pair is (tile i, tile i+1) for TW = 16 and (lane, lane ^ 8)
                     // for TW = 8; the column pair is (lane, lane ^ 1)
                     if (IP == 2 && (i & 1) == 0) {
@@ -1952,14 +1977,14 @@ static void launch_resw(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t
     const int grid = chunk > 0 ? (ntiles + chunk - 1) / chunk : (ntiles < resident ? ntiles : resident);
     hipLaunchKernelGGL((conv3x3_resw_kernel<16, 16, PROF>), dim3((unsigned)grid), dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, chunk);
 }
-template <int CI, int CO, int TWV, bool PROF = false>
-static void launch_stream(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
+template <int CI, int CO, int TWV, bool MASK, bool PROF = false>
+static void launch_stream_t(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
     static int resident = 0;
     if (!resident) {
         int dev = 0, ncu = 0, per_cu = 0;
         hipGetDevice(&dev);
         hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3x3_stream_kernel<CI, CO, 16, TWV, PROF>, 384, 0);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3x3_stream_kernel<CI, CO, 16, TWV, MASK, PROF>, 384, 0);
         if (ncu <= 0) ncu = 256;
         if (per_cu <= 0) per_cu = 1;
         static const int cap = getenv("MASR_CONV_STREAM_WGPC") ? atoi(getenv("MASR_CONV_STREAM_WGPC")) : 2;
@@ -1974,7 +1999,12 @@ static void launch_stream(const ConvArgs& a, int tiles_x, int tiles_y, hipStream
     }
     const int chunk = stream_chunk();
     const int grid = chunk > 0 ? (ntiles + chunk - 1) / chunk : (ntiles < resident ? ntiles : resident);
-    hipLaunchKernelGGL((conv3x3_stream_kernel<CI, CO, 16, TWV, PROF>), dim3((unsigned)grid), dim3(384), 0, s, b, ntiles, tiles_x, tiles_y, chunk);
+    hipLaunchKernelGGL((conv3x3_stream_kernel<CI, CO, 16, TWV, MASK, PROF>), dim3((unsigned)grid), dim3(384), 0, s, b, ntiles, tiles_x, tiles_y, chunk);
+}
+template <int CI, int CO, int TWV, bool PROF = false>
+static void launch_stream(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
+    if (a.mask) launch_stream_t<CI, CO, TWV, true, PROF>(a, tiles_x, tiles_y, s);
+    else launch_stream_t<CI, CO, TWV, false, PROF>(a, tiles_x, tiles_y, s);
 }
 int mk_conv3x3(const ConvArgs& a, hipStream_t s) {
     if (getenv("MASR_CONV_V1")) {                          // first-generation im2col-on-the-fly kernel (kept for A/B runs)
@@ -2012,14 +2042,14 @@ int mk_conv3x3(const ConvArgs& a, hipStream_t s) {
     static const bool allow_narrow = !getenv("MASR_CONV_NO_TW8");
     const bool narrow = allow_narrow && (a.W + 7) / 8 * 8 < (a.W + 15) / 16 * 16 && a.CIN <= 128 && a.COUT <= 128;
     static const bool stream = !(getenv("MASR_CONV_STREAM") && atoi(getenv("MASR_CONV_STREAM")) == 0);
-    // (forward launches only: the dgrad epilogue needs the ReLU-mask tile, which would have to be streamed in as well)
-    if (stream && !a.x1 && !a.mask && a.CIN <= 128 && a.COUT <= 128 && (narrow || (a.CIN == 64 && a.COUT == 64))) {
+    // (a forward flavour -- bias / ReLU / pool -- and a dgrad flavour -- mask only; anything else takes the patch kernel)
+    if (stream && !a.x1 && !(a.mask && (a.bias || a.relu || a.pool_out)) && a.CIN <= 128 && a.COUT <= 128 && (narrow || (a.CIN == 64 && a.COUT == 64))) {
         const int TWv = narrow ? 8 : 16;
         const int tiles_x = (a.W + TWv - 1) / TWv, tiles_y = (a.H + 15) / 16;
         static const bool resw = !(getenv("MASR_CONV_RESW") && atoi(getenv("MASR_CONV_RESW")) == 0);
         // 64 -> 64 always takes the resident-weight kernel with 16-wide tiles, also on widths that pad badly to 16
         // (W = 83: 0.100 ms against 0.172 ms for the weight-ring kernel on 8-wide tiles)
-        if (a.CIN == 64 && a.COUT == 64 && resw) launch_resw<false>(a, (a.W + 15) / 16, tiles_y, s);
+        if (a.CIN == 64 && a.COUT == 64 && resw && !a.mask) launch_resw<false>(a, (a.W + 15) / 16, tiles_y, s);
         else if (!narrow) launch_stream<64, 64, 16>(a, tiles_x, tiles_y, s);
         else if (a.CIN == 64 && a.COUT == 64) launch_stream<64, 64, 8>(a, tiles_x, tiles_y, s);
         else if (a.CIN == 64 && a.COUT == 128) launch_stream<64, 128, 8>(a, tiles_x, tiles_y, s);
