@@ -23,32 +23,50 @@ constexpr int LDK = 40;
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, bf16* __restrict__ out,
                                                         int B, int H, int W, int cstride) {
-    // one launch = 64 output channels of a map with `cstride` channels (w, bias, out pre-offset by the caller)
-    __shared__ float sw[64 * 9 + 64];
-    for (int i = threadIdx.x; i < 64 * 9 + 64; i += 256) sw[i] = i < 576 ? w[i] : bias[i - 576];
-    __syncthreads();
-    const long P = (long)B * H * W;
-    const long p = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
-    const int cg = threadIdx.x & 7;
-    if (p >= P) return;
-    const int d = (int)(p % W);
-    const int t = (int)((p / W) % H);
-    float xv[9];
+    // one launch = 64 output channels of a map with `cstride` channels (w, bias, out pre-offset by the caller).
+    // The launch is bound by vector-memory wave-instructions (~70 cycles each at the CU's one texture addresser; measured:
+    // loads + arithmetic 45 us, arithmetic + stores 32 us, everything 66 us with 2 loads + 1 store per 8 pixels), so a wave
+    // takes a 16-pixel row segment per step with ONE load -- its 3 x 18 input window, one float per lane -- and hands the
+    // taps round by lane permutes; thread = (pixel pair, group of 8 channels), the 72 weights + 8 biases stay in registers.
+    const int lane = threadIdx.x & 63;
+    const int pg = lane >> 3, cg = lane & 7;
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    f32x2 wr[4][9], br[4];                                 // channel pairs: the 72 FMAs per pixel issue as 36 v_pk_fma_f32
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int tt = t + tap / 3 - 1, dd = d + tap % 3 - 1;
-        xv[tap] = (tt >= 0 && tt < H && dd >= 0 && dd < W) ? x[p + (long)(tap / 3 - 1) * W + (tap % 3 - 1)] : 0.f;
+    for (int j = 0; j < 4; ++j) {
+        br[j] = f32x2{bias[cg * 8 + 2 * j], bias[cg * 8 + 2 * j + 1]};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) wr[j][tap] = f32x2{w[(cg * 8 + 2 * j) * 9 + tap], w[(cg * 8 + 2 * j + 1) * 9 + tap]};
     }
-    bf16x8 o;
+    const int nseg = (W + 15) / 16, total = B * H * nseg;  // 16-pixel segments (a segment never crosses a row)
+    const int gstride = gridDim.x * 4;
+    const int wrow = lane / 18, wcol = lane % 18;          // window element this lane loads (lanes 0..53)
+    for (int sg = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); sg < total; sg += gstride) {
+        const int row = sg / nseg, d0 = (sg - row * nseg) * 16, t = row % H;
+        float wv = 0.f;
+        {
+            const int tt = t + wrow - 1, dd = d0 + wcol - 1;
+            if (lane < 54 && tt >= 0 && tt < H && dd >= 0 && dd < W) wv = x[(long)(row + wrow - 1) * W + dd];
+        }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int co = cg * 8 + j;
-        float a = sw[576 + co];
+        for (int k = 0; k < 2; ++k) {
+            const int px = pg * 2 + k;
+            float xv[9];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) a = fmaf(sw[co * 9 + tap], xv[tap], a);
-        o[j] = (bf16)fmaxf(a, 0.f);
+            for (int tap = 0; tap < 9; ++tap) xv[tap] = __shfl(wv, (tap / 3) * 18 + px + tap % 3);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x2 a = br[j];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) a = __builtin_elementwise_fma(wr[j][tap], f32x2{xv[tap], xv[tap]}, a);
+                o[2 * j] = (bf16)fmaxf(a[0], 0.f);
+                o[2 * j + 1] = (bf16)fmaxf(a[1], 0.f);
+            }
+            const int d = d0 + px;
+            if (d < W) st8(out + ((long)row * W + d) * cstride + cg * 8, o);
+        }
     }
-    st8(out + p * cstride + cg * 8, o);
 }
 
 constexpr int C1_PIX = 2048;   // pixels per block in conv1 wgrad
@@ -1882,9 +1900,15 @@ __global__ void maxpool_relu_bwd_kernel(const bf16* __restrict__ in, const bf16*
 
 }  // namespace
 
+// workgroups of 4 waves stride over the 16-pixel row segments
+static long conv1_grid(int B, int H, int W) {
+    const long blocks = ((long)B * H * ((W + 15) / 16) + 3) / 4;
+    return blocks < 2048 ? blocks : 2048;
+}
 int mk_conv1_fwd(const float* x, const float* w, const float* bias, bf16* out, int B, int H, int W, hipStream_t s) {
     const long P = (long)B * H * W;
-    hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, s, x, w, bias, out, B, H, W, 64);
+    if (P >= (1L << 31) - 65536) { mk_set_error("mk_conv1_fwd", "map too large"); return -1; }
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)conv1_grid(B, H, W)), dim3(256), 0, s, x, w, bias, out, B, H, W, 64);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 long mk_conv1_wgrad_slab_floats(int B, int H, int W) { return (((long)B * H * W + C1_PIX - 1) / C1_PIX + C1_RSPLIT) * 640; }
@@ -1900,8 +1924,9 @@ int mk_conv1_wgrad(const float* x, const bf16* dy, float* dw, float* db, float* 
 int mk_conv1_fwd_n(const float* x, const float* w, const float* bias, bf16* out, int B, int H, int W, int COUT, hipStream_t s) {
     if (COUT % 64) { mk_set_error("mk_conv1_fwd_n", "COUT must be a multiple of 64"); return -1; }
     const long P = (long)B * H * W;
+    if (P >= (1L << 31) - 65536) { mk_set_error("mk_conv1_fwd_n", "map too large"); return -1; }
     for (int c0 = 0; c0 < COUT; c0 += 64)
-        hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, s, x, w + c0 * 9, bias + c0, out + c0, B, H, W, COUT);
+        hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)conv1_grid(B, H, W)), dim3(256), 0, s, x, w + c0 * 9, bias + c0, out + c0, B, H, W, COUT);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int mk_conv1_wgrad_n(const float* x, const bf16* dy, float* dw, float* db, float* slab, int B, int H, int W, int COUT, hipStream_t s) {
