@@ -68,28 +68,36 @@ __device__ __forceinline__ bf16x8 frag_global(const bf16* base, long ld, int row
     return ok ? v : zero8();
 }
 
-// copy a [64][HD] tile (rows row0.. of a [nrows] matrix) into LDS, zero-filling missing rows.  All loads are issued
-// unconditionally (clamped row) before the first LDS store: a branch around a global load costs an s_waitcnt vmcnt(0).
+// A [64][HD] tile (rows row0.. of a [nrows] matrix) on its way into LDS: fetch() issues the loads (unconditionally, row
+// clamped: a branch around a global load costs an s_waitcnt vmcnt(0)), commit() stores them, zero-filling missing rows.
+// The loops below fetch tile i+1 right after committing tile i, so the memory round trip runs under tile i's MFMAs
+// (fetch-then-use inside one iteration exposed it once per key/query block: 4 times for the 250-frame encoder).
 template <int HD>
-__device__ __forceinline__ void load_tile(bf16* dst, const bf16* src, long ld, int row0, int nrows, int tid) {
-    constexpr int LD = Cfg<HD>::LD;
-    constexpr int CPR = HD / 8;                        // chunks per row
-    constexpr int N = (BLK * CPR + 255) / 256;         // chunks per thread
+struct TileRegs {
+    static constexpr int CPR = HD / 8;                 // chunks per row
+    static constexpr int N = (BLK * CPR + 255) / 256;  // chunks per thread
     bf16x8 v[N];
+    int row0 = 0;
+    __device__ __forceinline__ void fetch(const bf16* src, long ld, int r0, int nrows, int tid) {
+        row0 = r0;
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const int c = tid + i * 256;
-        const int r = (c / CPR) % BLK, dc = (c % CPR) * 8;
-        const int row = row0 + r < nrows ? row0 + r : nrows - 1;
-        v[i] = ld8(src + (long)row * ld + dc);
+        for (int i = 0; i < N; ++i) {
+            const int c = tid + i * 256;
+            const int r = (c / CPR) % BLK, dc = (c % CPR) * 8;
+            const int row = r0 + r < nrows ? r0 + r : nrows - 1;
+            v[i] = ld8(src + (long)row * ld + dc);
+        }
     }
+    __device__ __forceinline__ void commit(bf16* dst, int nrows, int tid) const {
+        constexpr int LD = Cfg<HD>::LD;
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const int c = tid + i * 256;
-        const int r = c / CPR, dc = (c % CPR) * 8;
-        if (c < BLK * CPR) st8(dst + r * LD + dc, row0 + r < nrows ? v[i] : zero8());
+        for (int i = 0; i < N; ++i) {
+            const int c = tid + i * 256;
+            const int r = c / CPR, dc = (c % CPR) * 8;
+            if (c < BLK * CPR) st8(dst + r * LD + dc, row0 + r < nrows ? v[i] : zero8());
+        }
     }
-}
+};
 // only head dims < 32 have padding columns (dims HD..31) that must read as zero
 template <int HD>
 __device__ __forceinline__ void zero_tile(bf16* dst, int tid) {
@@ -137,11 +145,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     int nkb = (Tk + BLK - 1) / BLK;
     if (a.causal) { const int lim = (q0 + BLK - 1) / BLK + 1; if (lim < nkb) nkb = lim; }
 
+    TileRegs<HD> tk, tv;
+    tk.fetch(kb_, a.ldk, 0, Tk, tid);
+    tv.fetch(vb, a.ldv, 0, Tk, tid);
     for (int kb = 0; kb < nkb; ++kb) {
         __syncthreads();
-        load_tile<HD>(sK, kb_, a.ldk, kb * BLK, Tk, tid);
-        load_tile<HD>(sV, vb, a.ldv, kb * BLK, Tk, tid);
+        tk.commit(sK, Tk, tid);
+        tv.commit(sV, Tk, tid);
         __syncthreads();
+        if (kb + 1 < nkb) { tk.fetch(kb_, a.ldk, (kb + 1) * BLK, Tk, tid); tv.fetch(vb, a.ldv, (kb + 1) * BLK, Tk, tid); }
 
         f32x4 s[4];
 #pragma unroll
@@ -282,11 +294,15 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
 
     int nkb = (Tk + BLK - 1) / BLK;
     if (a.causal) { const int lim = (q0 + BLK - 1) / BLK + 1; if (lim < nkb) nkb = lim; }
+    TileRegs<HD> tk, tv;
+    tk.fetch(kb_, a.ldk, 0, Tk, tid);
+    tv.fetch(vb, a.ldv, 0, Tk, tid);
     for (int kb = 0; kb < nkb; ++kb) {
         __syncthreads();
-        load_tile<HD>(sK, kb_, a.ldk, kb * BLK, Tk, tid);
-        load_tile<HD>(sV, vb, a.ldv, kb * BLK, Tk, tid);
+        tk.commit(sK, Tk, tid);
+        tv.commit(sV, Tk, tid);
         __syncthreads();
+        if (kb + 1 < nkb) { tk.fetch(kb_, a.ldk, (kb + 1) * BLK, Tk, tid); tv.fetch(vb, a.ldv, (kb + 1) * BLK, Tk, tid); }
         bf16* sp = sP[wave];
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
@@ -364,17 +380,26 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
 
     const int nqb = (Tq + BLK - 1) / BLK;
     const int qb0 = a.causal ? k0 / BLK : 0;
-    for (int qbi = qb0; qbi < nqb; ++qbi) {
-        __syncthreads();
-        load_tile<HD>(sQ, qb, a.ldq, qbi * BLK, Tq, tid);
-        load_tile<HD>(sDO, dob, a.lddo, qbi * BLK, Tq, tid);
+    TileRegs<HD> tq, tdo;
+    float nlse = 0.f, ndl = 0.f;                           // threads 0..63: lse / delta of the next query block
+    auto fetch_q = [&](int qbi) {
+        tq.fetch(qb, a.ldq, qbi * BLK, Tq, tid);
+        tdo.fetch(dob, a.lddo, qbi * BLK, Tq, tid);
         if (tid < BLK) {
             const int qi = qbi * BLK + tid;
-            const long idx = ((long)b * a.H + h) * Tq + qi;
-            sLse[tid] = qi < Tq ? a.lse[idx] : 0.f;
-            sDl[tid] = qi < Tq ? a.delta[idx] : 0.f;
+            const long idx = ((long)b * a.H + h) * Tq + (qi < Tq ? qi : Tq - 1);
+            const float l0 = a.lse[idx], d0 = a.delta[idx];
+            nlse = qi < Tq ? l0 : 0.f; ndl = qi < Tq ? d0 : 0.f;
         }
+    };
+    if (qb0 < nqb) fetch_q(qb0);
+    for (int qbi = qb0; qbi < nqb; ++qbi) {
         __syncthreads();
+        tq.commit(sQ, Tq, tid);
+        tdo.commit(sDO, Tq, tid);
+        if (tid < BLK) { sLse[tid] = nlse; sDl[tid] = ndl; }
+        __syncthreads();
+        if (qbi + 1 < nqb) fetch_q(qbi + 1);
         bf16* sp = sP[wave];
         bf16* sd = sDS[wave];
 #pragma unroll
