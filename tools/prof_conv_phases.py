@@ -38,7 +38,9 @@ for (B, H, W, CI, CO, TH, TW) in shapes:
         abl = {n: timed(lambda f=f: L.masr_test_conv3x3_prof(P(x), P(wk), P(bias), 1 | f << 8, P(out), B, H, W, CI, CO, P(prof), S()))
                for n, f in (("no patch DMA", 1), ("no weight DMA", 2), ("no epilogue", 4), ("MFMA loop only", 7))}
         usp = timed(lambda: L.masr_test_conv3x3_prof(P(x), P(wk), P(bias), 1, P(out), B, H, W, CI, CO, P(prof), S()))
-        print("    ablations (us): " + ", ".join(f"{n} {v:.1f}" for n, v in abl.items()))
+        abl_line = "    ablations (us): " + ", ".join(f"{n} {v:.1f}" for n, v in abl.items())
+    else:
+        abl_line = None
     pr = prof.view(nwg, 6).double()
     if STREAM:
         pr = pr[pr[:, 1] > 0]                     # persistent grid: only the launched workgroups wrote
@@ -50,3 +52,5 @@ for (B, H, W, CI, CO, TH, TW) in shapes:
           f"{tot.mean():.0f} cycles/WG (min {tot.min():.0f} max {tot.max():.0f})")
     for k in range(6):
         print(f"    {NAMES[k]:26s} {mean[k]:9.0f} cycles  {100 * mean[k] / tot.mean():5.1f}%")
+    if abl_line:
+        print(abl_line)
