@@ -88,7 +88,8 @@ def test_conv3x3(L, B_, H, W, CIN, COUT):
     torch.testing.assert_close(out.float(), ref, rtol=1e-2, atol=1e-2)              # bf16 output rounding
 
 
-@pytest.mark.parametrize("B_,H,W,CIN,COUT", [(2, 38, 80, 64, 64), (3, 50, 40, 128, 128), (1, 33, 21, 128, 64), (2, 301, 80, 64, 64), (1, 17, 48, 128, 128)])
+@pytest.mark.parametrize("B_,H,W,CIN,COUT", [(2, 38, 80, 64, 64), (3, 50, 40, 128, 128), (1, 33, 21, 128, 64), (2, 301, 80, 64, 64), (1, 17, 48, 128, 128),
+                                             (2, 45, 83, 64, 64), (2, 27, 41, 64, 128), (1, 1000, 83, 64, 64)])   # idim 83: odd widths, 16-wide tiles with a ragged edge
 def test_conv3x3_mask_and_pool(L, B_, H, W, CIN, COUT):
     """the two epilogue flavours of the engine: dgrad (no bias, output zeroed where the ReLU mask is <= 0) and
     forward with the fused 2x2 max-pool (floor mode, odd H / W drop the last row / column)"""
