@@ -107,6 +107,25 @@ __device__ __forceinline__ void zero_tile(bf16* dst, int tid) {
     }
 }
 
+// Write a wave's 16 x HD accumulator tile (lane: rows 4g+r, column dt*16 + (lane&15)) as whole row segments: through the
+// wave's P scratch, then 16 bytes per lane.  The element-wise form issued 4*DT two-byte stores per lane -- for the three
+// outputs of the backward pass 192 vector-memory instructions per workgroup, more than all its loads.
+template <int HD>
+__device__ __forceinline__ void store_rows16(bf16* sp, const f32x4 (&acc)[HD / 16], const float (&mul)[4], bf16* dst, long ld, int row0,
+                                             int nrows, int lane) {
+    constexpr int DT = HD / 16, CPR = HD / 8;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) sp[((lane >> 4) * 4 + r) * LDP + dt * 16 + (lane & 15)] = (bf16)(acc[dt][r] * mul[r]);
+    // (same wave: LDS operations complete in order, no barrier needed)
+#pragma unroll
+    for (int u = 0; u < (16 * CPR + 63) / 64; ++u) {
+        const int c = lane + 64 * u, row = c / CPR, col = (c % CPR) * 8;
+        if (c < 16 * CPR && row0 + row < nrows) st8(dst + (long)(row0 + row) * ld + col, ld8(sp + row * LDP + col));
+    }
+}
+
 // ---------------------------------------------------------------------------- forward
 template <int HD>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
@@ -219,16 +238,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             for (int dt = 0; dt < DT; ++dt) o[dt] = mma16(pf, frag_tr<LD>(sV, ks2 * 32, dt * 16, lane), o[dt]);
         }
     }
+    float inv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int qi = qrow0 + (lane >> 4) * 4 + r;
-        if (qi >= Tq) continue;
-        const float inv = 1.f / l[r];
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-            a.o[((long)b * Tq + qi) * a.ldo + h * HD + dt * 16 + (lane & 15)] = (bf16)(o[dt][r] * inv);
-        if ((lane & 15) == 0) a.lse[((long)b * a.H + h) * Tq + qi] = m[r] + __logf(l[r]);
+        inv[r] = 1.f / l[r];
+        if (qi < Tq && (lane & 15) == 0) a.lse[((long)b * a.H + h) * Tq + qi] = m[r] + __logf(l[r]);
     }
+    store_rows16<HD>(sP[wave], o, inv, a.o + (long)b * Tq * a.ldo + h * HD, a.ldo, qrow0, Tq, lane);
 }
 
 // ---------------------------------------------------------------------------- backward
@@ -334,13 +351,9 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
             for (int dt = 0; dt < DT; ++dt) dq[dt] = mma16(df, frag_tr<LD>(sK, ks2 * 32, dt * 16, lane), dq[dt]);
         }
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qi = qrow0 + (lane >> 4) * 4 + r;
-        if (qi >= Tq) continue;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-            a.dq[((long)b * Tq + qi) * a.lddq + h * HD + dt * 16 + (lane & 15)] = (bf16)dq[dt][r];
+    {
+        const float one[4] = {1.f, 1.f, 1.f, 1.f};
+        store_rows16<HD>(sP[wave], dq, one, a.dq + (long)b * Tq * a.lddq + h * HD, a.lddq, qrow0, Tq, lane);
     }
 }
 
@@ -437,16 +450,10 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
             }
         }
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int kj = krow0 + (lane >> 4) * 4 + r;
-        if (kj >= Tk) continue;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const long off = ((long)b * Tk + kj);
-            a.dk[off * a.lddk + h * HD + dt * 16 + (lane & 15)] = (bf16)dk[dt][r];
-            a.dv[off * a.lddv + h * HD + dt * 16 + (lane & 15)] = (bf16)dv[dt][r];
-        }
+    {
+        const float one[4] = {1.f, 1.f, 1.f, 1.f};
+        store_rows16<HD>(sP[wave], dk, one, a.dk + (long)b * Tk * a.lddk + h * HD, a.lddk, krow0, Tk, lane);
+        store_rows16<HD>(sDS[wave], dv, one, a.dv + (long)b * Tk * a.lddv + h * HD, a.lddv, krow0, Tk, lane);
     }
 }
 
