@@ -565,6 +565,7 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
     constexpr int PBYTES = PPIECES * 1024, WPIECES = COUT / 8, WBYTES = COUT * 128;
     __shared__ __attribute__((aligned(1024))) char lds[2 * PBYTES + D * WBYTES];
     __shared__ int tileq[4];                               // tile ids of this workgroup's k-th, k+1-th, ... tile (-1 = none)
+    __shared__ __attribute__((aligned(16))) float sbias[COUT];
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
     typedef __attribute__((ext_vector_type(2))) short short2_t;
@@ -751,15 +752,9 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) poff[dx][kc] = (prow0 * PW + pcol0 + dx) * 128 + (((kc * 4 + q) ^ ((pcol0 + dx) & 7)) * 16);
     }
-    // lane (rr, q) ends up with channels h*32 + q*8 .. +7 of pixel rr of each pixel tile
-    f32x2 bv[NH][4];
-#pragma unroll
-    for (int h = 0; h < NH; ++h)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            bv[h][k][0] = (!MASK && a.bias) ? a.bias[h * 32 + q * 8 + 2 * k] : 0.f;
-            bv[h][k][1] = (!MASK && a.bias) ? a.bias[h * 32 + q * 8 + 2 * k + 1] : 0.f;
-        }
+    // lane (rr, q) ends up with channels h*32 + q*8 .. +7 of pixel rr of each pixel tile.  The bias waits in LDS for the
+    // epilogue (32 registers per lane at 128 output channels, which the 32-row tiles do not have)
+    for (int c = threadIdx.x; c < COUT; c += 256) sbias[c] = (!MASK && a.bias) ? a.bias[c] : 0.f;
 
     // One half-tap = MF*NF MFMAs on one fragment set while the reads of the NEXT set are issued in their shadow, one read
     // after each of the first MF+NF MFMAs (an MFMA holds the pipe for 16 cycles, the wave is free to issue in between; with
@@ -873,7 +868,7 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
                 for (int kk = 0; kk < 4; ++kk) {
                     const f32x4& c = acc[i][2 * h + (kk >> 1)];
                     f32x2 v = {c[2 * (kk & 1)], c[2 * (kk & 1) + 1]};
-                    v += bv[h][kk];
+                    v += *reinterpret_cast<const f32x2*>(&sbias[h * 32 + q * 8 + 2 * kk]);
                     unsigned r;
                     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(v[0]), "v"(v[1]));
                     pk[kk] = __builtin_elementwise_max(__builtin_bit_cast(short2_t, r), floor2);   // ReLU (or a no-op)
@@ -2002,14 +1997,14 @@ static void launch_resw(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t
     const int grid = chunk > 0 ? (ntiles + chunk - 1) / chunk : (ntiles < resident ? ntiles : resident);
     hipLaunchKernelGGL((conv3x3_resw_kernel<16, 16, PROF>), dim3((unsigned)grid), dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, chunk);
 }
-template <int CI, int CO, int TWV, bool MASK, bool PROF = false>
+template <int CI, int CO, int TWV, bool MASK, bool PROF = false, int THV = 16>
 static void launch_stream_t(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
     static int resident = 0;
     if (!resident) {
         int dev = 0, ncu = 0, per_cu = 0;
         hipGetDevice(&dev);
         hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3x3_stream_kernel<CI, CO, 16, TWV, MASK, PROF>, 384, 0);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3x3_stream_kernel<CI, CO, THV, TWV, MASK, PROF>, 384, 0);
         if (ncu <= 0) ncu = 256;
         if (per_cu <= 0) per_cu = 1;
         static const int cap = getenv("MASR_CONV_STREAM_WGPC") ? atoi(getenv("MASR_CONV_STREAM_WGPC")) : 2;
@@ -2024,12 +2019,12 @@ static void launch_stream_t(const ConvArgs& a, int tiles_x, int tiles_y, hipStre
     }
     const int chunk = stream_chunk();
     const int grid = chunk > 0 ? (ntiles + chunk - 1) / chunk : (ntiles < resident ? ntiles : resident);
-    hipLaunchKernelGGL((conv3x3_stream_kernel<CI, CO, 16, TWV, MASK, PROF>), dim3((unsigned)grid), dim3(384), 0, s, b, ntiles, tiles_x, tiles_y, chunk);
+    hipLaunchKernelGGL((conv3x3_stream_kernel<CI, CO, THV, TWV, MASK, PROF>), dim3((unsigned)grid), dim3(384), 0, s, b, ntiles, tiles_x, tiles_y, chunk);
 }
-template <int CI, int CO, int TWV, bool PROF = false>
+template <int CI, int CO, int TWV, bool PROF = false, int THV = 16>
 static void launch_stream(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
-    if (a.mask) launch_stream_t<CI, CO, TWV, true, PROF>(a, tiles_x, tiles_y, s);
-    else launch_stream_t<CI, CO, TWV, false, PROF>(a, tiles_x, tiles_y, s);
+    if (a.mask) launch_stream_t<CI, CO, TWV, true, PROF, THV>(a, tiles_x, tiles_y, s);
+    else launch_stream_t<CI, CO, TWV, false, PROF, THV>(a, tiles_x, tiles_y, s);
 }
 int mk_conv3x3(const ConvArgs& a, hipStream_t s) {
     if (getenv("MASR_CONV_V1")) {                          // first-generation im2col-on-the-fly kernel (kept for A/B runs)
@@ -2079,7 +2074,14 @@ int mk_conv3x3(const ConvArgs& a, hipStream_t s) {
         else if (a.CIN == 64 && a.COUT == 64) launch_stream<64, 64, 8>(a, tiles_x, tiles_y, s);
         else if (a.CIN == 64 && a.COUT == 128) launch_stream<64, 128, 8>(a, tiles_x, tiles_y, s);
         else if (a.CIN == 128 && a.COUT == 128) launch_stream<128, 128, 8>(a, tiles_x, tiles_y, s);
-        else launch_stream<128, 64, 8>(a, tiles_x, tiles_y, s);
+        else {
+            // 128 -> 64 takes 32-row tiles: the per-tap weight slices (the bulk of these kernels' vector-memory instructions)
+            // are amortised over twice the pixels (-14 % isolated).  At 128 output channels 32-row tiles need 128 accumulator
+            // + 96 fragment registers per lane and spill.
+            static const bool th32 = !(getenv("MASR_CONV_TH32") && atoi(getenv("MASR_CONV_TH32")) == 0);
+            if (th32) launch_stream<128, 64, 8, false, 32>(a, tiles_x, (a.H + 31) / 32, s);
+            else launch_stream<128, 64, 8>(a, tiles_x, tiles_y, s);
+        }
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     if (a.x1) {
