@@ -761,35 +761,48 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
     // all the reads issued up front the pipe idles for their issue time every half-tap).  sched_barrier(0) after every
     // instruction pins exactly this order.  The reads are inline asm waited on by hand: the compiler's own bookkeeping would
     // put a full lgkmcnt(0) between a set's reads and the MFMAs of the previous set, an exposed LDS round trip per half-tap.
-    struct Frags { bf16x8 a[MF], b[NF]; };
+    // Pixel fragments (A) are double-buffered; weight fragments (B) live in ONE set: the MFMAs run weight-block-major
+    // (all pixel tiles of block j, then block j+1), so block j's registers are free after its MF MFMAs and its reload for
+    // the next half-tap is issued right there -- it has the rest of this half-tap to land and is needed in the same order.
+    // (A second B set costs 32 registers per lane at 128 output channels, which 32-row tiles do not have.)
+    struct AFrags { bf16x8 a[MF]; };
+    bf16x8 bfr[NF];
     typedef __attribute__((address_space(3))) const char lds_cchar;
     f32x4 acc[MF][NF];
-    auto half_tap = [&](const Frags& use, Frags& ld, const char* pl, const char* wl, int tap, int kc) {
+    auto half_tap = [&](const AFrags& use, AFrags& ld, const char* pl, const char* wl, int tap, int kc) {
         const int dy = tap / 3, dx = tap % 3;
         const unsigned pa = (unsigned)(size_t)((lds_cchar*)pl) + poff[dx][kc];
         const unsigned wa = (unsigned)(size_t)((lds_cchar*)wl) + woff[kc];
+        // LDS reads return in issue order: ..., a[0..MF) , b[0], ..., b[NF-1] of the previous half-tap, then this half-tap's.
+        // Block 0 needs a[*] and b[0]: at most the NF-1 later weight reads may be outstanding.  Block j > 0 needs b[j]:
+        // behind it are b[j+1..NF) and this half-tap's MF + j reads, MF + NF - 1 in all.
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NF - 1) : "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < MF * NF; ++m) {
-            const int i = m / NF, j = m % NF;
-            acc[i][j] = mma16(use.b[j], use.a[i], acc[i][j]);   // weights as A: a lane ends up with 4 consecutive channels
+            const int j = m / MF, i = m % MF;
+            if (i == 0 && j > 0) {
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MF + NF - 1) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            acc[i][j] = mma16(bfr[j], use.a[i], acc[i][j]);     // weights as A: a lane ends up with 4 consecutive channels
             __builtin_amdgcn_sched_barrier(0);
             if (m < MF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ld.a[m < MF ? m : 0]) : "v"(pa), "n"(((m < MF ? m : 0) * RPT + dy) * PW * 128));
-            else if (m < MF + NF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ld.b[m < MF + NF ? m - MF : 0]) : "v"(wa), "n"((m < MF + NF ? m - MF : 0) * 2048));
+            if (i == MF - 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[j]) : "v"(wa), "n"(j * 2048));
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto load_frags = [&](Frags& f, const char* pcur, const char* wcur, int tap, int kc) {
+    auto load_frags = [&](AFrags& f, const char* pcur, const char* wcur, int tap, int kc) {
         const int dy = tap / 3, dx = tap % 3;
         const unsigned pa = (unsigned)(size_t)((lds_cchar*)pcur) + poff[dx][kc];
         const unsigned wa = (unsigned)(size_t)((lds_cchar*)wcur) + woff[kc];
 #pragma unroll
         for (int i = 0; i < MF; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.a[i]) : "v"(pa), "n"((i * RPT + dy) * PW * 128));
 #pragma unroll
-        for (int j = 0; j < NF; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.b[j]) : "v"(wa), "n"(j * 2048));
+        for (int j = 0; j < NF; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[j]) : "v"(wa), "n"(j * 2048));
     };
 
-    Frags f0, f1;
+    AFrags f0, f1;
     stamp(2);
     asm volatile("s_barrier" ::: "memory");               // opening barrier
     int tile = read_tileq(0);
@@ -834,11 +847,11 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
                 const char* wcur = wbuf + ((g + tap) & (D - 1)) * WBYTES;          // 9 g + tap = g + tap (mod 4)
                 const char* wnext = wbuf + ((g + tap + 1) & (D - 1)) * WBYTES;
                 // first half: MFMAs on f0 (read during the previous half-tap), reads of this tap's second k-half into f1
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 half_tap(f0, f1, pcur, wcur, tap, 1);
-                // barrier u: slice u+1 (and at tap 8 the next patch) is in.  lgkmcnt(0): every LDS read this wave has issued is
-                // complete before the producers may overwrite tap u-1's buffers, and f1 is ready
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                // barrier u: slice u+1 (and at tap 8 the next patch) is in.  No LDS wait is needed here: the reads this wave
+                // still has in flight are of slice u and of the current patch, not of the buffers the producers may now
+                // overwrite (slice u-1, the previous stage's patch: their last reads were consumed a half-tap ago)
+                asm volatile("s_barrier" ::: "memory");
                 // second half: MFMAs on f1, reads of the next tap's first k-half into f0 (after the very last tap of the
                 // workgroup these read stale LDS and are never used)
                 if (tap < 8) half_tap(f1, f0, pcur, wnext, tap + 1, 0);
@@ -2073,13 +2086,16 @@ int mk_conv3x3(const ConvArgs& a, hipStream_t s) {
         else if (!narrow) launch_stream<64, 64, 16>(a, tiles_x, tiles_y, s);
         else if (a.CIN == 64 && a.COUT == 64) launch_stream<64, 64, 8>(a, tiles_x, tiles_y, s);
         else if (a.CIN == 64 && a.COUT == 128) launch_stream<64, 128, 8>(a, tiles_x, tiles_y, s);
-        else if (a.CIN == 128 && a.COUT == 128) launch_stream<128, 128, 8>(a, tiles_x, tiles_y, s);
         else {
-            // 128 -> 64 takes 32-row tiles: the per-tap weight slices (the bulk of these kernels' vector-memory instructions)
-            // are amortised over twice the pixels (-14 % isolated).  At 128 output channels 32-row tiles need 128 accumulator
-            // + 96 fragment registers per lane and spill.
+            // 32-row tiles where the registers allow: the per-tap weight slices (the bulk of these kernels' vector-memory
+            // instructions) are amortised over twice the pixels (128 -> 128 forward 103 -> 89 us, 128 -> 64 76 -> 61 us
+            // isolated).  Not for 64 -> 128 (spills, slower) nor for the masked 128 -> 128 dgrad (64 more mask registers).
             static const bool th32 = !(getenv("MASR_CONV_TH32") && atoi(getenv("MASR_CONV_TH32")) == 0);
-            if (th32) launch_stream<128, 64, 8, false, 32>(a, tiles_x, (a.H + 31) / 32, s);
+            const int ty32 = (a.H + 31) / 32;
+            if (a.CIN == 128 && a.COUT == 128) {
+                if (th32 && !a.mask) launch_stream_t<128, 128, 8, false, false, 32>(a, tiles_x, ty32, s);
+                else launch_stream<128, 128, 8>(a, tiles_x, tiles_y, s);
+            } else if (th32) launch_stream<128, 64, 8, false, 32>(a, tiles_x, ty32, s);
             else launch_stream<128, 64, 8>(a, tiles_x, tiles_y, s);
         }
         return hipGetLastError() == hipSuccess ? 0 : -1;
