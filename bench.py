@@ -122,10 +122,31 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--mixed", action="store_true", help="also time a mixed-length leg (ilens ~ U{200..1500}), reported as \"mixed_lengths\"")
     ap.add_argument("--no-stagger", action="store_true", help="start all concurrent tasks at the same instant (lock-step)")
+    ap.add_argument("--no-meta-step", action="store_true", help="skip the whole-meta-step leg (\"meta_step\" in the output)")
+    ap.add_argument("--meta-rounds", type=int, default=2, help="task rounds per rank in the meta-step leg (>= 2 shows the all-reduce overlap)")
+    ap.add_argument("--meta-steps", type=int, default=5)
     ap.add_argument("--tasks-per-gpu", type=int, default=4, help="concurrent independent accent-tasks per GPU (1 = reference order)")
     args = ap.parse_args()
 
+    # ---- `python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This process has not touched the
+    # GPU (no HIP call, no torch.cuda.* so far), it only waits for the child launcher and returns its exit code; the ranks
+    # are fresh child processes (a GPU-initialised process is never re-exec'd).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        log(f"launching {args.gpus} ranks: {' '.join(cmd)}")
+        sys.exit(subprocess.run(cmd, env=env).returncode)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
+                 f"`python bench.py --gpus N` or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -284,17 +305,75 @@ def main():
     def step(i):
         tasks[0].step()
 
-    # ---- one FOMAML meta-step's exchange (all-reduce of the flat meta-gradient) for information
+    # ---- one whole FOMAML meta-step (fo_meta_interface.py:136-158,200-221) with its exchange: every rank runs R task
+    # rounds {copy meta->task, k=1 inner step, val-batch gradient, clip 5}; each round's clipped gradient is all-reduced
+    # on the side stream (parallel.TaskSharder.reduce_async, RCCL) WHILE the next round's inner step runs; then
+    # sum / n_tasks and the replicated Noam-Adam step.  Timed with and without the exchange: the difference is the part
+    # of the all-reduce that is NOT hidden.  (The metric itself counts inner steps, which have no exchange.)
     meta = None
-    if dist is not None:
-        upd = torch.zeros_like(eng.params)
-        eng.clip_accumulate(upd, 5.0)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(5):
-            all_reduce_(upd)
-        torch.cuda.synchronize(dev)
-        meta = {"allreduce_ms": (time.perf_counter() - t1) / 5 * 1e3, "payload_mb": upd.numel() * 4 / 1e6}
+    if not args.no_meta_step:
+        from masr_amd.parallel import TaskSharder
+        sharder = TaskSharder.from_env() if dist is not None else TaskSharder()
+        t0_ = tasks[0]
+        R, nmeta = args.meta_rounds, args.meta_steps
+        orig = eng.params.clone()
+        ea, eas = torch.zeros_like(orig), torch.zeros_like(orig)
+        contribs = [torch.zeros_like(orig) for _ in range(R)]
+        total = torch.zeros_like(orig)
+
+        def meta_step(i, exchange):
+            for r in range(R):
+                eng.copy(eng.params, orig)
+                eng.mark_dirty()
+                eng.run_batch(t0_.xs, t0_.il, t0_.ys, t0_.ol, train=True)
+                eng.clip_sgd_step(t0_.mom, 5.0, lr, 0.9, True, first_step=True)
+                eng.run_batch(t0_.xs, t0_.il, t0_.ys, t0_.ol, train=True)        # val batch at the adapted weights
+                contribs[r].zero_()
+                eng.clip_accumulate(contribs[r], 5.0)
+                if exchange and dist is not None:
+                    if backend == "nccl":
+                        sharder.reduce_async(contribs[r])
+                    else:
+                        all_reduce_(contribs[r])
+            if exchange:
+                sharder.wait_all()
+            total.zero_()
+            for c in contribs:
+                eng.axpy(total, c, 1.0)
+            eng.scale(total, 1.0 / (R * world))
+            eng.adam_step(orig, total, ea, eas, 1e-7, 0.9, 0.98, 1e-9, i + 1)
+
+        def time_meta(exchange):
+            meta_step(0, exchange)
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(nmeta):
+                meta_step(1 + i, exchange)
+            barrier()
+            d = time.perf_counter() - t1
+            if dist is not None:
+                tt = torch.tensor([d], device=coll_dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                d = float(tt.item())
+            return d / nmeta * 1e3
+        ms_no = time_meta(False)
+        ms_ex = time_meta(True) if dist is not None else ms_no
+        ar_ms = None
+        if dist is not None:
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                all_reduce_(contribs[0])
+            torch.cuda.synchronize(dev)
+            ar_ms = (time.perf_counter() - t1) / 5 * 1e3
+        meta = {"rounds_per_rank": R, "inner_steps": 1, "tasks": R * world, "ms": ms_ex, "ms_without_exchange": ms_no,
+                "exposed_exchange_ms": ms_ex - ms_no, "allreduce_ms_isolated": ar_ms, "allreduces_per_meta_step": R if dist is not None else 0,
+                "payload_mb": orig.numel() * 4 / 1e6, "backend": ("rccl" if backend == "nccl" else backend) if dist is not None else None,
+                "utt_per_s": world * R * 2 * B / (ms_ex * 1e-3)}
+        log(f"meta-step: {ms_ex:.2f} ms with exchange, {ms_no:.2f} ms without, isolated all-reduce {ar_ms}")
+        eng.copy(eng.params, orig)
+        eng.mark_dirty()
+        del contribs, total, ea, eas
 
     # ---- roofline of the dominant kernel, timed live with HIP events on the launch stream
     roof = None

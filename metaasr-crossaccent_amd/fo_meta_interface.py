@@ -10,6 +10,7 @@ Reference quirks kept by default: snapshots hold the LAST TA
 evaluation runs on them too (Q2), a NaN val gradient is still accumulated (Q5); --fix_* flags opt out."""
 import math
 import pickle
+import random
 import threading
 from functools import partial
 
@@ -46,7 +47,10 @@ class FOMetaASRInterface(PretrainInterface):
         # (small decoder GEMMs, kernel tails); three concurrent tasks raise the throughput ~1.6x.  1 = reference order.
         self.tasks_per_gpu = max(1, int(getattr(paras, 'tasks_per_gpu', 1) or 1))
         self._slots = None
-        self._task_rng = self.sharder.task_rng(getattr(paras, 'seed', 531))
+        # task order: the reference's global `random` stream (:136).  Every rank consumes that stream identically (data
+        # draws of non-owned tasks are replayed index-only, see train()), so the order is the same on all ranks and the
+        # same as in the single-process run.
+        self._task_rng = random
         logger.notice(f"Meta batch size {self.meta_batch_size}, {self.meta_k} inner steps, inner lr {self.inner_lr:.3e}, "
                       f"rank {self.sharder.rank}/{self.sharder.world}")
 
@@ -108,8 +112,8 @@ class FOMetaASRInterface(PretrainInterface):
             models.append(MyTransformer(self.id2ch, self.config['asr_model'], self.label_smooth_rate, device=dev, init=False))
         self._slots = [{'model': m, 'engine': m.engine, 'stream': _t.cuda.Stream(device=dev) if self.tasks_per_gpu > 1 else None}
                        for m in models]
-        for i, sl in enumerate(self._slots[1:], 1):
-            sl['engine'].set_seed(getattr(self.paras, 'seed', 531) + 7919 * i)
+        for i, sl in enumerate(self._slots):                                 # one dropout stream per (rank, slot)
+            sl['engine'].set_seed(getattr(self.paras, 'seed', 531) + 7919 * (self.sharder.rank * self.tasks_per_gpu + i))
 
     def write_tr_logs(self):
         for k, v in self.train_info.items():
@@ -135,9 +139,12 @@ class FOMetaASRInterface(PretrainInterface):
         """tasks_per_gpu > 1: batches are drawn on the main thread in the reference's order (the samplers share RNG
         streams), then waves of K tasks run concurrently; gradients are accumulated in task order -> deterministic."""
         fetched = []
-        for accent_id in task_ids:
-            tr = self.data_container.get_item(accent_id, self.meta_k)
-            fetched.append((accent_id, tr, self.data_container.get_item(accent_id)[0]))
+        for pos, accent_id in enumerate(task_ids):
+            own = self.sharder.owns(pos)
+            tr = self.data_container.get_item(accent_id, self.meta_k, materialize=own)
+            val = self.data_container.get_item(accent_id, materialize=own)[0]
+            if own:
+                fetched.append((accent_id, tr, val))
         main = torch.cuda.current_stream()
         K = self.tasks_per_gpu
         for w0 in range(0, len(fetched), K):
@@ -173,8 +180,15 @@ class FOMetaASRInterface(PretrainInterface):
                     n_local = 0
                     meta_batch = task_ids[:self.meta_batch_size]
                     if self.tasks_per_gpu > 1:
-                        n_local = self._run_tasks_concurrently(self.sharder.my_tasks(meta_batch))
-                    for accent_id in (self.sharder.my_tasks(meta_batch) if self.tasks_per_gpu == 1 else []):
+                        n_local = self._run_tasks_concurrently(meta_batch)
+                    for pos, accent_id in (enumerate(meta_batch) if self.tasks_per_gpu == 1 else []):
+                        if not self.sharder.owns(pos):
+                            # another rank's task: advance this accent's sampler and the shared RNG streams exactly as
+                            # the owner does (indices only, no feature row is read), so that every rank sees the data
+                            # order of the single-process run whichever rank an accent lands on next
+                            self.data_container.get_item(accent_id, self.meta_k, materialize=False)
+                            self.data_container.get_item(accent_id, materialize=False)
+                            continue
                         tr_batches = self.data_container.get_item(accent_id, self.meta_k)
                         self.run_task(tr_batches)
                         val_batch = self.data_container.get_item(accent_id)[0]
@@ -284,15 +298,41 @@ class FOMetaASRInterface(PretrainInterface):
 
     # ------------------------------------------------------------------ evaluation (:253-298)
     def evaluate(self):
+        """(:253-298).  Quirk Q2: runs on whatever `asr_model` holds -- the last task's adapted weights.  With several
+        ranks that model differs per rank, so rank 0 alone evaluates (its own last task) while the others wait.
+        --fix_snapshot_meta_weights: the META weights are evaluated (and saved); being rank-independent, the dev accents
+        are then split over the ranks and the per-accent averages gathered."""
+        sh = self.sharder
+        if self.fix_snapshot:
+            eng = self.asr_model.engine
+            eng.copy(eng.params, self._original)
+            eng.mark_dirty()
+            self._evaluate_accents(range(sh.rank, self.num_pretrain, sh.world), gather=sh.world > 1)
+        elif sh.world > 1:
+            if sh.rank == 0:
+                self._evaluate_accents(range(self.num_pretrain))
+            sh.barrier()
+        else:
+            self._evaluate_accents(range(self.num_pretrain))
+
+    def _evaluate_accents(self, accent_ids, gather=False):
         self.asr_model.eval()
         self.write_tr_logs()
         dev_info_ls = [RunningAvgDict(decay_rate=1.) for _ in range(self.num_pretrain)]
-        for idx, dev_loader in enumerate(self.data_container.dev_loaders):
+        for idx in accent_ids:
+            dev_loader = self.data_container.dev_loaders[idx]
             for cur_b, (x, ilens, ys, olens) in enumerate(dev_loader):
                 if ilens.max() > self.dev_max_ilen:
                     continue
                 info = self._eval(idx, x, ilens, ys, olens)
                 dev_info_ls[idx].add(info, len(ys))
+        if gather:                                                         # every rank ends up with every accent's averages
+            parts = self.sharder.all_gather_object({i: dict(dev_info_ls[i]) for i in accent_ids})
+            for part in parts:
+                for i, d in part.items():
+                    dev_info_ls[i] = RunningAvgDict(decay_rate=1.)
+                    dev_info_ls[i].add(d)
+        for idx in range(self.num_pretrain):
             self.dashboard.log_info(f"dev_{self.accents[idx]}", dev_info_ls[idx])
             self.write_dev_logs(f"dev_{self.accents[idx]}", dev_info_ls[idx])
         dev_avg = RunningAvgDict(decay_rate=1.0)

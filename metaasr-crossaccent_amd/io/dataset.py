@@ -85,10 +85,10 @@ class CommonVoiceDataset:
 
     def __init__(self, data_dir, is_memmap):
         data_dir = Path(data_dir)
-        if is_memmap:
-            self.feat = np.load(data_dir / 'feat.dat', mmap_mode='r')
-        else:
-            self.feat = np.load(data_dir / 'feat.npy')
+        self._feat_path = data_dir / ('feat.dat' if is_memmap else 'feat.npy')
+        self._is_memmap = is_memmap
+        self._feat = None                      # opened on first use: a rank that never materialises a batch of this
+        self._device = None                    # accent (multi-GPU task sharding) never maps / uploads its features
         self.ilens = np.load(data_dir / 'ilens.npy')
         self.olens = np.load(data_dir / 'olens.npy')
         self.label = np.load(data_dir / 'label.npy')
@@ -96,6 +96,12 @@ class CommonVoiceDataset:
         self.iptr = np.concatenate([[0], np.cumsum(self.ilens)]).astype(np.int64)
         self.optr = np.concatenate([[0], np.cumsum(self.olens)]).astype(np.int64)
         self.dev_feat = None
+
+    @property
+    def feat(self):
+        if self._feat is None:
+            self._feat = np.load(self._feat_path, mmap_mode='r') if self._is_memmap else np.load(self._feat_path)
+        return self._feat
 
     def __len__(self):
         return len(self.ilens)
@@ -109,16 +115,28 @@ class CommonVoiceDataset:
         }
 
     # ---- HBM-resident shard -------------------------------------------------------------
-    def to_device(self, device):
-        """Upload the whole shard once (coalesced HBM reads afterwards; SURVEY 8(d) 'ragged gather')."""
-        self.dev_feat = torch.from_numpy(np.ascontiguousarray(self.feat, dtype=np.float32)).to(device)
+    def to_device(self, device, lazy=False):
+        """Upload the whole shard once (coalesced HBM reads afterwards; SURVEY 8(d) 'ragged gather').
+        lazy: upload when the first batch is gathered (a rank only pays for the accents it actually runs)."""
+        self._device = device
+        if not lazy:
+            self._upload()
         return self
+
+    def _upload(self):
+        self.dev_feat = torch.from_numpy(np.ascontiguousarray(self.feat, dtype=np.float32)).to(self._device)
+
+    @property
+    def on_device(self):
+        return self._device is not None
 
     def gather_batch(self, idxs):
         """collate on the GPU: same sort / pad semantics as collate_fn, features never leave HBM."""
         import ctypes as C
         from .._cabi import lib, check
-        assert self.dev_feat is not None, "call to_device() first"
+        assert self._device is not None, "call to_device() first"
+        if self.dev_feat is None:
+            self._upload()
         idxs = sorted(idxs, key=lambda i: int(self.ilens[i]), reverse=True)
         dev = self.dev_feat.device
         lens = torch.tensor([int(self.ilens[i]) for i in idxs], dtype=torch.int32)
@@ -157,12 +175,18 @@ class Loader:
             if len(chunk) == self.batch_size or not self.drop_last:
                 yield chunk
 
+    def iter_indices(self):
+        """the batch INDEX stream alone: consumes the RNG streams exactly like __iter__ but touches no features"""
+        return self._batches()
+
+    def materialize(self, idxs):
+        if self.dset.on_device:
+            return self.dset.gather_batch(idxs)
+        return collate_fn([self.dset[i] for i in idxs])
+
     def __iter__(self):
         for idxs in self._batches():
-            if self.dset.dev_feat is not None:
-                yield self.dset.gather_batch(idxs)
-            else:
-                yield collate_fn([self.dset[i] for i in idxs])
+            yield self.materialize(idxs)
 
     def __len__(self):
         if self.batch_sampler is not None:
@@ -173,12 +197,12 @@ class Loader:
 
 def get_loader(data_dir, batch_size, is_memmap, is_bucket, num_workers=0, split_rate=1.0, split_seed=531,
                min_ilen=None, max_ilen=None, half_batch_ilen=None, bucket_reverse=False, shuffle=True,
-               read_file=False, drop_last=False, pin_memory=True, device=None):
+               read_file=False, drop_last=False, pin_memory=True, device=None, lazy_upload=False):
     """dataset.py:156-198.  num_workers / pin_memory are accepted for signature parity and ignored."""
     assert not read_file, "Load from Kaldi ark haven't been implemented yet"
     dset = CommonVoiceDataset(data_dir, is_memmap)
     if device is not None:
-        dset.to_device(device)
+        dset.to_device(device, lazy=lazy_upload)
     indices = None
     if split_rate < 1.0:
         n_tr = int(len(dset) * split_rate)
@@ -193,34 +217,48 @@ def get_loader(data_dir, batch_size, is_memmap, is_bucket, num_workers=0, split_
 
 
 class DataContainer:
-    """dataset.py:200-277: one endless train iterator per accent + dev loaders."""
+    """dataset.py:200-277: one endless train iterator per accent + dev loaders.
+
+    Multi-GPU (tasks sharded over ranks): the sampler state of EVERY accent and the global `random` / `np.random`
+    streams must advance identically on every rank, or an accent that moves to another rank would be served batches
+    that were already consumed.  get_item(..., materialize=False) therefore draws the batch INDICES (all the RNG
+    consumption there is) without reading a single feature row; only the owning rank materialises the batch.  Shards
+    are opened / uploaded on first materialisation, so a rank only ever maps the accents it runs."""
 
     def __init__(self, data_dirs, batch_size, dev_batch_size, is_memmap, is_bucket, num_workers=0, min_ilen=None,
                  max_ilen=None, half_batch_ilen=None, bucket_reverse=False, shuffle=True, read_file=False,
-                 drop_last=False, pin_memory=True, device=None, accent_filter=None):
+                 drop_last=False, pin_memory=True, device=None, lazy_upload=False):
         self.data_dirs = [Path(d) for d in data_dirs]
         self.num_datasets = len(self.data_dirs)
         self.kw = dict(batch_size=batch_size, is_memmap=is_memmap, is_bucket=is_bucket, num_workers=num_workers,
                        min_ilen=min_ilen, max_ilen=max_ilen, half_batch_ilen=half_batch_ilen,
-                       bucket_reverse=bucket_reverse, shuffle=shuffle, read_file=read_file, device=device)
+                       bucket_reverse=bucket_reverse, shuffle=shuffle, read_file=read_file, device=device, lazy_upload=lazy_upload)
         self.reload_cnt = 0
-        self.loader_iters, self.dev_loaders = [], []
-        for i, d in enumerate(self.data_dirs):
-            # accent_filter (multi-GPU): a rank only opens the shards of the tasks it owns
-            mine = accent_filter is None or i in accent_filter
-            self.loader_iters.append(iter(get_loader(d / 'train', **self.kw)) if mine else None)
+        self.loaders, self.loader_iters, self.dev_loaders = [], [], []
+        for d in self.data_dirs:
+            ld = get_loader(d / 'train', **self.kw)
+            self.loaders.append(ld)
+            self.loader_iters.append(ld.iter_indices())
             self.dev_loaders.append(get_loader(d / 'dev', batch_size=dev_batch_size, is_memmap=is_memmap, is_bucket=False,
-                                               num_workers=num_workers, shuffle=False, device=device))
+                                               num_workers=num_workers, shuffle=False, device=device, lazy_upload=lazy_upload))
 
-    def get_item(self, accent_idx=None, num=1):
+    def _reload(self, a):
+        old = self.loaders[a]
+        self.loaders[a] = get_loader(self.data_dirs[a] / 'train', **self.kw)
+        ds, od = self.loaders[a].dset, old.dset                 # keep the mapped / uploaded shard of the old loader
+        ds._feat, ds.dev_feat = od._feat, od.dev_feat
+        self.loader_iters[a] = self.loaders[a].iter_indices()
+        self.reload_cnt += 1
+
+    def get_item(self, accent_idx=None, num=1, materialize=True):
+        """-> [(accent, batch)] * num.  materialize=False: [(accent, None)] with the same RNG / iterator side effects."""
         out = []
         ids = np.random.randint(self.num_datasets, size=num) if accent_idx is None else np.repeat(accent_idx, num)
         for a in ids:
             try:
-                batch = next(self.loader_iters[a])
+                idxs = next(self.loader_iters[a])
             except StopIteration:
-                self.loader_iters[a] = iter(get_loader(self.data_dirs[a] / 'train', **self.kw))
-                self.reload_cnt += 1
-                batch = next(self.loader_iters[a])
-            out.append((a, batch))
+                self._reload(a)
+                idxs = next(self.loader_iters[a])
+            out.append((a, self.loaders[a].materialize(idxs) if materialize else None))
         return out

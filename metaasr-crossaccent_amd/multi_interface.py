@@ -68,7 +68,12 @@ class MultiASRInterface(PretrainInterface):
         try:
             while self.global_step < self.max_step:
                 for _ in range(self.eval_ival):
-                    idx, (x, ilens, ys, olens) = self.data_container.get_item()[0]
+                    # N ranks = N consecutive draws of the ONE shared accent/batch stream per step (rank r keeps draw r, the
+                    # others are replayed index-only): N different random-accent batches, same stream as a single process
+                    for r in range(self.sharder.world):
+                        item = self.data_container.get_item(materialize=(r == self.sharder.rank))[0]
+                        if r == self.sharder.rank:
+                            idx, (x, ilens, ys, olens) = item
                     info = self._train(idx, x, ilens, ys, olens, accent_idx=idx)
                     self.train_info.add(info, len(ys))
                     if self.sharder.world > 1:                            # DP: mean gradient over ranks

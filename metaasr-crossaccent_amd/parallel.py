@@ -13,7 +13,6 @@ few large chunks (ring all-reduce is per-link bound) rather than per-tensor buck
 Backends: "nccl" (= RCCL on ROCm) on GPUs, "gloo" on CPU tensors (tests, world_size 2).
 """
 import os
-import random
 
 import torch
 
@@ -50,19 +49,14 @@ class TaskSharder:
             dist.init_process_group(backend)
 
     # ------------------------------------------------------------------ task assignment
-    def task_rng(self, seed):
-        """Task order must be identical on every rank.  The reference shuffles with the global `random` stream
-        (fo_meta_interface.py:136), which data-loader re-creation also consumes at rank-dependent times, so in
-        multi-rank runs a dedicated generator is used; world_size 1 keeps the global stream (bit parity)."""
-        return random if self.world == 1 else random.Random(seed)
+    def owns(self, pos):
+        """is the task at position `pos` of the (rank-identical) shuffled meta-batch this rank's?  Round-robin by
+        position keeps the ranks balanced for any meta_batch_size; which accent lands where changes every meta-step,
+        so shards are opened / uploaded lazily by the rank that first runs them (io/dataset.py)."""
+        return pos % self.world == self.rank
 
     def my_tasks(self, meta_batch):
-        """tasks of this meta-step owned by this rank: round-robin over the (rank-identical) shuffled list"""
-        return list(meta_batch[self.rank::self.world])
-
-    def owned_accents(self, num_tasks, meta_batch_size):
-        """with meta_batch_size == num_tasks every accent can land on any rank over time -> all shards stay open"""
-        return None
+        return [t for pos, t in enumerate(meta_batch) if self.owns(pos)]
 
     def barrier(self):
         if self.world > 1:
@@ -100,6 +94,14 @@ class TaskSharder:
     def all_reduce(self, buf):
         self.reduce_async(buf)
         self.wait_all()
+
+    def all_gather_object(self, obj):
+        if self.world == 1:
+            return [obj]
+        import torch.distributed as dist
+        out = [None] * self.world
+        dist.all_gather_object(out, obj)
+        return out
 
     def all_reduce_scalar_sum(self, x: float) -> float:
         if self.world == 1:

@@ -88,7 +88,7 @@ class PretrainInterface:
             self.data_dirs, batch_size=sv['batch_size'], dev_batch_size=sv['dev_batch_size'], is_memmap=self.is_memmap,
             is_bucket=self.is_bucket, num_workers=self.paras.njobs, min_ilen=sv['min_ilen'], max_ilen=sv['max_ilen'],
             half_batch_ilen=sv['half_batch_ilen'],
-            device=getattr(self.paras, 'hbm_shards_device', None))
+            device=getattr(self.paras, 'hbm_shards_device', None), lazy_upload=self.sharder.world > 1)
 
     def write_log(self, k, v):
         if self.sharder.rank != 0:

@@ -92,6 +92,9 @@ class Tester:
         return True
 
     def write_hyp(self, y, hyp):
+        if getattr(self, '_skip_lines', 0) > 0:                  # utterance already in best-hyp (resumed inside a batch)
+            self._skip_lines -= 1
+            return
         with open(Path(self.decode_dir, 'best-hyp'), 'a') as fout:
             fout.write("{}\t{}\n".format(" ".join(str(i) for i in y), " ".join(str(i) for i in hyp)))
 
@@ -99,7 +102,18 @@ class Tester:
         if self.decode_mode != 'greedy':
             raise NotImplementedError(f"{self.decode_mode} haven't supported yet")      # as the reference (tester.py:121-124)
         logger.notice(f"Start greedy decoding: {len(self.eval_set)} batches of <= {self.batch_size}")
-        for cur_b, (xs, ilens, ys, olens) in enumerate(self.eval_set):
-            if cur_b < self.prev_decode_step:
+        # --resume: prev_decode_step counts the LINES (utterances) already in best-hyp.  The reference's batch path does not
+        # skip at all (tester.py:149-152: a resumed batch decode appends everything again); its per-utterance path skips
+        # by step.  Here whole batches are skipped while all their utterances are already written; a partially written
+        # batch (killed between two write_hyp calls) is decoded again and only its missing tail is appended.
+        done = max(self.prev_decode_step, 0)
+        seen = 0
+        for idxs in self.eval_set.iter_indices():
+            n = len(idxs)
+            if seen + n <= done:
+                seen += n
                 continue
-            self.batch_greedy_decode(xs, ilens, ys, olens)
+            self._skip_lines = done - seen if seen < done else 0
+            self.batch_greedy_decode(*self.eval_set.materialize(idxs))
+            seen += n
+        self._skip_lines = 0

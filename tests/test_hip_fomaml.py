@@ -207,3 +207,14 @@ def test_tester_writes_best_hyp_like_the_reference(golden_dir, tmp_path, monkeyp
         hyp = [int(x) for x in l.split("\t")[1].split()] if "\t" in l and l.split("\t")[1] else []
         assert ODIM - 1 not in hyp[1:]                       # nothing after (and including) the first </s> survives trim
     assert t.trim([5, 366, 7]) == [5] and t.trim([366, 4, 366, 9]) == [366, 4] and t.trim([3]) == [] and t.trim([1, 2, 3]) == [1, 2, 3]
+    # --resume with decode_batch_size > 1: best-hyp is cut inside the second batch (5 of 6 lines) and then after a whole batch
+    # (4 lines); the resumed decode must append exactly the missing utterances
+    hyp_file = log_dir / "greedy_decode" / "best-hyp"
+    full = hyp_file.read_text()
+    for keep in (5, 4, 1):
+        hyp_file.write_text("".join(l + "\n" for l in full.splitlines()[:keep]))
+        paras.resume = True
+        t2 = Tester(cfg, paras, id2accent)
+        assert t2.prev_decode_step == keep
+        t2.load_data(); t2.set_model(); t2.exec()
+        assert hyp_file.read_text() == full, f"resume after {keep} lines"

@@ -1,0 +1,237 @@
+"""World-2 (gloo, CPU) runs of the PRODUCT loops -- FOMetaASRInterface.train() and MultiASRInterface.train() -- on real toy
+shards through the real DataContainer / BucketSampler, with a CPU engine double in place of the HIP engine (the double
+exists only here; it has MasrEngine's call surface and a gradient that is a deterministic function of the batch CONTENT
+and the current weights).  Checked:
+  * FOMAML: 2 ranks end with the same meta weights as the single-process run (same task order, every accent served the
+    batches of the single-process stream whichever rank it lands on, all-reduce(sum)/n_tasks, replicated Adam);
+  * the batches the two ranks materialise are, together, exactly the single-process batch list (each once);
+  * evaluate()/snapshots run inside the multi-rank loop (rank-0 evaluation + barrier; meta-weight evaluation split over
+    ranks with --fix_snapshot_meta_weights);
+  * multi-task: the N ranks of a step draw N different batches of the one shared stream.
+Reference loops: src/fo_meta_interface.py:128-177, src/multi_interface.py:94-140."""
+import json
+import math
+import os
+import random
+import socket
+import tempfile
+from functools import partial
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import masr_amd  # noqa: F401
+from masr_amd.optimizer import FlatAdam, TransformerOptimizer
+from oracle.make_goldens import write_toy_shard
+
+N = 193
+ACCENTS = {"af": "african", "au": "australia", "ca": "canada", "en": "england", "us": "us"}
+
+
+def batch_fingerprint(x, ys):
+    return round(float(x.double().sum()), 4) + 1000.0 * int(sum(int(y.sum()) for y in ys))
+
+
+class CpuEngine:
+    def __init__(self, log):
+        self.params = torch.linspace(-1, 1, N, dtype=torch.float64)
+        self.grads = torch.zeros(N, dtype=torch.float64)
+        self._norm, self._loss, self.log = 0.0, 0.0, log
+        self.device = torch.device("cpu")
+
+    def copy(self, dst, src): dst.copy_(src)
+    def mark_dirty(self): pass
+    def set_seed(self, s): pass
+    def axpy(self, y, x, a): y.add_(x, alpha=a)
+    def scale(self, x, a): x.mul_(a)
+
+    def state_dict(self, flat=None, clone=True):
+        t = self.params if flat is None else flat
+        return {"w": t.clone() if clone else t}
+
+    def load_state_dict(self, sd): self.params.copy_(sd["w"])
+
+    def run_batch(self, x, ilens, ys, olens, train):
+        fp = batch_fingerprint(x, ys)
+        self.log.append((bool(train), fp))
+        ph = (fp % 7.0) + 0.5
+        self.grads = self.params * (0.1 + 0.01 * (fp % 3.0)) + 0.4 * torch.sin(torch.arange(N, dtype=torch.float64) * ph)
+        self._loss = float(self.grads.abs().mean())
+
+    def read_stats(self):
+        return {"loss": self._loss, "n_correct": 1.0, "n_total": 2.0, "grad_norm": self._norm}
+
+    def clip_grads(self, max_norm):
+        self._norm = float(self.grads.norm())
+        self.grads.mul_(min(1.0, max_norm / (self._norm + 1e-6)))
+
+    def clip_sgd_step(self, buf, max_norm, lr, momentum, nesterov, first):
+        self.clip_grads(max_norm)
+        g = self.grads
+        if first:
+            buf.copy_(g)
+        else:
+            buf.mul_(momentum).add_(g)
+        self.params.sub_(lr * (g + momentum * buf if nesterov else buf))
+
+    def adam_step(self, p, g, m, v, lr, b1, b2, eps, t, weight_decay=0.0, decoupled=False):
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        p.addcdiv_(m, (v.sqrt() / math.sqrt(1 - b2 ** t)).add_(eps), value=-lr / (1 - b1 ** t))
+
+
+def get_cpu_trainer(cls, config, paras, id2accent, log):
+    """the Trainer mixin contract (transformer_torch_trainer.get_trainer) over the CPU double"""
+
+    class CpuTrainer(cls):
+        def set_model(self):
+            eng = CpuEngine(log)
+            self.asr_model = SimpleNamespace(engine=eng, train=lambda: None, eval=lambda: None,
+                                             load_state_dict=eng.load_state_dict)
+            self.label_smooth_rate = 0.0
+            mp_ = self.config['asr_model']
+            if 'inner_optimizer_cls' not in mp_:
+                self.asr_opt = TransformerOptimizer(FlatAdam(eng, eng.params, betas=(0.9, 0.98), eps=1e-9), 1.0, 64, 4)
+            super().load_model()
+
+        def _make_slots(self):
+            self._slots = None
+
+        def exec(self):
+            self.train()
+
+        def run_batch(self, cur_b, x, ilens, ys, olens, train, accent_idx=None, engine=None):
+            eng = self.asr_model.engine
+            eng.run_batch(x, ilens, ys, olens, train)
+            olens += 1
+            st = eng.read_stats()
+            info = {'loss': st['loss'], 'acc': 0.5}
+            if not train:
+                info['cer'] = 50.0 + st['loss']
+                info['wer'] = 60.0 + st['loss']
+            return info
+
+        def opt_step(self):
+            self.asr_opt.optimizer.grad = self.asr_model.engine.grads
+            self.asr_opt.step()
+
+        def clip_grad_norm_(self, max_norm, engine=None):
+            self.asr_model.engine.clip_grads(max_norm)
+            return self.asr_model.engine.read_stats()['grad_norm']
+
+    return CpuTrainer(config, paras, id2accent)
+
+
+def make_workspace(root):
+    root = Path(root)
+    (root / "data").mkdir(parents=True)
+    json.dump(ACCENTS, open(root / "data" / "accent-code.json", "w"))
+    with open(root / "data" / "units.txt", "w") as f:
+        for i in range(365):
+            f.write(f"u{i} {i + 1}\n")
+    for ai, a in enumerate(ACCENTS.values()):
+        write_toy_shard(root / "data", a, "train", 14, seed=100 + ai)
+        write_toy_shard(root / "data", a, "dev", 3, seed=200 + ai)
+
+
+def run(root, algo, world, rank, fix_snapshot=False, meta_batch=3, steps=5):
+    os.chdir(root)
+    model = {"d_model": 64}
+    if algo == "fomaml":
+        model.update({"inner_optimizer_cls": "SGD", "inner_optimizer_opt": {"momentum": 0.9, "nesterov": True},
+                      "meta_opt_cls": "noam", "meta": {"optimizer_opt": {"k": 1.0, "warmup_steps": 4}}})
+    else:
+        model.update({"optimizer_cls": "noam", "optimizer_opt": {"k": 1.0, "warmup_steps": 4}})
+    cfg = {"asr_model": model,
+           "solver": {"setting": "t", "data_root": "data", "total_steps": 100, "spm_mapping": "data/units.txt", "spm_model": "none",
+                      "label_smoothing": 0.0, "eval_ival": 2, "log_ival": 1, "save_ival": 2, "batch_size": 4, "dev_batch_size": 4,
+                      "min_ilen": 10, "max_ilen": 50, "dev_max_ilen": 3000, "half_batch_ilen": 30}}
+    paras = SimpleNamespace(pretrain_suffix=f"w{world}", pretrain_accents=["af", "au", "en", "us"], num_pretrain=4, tgt_accent="ca", runs=0,
+                            overwrite=True, seed=531, meta_k=2, meta_batch_size=meta_batch, sample_strategy="normal", max_step=steps,
+                            resume=False, model_name="transformer", algo=algo, njobs=0, is_bucket=True, is_memmap=True,
+                            use_tensorboard=False, fix_snapshot_meta_weights=fix_snapshot, tasks_per_gpu=1)
+    random.seed(531); np.random.seed(531); torch.manual_seed(531)
+    if algo == "fomaml":
+        from masr_amd.fo_meta_interface import FOMetaASRInterface as Iface
+    else:
+        from masr_amd.multi_interface import MultiASRInterface as Iface
+    log = []
+    solver = get_cpu_trainer(Iface, cfg, paras, ACCENTS, log)
+    solver.load_data()
+    solver.set_model()
+    solver.exec()
+    weights = solver._original.clone() if algo == "fomaml" else solver.asr_model.engine.params.clone()
+    files = sorted(p.name for p in solver.log_dir.iterdir()) if rank == 0 else []
+    dev_log = (solver.log_dir / "dev_avg_wer").read_text() if rank == 0 and (solver.log_dir / "dev_avg_wer").exists() else ""
+    return {"weights": weights, "train_fps": [fp for tr, fp in log if tr], "files": files, "dev_avg_wer": dev_log,
+            "global_step": solver.global_step}
+
+
+def _worker(rank, world, port, root, algo, fix_snapshot, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = run(root, algo, world, rank, fix_snapshot)
+    torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _two_ranks(root, algo, fix_snapshot=False):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, _free_port(), root, algo, fix_snapshot, d), nprocs=2, join=True)
+        return [torch.load(os.path.join(d, f"r{r}.pt"), weights_only=False) for r in range(2)]
+
+
+@pytest.fixture()
+def workspace():
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        make_workspace(d)
+        yield d
+        os.chdir(cwd)
+
+
+@pytest.mark.parametrize("fix_snapshot", [False, True])
+def test_fomaml_train_two_ranks_match_single_process(workspace, fix_snapshot):
+    single = run(workspace, "fomaml", 1, 0, fix_snapshot)
+    r0, r1 = _two_ranks(workspace, "fomaml", fix_snapshot)
+    assert single["global_step"] == r0["global_step"] == r1["global_step"] == 5
+    assert torch.equal(r0["weights"], r1["weights"]), "replicated Adam must leave identical meta weights on every rank"
+    torch.testing.assert_close(r0["weights"], single["weights"], rtol=1e-9, atol=1e-11)
+    # together the ranks materialised exactly the single-process batch list, each batch once (as a multiset: the toy shards
+    # are small, so an utterance comes back in a later epoch, possibly on the other rank)
+    assert sorted(r0["train_fps"] + r1["train_fps"]) == sorted(single["train_fps"])
+    assert len(r0["train_fps"]) > 0 and len(r1["train_fps"]) > 0
+    # evaluation + checkpoints ran inside the multi-rank loop and left the reference's files (rank 0 writes)
+    for f in ("snapshot.latest", "snapshot.step.2", "snapshot.step.4", "model.wer.best", "best_wer", "best_cer", "global_step",
+              "dev_avg_wer", "dev_african_loss", "train_loss"):
+        assert f in r0["files"], (f, r0["files"])
+    assert sorted(single["files"]) == sorted(r0["files"])
+    assert len(r0["dev_avg_wer"].splitlines()) == len(single["dev_avg_wer"].splitlines()) == 2
+    if fix_snapshot:                                   # meta weights are rank-independent -> same dev numbers as one process
+        a = [float(l.split()[1]) for l in r0["dev_avg_wer"].splitlines()]
+        b = [float(l.split()[1]) for l in single["dev_avg_wer"].splitlines()]
+        assert np.allclose(a, b, rtol=1e-9)
+
+
+def test_multi_train_two_ranks_draw_different_batches(workspace):
+    single = run(workspace, "multi", 1, 0, steps=9)
+    r0, r1 = _two_ranks(workspace, "multi")
+    assert torch.equal(r0["weights"], r1["weights"])
+    # rank r of step s took draw 2 s + r of the one shared stream: the two ranks never share a batch within a step, and the
+    # interleaved sequence is the single-process stream
+    n = min(len(r0["train_fps"]), len(r1["train_fps"]))
+    assert n >= 4
+    assert all(a != b for a, b in zip(r0["train_fps"], r1["train_fps"]))
+    inter = [fp for pair in zip(r0["train_fps"], r1["train_fps"]) for fp in pair]
+    assert inter[:len(single["train_fps"])] == single["train_fps"][:len(inter)]
