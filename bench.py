@@ -143,6 +143,12 @@ def main():
         log(f"launching {args.gpus} ranks: {' '.join(cmd)}")
         sys.exit(subprocess.run(cmd, env=env).returncode)
 
+    # stdout carries exactly ONE JSON line: native libraries (gloo, RCCL with NCCL_DEBUG) print to fd 1 on their own, so
+    # fd 1 is pointed at stderr for the whole run and the JSON line goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
@@ -428,7 +434,7 @@ def main():
             log("cpu baseline (oracle on host cores) ...")
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch, T, D)
             log("cpu baseline done")
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

@@ -378,6 +378,119 @@ def gen_fomaml_goldens():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+CFG3_ACCENTS = [("af", "african"), ("au", "australia"), ("en", "england"), ("us", "us")]
+
+
+def cfg3_workspace(root, spm_dir):
+    """4 accents x (16 train, 4 dev) toy utterances + the toy SentencePiece model (tests/golden/toy_spm.*).  Shared by the
+    golden generator below and by the tests that replay it."""
+    root = Path(root)
+    (root / "data").mkdir(parents=True, exist_ok=True)
+    json.dump(dict(CFG3_ACCENTS + [("ca", "canada")]), open(root / "data" / "accent-code.json", "w"))
+    shutil.copy(Path(spm_dir) / "toy_spm.model", root / "data" / "toy_spm.model")
+    shutil.copy(Path(spm_dir) / "toy_spm_units.txt", root / "data" / "toy_spm_units.txt")
+    for ai, (_, a) in enumerate(CFG3_ACCENTS):
+        write_toy_shard(root / "data", a, "train", 16, seed=400 + ai)
+        write_toy_shard(root / "data", a, "dev", 4, seed=500 + ai)
+    model = dict(TINY)
+    model["meta"] = {"optimizer_opt": {"k": 1.0, "warmup_steps": 25000}}       # the shipped fometa-hkust.yaml schedule
+    solver = {"setting": "cfg3", "data_root": "data", "total_steps": 10, "spm_mapping": "data/toy_spm_units.txt",
+              "spm_model": "data/toy_spm.model", "label_smoothing": 0.2, "eval_ival": 2, "log_ival": 1, "save_ival": 2,
+              "batch_size": 4, "dev_batch_size": 4, "min_ilen": 10, "max_ilen": 50, "dev_max_ilen": 3000, "half_batch_ilen": 30}
+    return {"asr_model": model, "solver": solver}
+
+
+def cfg3_paras(meta_k, **extra):
+    p = dict(config="x", pretrain_suffix=f"k{meta_k}", pretrain_accents=[c for c, _ in CFG3_ACCENTS], num_pretrain=4, tgt_accent="ca",
+             runs=0, overwrite=True, seed=531, no_cuda=True, no_memmap=False, no_bucket=False, meta_k=meta_k, meta_batch_size=4,
+             sample_strategy="normal", max_step=5, resume=False, resume_step=-1, use_tensorboard=False, model_name="transformer",
+             algo="fomaml", njobs=0, cuda=False, is_bucket=True, is_memmap=True)
+    p.update(extra)
+    return SimpleNamespace(**p)
+
+
+def gen_fomaml_cfg3_goldens():
+    """BASELINE configs[2] literally: `pretrain.py --algo fomaml`, 4 accents, inner_steps (meta_k) = 1, the shipped Noam
+    schedule (warmup_steps 25000 -> inner lr 7.9e-4 at d_model 64), plus a meta_k = 2 variant.  The reference's
+    get_trainer(FOMetaASRInterface...).exec() runs 4 meta-steps with its own evaluate() after the 2nd and 4th (toy
+    SentencePiece model, so CER/WER are reproducible on the GPU box).  Captured: EVERY run_batch call, train and eval
+    (batch identity, loss, acc, cer, wer); per meta-step the meta-gradient (_updates / _counter, before Adam) and the
+    meta weights after Adam, per tensor; every log file; the snapshot."""
+    from src.fo_meta_interface import FOMetaASRInterface
+    from src.transformer_torch_trainer import get_trainer
+    from functools import partial
+    out = {}
+    for meta_k in (1, 2):
+        tmp = Path(tempfile.mkdtemp(prefix="masr_gold_"))
+        cwd = os.getcwd()
+        try:
+            cfg = cfg3_workspace(tmp, OUT)
+            os.chdir(tmp)
+            id2accent = json.load(open("data/accent-code.json"))
+            paras = cfg3_paras(meta_k)
+            random.seed(531); np.random.seed(531); torch.manual_seed(531)
+            solver = get_trainer(FOMetaASRInterface, cfg, paras, id2accent)
+            solver.load_data()
+            solver.set_model()
+            solver.asr_model.load_state_dict(ref_cpu.deterministic_state_dict(cfg["asr_model"], ODIM, seed=7))
+            solver.load_model()
+            rec = []
+            orig_run_batch = solver.run_batch
+
+            def spy(idx, x, ilens, ys, olens, train, accent_idx=None):
+                info = orig_run_batch(idx, x, ilens.clone(), [y.clone() for y in ys], olens.clone(), train=train, accent_idx=accent_idx)
+                rec.append((int(idx), bool(train), x.numpy().copy(), ilens.numpy().copy(), [y.numpy().copy() for y in ys], dict(info)))
+                return info
+            solver._train = partial(spy, train=True)
+            solver._eval = partial(spy, train=False)
+            steps = []
+            orig_final = solver._final_meta_update
+
+            def final_spy():
+                mg = {n: (u / solver._counter).clone() for n, u in solver._updates.items()}
+                orig_final()
+                steps.append((mg, {n: t.detach().clone() for n, t in solver._original.items()}))
+            solver._final_meta_update = final_spy
+            solver.exec()
+            pre = f"k{meta_k}/"
+            out[pre + "n_calls"] = np.int64(len(rec))
+            for i, (idx, train, x, il, ys, info) in enumerate(rec):
+                out[f"{pre}call{i}/accent"] = np.int64(idx)
+                out[f"{pre}call{i}/train"] = np.int64(train)
+                out[f"{pre}call{i}/ilens"] = il
+                out[f"{pre}call{i}/x_fp"] = flat_checks(torch.from_numpy(x))
+                out[f"{pre}call{i}/ys"] = np.concatenate(ys)
+                for k, v in info.items():
+                    out[f"{pre}call{i}/{k}"] = np.float64(v)
+            out[pre + "n_meta_steps"] = np.int64(len(steps))
+            for si, (mg, meta) in enumerate(steps):
+                for n in mg:
+                    out[f"{pre}step{si}/metagrad/fp/{n}"] = flat_checks(mg[n])
+                    if n != "pos_encoder.pe" and n in meta:
+                        out[f"{pre}step{si}/meta/fp/{n}"] = flat_checks(meta[n])
+                for n in ("vgg2enc.bias", "decoder.norm.weight", "char_trans.bias", "feat_extractor.0.weight", "encoder.layers.1.linear2.bias"):
+                    out[f"{pre}step{si}/metagrad/full/{n}"] = mg[n].numpy().copy()
+            out[pre + "meta/step_num"] = np.int64(solver.meta_opt.step_num)
+            out[pre + "meta/lr"] = np.float64(solver.meta_opt.lr)
+            out[pre + "global_step"] = np.int64(solver.global_step)
+            out[pre + "inner_lr"] = np.float64(solver.inner_lr)
+            out[pre + "files"] = np.array(sorted(p.name for p in solver.log_dir.iterdir()))
+            for f in solver.log_dir.iterdir():
+                if f.name.startswith(("dev_", "train_", "best_")) or f.name == "global_step":
+                    out[f"{pre}log/{f.name}"] = np.array(open(f).read())
+            snap = torch.load(solver.log_dir / "snapshot.latest")
+            for n, t in snap.items():
+                out[f"{pre}snap/fp/{n}"] = flat_checks(t)
+            print(f"fomaml_cfg3 k={meta_k}: {len(rec)} calls ({sum(1 for r in rec if not r[1])} eval), {len(steps)} meta-steps, files {list(out[pre + 'files'])}")
+            print("   dev_avg_wer:", repr(str(out[pre + 'log/dev_avg_wer'])), "best_wer:", repr(str(out[pre + 'log/best_wer'])))
+        finally:
+            os.chdir(cwd)
+            shutil.rmtree(tmp, ignore_errors=True)
+    np.savez_compressed(OUT / "fomaml_cfg3.npz", **out)
+    print("fomaml_cfg3.npz", len(out), "arrays")
+
+
+
 def _toy_workspace(tmp):
     (tmp / "data").mkdir()
     for f in ("accent-code.json", "valid_train_en_unigram150.model", "valid_train_en_unigram150_units.txt"):
@@ -760,19 +873,13 @@ def main():
     install_stubs()
     sys.path.insert(0, str(REF))
     torch.set_num_threads(4)
-    gen_masks_noam()
-    gen_sampler_goldens()
-    gen_ctc_goldens()
-    gen_init_goldens()
-    gen_metric_goldens()
-    gen_model_goldens()
-    gen_fomaml_goldens()
-    gen_multi_goldens()
-    gen_mono_goldens()
-    gen_tester_goldens()
-    gen_blstm_goldens()
-    gen_blstm_mono_goldens()
-    gen_blstm_tester_goldens()
+    gens = [gen_masks_noam, gen_sampler_goldens, gen_ctc_goldens, gen_init_goldens, gen_metric_goldens, gen_model_goldens,
+            gen_fomaml_goldens, gen_fomaml_cfg3_goldens, gen_multi_goldens, gen_mono_goldens, gen_tester_goldens, gen_blstm_goldens,
+            gen_blstm_mono_goldens, gen_blstm_tester_goldens]
+    only = set(sys.argv[1:])                       # e.g.  python oracle/make_goldens.py gen_fomaml_cfg3_goldens
+    for g in gens:
+        if not only or g.__name__ in only:
+            g()
 
 
 if __name__ == "__main__":

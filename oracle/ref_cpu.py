@@ -420,24 +420,26 @@ def inner_step(p, cfg, batch, eps, bufs, lr, momentum=0.9, nesterov=True):
     return info
 
 
-def fomaml_meta_step(meta, cfg, tasks, eps, adam_state, meta_step_num, momentum=0.9, nesterov=True):
+def fomaml_meta_step(meta, cfg, tasks, eps, adam_state, meta_step_num, momentum=0.9, nesterov=True, keep=None):
     """One outer step (fo_meta_interface.py:139-156,180-250).
 
     meta: name -> tensor (the `_original` weights, updated in place);
     tasks: list of (train_batches, val_batch); each batch = (xs_pad, ilens, ys, olens).
     Per task: copy meta -> model, fresh SGD, k inner steps, val fwd+bwd at adapted
     weights, clip 5 (NaN only warns), accumulate.  Then /= counter, Noam-Adam step.
-    Returns (per-task val infos, lr).
+    Returns (per-task val infos, lr).  `keep` (dict, optional) receives what the checks of the outer loop need:
+    'inner_infos' (per task, the infos of its k inner steps), 'meta_grad' (name -> mean clipped val gradient, before
+    Adam) and 'last_adapted' (the last task's adapted weights: what the reference evaluates and snapshots, quirks Q1/Q2).
     """
     names = grad_param_names(meta, cfg)
     updates = {n: torch.zeros_like(meta[n]) for n in names}
-    infos = []
+    infos, inner_infos = [], []
     lr_in = inner_lr(cfg)
+    p = None
     for tr_batches, val_batch in tasks:
         p = leafify(meta, cfg)
         bufs = {}
-        for b in tr_batches:
-            inner_step(p, cfg, b, eps, bufs, lr_in, momentum, nesterov)
+        inner_infos.append([inner_step(p, cfg, b, eps, bufs, lr_in, momentum, nesterov) for b in tr_batches])
         info, grads, _, _ = run_batch_train(p, cfg, val_batch, eps)
         info["grad_norm"] = clip_grad_norm_(grads)
         for n in names:
@@ -445,10 +447,24 @@ def fomaml_meta_step(meta, cfg, tasks, eps, adam_state, meta_step_num, momentum=
         infos.append(info)
     for n in names:
         updates[n] /= len(tasks)
+    if keep is not None:
+        keep["inner_infos"] = inner_infos
+        keep["meta_grad"] = {n: u.clone() for n, u in updates.items()}
+        keep["last_adapted"] = p
     o = cfg["meta"]["optimizer_opt"]
     lr = noam_lr(meta_step_num, o["k"], cfg["d_model"], o["warmup_steps"])
     adam_step(meta, updates, adam_state, lr)
     return infos, lr
+
+
+def run_batch_eval(p, cfg, batch, eps):
+    """run_batch(train=False) without the CER/WER text metrics (transformer_torch_trainer.py:59-84,94-97): loss and
+    accuracy of the teacher-forced forward, plus the arg-max tokens and gold the metrics are computed from."""
+    xs_pad, ilens, ys, olens = batch
+    with torch.no_grad():
+        logit, gold = model_forward(p, cfg, xs_pad, ilens, ys, olens)
+        loss, n_correct, n_total = label_smoothed_ce(logit, gold, eps)
+    return {"loss": float(loss), "acc": float(n_correct) / n_total}, logit, gold
 
 
 def reptile_meta_step(meta, cfg, tasks, eps, adam_state, meta_step_num, momentum=0.9, nesterov=True):

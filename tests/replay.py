@@ -1,0 +1,60 @@
+"""Shared by the CPU and GPU parity tests: the reference's FOMAML outer loop (src/fo_meta_interface.py:128-177,253-298)
+driven with the ORACLE's arithmetic (oracle/ref_cpu.py) over the product's DataContainer, so that one function yields,
+for the literal BASELINE config-3 run (4 accents, meta_k inner steps, shipped Noam schedule), every run_batch info, every
+meta-gradient and every meta-weight tensor in full.  TEST INFRASTRUCTURE (imports oracle/)."""
+import random
+from collections import OrderedDict
+
+import torch
+
+from oracle import ref_cpu
+
+
+def oracle_fomaml_run(cfg, data_container, meta_k, meta_batch_size, max_step, eps, dev_max_ilen=3000, on_batch=None):
+    """-> dict(calls=[(accent, train, info)], steps=[(meta_grad, meta_after_adam)], lr, evals=[[(logit, gold)]])
+    Call order = the reference's: per meta-step and task the k inner-step batches, then the val batch; after the meta-step
+    of every eval_ival-th global step one eval call per dev batch per accent (on the LAST task's adapted weights, Q2)."""
+    mcfg = cfg["asr_model"]
+    eval_ival = cfg["solver"]["eval_ival"]
+    odim = 367
+    meta = OrderedDict((n, t.clone()) for n, t in ref_cpu.deterministic_state_dict(mcfg, odim, 7).items())
+    if mcfg["tgt_share_weight"]:
+        meta["pre_embed.weight"] = meta["char_trans.weight"]
+    adam_state, calls, steps, evals = {}, [], [], []
+    task_ids = list(range(data_container.num_datasets))
+    global_step, meta_step, lr = 1, 0, None
+
+    def note(accent, train, batch, info):
+        calls.append((int(accent), train, info))
+        if on_batch is not None:
+            on_batch(len(calls) - 1, int(accent), train, batch)
+
+    while global_step < max_step:
+        for _ in range(eval_ival):
+            random.shuffle(task_ids)
+            tasks, metas = [], []
+            for a in task_ids[:meta_batch_size]:
+                tr = [b for _, b in data_container.get_item(a, meta_k)]
+                val = data_container.get_item(a)[0][1]
+                tasks.append(([(x, il, ys, ol.clone()) for x, il, ys, ol in tr], (val[0], val[1], val[2], val[3].clone())))
+                metas.append((a, tr, val))
+            keep = {}
+            meta_step += 1
+            infos, lr = ref_cpu.fomaml_meta_step(meta, mcfg, tasks, eps, adam_state, meta_step, keep=keep)
+            for (a, tr, val), inner, vinfo in zip(metas, keep["inner_infos"], infos):
+                for b, info in zip(tr, inner):
+                    note(a, True, b, info)
+                note(a, True, val, vinfo)
+            steps.append((keep["meta_grad"], OrderedDict((n, t.detach().clone()) for n, t in meta.items())))
+            if global_step % eval_ival == 0:
+                outs = []
+                for a, loader in enumerate(data_container.dev_loaders):
+                    for x, il, ys, ol in loader:
+                        if il.max() > dev_max_ilen:
+                            continue
+                        info, logit, gold = ref_cpu.run_batch_eval(keep["last_adapted"], mcfg, (x, il, ys, ol.clone()), eps)
+                        note(a, False, (x, il, ys, ol), info)
+                        outs.append((logit, gold))
+                evals.append(outs)
+            global_step += 1
+    return {"calls": calls, "steps": steps, "lr": lr, "evals": evals, "global_step": global_step}

@@ -259,3 +259,55 @@ def test_blstm_oracle_matches_reference(golden_dir, tag, ilens, olens):
     np.testing.assert_allclose(p["head.bias"].grad.numpy(), g[f"{tag}/gradfull/head.bias"], rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(p["encoder.blstm.rnn0.weight_hh_l0_reverse"].grad.numpy(),
                                g[f"{tag}/gradfull/encoder.blstm.rnn0.weight_hh_l0_reverse"], rtol=1e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize("meta_k", [1, 2])
+def test_fomaml_cfg3_oracle_matches_reference(golden_dir, tmp_path, monkeypatch, meta_k):
+    """BASELINE configs[2] literally (pretrain.py --algo fomaml, 4 accents, inner_steps = meta_k, shipped warmup 25000; plus
+    a meta_k = 2 variant): the oracle's meta loop over the product's DataContainer reproduces the reference run captured in
+    tests/golden/fomaml_cfg3.npz -- same batches in the same order, EVERY train and eval loss within 2e-5, every meta-gradient
+    tensor of every meta-step (norm within 1e-4, first/last elements), the meta weights after every Adam step."""
+    import masr_amd  # noqa: F401
+    from masr_amd.io.dataset import DataContainer
+    from oracle.make_goldens import cfg3_workspace
+    from replay import oracle_fomaml_run
+    g = np.load(golden_dir / "fomaml_cfg3.npz")
+    pre = f"k{meta_k}/"
+    cfg = cfg3_workspace(tmp_path, golden_dir)
+    monkeypatch.chdir(tmp_path)
+    sv = cfg["solver"]
+    random.seed(531); np.random.seed(531); torch.manual_seed(531)
+    dc = DataContainer([tmp_path / "data" / a for _, a in (("af", "african"), ("au", "australia"), ("en", "england"), ("us", "us"))],
+                       batch_size=sv["batch_size"], dev_batch_size=sv["dev_batch_size"], is_memmap=True, is_bucket=True,
+                       min_ilen=sv["min_ilen"], max_ilen=sv["max_ilen"], half_batch_ilen=sv["half_batch_ilen"])
+
+    def on_batch(i, accent, train, batch):
+        assert accent == int(g[f"{pre}call{i}/accent"]) and int(train) == int(g[f"{pre}call{i}/train"]), i
+        np.testing.assert_array_equal(batch[1].numpy(), g[f"{pre}call{i}/ilens"])
+        np.testing.assert_array_equal(np.concatenate([y.numpy() for y in batch[2]]), g[f"{pre}call{i}/ys"])
+        _fp_close(flat_checks(batch[0]), g[f"{pre}call{i}/x_fp"], rtol=1e-6)
+
+    run = oracle_fomaml_run(cfg, dc, meta_k, 4, 5, sv["label_smoothing"], on_batch=on_batch)
+    assert len(run["calls"]) == int(g[pre + "n_calls"]) and len(run["steps"]) == int(g[pre + "n_meta_steps"]) == 4
+    worst = 0.0
+    for i, (accent, train, info) in enumerate(run["calls"]):
+        for k in ("loss", "acc"):
+            ref = float(g[f"{pre}call{i}/{k}"])
+            worst = max(worst, abs(info[k] - ref) / max(abs(ref), 1e-9)) if k == "loss" else worst
+            assert abs(info[k] - ref) <= 2e-5 * abs(ref) + 1e-12, (i, k, info[k], ref)
+    print(f"meta_k {meta_k}: {len(run['calls'])} calls, worst relative loss error {worst:.2e}")
+    assert abs(run["lr"] - float(g[pre + "meta/lr"])) <= 1e-15
+    names = ref_cpu.grad_param_names(run["steps"][0][1], cfg["asr_model"])
+    for si, (mg, meta) in enumerate(run["steps"]):
+        for n in names:
+            a, b = flat_checks(mg[n]), g[f"{pre}step{si}/metagrad/fp/{n}"]
+            if not n.endswith("in_proj_bias"):               # (key third: exactly-zero true gradient, rounding noise only)
+                assert abs(a[2] - b[2]) <= 1e-4 * b[2] + 1e-9, (si, n, a[2], b[2])
+                assert np.all(np.abs(a[3:] - b[3:]) <= 2e-4 * np.abs(b[3:]) + 1e-6 * b[2]), (si, n)
+            # meta weights after Adam: every element moved by at most lr; compare at a fraction of that step
+            wa, wb = flat_checks(meta[n]), g[f"{pre}step{si}/meta/fp/{n}"]
+            assert abs(wa[2] - wb[2]) <= 1e-6 * wb[2], (si, n)
+        for n in ("vgg2enc.bias", "decoder.norm.weight", "char_trans.bias", "feat_extractor.0.weight", "encoder.layers.1.linear2.bias"):
+            ref = g[f"{pre}step{si}/metagrad/full/{n}"]
+            err = np.linalg.norm(mg[n].numpy() - ref) / np.linalg.norm(ref)
+            assert err < 2e-4, (si, n, err)
