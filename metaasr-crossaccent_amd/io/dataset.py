@@ -176,7 +176,11 @@ class Loader:
                 yield chunk
 
     def iter_indices(self):
-        """the batch INDEX stream alone: consumes the RNG streams exactly like __iter__ but touches no features"""
+        """the batch INDEX stream alone: consumes the RNG streams exactly like __iter__ but touches no features.
+        torch's DataLoader draws a base seed from the default generator every time an iterator is created
+        (_BaseDataLoaderIter.__init__), BEFORE the sampler's own draws: replayed here, so that whatever consumes the torch
+        stream next -- the model initialisation of the CLIs, which runs after load_data() -- sees the reference's values."""
+        torch.empty((), dtype=torch.int64).random_()
         return self._batches()
 
     def materialize(self, idxs):
@@ -185,8 +189,7 @@ class Loader:
         return collate_fn([self.dset[i] for i in idxs])
 
     def __iter__(self):
-        for idxs in self._batches():
-            yield self.materialize(idxs)
+        return (self.materialize(idxs) for idxs in self.iter_indices())
 
     def __len__(self):
         if self.batch_sampler is not None:

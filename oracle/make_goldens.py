@@ -272,6 +272,34 @@ def write_toy_shard(root, accent, split, n_utt, seed, idim=83, lo=12, hi=40):
     return ilens, olens
 
 
+def write_learnable_shard(root, accent, split, n_utt, seed, idim=83, n_class=8):
+    """A toy shard a tiny model can actually learn within a few hundred steps (peaked logits -> arg-max decisions that
+    survive bf16 rounding): every utterance belongs to one of `n_class` classes; a class fixes the label sequence (2..5
+    tokens from U{1..365}, a seeded table shared by all shards) and the feature pattern (every frame = the class's
+    codebook vector + N(0, 0.3) noise); lengths are random (16..45 frames).  Layout: SURVEY Appendix D."""
+    from numpy.lib.format import open_memmap
+    tab = np.random.RandomState(4242)
+    code = (tab.randn(n_class, idim) * 1.5).astype(np.float32)
+    seqs = [tab.randint(1, 366, size=tab.randint(2, 6)).astype(np.int64) for _ in range(n_class)]
+    rng = np.random.RandomState(seed)
+    d = Path(root) / accent / split
+    d.mkdir(parents=True, exist_ok=True)
+    cls = rng.randint(0, n_class, size=n_utt)
+    ilens = rng.randint(16, 46, size=n_utt).astype(np.int64)
+    olens = np.array([len(seqs[c]) for c in cls], dtype=np.int64)
+    feat = open_memmap(d / "feat.dat", mode="w+", dtype=np.float32, shape=(int(ilens.sum()), idim))
+    row = 0
+    for c, n in zip(cls, ilens):
+        feat[row:row + n] = code[c] + 0.3 * rng.randn(n, idim).astype(np.float32)
+        row += n
+    feat.flush()
+    del feat
+    np.save(d / "ilens.npy", ilens)
+    np.save(d / "olens.npy", olens)
+    np.save(d / "label.npy", np.concatenate([seqs[c] for c in cls]))
+    return ilens, olens
+
+
 def gen_sampler_goldens():
     from src.io.dataset import BucketSampler
     out = {}
@@ -488,6 +516,139 @@ def gen_fomaml_cfg3_goldens():
             shutil.rmtree(tmp, ignore_errors=True)
     np.savez_compressed(OUT / "fomaml_cfg3.npz", **out)
     print("fomaml_cfg3.npz", len(out), "arrays")
+
+
+
+def chain_workspace(root, spm_dir):
+    """BASELINE configs[4] in miniature: learnable toy shards for 4 pretraining accents and the target accent (canada:
+    train / dev / test), the toy SentencePiece model, and the two YAML-shaped configs (pretrain: cfg3's; fine-tune: the
+    adapt/*.yaml shape with pretrain_module / freeze_module)."""
+    root = Path(root)
+    (root / "data").mkdir(parents=True, exist_ok=True)
+    json.dump(dict(CFG3_ACCENTS + [("ca", "canada")]), open(root / "data" / "accent-code.json", "w"))
+    for f in ("toy_spm.model", "toy_spm_units.txt"):
+        shutil.copy(Path(spm_dir) / f, root / "data" / f)
+    for ai, (_, a) in enumerate(CFG3_ACCENTS):
+        write_learnable_shard(root / "data", a, "train", 32, seed=600 + ai)
+        write_learnable_shard(root / "data", a, "dev", 4, seed=700 + ai)
+    write_learnable_shard(root / "data", "canada", "train", 96, seed=801)
+    write_learnable_shard(root / "data", "canada", "dev", 8, seed=802)
+    write_learnable_shard(root / "data", "canada", "test", 12, seed=803)
+    base = {"data_root": "data", "spm_mapping": "data/toy_spm_units.txt", "spm_model": "data/toy_spm.model", "dev_max_ilen": 3000,
+            "min_ilen": 10, "max_ilen": 60, "half_batch_ilen": 100}
+    pre_model = dict(TINY)
+    pre_model["meta"] = {"optimizer_opt": {"k": 1.0, "warmup_steps": 25000}}
+    pre = {"asr_model": pre_model,
+           "solver": dict(base, setting="chain", total_steps=10, label_smoothing=0.1, eval_ival=2, log_ival=1, save_ival=2, batch_size=4,
+                          dev_batch_size=4)}
+    ft_model = {k: v for k, v in TINY.items() if k not in ("inner_optimizer_cls", "inner_optimizer_opt", "meta_opt_cls", "meta")}
+    ft_model.update({"optimizer_cls": "noam", "optimizer_opt": {"k": 0.5, "warmup_steps": 50}})
+    ft = {"asr_model": ft_model,
+          "solver": dict(base, setting="chain-ft", total_epochs=70, label_smoothing=0.1, eval_ival=100, log_ival=1000, batch_size=8,
+                         dev_batch_size=8, pretrain_module=["feat_extractor", "vgg2enc", "char_trans", "pre_embed", "encoder", "decoder"],
+                         freeze_module=["feat_extractor"], beam_decode={"beam_size": 1})}
+    return pre, ft
+
+
+def chain_paras(stage, **extra):
+    """argparse namespaces of the three CLI calls of the chain: pretrain.py --algo X / train.py --pretrain ... / train.py --test"""
+    if stage == "pretrain":
+        p = vars(cfg3_paras(1, pretrain_suffix="chain"))
+    else:
+        p = dict(config="x", accent="ca", algo="fomaml", model_name="transformer", eval_suffix="ft", runs=0, overwrite=True, seed=531,
+                 resume=False, use_tensorboard=False, save_verbose=False, split_rate=1.0, freeze_layer=None, pretrain=True,
+                 pretrain_suffix="chain", pretrain_setting="chain", pretrain_runs=0, pretrain_step=4, pretrain_tgt_accent="ca",
+                 pretrain_model_path=None, njobs=0, is_bucket=True, is_memmap=True, no_cuda=True, cuda=False, test=False,
+                 eval_every_epoch=False)
+        if stage == "test":
+            p.update(test=True, test_model="model.wer.best", decode_suffix="greedy_decode", decode_mode="greedy", decode_batch_size=4,
+                     njobs=1, lm_model_path=None)
+    p.update(extra)
+    return SimpleNamespace(**p)
+
+
+def gen_chain_goldens():
+    """BASELINE configs[4] chain on toy data, run by the REFERENCE: pretrain.py --algo fomaml (4 accents) -> snapshot.step.4
+    -> train.py fine-tune on the target accent (pretrain_module / freeze_module, Noam-Adam, 70 epochs, evaluate() every 100
+    steps) -> train.py --test (Tester, greedy, batch 4) -> best-hyp.  Captured: the fine-tune's per-call losses, its dev logs
+    and file set, the best-hyp lines."""
+    from functools import partial
+    from src.fo_meta_interface import FOMetaASRInterface
+    from src.mono_interface import MonoASRInterface
+    from src.tester import Tester
+    from src.transformer_torch_trainer import get_trainer
+    from src.io.dataset import get_loader
+    tmp = Path(tempfile.mkdtemp(prefix="masr_gold_"))
+    cwd = os.getcwd()
+    try:
+        pre_cfg, ft_cfg = chain_workspace(tmp, OUT)
+        os.chdir(tmp)
+        id2accent = json.load(open("data/accent-code.json"))
+        out = {}
+        # ---- 1. pretrain
+        random.seed(531); np.random.seed(531); torch.manual_seed(531)
+        solver = get_trainer(FOMetaASRInterface, pre_cfg, chain_paras("pretrain"), id2accent)
+        solver.load_data(); solver.set_model()                  # the reference's own seed-531 initialisation, as its CLI does
+        out["pre/init/fp/vgg2enc.weight"] = flat_checks(solver._original["vgg2enc.weight"])
+        rec = []
+        orig = solver.run_batch
+
+        def spy(idx, x, ilens, ys, olens, train, accent_idx=None):
+            info = orig(idx, x, ilens.clone(), [y.clone() for y in ys], olens.clone(), train=train, accent_idx=accent_idx)
+            rec.append((bool(train), dict(info)))
+            return info
+        solver._train, solver._eval = partial(spy, train=True), partial(spy, train=False)
+        solver.exec()
+        out["pre/loss"] = np.array([r[1]["loss"] for r in rec])
+        out["pre/train"] = np.array([r[0] for r in rec])
+        snap = torch.load(solver.log_dir / "snapshot.step.4")
+        for n, t in snap.items():
+            out[f"pre/snap/fp/{n}"] = flat_checks(t)
+        for f in solver.log_dir.iterdir():
+            if f.name.startswith(("dev_", "train_", "best_")):
+                out[f"pre/log/{f.name}"] = np.array(open(f).read())
+        # ---- 2. fine-tune from the snapshot (path built by TrainInterface from the pretrain_* flags, train_interface.py:64-68)
+        random.seed(531); np.random.seed(531); torch.manual_seed(531)
+        ft = get_trainer(MonoASRInterface, ft_cfg, chain_paras("finetune"), id2accent)
+        ft.load_data(); ft.set_model()
+        rec2 = []
+        orig2 = ft.run_batch
+
+        def spy2(idx, x, ilens, ys, olens, train, accent_idx=None):
+            info = orig2(idx, x, ilens.clone(), [y.clone() for y in ys], olens.clone(), train=train, accent_idx=accent_idx)
+            rec2.append((bool(train), ilens.numpy().copy(), np.concatenate([y.numpy() for y in ys]), dict(info)))
+            return info
+        ft._train, ft._eval = partial(spy2, train=True), partial(spy2, train=False)
+        ft.exec()
+        out["ft/n_calls"] = np.int64(len(rec2))
+        out["ft/train"] = np.array([r[0] for r in rec2])
+        out["ft/loss"] = np.array([r[3]["loss"] for r in rec2])
+        out["ft/acc"] = np.array([r[3]["acc"] for r in rec2])
+        for i in range(40):                                   # batch identity of the first calls (the order is RNG-driven)
+            out[f"ft/call{i}/ilens"], out[f"ft/call{i}/ys"] = rec2[i][1], rec2[i][2]
+        out["ft/global_step"], out["ft/ep"] = np.int64(ft.global_step), np.int64(ft.ep)
+        out["ft/files"] = np.array(sorted(p.name for p in ft.log_dir.iterdir()))
+        for f in ft.log_dir.iterdir():
+            if f.name.startswith(("dev_", "train_", "best_")):
+                out[f"ft/log/{f.name}"] = np.array(open(f).read())
+        frozen = torch.load(ft.log_dir / "snapshot.latest")["feat_extractor.0.weight"]
+        assert torch.equal(frozen, snap["feat_extractor.0.weight"])
+        # ---- 3. decode the test shard with model.wer.best
+        t = Tester(ft_cfg, chain_paras("test"), id2accent)
+        t.load_data()
+        t.eval_set = get_loader(t.data_dir.joinpath("test"), batch_size=4, half_batch_ilen=512, is_memmap=True, is_bucket=False,
+                                shuffle=False, num_workers=0)
+        t.set_model()
+        t.exec()
+        lines = (t.decode_dir / "best-hyp").read_text().splitlines()
+        out["test/lines"] = np.array(lines)
+        np.savez_compressed(OUT / "chain_toy.npz", **out)
+        print("chain_toy.npz: pretrain calls", len(rec), "fine-tune calls", len(rec2), "global_step", ft.global_step)
+        print("   dev_acc:", str(out["ft/log/dev_acc"]).replace("\n", " | ")[-300:])
+        print("   best_wer:", str(out["ft/log/best_wer"]).strip(), "| best-hyp:", sum(l.split("\t")[0] == l.split("\t")[1] for l in lines), "of", len(lines), "exact")
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 
@@ -874,7 +1035,7 @@ def main():
     sys.path.insert(0, str(REF))
     torch.set_num_threads(4)
     gens = [gen_masks_noam, gen_sampler_goldens, gen_ctc_goldens, gen_init_goldens, gen_metric_goldens, gen_model_goldens,
-            gen_fomaml_goldens, gen_fomaml_cfg3_goldens, gen_multi_goldens, gen_mono_goldens, gen_tester_goldens, gen_blstm_goldens,
+            gen_fomaml_goldens, gen_fomaml_cfg3_goldens, gen_chain_goldens, gen_multi_goldens, gen_mono_goldens, gen_tester_goldens, gen_blstm_goldens,
             gen_blstm_mono_goldens, gen_blstm_tester_goldens]
     only = set(sys.argv[1:])                       # e.g.  python oracle/make_goldens.py gen_fomaml_cfg3_goldens
     for g in gens:

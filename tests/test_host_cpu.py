@@ -182,3 +182,23 @@ def test_blstm_init_replay_matches_reference_seed_531(golden_dir):
     assert list(sd.keys()) == g["state_dict_keys"].tolist()
     for n, t in sd.items():
         np.testing.assert_allclose(flat_checks(t), g[f"init/{n}"], rtol=1e-6, atol=1e-7, err_msg=n)
+
+
+def test_cli_level_init_parity_after_load_data(golden_dir, tmp_path, monkeypatch):
+    """pretrain.py order: seeds -> load_data() -> set_model().  The reference's DataLoader iterators draw their base seeds from
+    the torch default generator while load_data() runs, so the model initialised afterwards differs from one initialised
+    straight after manual_seed(531).  Our Loader replays those draws: DataContainer over the chain's 4 accents followed by the
+    init replay yields the weights the reference's own CLI flow started from (tests/golden/chain_toy.npz)."""
+    import random
+    from masr_amd.io.dataset import DataContainer
+    from masr_amd.model import reference_init_state_dict
+    from oracle.make_goldens import CFG3_ACCENTS, ODIM, chain_workspace, flat_checks
+    g = np.load(golden_dir / "chain_toy.npz")
+    pre, _ = chain_workspace(tmp_path, golden_dir)
+    monkeypatch.chdir(tmp_path)
+    sv = pre["solver"]
+    random.seed(531); np.random.seed(531); torch.manual_seed(531)
+    DataContainer([tmp_path / "data" / a for _, a in CFG3_ACCENTS], batch_size=sv["batch_size"], dev_batch_size=sv["dev_batch_size"],
+                  is_memmap=True, is_bucket=True, min_ilen=sv["min_ilen"], max_ilen=sv["max_ilen"], half_batch_ilen=sv["half_batch_ilen"])
+    sd = reference_init_state_dict(pre["asr_model"], ODIM)
+    np.testing.assert_allclose(flat_checks(sd["vgg2enc.weight"]), g["pre/init/fp/vgg2enc.weight"], rtol=1e-6, atol=1e-7)
