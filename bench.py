@@ -62,15 +62,21 @@ def synth_batch(B, T, D, seed):
     return xs, torch.full((B,), T, dtype=torch.int64), ys, torch.from_numpy(olens.astype(np.int64))
 
 
-def fwd_flops_per_utt(T, D, L=31, E=512, F=2048, NE=2, ND=4, C=367):
-    """SURVEY 8(d) algorithmic forward FLOPs per utterance (multiply-add = 2)."""
+def fwd_flops_by_class(T, D, L=31, E=512, F=2048, NE=2, ND=4, C=367):
+    """SURVEY 8(d) algorithmic forward FLOPs per utterance (multiply-add = 2), split by kernel class."""
     H2, W2 = T // 2, D // 2
     Tp, Dp = H2 // 2, W2 // 2
     conv = 2 * 9 * (1 * 64 * T * D + 64 * 64 * T * D + 64 * 128 * H2 * W2 + 128 * 128 * H2 * W2)
-    v2e = 2 * Tp * (128 * Dp) * E
-    enc = NE * (2 * Tp * E * 3 * E + 2 * Tp * E * E + 4 * Tp * Tp * E + 4 * Tp * E * F)
-    dec = ND * ((2 * L * E * 3 * E + 2 * L * E * E + 4 * L * L * E) + (2 * L * E * E + 2 * Tp * E * 2 * E + 2 * L * E * E + 4 * L * Tp * E) + 4 * L * E * F)
-    return conv + v2e + enc + dec + 2 * L * E * C
+    gemm = 2 * Tp * (128 * Dp) * E                                                            # vgg2enc
+    gemm += NE * (2 * Tp * E * 3 * E + 2 * Tp * E * E + 4 * Tp * E * F)                        # encoder Linears
+    gemm += ND * ((2 * L * E * 3 * E + 2 * L * E * E) + (2 * L * E * E + 2 * Tp * E * 2 * E + 2 * L * E * E) + 4 * L * E * F)
+    gemm += 2 * L * E * C                                                                     # char_trans
+    attn = NE * 4 * Tp * Tp * E + ND * (4 * L * L * E + 4 * L * Tp * E)                        # QK^T and PV
+    return {"conv": conv, "gemm": gemm, "attn": attn}
+
+
+def fwd_flops_per_utt(T, D, L=31, **kw):
+    return sum(fwd_flops_by_class(T, D, L, **kw).values())
 
 
 def host_cores():
@@ -86,7 +92,7 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("MASR_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(cfg, B, T, D, steps=12):
+def cpu_baseline(cfg, B, T, D, steps=6):
     """The oracle's inner step (fp32 torch on the host cores) on a bounded sample of the same workload."""
     from oracle import ref_cpu
     n = host_cores()
@@ -119,7 +125,9 @@ def main():
     ap.add_argument("--idim", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=16, help="utterances per step of the CPU baseline leg (same B as the GPU leg by default)")
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--long-seconds", type=float, default=2.0, help="also time a region of at least this many seconds (\"long_run\"); 0 = skip")
     ap.add_argument("--mixed", action="store_true", help="also time a mixed-length leg (ilens ~ U{200..1500}), reported as \"mixed_lengths\"")
     ap.add_argument("--no-stagger", action="store_true", help="start all concurrent tasks at the same instant (lock-step)")
     ap.add_argument("--no-meta-step", action="store_true", help="skip the whole-meta-step leg (\"meta_step\" in the output)")
@@ -273,6 +281,13 @@ def main():
     st = eng.read_stats()
     assert np.isfinite(st["loss"]) and np.isfinite(st["grad_norm"]), st
     log(f"timed region: {dt:.3f} s for {args.steps} steps x {K} task(s); loss {st['loss']:.4f}")
+    long_run = None
+    if args.long_seconds > 0:
+        # the driver's K-step region is ~0.2 s (clock ramp and jitter are a visible part of it): the same measurement over >= 2 s
+        nlong = max(args.steps, int(args.long_seconds / (dt / args.steps)) + 1)
+        dtl = timed(tasks, nlong, 2, stagger)
+        long_run = {"steps": nlong, "seconds": dtl, "value": world * K * B * nlong / dtl, "ms_per_step": dtl / nlong * 1e3}
+        log(f"long run: {dtl:.2f} s for {nlong} steps -> {long_run['value']:.1f} utt/s")
 
     # ---- mixed-length leg (ilens ~ U{200..1500}): every task cycles through 8 batches of its own; all
     # utterances of a batch share one length (what the reference's BucketSampler yields) and the half-batch rule applies
@@ -381,31 +396,70 @@ def main():
         eng.mark_dirty()
         del contribs, total, ea, eas
 
-    # ---- roofline of the dominant kernel, timed live with HIP events on the launch stream
+    # ---- roofline: every conv launch of the step timed live with HIP events on the launch stream (one engine slot per
+    # launch), the LONGEST launch is the "dominant kernel"; plus a per-class table (algorithmic GFLOP per step / measured ms)
     roof = None
     prof_all = None
+    nprof = 5
     if rank == 0 and not args.no_profile:
         eng.profile(True)
-        nprof = 5
         for i in range(nprof):
             step(i)
         prof_all = eng.profile_read()
         eng.profile(False)
-        ms, n = prof_all["conv2_fwd"]
-        flops = 2.0 * 9 * 64 * 64 * B * T * D                    # algorithmic FLOPs of one conv 64->64 launch
-        achieved = flops / (ms / n * 1e-3) / 1e12
-        traffic = None                                           # HBM bytes per launch from the committed PMC passes (same workload)
-        try:
-            pmc = json.load(open(ROOT / "profiles" / "pmc_traffic.json"))
-            if pmc["workload"] == {"batch": B, "frames": T, "idim": D}:
-                traffic = pmc["traffic_bytes"]
+        H2, W2 = T // 2, D // 2
+        c2, c3, c4 = 2.0 * 9 * 64 * 64 * B * T * D, 2.0 * 9 * 64 * 128 * B * H2 * W2, 2.0 * 9 * 128 * 128 * B * H2 * W2
+        conv_launch = {   # name -> (kernel, algorithmic FLOPs per launch, algorithmic HBM bytes per launch: bf16 in + out (+ pooled out))
+            "conv2_fwd": ("conv3x3_resw_kernel<16,16> (64->64 forward + fused 2x2 max-pool)", c2, 2 * B * T * D * 64 * 2 + B * H2 * W2 * 64 * 2),
+            "conv3_fwd": ("conv3x3_stream_kernel<64,128> (64->128 forward)", c3, B * H2 * W2 * (64 + 128) * 2),
+            "conv4_fwd": ("conv3x3_stream_kernel<128,128> (128->128 forward + fused 2x2 max-pool)", c4, B * H2 * W2 * 256 * 2 + B * (H2 // 2) * (W2 // 2) * 128 * 2),
+            "conv2_dgrad": ("conv3x3_resw_w1_kernel (64<-64 dgrad + fused conv1 weight gradient)", c2, B * T * D * (64 + 64) * 2 + B * T * D * 4),
+            "conv3_dgrad": ("conv3x3_stream_kernel<128,64> (64<-128 dgrad)", c3, B * H2 * W2 * (128 + 64) * 2),
+            "conv4_dgrad": ("conv3x3_stream_kernel<128,128,mask> (128<-128 dgrad through the ReLU mask)", c4, B * H2 * W2 * 384 * 2),
+            "conv2_wgrad": ("conv3x3_wgrad2_kernel<64,64>", c2, 2 * B * T * D * 64 * 2),
+            "conv3_wgrad": ("conv3x3_wgrad2_kernel<64,128>", c3, B * H2 * W2 * (64 + 128) * 2),
+            "conv4_wgrad": ("conv3x3_wgrad2_kernel<128,128>", c4, B * H2 * W2 * 256 * 2),
+        }
+        pmc, pmc_src = {}, None
+        try:                                                     # HBM bytes per launch from this round's PMC passes (tools/pmc_traffic.py)
+            pj = json.load(open(ROOT / "profiles" / "pmc_traffic.json"))
+            if pj["workload"] == {"batch": B, "frames": T, "idim": D}:
+                pmc, pmc_src = pj["kernels"], f"profiles/pmc_traffic.json ({pj['collected']}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `{pj['command']}`)"
         except Exception:
             pass
-        roof = {"bound": "mfma", "kernel": "conv3x3_resw_kernel<16,16> (conv2 forward + fused 2x2 max-pool; persistent, LDS-resident weights, LDS-DMA patches)",
-                "achieved": achieved,
-                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
-                "algorithmic_bytes": 2 * B * T * D * 64 * 2 + B * (T // 2) * (D // 2) * 64 * 2,   # in + out + pooled out (bf16)
-                "avg_launch_ms": ms / n, "flops_per_launch": flops}
+        launches = {}
+        for name, (kern, flops, abytes) in conv_launch.items():
+            ms, n = prof_all[name]
+            if n == 0:
+                continue
+            per = ms / n
+            launches[name] = {"kernel": kern, "avg_launch_ms": per, "gflop_per_launch": flops / 1e9, "tflops": flops / (per * 1e-3) / 1e12,
+                              "frac_of_bf16_peak": flops / (per * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "algorithmic_bytes": abytes,
+                              "traffic_bytes": pmc.get(name)}
+        dom = max(launches, key=lambda k: launches[k]["avg_launch_ms"])
+        d = launches[dom]
+        roof = {"bound": "mfma", "kernel": d["kernel"], "slot": dom, "achieved": d["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": d["frac_of_bf16_peak"], "traffic": d["traffic_bytes"], "traffic_source": pmc_src if d["traffic_bytes"] else None,
+                "algorithmic_bytes": d["algorithmic_bytes"], "avg_launch_ms": d["avg_launch_ms"], "flops_per_launch": d["gflop_per_launch"] * 1e9,
+                "selection": "longest single launch of the step at this commit (all conv launches are listed under \"launches\")",
+                "launches": launches}
+        # per-class table of ONE single-task step: algorithmic FLOPs (forward x 3; conv1 has no dgrad) vs measured kernel time
+        Lmax = int(max(tasks[0].ol)) + 1
+        fc = fwd_flops_by_class(T, D, Lmax)
+        gf = {"conv": (3 * fc["conv"] - 2 * 9 * 64 * T * D) * B / 1e9, "gemm": 3 * fc["gemm"] * B / 1e9, "attn": 3 * fc["attn"] * B / 1e9}
+        cls_of = lambda k: "conv" if k.startswith("conv") else "gemm" if k.startswith(("gemm", "wgrad")) else "attn" if k.startswith("attn") else "other"
+        per_class = {c: {"ms_per_step": 0.0, "launches_per_step": 0.0} for c in ("conv", "gemm", "attn", "other")}
+        for k, (ms, n) in prof_all.items():
+            per_class[cls_of(k)]["ms_per_step"] += ms / nprof
+            per_class[cls_of(k)]["launches_per_step"] += n / nprof               # (profiling scopes; a scope may hold 2-3 tiny launches)
+        for c_, g_ in gf.items():
+            t_ = per_class[c_]["ms_per_step"] * 1e-3
+            per_class[c_].update({"algorithmic_gflop_per_step": g_, "tflops": g_ / 1e3 / t_, "frac_of_bf16_peak": g_ / 1e3 / t_ / PEAK_BF16_TFLOPS})
+        per_class["other"]["note"] = "HBM-bound passes: LayerNorm, pools, loss/embedding, grad-norm + clip + SGD (24 B/param), operand shadows"
+        tot_ms = sum(v["ms_per_step"] for v in per_class.values())
+        roof["per_class"] = per_class
+        roof["single_task_step"] = {"kernel_ms": tot_ms, "algorithmic_gflop": sum(gf.values()),
+                                    "frac_of_bf16_peak": sum(gf.values()) / 1e3 / (tot_ms * 1e-3) / PEAK_BF16_TFLOPS}
 
     if rank == 0:
         utt = world * K * B * args.steps
@@ -422,17 +476,19 @@ def main():
             "algorithmic_gflop_per_utt_fwd_bwd": 3 * F / 1e9,
             "model_tflops": value * 3 * F / 1e12, "model_frac_of_bf16_peak": value * 3 * F / 1e12 / (PEAK_BF16_TFLOPS * world),
             "single_task": single,
+            "long_run": long_run,
+            "rccl_ranks": world if (dist is not None and backend == "nccl") else 0,
             "mixed_lengths": mixed,
             "loss": st["loss"], "grad_norm": st["grad_norm"],
         }
         if roof:
             out["roofline"] = roof
-            out["kernel_ms_per_step"] = {k: v[0] / 5 for k, v in prof_all.items()}
+            out["kernel_ms_per_step"] = {k: v[0] / nprof for k, v in prof_all.items()}
         if meta:
             out["meta_step"] = meta
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline (oracle on host cores) ...")
-            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch, T, D)
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch, T, D, args.cpu_steps)
             log("cpu baseline done")
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:

@@ -161,15 +161,32 @@ int masr_ctc_loss(const float* logits, const int32_t* targets, const int32_t* tg
                   const int32_t* tgt_len, int T, int B, int C, int blank, float* nll, float* loss, float* grad,
                   float* work, int maxS, void* stream);
 
-/* per-kernel-family device timing (HIP events on the launch stream) for bench.py's roofline block */
-#define MASR_PROF_CONV_FWD 0
-#define MASR_PROF_CONV_DGRAD 1
-#define MASR_PROF_CONV_WGRAD 2
-#define MASR_PROF_GEMM 3
-#define MASR_PROF_ATTN 4
-#define MASR_PROF_OTHER 5
-#define MASR_PROF_CONV2_FWD 6   /* the single largest launch: conv 64->64 forward on the full-resolution map */
-#define MASR_PROF_N 7
+/* device timing (HIP events on the launch stream) for bench.py's roofline block: one slot per conv launch of the VGG
+ * front-end (each is ONE launch per step, so slot time / launches = that kernel's average duration) and one per kernel
+ * class for the rest.  bench.py::PROF_NAMES mirrors this list. */
+#define MASR_PROF_CONV1_FWD 0     /* 1 -> 64, direct fp32 (HBM-bound) */
+#define MASR_PROF_CONV2_FWD 1     /* 64 -> 64 on the full-resolution map + fused 2x2 max-pool */
+#define MASR_PROF_CONV3_FWD 2     /* 64 -> 128 */
+#define MASR_PROF_CONV4_FWD 3     /* 128 -> 128 + fused 2x2 max-pool */
+#define MASR_PROF_CONV2_DGRAD 4   /* 64 <- 64 with conv1's weight gradient fused into the epilogue */
+#define MASR_PROF_CONV3_DGRAD 5
+#define MASR_PROF_CONV4_DGRAD 6
+#define MASR_PROF_CONV2_WGRAD 7
+#define MASR_PROF_CONV3_WGRAD 8
+#define MASR_PROF_CONV4_WGRAD 9
+#define MASR_PROF_CONV1_WGRAD 10  /* fold of the fused conv1 weight-gradient partials */
+#define MASR_PROF_GEMM_ENC 11     /* Linear forward / dgrad over the B*T' encoder rows (incl. vgg2enc, grouped cross-attention K/V) */
+#define MASR_PROF_GEMM_DEC 12     /* ... over the B*L decoder rows */
+#define MASR_PROF_WGRAD_ENC 13    /* Linear weight gradients reducing over encoder rows (split-K) */
+#define MASR_PROF_WGRAD_DEC 14    /* grouped launch of the decoder-row weight gradients */
+#define MASR_PROF_ATTN_ENC 15
+#define MASR_PROF_ATTN_DEC 16
+#define MASR_PROF_LAYERNORM 17
+#define MASR_PROF_POOL 18         /* max-pool/ReLU backward */
+#define MASR_PROF_OPTIM 19        /* grad norm, clip + SGD */
+#define MASR_PROF_SHADOWS 20      /* bf16 operand shadows after a parameter update */
+#define MASR_PROF_MISC 21         /* loss, embedding, casts, split-K combine */
+#define MASR_PROF_N 22
 int masr_profile_enable(masr_model* m, int on);
 /* sums since the last call: ms[MASR_PROF_N], launches[MASR_PROF_N]; synchronises */
 int masr_profile_read(masr_model* m, float* ms, int* launches);

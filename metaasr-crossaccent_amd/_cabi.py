@@ -73,7 +73,9 @@ _SIGS = {
     "masr_test_attention": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
 }
 EXPORTS = tuple(_SIGS)
-PROF_NAMES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "gemm", "attn", "other", "conv2_fwd")
+PROF_NAMES = ("conv1_fwd", "conv2_fwd", "conv3_fwd", "conv4_fwd", "conv2_dgrad", "conv3_dgrad", "conv4_dgrad", "conv2_wgrad",
+              "conv3_wgrad", "conv4_wgrad", "conv1_wgrad", "gemm_enc", "gemm_dec", "wgrad_enc", "wgrad_dec", "attn_enc", "attn_dec",
+              "layernorm", "pool", "optim", "shadows", "misc")          # include/masr.h MASR_PROF_*
 
 _lib = None
 

@@ -249,26 +249,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------- backward
-template <int HD>
-__global__ void attn_delta_kernel(AttnArgs a) {
-    const long n = (long)a.B * a.H * a.Tq;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int qi = (int)(i % a.Tq);
-    const int h = (int)((i / a.Tq) % a.H);
-    const int b = (int)(i / ((long)a.Tq * a.H));
-    const bf16* o = a.o + ((long)b * a.Tq + qi) * a.ldo + h * HD;
-    const bf16* d = a.dout + ((long)b * a.Tq + qi) * a.lddo + h * HD;
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < HD; c += 8) {
-        const bf16x8 x = ld8(o + c), y = ld8(d + c);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s += (float)x[j] * (float)y[j];
-    }
-    a.delta[i] = s;
-}
-
+// delta_i = rowsum(dO_i * O_i) is not a separate pass: the dQ workgroups take it from the dO / O fragments they hold anyway,
+// the dK/dV workgroups compute it for each query block while that block's tiles are in flight (two 16-byte loads per thread).
 template <int HD>
 __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx) {
     using C = Cfg<HD>;
@@ -287,23 +269,29 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
     const bf16* kb_ = a.k + (long)b * Tk * a.ldk + h * HD;
     const bf16* vb = a.v + (long)b * Tk * a.ldv + h * HD;
     const bf16* dob = a.dout + (long)b * Tq * a.lddo + h * HD;
+    const bf16* ob = a.o + (long)b * Tq * a.ldo + h * HD;
 
     zero_tile<HD>(sK, tid);
     zero_tile<HD>(sV, tid);
     const int qrow0 = q0 + wave * 16;
     bf16x8 qf[KS], dof[KS];
+    float dpart = 0.f;                                     // this lane's share of rowsum(dO * O) for query row (lane & 15)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         qf[ks] = frag_global<HD>(qb, a.ldq, qrow0, Tq, ks, lane);
         dof[ks] = frag_global<HD>(dob, a.lddo, qrow0, Tq, ks, lane);
+        const bf16x8 of = frag_global<HD>(ob, a.ldo, qrow0, Tq, ks, lane);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dpart = fmaf((float)of[j], (float)dof[ks][j], dpart);
     }
+    dpart += __shfl_xor(dpart, 16, 64); dpart += __shfl_xor(dpart, 32, 64);     // the 4 lanes of a row hold its 4 dim chunks
     float lse[4], dl[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int qi = qrow0 + (lane >> 4) * 4 + r;
         const long idx = ((long)b * a.H + h) * Tq + qi;
         lse[r] = qi < Tq ? a.lse[idx] : 0.f;
-        dl[r] = qi < Tq ? a.delta[idx] : 0.f;
+        dl[r] = __shfl(dpart, (lane >> 4) * 4 + r, 64);      // accumulator row (lane>>4)*4 + r  <-  lane with that row index
     }
     f32x4 dq[DT];
 #pragma unroll
@@ -377,6 +365,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
     const bf16* kb_ = a.k + (long)b * Tk * a.ldk + h * HD;
     const bf16* vb = a.v + (long)b * Tk * a.ldv + h * HD;
     const bf16* dob = a.dout + (long)b * Tq * a.lddo + h * HD;
+    const bf16* ob = a.o + (long)b * Tq * a.ldo + h * HD;
 
     zero_tile<HD>(sQ, tid);
     zero_tile<HD>(sDO, tid);
@@ -394,15 +383,31 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
     const int nqb = (Tq + BLK - 1) / BLK;
     const int qb0 = a.causal ? k0 / BLK : 0;
     TileRegs<HD> tq, tdo;
-    float nlse = 0.f, ndl = 0.f;                           // threads 0..63: lse / delta of the next query block
+    float nlse = 0.f, ndl = 0.f;       // lse (threads 0..63) / delta (threads 4r..4r+3: row r) of the next query block
     auto fetch_q = [&](int qbi) {
         tq.fetch(qb, a.ldq, qbi * BLK, Tq, tid);
         tdo.fetch(dob, a.lddo, qbi * BLK, Tq, tid);
         if (tid < BLK) {
             const int qi = qbi * BLK + tid;
             const long idx = ((long)b * a.H + h) * Tq + (qi < Tq ? qi : Tq - 1);
-            const float l0 = a.lse[idx], d0 = a.delta[idx];
-            nlse = qi < Tq ? l0 : 0.f; ndl = qi < Tq ? d0 : 0.f;
+            const float l0 = a.lse[idx];
+            nlse = qi < Tq ? l0 : 0.f;
+        }
+        {   // delta of row tid/4: the row's HD/8 16-byte chunks are dealt to its 4 threads, then folded over those lanes
+            constexpr int CPR = HD / 8;
+            const int qi = qbi * BLK + (tid >> 2), row = qi < Tq ? qi : Tq - 1;
+            float d0 = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < (CPR + 3) / 4; ++cc) {
+                const int ch = (tid & 3) + 4 * cc, chc = ch < CPR ? ch : 0;
+                const bf16x8 x = ld8(ob + (long)row * a.ldo + chc * 8), y = ld8(dob + (long)row * a.lddo + chc * 8);
+                float t = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t = fmaf((float)x[j], (float)y[j], t);
+                d0 += ch < CPR ? t : 0.f;
+            }
+            d0 += __shfl_xor(d0, 1, 64); d0 += __shfl_xor(d0, 2, 64);
+            ndl = qi < Tq ? d0 : 0.f;
         }
     };
     if (qb0 < nqb) fetch_q(qb0);
@@ -410,7 +415,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
         __syncthreads();
         tq.commit(sQ, Tq, tid);
         tdo.commit(sDO, Tq, tid);
-        if (tid < BLK) { sLse[tid] = nlse; sDl[tid] = ndl; }
+        if (tid < BLK) sLse[tid] = nlse;
+        if ((tid & 3) == 0) sDl[tid >> 2] = ndl;
         __syncthreads();
         if (qbi + 1 < nqb) fetch_q(qbi + 1);
         bf16* sp = sP[wave];
@@ -473,8 +479,6 @@ int launch_fwd(const AttnArgs& a, hipStream_t s) {
 }
 template <int HD>
 int launch_bwd(const AttnArgs& a, hipStream_t s) {
-    const long n = (long)a.B * a.H * a.Tq;
-    hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
     const int nqb = (a.Tq + BLK - 1) / BLK, nkb = (a.Tk + BLK - 1) / BLK;
     hipLaunchKernelGGL(attn_bwd_kernel<HD>, dim3(nqb + nkb, a.H, a.B), dim3(256), 0, s, a, nqb);
     return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -24,7 +24,7 @@ namespace {
 struct PInfo { std::string name; int64_t shape[4]; int ndim; int64_t off; int64_t numel; };
 struct Lin { int64_t w, b; int N, K; bf16 *k16, *t16; };          // weight [N][K]; k16 = bf16 copy, t16 = bf16 [K][Npad]
 struct Norm { int64_t w, b; };
-struct Attn { Lin in, out; };
+struct Attn { Lin in, out; bf16 *q_k16, *q_t16; };             // q_*: cross-attention only -- the query third of in_proj on its own
 struct EncL { Attn sa; Lin l1, l2; Norm n1, n2; };
 struct DecL { Attn sa, ca; Lin l1, l2; Norm n1, n2, n3; };
 struct Conv { int64_t w, b; int CO, CI; bf16 *k16, *d16; };
@@ -42,7 +42,7 @@ struct Arena {
 struct EncAct { float *s1, *x1_32, *s2, *m1, *r1, *m2, *r2, *lse; bf16 *qkv, *ao, *x1_16, *f; uint32_t site[4]; };
 struct DecAct {
     float *s1, *y1_32, *s2, *y2_32, *s3, *m1, *r1, *m2, *r2, *m3, *r3, *lse_s, *lse_c;
-    bf16 *qkv, *ao, *y1_16, *q, *kv, *co, *y2_16, *f; uint32_t site[6];
+    bf16 *qkv, *ao, *y1_16, *q, *kv, *co, *y2_16, *f; uint32_t site[6];      // kv: this layer's 2E columns of Acts::kv_all (row stride NK)
 };
 // per-decoder-layer bf16 gradient operands of the deferred (grouped) weight-gradient launch
 struct DecGrad { bf16 *g3, *g2, *g1, *gf, *gq, *gqkv; };
@@ -53,7 +53,7 @@ struct Acts {
     bf16 *a1, *a2, *p1, *a3, *a4, *p2;
     std::vector<float*> x32; std::vector<bf16*> x16;        // encoder layer inputs/outputs [NE+1]
     std::vector<EncAct> enc;
-    float *mf, *rf; bf16* mem16;
+    float *mf, *rf; bf16* mem16; bf16* kv_all;             // kv_all [rows_e][ND*2E]: K|V of every decoder layer's cross-attention
     std::vector<float*> y32; std::vector<bf16*> y16;        // decoder layer inputs/outputs [ND+1]
     std::vector<DecAct> dec;
     float *mdf, *rdf; bf16* yf16;
@@ -61,7 +61,7 @@ struct Acts {
     uint32_t site_v2e, site_emb;
     // backward scratch
     float *ge_a, *ge_b, *gd_a, *gd_b, *dmem32, *v2e_g32;
-    bf16 *ge16, *gqkv_e, *gf_e, *gao_e, *gao_d, *gkv_d, *dp2, *da4, *da3, *dp1, *da2, *da1;
+    bf16 *ge16, *gqkv_e, *gf_e, *gao_e, *gao_d, *gkv_all, *dp2, *da4, *da3, *dp1, *da2, *da1;
     float *delta_e, *delta_d;
     std::vector<DecGrad> dgr;
     float* slab; int64_t slab_floats;
@@ -80,8 +80,12 @@ struct masr_model {
     float *P = nullptr, *G = nullptr; const float* pe = nullptr;
     char* ws = nullptr; int64_t ws_bytes = 0, persist_bytes = 0;
     bf16 *v2e_k = nullptr;                    // permuted vgg2enc weight (NHWC feature order)
+    // cross-attention K/V projections of ALL decoder layers as one operand: the encoder memory is projected once by one GEMM
+    // with N = ND*2E (forward), its gradient comes back through one GEMM with K = ND*2E and the ND weight gradients are one
+    // reduction-major GEMM with M = ND*2E (segmented output rows).  kv_k16 [ND*2E][E], kvT [E][ND*2E], kv_bias [ND*2E].
+    bf16 *kv_k16 = nullptr, *kvT = nullptr; float* kv_bias = nullptr; int NK = 0;
     long* d_ranges = nullptr; int nranges = 0;            // split-K combine table: (offset, length) of every Linear weight / bias
-    ShadowDesc* d_sdesc = nullptr; bf16** d_sptrs = nullptr; int nsdesc = 0, shadow_tiles = 0;
+    ShadowJobs shadows{};                                  // job list of the one-launch operand-shadow refresh
     float* stats = nullptr;                   // device [8]: loss, n_correct, n_total, grad_norm
     unsigned* conv_sched = nullptr;           // tile counters of the streaming conv kernel (this model's stream only)
     float* h_stats = nullptr;                 // pinned
@@ -154,13 +158,16 @@ void plan_persistent(masr_model* m, Arena& ar) {
     m->ct.k16 = ar.get<bf16>((int64_t)m->Cp * m->E);
     m->ct.t16 = ar.get<bf16>((int64_t)m->E * m->Cp);
     for (auto& e : m->enc) { lin(e.sa.in); lin(e.sa.out); lin(e.l1); lin(e.l2); }
-    for (auto& d : m->dec) { lin(d.sa.in); lin(d.sa.out); lin(d.ca.in); lin(d.ca.out); lin(d.l1); lin(d.l2); }
+    for (auto& d : m->dec) {
+        lin(d.sa.in); lin(d.sa.out); lin(d.ca.out); lin(d.l1); lin(d.l2);
+        d.ca.q_k16 = ar.get<bf16>((int64_t)m->E * m->E); d.ca.q_t16 = ar.get<bf16>((int64_t)m->E * m->E);
+        d.ca.in.k16 = d.ca.in.t16 = nullptr;                        // (the packed in_proj of a cross-attention has no shadow of its own)
+    }
+    m->NK = m->ND * 2 * m->E;
+    m->kv_k16 = ar.get<bf16>((int64_t)m->NK * m->E); m->kvT = ar.get<bf16>((int64_t)m->E * m->NK); m->kv_bias = ar.get<float>(m->NK);
     m->stats = ar.get<float>(64);
     m->conv_sched = ar.get<unsigned>(64);
-    const int nlin = (int)(m->enc.size() * 4 + m->dec.size() * 6);
     m->d_ranges = ar.get<long>((int64_t)split_chunks(m).size());
-    m->d_sdesc = ar.get<ShadowDesc>(nlin);
-    m->d_sptrs = ar.get<bf16*>(2 * nlin);
 }
 
 // ------------------------------------------------------------------ activation plan
@@ -184,17 +191,19 @@ void plan_acts(const masr_model* m, Arena& ar, Acts& a, int B, int T, int L, boo
         e.s2 = ar.get<float>(re * E); e.m2 = ar.get<float>(re); e.r2 = ar.get<float>(re);
     }
     a.mf = ar.get<float>(re); a.rf = ar.get<float>(re); a.mem16 = ar.get<bf16>(re * E);
+    a.kv_all = ar.get<bf16>(re * m->NK);
     a.y32.resize(m->ND + 1); a.y16.resize(m->ND + 1); a.dec.resize(m->ND);
     for (int l = 0; l <= m->ND; ++l) { a.y32[l] = ar.get<float>(rd * E); a.y16[l] = ar.get<bf16>(rd * E); }
     for (auto& d : a.dec) {
         d.qkv = ar.get<bf16>(rd * 3 * E); d.ao = ar.get<bf16>(rd * E); d.lse_s = ar.get<float>((int64_t)B * H * L);
         d.s1 = ar.get<float>(rd * E); d.y1_32 = ar.get<float>(rd * E); d.y1_16 = ar.get<bf16>(rd * E);
         d.m1 = ar.get<float>(rd); d.r1 = ar.get<float>(rd);
-        d.q = ar.get<bf16>(rd * E); d.kv = ar.get<bf16>(re * 2 * E); d.co = ar.get<bf16>(rd * E); d.lse_c = ar.get<float>((int64_t)B * H * L);
+        d.q = ar.get<bf16>(rd * E); d.kv = nullptr; d.co = ar.get<bf16>(rd * E); d.lse_c = ar.get<float>((int64_t)B * H * L);
         d.s2 = ar.get<float>(rd * E); d.y2_32 = ar.get<float>(rd * E); d.y2_16 = ar.get<bf16>(rd * E);
         d.m2 = ar.get<float>(rd); d.r2 = ar.get<float>(rd);
         d.f = ar.get<bf16>(rd * Fi); d.s3 = ar.get<float>(rd * E); d.m3 = ar.get<float>(rd); d.r3 = ar.get<float>(rd);
     }
+    if (a.kv_all) for (int l = 0; l < m->ND; ++l) a.dec[l].kv = a.kv_all + (int64_t)l * 2 * E;
     a.mdf = ar.get<float>(rd); a.rdf = ar.get<float>(rd); a.yf16 = ar.get<bf16>(rd * E);
     a.logits = ar.get<float>(rd * m->Cp); a.dlogits = ar.get<bf16>(rd * m->Cp);
     a.row_loss = ar.get<float>(rd); a.row_correct = ar.get<int>(rd);
@@ -221,7 +230,7 @@ void plan_acts(const masr_model* m, Arena& ar, Acts& a, int B, int T, int L, boo
         a.gqkv_e = ar.get<bf16>(re * 3 * E);
         a.gf_e = ar.get<bf16>(re * Fi);
         a.gao_e = ar.get<bf16>(re * E); a.gao_d = ar.get<bf16>(rd * E);
-        a.gkv_d = ar.get<bf16>(re * 2 * E);
+        a.gkv_all = ar.get<bf16>(re * m->NK);
         a.delta_e = ar.get<float>((int64_t)B * H * a.Tp); a.delta_d = ar.get<float>((int64_t)B * H * L);
         a.dgr.resize(m->ND);
         for (auto& g : a.dgr) {
@@ -262,7 +271,12 @@ GemmArgs lin_fwd_args(const bf16* x, long ldx, const bf16* wk, int M, int N, int
 
 struct Ctx { masr_model* m; hipStream_t s; uint32_t seed; bool train; float p_drop, p_pos; };
 
-int gemm(Ctx& c, const GemmArgs& g) { Prof p(c.m, MASR_PROF_GEMM, c.s); return mk_gemm(g, c.s); }
+int gemm(Ctx& c, const GemmArgs& g) {
+    const int re = c.m->acts.rows_e;
+    const int cat = g.reduction_major ? (g.K == re ? MASR_PROF_WGRAD_ENC : MASR_PROF_WGRAD_DEC) : (g.M == re ? MASR_PROF_GEMM_ENC : MASR_PROF_GEMM_DEC);
+    Prof p(c.m, cat, c.s);
+    return mk_gemm(g, c.s);
+}
 
 // weight/bias gradients of a Linear: dW[N][K] = dy^T x, db = colsum(dy)
 int lin_wgrad(Ctx& c, const bf16* dy, long lddy, const bf16* x, long ldx, int rows, int N, int K, float* dW, float* db, bool split = false,
@@ -288,7 +302,7 @@ int flush_wgrads(Ctx& c) {
     masr_model* m = c.m;
     m->wg_defer = false;
     if (m->wg.n == 0) return 0;
-    Prof p(m, MASR_PROF_GEMM, c.s);
+    Prof p(m, MASR_PROF_WGRAD_DEC, c.s);
     const int rc = mk_gemm_wgrad_grouped(m->wg, c.s);
     m->wg.n = 0;
     return rc;
@@ -310,15 +324,15 @@ int attn_block_fwd(Ctx& c, const Attn& at, const bf16* xq, const bf16* xkv, int 
         CK(gemm(c, g));
         a.q = qkv_or_q; a.k = qkv_or_q + E; a.v = qkv_or_q + 2 * E; a.ldq = a.ldk = a.ldv = 3 * E;
     } else {
-        GemmArgs g = lin_fwd_args(xq, E, at.in.k16, rows_q, E, E, P + at.in.b); g.C16 = qkv_or_q; g.ldc16 = E;
+        GemmArgs g = lin_fwd_args(xq, E, at.q_k16, rows_q, E, E, P + at.in.b); g.C16 = qkv_or_q; g.ldc16 = E;
         CK(gemm(c, g));
-        GemmArgs h = lin_fwd_args(xkv, E, at.in.k16 + (long)E * E, rows_kv, 2 * E, E, P + at.in.b + E); h.C16 = kv; h.ldc16 = 2 * E;
-        CK(gemm(c, h));
-        a.q = qkv_or_q; a.ldq = E; a.k = kv; a.v = kv + E; a.ldk = a.ldv = 2 * E;
+        // K|V of the encoder memory were projected for all layers at once (project_memory_kv); kv = this layer's columns
+        (void)xkv; (void)rows_kv;
+        a.q = qkv_or_q; a.ldq = E; a.k = kv; a.v = kv + E; a.ldk = a.ldv = m->NK;
     }
     a.o = ao; a.ldo = E; a.lse = lse; a.klens = klens; a.B = m->acts.B; a.H = m->H; a.Tq = Tq; a.Tk = Tk; a.hd = m->hd;
     a.causal = causal; a.drop_p = c.p_drop; a.seed = c.seed; a.site = site_p;
-    { Prof p(m, MASR_PROF_ATTN, c.s); CK(mk_attn_fwd(a, c.s)); }
+    { Prof p(m, Tk == m->acts.Tp && Tq == Tk ? MASR_PROF_ATTN_ENC : MASR_PROF_ATTN_DEC, c.s); CK(mk_attn_fwd(a, c.s)); }
     GemmArgs o = lin_fwd_args(ao, E, at.out.k16, rows_q, E, E, P + at.out.b);
     o.drop_p = c.p_drop; o.seed = c.seed; o.site = site_o; o.residual = resid; o.ldres = E; o.C32 = s_out; o.ldc = E;
     CK(gemm(c, o));
@@ -336,12 +350,12 @@ int ffn_fwd(Ctx& c, const Lin& l1, const Lin& l2, const bf16* x16, const float* 
     return 0;
 }
 int ln_fwd(Ctx& c, const Norm& n, const float* x, float* y32, bf16* y16, float* mean, float* rstd, int rows) {
-    Prof p(c.m, MASR_PROF_OTHER, c.s);
+    Prof p(c.m, MASR_PROF_LAYERNORM, c.s);
     return mk_layernorm_fwd(x, c.m->P + n.w, c.m->P + n.b, y32, y16, mean, rstd, rows, c.m->E, c.s);
 }
 int ln_bwd(Ctx& c, const Norm& n, const float* dy, const float* x, const float* mean, const float* rstd, float* dx32, bf16* dx16,
            uint32_t site, int rows) {
-    Prof p(c.m, MASR_PROF_OTHER, c.s);
+    Prof p(c.m, MASR_PROF_LAYERNORM, c.s);
     masr_model* m = c.m;
     // the dgamma/dbeta partials of every LayerNorm go to their own slab region; flush_ln_reduce folds them all at once
     const int64_t need = mk_layernorm_bwd_slab_floats(rows, m->E);
@@ -358,7 +372,7 @@ int ln_bwd(Ctx& c, const Norm& n, const float* dy, const float* x, const float* 
 }
 int flush_ln_reduce(Ctx& c) {
     masr_model* m = c.m;
-    Prof p(m, MASR_PROF_OTHER, c.s);
+    Prof p(m, MASR_PROF_LAYERNORM, c.s);
     const int rc = mk_layernorm_bwd_reduce_grouped(m->lng, m->E, c.s);
     m->lng.n = 0; m->ln_slab_used = 0;
     return rc;
@@ -432,6 +446,7 @@ masr_model* masr_create(const masr_config* cfg) {
         d.n1 = add_norm(m, pre + ".norm1"); d.n2 = add_norm(m, pre + ".norm2"); d.n3 = add_norm(m, pre + ".norm3");
     }
     m->dec_norm = add_norm(m, "decoder.norm");
+    if (5 + 4 * m->NE + 8 * m->ND > SHADOW_JOBS_MAX) { mk_set_error("masr_create", "too many layers for the shadow job list (4*enc + 8*dec <= 51)"); delete m; return nullptr; }
     Arena ar{nullptr, 0, 0};
     plan_persistent(m, ar);
     m->persist_bytes = ar.off;
@@ -481,20 +496,30 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
         HIP_CHECK_RET(hipHostMalloc((void**)&m->h_stats, sizeof(float) * 64, hipHostMallocDefault));
         for (auto& e : m->stage_ev) HIP_CHECK_RET(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    {   // device tables: split-K combine ranges and the fused shadow-refresh descriptors
-        std::vector<long> ranges = split_chunks(m); std::vector<ShadowDesc> desc; std::vector<bf16*> ptrs;
-        int tiles = 0;
-        auto lin = [&](const Lin& l, bool) {
-            ShadowDesc d; d.src = l.w; d.N = l.N; d.K = l.K; d.Np = (l.N + 7) / 8 * 8; d.tile_start = tiles;
-            tiles += ((l.N + 31) / 32) * ((l.K + 31) / 32);
-            desc.push_back(d); ptrs.push_back(l.k16); ptrs.push_back(l.t16);
+    {   // device tables: split-K combine ranges and the job list of the one-launch shadow refresh
+        std::vector<long> ranges = split_chunks(m);
+        ShadowJobs& J = m->shadows; J.n = 0;
+        int blocks = 0;
+        auto job = [&](int type, long src, int N, int K, int ldt, int a0, int a1, void* p0, void* p1) {
+            ShadowDesc d{}; d.src = src; d.type = type; d.N = N; d.K = K; d.ldt = ldt; d.a0 = a0; d.a1 = a1; d.tile_start = blocks;
+            blocks += mk_shadow_blocks(d);
+            J.d[J.n] = d; J.p[2 * J.n] = (bf16*)p0; J.p[2 * J.n + 1] = (bf16*)p1; ++J.n;
         };
-        for (auto& e : m->enc) { lin(e.sa.in, true); lin(e.sa.out, true); lin(e.l1, true); lin(e.l2, true); }
-        for (auto& d : m->dec) { lin(d.sa.in, false); lin(d.sa.out, false); lin(d.ca.in, false); lin(d.ca.out, false); lin(d.l1, false); lin(d.l2, false); }
-        m->nranges = (int)ranges.size() / 2; m->nsdesc = (int)desc.size(); m->shadow_tiles = tiles;
+        auto lin = [&](const Lin& l) { job(SH_LINEAR, l.w, l.N, l.K, (l.N + 7) / 8 * 8, 0, 0, l.k16, l.t16); };
+        const int E = m->E;
+        for (int i = 1; i < 4; ++i) job(SH_CONV, m->conv[i].w, m->conv[i].CO, m->conv[i].CI, 0, 0, 0, m->conv[i].k16, m->conv[i].d16);
+        job(SH_VGG2ENC, m->v2e.w, E, 0, 0, 128, m->Dp, m->v2e_k, m->v2e.t16);
+        job(SH_LINEAR, m->ct.w, m->C, E, m->Cp, 0, 0, m->ct.k16, m->ct.t16);     // pads (rows / columns >= odim) stay zero, see below
+        for (auto& e : m->enc) { lin(e.sa.in); lin(e.sa.out); lin(e.l1); lin(e.l2); }
+        for (int l = 0; l < m->ND; ++l) {
+            const DecL& d = m->dec[l];
+            lin(d.sa.in); lin(d.sa.out); lin(d.ca.out); lin(d.l1); lin(d.l2);
+            job(SH_LINEAR, d.ca.in.w, E, E, E, 0, 0, d.ca.q_k16, d.ca.q_t16);                                              // query third
+            job(SH_LINEAR, d.ca.in.w + (long)E * E, 2 * E, E, m->NK, 0, 0, m->kv_k16 + (long)l * 2 * E * E, m->kvT + (long)l * 2 * E);   // key|value thirds
+            job(SH_COPY32, d.ca.in.b + E, 2 * E, 0, 0, 0, 0, m->kv_bias + (long)l * 2 * E, nullptr);
+        }
+        m->nranges = (int)ranges.size() / 2; J.blocks = blocks;
         HIP_CHECK_RET(hipMemcpy(m->d_ranges, ranges.data(), sizeof(long) * ranges.size(), hipMemcpyHostToDevice));
-        HIP_CHECK_RET(hipMemcpy(m->d_sdesc, desc.data(), sizeof(ShadowDesc) * desc.size(), hipMemcpyHostToDevice));
-        HIP_CHECK_RET(hipMemcpy(m->d_sptrs, ptrs.data(), sizeof(bf16*) * ptrs.size(), hipMemcpyHostToDevice));
     }
     // pads of the char_trans shadows must be zero (rows/cols >= odim); the refresh kernels only write the odim part
     HIP_CHECK_RET(hipMemset(m->conv_sched, 0, sizeof(unsigned) * 64));   // tile counters of the streaming conv (re-armed by the kernel itself)
@@ -509,15 +534,10 @@ void masr_set_seed(masr_model* m, uint64_t seed) { m->seed = seed; m->step = 0; 
 int masr_refresh(masr_model* m, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!m->P) { mk_set_error("masr_refresh", "not bound"); return -1; }
-    Prof p(m, MASR_PROF_OTHER, s);
-    const float* P = m->P;
-    // (the pads of the char_trans shadows -- rows / columns >= odim -- are zeroed once in masr_bind and never written)
-    for (int i = 1; i < 4; ++i) CK(mk_conv_weight_shadows(P + m->conv[i].w, m->conv[i].k16, m->conv[i].d16, m->conv[i].CO, m->conv[i].CI, s));
-    CK(mk_vgg2enc_shadows(P + m->v2e.w, m->v2e_k, m->v2e.t16, m->E, 128, m->Dp, s));
-    CK(mk_cast_bf16(P + m->ct.w, m->ct.k16, (long)m->C * m->E, s));
-    CK(mk_transpose_cast_bf16(P + m->ct.w, m->ct.t16, m->C, m->E, m->Cp, s));
-    CK(mk_linear_shadows(P, m->d_sdesc, m->d_sptrs, m->nsdesc, m->shadow_tiles, s));
-    return 0;
+    Prof p(m, MASR_PROF_SHADOWS, s);
+    // every bf16 operand shadow (conv forward/dgrad layouts, permuted vgg2enc, all Linear weights and their transposes, the
+    // gathered cross-attention K/V operand) in ONE launch; the pads of the char_trans shadows are zeroed once in masr_bind
+    return mk_all_shadows(m->P, m->shadows, s);
 }
 
 static int forward_encoder(Ctx& c, const float* xs) {
@@ -525,21 +545,21 @@ static int forward_encoder(Ctx& c, const float* xs) {
     const int B = a.B, T = a.T, D = a.D, E = m->E;
     uint32_t site = 1;
     {
-        Prof p(m, MASR_PROF_CONV_FWD, s);
+        Prof p(m, MASR_PROF_CONV1_FWD, s);
         CK(mk_conv1_fwd(xs, P + m->conv[0].w, P + m->conv[0].b, a.a1, B, T, D, s));
     }
     static const bool fuse_pool = !getenv("MASR_NO_FUSED_POOL");      // MaxPool2d written by the producing conv's epilogue
     auto conv = [&](const bf16* in, const Conv& cv, bf16* out, int H, int W, bf16* pooled) -> int {
-        Prof p(m, &cv == &m->conv[1] ? MASR_PROF_CONV2_FWD : MASR_PROF_CONV_FWD, s);
+        Prof p(m, MASR_PROF_CONV2_FWD + (int)(&cv - &m->conv[1]), s);
         ConvArgs ca{}; ca.sched = m->conv_sched; ca.in = in; ca.wk = cv.k16; ca.bias = P + cv.b; ca.relu = 1; ca.mask = nullptr; ca.out = out;
         ca.B = B; ca.H = H; ca.W = W; ca.CIN = cv.CI; ca.COUT = cv.CO; ca.pool_out = fuse_pool ? pooled : nullptr;
         return mk_conv3x3(ca, s);
     };
     CK(conv(a.a1, m->conv[1], a.a2, T, D, a.p1));
-    if (!fuse_pool) { Prof p(m, MASR_PROF_OTHER, s); CK(mk_maxpool_fwd(a.a2, a.p1, B, T, D, 64, s)); }
+    if (!fuse_pool) { Prof p(m, MASR_PROF_POOL, s); CK(mk_maxpool_fwd(a.a2, a.p1, B, T, D, 64, s)); }
     CK(conv(a.p1, m->conv[2], a.a3, a.H2, a.W2, nullptr));
     CK(conv(a.a3, m->conv[3], a.a4, a.H2, a.W2, a.p2));
-    if (!fuse_pool) { Prof p(m, MASR_PROF_OTHER, s); CK(mk_maxpool_fwd(a.a4, a.p2, B, a.H2, a.W2, 128, s)); }
+    if (!fuse_pool) { Prof p(m, MASR_PROF_POOL, s); CK(mk_maxpool_fwd(a.a4, a.p2, B, a.H2, a.W2, 128, s)); }
     // vgg2enc + positional encoding + pos dropout
     {
         GemmArgs g = lin_fwd_args(a.p2, m->F, m->v2e_k, a.rows_e, E, m->F, P + m->v2e.b);
@@ -560,12 +580,21 @@ static int forward_encoder(Ctx& c, const float* xs) {
     return 0;
 }
 
-static int forward_decoder(Ctx& c) {
+// K|V projections of the encoder memory for the cross-attention of EVERY decoder layer: one GEMM, N = ND*2E
+static int project_memory_kv(Ctx& c) {
+    masr_model* m = c.m; Acts& a = m->acts;
+    GemmArgs h = lin_fwd_args(a.mem16, m->E, m->kv_k16, a.rows_e, m->NK, m->E, m->kv_bias);
+    h.C16 = a.kv_all; h.ldc16 = m->NK;
+    return gemm(c, h);
+}
+
+static int forward_decoder(Ctx& c, bool project_kv = true) {
     masr_model* m = c.m; Acts& a = m->acts; hipStream_t s = c.s; const float* P = m->P;
     const int E = m->E, L = a.L;
     uint32_t site = 100;
     a.site_emb = site++;
-    { Prof p(m, MASR_PROF_OTHER, s); CK(mk_embed_fwd(a.tok_in, P + m->embed_w, m->pe, a.y32[0], a.y16[0], a.B, L, E, c.p_pos, c.seed, a.site_emb, s)); }
+    if (project_kv) CK(project_memory_kv(c));
+    { Prof p(m, MASR_PROF_MISC, s); CK(mk_embed_fwd(a.tok_in, P + m->embed_w, m->pe, a.y32[0], a.y16[0], a.B, L, E, c.p_pos, c.seed, a.site_emb, s)); }
     for (int l = 0; l < m->ND; ++l) {
         DecAct& d = a.dec[l]; const DecL& w = m->dec[l];
         for (int i = 0; i < 6; ++i) d.site[i] = site++;
@@ -601,12 +630,12 @@ static int attn_block_bwd(Ctx& c, const Attn& at, const bf16* xq16, const bf16* 
         a.q = qkv_or_q; a.k = qkv_or_q + E; a.v = qkv_or_q + 2 * E; a.ldq = a.ldk = a.ldv = 3 * E;
         a.dq = gqkv_or_q; a.dk = gqkv_or_q + E; a.dv = gqkv_or_q + 2 * E; a.lddq = a.lddk = a.lddv = 3 * E;
     } else {
-        a.q = qkv_or_q; a.ldq = E; a.k = kv; a.v = kv + E; a.ldk = a.ldv = 2 * E;
-        a.dq = gqkv_or_q; a.lddq = E; a.dk = gkv; a.dv = gkv + E; a.lddk = a.lddv = 2 * E;
+        a.q = qkv_or_q; a.ldq = E; a.k = kv; a.v = kv + E; a.ldk = a.ldv = m->NK;
+        a.dq = gqkv_or_q; a.lddq = E; a.dk = gkv; a.dv = gkv + E; a.lddk = a.lddv = m->NK;     // this layer's columns of gkv_all
     }
     a.o = const_cast<bf16*>(ao); a.ldo = E; a.lse = const_cast<float*>(lse); a.dout = gao; a.lddo = E; a.delta = delta; a.klens = klens;
     a.B = m->acts.B; a.H = m->H; a.Tq = Tq; a.Tk = Tk; a.hd = m->hd; a.causal = causal; a.drop_p = c.p_drop; a.seed = c.seed; a.site = site_p;
-    { Prof p(m, MASR_PROF_ATTN, c.s); CK(mk_attn_bwd(a, c.s)); }
+    { Prof p(m, Tk == m->acts.Tp && Tq == Tk ? MASR_PROF_ATTN_ENC : MASR_PROF_ATTN_DEC, c.s); CK(mk_attn_bwd(a, c.s)); }
     if (self) {
         CK(lin_wgrad(c, gqkv_or_q, 3 * E, xq16, E, rows_q, 3 * E, E, G + at.in.w, G + at.in.b, split));
         GemmArgs g = lin_dgrad_args(gqkv_or_q, 3 * E, at.in.t16, 3 * E, rows_q, 3 * E, E);
@@ -614,14 +643,32 @@ static int attn_block_bwd(Ctx& c, const Attn& at, const bf16* xq16, const bf16* 
         CK(gemm(c, g));
     } else {
         CK(lin_wgrad(c, gqkv_or_q, E, xq16, E, rows_q, E, E, G + at.in.w, G + at.in.b));
-        GemmArgs g = lin_dgrad_args(gqkv_or_q, E, at.in.t16, 3 * E, rows_q, E, E);
+        GemmArgs g = lin_dgrad_args(gqkv_or_q, E, at.q_t16, E, rows_q, E, E);
         g.residual = gs32; g.ldres = E; g.C32 = gout; g.ldc = E;
         CK(gemm(c, g));
-        CK(lin_wgrad(c, gkv, 2 * E, xkv16, E, rows_kv, 2 * E, E, G + at.in.w + (long)E * E, G + at.in.b + E, true));   // encoder rows
-        GemmArgs h = lin_dgrad_args(gkv, 2 * E, at.in.t16 + E, 3 * E, rows_kv, 2 * E, E);
-        h.C32 = dmem; h.ldc = E; h.accumulate = dmem_accumulate;
-        CK(gemm(c, h));
+        // the K|V halves (weight gradients, gradient of the encoder memory) are handled for all layers at once by
+        // memory_kv_bwd after the decoder layer loop
+        (void)xkv16; (void)rows_kv; (void)dmem; (void)dmem_accumulate;
     }
+    return 0;
+}
+
+// backward of project_memory_kv for all decoder layers at once: the ND weight gradients dW_l = gkv_l^T mem are ONE
+// reduction-major GEMM with M = ND*2E whose output rows are segmented over the layers' in_proj_weight blocks (constant
+// distance in the flat gradient buffer), and d(memory) = sum_l gkv_l Wkv_l is ONE GEMM with K = ND*2E
+static int memory_kv_bwd(Ctx& c) {
+    masr_model* m = c.m; Acts& a = m->acts; float* G = m->G;
+    const int E = m->E;
+    const DecL& d0 = m->dec[0];
+    GemmArgs g = gemm_args();
+    g.reduction_major = 1; g.A = a.gkv_all; g.lda = m->NK; g.B = a.mem16; g.ldb = E; g.M = m->NK; g.N = E; g.K = a.rows_e;
+    g.C32 = G + d0.ca.in.w + (long)E * E; g.ldc = E; g.colsum = G + d0.ca.in.b + E;
+    g.cseg_rows = 2 * E; g.cseg_stride = m->ND > 1 ? m->dec[1].ca.in.w - d0.ca.in.w : 0;
+    g.split_k = WG_SPLIT; g.split_delta = a.wg_slab - G; g.split_stride = m->nparams;
+    CK(gemm(c, g));
+    GemmArgs h = lin_dgrad_args(a.gkv_all, m->NK, m->kvT, m->NK, a.rows_e, m->NK, E);
+    h.C32 = a.dmem32; h.ldc = E;
+    CK(gemm(c, h));
     return 0;
 }
 
@@ -644,12 +691,13 @@ static int backward(Ctx& c, const float* xs) {
         CK(ffn_bwd(c, w.l1, w.l2, d.y2_16, d.f, gs, dg.g3, a.rows_d, dg.gf, gcur, false));
         CK(ln_bwd(c, w.n2, gcur, d.s2, d.m2, d.r2, gs, dg.g2, d.site[3], a.rows_d));
         CK(attn_block_bwd(c, w.ca, d.y1_16, a.mem16, a.rows_d, a.rows_e, L, a.Tp, false, false, a.enc_lens, d.q, d.kv, d.co, d.lse_c, gs,
-                          dg.g2, a.gao_d, dg.gq, a.gkv_d, a.delta_d, gcur, a.dmem32, l == m->ND - 1 ? 0 : 1, d.site[2], false));
+                          dg.g2, a.gao_d, dg.gq, a.gkv_all + (int64_t)l * 2 * E, a.delta_d, gcur, a.dmem32, 0, d.site[2], false));
         CK(ln_bwd(c, w.n1, gcur, d.s1, d.m1, d.r1, gs, dg.g1, d.site[1], a.rows_d));
         CK(attn_block_bwd(c, w.sa, a.y16[l], nullptr, a.rows_d, 0, L, L, true, true, nullptr, d.qkv, nullptr, d.ao, d.lse_s, gs, dg.g1,
                           a.gao_d, dg.gqkv, nullptr, a.delta_d, gcur, nullptr, 0, d.site[0], false));
     }
     CK(flush_wgrads(c));
+    CK(memory_kv_bwd(c));
     float* g_dec_in = gcur;                                  // d(decoder input): consumed by embed_bwd after the split-K combine
     // ---- encoder
     gcur = a.ge_b; gs = a.ge_a;
@@ -663,47 +711,47 @@ static int backward(Ctx& c, const float* xs) {
                           a.gao_e, a.gqkv_e, nullptr, a.delta_e, gcur, nullptr, 0, e.site[0], true));
     }
     // ---- vgg2enc (through the positional dropout)
-    { Prof p(m, MASR_PROF_OTHER, s); CK(mk_cast_dropout(gcur, a.ge16, (long)a.rows_e * E, c.p_pos, c.seed, a.site_v2e, s)); }
+    { Prof p(m, MASR_PROF_MISC, s); CK(mk_cast_dropout(gcur, a.ge16, (long)a.rows_e * E, c.p_pos, c.seed, a.site_v2e, s)); }
     CK(lin_wgrad(c, a.ge16, E, a.p2, m->F, a.rows_e, E, m->F, a.v2e_g32, G + m->v2e.b));
-    { Prof p(m, MASR_PROF_OTHER, s); CK(mk_vgg2enc_grad_unpermute(a.v2e_g32, G + m->v2e.w, E, 128, m->Dp, s)); }
+    { Prof p(m, MASR_PROF_MISC, s); CK(mk_vgg2enc_grad_unpermute(a.v2e_g32, G + m->v2e.w, E, 128, m->Dp, s)); }
     { GemmArgs g = lin_dgrad_args(a.ge16, E, m->v2e.t16, E, a.rows_e, E, m->F); g.C16 = a.dp2; g.ldc16 = m->F; CK(gemm(c, g)); }
     // ---- VGG
     const int64_t P1 = (int64_t)B * a.T * a.D, P2 = (int64_t)B * a.H2 * a.W2;
     auto wgrad = [&](const bf16* in, const bf16* dy, const Conv& cv, int H, int W, int64_t P) -> int {
-        { Prof p(m, MASR_PROF_CONV_WGRAD, s);
+        { Prof p(m, MASR_PROF_CONV2_WGRAD + (int)(&cv - &m->conv[1]), s);
           ConvWgradArgs wa{}; wa.in = in; wa.dy = dy; wa.dw = G + cv.w; wa.db = G + cv.b; wa.slab = a.slab; wa.B = B; wa.H = H; wa.W = W; wa.CIN = cv.CI; wa.COUT = cv.CO;
           CK(mk_conv3x3_wgrad(wa, s)); }
         (void)P;
         return 0;
     };
     auto dgrad = [&](const bf16* dy, const Conv& cv, const bf16* mask, bf16* out, int H, int W) -> int {
-        Prof p(m, MASR_PROF_CONV_DGRAD, s);
+        Prof p(m, MASR_PROF_CONV2_DGRAD + (int)(&cv - &m->conv[1]), s);
         ConvArgs ca{}; ca.sched = m->conv_sched; ca.in = dy; ca.wk = cv.d16; ca.bias = nullptr; ca.relu = 0; ca.mask = mask; ca.out = out; ca.B = B; ca.H = H; ca.W = W;
         ca.CIN = cv.CO; ca.COUT = cv.CI;
         return mk_conv3x3(ca, s);
     };
-    { Prof p(m, MASR_PROF_OTHER, s); CK(mk_maxpool_relu_bwd(a.a4, a.dp2, a.da4, B, a.H2, a.W2, 128, s)); }
+    { Prof p(m, MASR_PROF_POOL, s); CK(mk_maxpool_relu_bwd(a.a4, a.dp2, a.da4, B, a.H2, a.W2, 128, s)); }
     CK(wgrad(a.a3, a.da4, m->conv[3], a.H2, a.W2, P2));
     CK(dgrad(a.da4, m->conv[3], a.a3, a.da3, a.H2, a.W2));
     CK(wgrad(a.p1, a.da3, m->conv[2], a.H2, a.W2, P2));
     CK(dgrad(a.da3, m->conv[2], nullptr, a.dp1, a.H2, a.W2));
-    { Prof p(m, MASR_PROF_OTHER, s); CK(mk_maxpool_relu_bwd(a.a2, a.dp1, a.da2, B, a.T, a.D, 64, s)); }
+    { Prof p(m, MASR_PROF_POOL, s); CK(mk_maxpool_relu_bwd(a.a2, a.dp1, a.da2, B, a.T, a.D, 64, s)); }
     CK(wgrad(a.a1, a.da2, m->conv[1], a.T, a.D, P1));
     static const bool fuse_w1 = !getenv("MASR_NO_FUSED_CONV1_WGRAD");
     if (fuse_w1) {
         // d(conv1 output) is consumed only by conv1's weight gradient: contract it inside the dgrad epilogue, never store it
-        { Prof p(m, MASR_PROF_CONV_DGRAD, s);
+        { Prof p(m, MASR_PROF_CONV2_DGRAD, s);
           ConvArgs ca{}; ca.sched = m->conv_sched; ca.in = a.da2; ca.wk = m->conv[1].d16; ca.mask = a.a1; ca.out = a.da1; ca.B = B; ca.H = a.T; ca.W = a.D;
           ca.CIN = 64; ca.COUT = 64; ca.x1 = xs; ca.w1_slab = a.slab;
           CK(mk_conv3x3(ca, s)); }
-        { Prof p(m, MASR_PROF_CONV_WGRAD, s); CK(mk_conv1_wgrad_fused_reduce(a.slab, B, a.T, a.D, G + m->conv[0].w, G + m->conv[0].b, s)); }
+        { Prof p(m, MASR_PROF_CONV1_WGRAD, s); CK(mk_conv1_wgrad_fused_reduce(a.slab, B, a.T, a.D, G + m->conv[0].w, G + m->conv[0].b, s)); }
     } else {
         CK(dgrad(a.da2, m->conv[1], a.a1, a.da1, a.T, a.D));
-        { Prof p(m, MASR_PROF_CONV_WGRAD, s); CK(mk_conv1_wgrad(xs, a.da1, G + m->conv[0].w, G + m->conv[0].b, a.slab, B, a.T, a.D, s)); }
+        { Prof p(m, MASR_PROF_CONV1_WGRAD, s); CK(mk_conv1_wgrad(xs, a.da1, G + m->conv[0].w, G + m->conv[0].b, a.slab, B, a.T, a.D, s)); }
     }
     CK(flush_ln_reduce(c));
     // ---- combine the split-K partials of all Linear gradients, then add the embedding rows into the (tied) table
-    { Prof p(m, MASR_PROF_OTHER, s);
+    { Prof p(m, MASR_PROF_MISC, s);
       CK(mk_split_reduce(G, a.wg_slab, WG_SPLIT - 1, m->nparams, m->d_ranges, m->nranges, s));
       CK(mk_embed_bwd(a.tok_in, g_dec_in, G + m->embed_w, a.rows_d, m->C, E, m->cfg.tie_weights ? 1 : 0, c.p_pos, c.seed, a.site_emb, s)); }
     return 0;
@@ -752,7 +800,7 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
     m->step++;
     CK(forward_encoder(c, xs));
     CK(forward_decoder(c));
-    { Prof p(m, MASR_PROF_OTHER, s);
+    { Prof p(m, MASR_PROF_MISC, s);
       CK(mk_ls_ce(a.logits, m->Cp, a.gold, a.rows_d, m->C, m->cfg.label_smoothing, 1.0f / (float)ntot, a.dlogits, a.row_loss, a.row_correct,
                   m->stats, s)); }
     if (train) CK(backward(c, xs));
@@ -781,12 +829,12 @@ static float* slab_of(masr_model* m) {
 int masr_grad_norm(masr_model* m, void* stream) {
     float* slab = slab_of(m);
     if (!slab) { mk_set_error("masr_grad_norm", "run a batch first"); return -1; }
-    Prof p(m, MASR_PROF_OTHER, (hipStream_t)stream);
+    Prof p(m, MASR_PROF_OPTIM, (hipStream_t)stream);
     return mk_sumsq(m->G, m->nparams, slab, m->stats + 3, (hipStream_t)stream);
 }
 int masr_clip_sgd_step(masr_model* m, float* mom, float max_norm, float lr, float momentum, int nesterov, int first_step, void* stream) {
     CK(masr_grad_norm(m, stream));
-    { Prof p(m, MASR_PROF_OTHER, (hipStream_t)stream);
+    { Prof p(m, MASR_PROF_OPTIM, (hipStream_t)stream);
       CK(mk_clip_sgd(m->P, m->G, mom, m->nparams, m->stats + 3, max_norm, lr, momentum, nesterov, first_step, (hipStream_t)stream)); }
     return masr_refresh(m, stream);
 }
@@ -838,10 +886,10 @@ static int decode_step(Ctx& c, int* out) {
         CK(mk_skinny_gemm(g, s));
         CK(ln_fwd(c, w.n1, d.s1, d.y1_32, d.y1_16, d.m1, d.r1, B));
         // cross-attention over the encoder memory: d.kv was projected once, before the first step
-        g = lin(d.y1_16, E, w.ca.in.k16, E, E, P + w.ca.in.b); g.C16 = d.q; g.ldc16 = E;
+        g = lin(d.y1_16, E, w.ca.q_k16, E, E, P + w.ca.in.b); g.C16 = d.q; g.ldc16 = E;
         CK(mk_skinny_gemm(g, s));
         t = att();
-        t.q = d.q; t.ldq = E; t.k = d.kv; t.v = d.kv + E; t.ldk = 2 * E; t.kv_batch_stride = (long)a.Tp * 2 * E;
+        t.q = d.q; t.ldq = E; t.k = d.kv; t.v = d.kv + E; t.ldk = m->NK; t.kv_batch_stride = (long)a.Tp * m->NK;
         t.klens = a.enc_lens; t.o = d.co; t.Tk_cap = a.Tp;
         CK(mk_attn_decode(t, s));
         g = lin(d.co, E, w.ca.out.k16, E, E, P + w.ca.out.b); g.residual = d.y1_32; g.ldres = E; g.C32 = d.s2; g.ldc = E;
@@ -894,10 +942,11 @@ int masr_recog_full(masr_model* m, const float* xs, const int64_t* ilens, int B,
     { const int rc = recog_prepare(m, xs, ilens, B, T, s, &Ldec); if (rc) return rc; }
     Acts& a = m->acts;
     Ctx c{m, s, 0u, false, 0.f, 0.f};
+    CK(project_memory_kv(c));                               // (the memory does not change between steps)
     for (int step = 1; step <= Ldec; ++step) {
         a.L = step; a.rows_d = B * step;
         CK(mk_recog_build_tok(a.tok_in, out, B, step, 0, s));
-        CK(forward_decoder(c));
+        CK(forward_decoder(c, false));
         CK(mk_recog_argmax(a.logits, m->Cp, out, B, step, m->C, s));
     }
     m->have_acts = false;                                   // logits/gold views are not meaningful after a decode
@@ -915,12 +964,7 @@ int masr_recog(masr_model* m, const float* xs, const int64_t* ilens, int B, int 
     { const int rc = recog_prepare(m, xs, ilens, B, T, s, &Ldec); if (rc) return rc; }
     Acts& a = m->acts; const int E = m->E;
     Ctx c{m, s, 0u, false, 0.f, 0.f};
-    for (int l = 0; l < m->ND; ++l) {
-        const Lin& in = m->dec[l].ca.in;
-        GemmArgs h = lin_fwd_args(a.mem16, E, in.k16 + (long)E * E, a.rows_e, 2 * E, E, m->P + in.b + E);
-        h.C16 = a.dec[l].kv; h.ldc16 = 2 * E;
-        CK(gemm(c, h));
-    }
+    CK(project_memory_kv(c));
     CK(mk_recog_step_set(a.step_dev, 1, 0, s));
     const bool use_graph = s != nullptr && !m->prof && !getenv("MASR_RECOG_NO_GRAPH");
     if (!use_graph) {

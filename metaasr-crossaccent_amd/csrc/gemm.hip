@@ -117,6 +117,10 @@ __device__ __forceinline__ bf16x8 frag_rm(const bf16* tile, int r0, int lane, in
 
 // EPI >= 0: the set of epilogue features is a compile-time constant (dead paths vanish: the fully generic epilogue is
 // ~2000 instructions, which alone cost ~8 us per launch on the small decoder GEMMs); EPI < 0: decided at run time.
+// row m of the fp32 output (see GemmArgs::cseg_rows)
+__device__ __forceinline__ long crow(const GemmArgs& g, int m) {
+    return g.cseg_rows ? (long)(m / g.cseg_rows) * g.cseg_stride + (long)(m % g.cseg_rows) * g.ldc : (long)m * g.ldc;
+}
 enum { E_BIAS = 1, E_PE = 2, E_RELU = 4, E_MASK = 8, E_DROP = 16, E_RES = 32, E_ACC = 64, E_C32 = 128, E_C16 = 256 };
 #define HAS(flag, runtime) (EPI >= 0 ? bool(EPI & (flag)) : bool(runtime))
 
@@ -162,7 +166,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
     for (int e = 0; e < SW; ++e) bv[e] = (f_bias && e < nv) ? g.bias[n + e] : 0.f;
     // vector paths need a full strip and aligned rows (n is a multiple of SW by construction)
     constexpr int A16 = SW - 1;                                  // bf16 strip = SW * 2 bytes: leading dimension multiple of SW
-    const bool v_c32 = nv == SW && f_c32 && !((g.ldc | out_delta) & 3) && !((uintptr_t)g.C32 & 15);
+    const bool v_c32 = nv == SW && f_c32 && !((g.ldc | out_delta | g.cseg_stride) & 3) && !((uintptr_t)g.C32 & 15);
     const bool v_res = nv == SW && f_res && !(g.ldres & 3) && !((uintptr_t)g.residual & 15);
     const bool v_c16 = nv == SW && f_c16 && !(g.ldc16 & A16) && !((uintptr_t)g.C16 & (2 * SW - 1));
     const bool v_msk = nv == SW && f_mask && !(g.ldmask & A16) && !((uintptr_t)g.mask & (2 * SW - 1));
@@ -204,7 +208,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
             } else { for (int e = 0; e < nv; ++e) mk[i][e] = (float)p[e]; }
         }
         if (f_c32 && f_acc) {
-            const float* c32 = g.C32 + out_delta + (long)m * g.ldc + n;
+            const float* c32 = g.C32 + out_delta + crow(g, m) + n;
             if (v_c32) ldf(c32, old[i]);
             else { for (int e = 0; e < nv; ++e) old[i][e] = c32[e]; }
         }
@@ -225,7 +229,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
             v[e] = x + rs[i][e] + old[i][e];
         }
         if (f_c32) {
-            float* c32 = g.C32 + out_delta + (long)m * g.ldc + n;
+            float* c32 = g.C32 + out_delta + crow(g, m) + n;
             if (v_c32) {
 #pragma unroll
                 for (int h = 0; h < SW / 4; ++h) *reinterpret_cast<f32x4*>(c32 + 4 * h) = f32x4{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
@@ -346,7 +350,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
                 const int rc = tid / 8, j = tid % 8;
                 float sum = 0.f;
                 for (int t = rc; t < 256; t += RC) sum += red[t * 8 + j];
-                if (m0 + tid < g.M) g.colsum[out_delta + m0 + tid] = sum;
+                if (m0 + tid < g.M) {
+                    const int m = m0 + tid;
+                    g.colsum[out_delta + (g.cseg_rows ? (long)(m / g.cseg_rows) * g.cseg_stride + m % g.cseg_rows : (long)m)] = sum;
+                }
             }
             __syncthreads();
         }
@@ -573,6 +580,7 @@ int mk_gemm(const GemmArgs& g, hipStream_t s) {
         return -1;
     }
     if (!g.reduction_major && (g.K & 7)) { mk_set_error("mk_gemm", "K must be a multiple of 8"); return -1; }
+    if (g.cseg_rows && (g.cseg_rows % 128 || g.M % g.cseg_rows)) { mk_set_error("mk_gemm", "cseg_rows must be a multiple of 128 dividing M"); return -1; }
     // reduction-major tiles are fetched in 8-element chunks along m / n: the padded row must exist
     if (g.reduction_major && (g.lda < (g.M + 7) / 8 * 8 || g.ldb < (g.N + 7) / 8 * 8)) {
         mk_set_error("mk_gemm", "reduction-major form needs lda >= roundup8(M), ldb >= roundup8(N)");
@@ -584,7 +592,8 @@ int mk_gemm(const GemmArgs& g, hipStream_t s) {
     static const int rm_tile = getenv("MASR_GEMM_RM_TILE") ? atoi(getenv("MASR_GEMM_RM_TILE")) : 0;     // A/B switch: 1 = 64x64, 2 = 128x64
     if (g.reduction_major && rm_tile == 1) return launch_tile<64, 64>(g, s);
     if (g.reduction_major && rm_tile == 2) return launch_tile<128, 64>(g, s);
-    if (wgs(128, 128) >= 192) return launch_tile<128, 128>(g, s);
-    if (wgs(128, 64) >= 192) return launch_tile<128, 64>(g, s);
+    static const long min_wgs = getenv("MASR_GEMM_MIN_WGS") ? atol(getenv("MASR_GEMM_MIN_WGS")) : 192;   // A/B switch for the tile choice
+    if (wgs(128, 128) >= min_wgs) return launch_tile<128, 128>(g, s);
+    if (wgs(128, 64) >= min_wgs) return launch_tile<128, 64>(g, s);
     return launch_tile<64, 64>(g, s);
 }

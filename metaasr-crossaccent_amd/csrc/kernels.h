@@ -24,6 +24,11 @@ struct GemmArgs {
     int xcd_order;                // set by mk_gemm: XCD-contiguous tile order
     float* C32; long ldc;         // fp32 output or null
     bf16* C16; long ldc16;        // bf16 output or null
+    // segmented fp32 output rows (grouped weight gradients: one GEMM whose M axis spans several Linear layers that sit at a
+    // constant distance from each other in the flat gradient buffer): row m lives at C32 + (m / cseg_rows) * cseg_stride +
+    // (m % cseg_rows) * ldc, colsum[m] at colsum + (m / cseg_rows) * cseg_stride + m % cseg_rows.  cseg_rows = 0: plain rows;
+    // otherwise a multiple of the 128-row tile.
+    int cseg_rows; long cseg_stride;
 };
 int mk_gemm(const GemmArgs& g, hipStream_t s);
 // Linear weight gradients as one grouped launch: dW[N][K] = dy[rows][N]^T x[rows][K], db[N] = column sums of dy (or null)
@@ -152,14 +157,22 @@ int mk_axpy(float* y, const float* x, long n, float a, hipStream_t s);
 int mk_cast_bf16(const float* x, bf16* y, long n, hipStream_t s);
 int mk_transpose_cast_bf16(const float* x /*[R][C]*/, bf16* y /*[C][ldy]*/, int R, int C, long ldy, hipStream_t s);
 // conv weight shadows: w [CO][CI][3][3] fp32 -> wk [CO][tap*CI+ci] (fwd) and wd [CI][tap'*CO+co] = w[co][ci][8-tap'] (dgrad)
+int mk_conv_weight_shadows(const float* w, bf16* wk, bf16* wd, int CO, int CI, hipStream_t s);       // (BLSTM engine; the transformer uses mk_all_shadows)
 // G[i] += sum_{s<nslab} slab[s*stride + i] over the listed (offset, length <= 2048) chunks (deterministic split-K combine)
 int mk_split_reduce(float* G, const float* slab, int nslab, long stride, const long* ranges, int nranges, hipStream_t s);
-// all Linear-layer shadows in one launch: desc[i] = {src offset, N, K, Np, tile_start}, ptrs[2i] = k16, ptrs[2i+1] = t16
-struct ShadowDesc { long src; int N, K, Np, tile_start; };
-int mk_linear_shadows(const float* P, const ShadowDesc* desc, bf16* const* ptrs, int ndesc, int total_tiles, hipStream_t s);
-int mk_conv_weight_shadows(const float* w, bf16* wk, bf16* wd, int CO, int CI, hipStream_t s);
-// vgg2enc weight [E][128*Dp] with reference feature index c*Dp+d  ->  bf16 [E][d*128+c] (NHWC order) and transpose
-int mk_vgg2enc_shadows(const float* w, bf16* wk, bf16* wt, int E, int C, int Dp, hipStream_t s);
+// EVERY bf16 operand shadow of the model in ONE launch (masr_refresh after each parameter update), descriptor driven:
+//   SH_LINEAR   weight [N][K] at P+src -> k16 [N][K] and its transpose t16 [K][ldt] (32x32 tiles); ptrs[2i] = k16, ptrs[2i+1] = t16
+//   SH_CONV     w [CO=N][CI=K][3][3] -> wk [CO][tap*CI+ci] (forward) and wd [CI][tap'*CO+co] = w[co][ci][8-tap'] (dgrad)
+//   SH_VGG2ENC  w [E=N][a0*a1] with reference feature index c*Dp+d (a0 = C, a1 = Dp) -> wk [E][d*C+c] (NHWC order) and wt = wk^T
+//   SH_COPY32   N floats at P+src -> (float*)ptrs[2i]   (the cross-attention K/V biases gathered into one vector)
+enum { SH_LINEAR = 0, SH_CONV = 1, SH_VGG2ENC = 2, SH_COPY32 = 3 };
+struct ShadowDesc { long src; int type, N, K, ldt, tile_start, a0, a1; };
+// the whole job list travels in the kernel-argument segment (uniform scalar loads; a descriptor table in global memory cost
+// every workgroup a chain of dependent loads to find its job)
+constexpr int SHADOW_JOBS_MAX = 56;
+struct ShadowJobs { int n, blocks; ShadowDesc d[SHADOW_JOBS_MAX]; bf16* p[2 * SHADOW_JOBS_MAX]; };
+int mk_shadow_blocks(const ShadowDesc& d);                          // workgroups this job needs (tile_start bookkeeping on the host)
+int mk_all_shadows(const float* P, const ShadowJobs& jobs, hipStream_t s);
 // inverse map for the weight gradient: g_nhwc [E][d*C+c] fp32 -> dw [E][c*Dp+d]
 int mk_vgg2enc_grad_unpermute(const float* g_nhwc, float* dw, int E, int C, int Dp, hipStream_t s);
 

@@ -130,18 +130,6 @@ __global__ void conv_shadow_kernel(const float* __restrict__ w, bf16* __restrict
     wk[(long)co * 9 * CI + tap * CI + ci] = v;                        // forward: out[co] += in[p+off(tap)][ci] * w
     if (wd) wd[(long)ci * 9 * CO + (8 - tap) * CO + co] = v;          // dgrad: din[ci] += dy[p-off(tap)][co] * w
 }
-__global__ void vgg2enc_shadow_kernel(const float* __restrict__ w, bf16* __restrict__ wk, bf16* __restrict__ wt, int E, int C, int Dp) {
-    const int F = C * Dp;
-    const long n = (long)E * F;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int f = (int)(i % F), e = (int)(i / F);
-    const int c = f / Dp, d = f % Dp;                                   // reference feature index c*Dp + d
-    const int fn = d * C + c;                                           // NHWC feature index
-    const bf16 v = (bf16)w[i];
-    wk[(long)e * F + fn] = v;
-    wt[(long)fn * E + e] = v;
-}
 __global__ void vgg2enc_unpermute_kernel(const float* __restrict__ g, float* __restrict__ dw, int E, int C, int Dp) {
     const int F = C * Dp;
     const long n = (long)E * F;
@@ -167,27 +155,55 @@ __global__ __launch_bounds__(256) void split_reduce_kernel(float* __restrict__ G
 #pragma unroll
     for (int e = 0; e < 8; ++e) { const int i = threadIdx.x + e * 256; if (i < len) G[off + i] = v[e]; }
 }
-// every Linear weight -> bf16 copy [N][K] and bf16 transpose [K][Np], one 32x32 tile per workgroup
-__global__ __launch_bounds__(256) void linear_shadows_kernel(const float* __restrict__ P, const ShadowDesc* __restrict__ desc,
-                                                             bf16* const* __restrict__ ptrs, int ndesc) {
-    int e = 0;
-    while (e + 1 < ndesc && (int)blockIdx.x >= desc[e + 1].tile_start) ++e;
-    const ShadowDesc d = desc[e];
-    const int tile = blockIdx.x - d.tile_start, tc = (d.K + 31) / 32;
-    const int r0 = (tile / tc) * 32, c0 = (tile % tc) * 32;
-    const float* x = P + d.src;
-    bf16* k16 = ptrs[2 * e]; bf16* t16 = ptrs[2 * e + 1];
-    __shared__ float t[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int k = ty; k < 32; k += 8) {
-        const bool ok = r0 + k < d.N && c0 + tx < d.K;
-        const float v = ok ? x[(long)(r0 + k) * d.K + c0 + tx] : 0.f;
-        t[k][tx] = v;
-        if (ok) k16[(long)(r0 + k) * d.K + c0 + tx] = (bf16)v;
+// every operand shadow of the model, one job list, one launch (see kernels.h)
+constexpr int SH_TILE = 64;
+__global__ __launch_bounds__(256) void all_shadows_kernel(const float* __restrict__ P, const ShadowJobs jobs) {
+    int lo = 0, hi = jobs.n - 1;                                  // last job whose tile_start <= blockIdx.x (uniform: scalar ALU)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)blockIdx.x >= jobs.d[mid].tile_start) lo = mid; else hi = mid - 1;
     }
-    __syncthreads();
-    for (int k = ty; k < 32; k += 8)
-        if (c0 + k < d.K && r0 + tx < d.N) t16[(long)(c0 + k) * d.Np + r0 + tx] = (bf16)t[tx][k];
+    const int e = lo;
+    const ShadowDesc& d = jobs.d[e];
+    const int blk = blockIdx.x - d.tile_start;
+    const float* x = P + d.src;
+    bf16* p0 = jobs.p[2 * e]; bf16* p1 = jobs.p[2 * e + 1];
+    if (d.type == SH_LINEAR) {
+        const int tc = (d.K + SH_TILE - 1) / SH_TILE;
+        const int r0 = (blk / tc) * SH_TILE, c0 = (blk % tc) * SH_TILE;
+        __shared__ float t[SH_TILE][SH_TILE + 1];
+        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 4 rows per pass, 64 consecutive columns per row
+        for (int k = ty; k < SH_TILE; k += 4) {
+            const bool ok = r0 + k < d.N && c0 + tx < d.K;
+            const float v = ok ? x[(long)(r0 + k) * d.K + c0 + tx] : 0.f;
+            t[k][tx] = v;
+            if (ok) p0[(long)(r0 + k) * d.K + c0 + tx] = (bf16)v;
+        }
+        __syncthreads();
+        for (int k = ty; k < SH_TILE; k += 4)
+            if (c0 + k < d.K && r0 + tx < d.N) p1[(long)(c0 + k) * d.ldt + r0 + tx] = (bf16)t[tx][k];
+    } else if (d.type == SH_CONV) {
+        const int CO = d.N, CI = d.K, n = CO * CI * 9;
+        const int i = blk * 256 + threadIdx.x;
+        if (i >= n) return;
+        const int tap = i % 9, ci = (i / 9) % CI, co = i / (9 * CI);
+        const bf16 v = (bf16)x[i];
+        p0[(long)co * 9 * CI + tap * CI + ci] = v;                        // forward: out[co] += in[p+off(tap)][ci] * w
+        p1[(long)ci * 9 * CO + (8 - tap) * CO + co] = v;                  // dgrad: din[ci] += dy[p-off(tap)][co] * w
+    } else if (d.type == SH_VGG2ENC) {
+        const int E = d.N, C = d.a0, Dp = d.a1, F = C * Dp;
+        const long i = (long)blk * 256 + threadIdx.x;
+        if (i >= (long)E * F) return;
+        const int f = (int)(i % F), en = (int)(i / F);
+        const int c = f / Dp, dd = f % Dp;                                   // reference feature index c*Dp + d
+        const int fn = dd * C + c;                                           // NHWC feature index
+        const bf16 v = (bf16)x[i];
+        p0[(long)en * F + fn] = v;
+        p1[(long)fn * E + en] = v;
+    } else {
+        const int i = blk * 256 + threadIdx.x;
+        if (i < d.N) reinterpret_cast<float*>(p0)[i] = x[i];
+    }
 }
 
 inline unsigned flat_blocks(long n) {
@@ -245,18 +261,22 @@ int mk_split_reduce(float* G, const float* slab, int nslab, long stride, const l
     hipLaunchKernelGGL(split_reduce_kernel, dim3(nranges), dim3(256), 0, s, G, slab, nslab, stride, ranges);
     return LAUNCH_OK();
 }
-int mk_linear_shadows(const float* P, const ShadowDesc* desc, bf16* const* ptrs, int ndesc, int total_tiles, hipStream_t s) {
-    hipLaunchKernelGGL(linear_shadows_kernel, dim3(total_tiles), dim3(256), 0, s, P, desc, ptrs, ndesc);
+int mk_shadow_blocks(const ShadowDesc& d) {
+    switch (d.type) {
+        case SH_LINEAR: return ((d.N + SH_TILE - 1) / SH_TILE) * ((d.K + SH_TILE - 1) / SH_TILE);
+        case SH_CONV: return (d.N * d.K * 9 + 255) / 256;
+        case SH_VGG2ENC: return (int)(((long)d.N * d.a0 * d.a1 + 255) / 256);
+        default: return (d.N + 255) / 256;
+    }
+}
+int mk_all_shadows(const float* P, const ShadowJobs& jobs, hipStream_t s) {
+    if (jobs.n <= 0) return 0;
+    hipLaunchKernelGGL(all_shadows_kernel, dim3(jobs.blocks), dim3(256), 0, s, P, jobs);
     return LAUNCH_OK();
 }
 int mk_conv_weight_shadows(const float* w, bf16* wk, bf16* wd, int CO, int CI, hipStream_t s) {
     const int n = CO * CI * 9;
     hipLaunchKernelGGL(conv_shadow_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, wk, wd, CO, CI);
-    return LAUNCH_OK();
-}
-int mk_vgg2enc_shadows(const float* w, bf16* wk, bf16* wt, int E, int C, int Dp, hipStream_t s) {
-    const long n = (long)E * C * Dp;
-    hipLaunchKernelGGL(vgg2enc_shadow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, wk, wt, E, C, Dp);
     return LAUNCH_OK();
 }
 int mk_vgg2enc_grad_unpermute(const float* g, float* dw, int E, int C, int Dp, hipStream_t s) {

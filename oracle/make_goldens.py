@@ -276,7 +276,7 @@ def write_learnable_shard(root, accent, split, n_utt, seed, idim=83, n_class=8):
     """A toy shard a tiny model can actually learn within a few hundred steps (peaked logits -> arg-max decisions that
     survive bf16 rounding): every utterance belongs to one of `n_class` classes; a class fixes the label sequence (2..5
     tokens from U{1..365}, a seeded table shared by all shards) and the feature pattern (every frame = the class's
-    codebook vector + N(0, 0.3) noise); lengths are random (16..45 frames).  Layout: SURVEY Appendix D."""
+    codebook vector + N(0, 0.1) noise); lengths are random (16..45 frames).  Layout: SURVEY Appendix D."""
     from numpy.lib.format import open_memmap
     tab = np.random.RandomState(4242)
     code = (tab.randn(n_class, idim) * 1.5).astype(np.float32)
@@ -290,7 +290,7 @@ def write_learnable_shard(root, accent, split, n_utt, seed, idim=83, n_class=8):
     feat = open_memmap(d / "feat.dat", mode="w+", dtype=np.float32, shape=(int(ilens.sum()), idim))
     row = 0
     for c, n in zip(cls, ilens):
-        feat[row:row + n] = code[c] + 0.3 * rng.randn(n, idim).astype(np.float32)
+        feat[row:row + n] = code[c] + 0.1 * rng.randn(n, idim).astype(np.float32)
         row += n
     feat.flush()
     del feat
@@ -531,9 +531,9 @@ def chain_workspace(root, spm_dir):
     for ai, (_, a) in enumerate(CFG3_ACCENTS):
         write_learnable_shard(root / "data", a, "train", 32, seed=600 + ai)
         write_learnable_shard(root / "data", a, "dev", 4, seed=700 + ai)
-    write_learnable_shard(root / "data", "canada", "train", 96, seed=801)
-    write_learnable_shard(root / "data", "canada", "dev", 8, seed=802)
-    write_learnable_shard(root / "data", "canada", "test", 12, seed=803)
+    write_learnable_shard(root / "data", "canada", "train", 96, seed=801, n_class=2)
+    write_learnable_shard(root / "data", "canada", "dev", 8, seed=802, n_class=2)
+    write_learnable_shard(root / "data", "canada", "test", 12, seed=803, n_class=2)
     base = {"data_root": "data", "spm_mapping": "data/toy_spm_units.txt", "spm_model": "data/toy_spm.model", "dev_max_ilen": 3000,
             "min_ilen": 10, "max_ilen": 60, "half_batch_ilen": 100}
     pre_model = dict(TINY)
@@ -544,7 +544,7 @@ def chain_workspace(root, spm_dir):
     ft_model = {k: v for k, v in TINY.items() if k not in ("inner_optimizer_cls", "inner_optimizer_opt", "meta_opt_cls", "meta")}
     ft_model.update({"optimizer_cls": "noam", "optimizer_opt": {"k": 0.5, "warmup_steps": 50}})
     ft = {"asr_model": ft_model,
-          "solver": dict(base, setting="chain-ft", total_epochs=70, label_smoothing=0.1, eval_ival=100, log_ival=1000, batch_size=8,
+          "solver": dict(base, setting="chain-ft", total_epochs=20, label_smoothing=0.1, eval_ival=50, log_ival=1000, batch_size=8,
                          dev_batch_size=8, pretrain_module=["feat_extractor", "vgg2enc", "char_trans", "pre_embed", "encoder", "decoder"],
                          freeze_module=["feat_extractor"], beam_decode={"beam_size": 1})}
     return pre, ft
@@ -569,7 +569,7 @@ def chain_paras(stage, **extra):
 
 def gen_chain_goldens():
     """BASELINE configs[4] chain on toy data, run by the REFERENCE: pretrain.py --algo fomaml (4 accents) -> snapshot.step.4
-    -> train.py fine-tune on the target accent (pretrain_module / freeze_module, Noam-Adam, 70 epochs, evaluate() every 100
+    -> train.py fine-tune on the target accent (pretrain_module / freeze_module, Noam-Adam, 20 epochs, evaluate() every 50
     steps) -> train.py --test (Tester, greedy, batch 4) -> best-hyp.  Captured: the fine-tune's per-call losses, its dev logs
     and file set, the best-hyp lines."""
     from functools import partial

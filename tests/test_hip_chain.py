@@ -1,7 +1,7 @@
 """BASELINE configs[4] in miniature, through the drop-in CLIs on the GPU:
 
     pretrain.py --algo fomaml (4 accents)  ->  testing-logs/pretrain/.../snapshot.step.4
-    train.py --pretrain ... (fine-tune on the target accent: pretrain_module / freeze_module, Noam-Adam, evaluate() every 100 steps)
+    train.py --pretrain ... (fine-tune on the target accent: pretrain_module / freeze_module, Noam-Adam, evaluate() every 50 steps)
     train.py --test (greedy decode of the test shard with model.wer.best)  ->  best-hyp  ->  CER / WER
 
 and compared with the SAME chain run by the reference (tests/golden/chain_toy.npz, oracle/make_goldens.py::gen_chain_goldens):
@@ -94,11 +94,13 @@ def test_chain_fomaml_matches_reference_chain(golden_dir, tmp_path, monkeypatch)
     da, ra = _log(ft_dir / "dev_acc"), _glog(g, "ft/log/dev_acc")
     assert [s for s, _ in dl] == [s for s, _ in rl]
     assert abs(dl[0][1] - rl[0][1]) <= 1e-3 * rl[0][1]                    # evaluation of the loaded snapshot, before any step
-    assert abs(dl[1][1] - rl[1][1]) <= 5e-2 * rl[1][1]                    # after 100 Noam-Adam steps (sign-like updates amplify bf16 gradient noise)
-    print("fine-tune dev_loss ours/ref:", [(s, round(a, 3), round(b, 3)) for (s, a), (_, b) in zip(dl, rl)][:8], "...")
-    print("fine-tune dev_acc  ours/ref:", [(s, round(a, 3), round(b, 3)) for (s, a), (_, b) in zip(da, ra)][-6:])
-    # both converge (median: a late Noam-Adam step can knock one evaluation off its plateau in either run)
-    assert np.median([a for _, a in da[-5:]]) >= 0.97 and np.median([b for _, b in ra[-5:]]) >= 0.97
+    print("fine-tune dev_loss ours/ref:", [(s, round(a, 4), round(b, 4)) for (s, a), (_, b) in zip(dl, rl)])
+    print("fine-tune dev_acc  ours/ref:", [(s, round(a, 3), round(b, 3)) for (s, a), (_, b) in zip(da, ra)])
+    # the target accent is a two-class toy: both runs reach accuracy 1 within the first hundreds of Noam-Adam steps and then sit
+    # on the label-smoothing floor of the loss -- an end point that does not depend on the (chaotic) path taken to it
+    assert all(a == 1.0 for _, a in da[-4:]) and all(b == 1.0 for _, b in ra[-4:])
+    for (_, a), (_, b) in zip(dl[-4:], rl[-4:]):
+        assert abs(a - b) <= 5e-3 * b, (a, b)
     best_o, best_r = _log(ft_dir / "best_wer")[0], _glog(g, "ft/log/best_wer")[0]
     assert best_o[1] == best_r[1] == 0.0
     sd = torch.load(ft_dir / "snapshot.latest")
@@ -146,5 +148,5 @@ def test_chain_reptile_fix_runs_and_converges(golden_dir, tmp_path, monkeypatch)
     pre_dir, ft_dir, lines = run_chain(tmp_path, golden_dir, "reptile", extra=("--fix_reptile",))
     da = _log(ft_dir / "dev_acc")
     print("reptile chain dev_acc:", da[-4:], "token error rate", corpus_er(lines))
-    assert np.median([a for _, a in da[-5:]]) >= 0.95
+    assert np.median([a for _, a in da[-5:]]) >= 0.99
     assert corpus_er(lines) <= 10.0
