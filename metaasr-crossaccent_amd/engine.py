@@ -167,7 +167,8 @@ class MasrEngine:
     def read_stats(self):
         out = (C.c_float * 4)()
         check(self._l.masr_read_stats(self.h, out, self.stream()), "masr_read_stats")
-        return {"loss": float(out[0]), "n_correct": float(out[1]), "n_total": float(out[2]), "grad_norm": float(out[3])}
+        self._last_stats = {"loss": float(out[0]), "n_correct": float(out[1]), "n_total": float(out[2]), "grad_norm": float(out[3])}
+        return self._last_stats
 
     def last_logits(self):
         """[B, L, odim] fp32 view of the last forward's logits and gold [B, L] (int32, -1 = pad)."""

@@ -131,20 +131,17 @@ class FOMetaASRInterface(PretrainInterface):
         """one task = run_task + val-batch gradient + clip, entirely on the slot's stream (host thread body)"""
         with torch.cuda.stream(slot['stream']):
             self.run_task(tr_batches, engine=slot['engine'])
-            info = self._train(val_batch[0], *val_batch[1], accent_idx=val_batch[0], engine=slot['engine'])
-            grad_norm = self.clip_grad_norm_(GRAD_CLIP, engine=slot['engine'])
+            info = self._train(val_batch[0], *val_batch[1], accent_idx=val_batch[0], engine=slot['engine'], want_info=False)
+            grad_norm = self.clip_grad_norm_(GRAD_CLIP, engine=slot['engine'])       # the task's ONE host sync: loss, counts, norm
+            if info is None:
+                info = self.info_from_stats(slot['engine'])
         out[i] = (info, grad_norm)
 
     def _run_tasks_concurrently(self, task_ids):
+        # (task_ids: the drawn tasks of this rank, see _draw_meta_batch)
         """tasks_per_gpu > 1: batches are drawn on the main thread in the reference's order (the samplers share RNG
         streams), then waves of K tasks run concurrently; gradients are accumulated in task order -> deterministic."""
-        fetched = []
-        for pos, accent_id in enumerate(task_ids):
-            own = self.sharder.owns(pos)
-            tr = self.data_container.get_item(accent_id, self.meta_k, materialize=own)
-            val = self.data_container.get_item(accent_id, materialize=own)[0]
-            if own:
-                fetched.append((accent_id, tr, val))
+        fetched = [(a, [(i, f.result()) for i, f in tr], (val[0], val[1].result())) for a, tr, val in task_ids]
         main = torch.cuda.current_stream()
         K = self.tasks_per_gpu
         for w0 in range(0, len(fetched), K):
@@ -170,31 +167,51 @@ class FOMetaASRInterface(PretrainInterface):
                 self.asr_model = sl['model']                         # quirk Q1/Q2: the LAST task's adapted weights are "the model"
         return len(fetched)
 
+    def _draw_meta_batch(self, meta_batch):
+        """Batch INDICES of every task of the meta-step, drawn in the reference's order (per task: k inner batches, then the
+        val batch -- nothing else consumes the RNG streams in between, :139-145); the batches of this rank's tasks are
+        assembled by the collate pool while earlier tasks already run on the GPU.  Tasks of other ranks are drawn index-only:
+        that advances their samplers and the shared RNG streams exactly as their owner does, so every rank sees the data order
+        of the single-process run whichever rank an accent lands on next."""
+        out = []
+        for pos, accent_id in enumerate(meta_batch):
+            mode = 'async' if self.sharder.owns(pos) else False
+            tr = self.data_container.get_item(accent_id, self.meta_k, materialize=mode)
+            val = self.data_container.get_item(accent_id, materialize=mode)[0]
+            if mode:
+                out.append((accent_id, tr, val))
+        return out
+
+    def _shuffle_and_draw(self, task_ids):
+        self._task_rng.shuffle(task_ids)                                          # :136
+        meta_batch = list(task_ids[:self.meta_batch_size])
+        return meta_batch, self._draw_meta_batch(meta_batch)
+
     # ------------------------------------------------------------------ the outer loop (:128-177)
     def train(self):
         task_ids = list(range(self.num_pretrain))
+        nxt = None
         try:
             while self.global_step < self.max_step:
-                for _ in range(self.eval_ival):
-                    self._task_rng.shuffle(task_ids)
+                for it in range(self.eval_ival):
+                    meta_batch, drawn = nxt if nxt is not None else self._shuffle_and_draw(task_ids)
+                    # look-ahead: the NEXT meta-step's task order and batch indices are drawn now (same RNG order as drawing
+                    # them after this step: nothing in between consumes `random` / `np.random`), so that its batches are
+                    # assembled in pinned memory by the collate pool while this step runs on the GPU.  Bucketed loaders only:
+                    # a RandomSampler also reads the torch stream, which evaluate()'s dev loaders touch in between.
+                    more = it + 1 < self.eval_ival or self.global_step + 1 < self.max_step
+                    nxt = self._shuffle_and_draw(task_ids) if (more and self.is_bucket and self.data_container.pool is not None) else None
                     n_local = 0
-                    meta_batch = task_ids[:self.meta_batch_size]
                     if self.tasks_per_gpu > 1:
-                        n_local = self._run_tasks_concurrently(meta_batch)
-                    for pos, accent_id in (enumerate(meta_batch) if self.tasks_per_gpu == 1 else []):
-                        if not self.sharder.owns(pos):
-                            # another rank's task: advance this accent's sampler and the shared RNG streams exactly as
-                            # the owner does (indices only, no feature row is read), so that every rank sees the data
-                            # order of the single-process run whichever rank an accent lands on next
-                            self.data_container.get_item(accent_id, self.meta_k, materialize=False)
-                            self.data_container.get_item(accent_id, materialize=False)
-                            continue
-                        tr_batches = self.data_container.get_item(accent_id, self.meta_k)
-                        self.run_task(tr_batches)
-                        val_batch = self.data_container.get_item(accent_id)[0]
+                        n_local = self._run_tasks_concurrently(drawn)
+                    for accent_id, tr, val in (drawn if self.tasks_per_gpu == 1 else []):
+                        self.run_task([(i, f.result()) for i, f in tr])
+                        val_batch = (val[0], val[1].result())
                         batch_size = len(val_batch[1][2])
-                        info = self._train(val_batch[0], *val_batch[1], accent_idx=val_batch[0])
-                        grad_norm = self.clip_grad_norm_(GRAD_CLIP)
+                        info = self._train(val_batch[0], *val_batch[1], accent_idx=val_batch[0], want_info=False)
+                        grad_norm = self.clip_grad_norm_(GRAD_CLIP)                     # the task's ONE host sync: loss, counts, norm
+                        if info is None:
+                            info = self.info_from_stats()
                         if math.isnan(grad_norm):
                             logger.warning(f"grad norm NaN @ step {self.global_step} on {self.accents[accent_id]}, ignore...")
                         self._partial_meta_update()
@@ -290,10 +307,12 @@ class FOMetaASRInterface(PretrainInterface):
         if engine is None:
             self.asr_opt = opt
         for idx, (x, ilens, ys, olens) in batches:
+            # the reference discards the info of the inner steps (:240): no host sync for it here, the next launches queue
+            # behind this batch while it runs
             if engine is None:
-                self._train(idx, x, ilens, ys, olens)
+                self._train(idx, x, ilens, ys, olens, want_info=False)
             else:
-                self._train(idx, x, ilens, ys, olens, engine=engine)
+                self._train(idx, x, ilens, ys, olens, engine=engine, want_info=False)
             opt.clip_and_step(GRAD_CLIP)                                  # clip 5; NaN norm -> step skipped on the device
 
     # ------------------------------------------------------------------ evaluation (:253-298)

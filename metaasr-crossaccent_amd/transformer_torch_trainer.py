@@ -48,13 +48,16 @@ def get_trainer(cls, config, paras, id2accent):
         def exec(self):
             self.train()
 
-        def run_batch(self, cur_b, x, ilens, ys, olens, train, accent_idx=None, engine=None):
+        def run_batch(self, cur_b, x, ilens, ys, olens, train, accent_idx=None, engine=None, want_info=True):
             """forward + label-smoothed CE + (train) backward, gradients left in engine.grads
             (reference :59-99).  One host sync (read_stats) instead of the reference's three .item() calls.
-            `engine` selects a task slot's replica (concurrent tasks per GPU); default = self.asr_model."""
+            `engine` selects a task slot's replica (concurrent tasks per GPU); default = self.asr_model.
+            want_info=False (callers that discard the returned dict, i.e. the inner steps of run_task): no host sync at all."""
             eng = engine if engine is not None else self.asr_model.engine
             eng.run_batch(x, ilens, ys, olens, train=train)
             olens += 1                                                        # quirk Q6 (mono_transformer_torch.py:139)
+            if not want_info and not (train and self.global_step % 500 == 0 and engine is None):
+                return None
             st = eng.read_stats()
             info = {'loss': st['loss'], 'acc': st['n_correct'] / st['n_total']}
             if train:
@@ -66,6 +69,12 @@ def get_trainer(cls, config, paras, id2accent):
                 info['cer'] = self.metric_observer.batch_cal_er(pred, gold, ['att'], ['cer'])['att_cer']
                 info['wer'] = self.metric_observer.batch_cal_er(pred, gold, ['att'], ['wer'])['att_wer']
             return info
+
+        def info_from_stats(self, engine=None):
+            """{'loss', 'acc'} of the last run_batch from the stats the last host sync brought back (clip_grad_norm_ reads the
+            loss, the token counts and the gradient norm in ONE copy): run_batch(want_info=False) + clip + this = one sync"""
+            st = (engine if engine is not None else self.asr_model.engine)._last_stats
+            return {'loss': st['loss'], 'acc': st['n_correct'] / st['n_total']}
 
         def opt_step(self):
             """asr_opt.step() with the engine's flat gradient attached (torch optimisers read p.grad implicitly)"""

@@ -19,6 +19,7 @@ import yaml
 
 import masr_amd  # noqa: F401
 from masr_amd.marcos import AVAIL_ACCENTS
+from masr_amd.utils import setup_host_threads, usable_cpus
 from masr_amd.parallel import TaskSharder
 
 
@@ -61,7 +62,8 @@ def main(argv=None):
     mbs = paras.num_pretrain if paras.meta_batch_size is None else paras.meta_batch_size
     assert mbs <= paras.num_pretrain, f"Meta batch size {mbs} > Number of pretraining accents {paras.num_pretrain}"
     paras.meta_batch_size = mbs
-    paras.njobs = paras.njobs if paras.njobs > 0 else len(os.sched_getaffinity(0))
+    paras.njobs = paras.njobs if paras.njobs > 0 else usable_cpus()
+    setup_host_threads(paras.njobs)
     config = yaml.safe_load(open(paras.config))
 
     TaskSharder.init_process_group()

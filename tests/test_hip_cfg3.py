@@ -30,7 +30,9 @@ from replay import oracle_fomaml_run  # noqa: E402
 
 def product_run(tmp_path, golden_dir, meta_k, tasks_per_gpu=1):
     cfg = cfg3_workspace(tmp_path, golden_dir)
-    paras = cfg3_paras(meta_k, device="cuda:0", tasks_per_gpu=tasks_per_gpu, cuda=True, no_cuda=False)
+    # njobs 2: batches are assembled by the collate pool and the next meta-step is drawn ahead -- the golden's call order and
+    # batch contents below prove that this changes neither the RNG consumption nor the data
+    paras = cfg3_paras(meta_k, device="cuda:0", tasks_per_gpu=tasks_per_gpu, cuda=True, no_cuda=False, njobs=2)
     random.seed(531); np.random.seed(531); torch.manual_seed(531)
     solver = get_trainer(FOMetaASRInterface, cfg, paras, dict(CFG3_ACCENTS + [("ca", "canada")]))
     solver.load_data()
@@ -42,6 +44,7 @@ def product_run(tmp_path, golden_dir, meta_k, tasks_per_gpu=1):
 
     def spy(idx, x, ilens, ys, olens, train, accent_idx=None, **kw):
         rec = (int(idx), bool(train), ilens.clone(), [y.clone() for y in ys])
+        kw["want_info"] = True                                   # (run_task skips the host sync of its inner steps; the check wants every loss)
         info = orig(idx, x, ilens, ys, olens, train=train, accent_idx=accent_idx, **kw)
         calls.append(rec + (dict(info),))
         return info

@@ -57,7 +57,7 @@ def test_fomaml_run_matches_reference_golden(golden_dir, tmp_path, monkeypatch):
     rec = []
     orig = solver.run_batch
 
-    def spy(idx, x, ilens, ys, olens, train, accent_idx=None):
+    def spy(idx, x, ilens, ys, olens, train, accent_idx=None, **kw):
         info = orig(idx, x, ilens, ys, olens, train=train, accent_idx=accent_idx)
         rec.append((int(idx), ilens.clone(), [y.clone() for y in ys], dict(info)))
         return info
@@ -127,7 +127,7 @@ def test_reptile_behind_fix_flag_matches_oracle(tmp_path, monkeypatch):
     rec = []
     orig = solver.run_batch
 
-    def spy(idx, x, ilens, ys, olens, train, accent_idx=None):
+    def spy(idx, x, ilens, ys, olens, train, accent_idx=None, **kw):
         batch = (x.clone().cpu(), ilens.clone(), [y.clone() for y in ys], olens.clone())
         info = orig(idx, x, ilens, ys, olens, train=train, accent_idx=accent_idx)
         rec.append((batch, dict(info)))

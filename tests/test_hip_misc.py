@@ -179,7 +179,7 @@ def test_multi_run_matches_reference_golden(golden_dir, tmp_path, monkeypatch):
     rec = []
     orig = s.run_batch
 
-    def spy(idx, x, ilens, ys, olens, train, accent_idx=None):
+    def spy(idx, x, ilens, ys, olens, train, accent_idx=None, **kw):
         info = orig(idx, x, ilens, ys, olens, train=train, accent_idx=accent_idx)
         rec.append((int(idx), ilens.clone(), [y.clone() for y in ys], dict(info)))
         return info
@@ -259,7 +259,7 @@ def test_mono_finetune_matches_reference_golden(golden_dir, tmp_path, monkeypatc
     rec = []
     orig = s.run_batch
 
-    def spy(idx, x, ilens, ys, olens, train, accent_idx=None):
+    def spy(idx, x, ilens, ys, olens, train, accent_idx=None, **kw):
         info = orig(idx, x, ilens, ys, olens, train=train, accent_idx=accent_idx)
         rec.append((int(idx), ilens.clone(), [y.clone() for y in ys], dict(info)))
         return info

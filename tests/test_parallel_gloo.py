@@ -93,7 +93,7 @@ def make_solver(sharder, num_tasks, meta_batch):
     s._task_rng = random.Random(531)
     from functools import partial
 
-    def run_batch(idx, x, ilens, ys, olens, train, accent_idx=None):
+    def run_batch(idx, x, ilens, ys, olens, train, accent_idx=None, **kw):
         eng.run_batch(x, ilens, ys, olens, train)
         return {"loss": 0.0, "acc": 0.0}
     s._train = partial(run_batch, train=True)

@@ -105,7 +105,7 @@ def get_cpu_trainer(cls, config, paras, id2accent, log):
         def exec(self):
             self.train()
 
-        def run_batch(self, cur_b, x, ilens, ys, olens, train, accent_idx=None, engine=None):
+        def run_batch(self, cur_b, x, ilens, ys, olens, train, accent_idx=None, engine=None, want_info=True):
             eng = self.asr_model.engine
             eng.run_batch(x, ilens, ys, olens, train)
             olens += 1
@@ -153,7 +153,7 @@ def run(root, algo, world, rank, fix_snapshot=False, meta_batch=3, steps=5):
                       "min_ilen": 10, "max_ilen": 50, "dev_max_ilen": 3000, "half_batch_ilen": 30}}
     paras = SimpleNamespace(pretrain_suffix=f"w{world}", pretrain_accents=["af", "au", "en", "us"], num_pretrain=4, tgt_accent="ca", runs=0,
                             overwrite=True, seed=531, meta_k=2, meta_batch_size=meta_batch, sample_strategy="normal", max_step=steps,
-                            resume=False, model_name="transformer", algo=algo, njobs=0, is_bucket=True, is_memmap=True,
+                            resume=False, model_name="transformer", algo=algo, njobs=2 if world > 1 else 0, is_bucket=True, is_memmap=True,
                             use_tensorboard=False, fix_snapshot_meta_weights=fix_snapshot, tasks_per_gpu=1)
     random.seed(531); np.random.seed(531); torch.manual_seed(531)
     if algo == "fomaml":

@@ -1,12 +1,14 @@
 # One measurement pass for profiles/: default bench line, kernel-trace stats (default and single task), HBM-traffic PMC passes.
-# Run on the GPU box from the repo root: bash tools/measure_round.sh ; then python tools/save_profiles.py rNN here.
+# Run on the GPU box from the repo root: bash tools/measure_round.sh ; then here: python tools/save_profiles.py rNN && python tools/pmc_traffic.py rNN <sha>
 set -e
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 O=gpurun_out
-python3 bench.py > $O/bench_default.json 2> $O/bench_default.err && echo "bench done" && tail -c 600 $O/bench_default.json
+python3 bench.py > $O/bench_default.json 2> $O/bench_default.err && echo "bench done" && tail -c 400 $O/bench_default.json
 rm -rf $O/prof_k4 $O/prof_single $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
-rocprofv3 --kernel-trace --stats -d $O/prof_k4 -o k4 --output-format csv -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-profile > $O/prof_k4.log 2>&1 && echo "k4 profile done"
-rocprofv3 --kernel-trace --stats -d $O/prof_single -o s --output-format csv -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-profile --tasks-per-gpu 1 > $O/prof_single.log 2>&1 && echo "single profile done"
+Q="--no-cpu-baseline --no-profile --no-meta-step --long-seconds 0"
+rocprofv3 --kernel-trace --stats -d $O/prof_k4 -o k4 --output-format csv -- python3 bench.py --steps 30 --warmup 5 $Q > $O/prof_k4.log 2>&1 && echo "k4 profile done"
+rocprofv3 --kernel-trace --stats -d $O/prof_single -o s --output-format csv -- python3 bench.py --steps 30 --warmup 5 $Q --tasks-per-gpu 1 > $O/prof_single.log 2>&1 && echo "single profile done"
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace -d $O/pmc_$C -o p --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --tasks-per-gpu 1 > $O/pmc_$C.log 2>&1 && echo "pmc $C done"
+  rocprofv3 --pmc $C --kernel-trace -d $O/pmc_$C -o p --output-format csv -- python3 bench.py --steps 3 --warmup 2 $Q --tasks-per-gpu 1 > $O/pmc_$C.log 2>&1 && echo "pmc $C done"
 done
+find $O/prof_k4 $O/prof_single -name "*kernel_trace.csv" -delete      # (the per-dispatch traces are large; the stats files are what is kept)

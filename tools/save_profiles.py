@@ -25,12 +25,15 @@ def summary(src, steps, header, dst):
 line = open(g / "bench_default.json").read().strip().splitlines()[-1]
 json.loads(line)
 (out / f"{tag}_bench.json").write_text(line + "\n")
-shutil.copy(g / "prof_k4/k4_kernel_stats.csv", out / f"{tag}_bench_kernel_stats.csv")
-shutil.copy(g / "prof_single/s_kernel_stats.csv", out / f"{tag}_single_task_kernel_stats.csv")
-summary(g / "prof_k4/k4_kernel_stats.csv", 35 * 4 + 15,
-        "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-profile  (MI355X, default = 4 concurrent tasks; + the 10+5-step single-task leg)",
+import glob
+k4 = glob.glob(str(g / "prof_k4/**/*kernel_stats.csv"), recursive=True)[0]
+sg = glob.glob(str(g / "prof_single/**/*kernel_stats.csv"), recursive=True)[0]
+shutil.copy(k4, out / f"{tag}_bench_kernel_stats.csv")
+shutil.copy(sg, out / f"{tag}_single_task_kernel_stats.csv")
+summary(k4, 35 * 4 + 15,
+        "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-profile --no-meta-step --long-seconds 0  (MI355X, default = 4 concurrent tasks; + the 10+5-step single-task leg)",
         out / f"{tag}_bench_kernel_stats.txt")
-summary(g / "prof_single/s_kernel_stats.csv", 35,
-        "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-profile --tasks-per-gpu 1  (MI355X, one task per GPU)",
+summary(sg, 35,
+        "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --tasks-per-gpu 1  (MI355X, one task per GPU)",
         out / f"{tag}_single_task_kernel_stats.txt")
 print("saved")

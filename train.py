@@ -13,6 +13,7 @@ import yaml
 
 import masr_amd  # noqa: F401
 from masr_amd.marcos import AVAIL_ACCENTS
+from masr_amd.utils import setup_host_threads, usable_cpus
 
 
 def build_parser():
@@ -54,7 +55,8 @@ def build_parser():
 def main(argv=None):
     paras = build_parser().parse_args(argv)
     paras.cuda, paras.is_bucket, paras.is_memmap = not paras.no_cuda, not paras.no_bucket, not paras.no_memmap
-    paras.njobs = paras.njobs if paras.njobs > 0 else len(os.sched_getaffinity(0))
+    paras.njobs = paras.njobs if paras.njobs > 0 else usable_cpus()
+    setup_host_threads(paras.njobs)
     paras.eval_suffix = paras.eval_suffix or "default"
     paras.device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
     paras.hbm_shards_device = paras.device if paras.hbm_shards else None
