@@ -194,6 +194,13 @@ int masr_profile_read(masr_model* m, float* ms, int* launches);
 /* standalone kernel entry points used by the parity tests (bf16 passed as uint16_t bit patterns) */
 int masr_test_gemm(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int K, int reduction_major,
                    const float* bias, int relu, float* C32, int64_t ldc, void* stream);
+/* dropout (torch nn.Dropout inside nn.Transformer*Layer / PositionalEncoding, mono_transformer_torch.py:30-32,74-98): the keep-scale
+ * (0 or 1/(1-p)) of element i at a site; the GEMM epilogue and the attention-probability sites with their dropout switched on */
+int masr_test_dropout_mask(uint32_t seed, uint32_t site, int64_t n, float p, float* out, void* stream);
+int masr_test_gemm_dropout(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int K, float drop_p,
+                           uint32_t seed, uint32_t site, float* C32, int64_t ldc, void* stream);
+int masr_test_attention_dropout(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* lse, int B, int H,
+                                int Tq, int Tk, int hd, float drop_p, uint32_t seed, uint32_t site, void* stream);
 int masr_test_conv3x3(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, uint16_t* out,
                       int B, int H, int W, int CIN, int COUT, void* stream);
 /* dgrad/fused-pool flavours of the same kernel: mask (optional, same shape as out) zeroes outputs where mask <= 0;

@@ -29,6 +29,10 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
     float* wlse = work + (long)B * T * Spad + (long)b * T;        // [T]
     __shared__ float row[2][MAXS];
     __shared__ float acc[4096];
+    __shared__ float post[MAXS];                                  // state posteriors of the current frame
+    __shared__ float red[256];
+    __shared__ short nxt_same[MAXS / 2];                          // label i -> next position with the same label (or -1)
+    __shared__ unsigned char is_first[MAXS / 2];                  // label i is the first occurrence of its class
     __shared__ float s_ll;
 
     // zero the gradient of this utterance (frames >= Tb stay zero)
@@ -44,6 +48,17 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
         for (int c = lane; c < C; c += 64) se += __expf(z[c] - mx);
         se = wave_sum(se);
         if (lane == 0) wlse[t] = mx + __logf(se);
+    }
+    // class ownership for the posterior sums: every class is summed by ONE thread in a fixed order (the first occurrence of
+    // a label walks the chain of its repeats; blanks are folded by a fixed tree), so the gradient is bit-reproducible --
+    // LDS float atomics made it depend on the order in which the lanes arrived
+    for (int i = tid; i < Lb; i += 256) {
+        const int v = tg[i];
+        int nx = -1;
+        for (int j = i + 1; j < Lb; ++j) if (tg[j] == v) { nx = j; break; }
+        bool first = true;
+        for (int j = 0; j < i; ++j) if (tg[j] == v) { first = false; break; }
+        nxt_same[i] = (short)nx; is_first[i] = first ? 1 : 0;
     }
     __syncthreads();
     auto ext = [&](int s) { return (s & 1) ? tg[s >> 1] : blank; };
@@ -101,8 +116,24 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
             }
             cur[s] = bta;
             const float al = walpha[(long)t * Spad + s];
-            if (al != NINF && bta != NINF) atomicAdd(&acc[ext(s)], __expf(al + bta - lp(t, s) - ll));
+            post[s] = (al != NINF && bta != NINF) ? __expf(al + bta - lp(t, s) - ll) : 0.f;
         }
+        __syncthreads();
+        float bsum = 0.f;                                         // blank states: even s, strided partials + fixed tree
+        for (int s = 2 * tid; s < S; s += 512) bsum += post[s];
+        red[tid] = bsum;
+        for (int i = tid; i < Lb; i += 256) {                     // label classes: the first occurrence sums its chain
+            if (!is_first[i]) continue;
+            float v = post[2 * i + 1];
+            for (int j = nxt_same[i]; j >= 0; j = nxt_same[j]) v += post[2 * j + 1];
+            acc[tg[i]] = v;
+        }
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) acc[blank] = red[0];
         __syncthreads();
         const float* z = logits + ((long)t * st_t + b * st_b) * C;
         float* g = grad + ((long)t * st_t + b * st_b) * C;

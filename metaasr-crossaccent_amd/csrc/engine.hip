@@ -1051,6 +1051,24 @@ int masr_test_gemm(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ld
     g.bias = bias; g.relu = relu; g.C32 = C32; g.ldc = ldc;
     return mk_gemm(g, (hipStream_t)stream);
 }
+int masr_test_dropout_mask(uint32_t seed, uint32_t site, int64_t n, float p, float* out, void* stream) {
+    return mk_dropout_mask(out, n, p, seed, site, (hipStream_t)stream);
+}
+int masr_test_gemm_dropout(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int K, float drop_p, uint32_t seed,
+                           uint32_t site, float* C32, int64_t ldc, void* stream) {
+    GemmArgs g = gemm_args();
+    g.A = (const bf16*)A; g.lda = lda; g.B = (const bf16*)B; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
+    g.drop_p = drop_p; g.seed = seed; g.site = site; g.C32 = C32; g.ldc = ldc;
+    return mk_gemm(g, (hipStream_t)stream);
+}
+int masr_test_attention_dropout(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* lse, int B, int H, int Tq, int Tk,
+                                int hd, float drop_p, uint32_t seed, uint32_t site, void* stream) {
+    const long E = (long)H * hd;
+    AttnArgs a{};
+    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ldq = a.ldk = a.ldv = E; a.o = (bf16*)o; a.ldo = E; a.lse = lse;
+    a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.drop_p = drop_p; a.seed = seed; a.site = site;
+    return mk_attn_fwd(a, (hipStream_t)stream);
+}
 int masr_test_conv3x3(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, uint16_t* out, int B, int H, int W, int CIN,
                       int COUT, void* stream) {
     ConvArgs a{}; a.in = (const bf16*)in; a.wk = (const bf16*)wk; a.bias = bias; a.relu = relu; a.out = (bf16*)out;

@@ -130,6 +130,8 @@ int mk_embed_bwd(const int* tok, const float* dy, float* dtable, int rows, int V
 // greedy decode: build the next decoder input from the previous step's tokens; arg-max of every logits row
 int mk_recog_build_tok(int* tok, const int* out, int B, int L, int sos, hipStream_t s);
 int mk_recog_argmax(const float* logits, long ld, int* out, int B, int L, int C, hipStream_t s);
+// out[i] = the keep-scale (0 or 1/(1-p)) every dropout site applies to element i of its tensor (parity tests)
+int mk_dropout_mask(float* out, long n, float p, uint32_t seed, uint32_t site, hipStream_t s);
 // y16 = bf16(x32 * dropout_mask)
 int mk_cast_dropout(const float* x, bf16* y, long n, float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
 // column sums of x[rows][cols] (cols % 8 == 0, ld >= cols); only the first out_cols are written

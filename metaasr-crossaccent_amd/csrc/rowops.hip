@@ -390,6 +390,14 @@ int mk_recog_argmax(const float* logits, long ld, int* out, int B, int L, int C,
     hipLaunchKernelGGL(recog_argmax_kernel, dim3((B * L + 3) / 4), dim3(256), 0, s, logits, ld, out, B, L, C);
     return LAUNCH_OK();
 }
+__global__ void dropout_mask_kernel(float* __restrict__ out, long n, float p, uint32_t seed, uint32_t site) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = dropout_scale(seed, site, (uint32_t)i, p, 1.0f / (1.0f - p));
+}
+int mk_dropout_mask(float* out, long n, float p, uint32_t seed, uint32_t site, hipStream_t s) {
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n, p, seed, site);
+    return LAUNCH_OK();
+}
 int mk_cast_dropout(const float* x, bf16* y, long n, float drop_p, uint32_t seed, uint32_t site, hipStream_t s) {
     hipLaunchKernelGGL(cast_dropout_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, s, x, y, n, drop_p, seed, site);
     return LAUNCH_OK();

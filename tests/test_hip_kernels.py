@@ -169,3 +169,57 @@ def test_attention(L, B_, H, Tq, Tk, hd, causal, masked):
     if masked:                                   # masked keys receive exactly zero gradient
         for b in range(B_):
             assert torch.all(dk[b, int(klens[b]):] == 0) and torch.all(dv[b, int(klens[b]):] == 0)
+
+
+def test_dropout_keep_rate_and_scale_per_site():
+    """nn.Dropout semantics at every site of the engine (PE dropout 1 / 100, attention probabilities, attention out-proj,
+    FFN inner, FFN out: sites 1.. and 100.. in csrc/engine.hip): an element is kept with probability 1 - p and scaled by
+    1/(1-p); masks of different sites, seeds and elements are independent.  The mask is a stateless hash of (seed, site,
+    index): checked through the hash itself, through the GEMM epilogue and through the attention-probability path."""
+    L = _cabi.lib()
+    P = lambda t: C.c_void_p(t.data_ptr())
+    S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    n = 1 << 20
+    masks = {}
+    for p in (0.1, 0.2):
+        for site in (1, 2, 3, 4, 5, 100, 101, 106, 125):
+            out = torch.empty(n, device="cuda")
+            _cabi.check(L.masr_test_dropout_mask(1234, site, n, p, P(out), S()))
+            vals = torch.unique(out)
+            assert len(vals) == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1.0 / (1.0 - p)) < 1e-6
+            keep = float((out > 0).float().mean())
+            assert abs(keep - (1.0 - p)) < 4 * (p * (1 - p) / n) ** 0.5 + 1e-4, (site, p, keep)          # 4 sigma
+            assert abs(float(out.mean()) - 1.0) < 2e-3                                                  # mean-preserving
+            masks[(p, site)] = out > 0
+    a, b = masks[(0.2, 1)].float(), masks[(0.2, 2)].float()
+    corr = float(((a - a.mean()) * (b - b.mean())).mean() / (a.std() * b.std()))
+    assert abs(corr) < 5e-3, "masks of two sites are correlated"
+    o2 = torch.empty(n, device="cuda")
+    _cabi.check(L.masr_test_dropout_mask(1235, 1, n, 0.2, P(o2), S()))
+    c = (o2 > 0).float()
+    assert abs(float(((a - a.mean()) * (c - c.mean())).mean() / (a.std() * c.std()))) < 5e-3, "masks of two seeds are correlated"
+    # GEMM epilogue site: C = 8 everywhere before dropout
+    M, N, K, p = 512, 384, 64, 0.1
+    A = torch.ones(M, K, device="cuda", dtype=torch.bfloat16)
+    B = torch.full((N, K), 0.125, device="cuda", dtype=torch.bfloat16)
+    Cm = torch.empty(M, N, device="cuda")
+    _cabi.check(L.masr_test_gemm_dropout(P(A), K, P(B), K, M, N, K, p, 77, 3, P(Cm), N, S()))
+    vals = torch.unique(Cm)
+    assert len(vals) == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 8.0 / (1 - p)) < 1e-4
+    assert abs(float((Cm > 0).float().mean()) - (1 - p)) < 4e-3
+    ref = torch.empty(M * N, device="cuda")
+    _cabi.check(L.masr_test_dropout_mask(77, 3, M * N, p, P(ref), S()))
+    assert torch.equal(Cm.reshape(-1) > 0, ref > 0), "the epilogue indexes its mask by m*N+n (the backward regenerates it the same way)"
+    # attention probabilities: q = k = 0 -> uniform probabilities, v = 1 -> o = (kept keys / Tk) / (1 - p): mean 1, binomial spread
+    Bq, H, Tq, Tk, hd, p = 4, 4, 128, 256, 64, 0.2
+    q = torch.zeros(Bq * Tq, H * hd, device="cuda", dtype=torch.bfloat16)
+    k = torch.zeros(Bq * Tk, H * hd, device="cuda", dtype=torch.bfloat16)
+    v = torch.ones(Bq * Tk, H * hd, device="cuda", dtype=torch.bfloat16)
+    o = torch.empty(Bq * Tq, H * hd, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(Bq * H * Tq, device="cuda")
+    _cabi.check(L.masr_test_attention_dropout(P(q), P(k), P(v), P(o), P(lse), Bq, H, Tq, Tk, hd, p, 5, 9, S()))
+    of = o.float()
+    assert abs(float(of.mean()) - 1.0) < 5e-3
+    sd_expect = (p / (1 - p) / Tk) ** 0.5
+    row = of.view(Bq * Tq, H, hd)[:, :, 0]
+    assert abs(float(row.std()) - sd_expect) < 0.15 * sd_expect, (float(row.std()), sd_expect)

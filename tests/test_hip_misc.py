@@ -69,6 +69,36 @@ def test_ctc_speech_sized_lattice():
     torch.testing.assert_close(grad.cpu(), lr.grad, rtol=2e-3, atol=2e-6)
 
 
+def test_ctc_gradient_is_bit_reproducible_with_repeated_labels():
+    """heavy label repetition (6 classes over up to 60 labels: many lattice states feed one class) -- the gradient must still
+    match torch AND come out bit-identical on every launch (class posteriors are summed by one owner thread in a fixed order,
+    not by LDS float atomics)"""
+    g = torch.Generator().manual_seed(8)
+    T, B, Cc = 180, 8, 7
+    logits = torch.randn(T, B, Cc, generator=g)
+    tl = torch.randint(20, 61, (B,), generator=g)
+    il = torch.randint(150, T + 1, (B,), generator=g)
+    tgt = torch.randint(1, Cc, (int(tl.sum()),), generator=g)
+    lr = logits.clone().requires_grad_(True)
+    ref = torch.nn.CTCLoss(blank=0, reduction="mean", zero_infinity=True)(torch.log_softmax(lr, -1), tgt, il, tl)
+    ref.backward()
+    L = _cabi.lib()
+    d = lambda t: t.to(torch.int32).cuda()
+    off = torch.cat([torch.zeros(1, dtype=torch.int64), tl.cumsum(0)[:-1]])
+    maxS = int(2 * tl.max() + 1)
+    work = torch.zeros(int(L.masr_ctc_work_floats(T, B, maxS)), device="cuda")
+    lg = logits.cuda().contiguous()
+    tg, of, ild, tld = d(tgt), d(off), d(il), d(tl)
+    grads = []
+    for _ in range(4):
+        nll, loss, grad = torch.zeros(B, device="cuda"), torch.zeros(1, device="cuda"), torch.zeros_like(lg)
+        _cabi.check(L.masr_ctc_loss(P(lg), P(tg), P(of), P(ild), P(tld), T, B, Cc, 0, P(nll), P(loss), P(grad), P(work), maxS, S()))
+        grads.append(grad.cpu())
+    assert abs(float(loss) - float(ref)) <= 2e-5 * abs(float(ref))
+    torch.testing.assert_close(grads[0], lr.grad, rtol=2e-3, atol=2e-6)
+    assert all(torch.equal(grads[0], x) for x in grads[1:])
+
+
 def test_gather_pad_equals_collate(tmp_path):
     write_toy_shard(tmp_path, "af", "train", 12, seed=9)
     ds = CommonVoiceDataset(tmp_path / "af" / "train", is_memmap=True)
