@@ -61,6 +61,13 @@ void masr_set_seed(masr_model* m, uint64_t seed);      /* dropout stream */
  * are left in `grads`.  olens is NOT mutated (quirk Q6 is reproduced by the Python mirror). */
 int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const int64_t* ys_flat,
                    const int64_t* olens, int B, int T, int flags, void* stream);
+/* Opt-in (or MASR_STEP_GRAPH=1): a batch shape (B, T, L, flags, xs pointer) that repeats on a non-null stream is captured into
+ * a hipGraph on its second consecutive occurrence and replayed afterwards (one launch instead of ~150; tokens, lengths, dropout
+ * seed and 1/n_total reach the kernels through the per-step upload, so replays are bit-identical to direct launches).  It cuts
+ * the host's enqueue time 6x and leaves the step time unchanged -- the step is GPU-bound -- hence off by default.
+ * counters: out[0] = steps launched kernel by kernel, out[1] = graphs captured, out[2] = steps replayed from a graph. */
+void masr_set_step_graphs(masr_model* m, int on);
+void masr_step_counters(const masr_model* m, int64_t out[3]);
 /* out[0]=loss, out[1]=n_correct, out[2]=n_total, out[3]=last grad norm.  Synchronises the stream. */
 int masr_read_stats(masr_model* m, float out[4], void* stream);
 /* device view of the last forward's logits: fp32 [rows = B*L][ld], first odim columns valid; and gold */

@@ -29,6 +29,8 @@ _SIGS = {
     "masr_refresh": (i32, [vp, vp]),
     "masr_set_seed": (None, [vp, C.c_uint64]),
     "masr_run_batch": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "masr_set_step_graphs": (None, [vp, i32]),
+    "masr_step_counters": (None, [vp, C.POINTER(i64)]),
     "masr_read_stats": (i32, [vp, C.POINTER(f32), vp]),
     "masr_last_logits": (i32, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "masr_grad_norm": (i32, [vp, vp]),

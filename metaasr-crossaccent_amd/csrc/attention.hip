@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const int klen = a.klens ? a.klens[b] : Tk;
     const float scale = rsqrtf((float)HD);
     const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const uint32_t dseed = (a.drop_p > 0.f && a.seed_ptr) ? *a.seed_ptr : a.seed;
 
     const bf16* qb = a.q + (long)b * Tq * a.ldq + h * HD;
     const bf16* kb_ = a.k + (long)b * Tk * a.ldk + h * HD;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 rs[r] += p;
                 if (a.drop_p > 0.f) {
                     const uint32_t idx = (uint32_t)((((long)b * a.H + h) * Tq + (qrow0 + row)) * Tk + kj);
-                    p *= dropout_scale(a.seed, a.site, idx, a.drop_p, inv_keep);
+                    p *= dropout_scale(dseed, a.site, idx, a.drop_p, inv_keep);
                 }
                 sp[row * LDP + jt * 16 + (lane & 15)] = (bf16)p;
             }
@@ -265,6 +266,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
     const int klen = a.klens ? a.klens[b] : Tk;
     const float scale = rsqrtf((float)HD);
     const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const uint32_t dseed = (a.drop_p > 0.f && a.seed_ptr) ? *a.seed_ptr : a.seed;
     const bf16* qb = a.q + (long)b * Tq * a.ldq + h * HD;
     const bf16* kb_ = a.k + (long)b * Tk * a.ldk + h * HD;
     const bf16* vb = a.v + (long)b * Tk * a.ldv + h * HD;
@@ -326,7 +328,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
                 float dpv = dp[r];
                 if (a.drop_p > 0.f) {
                     const uint32_t idx = (uint32_t)((((long)b * a.H + h) * Tq + qi) * Tk + kj);
-                    dpv *= dropout_scale(a.seed, a.site, idx, a.drop_p, inv_keep);
+                    dpv *= dropout_scale(dseed, a.site, idx, a.drop_p, inv_keep);
                 }
                 sp[row * LDP + jt * 16 + (lane & 15)] = (bf16)(p * (dpv - dl[r]) * scale);
             }
@@ -361,6 +363,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
     const int klen = a.klens ? a.klens[b] : Tk;
     const float scale = rsqrtf((float)HD);
     const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const uint32_t dseed = (a.drop_p > 0.f && a.seed_ptr) ? *a.seed_ptr : a.seed;
     const bf16* qb = a.q + (long)b * Tq * a.ldq + h * HD;
     const bf16* kb_ = a.k + (long)b * Tk * a.ldk + h * HD;
     const bf16* vb = a.v + (long)b * Tk * a.ldv + h * HD;
@@ -438,7 +441,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
                 float ms = 1.f;
                 if (a.drop_p > 0.f) {
                     const uint32_t idx = (uint32_t)((((long)b * a.H + h) * Tq + qi) * Tk + kj);
-                    ms = dropout_scale(a.seed, a.site, idx, a.drop_p, inv_keep);
+                    ms = dropout_scale(dseed, a.site, idx, a.drop_p, inv_keep);
                 }
                 sp[row * LDP + ql] = (bf16)(p * ms);
                 sd[row * LDP + ql] = (bf16)(p * (dpt[r] * ms - sDl[ql]) * scale);

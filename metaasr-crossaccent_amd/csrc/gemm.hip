@@ -161,6 +161,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
     const bool f_acc = HAS(E_ACC, g.accumulate), f_c32 = HAS(E_C32, g.C32), f_c16 = HAS(E_C16, g.C16);
     const int nv = g.N - n < SW ? g.N - n : SW;                 // valid columns of this thread's strip
     const float inv_keep = f_drop ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+    const uint32_t seed = (f_drop && g.seed_ptr) ? *g.seed_ptr : g.seed;
     float bv[SW];
 #pragma unroll
     for (int e = 0; e < SW; ++e) bv[e] = (f_bias && e < nv) ? g.bias[n + e] : 0.f;
@@ -225,7 +226,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
             float x = v[e] + bv[e] + pev[i][e];
             if (f_relu) x = fmaxf(x, 0.f);
             if (f_mask) x = mk[i][e] > 0.f ? x * g.mask_scale : 0.f;
-            if (f_drop) x *= dropout_scale(g.seed, g.site, (uint32_t)((long)m * g.N + n + e), g.drop_p, inv_keep);
+            if (f_drop) x *= dropout_scale(seed, g.site, (uint32_t)((long)m * g.N + n + e), g.drop_p, inv_keep);
             v[e] = x + rs[i][e] + old[i][e];
         }
         if (f_c32) {

@@ -16,6 +16,7 @@ struct GemmArgs {
     int relu;
     const bf16* mask; long ldmask; float mask_scale;   // v = mask>0 ? v*mask_scale : 0
     float drop_p; uint32_t seed, site;                 // dropout on element index m*N+n
+    const uint32_t* seed_ptr;                          // non-null: the seed is read from device memory (graph-replayed steps)
     const float* residual; long ldres;                 // + residual[m*ldres + n]
     float* colsum;                // reduction-major only: colsum[m] = sum_k A(m,k) (fused bias gradient) or null
     int split_k;                  // reduction-major only: >1 splits the reduction over gridDim.z workgroups; split 0 writes
@@ -79,6 +80,7 @@ struct AttnArgs {
     const int* klens;                            // [B] valid keys per batch or null (all Tk)
     int B, H, Tq, Tk, hd, causal;
     float drop_p; uint32_t seed, site;
+    const uint32_t* seed_ptr;                    // non-null: the seed is read from device memory (graph-replayed steps)
 };
 int mk_attn_fwd(const AttnArgs& a, hipStream_t s);
 int mk_attn_bwd(const AttnArgs& a, hipStream_t s);
@@ -114,7 +116,7 @@ int mk_layernorm_fwd(const float* x, const float* gamma, const float* beta, floa
 // dx32 = LN backward; dx16 = bf16 copy (optionally dropout-masked with (seed,site) for the branch GEMMs)
 int mk_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        float* dx32, bf16* dx16, float drop_p, uint32_t seed, uint32_t site,
-                       float* dgamma, float* dbeta, float* slab, int rows, int E, hipStream_t s);
+                       float* dgamma, float* dbeta, float* slab, int rows, int E, hipStream_t s, const uint32_t* seed_ptr = nullptr);
 long mk_layernorm_bwd_slab_floats(int rows, int E);
 // dgamma == null: only the per-block partials are written to `slab` (each LayerNorm its own region) and
 // mk_layernorm_bwd_reduce_grouped folds all of them in one launch at the end of the backward pass
@@ -123,24 +125,24 @@ constexpr int LN_GROUP_MAX = 64;
 struct LnReduceGroup { int n; LnReduceDesc p[LN_GROUP_MAX]; };
 int mk_layernorm_bwd_reduce_grouped(const LnReduceGroup& grp, int E, hipStream_t s);
 int mk_embed_fwd(const int* tok, const float* table, const float* pe, float* y32, bf16* y16,
-                   int B, int L, int E, float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
+                   int B, int L, int E, float drop_p, uint32_t seed, uint32_t site, hipStream_t s, const uint32_t* seed_ptr = nullptr);
 // dtable[v] (+)= sum over rows with tok==v of dy[row]  (deterministic: one block per vocab row)
 int mk_embed_bwd(const int* tok, const float* dy, float* dtable, int rows, int V, int E, int accumulate,
-                   float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
+                   float drop_p, uint32_t seed, uint32_t site, hipStream_t s, const uint32_t* seed_ptr = nullptr);
 // greedy decode: build the next decoder input from the previous step's tokens; arg-max of every logits row
 int mk_recog_build_tok(int* tok, const int* out, int B, int L, int sos, hipStream_t s);
 int mk_recog_argmax(const float* logits, long ld, int* out, int B, int L, int C, hipStream_t s);
 // out[i] = the keep-scale (0 or 1/(1-p)) every dropout site applies to element i of its tensor (parity tests)
 int mk_dropout_mask(float* out, long n, float p, uint32_t seed, uint32_t site, hipStream_t s);
 // y16 = bf16(x32 * dropout_mask)
-int mk_cast_dropout(const float* x, bf16* y, long n, float drop_p, uint32_t seed, uint32_t site, hipStream_t s);
+int mk_cast_dropout(const float* x, bf16* y, long n, float drop_p, uint32_t seed, uint32_t site, hipStream_t s, const uint32_t* seed_ptr = nullptr);
 // column sums of x[rows][cols] (cols % 8 == 0, ld >= cols); only the first out_cols are written
 int mk_colsum(const bf16* x, long ld, float* out, float* slab, int rows, int cols, int out_cols, hipStream_t s);
 long mk_colsum_slab_floats(int rows, int cols);
 // label-smoothed CE: logits fp32 [rows][ld]; gold int [rows] (-1 ignored); writes dlogits bf16 [rows][ld]
 // stats[0] = loss (already / n_total), stats[1] = n_correct, stats[2] = n_total
 int mk_ls_ce(const float* logits, long ld, const int* gold, int rows, int C, float eps, float inv_ntotal,
-               bf16* dlogits, float* row_loss, int* row_correct, float* stats, hipStream_t s);
+               bf16* dlogits, float* row_loss, int* row_correct, float* stats, hipStream_t s, const float* inv_ntotal_ptr = nullptr);
 
 // ---------------------------------------------------------------- flat optimiser ops (optim.hip)
 int mk_sumsq(const float* x, long n, float* slab, float* out_norm, hipStream_t s);       // out_norm[0] = sqrt(sum x^2)

@@ -45,8 +45,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx32,
                                                      bf16* __restrict__ dx16, float drop_p, uint32_t seed, uint32_t site,
-                                                     float* __restrict__ slab, int rows) {
+                                                     float* __restrict__ slab, int rows, const uint32_t* __restrict__ seed_ptr) {
     constexpr int E = 64 * PT;
+    if (seed_ptr) seed = *seed_ptr;                           // replayed (graph-captured) step: the seed of THIS step lives on the device
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float dg[PT], db[PT], gm[PT];
 #pragma unroll
@@ -130,7 +131,8 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_grouped(LnReduceGroup grp, 
 // ---------------------------------------------------------------- embedding + positional encoding
 __global__ void embed_fwd_kernel(const int* __restrict__ tok, const float* __restrict__ table, const float* __restrict__ pe,
                                  float* __restrict__ y32, bf16* __restrict__ y16, int B, int L, int E,
-                                 float drop_p, uint32_t seed, uint32_t site) {
+                                 float drop_p, uint32_t seed, uint32_t site, const uint32_t* __restrict__ seed_ptr) {
+    if (seed_ptr) seed = *seed_ptr;
     const long n = (long)B * L * E;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -147,7 +149,8 @@ __global__ void embed_fwd_kernel(const int* __restrict__ tok, const float* __res
 // deterministic).  Most vocabulary rows have no hit; the padding token (</s>) has hundreds, hence the 2-D split.
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ tok, const float* __restrict__ dy,
                                                         float* __restrict__ dtable, int rows, int E, int accumulate,
-                                                        float drop_p, uint32_t seed, uint32_t site) {
+                                                        float drop_p, uint32_t seed, uint32_t site, const uint32_t* __restrict__ seed_ptr) {
+    if (seed_ptr) seed = *seed_ptr;
     const int v = blockIdx.x, col = blockIdx.y * 64 + (threadIdx.x & 63);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -194,7 +197,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ 
 }
 
 __global__ void cast_dropout_kernel(const float* __restrict__ x, bf16* __restrict__ y, long n, float drop_p,
-                                    uint32_t seed, uint32_t site) {
+                                    uint32_t seed, uint32_t site, const uint32_t* __restrict__ seed_ptr) {
+    if (seed_ptr) seed = *seed_ptr;
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
     const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -272,7 +276,8 @@ __global__ __launch_bounds__(256) void recog_argmax_kernel(const float* __restri
 __global__ __launch_bounds__(256) void ls_ce_kernel(const float* __restrict__ logits, long ld, const int* __restrict__ gold,
                                                     int rows, int C, float eps, float inv_ntotal,
                                                     bf16* __restrict__ dlogits, float* __restrict__ row_loss,
-                                                    int* __restrict__ row_correct) {
+                                                    int* __restrict__ row_correct, const float* __restrict__ inv_ptr) {
+    if (inv_ptr) inv_ntotal = *inv_ptr;                       // replayed step: 1 / n_total of THIS batch lives on the device
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* z = logits + (long)row * ld;
@@ -313,7 +318,8 @@ __global__ __launch_bounds__(256) void ls_ce_kernel(const float* __restrict__ lo
     }
 }
 __global__ __launch_bounds__(256) void ls_ce_reduce(const float* __restrict__ row_loss, const int* __restrict__ row_correct,
-                                                    int rows, float inv_ntotal, float* __restrict__ stats) {
+                                                    int rows, float inv_ntotal, float* __restrict__ stats, const float* __restrict__ inv_ptr) {
+    if (inv_ptr) inv_ntotal = *inv_ptr;
     __shared__ float sl[256]; __shared__ int sc[256];
     float l = 0.f; int c = 0;
     for (int r = threadIdx.x; r < rows; r += 256) { l += row_loss[r]; c += row_correct[r]; }
@@ -336,8 +342,8 @@ static void ln_fwd_launch(const float* x, const float* gamma, const float* beta,
 }
 template <int PT>
 static void ln_bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx32, bf16* dx16,
-                          float drop_p, uint32_t seed, uint32_t site, float* slab, int rows, int nb, hipStream_t s) {
-    hipLaunchKernelGGL(ln_bwd_kernel<PT>, dim3(nb), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx32, dx16, drop_p, seed, site, slab, rows);
+                          float drop_p, uint32_t seed, uint32_t site, float* slab, int rows, int nb, hipStream_t s, const uint32_t* seed_ptr) {
+    hipLaunchKernelGGL(ln_bwd_kernel<PT>, dim3(nb), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx32, dx16, drop_p, seed, site, slab, rows, seed_ptr);
 }
 #define LN_DISPATCH(E, CALL)                                                                      \
     switch ((E) / 64) {                                                                           \
@@ -356,10 +362,10 @@ int mk_layernorm_fwd(const float* x, const float* gamma, const float* beta, floa
 long mk_layernorm_bwd_slab_floats(int rows, int E) { return (long)((rows + LN_ROWS - 1) / LN_ROWS) * 2 * E; }
 int mk_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        float* dx32, bf16* dx16, float drop_p, uint32_t seed, uint32_t site, float* dgamma, float* dbeta,
-                       float* slab, int rows, int E, hipStream_t s) {
+                       float* slab, int rows, int E, hipStream_t s, const uint32_t* seed_ptr) {
     if (E % 64) { mk_set_error("mk_layernorm_bwd", "d_model must be a multiple of 64"); return -1; }
     const int nb = (rows + LN_ROWS - 1) / LN_ROWS;
-#define CALL(P) ln_bwd_launch<P>(dy, x, gamma, mean, rstd, dx32, dx16, drop_p, seed, site, slab, rows, nb, s)
+#define CALL(P) ln_bwd_launch<P>(dy, x, gamma, mean, rstd, dx32, dx16, drop_p, seed, site, slab, rows, nb, s, seed_ptr)
     LN_DISPATCH(E, CALL)
 #undef CALL
     if (dgamma) hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * E + 31) / 32), dim3(256), 0, s, slab, nb, dgamma, dbeta, E);
@@ -371,15 +377,15 @@ int mk_layernorm_bwd_reduce_grouped(const LnReduceGroup& grp, int E, hipStream_t
     return LAUNCH_OK();
 }
 int mk_embed_fwd(const int* tok, const float* table, const float* pe, float* y32, bf16* y16, int B, int L, int E,
-                   float drop_p, uint32_t seed, uint32_t site, hipStream_t s) {
+                   float drop_p, uint32_t seed, uint32_t site, hipStream_t s, const uint32_t* seed_ptr) {
     const long n = (long)B * L * E;
-    hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tok, table, pe, y32, y16, B, L, E, drop_p, seed, site);
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tok, table, pe, y32, y16, B, L, E, drop_p, seed, site, seed_ptr);
     return LAUNCH_OK();
 }
 int mk_embed_bwd(const int* tok, const float* dy, float* dtable, int rows, int V, int E, int accumulate, float drop_p,
-                   uint32_t seed, uint32_t site, hipStream_t s) {
+                   uint32_t seed, uint32_t site, hipStream_t s, const uint32_t* seed_ptr) {
     if (E % 64) { mk_set_error("mk_embed_bwd", "d_model must be a multiple of 64"); return -1; }
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(V, E / 64), dim3(256), 0, s, tok, dy, dtable, rows, E, accumulate, drop_p, seed, site);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(V, E / 64), dim3(256), 0, s, tok, dy, dtable, rows, E, accumulate, drop_p, seed, site, seed_ptr);
     return LAUNCH_OK();
 }
 int mk_recog_build_tok(int* tok, const int* out, int B, int L, int sos, hipStream_t s) {
@@ -398,8 +404,8 @@ int mk_dropout_mask(float* out, long n, float p, uint32_t seed, uint32_t site, h
     hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n, p, seed, site);
     return LAUNCH_OK();
 }
-int mk_cast_dropout(const float* x, bf16* y, long n, float drop_p, uint32_t seed, uint32_t site, hipStream_t s) {
-    hipLaunchKernelGGL(cast_dropout_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, s, x, y, n, drop_p, seed, site);
+int mk_cast_dropout(const float* x, bf16* y, long n, float drop_p, uint32_t seed, uint32_t site, hipStream_t s, const uint32_t* seed_ptr) {
+    hipLaunchKernelGGL(cast_dropout_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, s, x, y, n, drop_p, seed, site, seed_ptr);
     return LAUNCH_OK();
 }
 long mk_colsum_slab_floats(int rows, int cols) { return (long)((rows + CS_ROWS - 1) / CS_ROWS) * cols; }
@@ -411,8 +417,8 @@ int mk_colsum(const bf16* x, long ld, float* out, float* slab, int rows, int col
     return LAUNCH_OK();
 }
 int mk_ls_ce(const float* logits, long ld, const int* gold, int rows, int C, float eps, float inv_ntotal, bf16* dlogits,
-               float* row_loss, int* row_correct, float* stats, hipStream_t s) {
-    hipLaunchKernelGGL(ls_ce_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, logits, ld, gold, rows, C, eps, inv_ntotal, dlogits, row_loss, row_correct);
-    hipLaunchKernelGGL(ls_ce_reduce, dim3(1), dim3(256), 0, s, row_loss, row_correct, rows, inv_ntotal, stats);
+               float* row_loss, int* row_correct, float* stats, hipStream_t s, const float* inv_ptr) {
+    hipLaunchKernelGGL(ls_ce_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, logits, ld, gold, rows, C, eps, inv_ntotal, dlogits, row_loss, row_correct, inv_ptr);
+    hipLaunchKernelGGL(ls_ce_reduce, dim3(1), dim3(256), 0, s, row_loss, row_correct, rows, inv_ntotal, stats, inv_ptr);
     return LAUNCH_OK();
 }

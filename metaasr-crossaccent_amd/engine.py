@@ -170,6 +170,16 @@ class MasrEngine:
         self._last_stats = {"loss": float(out[0]), "n_correct": float(out[1]), "n_total": float(out[2]), "grad_norm": float(out[3])}
         return self._last_stats
 
+    def set_step_graphs(self, on: bool):
+        """opt-in graph replay of repeated batch shapes (include/masr.h masr_set_step_graphs)"""
+        self._l.masr_set_step_graphs(self.h, int(bool(on)))
+
+    def step_counters(self):
+        """{'direct', 'captured', 'replayed'}: how run_batch calls reached the GPU (kernel by kernel / graph capture / graph replay)"""
+        out = (C.c_int64 * 3)()
+        self._l.masr_step_counters(self.h, out)
+        return {"direct": int(out[0]), "captured": int(out[1]), "replayed": int(out[2])}
+
     def last_logits(self):
         """[B, L, odim] fp32 view of the last forward's logits and gold [B, L] (int32, -1 = pad)."""
         lp, gp = C.c_void_p(), C.c_void_p()

@@ -283,3 +283,45 @@ def test_hkust_geometry_inner_steps_vs_oracle():
     cos = float((a * bq).sum() / (a.norm() * bq.norm()))
     print(f"hkust: losses {[round(g['loss'], 5) for g in got]} vs {[round(r['loss'], 5) for r in ref]}; grad cos {cos:.5f}")
     assert cos > 0.995 and abs(float(a.norm() / bq.norm()) - 1) < 2e-2
+
+
+def test_graph_replayed_steps_equal_direct_launches(sd):
+    """(opt-in, masr_set_step_graphs) A batch shape that repeats is captured into a hipGraph on its second occurrence and replayed afterwards; everything that
+    changes between steps (tokens, lengths, dropout seed, 1/n_total) reaches the kernels through device memory.  Replayed
+    steps must be BIT-identical to directly launched ones: same losses, same gradients, same dropout masks, step after step
+    (the direct engine is kept off the graph path by its profiling switch), including a change of labels at a fixed shape."""
+    cfg = dict(TINY); cfg["dropout"] = 0.1; cfg["pos_dropout"] = 0.1
+    xs, il, ys, ol = synth_batch(11, *CASES["ragged"])
+    ys2 = [(y + 1) % 365 + 1 for y in ys]                     # other labels, same lengths -> same shape, other n_correct / loss
+    xs_dev = xs.cuda()
+    engs = []
+    for direct in (False, True):
+        e = MasrEngine(cfg, ODIM, label_smoothing=0.2)
+        e.load_state_dict(sd); e.set_seed(99)
+        if direct:
+            e.profile(True)
+        e.set_step_graphs(True)
+        engs.append(e)
+    moms = [torch.zeros_like(e.params) for e in engs]
+    with torch.cuda.stream(torch.cuda.Stream()):               # (steps on the legacy NULL stream are never captured)
+        for step in range(6):
+            labels = ys if step % 3 else ys2
+            out = []
+            for e, mom in zip(engs, moms):
+                e.run_batch(xs_dev, il, labels, ol, train=True)
+                g = e.grads.clone()
+                e.clip_sgd_step(mom, 5.0, 0.01, 0.9, True, step == 0)
+                out.append((e.read_stats(), g, e.params.clone()))
+            (s0, g0, p0), (s1, g1, p1) = out
+            assert s0 == s1, (step, s0, s1)
+            assert torch.equal(g0, g1) and torch.equal(p0, p1), f"step {step}: replayed and direct launches differ"
+        # evaluation at the same shape (separate graph: no dropout, no backward)
+        for _ in range(3):
+            r = []
+            for e in engs:
+                e.run_batch(xs_dev, il, ys, ol, train=False)
+                r.append(e.read_stats()["loss"])
+            assert r[0] == r[1]
+        torch.cuda.current_stream().synchronize()
+    assert engs[0].step_counters() == {"direct": 2, "captured": 2, "replayed": 7}, engs[0].step_counters()
+    assert engs[1].step_counters()["replayed"] == 0
