@@ -30,7 +30,9 @@ from masr_amd.optimizer import FlatAdam, TransformerOptimizer
 from oracle.make_goldens import write_toy_shard
 
 N = 193
-ACCENTS = {"af": "african", "au": "australia", "ca": "canada", "en": "england", "us": "us"}
+ACCENTS = {"af": "african", "au": "australia", "ca": "canada", "en": "england", "us": "us", "hk": "hongkong", "in": "indian",
+           "ir": "ireland", "nz": "newzealand"}
+EIGHT = ["af", "au", "en", "us", "hk", "in", "ir", "nz"]
 
 
 def batch_fingerprint(x, ys):
@@ -139,10 +141,10 @@ def make_workspace(root):
         write_toy_shard(root / "data", a, "dev", 3, seed=200 + ai)
 
 
-def run(root, algo, world, rank, fix_snapshot=False, meta_batch=3, steps=5):
+def run(root, algo, world, rank, fix_snapshot=False, meta_batch=3, steps=5, accents=("af", "au", "en", "us"), meta_k=2, fix_reptile=False):
     os.chdir(root)
     model = {"d_model": 64}
-    if algo == "fomaml":
+    if algo in ("fomaml", "reptile"):
         model.update({"inner_optimizer_cls": "SGD", "inner_optimizer_opt": {"momentum": 0.9, "nesterov": True},
                       "meta_opt_cls": "noam", "meta": {"optimizer_opt": {"k": 1.0, "warmup_steps": 4}}})
     else:
@@ -151,12 +153,12 @@ def run(root, algo, world, rank, fix_snapshot=False, meta_batch=3, steps=5):
            "solver": {"setting": "t", "data_root": "data", "total_steps": 100, "spm_mapping": "data/units.txt", "spm_model": "none",
                       "label_smoothing": 0.0, "eval_ival": 2, "log_ival": 1, "save_ival": 2, "batch_size": 4, "dev_batch_size": 4,
                       "min_ilen": 10, "max_ilen": 50, "dev_max_ilen": 3000, "half_batch_ilen": 30}}
-    paras = SimpleNamespace(pretrain_suffix=f"w{world}", pretrain_accents=["af", "au", "en", "us"], num_pretrain=4, tgt_accent="ca", runs=0,
-                            overwrite=True, seed=531, meta_k=2, meta_batch_size=meta_batch, sample_strategy="normal", max_step=steps,
+    paras = SimpleNamespace(pretrain_suffix=f"w{world}", pretrain_accents=list(accents), num_pretrain=len(accents), tgt_accent="ca", runs=0,
+                            overwrite=True, seed=531, meta_k=meta_k, meta_batch_size=meta_batch, sample_strategy="normal", max_step=steps,
                             resume=False, model_name="transformer", algo=algo, njobs=2 if world > 1 else 0, is_bucket=True, is_memmap=True,
-                            use_tensorboard=False, fix_snapshot_meta_weights=fix_snapshot, tasks_per_gpu=1)
+                            use_tensorboard=False, fix_snapshot_meta_weights=fix_snapshot, tasks_per_gpu=1, fix_reptile=fix_reptile)
     random.seed(531); np.random.seed(531); torch.manual_seed(531)
-    if algo == "fomaml":
+    if algo in ("fomaml", "reptile"):
         from masr_amd.fo_meta_interface import FOMetaASRInterface as Iface
     else:
         from masr_amd.multi_interface import MultiASRInterface as Iface
@@ -165,17 +167,18 @@ def run(root, algo, world, rank, fix_snapshot=False, meta_batch=3, steps=5):
     solver.load_data()
     solver.set_model()
     solver.exec()
-    weights = solver._original.clone() if algo == "fomaml" else solver.asr_model.engine.params.clone()
+    weights = solver._original.clone() if algo in ("fomaml", "reptile") else solver.asr_model.engine.params.clone()
     files = sorted(p.name for p in solver.log_dir.iterdir()) if rank == 0 else []
     dev_log = (solver.log_dir / "dev_avg_wer").read_text() if rank == 0 and (solver.log_dir / "dev_avg_wer").exists() else ""
     return {"weights": weights, "train_fps": [fp for tr, fp in log if tr], "files": files, "dev_avg_wer": dev_log,
             "global_step": solver.global_step}
 
 
-def _worker(rank, world, port, root, algo, fix_snapshot, out_dir):
+def _worker(rank, world, port, root, algo, fix_snapshot, out_dir, kw):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    res = run(root, algo, world, rank, fix_snapshot)
+    res = run(root, algo, world, rank, fix_snapshot, **kw)
     torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
     dist.destroy_process_group()
 
@@ -186,10 +189,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _two_ranks(root, algo, fix_snapshot=False):
+def _ranks(root, algo, fix_snapshot=False, world=2, **kw):
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(2, _free_port(), root, algo, fix_snapshot, d), nprocs=2, join=True)
-        return [torch.load(os.path.join(d, f"r{r}.pt"), weights_only=False) for r in range(2)]
+        mp.spawn(_worker, args=(world, _free_port(), root, algo, fix_snapshot, d, kw), nprocs=world, join=True)
+        return [torch.load(os.path.join(d, f"r{r}.pt"), weights_only=False) for r in range(world)]
+
+
+def _two_ranks(root, algo, fix_snapshot=False):
+    return _ranks(root, algo, fix_snapshot, 2)
 
 
 @pytest.fixture()
@@ -235,3 +242,21 @@ def test_multi_train_two_ranks_draw_different_batches(workspace):
     assert all(a != b for a, b in zip(r0["train_fps"], r1["train_fps"]))
     inter = [fp for pair in zip(r0["train_fps"], r1["train_fps"]) for fp in pair]
     assert inter[:len(single["train_fps"])] == single["train_fps"][:len(inter)]
+
+
+@pytest.mark.parametrize("algo,meta_k", [("fomaml", 1), ("reptile", 5)])
+def test_eight_accents_one_task_per_rank_on_eight_ranks(workspace, algo, meta_k):
+    """BASELINE configs[3] / [4] as far as a CPU can take them: `pretrain.py --algo fomaml` with 8 accents sharded one task per
+    rank on 8 ranks (all-reduce of the meta-gradient, replicated Noam-Adam), and `--algo reptile --fix_reptile` with 8 accents and
+    inner_steps = 5.  Eight gloo ranks through the real train() loop end with the single-process meta weights; every rank ran
+    exactly one task per meta-step; together they consumed the single-process batch list."""
+    kw = dict(meta_batch=8, steps=4, accents=EIGHT, meta_k=meta_k, fix_reptile=(algo == "reptile"))
+    single = run(workspace, algo, 1, 0, **kw)
+    ranks = _ranks(workspace, algo, world=8, **kw)
+    for r in ranks[1:]:
+        assert torch.equal(ranks[0]["weights"], r["weights"])
+    torch.testing.assert_close(ranks[0]["weights"], single["weights"], rtol=1e-9, atol=1e-11)
+    per_step = meta_k + 1                                            # k inner batches + the val batch of the rank's one task
+    n_meta = len(single["train_fps"]) // (8 * per_step)              # (the loop runs whole eval_ival rounds: 4 meta-steps)
+    assert n_meta == 4 and all(len(r["train_fps"]) == n_meta * per_step for r in ranks)
+    assert sorted(fp for r in ranks for fp in r["train_fps"]) == sorted(single["train_fps"])
