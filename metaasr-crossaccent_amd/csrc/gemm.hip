@@ -406,7 +406,10 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
     constexpr int FM = WM / 16, FN = WN / 16;
     constexpr int LDC = BN + 4;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
-    constexpr int NBUF = (BM * BN >= 128 * 128) ? 2 : 3;   // 128x128: 2 x 32 KB keeps two workgroups per CU
+#ifndef MASR_GLDS_NBUF_SMALL
+#define MASR_GLDS_NBUF_SMALL 3
+#endif
+    constexpr int NBUF = (BM * BN >= 128 * 128) ? 2 : MASR_GLDS_NBUF_SMALL;   // 128x128: 2 x 32 KB keeps two workgroups per CU
     constexpr size_t OUT_BYTES = sizeof(float) * BM * LDC;
     __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF > OUT_BYTES ? NBUF * BUF : OUT_BYTES];
     typedef __attribute__((address_space(1))) const void gptr_t;
