@@ -90,7 +90,12 @@ int masr_adam_step(float* params, const float* grads, float* exp_avg, float* exp
  * weight_decay (decoupled == 0: g += weight_decay*p) -- config/transformer/adapt/hkust-adamw.yaml through
  * getattr(torch.optim, cls) (src/transformer_torch_trainer.py:44-46) */
 int masr_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                    float beta1, float beta2, float eps, float weight_decay, int decoupled, int step, void* stream);      /* torch.optim.Adam, optimizer.py:19-21 */
+                    float beta1, float beta2, float eps, float weight_decay, int decoupled, int step, void* stream);
+/* optimizer_cls 'RAdam' of set_model (src/transformer_torch_trainer.py:36-41).  The reference takes it from `torch_optimizer`, an
+ * un-vendored third-party package that is absent from its tree (parity unpinned against that); this entry follows the published
+ * algorithm as torch.optim.RAdam implements it (pinned by tests/test_hip_misc.py against torch.optim.RAdam on the CPU). */
+int masr_radam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float b1, float b2,
+                    float eps, float weight_decay, int step, void* stream);      /* torch.optim.Adam, optimizer.py:19-21 */
 int masr_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr, float momentum,
                   int nesterov, int first_step, void* stream);
 int masr_scale(float* x, int64_t n, float a, void* stream);                           /* _updates /= counter (:201-202) */

@@ -39,6 +39,7 @@ _SIGS = {
     "masr_clip_accumulate": (i32, [vp, vp, f32, vp]),
     "masr_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]),
     "masr_adamw_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, i32, vp]),
+    "masr_radam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
     "masr_sgd_step": (i32, [vp, vp, vp, i64, f32, f32, i32, i32, vp]),
     "masr_scale": (i32, [vp, i64, f32, vp]),
     "masr_axpy": (i32, [vp, vp, i64, f32, vp]),

@@ -908,6 +908,10 @@ int masr_adamw_step(float* p, const float* g, float* ea, float* eas, int64_t n, 
                     int decoupled, int step, void* stream) {
     return mk_adam(p, g, ea, eas, n, lr, b1, b2, eps, step, weight_decay, decoupled, (hipStream_t)stream);
 }
+int masr_radam_step(float* p, const float* g, float* ea, float* eas, int64_t n, float lr, float b1, float b2, float eps, float weight_decay,
+                    int step, void* stream) {
+    return mk_radam(p, g, ea, eas, n, lr, b1, b2, eps, step, weight_decay, (hipStream_t)stream);
+}
 int masr_sgd_step(float* p, const float* g, float* mom, int64_t n, float lr, float momentum, int nesterov, int first_step, void* stream) {
     return mk_clip_sgd(p, g, mom, n, nullptr, 0.f, lr, momentum, nesterov, first_step, (hipStream_t)stream);
 }

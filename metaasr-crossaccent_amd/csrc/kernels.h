@@ -157,6 +157,7 @@ int mk_scale(float* x, long n, float a, hipStream_t s);
 // weight_decay: decoupled != 0 -> AdamW (p *= 1 - lr*wd first), else torch.optim.Adam's L2 term (g += wd*p); 0 = plain Adam
 int mk_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int t, float weight_decay,
             int decoupled, hipStream_t s);
+int mk_radam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int t, float weight_decay, hipStream_t s);
 int mk_axpy(float* y, const float* x, long n, float a, hipStream_t s);
 int mk_cast_bf16(const float* x, bf16* y, long n, hipStream_t s);
 int mk_transpose_cast_bf16(const float* x /*[R][C]*/, bf16* y /*[C][ldy]*/, int R, int C, long ldy, hipStream_t s);

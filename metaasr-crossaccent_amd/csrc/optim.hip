@@ -248,6 +248,21 @@ int mk_adam(float* p, const float* g, float* m, float* v, long n, float lr, floa
                        (float)(1.0 / sqrt(bc2)), decoupled ? 1.f - lr * weight_decay : 1.f, decoupled ? 0.f : weight_decay);
     return LAUNCH_OK();
 }
+// RAdam (Liu et al. 2020, as torch.optim.RAdam): Adam moments; while the variance estimate is unreliable (rho_t <= 5) the step is
+// the bias-corrected momentum alone, afterwards Adam's step times the rectification r_t.  All of that is scalar work on the host:
+// the update itself is adam_kernel with step_size = lr (r_t) / (1 - b1^t) and, in the unrectified phase, a denominator of 1
+// (inv_sqrt_bc2 = 0, eps = 1).  weight_decay = L2 term added to the gradient (torch's default, decoupled_weight_decay=False).
+int mk_radam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int t, float weight_decay, hipStream_t s) {
+    const double bc1 = 1.0 - pow((double)b1, t), bc2 = 1.0 - pow((double)b2, t);
+    const double rho_inf = 2.0 / (1.0 - b2) - 1.0, rho_t = rho_inf - 2.0 * t * pow((double)b2, t) / bc2;
+    double step = lr / bc1; float inv_sqrt_bc2 = 0.f, e = 1.f;
+    if (rho_t > 5.0) {
+        step *= sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t));
+        inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2)); e = eps;
+    }
+    hipLaunchKernelGGL(adam_kernel, dim3(flat_blocks(n)), dim3(256), 0, s, p, g, m, v, n, (float)step, b1, b2, e, inv_sqrt_bc2, 1.f, weight_decay);
+    return LAUNCH_OK();
+}
 int mk_cast_bf16(const float* x, bf16* y, long n, hipStream_t s) {
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(flat_blocks(n)), dim3(256), 0, s, x, y, n);
     return LAUNCH_OK();

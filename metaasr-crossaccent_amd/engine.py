@@ -214,6 +214,10 @@ class MasrEngine:
         else:
             check(self._l.masr_adam_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, b1, b2, eps, step, self.stream()), "masr_adam_step")
 
+    def radam_step(self, params, grads, m, v, lr, b1, b2, eps, step, weight_decay=0.0):
+        check(self._l.masr_radam_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, b1, b2, eps, weight_decay, step, self.stream()),
+              "masr_radam_step")
+
     def sgd_step(self, params, grads, mom, lr, momentum, nesterov, first_step):
         check(self._l.masr_sgd_step(_ptr(params), _ptr(grads), _ptr(mom), params.numel(), lr, momentum, int(nesterov), int(first_step), self.stream()), "masr_sgd_step")
 

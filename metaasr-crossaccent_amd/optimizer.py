@@ -39,6 +39,22 @@ class FlatAdam:
         self.param_groups[0]['lr'] = sd['lr']
 
 
+class FlatRAdam(FlatAdam):
+    """optimizer_cls 'RAdam' (src/transformer_torch_trainer.py:36-41, there from the un-vendored `torch_optimizer`): the published
+    algorithm with torch.optim.RAdam's conventions (rectification once rho_t > 5, L2 weight decay)."""
+
+    def __init__(self, engine, params_flat, betas=(0.9, 0.999), eps=1e-8, lr=1e-3, weight_decay=0.0):
+        super().__init__(engine, params_flat, betas=betas, eps=eps, lr=lr, weight_decay=weight_decay, decoupled=False)
+
+    def step(self):
+        assert self.grad is not None, "FlatRAdam.step(): no gradient attached"
+        self.t += 1
+        self.engine.radam_step(self.params, self.grad, self.exp_avg, self.exp_avg_sq, self.param_groups[0]['lr'], self.betas[0],
+                               self.betas[1], self.eps, self.t, self.weight_decay)
+        if self.params.data_ptr() == self.engine.params.data_ptr():
+            self.engine.mark_dirty()
+
+
 class FlatSGD:
     """torch.optim.SGD(lr, momentum, nesterov) on the engine's own params/grads; `clip` fuses clip_grad_norm_."""
 

@@ -5,7 +5,7 @@ import torch
 
 from .marcos import IGNORE_ID
 from .model import MyTransformer
-from .optimizer import FlatAdam, FlatSGD, TransformerOptimizer
+from .optimizer import FlatAdam, FlatRAdam, FlatSGD, TransformerOptimizer
 from .monitor import logger
 
 
@@ -38,8 +38,12 @@ def get_trainer(cls, config, paras, id2accent):
                     wd = o.get('weight_decay', 1e-2 if cls_name == 'AdamW' else 0.0)
                     self.asr_opt = FlatAdam(eng, eng.params, betas=tuple(o.get('betas', (0.9, 0.999))), eps=o.get('eps', 1e-8),
                                             lr=o.get('lr', 1e-3), weight_decay=wd, decoupled=(cls_name == 'AdamW'))
+                elif cls_name == 'RAdam':                                    # reference: torch_optimizer.RAdam(**optimizer_opt) (:36-41)
+                    o = mp['optimizer_opt']
+                    self.asr_opt = FlatRAdam(eng, eng.params, betas=tuple(o.get('betas', (0.9, 0.999))), eps=o.get('eps', 1e-8),
+                                             lr=o.get('lr', 1e-3), weight_decay=o.get('weight_decay', 0.0))
                 else:
-                    raise NotImplementedError(f"optimizer_cls {cls_name} (reference: getattr(torch.optim, cls) / torch_optimizer.RAdam)")
+                    raise NotImplementedError(f"optimizer_cls {cls_name} (reference: getattr(torch.optim, cls))")
             else:
                 logger.notice("During meta-training, model optimizer will reset after running each task")
             self.sos_id, self.eos_id = self.asr_model.sos_id, self.asr_model.eos_id

@@ -146,6 +146,29 @@ def test_flat_adam_and_sgd_match_oracle():
         torch.testing.assert_close(p.cpu(), w.detach(), rtol=2e-6, atol=2e-7)
 
 
+def test_flat_radam_matches_torch_radam():
+    """optimizer_cls 'RAdam' (transformer_torch_trainer.py:36-41): 12 steps against torch.optim.RAdam on the CPU -- the first
+    five run in the unrectified phase (rho_t <= 5 at beta2 = 0.999), the rest with the rectification term; with and without the
+    L2 weight-decay term."""
+    from masr_amd.optimizer import FlatRAdam
+    eng = MasrEngine(TINY, ODIM)
+    g = torch.Generator().manual_seed(2)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    for wd in (0.0, 1e-2):
+        w = torch.nn.Parameter(p0.clone())
+        ref = torch.optim.RAdam([w], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+        p = p0.clone().cuda()
+        opt = FlatRAdam(eng, p, betas=(0.9, 0.999), eps=1e-8, lr=1e-3, weight_decay=wd)
+        for t in range(12):
+            gr = torch.randn(n, generator=g)
+            w.grad = gr.clone()
+            ref.step()
+            opt.grad = gr.cuda()
+            opt.step()
+            torch.testing.assert_close(p.cpu(), w.detach(), rtol=3e-6, atol=3e-7, msg=f"step {t + 1}, weight_decay {wd}")
+
+
 def _common(tmp_path, extra_model):
     data = tmp_path / "data"
     data.mkdir(exist_ok=True)
