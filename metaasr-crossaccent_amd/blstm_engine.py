@@ -30,8 +30,13 @@ class BlstmEngine:
         e = model_para["encoder"]
         rates = [int(v) for v in e["sample_rate"].split("_")]
         drops = [float(v) for v in e["dropout"].split("_")]
-        if any(r != 1 for r in rates) or any(d != 0 for d in drops):
-            raise NotImplementedError("BLSTM encoder: sample_rate 1 and dropout 0 per layer (the shipped config/blstm settings)")
+        # `dropout` goes to nn.LSTM(dropout=..., num_layers=1) in the reference (src/modules/encoder.py:86-90), where torch applies
+        # it only BETWEEN stacked layers: with one layer per module it is a no-op (torch warns), so any value gives the same
+        # results and is accepted here.  Sub-sampling between layers is not built (the shipped config uses 1_1_1).
+        if len(drops) != len(rates):
+            raise ValueError("encoder.sample_rate and encoder.dropout must list one value per BLSTM layer")
+        if any(r != 1 for r in rates):
+            raise NotImplementedError("BLSTM encoder: sample_rate 1 per layer (the shipped config/blstm setting)")
         self.device = torch.device(device)
         self.odim = odim
         self.cfg = BlstmConfig(idim=e["idim"], odim=odim, enc_dim=e["enc_dim"], proj_dim=e["proj_dim"], enc_odim=e["odim"], nlayers=len(rates))
