@@ -213,6 +213,9 @@ int masr_test_gemm_dropout(const uint16_t* A, int64_t lda, const uint16_t* B, in
                            uint32_t seed, uint32_t site, float* C32, int64_t ldc, void* stream);
 int masr_test_attention_dropout(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* lse, int B, int H,
                                 int Tq, int Tk, int hd, float drop_p, uint32_t seed, uint32_t site, void* stream);
+/* the NT GEMM with any combination of its fused epilogue stages (tools/bench_gemm_epi.py: what each stage costs per launch) */
+int masr_test_gemm_epi(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int K, const float* bias, int relu,
+                       float drop_p, const float* residual, const uint16_t* mask, float* C32, uint16_t* C16, void* stream);
 int masr_test_conv3x3(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, uint16_t* out,
                       int B, int H, int W, int CIN, int COUT, void* stream);
 /* dgrad/fused-pool flavours of the same kernel: mask (optional, same shape as out) zeroes outputs where mask <= 0;

@@ -69,7 +69,9 @@ struct Acts {
     float* ln_slab; int64_t ln_slab_floats;                // one region per LayerNorm backward (grouped reduce)
     float* wg_slab;                                        // split-K partials: (WG_SPLIT-1) x nparams
 };
-constexpr int WG_SPLIT = 4;
+constexpr int WG_SPLIT_MAX = 4;
+// split-K factor of the encoder-row weight gradients (MASR_WG_SPLIT = 1..4 for A/B runs)
+static const int WG_SPLIT = [] { const char* e = getenv("MASR_WG_SPLIT"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > WG_SPLIT_MAX ? WG_SPLIT_MAX : v); }();
 
 }  // namespace
 
@@ -232,7 +234,7 @@ void plan_acts(const masr_model* m, Arena& ar, Acts& a, int B, int T, int L, boo
         a.ln_slab_floats = 0;
         for (int i = 0; i < nln; ++i) a.ln_slab_floats += mk_layernorm_bwd_slab_floats((int)(i < 2 * m->NE + 1 ? re : rd), E);
         a.ln_slab = ar.get<float>(a.ln_slab_floats);
-        a.wg_slab = ar.get<float>((int64_t)(WG_SPLIT - 1) * m->nparams);
+        a.wg_slab = ar.get<float>((int64_t)(WG_SPLIT_MAX - 1) * m->nparams);
         a.ge_a = ar.get<float>(re * E); a.ge_b = ar.get<float>(re * E); a.gd_a = ar.get<float>(rd * E); a.gd_b = ar.get<float>(rd * E);
         a.dmem32 = ar.get<float>(re * E); a.v2e_g32 = ar.get<float>((int64_t)E * m->F);
         a.ge16 = ar.get<bf16>(re * E);
@@ -766,7 +768,7 @@ static int backward(Ctx& c, const float* xs) {
     CK(flush_ln_reduce(c));
     // ---- combine the split-K partials of all Linear gradients, then add the embedding rows into the (tied) table
     { Prof p(m, MASR_PROF_MISC, s);
-      CK(mk_split_reduce(G, a.wg_slab, WG_SPLIT - 1, m->nparams, m->d_ranges, m->nranges, s));
+      if (WG_SPLIT > 1) CK(mk_split_reduce(G, a.wg_slab, WG_SPLIT - 1, m->nparams, m->d_ranges, m->nranges, s));
       CK(mk_embed_bwd(a.tok_in, g_dec_in, G + m->embed_w, a.rows_d, m->C, E, m->cfg.tie_weights ? 1 : 0, c.p_pos, c.seed, a.site_emb, s, c.seed_ptr)); }
     return 0;
 }
@@ -1127,6 +1129,14 @@ int masr_test_attention_dropout(const uint16_t* q, const uint16_t* k, const uint
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ldq = a.ldk = a.ldv = E; a.o = (bf16*)o; a.ldo = E; a.lse = lse;
     a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.drop_p = drop_p; a.seed = seed; a.site = site;
     return mk_attn_fwd(a, (hipStream_t)stream);
+}
+int masr_test_gemm_epi(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int K, const float* bias, int relu,
+                       float drop_p, const float* residual, const uint16_t* mask, float* C32, uint16_t* C16, void* stream) {
+    GemmArgs g = gemm_args();
+    g.A = (const bf16*)A; g.lda = lda; g.B = (const bf16*)B; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.bias = bias; g.relu = relu;
+    g.drop_p = drop_p; g.seed = 1; g.site = 2; g.residual = residual; g.ldres = N; g.mask = (const bf16*)mask; g.ldmask = N;
+    g.C32 = C32; g.ldc = N; g.C16 = (bf16*)C16; g.ldc16 = N;
+    return mk_gemm(g, (hipStream_t)stream);
 }
 int masr_test_conv3x3(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, uint16_t* out, int B, int H, int W, int CIN,
                       int COUT, void* stream) {
