@@ -1,5 +1,5 @@
 # One measurement pass for profiles/: default bench line, kernel-trace stats (default and single task), HBM-traffic PMC passes.
-# Run on the GPU box from the repo root: bash tools/measure_round.sh ; then here: python tools/save_profiles.py rNN && python tools/pmc_traffic.py rNN <sha>
+# Run on the GPU box from the repo root: bash tools/measure_round.sh ; then here: python tools/save_profiles.py rNN && python tools/pmc_traffic.py rNN <sha> && python tools/sq_counters.py rNN
 set -e
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 O=gpurun_out
@@ -11,4 +11,6 @@ rocprofv3 --kernel-trace --stats -d $O/prof_single -o s --output-format csv -- p
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace -d $O/pmc_$C -o p --output-format csv -- python3 bench.py --steps 3 --warmup 2 $Q --tasks-per-gpu 1 > $O/pmc_$C.log 2>&1 && echo "pmc $C done"
 done
+rm -rf $O/pmc_sq
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAIT_INST_LDS --kernel-trace -d $O/pmc_sq -o p --output-format csv -- python3 bench.py --steps 3 --warmup 2 $Q --tasks-per-gpu 1 > $O/pmc_sq.log 2>&1 && echo "pmc sq done"
 find $O/prof_k4 $O/prof_single -name "*kernel_trace.csv" -delete      # (the per-dispatch traces are large; the stats files are what is kept)

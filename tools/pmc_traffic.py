@@ -27,7 +27,8 @@ SLOTS = {   # bench.py roofline slot -> substring of the kernel name
 
 
 def per_launch(counter):
-    files = glob.glob(f"gpurun_out/pmc_{counter}/**/*counter_collection.csv", recursive=True)
+    import os
+    files = sorted(glob.glob(f"gpurun_out/pmc_{counter}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime, reverse=True)
     assert files, f"no counter_collection.csv under gpurun_out/pmc_{counter}"
     acc = defaultdict(list)
     for r in csv.DictReader(open(files[0])):
