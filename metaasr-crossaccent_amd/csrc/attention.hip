@@ -252,13 +252,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 // ---------------------------------------------------------------------------- backward
 // delta_i = rowsum(dO_i * O_i) is not a separate pass: the dQ workgroups take it from the dO / O fragments they hold anyway,
 // the dK/dV workgroups compute it for each query block while that block's tiles are in flight (two 16-byte loads per thread).
+// LDS of the two bodies of attn_bwd_kernel is ONE buffer (a workgroup runs one body or the other): as separate __shared__ arrays the
+// kernel was charged the SUM (69 KB -> two workgroups per CU); the union is 39 KB -> four per CU
+template <int HD> struct BwdSmem {
+    static constexpr int LD = Cfg<HD>::LD;
+    static constexpr size_t TILE = sizeof(bf16) * BLK * LD, SCR = sizeof(bf16) * 4 * 16 * LDP;
+    static constexpr size_t DQ = 2 * TILE + SCR, DKV = 2 * TILE + 2 * SCR + sizeof(float) * 2 * BLK;
+    static constexpr size_t BYTES = DQ > DKV ? DQ : DKV;
+};
 template <int HD>
-__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx) {
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx, char* smem) {
     using C = Cfg<HD>;
     constexpr int LD = C::LD, KS = C::KS, DT = C::DT;
-    __shared__ __attribute__((aligned(16))) bf16 sK[BLK * LD];
-    __shared__ __attribute__((aligned(16))) bf16 sV[BLK * LD];
-    __shared__ __attribute__((aligned(16))) bf16 sP[4][16 * LDP];
+    bf16* sK = reinterpret_cast<bf16*>(smem);
+    bf16* sV = sK + BLK * LD;
+    bf16 (*sP)[16 * LDP] = reinterpret_cast<bf16 (*)[16 * LDP]>(sV + BLK * LD);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, h = blockIdx.y, q0 = bx * BLK;
@@ -348,14 +356,15 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
 }
 
 template <int HD>
-__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int bx) {
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int bx, char* smem) {
     using C = Cfg<HD>;
     constexpr int LD = C::LD, KS = C::KS, DT = C::DT;
-    __shared__ __attribute__((aligned(16))) bf16 sQ[BLK * LD];
-    __shared__ __attribute__((aligned(16))) bf16 sDO[BLK * LD];
-    __shared__ __attribute__((aligned(16))) bf16 sP[4][16 * LDP];
-    __shared__ __attribute__((aligned(16))) bf16 sDS[4][16 * LDP];
-    __shared__ float sLse[BLK], sDl[BLK];
+    bf16* sQ = reinterpret_cast<bf16*>(smem);
+    bf16* sDO = sQ + BLK * LD;
+    bf16 (*sP)[16 * LDP] = reinterpret_cast<bf16 (*)[16 * LDP]>(sDO + BLK * LD);
+    bf16 (*sDS)[16 * LDP] = sP + 4;
+    float* sLse = reinterpret_cast<float*>(sDS + 4);
+    float* sDl = sLse + BLK;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, h = blockIdx.y, k0 = bx * BLK;
@@ -470,8 +479,9 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
 // halves are independent given delta, so they overlap instead of queueing as two launch-latency-bound kernels.
 template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a, int nqb) {
-    if ((int)blockIdx.x < nqb) attn_bwd_dq_body<HD>(a, blockIdx.x);
-    else attn_bwd_dkv_body<HD>(a, blockIdx.x - nqb);
+    __shared__ __attribute__((aligned(16))) char smem[BwdSmem<HD>::BYTES];
+    if ((int)blockIdx.x < nqb) attn_bwd_dq_body<HD>(a, blockIdx.x, smem);
+    else attn_bwd_dkv_body<HD>(a, blockIdx.x - nqb, smem);
 }
 
 template <int HD>
