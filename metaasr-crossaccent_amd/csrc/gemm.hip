@@ -409,7 +409,10 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
 #ifndef MASR_GLDS_NBUF_SMALL
 #define MASR_GLDS_NBUF_SMALL 3
 #endif
-    constexpr int NBUF = (BM * BN >= 128 * 128) ? 2 : MASR_GLDS_NBUF_SMALL;   // 128x128: 2 x 32 KB keeps two workgroups per CU
+#ifndef MASR_GLDS_NBUF_MID
+#define MASR_GLDS_NBUF_MID 3
+#endif
+    constexpr int NBUF = (BM * BN >= 128 * 128) ? 2 : (BM * BN >= 128 * 64) ? MASR_GLDS_NBUF_MID : MASR_GLDS_NBUF_SMALL;   // 128x128: 2 x 32 KB keeps two workgroups per CU
     constexpr size_t OUT_BYTES = sizeof(float) * BM * LDC;
     __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF > OUT_BYTES ? NBUF * BUF : OUT_BYTES];
     typedef __attribute__((address_space(1))) const void gptr_t;
