@@ -40,7 +40,7 @@ class TaskSharder:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("MASR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             local = int(os.environ.get("LOCAL_RANK", "0"))
             torch.cuda.set_device(local)
@@ -75,6 +75,14 @@ class TaskSharder:
         if self.world == 1:
             return
         import torch.distributed as dist
+        if buf.device.type == "cuda" and self.backend == "gloo":
+            # rehearsal of the multi-rank path on a box with fewer GPUs than ranks (gloo has no device collectives worth the
+            # name): through host memory, synchronously.  The RCCL path below is the product.
+            torch.cuda.current_stream(buf.device).synchronize()
+            host = buf.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            buf.copy_(host)
+            return
         if buf.device.type == "cuda":
             side = self._side_stream(buf.device)
             side.wait_stream(torch.cuda.current_stream(buf.device))

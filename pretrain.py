@@ -68,6 +68,8 @@ def main(argv=None):
 
     TaskSharder.init_process_group()
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MASR_DIST_BACKEND") == "gloo" and torch.cuda.device_count() > 0:
+        local %= torch.cuda.device_count()                      # gloo rehearsal: more ranks than GPUs share the cards
     paras.device = f"cuda:{local}"
     paras.hbm_shards_device = paras.device if paras.hbm_shards else None
 

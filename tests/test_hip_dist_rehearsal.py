@@ -1,0 +1,43 @@
+"""The multi-rank PRODUCT path with the real HIP engine: `pretrain.py --algo fomaml` (config-3 toy workspace, 4 accents) as 2 ranks
+started by torch.distributed.run, both on the one GPU of the box, meta-gradient exchange over gloo (MASR_DIST_BACKEND=gloo:
+RCCL refuses two ranks on one device).  Everything but the transport is the 8-GPU code path: rank-consistent index draws,
+task-per-rank sharding, padding rounds, replicated Noam-Adam, rank-0 evaluation + barrier, rank-0 checkpoints.  The two ranks must
+end with identical meta weights, equal to the single-process CLI run up to the summation order of the four task gradients."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+
+from oracle.make_goldens import cfg3_workspace  # noqa: E402
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_two_rank_cli_run_matches_single_process(golden_dir, tmp_path):
+    cfg = cfg3_workspace(tmp_path, golden_dir)
+    yaml.safe_dump(cfg, open(tmp_path / "cfg3.yaml", "w"))
+    worker = str(ROOT / "tests" / "_dist_pretrain_worker.py")
+    env = dict(os.environ, PYTHONPATH=str(ROOT), MASR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r1 = subprocess.run([sys.executable, worker, str(tmp_path), "w1"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29653", worker, str(tmp_path), "w2"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    one = torch.load(tmp_path / "w1_r0.pt")
+    a, b = torch.load(tmp_path / "w2_r0.pt"), torch.load(tmp_path / "w2_r1.pt")
+    assert one["step"] == a["step"] == b["step"] == 5
+    assert torch.equal(a["meta"], b["meta"]), "replicated Noam-Adam must leave identical meta weights on both ranks"
+    # 4 task gradients summed in task order (one process) vs (t0 + t2) + (t1 + t3) after two all-reduces: fp32 rounding of the
+    # gradient only; Adam's step is <= lr = 3.2e-8 per element and meta-step, 4 meta-steps
+    assert float((a["meta"] - one["meta"]).abs().max()) <= 4 * 2.5 * 3.2e-8 + 1.2e-7
+    log_dir = tmp_path / "testing-logs" / "pretrain" / "cfg3" / "fomaml" / "w2" / "canada" / "0"
+    for f in ("snapshot.step.4", "model.wer.best", "best_wer", "dev_avg_wer", "train_loss", "global_step"):
+        assert (log_dir / f).exists(), f
+    assert len((log_dir / "dev_avg_wer").read_text().splitlines()) == 2           # rank 0 evaluated after meta-steps 2 and 4
