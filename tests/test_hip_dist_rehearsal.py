@@ -41,3 +41,28 @@ def test_two_rank_cli_run_matches_single_process(golden_dir, tmp_path):
     for f in ("snapshot.step.4", "model.wer.best", "best_wer", "dev_avg_wer", "train_loss", "global_step"):
         assert (log_dir / f).exists(), f
     assert len((log_dir / "dev_avg_wer").read_text().splitlines()) == 2           # rank 0 evaluated after meta-steps 2 and 4
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` (no launcher, no WORLD_SIZE) starts two ranks itself and prints exactly ONE JSON line on stdout
+    with n_gpus = 2, the weak-scaling value, the long-run leg and the whole-meta-step leg (exchange over gloo here, both ranks on
+    the one GPU of the box); a --gpus that disagrees with WORLD_SIZE is refused."""
+    import json
+    env = dict(os.environ, MASR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--tasks-per-gpu", "2",
+                        "--no-cpu-baseline", "--long-seconds", "0.3", "--meta-steps", "2"], cwd=tmp_path, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["unit"] == "utt/s" and d["value"] > 0
+    assert d["config"]["tasks"] == 4 and d["long_run"]["seconds"] >= 0.3
+    ms = d["meta_step"]
+    assert ms["tasks"] == 4 and ms["allreduces_per_meta_step"] == 2 and ms["ms"] >= ms["ms_without_exchange"] > 0 and ms["allreduce_ms_isolated"] > 0
+    assert "roofline" in d and d["roofline"]["slot"] in d["roofline"]["launches"]
+    bad = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1"], cwd=tmp_path, env=dict(env, WORLD_SIZE="1"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
