@@ -137,11 +137,11 @@ class FOMetaASRInterface(PretrainInterface):
                 info = self.info_from_stats(slot['engine'])
         out[i] = (info, grad_norm)
 
-    def _run_tasks_concurrently(self, task_ids):
-        # (task_ids: the drawn tasks of this rank, see _draw_meta_batch)
-        """tasks_per_gpu > 1: batches are drawn on the main thread in the reference's order (the samplers share RNG
-        streams), then waves of K tasks run concurrently; gradients are accumulated in task order -> deterministic."""
-        fetched = [(a, [(i, f.result()) for i, f in tr], (val[0], val[1].result())) for a, tr, val in task_ids]
+    def _run_tasks_concurrently(self, drawn):
+        """tasks_per_gpu > 1.  `drawn` = this rank's tasks of the meta-step as _draw_meta_batch returns them (indices drawn on
+        the main thread in the reference's order, batches being assembled by the collate pool).  Waves of K tasks run
+        concurrently, one replica + stream + host thread each; gradients are accumulated in task order -> deterministic."""
+        fetched = [(a, [(i, f.result()) for i, f in tr], (val[0], val[1].result())) for a, tr, val in drawn]
         main = torch.cuda.current_stream()
         K = self.tasks_per_gpu
         for w0 in range(0, len(fetched), K):
