@@ -169,19 +169,43 @@ __global__ __launch_bounds__(256) void all_shadows_kernel(const float* __restric
     const float* x = P + d.src;
     bf16* p0 = jobs.p[2 * e]; bf16* p1 = jobs.p[2 * e + 1];
     if (d.type == SH_LINEAR) {
+        // 64 x 64 tile: fp32 rows in (4 bytes per lane: the flat parameter buffer guarantees no more than dword alignment),
+        // through LDS, bf16 out as 16 bytes per lane in BOTH layouts -- the pass is bound by vector-memory instructions, and
+        // 2-byte-per-lane stores made 32 of them per wave and tile where 4 suffice
         const int tc = (d.K + SH_TILE - 1) / SH_TILE;
         const int r0 = (blk / tc) * SH_TILE, c0 = (blk % tc) * SH_TILE;
         __shared__ float t[SH_TILE][SH_TILE + 1];
         const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 4 rows per pass, 64 consecutive columns per row
         for (int k = ty; k < SH_TILE; k += 4) {
             const bool ok = r0 + k < d.N && c0 + tx < d.K;
-            const float v = ok ? x[(long)(r0 + k) * d.K + c0 + tx] : 0.f;
-            t[k][tx] = v;
-            if (ok) p0[(long)(r0 + k) * d.K + c0 + tx] = (bf16)v;
+            t[k][tx] = ok ? x[(long)(r0 + k) * d.K + c0 + tx] : 0.f;
         }
         __syncthreads();
-        for (int k = ty; k < SH_TILE; k += 4)
-            if (c0 + k < d.K && r0 + tx < d.N) p1[(long)(c0 + k) * d.ldt + r0 + tx] = (bf16)t[tx][k];
+        const int sub = threadIdx.x & 7, line = threadIdx.x >> 3;        // 8 lanes x 8 elements = one 64-element line
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int l = line + 32 * pass;
+            {   // k16 [N][K]: line = tile row
+                const int r = r0 + l, c = c0 + sub * 8;
+                if (r < d.N && c < d.K) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16)t[l][sub * 8 + e];
+                    if (c + 8 <= d.K) st8(p0 + (long)r * d.K + c, o);
+                    else for (int e = 0; c + e < d.K; ++e) p0[(long)r * d.K + c + e] = o[e];
+                }
+            }
+            {   // t16 [K][ldt]: line = tile column, elements run over the tile's rows
+                const int c = c0 + l, r = r0 + sub * 8;
+                if (c < d.K && r < d.N) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16)t[sub * 8 + e][l];
+                    if (r + 8 <= d.N) st8(p1 + (long)c * d.ldt + r, o);
+                    else for (int e = 0; r + e < d.N; ++e) p1[(long)c * d.ldt + r + e] = o[e];       // (pads of a padded row stay untouched)
+                }
+            }
+        }
     } else if (d.type == SH_CONV) {
         const int CO = d.N, CI = d.K, n = CO * CI * 9;
         const int i = blk * 256 + threadIdx.x;
