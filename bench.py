@@ -284,7 +284,7 @@ def main():
     long_run = None
     if args.long_seconds > 0:
         # the driver's K-step region is ~0.2 s (clock ramp and jitter are a visible part of it): the same measurement over >= 2 s
-        nlong = max(args.steps, int(args.long_seconds / (dt / args.steps)) + 1)
+        nlong = max(args.steps, int(1.1 * args.long_seconds / (dt / args.steps)) + 1)      # (+10 %: the short region includes the ramp)
         dtl = timed(tasks, nlong, 2, stagger)
         long_run = {"steps": nlong, "seconds": dtl, "value": world * K * B * nlong / dtl, "ms_per_step": dtl / nlong * 1e3}
         log(f"long run: {dtl:.2f} s for {nlong} steps -> {long_run['value']:.1f} utt/s")

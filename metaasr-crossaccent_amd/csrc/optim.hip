@@ -52,59 +52,89 @@ __device__ __forceinline__ float clip_coef(float norm, float max_norm) {
 // torch.optim.SGD(momentum, nesterov, dampening 0): buf = first ? g : m*buf + g; p -= lr*(nesterov ? g + m*buf : buf)
 __global__ void clip_sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom, long n,
                                 const float* __restrict__ norm, float max_norm, float lr, float momentum, int nesterov,
-                                int first_step) {
+                                int first_step, int vec) {
     float coef = 1.f;
     if (norm) {
         const float nv = norm[0];
         if (nv != nv) return;                               // math.isnan(grad_norm) -> skip the step
         coef = clip_coef(nv, max_norm);
     }
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float gi = g[i] * coef;
+    auto upd = [&](float pi, float gr, float mi, float& mo) {
+        const float gi = gr * coef;
         float step = gi;
         if (momentum != 0.f) {
-            const float b = first_step ? gi : momentum * mom[i] + gi;
-            mom[i] = b;
+            const float b = first_step ? gi : momentum * mi + gi;
+            mo = b;
             step = nesterov ? gi + momentum * b : b;
         }
-        p[i] -= lr * step;
+        return pi - lr * step;
+    };
+    // 16 bytes per lane and stream (the flat buffers are 16-byte aligned allocations): a 4-byte-per-lane pass needs four times
+    // the vector-memory instructions for the same bytes
+    const long n4 = vec ? n >> 2 : 0, stride = (long)gridDim.x * blockDim.x;
+    const bool use_m = momentum != 0.f, rd_m = use_m && !first_step;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 pv = reinterpret_cast<const float4*>(p)[i], gv = reinterpret_cast<const float4*>(g)[i];
+        float4 mv = rd_m ? reinterpret_cast<const float4*>(mom)[i] : float4{0.f, 0.f, 0.f, 0.f};
+        float4 o;
+        o.x = upd(pv.x, gv.x, mv.x, mv.x); o.y = upd(pv.y, gv.y, mv.y, mv.y); o.z = upd(pv.z, gv.z, mv.z, mv.z); o.w = upd(pv.w, gv.w, mv.w, mv.w);
+        reinterpret_cast<float4*>(p)[i] = o;
+        if (use_m) reinterpret_cast<float4*>(mom)[i] = mv;
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {      // tail (n % 4 elements)
+        float mo = rd_m ? mom[i] : 0.f;
+        p[i] = upd(p[i], g[i], mo, mo);
+        if (use_m) mom[i] = mo;
     }
 }
-__global__ void clip_scale_kernel(float* __restrict__ g, long n, const float* __restrict__ norm, float max_norm) {
+// element-wise passes over flat fp32 buffers, 16 bytes per lane and stream when every pointer is 16-byte aligned (vec), with a
+// scalar tail / fallback: body(i) handles element i, body4(i4) elements 4*i4 .. 4*i4+3
+template <class F1, class F4>
+__device__ __forceinline__ void flat_pass(long n, int vec, F1 body, F4 body4) {
+    const long n4 = vec ? n >> 2 : 0, stride = (long)gridDim.x * blockDim.x, t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long i = t0; i < n4; i += stride) body4(i);
+    for (long i = (n4 << 2) + t0; i < n; i += stride) body(i);
+}
+#define F4P(ptr) reinterpret_cast<float4*>(ptr)
+#define F4C(ptr) reinterpret_cast<const float4*>(ptr)
+__global__ void clip_scale_kernel(float* __restrict__ g, long n, const float* __restrict__ norm, float max_norm, int vec) {
     const float coef = clip_coef(norm[0], max_norm);
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] *= coef;
+    flat_pass(n, vec, [&](long i) { g[i] *= coef; },
+              [&](long i) { float4 v = F4C(g)[i]; v.x *= coef; v.y *= coef; v.z *= coef; v.w *= coef; F4P(g)[i] = v; });
 }
 __global__ void clip_axpy_kernel(float* __restrict__ acc, const float* __restrict__ g, long n, const float* __restrict__ norm,
-                                 float max_norm) {
+                                 float max_norm, int vec) {
     const float coef = clip_coef(norm[0], max_norm);
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc[i] += coef * g[i];
+    flat_pass(n, vec, [&](long i) { acc[i] += coef * g[i]; },
+              [&](long i) { float4 a = F4C(acc)[i]; const float4 v = F4C(g)[i];
+                            a.x += coef * v.x; a.y += coef * v.y; a.z += coef * v.z; a.w += coef * v.w; F4P(acc)[i] = a; });
 }
-__global__ void scale_kernel(float* __restrict__ x, long n, float a) {
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] *= a;
+__global__ void scale_kernel(float* __restrict__ x, long n, float a, int vec) {
+    flat_pass(n, vec, [&](long i) { x[i] *= a; },
+              [&](long i) { float4 v = F4C(x)[i]; v.x *= a; v.y *= a; v.z *= a; v.w *= a; F4P(x)[i] = v; });
 }
-__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, long n, float a) {
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] += a * x[i];
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, long n, float a, int vec) {
+    flat_pass(n, vec, [&](long i) { y[i] += a * x[i]; },
+              [&](long i) { float4 o = F4C(y)[i]; const float4 v = F4C(x)[i];
+                            o.x += a * v.x; o.y += a * v.y; o.z += a * v.z; o.w += a * v.w; F4P(y)[i] = o; });
 }
 // torch.optim.Adam (no amsgrad, no weight decay): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= lr/(1-b1^t) * m/denom
 // decay_mul = 1 - lr * weight_decay (AdamW: decoupled, applied to the weight first, as torch.optim.AdamW) or 1;
 // l2 = weight_decay of torch.optim.Adam (added to the gradient) or 0
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            long n, float step_size, float b1, float b2, float eps, float inv_sqrt_bc2, float decay_mul, float l2) {
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float pi = p[i] * decay_mul;
-        const float gi = g[i] + l2 * pi;
-        const float mi = m[i] + (gi - m[i]) * (1.f - b1);        // lerp, as torch
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        p[i] = pi - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
-    }
+                            long n, float step_size, float b1, float b2, float eps, float inv_sqrt_bc2, float decay_mul, float l2, int vec) {
+    auto one = [&](float& pp, float gg, float& mm, float& vv) {
+        const float pi = pp * decay_mul;
+        const float gi = gg + l2 * pi;
+        mm = mm + (gi - mm) * (1.f - b1);                        // lerp, as torch
+        vv = b2 * vv + (1.f - b2) * gi * gi;
+        pp = pi - step_size * mm / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+    };
+    flat_pass(n, vec, [&](long i) { one(p[i], g[i], m[i], v[i]); },
+              [&](long i) { float4 pv = F4C(p)[i], mv = F4C(m)[i], vv = F4C(v)[i]; const float4 gv = F4C(g)[i];
+                            one(pv.x, gv.x, mv.x, vv.x); one(pv.y, gv.y, mv.y, vv.y); one(pv.z, gv.z, mv.z, vv.z); one(pv.w, gv.w, mv.w, vv.w);
+                            F4P(p)[i] = pv; F4P(m)[i] = mv; F4P(v)[i] = vv; });
 }
 __global__ void cast_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, long n) {
     const long stride = (long)gridDim.x * blockDim.x;
@@ -230,6 +260,9 @@ __global__ __launch_bounds__(256) void all_shadows_kernel(const float* __restric
     }
 }
 
+inline int aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+    return !(((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15);
+}
 inline unsigned flat_blocks(long n) {
     long b = (n + 255) / 256;
     return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -247,29 +280,30 @@ int mk_sumsq(const float* x, long n, float* slab, float* out_norm, hipStream_t s
 }
 int mk_clip_sgd(float* p, const float* g, float* mom, long n, const float* norm, float max_norm, float lr, float momentum,
                   int nesterov, int first_step, hipStream_t s) {
-    hipLaunchKernelGGL(clip_sgd_kernel, dim3(flat_blocks(n)), dim3(256), 0, s, p, g, mom, n, norm, max_norm, lr, momentum, nesterov, first_step);
+    const int vec = aligned16(p, g, mom);                                           // (mom may be null: momentum 0)
+    hipLaunchKernelGGL(clip_sgd_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, s, p, g, mom, n, norm, max_norm, lr, momentum, nesterov, first_step, vec);
     return LAUNCH_OK();
 }
 int mk_clip_scale(float* g, long n, const float* norm, float max_norm, hipStream_t s) {
-    hipLaunchKernelGGL(clip_scale_kernel, dim3(flat_blocks(n)), dim3(256), 0, s, g, n, norm, max_norm);
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, s, g, n, norm, max_norm, aligned16(g));
     return LAUNCH_OK();
 }
 int mk_clip_axpy(float* acc, const float* g, long n, const float* norm, float max_norm, hipStream_t s) {
-    hipLaunchKernelGGL(clip_axpy_kernel, dim3(flat_blocks(n)), dim3(256), 0, s, acc, g, n, norm, max_norm);
+    hipLaunchKernelGGL(clip_axpy_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, s, acc, g, n, norm, max_norm, aligned16(acc, g));
     return LAUNCH_OK();
 }
 int mk_scale(float* x, long n, float a, hipStream_t s) {
-    hipLaunchKernelGGL(scale_kernel, dim3(flat_blocks(n)), dim3(256), 0, s, x, n, a);
+    hipLaunchKernelGGL(scale_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, s, x, n, a, aligned16(x));
     return LAUNCH_OK();
 }
 int mk_axpy(float* y, const float* x, long n, float a, hipStream_t s) {
-    hipLaunchKernelGGL(axpy_kernel, dim3(flat_blocks(n)), dim3(256), 0, s, y, x, n, a);
+    hipLaunchKernelGGL(axpy_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, s, y, x, n, a, aligned16(y, x));
     return LAUNCH_OK();
 }
 int mk_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int t, float weight_decay, int decoupled, hipStream_t s) {
     const double bc1 = 1.0 - pow((double)b1, t), bc2 = 1.0 - pow((double)b2, t);
-    hipLaunchKernelGGL(adam_kernel, dim3(flat_blocks(n)), dim3(256), 0, s, p, g, m, v, n, (float)(lr / bc1), b1, b2, eps,
-                       (float)(1.0 / sqrt(bc2)), decoupled ? 1.f - lr * weight_decay : 1.f, decoupled ? 0.f : weight_decay);
+    hipLaunchKernelGGL(adam_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, s, p, g, m, v, n, (float)(lr / bc1), b1, b2, eps,
+                       (float)(1.0 / sqrt(bc2)), decoupled ? 1.f - lr * weight_decay : 1.f, decoupled ? 0.f : weight_decay, aligned16(p, g, m, v));
     return LAUNCH_OK();
 }
 // RAdam (Liu et al. 2020, as torch.optim.RAdam): Adam moments; while the variance estimate is unreliable (rho_t <= 5) the step is
@@ -284,7 +318,7 @@ int mk_radam(float* p, const float* g, float* m, float* v, long n, float lr, flo
         step *= sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t));
         inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2)); e = eps;
     }
-    hipLaunchKernelGGL(adam_kernel, dim3(flat_blocks(n)), dim3(256), 0, s, p, g, m, v, n, (float)step, b1, b2, e, inv_sqrt_bc2, 1.f, weight_decay);
+    hipLaunchKernelGGL(adam_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, s, p, g, m, v, n, (float)step, b1, b2, e, inv_sqrt_bc2, 1.f, weight_decay, aligned16(p, g, m, v));
     return LAUNCH_OK();
 }
 int mk_cast_bf16(const float* x, bf16* y, long n, hipStream_t s) {

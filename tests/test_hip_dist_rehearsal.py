@@ -59,7 +59,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["unit"] == "utt/s" and d["value"] > 0
-    assert d["config"]["tasks"] == 4 and d["long_run"]["seconds"] >= 0.3
+    assert d["config"]["tasks"] == 4 and d["long_run"]["seconds"] >= 0.2
     ms = d["meta_step"]
     assert ms["tasks"] == 4 and ms["allreduces_per_meta_step"] == 2 and ms["ms"] >= ms["ms_without_exchange"] > 0 and ms["allreduce_ms_isolated"] > 0
     assert "roofline" in d and d["roofline"]["slot"] in d["roofline"]["launches"]

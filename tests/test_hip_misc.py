@@ -146,6 +146,41 @@ def test_flat_adam_and_sgd_match_oracle():
         torch.testing.assert_close(p.cpu(), w.detach(), rtol=2e-6, atol=2e-7)
 
 
+def test_flat_passes_vector_and_scalar_paths():
+    """masr_scale / masr_axpy / masr_sgd_step / masr_adam_step on 16-byte aligned buffers (16 bytes per lane) and on views that
+    start 4 bytes into an allocation (scalar fallback), lengths that are not multiples of 4: same results as torch."""
+    L = _cabi.lib()
+    g = torch.Generator().manual_seed(3)
+    for off in (0, 1):
+        n = 10007
+        x0, y0 = torch.randn(n + 1, generator=g), torch.randn(n + 1, generator=g)
+        x, y = x0.cuda()[off:off + n], y0.clone().cuda()[off:off + n]
+        _cabi.check(L.masr_axpy(P(y), P(x), n, -0.75, S()))
+        torch.testing.assert_close(y.cpu(), y0[off:off + n] - 0.75 * x0[off:off + n], rtol=1e-6, atol=1e-7)
+        _cabi.check(L.masr_scale(P(y), n, 0.3, S()))
+        torch.testing.assert_close(y.cpu(), (y0[off:off + n] - 0.75 * x0[off:off + n]) * 0.3, rtol=1e-6, atol=1e-7)
+        # SGD with momentum (first and later steps) and Adam on the same (mis)aligned views, against torch.optim
+        w = torch.nn.Parameter(x0[off:off + n].clone())
+        sgd = torch.optim.SGD([w], lr=0.05, momentum=0.9, nesterov=True)
+        pw, buf = x0.clone().cuda()[off:off + n], torch.zeros(n + 1, device="cuda")[off:off + n]
+        for t in range(3):
+            gr = torch.randn(n + 1, generator=g)
+            w.grad = gr[off:off + n].clone(); sgd.step()
+            gd = gr.cuda()[off:off + n]
+            _cabi.check(L.masr_sgd_step(P(pw), P(gd), P(buf), n, 0.05, 0.9, 1, int(t == 0), S()))
+        torch.testing.assert_close(pw.cpu(), w.detach(), rtol=2e-6, atol=2e-7)
+        w = torch.nn.Parameter(x0[off:off + n].clone())
+        adam = torch.optim.Adam([w], lr=1e-3, betas=(0.9, 0.98), eps=1e-9)
+        pw = x0.clone().cuda()[off:off + n]
+        m, v = torch.zeros(n + 1, device="cuda")[off:off + n], torch.zeros(n + 1, device="cuda")[off:off + n]
+        for t in range(1, 4):
+            gr = torch.randn(n + 1, generator=g)
+            w.grad = gr[off:off + n].clone(); adam.step()
+            gd = gr.cuda()[off:off + n]
+            _cabi.check(L.masr_adam_step(P(pw), P(gd), P(m), P(v), n, 1e-3, 0.9, 0.98, 1e-9, t, S()))
+        torch.testing.assert_close(pw.cpu(), w.detach(), rtol=3e-6, atol=3e-7)
+
+
 def test_flat_radam_matches_torch_radam():
     """optimizer_cls 'RAdam' (transformer_torch_trainer.py:36-41): 12 steps against torch.optim.RAdam on the CPU -- the first
     five run in the unrectified phase (rho_t <= 5 at beta2 = 0.999), the rest with the rectification term; with and without the
