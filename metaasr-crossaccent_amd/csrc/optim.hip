@@ -199,16 +199,43 @@ __global__ __launch_bounds__(256) void all_shadows_kernel(const float* __restric
     const float* x = P + d.src;
     bf16* p0 = jobs.p[2 * e]; bf16* p1 = jobs.p[2 * e + 1];
     if (d.type == SH_LINEAR) {
-        // 64 x 64 tile: fp32 rows in (4 bytes per lane: the flat parameter buffer guarantees no more than dword alignment),
-        // through LDS, bf16 out as 16 bytes per lane in BOTH layouts -- the pass is bound by vector-memory instructions, and
-        // 2-byte-per-lane stores made 32 of them per wave and tile where 4 suffice
+        // 64 x 64 tile: fp32 rows in, through LDS, bf16 out as 16 bytes per lane in BOTH layouts -- the pass is bound by
+        // vector-memory instructions: 4-byte loads and 2-byte stores made 48 of them per wave and tile where 9 suffice
         const int tc = (d.K + SH_TILE - 1) / SH_TILE;
         const int r0 = (blk / tc) * SH_TILE, c0 = (blk % tc) * SH_TILE;
         __shared__ float t[SH_TILE][SH_TILE + 1];
-        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 4 rows per pass, 64 consecutive columns per row
-        for (int k = ty; k < SH_TILE; k += 4) {
-            const bool ok = r0 + k < d.N && c0 + tx < d.K;
-            t[k][tx] = ok ? x[(long)(r0 + k) * d.K + c0 + tx] : 0.f;
+        if ((d.K & 3) == 0 && c0 + SH_TILE <= d.K) {
+            // 16-byte loads although the tensor sits at an arbitrary dword offset of the flat buffer (P itself is 16-byte
+            // aligned): every row of the tile starts `mis` floats past a 16-byte boundary (K % 4 == 0: the same for all rows);
+            // 16 lanes fetch the row's 17 ALIGNED float4s (the last lane two of them) and each lane assembles its four
+            // elements from its own vector and its right neighbour's.  The bytes before / behind a row belong to neighbouring
+            // tensors of P (never to the first or the last one): readable, ignored.
+            const int mis = (int)((d.src + (long)r0 * d.K + c0) & 3);
+            const int j = threadIdx.x & 15, rr = threadIdx.x >> 4;          // 16 rows per pass
+#pragma unroll
+            for (int pass = 0; pass < SH_TILE / 16; ++pass) {
+                const int k = rr + 16 * pass;
+                const bool ok = r0 + k < d.N;
+                const float* ab = x + (long)(ok ? r0 + k : r0) * d.K + c0 - mis;
+                const float4 q = *reinterpret_cast<const float4*>(ab + 4 * j);
+                const float4 qx = *reinterpret_cast<const float4*>(ab + 4 * (j == 15 ? 16 : j));      // (lane 15: the 17th vector)
+                float4 nb;
+                nb.x = __shfl_down(q.x, 1, 16); nb.y = __shfl_down(q.y, 1, 16); nb.z = __shfl_down(q.z, 1, 16); nb.w = __shfl_down(q.w, 1, 16);
+                if (j == 15) nb = qx;
+                const float w8[8] = {q.x, q.y, q.z, q.w, nb.x, nb.y, nb.z, nb.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = w8[e];                                                                       // mis == 0
+                    if (mis == 1) v = w8[e + 1]; else if (mis == 2) v = w8[e + 2]; else if (mis == 3) v = w8[e + 3];
+                    t[k][4 * j + e] = ok ? v : 0.f;
+                }
+            }
+        } else {
+            const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 4 rows per pass, 64 consecutive columns per row
+            for (int k = ty; k < SH_TILE; k += 4) {
+                const bool ok = r0 + k < d.N && c0 + tx < d.K;
+                t[k][tx] = ok ? x[(long)(r0 + k) * d.K + c0 + tx] : 0.f;
+            }
         }
         __syncthreads();
         const int sub = threadIdx.x & 7, line = threadIdx.x >> 3;        // 8 lanes x 8 elements = one 64-element line
