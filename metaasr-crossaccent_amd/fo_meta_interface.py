@@ -137,7 +137,7 @@ class FOMetaASRInterface(PretrainInterface):
                 info = self.info_from_stats(slot['engine'])
         out[i] = (info, grad_norm)
 
-    def _run_tasks_concurrently(self, drawn):
+    def _run_tasks_concurrently(self, drawn, while_running=None):
         """tasks_per_gpu > 1.  `drawn` = this rank's tasks of the meta-step as _draw_meta_batch returns them (indices drawn on
         the main thread in the reference's order, batches being assembled by the collate pool).  Waves of K tasks run
         concurrently, one replica + stream + host thread each; gradients are accumulated in task order -> deterministic."""
@@ -153,6 +153,8 @@ class FOMetaASRInterface(PretrainInterface):
                 sl['stream'].wait_stream(main)                      # meta weights / previous accumulation are ready
                 t = threading.Thread(target=self._task_on_slot, args=(sl, tr, val, out, i))
                 t.start(); threads.append(t)
+            if while_running is not None:                            # host work of the main thread, hidden behind the first wave
+                while_running(); while_running = None
             for t in threads:
                 t.join()
             for i, (accent_id, tr, val) in enumerate(wave):
@@ -200,12 +202,21 @@ class FOMetaASRInterface(PretrainInterface):
                     # assembled in pinned memory by the collate pool while this step runs on the GPU.  Bucketed loaders only:
                     # a RandomSampler also reads the torch stream, which evaluate()'s dev loaders touch in between.
                     more = it + 1 < self.eval_ival or self.global_step + 1 < self.max_step
-                    nxt = self._shuffle_and_draw(task_ids) if (more and self.is_bucket and self.data_container.pool is not None) else None
+                    ahead = more and self.is_bucket and self.data_container.pool is not None
+                    nxt = None
+
+                    def look_ahead():                                   # runs once the first task's launches are queued: its host
+                        nonlocal nxt                                    # time (index draws, HBM gathers) overlaps GPU work
+                        nxt = self._shuffle_and_draw(task_ids)
                     n_local = 0
                     if self.tasks_per_gpu > 1:
-                        n_local = self._run_tasks_concurrently(drawn)
-                    for accent_id, tr, val in (drawn if self.tasks_per_gpu == 1 else []):
+                        n_local = self._run_tasks_concurrently(drawn, look_ahead if ahead else None)
+                    elif ahead and not drawn:
+                        look_ahead()
+                    for ti, (accent_id, tr, val) in enumerate(drawn if self.tasks_per_gpu == 1 else []):
                         self.run_task([(i, f.result()) for i, f in tr])
+                        if ti == 0 and ahead:
+                            look_ahead()
                         val_batch = (val[0], val[1].result())
                         batch_size = len(val_batch[1][2])
                         info = self._train(val_batch[0], *val_batch[1], accent_idx=val_batch[0], want_info=False)

@@ -161,10 +161,16 @@ class CommonVoiceDataset:
         idxs = sorted(idxs, key=lambda i: int(self.ilens[i]), reverse=True)
         dev = self.dev_feat.device
         lens = torch.tensor([int(self.ilens[i]) for i in idxs], dtype=torch.int32)
-        rows = torch.tensor([int(self.iptr[i]) for i in idxs], dtype=torch.int64)
         B, tmax, D = len(idxs), int(lens.max()), self.dev_feat.shape[1]
         xs = torch.empty(B, tmax, D, device=dev)
-        rows_d, lens_d = rows.to(dev), lens.to(dev)
+        # row starts | lengths in ONE pinned block, uploaded asynchronously: a pageable `.to(device)` is a blocking copy that
+        # first waits for everything already queued on the stream (the previous meta-step), which idles the GPU while the
+        # host then enqueues the next one
+        meta = torch.empty(2 * B, dtype=torch.int64, pin_memory=True)
+        meta[:B] = torch.tensor([int(self.iptr[i]) for i in idxs], dtype=torch.int64)
+        meta[B:] = lens.to(torch.int64)
+        meta_d = meta.to(dev, non_blocking=True)
+        rows_d, lens_d = meta_d[:B], meta_d[B:].to(torch.int32)
         s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         check(lib().masr_gather_pad(C.c_void_p(self.dev_feat.data_ptr()), C.c_void_p(rows_d.data_ptr()),
                                     C.c_void_p(lens_d.data_ptr()), C.c_void_p(xs.data_ptr()), B, tmax, D, s), "masr_gather_pad")
