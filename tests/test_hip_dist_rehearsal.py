@@ -19,6 +19,13 @@ from oracle.make_goldens import cfg3_workspace  # noqa: E402
 ROOT = Path(__file__).resolve().parents[1]
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_two_rank_cli_run_matches_single_process(golden_dir, tmp_path):
     cfg = cfg3_workspace(tmp_path, golden_dir)
     yaml.safe_dump(cfg, open(tmp_path / "cfg3.yaml", "w"))
@@ -28,7 +35,7 @@ def test_two_rank_cli_run_matches_single_process(golden_dir, tmp_path):
     r1 = subprocess.run([sys.executable, worker, str(tmp_path), "w1"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
     assert r1.returncode == 0, r1.stderr[-2000:]
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                         "--master-port", "29653", worker, str(tmp_path), "w2"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+                         "--master-port", str(_free_port()), worker, str(tmp_path), "w2"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
     assert r2.returncode == 0, r2.stderr[-2000:]
     one = torch.load(tmp_path / "w1_r0.pt")
     a, b = torch.load(tmp_path / "w2_r0.pt"), torch.load(tmp_path / "w2_r1.pt")
