@@ -222,6 +222,13 @@ int masr_test_conv3x3(const uint16_t* in, const uint16_t* wk, const float* bias,
    pool_out (optional, [B][H/2][W/2][COUT]) receives MaxPool2d(2,2) of the ReLU'd output */
 int masr_test_conv3x3_ex(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, const uint16_t* mask, uint16_t* out,
                          uint16_t* pool_out, int B, int H, int W, int CIN, int COUT, void* stream);
+/* the pooling forward conv as the engine launches it: pool_idx ([B][H/2][W/2][COUT] bytes) receives, per pooled element, the
+   window position 0..3 (row-major) of its first maximum, or 4 where nothing passed the ReLU; drop_out != 0 allows the launch to
+   leave `out` unwritten (the streaming kernels then never store the full-resolution map; the others still do).
+   masr_test_maxpool_idx_bwd is the pool + ReLU backward from those bytes: din [B][H][W][C] from dout [B][H/2][W/2][C]. */
+int masr_test_conv3x3_pool_idx(const uint16_t* in, const uint16_t* wk, const float* bias, uint16_t* out, uint16_t* pool_out,
+                               uint8_t* pool_idx, int drop_out, int B, int H, int W, int CIN, int COUT, void* stream);
+int masr_test_maxpool_idx_bwd(const uint8_t* idx, const uint16_t* dout, uint16_t* din, int B, int H, int W, int C, void* stream);
 /* same launch with per-workgroup phase timing: prof receives 6 cycle counts per workgroup (tools/prof_conv_phases.py) */
 int masr_test_conv3x3_prof(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, uint16_t* out,
                            int B, int H, int W, int CIN, int COUT, int64_t* prof, void* stream);

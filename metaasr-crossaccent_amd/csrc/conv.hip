@@ -19,6 +19,35 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDK = 40;
 
+// ConvArgs::pool_idx codes of one 2 x 2 window, two channels per register: v00 v01 / v10 v11 are bit patterns of NON-NEGATIVE
+// bf16 values (they order like 15-bit integers, differences cannot overflow).  Position of the first maximum in row-major scan
+// order (strict >, as torch's max_pool2d backward), 4 where the maximum x is 0.  There is no packed 16-bit compare: a > b is the
+// sign of b - a (v_pk_sub_i16 + a shift), the selection is a v_bfi_b32.  The code of each channel lands in the low byte of
+// its 16-bit half; pool_pack4 gathers four of them into a word.  This runs on the MFMA waves' own time: every instruction counts.
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+__device__ __forceinline__ unsigned pool_code2(s16x2 v00, s16x2 v01, s16x2 v10, s16x2 v11, s16x2 m01, s16x2 m23, s16x2 x) {
+    // (written out: from vector C the compiler goes back to 16-bit scalar compares + v_cndmask through SDWA, twice the instructions)
+    unsigned s01, s23, lower, zr, code;
+    asm("v_pk_sub_i16 %0, %5, %6\n\t"                       // < 0 where v01 > v00
+        "v_pk_sub_i16 %1, %7, %8\n\t"                       // < 0 where v11 > v10
+        "v_pk_sub_i16 %2, %9, %10\n\t"                      // < 0 where the lower row holds the larger maximum
+        "v_pk_add_u16 %3, %11, -1 op_sel_hi:[1,0]\n\t"      // 0xffff where x == 0
+        "v_pk_lshrrev_b16 %0, 15, %0 op_sel_hi:[0,1]\n\t"   // 0 / 1: winner of the upper row
+        "v_pk_lshrrev_b16 %1, 15, %1 op_sel_hi:[0,1]\n\t"
+        "v_pk_ashrrev_i16 %2, 15, %2 op_sel_hi:[0,1]\n\t"   // -1 / 0
+        "v_pk_lshrrev_b16 %3, 15, %3 op_sel_hi:[0,1]\n\t"   // 1 where x == 0 (then every difference above is 0: sel = 0)
+        "v_or_b32 %1, 0x20002, %1\n\t"                      // 2 / 3: winner of the lower row
+        "v_bfi_b32 %4, %2, %1, %0\n\t"
+        "v_lshl_or_b32 %4, %3, 2, %4"
+        : "=&v"(s01), "=&v"(s23), "=&v"(lower), "=&v"(zr), "=&v"(code)
+        : "v"(v00), "v"(v01), "v"(v10), "v"(v11), "v"(m01), "v"(m23), "v"(x));
+    return code;
+}
+__device__ __forceinline__ unsigned pool_pack4(unsigned c01, unsigned c23) { return __builtin_amdgcn_perm(c23, c01, 0x06040200u); }
+// lane ^ 1 and lane ^ 8 as DPP moves (quad_perm [1,0,3,2]; rotation by 8 within the row of 16) instead of LDS permutes
+__device__ __forceinline__ s16x2 lane_xor1(s16x2 v) { return __builtin_bit_cast(s16x2, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false)); }
+__device__ __forceinline__ s16x2 lane_xor8(s16x2 v) { return __builtin_bit_cast(s16x2, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false)); }
+
 // ------------------------------------------------------------------ conv1 (CIN = 1), direct fp32
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, bf16* __restrict__ out,
@@ -869,6 +898,7 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
         constexpr int IP = (TW == 16) ? 2 : 1;             // pixel tiles per pooling group (TW = 16: two rows = two tiles)
         const short fl = (!MASK && (a.relu & 255)) ? (short)0 : (short)-32768;
         const short2_t floor2 = {fl, fl};
+        const bool store_dense = MASK || !(a.out_optional && a.pool_out), want_idx = a.pool_idx != nullptr;
         short2_t pm[NH][4];
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
@@ -896,7 +926,7 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
                         pk[kk] = pk[kk] & (zero2 - m);
                     }
                 }
-                if (ok) {
+                if (ok && store_dense) {
                     u32x4 ov;
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) ov[kk] = __builtin_bit_cast(unsigned, pk[kk]);
@@ -904,27 +934,31 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
                 }
                 if (!MASK && a.pool_out) {
                     // 2 x 2 window (ReLU'd values only): the row pair is (tile i, tile i+1) for TW = 16 and (lane, lane ^ 8)
-                    // for TW = 8; the column pair is (lane, lane ^ 1)
+                    // for TW = 8; the column pair is (lane, lane ^ 1).  The owner lane holds the window's top-left element.
                     if (IP == 2 && (i & 1) == 0) {
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk) pm[h][kk] = pk[kk];
                     } else {
                         u32x4 po;
+                        unsigned code[4];
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk) {
-                            short2_t x = IP == 2 ? __builtin_elementwise_max(pm[h][kk], pk[kk]) : pk[kk];
-                            if constexpr (TW == 8) {
-                                const int o8 = __shfl_xor(__builtin_bit_cast(int, x), 8);
-                                x = __builtin_elementwise_max(x, __builtin_bit_cast(short2_t, o8));
-                            }
-                            const int o1 = __shfl_xor(__builtin_bit_cast(int, x), 1);
-                            x = __builtin_elementwise_max(x, __builtin_bit_cast(short2_t, o1));
+                            const short2_t v00 = IP == 2 ? pm[h][kk] : pk[kk];
+                            const short2_t v01 = lane_xor1(v00);
+                            const short2_t v10 = TW == 8 ? lane_xor8(v00) : pk[kk];
+                            const short2_t v11 = lane_xor1(v10);
+                            const short2_t m01 = __builtin_elementwise_max(v00, v01), m23 = __builtin_elementwise_max(v10, v11);
+                            const short2_t x = __builtin_elementwise_max(m01, m23);
                             po[kk] = __builtin_bit_cast(unsigned, x);
+                            code[kk] = want_idx ? pool_code2(v00, v01, v10, v11, m01, m23, x) : 0u;
                         }
                         const int t2 = (tl + (i - (IP - 1)) * RPT) >> 1, d2 = dl >> 1;
                         const bool owner = (rr & 1) == 0 && (TW == 16 || rr < 8);
-                        if (owner && t2 < H2 && d2 < W2)
-                            *reinterpret_cast<u32x4*>(a.pool_out + (((long)b * H2 + t2) * W2 + d2) * COUT + h * 32 + q * 8) = po;
+                        if (owner && t2 < H2 && d2 < W2) {
+                            const long pe = (((long)b * H2 + t2) * W2 + d2) * COUT + h * 32 + q * 8;
+                            *reinterpret_cast<u32x4*>(a.pool_out + pe) = po;
+                            if (want_idx) *reinterpret_cast<uint2*>(a.pool_idx + pe) = uint2{pool_pack4(code[0], code[1]), pool_pack4(code[2], code[3])};
+                        }
                     }
                 }
             }
@@ -1156,6 +1190,7 @@ __global__ __launch_bounds__(320) void conv3x3_resw_kernel(ConvArgs a, int ntile
         constexpr int IP = (TW == 16) ? 2 : 1;
         const short fl = (a.relu & 255) ? (short)0 : (short)-32768;
         const short2_t floor2 = {fl, fl};
+        const bool store_dense = !(a.out_optional && a.pool_out), want_idx = a.pool_idx != nullptr;
         short2_t pm[NH][4];
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
@@ -1173,7 +1208,7 @@ __global__ __launch_bounds__(320) void conv3x3_resw_kernel(ConvArgs a, int ntile
                     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(v[0]), "v"(v[1]));
                     pk[kk] = __builtin_elementwise_max(__builtin_bit_cast(short2_t, r), floor2);
                 }
-                if (ok) {
+                if (ok && store_dense) {
                     u32x4 ov;
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) ov[kk] = __builtin_bit_cast(unsigned, pk[kk]);
@@ -1185,21 +1220,25 @@ __global__ __launch_bounds__(320) void conv3x3_resw_kernel(ConvArgs a, int ntile
                         for (int kk = 0; kk < 4; ++kk) pm[h][kk] = pk[kk];
                     } else {
                         u32x4 po;
+                        unsigned code[4];
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk) {
-                            short2_t x = IP == 2 ? __builtin_elementwise_max(pm[h][kk], pk[kk]) : pk[kk];
-                            if constexpr (TW == 8) {
-                                const int o8 = __shfl_xor(__builtin_bit_cast(int, x), 8);
-                                x = __builtin_elementwise_max(x, __builtin_bit_cast(short2_t, o8));
-                            }
-                            const int o1 = __shfl_xor(__builtin_bit_cast(int, x), 1);
-                            x = __builtin_elementwise_max(x, __builtin_bit_cast(short2_t, o1));
+                            const short2_t v00 = IP == 2 ? pm[h][kk] : pk[kk];
+                            const short2_t v01 = lane_xor1(v00);
+                            const short2_t v10 = TW == 8 ? lane_xor8(v00) : pk[kk];
+                            const short2_t v11 = lane_xor1(v10);
+                            const short2_t m01 = __builtin_elementwise_max(v00, v01), m23 = __builtin_elementwise_max(v10, v11);
+                            const short2_t x = __builtin_elementwise_max(m01, m23);
                             po[kk] = __builtin_bit_cast(unsigned, x);
+                            code[kk] = want_idx ? pool_code2(v00, v01, v10, v11, m01, m23, x) : 0u;
                         }
                         const int t2 = (tl + (i - (IP - 1)) * RPT) >> 1, d2 = dl >> 1;
                         const bool owner = (rr & 1) == 0 && (TW == 16 || rr < 8);
-                        if (owner && t2 < H2 && d2 < W2)
-                            *reinterpret_cast<u32x4*>(a.pool_out + (((long)b * H2 + t2) * W2 + d2) * COUT + h * 32 + q * 8) = po;
+                        if (owner && t2 < H2 && d2 < W2) {
+                            const long pe = (((long)b * H2 + t2) * W2 + d2) * COUT + h * 32 + q * 8;
+                            *reinterpret_cast<u32x4*>(a.pool_out + pe) = po;
+                            if (want_idx) *reinterpret_cast<uint2*>(a.pool_idx + pe) = uint2{pool_pack4(code[0], code[1]), pool_pack4(code[2], code[3])};
+                        }
                     }
                 }
             }
@@ -1906,6 +1945,64 @@ __global__ void maxpool_relu_bwd_kernel(const bf16* __restrict__ in, const bf16*
     }
 }
 
+// pool + ReLU backward from the ConvArgs::pool_idx bytes (floor mode): thread = pooled cell x 8 channels; 8 B of codes + 16 B
+// of gradient in, the four full-resolution positions out (zeros at the three that lost, and in the cropped last row / column)
+__global__ void maxpool_idx_bwd_kernel(const uint8_t* __restrict__ idx, const bf16* __restrict__ dout, bf16* __restrict__ din,
+                                       int B, int H, int W, int C) {
+    const int H2 = H / 2, W2 = W / 2, C8 = C / 8;
+    const int H2c = (H + 1) / 2, W2c = (W + 1) / 2;           // cells incl. the cropped edge
+    const long n = (long)B * H2c * W2c * C8;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c8 = (int)(i % C8);
+    const int d2 = (int)((i / C8) % W2c);
+    const int t2 = (int)((i / ((long)C8 * W2c)) % H2c);
+    const int b = (int)(i / ((long)C8 * W2c * H2c));
+    const long base = (((long)b * H + 2 * t2) * W + 2 * d2) * C + c8 * 8;
+    if (t2 < H2 && d2 < W2) {
+        const long pe = (((long)b * H2 + t2) * W2 + d2) * C + c8 * 8;
+        const uint2 code = *reinterpret_cast<const uint2*>(idx + pe);
+        const bf16x8 g = ld8(dout + pe);
+        bf16x8 o[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned cj = ((j < 4 ? code.x : code.y) >> (8 * (j & 3))) & 0xffu;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k][j] = cj == (unsigned)k ? g[j] : (bf16)0.f;
+        }
+        st8(din + base, o[0]);
+        st8(din + base + C, o[1]);
+        st8(din + base + (long)W * C, o[2]);
+        st8(din + base + (long)W * C + C, o[3]);
+    } else {
+        for (int dt = 0; dt < 2; ++dt)
+            for (int dd = 0; dd < 2; ++dd)
+                if (2 * t2 + dt < H && 2 * d2 + dd < W) st8(din + base + ((long)dt * W + dd) * C, zero8());
+    }
+}
+// the codes from a stored (ReLU'd) map: for the conv kernels that do not emit them in their epilogue
+__global__ void maxpool_idx_kernel(const bf16* __restrict__ in, uint8_t* __restrict__ idx, int B, int H, int W, int C) {
+    const int H2 = H / 2, W2 = W / 2, C8 = C / 8;
+    const long n = (long)B * H2 * W2 * C8;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c8 = (int)(i % C8);
+    const int d2 = (int)((i / C8) % W2);
+    const int t2 = (int)((i / ((long)C8 * W2)) % H2);
+    const int b = (int)(i / ((long)C8 * W2 * H2));
+    const bf16* base = in + (((long)b * H + 2 * t2) * W + 2 * d2) * C + c8 * 8;
+    const bf16x8 v[4] = {ld8(base), ld8(base + C), ld8(base + (long)W * C), ld8(base + (long)W * C + C)};
+    unsigned w[2] = {0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int arg = 0; float mx = (float)v[0][j];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if ((float)v[k][j] > mx) { mx = (float)v[k][j]; arg = k; }
+        w[j >> 2] |= (unsigned)(mx > 0.f ? arg : 4) << (8 * (j & 3));
+    }
+    *reinterpret_cast<uint2*>(idx + i * 8) = uint2{w[0], w[1]};
+}
+
 }  // namespace
 
 // workgroups of 4 waves stride over the 16-pixel row segments
@@ -2039,7 +2136,25 @@ static void launch_stream(const ConvArgs& a, int tiles_x, int tiles_y, hipStream
     if (a.mask) launch_stream_t<CI, CO, TWV, true, PROF, THV>(a, tiles_x, tiles_y, s);
     else launch_stream_t<CI, CO, TWV, false, PROF, THV>(a, tiles_x, tiles_y, s);
 }
-int mk_conv3x3(const ConvArgs& a, hipStream_t s) {
+static int conv3x3_dispatch(const ConvArgs& a, hipStream_t s);
+int mk_conv3x3(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    uint8_t* idx_after = nullptr;
+    {   // pool_idx / out_optional are honoured by the epilogues of the streaming kernels only: everywhere else the launch
+        // stores the map and the codes are computed from it afterwards
+        static const bool allow_narrow = !getenv("MASR_CONV_NO_TW8");
+        static const bool stream = !(getenv("MASR_CONV_STREAM") && atoi(getenv("MASR_CONV_STREAM")) == 0);
+        const bool narrow = allow_narrow && (a.W + 7) / 8 * 8 < (a.W + 15) / 16 * 16 && a.CIN <= 128 && a.COUT <= 128;
+        const bool in_epilogue = !getenv("MASR_CONV_V1") && !a.prof && stream && !a.x1 && !a.mask && a.CIN <= 128 && a.COUT <= 128 &&
+                                 (narrow || (a.CIN == 64 && a.COUT == 64));
+        if (!in_epilogue) { idx_after = a.pool_idx; a.pool_idx = nullptr; a.out_optional = 0; }
+        if ((a.pool_idx && !a.pool_out) || (!a.out && !(a.out_optional && a.pool_out))) { mk_set_error("mk_conv3x3", "pool_idx needs pool_out, and out may only be dropped when the launch pools"); return -1; }
+    }
+    const int rc = conv3x3_dispatch(a, s);
+    if (rc == 0 && idx_after) return mk_maxpool_idx(a.out, idx_after, a.B, a.H, a.W, a.COUT, s);
+    return rc;
+}
+static int conv3x3_dispatch(const ConvArgs& a, hipStream_t s) {
     if (getenv("MASR_CONV_V1")) {                          // first-generation im2col-on-the-fly kernel (kept for A/B runs)
         const long P = (long)a.B * a.H * a.W;
         dim3 grid((unsigned)((P + 127) / 128));
@@ -2184,5 +2299,17 @@ int mk_maxpool_fwd(const bf16* in, bf16* out, int B, int H, int W, int C, hipStr
 int mk_maxpool_relu_bwd(const bf16* in, const bf16* dout, bf16* din, int B, int H, int W, int C, hipStream_t s, int ceil_mode) {
     const long n = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
     hipLaunchKernelGGL(maxpool_relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, dout, din, B, H, W, C, ceil_mode);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int mk_maxpool_idx_bwd(const uint8_t* idx, const bf16* dout, bf16* din, int B, int H, int W, int C, hipStream_t s) {
+    const long n = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(maxpool_idx_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, idx, dout, din, B, H, W, C);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int mk_maxpool_idx(const bf16* in, uint8_t* idx, int B, int H, int W, int C, hipStream_t s) {
+    const long n = (long)B * (H / 2) * (W / 2) * (C / 8);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(maxpool_idx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, idx, B, H, W, C);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

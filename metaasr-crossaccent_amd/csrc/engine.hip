@@ -52,6 +52,7 @@ struct Acts {
     uint32_t* meta;                                        // [8] behind enc_lens, same upload: [0] dropout seed of the step, [1] 1/n_total (float bits)
     bf16* step_qkv;                                        // incremental decode: the newest position's q|k|v [B][3E]
     bf16 *a1, *a2, *p1, *a3, *a4, *p2;
+    uint8_t *i1, *i2;                                  // ConvArgs::pool_idx of the two pools (a2 / a4 are only written by conv kernels that cannot emit them)
     std::vector<float*> x32; std::vector<bf16*> x16;        // encoder layer inputs/outputs [NE+1]
     std::vector<EncAct> enc;
     float *mf, *rf; bf16* mem16; bf16* kv_all;             // kv_all [rows_e][ND*2E]: K|V of every decoder layer's cross-attention
@@ -193,6 +194,7 @@ void plan_acts(const masr_model* m, Arena& ar, Acts& a, int B, int T, int L, boo
     const int64_t P1 = (int64_t)B * T * m->D, P2 = (int64_t)B * a.H2 * a.W2;
     a.a1 = ar.get<bf16>(P1 * 64); a.a2 = ar.get<bf16>(P1 * 64); a.p1 = ar.get<bf16>(P2 * 64);
     a.a3 = ar.get<bf16>(P2 * 128); a.a4 = ar.get<bf16>(P2 * 128); a.p2 = ar.get<bf16>(re * m->F);
+    a.i1 = ar.get<uint8_t>(P2 * 64); a.i2 = ar.get<uint8_t>(re * m->F);
     a.x32.resize(m->NE + 1); a.x16.resize(m->NE + 1); a.enc.resize(m->NE);
     for (int l = 0; l <= m->NE; ++l) { a.x32[l] = ar.get<float>(re * E); a.x16[l] = ar.get<bf16>(re * E); }
     for (auto& e : a.enc) {
@@ -565,17 +567,20 @@ static int forward_encoder(Ctx& c, const float* xs) {
         CK(mk_conv1_fwd(xs, P + m->conv[0].w, P + m->conv[0].b, a.a1, B, T, D, s));
     }
     static const bool fuse_pool = !getenv("MASR_NO_FUSED_POOL");      // MaxPool2d written by the producing conv's epilogue
-    auto conv = [&](const bf16* in, const Conv& cv, bf16* out, int H, int W, bf16* pooled) -> int {
+    // the maps in front of the two pools are needed by nothing but the pool + ReLU backward, and that needs one byte per POOLED
+    // element (which window position won, or that none passed the ReLU): the pooling convs store those and drop the map
+    auto conv = [&](const bf16* in, const Conv& cv, bf16* out, int H, int W, bf16* pooled, uint8_t* idx) -> int {
         Prof p(m, MASR_PROF_CONV2_FWD + (int)(&cv - &m->conv[1]), s);
         ConvArgs ca{}; ca.sched = m->conv_sched; ca.in = in; ca.wk = cv.k16; ca.bias = P + cv.b; ca.relu = 1; ca.mask = nullptr; ca.out = out;
         ca.B = B; ca.H = H; ca.W = W; ca.CIN = cv.CI; ca.COUT = cv.CO; ca.pool_out = fuse_pool ? pooled : nullptr;
+        if (ca.pool_out) { ca.pool_idx = c.train ? idx : nullptr; ca.out_optional = 1; }
         return mk_conv3x3(ca, s);
     };
-    CK(conv(a.a1, m->conv[1], a.a2, T, D, a.p1));
-    if (!fuse_pool) { Prof p(m, MASR_PROF_POOL, s); CK(mk_maxpool_fwd(a.a2, a.p1, B, T, D, 64, s)); }
-    CK(conv(a.p1, m->conv[2], a.a3, a.H2, a.W2, nullptr));
-    CK(conv(a.a3, m->conv[3], a.a4, a.H2, a.W2, a.p2));
-    if (!fuse_pool) { Prof p(m, MASR_PROF_POOL, s); CK(mk_maxpool_fwd(a.a4, a.p2, B, a.H2, a.W2, 128, s)); }
+    CK(conv(a.a1, m->conv[1], a.a2, T, D, a.p1, a.i1));
+    if (!fuse_pool) { Prof p(m, MASR_PROF_POOL, s); CK(mk_maxpool_fwd(a.a2, a.p1, B, T, D, 64, s)); if (c.train) CK(mk_maxpool_idx(a.a2, a.i1, B, T, D, 64, s)); }
+    CK(conv(a.p1, m->conv[2], a.a3, a.H2, a.W2, nullptr, nullptr));
+    CK(conv(a.a3, m->conv[3], a.a4, a.H2, a.W2, a.p2, a.i2));
+    if (!fuse_pool) { Prof p(m, MASR_PROF_POOL, s); CK(mk_maxpool_fwd(a.a4, a.p2, B, a.H2, a.W2, 128, s)); if (c.train) CK(mk_maxpool_idx(a.a4, a.i2, B, a.H2, a.W2, 128, s)); }
     // vgg2enc + positional encoding + pos dropout
     {
         GemmArgs g = lin_fwd_args(a.p2, m->F, m->v2e_k, a.rows_e, E, m->F, P + m->v2e.b);
@@ -746,12 +751,12 @@ static int backward(Ctx& c, const float* xs) {
         ca.CIN = cv.CO; ca.COUT = cv.CI;
         return mk_conv3x3(ca, s);
     };
-    { Prof p(m, MASR_PROF_POOL, s); CK(mk_maxpool_relu_bwd(a.a4, a.dp2, a.da4, B, a.H2, a.W2, 128, s)); }
+    { Prof p(m, MASR_PROF_POOL, s); CK(mk_maxpool_idx_bwd(a.i2, a.dp2, a.da4, B, a.H2, a.W2, 128, s)); }
     CK(wgrad(a.a3, a.da4, m->conv[3], a.H2, a.W2, P2));
     CK(dgrad(a.da4, m->conv[3], a.a3, a.da3, a.H2, a.W2));
     CK(wgrad(a.p1, a.da3, m->conv[2], a.H2, a.W2, P2));
     CK(dgrad(a.da3, m->conv[2], nullptr, a.dp1, a.H2, a.W2));
-    { Prof p(m, MASR_PROF_POOL, s); CK(mk_maxpool_relu_bwd(a.a2, a.dp1, a.da2, B, a.T, a.D, 64, s)); }
+    { Prof p(m, MASR_PROF_POOL, s); CK(mk_maxpool_idx_bwd(a.i1, a.dp1, a.da2, B, a.T, a.D, 64, s)); }
     CK(wgrad(a.a1, a.da2, m->conv[1], a.T, a.D, P1));
     static const bool fuse_w1 = !getenv("MASR_NO_FUSED_CONV1_WGRAD");
     if (fuse_w1) {
@@ -1149,6 +1154,15 @@ int masr_test_conv3x3_ex(const uint16_t* in, const uint16_t* wk, const float* bi
     ConvArgs a{}; a.in = (const bf16*)in; a.wk = (const bf16*)wk; a.bias = bias; a.relu = relu; a.mask = (const bf16*)mask; a.out = (bf16*)out;
     a.pool_out = (bf16*)pool_out; a.B = B; a.H = H; a.W = W; a.CIN = CIN; a.COUT = COUT;
     return mk_conv3x3(a, (hipStream_t)stream);
+}
+int masr_test_conv3x3_pool_idx(const uint16_t* in, const uint16_t* wk, const float* bias, uint16_t* out, uint16_t* pool_out, uint8_t* pool_idx,
+                               int drop_out, int B, int H, int W, int CIN, int COUT, void* stream) {
+    ConvArgs a{}; a.in = (const bf16*)in; a.wk = (const bf16*)wk; a.bias = bias; a.relu = 1; a.out = (bf16*)out;
+    a.pool_out = (bf16*)pool_out; a.pool_idx = pool_idx; a.out_optional = drop_out; a.B = B; a.H = H; a.W = W; a.CIN = CIN; a.COUT = COUT;
+    return mk_conv3x3(a, (hipStream_t)stream);
+}
+int masr_test_maxpool_idx_bwd(const uint8_t* idx, const uint16_t* dout, uint16_t* din, int B, int H, int W, int C, void* stream) {
+    return mk_maxpool_idx_bwd(idx, (const bf16*)dout, (bf16*)din, B, H, W, C, (hipStream_t)stream);
 }
 int masr_test_conv3x3_prof(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, uint16_t* out, int B, int H, int W, int CIN,
                            int COUT, int64_t* prof, void* stream) {

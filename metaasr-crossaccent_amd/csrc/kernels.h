@@ -55,6 +55,10 @@ struct ConvArgs {
     unsigned* sched;              // streaming kernel: 2 zero-initialised counters owned by the calling stream (null: a process-wide pair)
     long* prof;                   // optional phase-timing output, 6 cycle counts per workgroup (see conv3x3_patch_kernel)
     bf16* pool_out;               // optional: MaxPool2d(2,2) (floor) of the ReLU'd output, [B][H/2][W/2][COUT], written by the same launch
+    // optional, with pool_out: one byte per pooled element = window position (0..3, row-major scan) of its FIRST maximum, 4 where
+    // that maximum is <= 0 (nothing passes the ReLU): all the pool + ReLU backward needs of the full-resolution map
+    uint8_t* pool_idx;
+    int out_optional;             // the caller does not need `out`: a launch that pools in its epilogue may skip storing it
 };
 int mk_conv3x3(const ConvArgs& a, hipStream_t s);
 long mk_conv1_wgrad_fused_slab_floats(int B, int H, int W);
@@ -66,6 +70,9 @@ long mk_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT);
 int mk_maxpool_fwd(const bf16* in, bf16* out, int B, int H, int W, int C, hipStream_t s, int ceil_mode = 0);
 // din = (in is the first max of its window && in > 0) ? dout : 0   (ReLU backward fused)
 int mk_maxpool_relu_bwd(const bf16* in, const bf16* dout, bf16* din, int B, int H, int W, int C, hipStream_t s, int ceil_mode = 0);
+// the same from ConvArgs::pool_idx instead of the full-resolution map (floor mode); mk_maxpool_idx computes the bytes from a stored map
+int mk_maxpool_idx_bwd(const uint8_t* idx, const bf16* dout, bf16* din, int B, int H, int W, int C, hipStream_t s);
+int mk_maxpool_idx(const bf16* in, uint8_t* idx, int B, int H, int W, int C, hipStream_t s);
 // CIN = 1 convs with COUT = 64 n channels
 int mk_conv1_fwd_n(const float* x, const float* w, const float* bias, bf16* out, int B, int H, int W, int COUT, hipStream_t s);
 int mk_conv1_wgrad_n(const float* x, const bf16* dy, float* dw, float* db, float* slab, int B, int H, int W, int COUT, hipStream_t s);

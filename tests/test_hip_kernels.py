@@ -115,6 +115,59 @@ def test_conv3x3_mask_and_pool(L, B_, H, W, CIN, COUT):
     assert torch.equal(pool.float(), pref)                       # pooling the stored map is exact
 
 
+@pytest.mark.parametrize("B_,H,W,CIN,COUT", [(2, 38, 80, 64, 64), (3, 50, 40, 128, 128), (2, 301, 80, 64, 64), (1, 17, 48, 128, 128),
+                                             (2, 45, 83, 64, 64), (2, 27, 41, 64, 128), (2, 64, 40, 64, 128), (1, 33, 20, 128, 128)])
+def test_conv3x3_pool_codes_and_their_backward(L, B_, H, W, CIN, COUT):
+    """the pooling convs of the engine emit one byte per pooled element (which window position won / nothing passed the ReLU) and may
+    drop the full-resolution map; the pool + ReLU backward runs from those bytes.  Codes are checked against the stored map of a second
+    launch (first maximum in row-major order, as torch's max_pool2d backward), the backward against torch autograd through
+    relu -> max_pool2d on that map.  Shapes cover both streaming kernels (16- and 8-wide tiles) and the fallback (patch kernel)."""
+    g = torch.Generator(device="cuda").manual_seed(3 * CIN + COUT + H)
+    x = torch.randn(B_, H, W, CIN, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(COUT, CIN, 3, 3, device="cuda", generator=g) * 0.05).bfloat16()
+    bias = torch.randn(COUT, device="cuda", generator=g) * 0.3
+    wk = w.permute(0, 2, 3, 1).reshape(COUT, 9 * CIN).contiguous()
+    H2, W2 = H // 2, W // 2
+    out = torch.zeros(B_, H, W, COUT, device="cuda").bfloat16()
+    pool = torch.zeros(B_, H2, W2, COUT, device="cuda").bfloat16()
+    idx = torch.full((B_, H2, W2, COUT), 9, device="cuda", dtype=torch.uint8)
+    _cabi.check(L.masr_test_conv3x3_pool_idx(P(x), P(wk), P(bias), P(out), P(pool), P(idx), 0, B_, H, W, CIN, COUT, S()))
+    # reference codes from the stored map
+    win = out.float()[:, :2 * H2, :2 * W2].reshape(B_, H2, 2, W2, 2, COUT).permute(0, 1, 3, 5, 2, 4).reshape(B_, H2, W2, COUT, 4)
+    mx, arg = win.max(dim=-1)
+    first = (win == mx.unsqueeze(-1)).float().argmax(dim=-1)            # first position holding the maximum
+    code = torch.where(mx > 0, first, torch.full_like(first, 4)).to(torch.uint8)
+    assert torch.equal(pool.float(), mx)
+    assert torch.equal(idx, code)
+    assert (code == 4).float().mean() < 0.5 and all((code == k).any() for k in range(4))      # the case is not degenerate
+    # the same launch allowed to drop the map: identical pool and codes
+    out2 = torch.full_like(out, 7.0)
+    pool2 = torch.zeros_like(pool)
+    idx2 = torch.full_like(idx, 9)
+    _cabi.check(L.masr_test_conv3x3_pool_idx(P(x), P(wk), P(bias), P(out2), P(pool2), P(idx2), 1, B_, H, W, CIN, COUT, S()))
+    assert torch.equal(pool2, pool) and torch.equal(idx2, idx)
+    assert bool((out2.float() == 7.0).all()) or torch.equal(out2, out)  # dropped (streaming kernels) or stored (fallback), never half
+    # backward from the codes
+    gp = torch.randn(B_, H2, W2, COUT, device="cuda", generator=g).bfloat16()
+    din = torch.full((B_, H, W, COUT), 5.0, device="cuda").bfloat16()
+    _cabi.check(L.masr_test_maxpool_idx_bwd(P(idx), P(gp), P(din), B_, H, W, COUT, S()))
+    pre = out.float().permute(0, 3, 1, 2).clone().requires_grad_(True)  # (the map is already ReLU'd: relu'(x) = [x > 0])
+    y = torch.nn.functional.max_pool2d(torch.relu(pre), 2, 2)
+    y.backward(gp.float().permute(0, 3, 1, 2))
+    ref = pre.grad.permute(0, 2, 3, 1)
+    if torch.equal(din.float(), ref):
+        return
+    # torch's CUDA max_pool2d backward breaks exact ties its own way: compare where the window has a unique maximum, and totals
+    uniq = (win == mx.unsqueeze(-1)).sum(-1) == 1
+    u = uniq.unsqueeze(-1).expand(-1, -1, -1, -1, 4).reshape(B_, H2, W2, COUT, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(B_, 2 * H2, 2 * W2, COUT)
+    assert torch.equal(din.float()[:, :2 * H2, :2 * W2][u], ref[:, :2 * H2, :2 * W2][u])
+    assert bool((din.float()[:, 2 * H2:] == 0).all()) and bool((din.float()[:, :, 2 * W2:] == 0).all())
+    exp = torch.zeros(B_, H2, W2, COUT, 4, device="cuda")
+    exp.scatter_(-1, code.long().clamp(max=3).unsqueeze(-1), (gp.float() * (code < 4)).unsqueeze(-1))
+    exp = exp.reshape(B_, H2, W2, COUT, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(B_, 2 * H2, 2 * W2, COUT)
+    assert torch.equal(din.float()[:, :2 * H2, :2 * W2], exp)
+
+
 @pytest.mark.parametrize("B_,H,W,CIN,COUT", [(2, 10, 9, 64, 64), (1, 33, 21, 64, 128), (2, 40, 20, 128, 128), (1, 21, 48, 128, 128), (1, 17, 80, 64, 64)])
 def test_conv3x3_wgrad(L, B_, H, W, CIN, COUT):
     g = torch.Generator(device="cuda").manual_seed(CIN + COUT + H + 1)
