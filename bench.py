@@ -409,10 +409,12 @@ def main():
         eng.profile(False)
         H2, W2 = T // 2, D // 2
         c2, c3, c4 = 2.0 * 9 * 64 * 64 * B * T * D, 2.0 * 9 * 64 * 128 * B * H2 * W2, 2.0 * 9 * 128 * 128 * B * H2 * W2
-        conv_launch = {   # name -> (kernel, algorithmic FLOPs per launch, algorithmic HBM bytes per launch: bf16 in + out (+ pooled out))
-            "conv2_fwd": ("conv3x3_resw_kernel<16,16> (64->64 forward + fused 2x2 max-pool)", c2, 2 * B * T * D * 64 * 2 + B * H2 * W2 * 64 * 2),
+        # name -> (kernel, algorithmic FLOPs per launch, algorithmic HBM bytes per launch: bf16 in + out; the pooling forwards write the
+        # pooled map (2 B) and one code byte per pooled element instead of the full-resolution map)
+        conv_launch = {
+            "conv2_fwd": ("conv3x3_resw_kernel<16,16> (64->64 forward + fused 2x2 max-pool, pooled map + codes out)", c2, B * T * D * 64 * 2 + B * H2 * W2 * 64 * 3),
             "conv3_fwd": ("conv3x3_stream_kernel<64,128> (64->128 forward)", c3, B * H2 * W2 * (64 + 128) * 2),
-            "conv4_fwd": ("conv3x3_stream_kernel<128,128> (128->128 forward + fused 2x2 max-pool)", c4, B * H2 * W2 * 256 * 2 + B * (H2 // 2) * (W2 // 2) * 128 * 2),
+            "conv4_fwd": ("conv3x3_stream_kernel<128,128> (128->128 forward + fused 2x2 max-pool, pooled map + codes out)", c4, B * H2 * W2 * 128 * 2 + B * (H2 // 2) * (W2 // 2) * 128 * 3),
             "conv2_dgrad": ("conv3x3_resw_w1_kernel (64<-64 dgrad + fused conv1 weight gradient)", c2, B * T * D * (64 + 64) * 2 + B * T * D * 4),
             "conv3_dgrad": ("conv3x3_stream_kernel<128,64> (64<-128 dgrad)", c3, B * H2 * W2 * (128 + 64) * 2),
             "conv4_dgrad": ("conv3x3_stream_kernel<128,128,mask> (128<-128 dgrad through the ReLU mask)", c4, B * H2 * W2 * 384 * 2),
