@@ -70,6 +70,10 @@ void masr_set_step_graphs(masr_model* m, int on);
 void masr_step_counters(const masr_model* m, int64_t out[3]);
 /* out[0]=loss, out[1]=n_correct, out[2]=n_total, out[3]=last grad norm.  Synchronises the stream. */
 int masr_read_stats(masr_model* m, float out[4], void* stream);
+/* the same four floats copied to host_out by the stream, WITHOUT waiting: host_out must be page-locked memory that stays valid until
+   the caller has seen the copy complete (an event recorded on the stream after this call).  Lets the host queue the next tasks while
+   these run: the reference reads loss / accuracy / norm only for its log lines (fo_meta_interface.py:147-151). */
+int masr_read_stats_async(masr_model* m, float* host_out, void* stream);
 /* device view of the last forward's logits: fp32 [rows = B*L][ld], first odim columns valid; and gold */
 int masr_last_logits(masr_model* m, const float** logits, const int32_t** gold, int* rows, int* L, int* ld);
 

@@ -32,6 +32,7 @@ _SIGS = {
     "masr_set_step_graphs": (None, [vp, i32]),
     "masr_step_counters": (None, [vp, C.POINTER(i64)]),
     "masr_read_stats": (i32, [vp, C.POINTER(f32), vp]),
+    "masr_read_stats_async": (i32, [vp, vp, vp]),
     "masr_last_logits": (i32, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "masr_grad_norm": (i32, [vp, vp]),
     "masr_clip_sgd_step": (i32, [vp, vp, f32, f32, f32, i32, i32, vp]),

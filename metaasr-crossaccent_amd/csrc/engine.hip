@@ -877,6 +877,12 @@ int masr_read_stats(masr_model* m, float out[4], void* stream) {
     return 0;
 }
 
+int masr_read_stats_async(masr_model* m, float* host_out, void* stream) {
+    if (!host_out) { mk_set_error("masr_read_stats_async", "null destination"); return -1; }
+    HIP_CHECK_RET(hipMemcpyAsync(host_out, m->stats, sizeof(float) * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return 0;
+}
+
 int masr_last_logits(masr_model* m, const float** logits, const int32_t** gold, int* rows, int* L, int* ld) {
     if (!m->have_acts) { mk_set_error("masr_last_logits", "no forward has run"); return -1; }
     *logits = m->acts.logits; *gold = m->acts.gold; *rows = m->acts.rows_d; *L = m->acts.L; *ld = m->Cp;

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import time
 from collections import OrderedDict
 
 import numpy as np
@@ -30,6 +31,29 @@ def sinusoid_pe(max_len: int, E: int) -> torch.Tensor:
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class PendingStats:
+    """stats block of one batch on its way to the host (MasrEngine.read_stats_async).  Completion is detected by POLLING the
+    page-locked words themselves (pre-set to a NaN bit pattern no kernel produces): on this ROCm, synchronising an event that was
+    recorded earlier on a stream which has had more work queued since waits for that later work too, i.e. it would hand the host
+    back exactly the lock-step this class exists to avoid (measured: tools/gap_analysis.py on the pretrain loop)."""
+    SENTINEL = 0x7FC0DEAD                                     # a quiet NaN with a payload
+
+    def __init__(self, buf):
+        self.buf = buf
+        self.bits = buf.view(torch.int32)
+
+    def ready(self):
+        return not bool((self.bits == self.SENTINEL).any())
+
+    def get(self):
+        n = 0
+        while not self.ready():
+            n += 1
+            time.sleep(0 if n < 50 else 5e-5)                 # (releases the interpreter to the task threads either way)
+        b = self.buf
+        return {"loss": float(b[0]), "n_correct": float(b[1]), "n_total": float(b[2]), "grad_norm": float(b[3])}
 
 
 class MasrEngine:
@@ -169,6 +193,15 @@ class MasrEngine:
         check(self._l.masr_read_stats(self.h, out, self.stream()), "masr_read_stats")
         self._last_stats = {"loss": float(out[0]), "n_correct": float(out[1]), "n_total": float(out[2]), "grad_norm": float(out[3])}
         return self._last_stats
+
+    def read_stats_async(self):
+        """the same block, copied into page-locked memory by the stream WITHOUT waiting for it (include/masr.h
+        masr_read_stats_async): returns a handle whose .get() waits for that copy only.  The host can then queue the next tasks
+        while these run; the stats are what the log lines need one meta-step later."""
+        buf = torch.empty(4, dtype=torch.float32, pin_memory=True)
+        buf.view(torch.int32).fill_(PendingStats.SENTINEL)
+        check(self._l.masr_read_stats_async(self.h, C.c_void_p(buf.data_ptr()), self.stream()), "masr_read_stats_async")
+        return PendingStats(buf)
 
     def set_step_graphs(self, on: bool):
         """opt-in graph replay of repeated batch shapes (include/masr.h masr_set_step_graphs)"""

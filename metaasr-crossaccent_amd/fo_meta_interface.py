@@ -23,6 +23,26 @@ from .optimizer import FlatAdam, FlatSGD, TransformerOptimizer
 from .pretrain_interface import PretrainInterface
 
 
+_TASK_STREAMS = {}
+
+
+def _task_streams(dev, n):
+    lst = _TASK_STREAMS.setdefault(str(dev), [])
+    while len(lst) < n:
+        lst.append(torch.cuda.Stream(device=dev))
+    return lst[:n]
+
+
+class _Resolved:
+    """stats handle of a task whose numbers are already on the host"""
+
+    def __init__(self, info, grad_norm):
+        self.info, self.grad_norm = info, grad_norm
+
+    def get(self):
+        return self.info, self.grad_norm
+
+
 class FOMetaASRInterface(PretrainInterface):
     def __init__(self, config, paras, id2accent):
         super().__init__(config, paras, id2accent)
@@ -35,6 +55,7 @@ class FOMetaASRInterface(PretrainInterface):
         self.meta_batch_size = paras.meta_batch_size if paras.meta_batch_size is not None else self.num_pretrain
         self._updates = None
         self._counter = 0
+        self._pending = []                                           # (meta-step, accent, stats handle, batch size) not booked yet
         mp = config['asr_model']
         o = mp['meta']['optimizer_opt']
         self.inner_lr = mp['d_model'] ** (-0.5) * o['k'] * (o['warmup_steps'] ** (-0.5))         # :41-45
@@ -69,6 +90,7 @@ class FOMetaASRInterface(PretrainInterface):
             print('{} {}'.format(self.global_step, getattr(self, f'best_{tpe}')), file=fout)
 
     def save_per_steps(self):
+        self._drain_stats()
         if self.sharder.rank != 0:
             return
         sd = {k: v.cpu() for k, v in self._snapshot_sd().items()}
@@ -110,8 +132,12 @@ class FOMetaASRInterface(PretrainInterface):
         models = [self.asr_model]
         for _ in range(self.tasks_per_gpu - 1):
             models.append(MyTransformer(self.id2ch, self.config['asr_model'], self.label_smooth_rate, device=dev, init=False))
-        self._slots = [{'model': m, 'engine': m.engine, 'stream': _t.cuda.Stream(device=dev) if self.tasks_per_gpu > 1 else None}
-                       for m in models]
+        # slot 0 runs on the caller's (main) stream, see _run_tasks_concurrently; the others on streams made ONCE per process:
+        # torch hands out its 32 pooled streams round-robin and HIP spreads them over the hardware queues, so a second
+        # interface in the same process (tests, tools/bench_pretrain.py) would otherwise land on queues that share a
+        # hardware pipe with the first one's -- measured: 8 040 utt/s on the first three pooled streams, 5 850 on the next three
+        streams = [None] + _task_streams(dev, self.tasks_per_gpu - 1) if self.tasks_per_gpu > 1 else [None]
+        self._slots = [{'model': m, 'engine': m.engine, 'stream': st} for m, st in zip(models, streams)]
         for i, sl in enumerate(self._slots):                                 # one dropout stream per (rank, slot)
             sl['engine'].set_seed(getattr(self.paras, 'seed', 531) + 7919 * (self.sharder.rank * self.tasks_per_gpu + i))
 
@@ -132,10 +158,29 @@ class FOMetaASRInterface(PretrainInterface):
         with torch.cuda.stream(slot['stream']):
             self.run_task(tr_batches, engine=slot['engine'])
             info = self._train(val_batch[0], *val_batch[1], accent_idx=val_batch[0], engine=slot['engine'], want_info=False)
-            grad_norm = self.clip_grad_norm_(GRAD_CLIP, engine=slot['engine'])       # the task's ONE host sync: loss, counts, norm
-            if info is None:
-                info = self.info_from_stats(slot['engine'])
-        out[i] = (info, grad_norm)
+            out[i] = self._clip_and_stats(info, engine=slot['engine'])
+
+    def _clip_and_stats(self, info, engine=None):
+        """clip_grad_norm_(GRAD_CLIP) of the val-batch gradient + the task's {loss, acc} and norm, as a handle: with a trainer that
+        can copy them to the host asynchronously (`clip_stats_async`) nothing waits here -- the reference uses these numbers for
+        log lines only (:147-151) -- and `_drain_stats` collects them one meta-step later, in task order.  Otherwise (or when
+        run_batch already returned an info): the one host sync of the task, as before."""
+        if info is None and hasattr(self, 'clip_stats_async') and not getattr(self.paras, 'sync_stats', False):
+            return self.clip_stats_async(GRAD_CLIP, engine=engine)
+        grad_norm = self.clip_grad_norm_(GRAD_CLIP, engine=engine) if engine is not None else self.clip_grad_norm_(GRAD_CLIP)
+        if info is None:
+            info = self.info_from_stats(engine) if engine is not None else self.info_from_stats()
+        return _Resolved(info, grad_norm)
+
+    def _drain_stats(self, keep_steps=0):
+        """book the pending task stats (all but those of the newest `keep_steps` meta-steps): NaN warning + train_info.add, in
+        the order the tasks ran.  Readers of train_info (log line, evaluate, snapshot) drain everything first."""
+        while self._pending and (keep_steps == 0 or self._pending[0][0] <= self.global_step - keep_steps):
+            step, accent_id, handle, batch_size = self._pending.pop(0)
+            info, grad_norm = handle.get()
+            if math.isnan(grad_norm):
+                logger.warning(f"grad norm NaN @ step {step} on {self.accents[accent_id]}, ignore...")
+            self.train_info.add(info, batch_size)
 
     def _run_tasks_concurrently(self, drawn, while_running=None):
         """tasks_per_gpu > 1.  `drawn` = this rank's tasks of the meta-step as _draw_meta_batch returns them (indices drawn on
@@ -143,6 +188,11 @@ class FOMetaASRInterface(PretrainInterface):
         concurrently, one replica + stream + host thread each; gradients are accumulated in task order -> deterministic."""
         fetched = [(a, [(i, f.result()) for i, f in tr], (val[0], val[1].result())) for a, tr, val in drawn]
         main = torch.cuda.current_stream()
+        # slot 0 runs ON the main stream: K streams in all.  The chip serves four compute queues at a time; with the host
+        # running ahead, a fifth queue holding nothing but the meta-update behind its waits on the task streams still takes
+        # one of the four places, and one task stream then only gets served once the other three have drained (measured:
+        # three tasks done after 14.8 ms, the fourth after 23.3 ms; tools/_prof_e2e.py)
+        self._slots[0]['stream'] = main
         K = self.tasks_per_gpu
         for w0 in range(0, len(fetched), K):
             wave = fetched[w0:w0 + K]
@@ -150,7 +200,8 @@ class FOMetaASRInterface(PretrainInterface):
             threads = []
             for i, (accent_id, tr, val) in enumerate(wave):
                 sl = self._slots[i]
-                sl['stream'].wait_stream(main)                      # meta weights / previous accumulation are ready
+                if sl['stream'] != main:
+                    sl['stream'].wait_stream(main)                  # meta weights / previous accumulation are ready
                 t = threading.Thread(target=self._task_on_slot, args=(sl, tr, val, out, i))
                 t.start(); threads.append(t)
             if while_running is not None:                            # host work of the main thread, hidden behind the first wave
@@ -159,13 +210,11 @@ class FOMetaASRInterface(PretrainInterface):
                 t.join()
             for i, (accent_id, tr, val) in enumerate(wave):
                 sl = self._slots[i]
-                main.wait_stream(sl['stream'])
-                info, grad_norm = out[i]
-                if math.isnan(grad_norm):
-                    logger.warning(f"grad norm NaN @ step {self.global_step} on {self.accents[accent_id]}, ignore...")
+                if sl['stream'] != main:
+                    main.wait_stream(sl['stream'])
                 self._counter += 1                                   # counted here (main thread), not in the worker
                 self._partial_meta_update(engine=sl['engine'])
-                self.train_info.add(info, len(val[1][2]))
+                self._pending.append((self.global_step, accent_id, out[i], len(val[1][2])))
                 self.asr_model = sl['model']                         # quirk Q1/Q2: the LAST task's adapted weights are "the model"
         return len(fetched)
 
@@ -207,29 +256,31 @@ class FOMetaASRInterface(PretrainInterface):
 
                     def look_ahead():                                   # runs once the first task's launches are queued: its host
                         nonlocal nxt                                    # time (index draws, HBM gathers) overlaps GPU work
-                        nxt = self._shuffle_and_draw(task_ids)
+                        if ahead:
+                            nxt = self._shuffle_and_draw(task_ids)
+                        # ... and the host now WAITS for the previous meta-step's stats, i.e. it stays at most one meta-step
+                        # ahead of the GPU, which always has this step's launches queued behind the previous one's
+                        self._drain_stats(keep_steps=1)
                     n_local = 0
                     if self.tasks_per_gpu > 1:
-                        n_local = self._run_tasks_concurrently(drawn, look_ahead if ahead else None)
-                    elif ahead and not drawn:
+                        n_local = self._run_tasks_concurrently(drawn, look_ahead)
+                    elif not drawn:
                         look_ahead()
                     for ti, (accent_id, tr, val) in enumerate(drawn if self.tasks_per_gpu == 1 else []):
                         self.run_task([(i, f.result()) for i, f in tr])
-                        if ti == 0 and ahead:
+                        if ti == 0:
                             look_ahead()
                         val_batch = (val[0], val[1].result())
                         batch_size = len(val_batch[1][2])
                         info = self._train(val_batch[0], *val_batch[1], accent_idx=val_batch[0], want_info=False)
-                        grad_norm = self.clip_grad_norm_(GRAD_CLIP)                     # the task's ONE host sync: loss, counts, norm
-                        if info is None:
-                            info = self.info_from_stats()
-                        if math.isnan(grad_norm):
-                            logger.warning(f"grad norm NaN @ step {self.global_step} on {self.accents[accent_id]}, ignore...")
+                        handle = self._clip_and_stats(info)
                         self._partial_meta_update()
-                        self.train_info.add(info, batch_size)
+                        self._pending.append((self.global_step, accent_id, handle, batch_size))
                         n_local += 1
                     self._pad_rounds(len(meta_batch), n_local)
                     self._final_meta_update(len(meta_batch))
+                    if self.global_step % self.log_ival == 0 or self.global_step % self.eval_ival == 0 or (self.global_step + 1) % self.save_ival == 0:
+                        self._drain_stats()                             # train_info is about to be read: this step's tasks included
                     self.log_msg(self.meta_opt.lr)
                     self.check_evaluate()
                     self.global_step += 1
@@ -238,9 +289,11 @@ class FOMetaASRInterface(PretrainInterface):
                         self.save_per_steps()
         except KeyboardInterrupt:
             logger.warning("Pretraining stopped")
+            self._drain_stats()
             self.save_per_steps()
             self.dashboard.set_status('pretrained(SIGINT)')
         else:
+            self._drain_stats()
             logger.notice("Pretraining completed")
             self.dashboard.set_status('pretrained')
 
@@ -333,6 +386,7 @@ class FOMetaASRInterface(PretrainInterface):
         --fix_snapshot_meta_weights: the META weights are evaluated (and saved); being rank-independent, the dev accents
         are then split over the ranks and the per-accent averages gathered."""
         sh = self.sharder
+        self._drain_stats()
         if self.fix_snapshot:
             eng = self.asr_model.engine
             eng.copy(eng.params, self._original)

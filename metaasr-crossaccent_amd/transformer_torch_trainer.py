@@ -93,6 +93,20 @@ def get_trainer(cls, config, paras, id2accent):
             eng.clip_grads(max_norm)
             return eng.read_stats()['grad_norm']
 
+        def clip_stats_async(self, max_norm, engine=None):
+            """clip_grad_norm_ without the host sync: the clip is queued, and so is the copy of {loss, counts, norm} to the host;
+            returns a handle, .get() -> (info, grad_norm) once that copy has landed (used by the meta loops to stay one
+            meta-step ahead of the GPU)"""
+            eng = engine if engine is not None else self.asr_model.engine
+            eng.clip_grads(max_norm)
+            pend = eng.read_stats_async()
+
+            class _H:
+                def get(self_):
+                    st = pend.get()
+                    return {'loss': st['loss'], 'acc': st['n_correct'] / st['n_total']}, st['grad_norm']
+            return _H()
+
         def probe_model(self, accent_idx):
             pred, gold = self.asr_model.engine.last_logits()
             p0, g0 = torch.argmax(pred[0].cpu(), dim=-1), gold[0].cpu().to(torch.int64)

@@ -50,6 +50,9 @@ def build_parser():
     p.add_argument('--hbm_shards', action='store_true', help='keep the fbank shards resident in HBM (GPU gather+pad)')
     p.add_argument('--tasks_per_gpu', type=int, default=1, help='FOMAML: accent-tasks of a meta-step run concurrently on one GPU '
                    '(replica + HIP stream + host thread each); results are identical to 1 (tasks are independent)')
+    p.add_argument('--sync_stats', action='store_true', help='FOMAML: read every task\'s loss / accuracy / gradient norm back before the next '
+                   'task is queued (the reference\'s timing of its log lines); default: the host runs one meta-step ahead of the GPU and books '
+                   'them then -- same numbers, same order')
     p.add_argument('--fix_snapshot_meta_weights', action='store_true', help='save the META weights in snapshots (reference saves the last task\'s adapted weights)')
     p.add_argument('--fix_reptile', action='store_true', help='run --algo reptile with the published pseudo-gradient (the reference raises ValueError for it)')
     return p

@@ -141,7 +141,8 @@ def make_workspace(root):
         write_toy_shard(root / "data", a, "dev", 3, seed=200 + ai)
 
 
-def run(root, algo, world, rank, fix_snapshot=False, meta_batch=3, steps=5, accents=("af", "au", "en", "us"), meta_k=2, fix_reptile=False):
+def run(root, algo, world, rank, fix_snapshot=False, meta_batch=3, steps=5, accents=("af", "au", "en", "us"), meta_k=2, fix_reptile=False,
+        deferred=False, log_ival=1, eval_ival=2, save_ival=2):
     os.chdir(root)
     model = {"d_model": 64}
     if algo in ("fomaml", "reptile"):
@@ -151,7 +152,7 @@ def run(root, algo, world, rank, fix_snapshot=False, meta_batch=3, steps=5, acce
         model.update({"optimizer_cls": "noam", "optimizer_opt": {"k": 1.0, "warmup_steps": 4}})
     cfg = {"asr_model": model,
            "solver": {"setting": "t", "data_root": "data", "total_steps": 100, "spm_mapping": "data/units.txt", "spm_model": "none",
-                      "label_smoothing": 0.0, "eval_ival": 2, "log_ival": 1, "save_ival": 2, "batch_size": 4, "dev_batch_size": 4,
+                      "label_smoothing": 0.0, "eval_ival": eval_ival, "log_ival": log_ival, "save_ival": save_ival, "batch_size": 4, "dev_batch_size": 4,
                       "min_ilen": 10, "max_ilen": 50, "dev_max_ilen": 3000, "half_batch_ilen": 30}}
     paras = SimpleNamespace(pretrain_suffix=f"w{world}", pretrain_accents=list(accents), num_pretrain=len(accents), tgt_accent="ca", runs=0,
                             overwrite=True, seed=531, meta_k=meta_k, meta_batch_size=meta_batch, sample_strategy="normal", max_step=steps,
@@ -164,6 +165,25 @@ def run(root, algo, world, rank, fix_snapshot=False, meta_batch=3, steps=5, acce
         from masr_amd.multi_interface import MultiASRInterface as Iface
     log = []
     solver = get_cpu_trainer(Iface, cfg, paras, ACCENTS, log)
+    booked = []
+    if deferred:
+        # a trainer WITH the asynchronous stats read (as the HIP one): run_batch(want_info=False) returns nothing, the numbers
+        # come out of a handle whenever the loop asks for them -- the handle notes at which meta-step that happened
+        eng_of = lambda: solver.asr_model.engine
+        plain_rb = solver.run_batch
+        solver.run_batch = lambda *a, want_info=True, **k: (plain_rb(*a, **k) if want_info else (plain_rb(*a, **k), None)[1])
+        solver._train = partial(solver.run_batch, train=True)
+
+        def clip_stats_async(max_norm, engine=None):
+            eng_of().clip_grads(max_norm)
+            st, made = dict(eng_of().read_stats()), solver.global_step
+
+            class H:
+                def get(self_):
+                    booked.append((made, solver.global_step))
+                    return {'loss': st['loss'], 'acc': 0.5}, st['grad_norm']
+            return H()
+        solver.clip_stats_async = clip_stats_async
     solver.load_data()
     solver.set_model()
     solver.exec()
@@ -171,7 +191,8 @@ def run(root, algo, world, rank, fix_snapshot=False, meta_batch=3, steps=5, acce
     files = sorted(p.name for p in solver.log_dir.iterdir()) if rank == 0 else []
     dev_log = (solver.log_dir / "dev_avg_wer").read_text() if rank == 0 and (solver.log_dir / "dev_avg_wer").exists() else ""
     return {"weights": weights, "train_fps": [fp for tr, fp in log if tr], "files": files, "dev_avg_wer": dev_log,
-            "global_step": solver.global_step}
+            "global_step": solver.global_step, "train_info": {k: float(v) for k, v in solver.train_info.items()}, "booked": booked,
+            "train_loss_log": (solver.log_dir / "train_loss").read_text() if rank == 0 and (solver.log_dir / "train_loss").exists() else ""}
 
 
 def _worker(rank, world, port, root, algo, fix_snapshot, out_dir, kw):
@@ -206,6 +227,23 @@ def workspace():
         make_workspace(d)
         yield d
         os.chdir(cwd)
+
+
+def test_deferred_task_stats_are_booked_one_meta_step_late_with_the_same_numbers(workspace):
+    """the host may run one meta-step ahead of the GPU: a task's {loss, acc, norm} are then read back while the NEXT meta-step is
+    queued.  Same weights, same running averages, same train_* log lines as with a read-back per task; every handle is consumed
+    at the latest one meta-step after it was made, and before anything reads train_info (log line, evaluate, snapshot)."""
+    ref = run(workspace, "fomaml", 1, 0, steps=7, log_ival=3, eval_ival=4, save_ival=5)
+    got = run(workspace, "fomaml", 1, 0, steps=7, log_ival=3, eval_ival=4, save_ival=5, deferred=True)
+    assert torch.equal(ref["weights"], got["weights"]) and ref["train_fps"] == got["train_fps"]
+    assert ref["train_info"] == got["train_info"] and ref["train_loss_log"] == got["train_loss_log"] and ref["dev_avg_wer"] == got["dev_avg_wer"]
+    steps_run = sorted({made for made, _ in got["booked"]})
+    assert not ref["booked"] and len(steps_run) >= 7 and len(got["booked"]) == 3 * len(steps_run)    # 3 tasks per meta-step, each booked once
+    lag = [at - made for made, at in got["booked"]]
+    assert set(lag) == {0, 1} and lag.count(1) >= 6                                 # mostly a step late, never more
+    for made, at in got["booked"]:
+        if made % 3 == 0 or made % 4 == 0 or (made + 1) % 5 == 0:                  # log / evaluate / snapshot at that step: booked before
+            assert at == made
 
 
 @pytest.mark.parametrize("fix_snapshot", [False, True])

@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--root", default="/tmp/masr_e2e")
     ap.add_argument("--out", default=None)
     ap.add_argument("--configs", default="host:1,host:4,hbm:1,hbm:4", help="comma list of <host|hbm>:<tasks_per_gpu>")
+    ap.add_argument("--sync-stats", action="store_true", help="pretrain.py --sync_stats: one host sync per task (the host cannot run ahead of the GPU)")
     args = ap.parse_args()
 
     import masr_amd  # noqa: F401
@@ -90,7 +91,7 @@ def main():
                                 runs=0, overwrite=True, seed=531, meta_k=1, meta_batch_size=4, sample_strategy="normal", max_step=n_steps + 1,
                                 resume=False, model_name="transformer", algo="fomaml", njobs=args.njobs, is_bucket=True, is_memmap=True,
                                 use_tensorboard=False, device="cuda:0", tasks_per_gpu=int(k),
-                                hbm_shards_device="cuda:0" if where == "hbm" else None)
+                                hbm_shards_device="cuda:0" if where == "hbm" else None, sync_stats=args.sync_stats)
         random.seed(531); np.random.seed(531); torch.manual_seed(531)
         solver = get_trainer(FOMetaASRInterface, cfg, paras, dict(ACC + [("ca", "canada")]))
         tl = time.perf_counter()
@@ -107,15 +108,19 @@ def main():
 
         def final(n_tasks=None):
             orig_final(n_tasks)
-            torch.cuda.synchronize()
+            if len(stamps) + 1 in (args.warm, n_steps):              # the two ends of the timed region only: in between the host
+                torch.cuda.synchronize()                             # runs ahead of the GPU as it does in a real run
             stamps.append((time.perf_counter(), utts[0]))
         from functools import partial
         solver._train = partial(rb, train=True)
         solver._final_meta_update = final
+        hs0 = dict(torch.cuda.host_memory_stats()) if hasattr(torch.cuda, "host_memory_stats") else {}
         solver.exec()
+        hs1 = dict(torch.cuda.host_memory_stats()) if hs0 else {}
         (ta, ua), (tb, ub) = stamps[args.warm - 1], stamps[-1]
         res = {"shards": where, "tasks_per_gpu": int(k), "meta_steps": len(stamps) - args.warm, "utt": ub - ua, "seconds": tb - ta,
-               "utt_per_s": (ub - ua) / (tb - ta), "ms_per_meta_step": (tb - ta) / (len(stamps) - args.warm) * 1e3, "load_data_s": t_load}
+               "utt_per_s": (ub - ua) / (tb - ta), "ms_per_meta_step": (tb - ta) / (len(stamps) - args.warm) * 1e3, "load_data_s": t_load,
+               "pinned_allocs_during_run": {k: hs1[k] - hs0.get(k, 0) for k in hs1 if ("num_host_alloc" in k or "host_alloc_time.total" in k or k == "allocated_bytes.allocated")} if hs0 else None}
         print(json.dumps(res), file=sys.stderr, flush=True)
         results.append(res)
         del solver
