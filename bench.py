@@ -211,7 +211,8 @@ def main():
             xs, self.il, self.ys, self.ol = synth_batch(B, T, D, seed=rank * 64 + k)   # numpy seed 0 + task index
             self.xs = xs.to(dev)
             self.mom = torch.zeros_like(self.eng.params)
-            self.stream = torch.cuda.Stream(device=dev)
+            # slot 0 on the default stream, as in FOMetaASRInterface: never more than K streams with work queued
+            self.stream = torch.cuda.current_stream(dev) if k == 0 else torch.cuda.Stream(device=dev)
             self.i = 0
 
         def step(self):
