@@ -191,11 +191,16 @@ class MonoASRInterface(TrainInterface):
                 torch.save(self._sd_cpu(), self.log_dir.joinpath("snapshot.init"))
             while self.ep < self.max_epoch:
                 for cur_b, (x, ilens, ys, olens) in enumerate(self.train_set):
-                    info = self._train(cur_b, x, ilens, ys, olens)
-                    self.train_info.add(info, len(ys))
+                    # one host sync per step where the trainer can defer the batch's {loss, acc} to the copy that brings the
+                    # gradient norm back (the NaN test below needs that one on the host before the optimiser may step)
+                    one_sync = hasattr(self, 'info_from_stats')
+                    info = self._train(cur_b, x, ilens, ys, olens, want_info=False) if one_sync else self._train(cur_b, x, ilens, ys, olens)
                     if self.frozen_mask is not None:
                         eng.grads.mul_(self.frozen_mask)
                     grad_norm = self.clip_grad_norm_(GRAD_CLIP)
+                    if info is None:
+                        info = self.info_from_stats()
+                    self.train_info.add(info, len(ys))
                     if math.isnan(grad_norm):
                         logger.warning(f"grad norm NaN @ step {self.global_step}")
                     else:

@@ -74,12 +74,15 @@ class MultiASRInterface(PretrainInterface):
                         item = self.data_container.get_item(materialize=(r == self.sharder.rank))[0]
                         if r == self.sharder.rank:
                             idx, (x, ilens, ys, olens) = item
-                    info = self._train(idx, x, ilens, ys, olens, accent_idx=idx)
-                    self.train_info.add(info, len(ys))
+                    one_sync = hasattr(self, 'info_from_stats')            # {loss, acc} ride on the copy that brings the norm back
+                    info = self._train(idx, x, ilens, ys, olens, accent_idx=idx, **({'want_info': False} if one_sync else {}))
                     if self.sharder.world > 1:                            # DP: mean gradient over ranks
                         self.sharder.all_reduce(eng.grads)
                         eng.scale(eng.grads, 1.0 / self.sharder.world)
                     grad_norm = self.clip_grad_norm_(GRAD_CLIP)
+                    if info is None:
+                        info = self.info_from_stats()
+                    self.train_info.add(info, len(ys))
                     if math.isnan(grad_norm):
                         logger.warning(f"grad norm NaN @ step {self.global_step}")
                     else:
