@@ -236,7 +236,7 @@ def test_multi_task_interface_runs_and_learns(tmp_path, monkeypatch):
     losses = []
     orig = s.run_batch
     def spy(*a, **k):
-        info = orig(*a, **k); losses.append(info["loss"]); return info
+        info = orig(*a, **{**k, "want_info": True}); losses.append(info["loss"]); return info
     from functools import partial
     s._train = partial(spy, train=True)
     s.exec()
