@@ -93,6 +93,11 @@ int masr_adam_step(float* params, const float* grads, float* exp_avg, float* exp
 /* torch.optim.AdamW (decoupled != 0: p *= 1 - lr*weight_decay, then the Adam update) or torch.optim.Adam with its L2
  * weight_decay (decoupled == 0: g += weight_decay*p) -- config/transformer/adapt/hkust-adamw.yaml through
  * getattr(torch.optim, cls) (src/transformer_torch_trainer.py:44-46) */
+/* the meta update of one meta-step in ONE pass: Adam on g = (((g_0 + g_1) + ...) + g_{n-1}) * gscale, the per-task gradients read
+   straight from n <= 8 device buffers (`grads` is a HOST array of device pointers).  Replaces the accumulator of
+   fo_meta_interface.py:180-202 (zero + n axpy passes + scale pass + Adam pass) with the same additions in the same order. */
+int masr_adam_sum_step(float* p, const float* const* grads, int n_grads, float gscale, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       float lr, float b1, float b2, float eps, int step, void* stream);
 int masr_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                     float beta1, float beta2, float eps, float weight_decay, int decoupled, int step, void* stream);
 /* optimizer_cls 'RAdam' of set_model (src/transformer_torch_trainer.py:36-41).  The reference takes it from `torch_optimizer`, an

@@ -917,6 +917,10 @@ int masr_clip_accumulate(masr_model* m, float* updates, float max_norm, void* st
 int masr_adam_step(float* p, const float* g, float* ea, float* eas, int64_t n, float lr, float b1, float b2, float eps, int step, void* stream) {
     return mk_adam(p, g, ea, eas, n, lr, b1, b2, eps, step, 0.f, 0, (hipStream_t)stream);
 }
+int masr_adam_sum_step(float* p, const float* const* grads, int n_grads, float gscale, float* ea, float* eas, int64_t n, float lr, float b1,
+                       float b2, float eps, int step, void* stream) {
+    return mk_adam_sum(p, grads, n_grads, gscale, ea, eas, n, lr, b1, b2, eps, step, (hipStream_t)stream);
+}
 int masr_adamw_step(float* p, const float* g, float* ea, float* eas, int64_t n, float lr, float b1, float b2, float eps, float weight_decay,
                     int decoupled, int step, void* stream) {
     return mk_adam(p, g, ea, eas, n, lr, b1, b2, eps, step, weight_decay, decoupled, (hipStream_t)stream);

@@ -136,6 +136,24 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
                             one(pv.x, gv.x, mv.x, vv.x); one(pv.y, gv.y, mv.y, vv.y); one(pv.z, gv.z, mv.z, vv.z); one(pv.w, gv.w, mv.w, vv.w);
                             F4P(p)[i] = pv; F4P(m)[i] = mv; F4P(v)[i] = vv; });
 }
+// the same step on g = (((g0 + g1) + g2) + ...) * scale, the sum the meta loop used to build with one axpy pass per task and a
+// scale pass (same additions in the same order: bit-identical), read straight from the task slots' gradient buffers
+struct GradList { const float* g[8]; int n; float scale; };
+__global__ void adam_sum_kernel(float* __restrict__ p, GradList gl, float* __restrict__ m, float* __restrict__ v,
+                                long n, float step_size, float b1, float b2, float eps, float inv_sqrt_bc2, int vec) {
+    auto one = [&](float& pp, float gg, float& mm, float& vv) {
+        mm = mm + (gg - mm) * (1.f - b1);
+        vv = b2 * vv + (1.f - b2) * gg * gg;
+        pp = pp - step_size * mm / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+    };
+    flat_pass(n, vec, [&](long i) { float gg = 0.f + gl.g[0][i]; for (int k = 1; k < gl.n; ++k) gg += gl.g[k][i]; one(p[i], gg * gl.scale, m[i], v[i]); },
+              [&](long i) { float4 pv = F4C(p)[i], mv = F4C(m)[i], vv = F4C(v)[i]; float4 gv = F4C(gl.g[0])[i];
+                            gv.x = 0.f + gv.x; gv.y = 0.f + gv.y; gv.z = 0.f + gv.z; gv.w = 0.f + gv.w;
+                            for (int k = 1; k < gl.n; ++k) { const float4 t = F4C(gl.g[k])[i]; gv.x += t.x; gv.y += t.y; gv.z += t.z; gv.w += t.w; }
+                            one(pv.x, gv.x * gl.scale, mv.x, vv.x); one(pv.y, gv.y * gl.scale, mv.y, vv.y);
+                            one(pv.z, gv.z * gl.scale, mv.z, vv.z); one(pv.w, gv.w * gl.scale, mv.w, vv.w);
+                            F4P(p)[i] = pv; F4P(m)[i] = mv; F4P(v)[i] = vv; });
+}
 __global__ void cast_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, long n) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = (bf16)x[i];
@@ -331,6 +349,17 @@ int mk_adam(float* p, const float* g, float* m, float* v, long n, float lr, floa
     const double bc1 = 1.0 - pow((double)b1, t), bc2 = 1.0 - pow((double)b2, t);
     hipLaunchKernelGGL(adam_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, s, p, g, m, v, n, (float)(lr / bc1), b1, b2, eps,
                        (float)(1.0 / sqrt(bc2)), decoupled ? 1.f - lr * weight_decay : 1.f, decoupled ? 0.f : weight_decay, aligned16(p, g, m, v));
+    return LAUNCH_OK();
+}
+int mk_adam_sum(float* p, const float* const* grads, int n_grads, float gscale, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                int t, hipStream_t s) {
+    if (n_grads < 1 || n_grads > 8) { mk_set_error("mk_adam_sum", "1 to 8 gradient buffers"); return -1; }
+    GradList gl{}; gl.n = n_grads; gl.scale = gscale;
+    bool al = aligned16(p, m, v);
+    for (int k = 0; k < n_grads; ++k) { gl.g[k] = grads[k]; al = al && !((uintptr_t)grads[k] & 15); }
+    const double bc1 = 1.0 - pow((double)b1, t), bc2 = 1.0 - pow((double)b2, t);
+    hipLaunchKernelGGL(adam_sum_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, s, p, gl, m, v, n, (float)(lr / bc1), b1, b2, eps,
+                       (float)(1.0 / sqrt(bc2)), al ? 1 : 0);
     return LAUNCH_OK();
 }
 // RAdam (Liu et al. 2020, as torch.optim.RAdam): Adam moments; while the variance estimate is unreliable (rho_t <= 5) the step is

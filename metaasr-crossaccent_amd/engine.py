@@ -247,6 +247,12 @@ class MasrEngine:
         else:
             check(self._l.masr_adam_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, b1, b2, eps, step, self.stream()), "masr_adam_step")
 
+    def adam_sum_step(self, params, grad_list, gscale, m, v, lr, b1, b2, eps, step):
+        """Adam on (sum of grad_list, in order) * gscale in one pass (include/masr.h masr_adam_sum_step)"""
+        arr = (C.c_void_p * len(grad_list))(*[g.data_ptr() for g in grad_list])
+        check(self._l.masr_adam_sum_step(_ptr(params), arr, len(grad_list), gscale, _ptr(m), _ptr(v), params.numel(), lr, b1, b2, eps, step,
+                                         self.stream()), "masr_adam_sum_step")
+
     def radam_step(self, params, grads, m, v, lr, b1, b2, eps, step, weight_decay=0.0):
         check(self._l.masr_radam_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, b1, b2, eps, weight_decay, step, self.stream()),
               "masr_radam_step")

@@ -17,11 +17,21 @@ class FlatAdam:
         self.exp_avg_sq = torch.zeros_like(params_flat)
         self.t = 0
         self.grad = None                      # set by the caller before step()
+        self.grad_list, self.grad_scale = None, 1.0     # ... or: several buffers whose (in-order) sum * grad_scale is the gradient
 
     def zero_grad(self):
         self.grad = None
+        self.grad_list = None
 
     def step(self):
+        if self.grad_list:
+            assert not self.weight_decay, "summed-gradient step: plain Adam only"
+            self.t += 1
+            self.engine.adam_sum_step(self.params, self.grad_list, self.grad_scale, self.exp_avg, self.exp_avg_sq,
+                                      self.param_groups[0]['lr'], self.betas[0], self.betas[1], self.eps, self.t)
+            if self.params.data_ptr() == self.engine.params.data_ptr():
+                self.engine.mark_dirty()
+            return
         assert self.grad is not None, "FlatAdam.step(): no gradient attached"
         self.t += 1
         self.engine.adam_step(self.params, self.grad, self.exp_avg, self.exp_avg_sq, self.param_groups[0]['lr'],

@@ -53,7 +53,13 @@ def product_run(tmp_path, golden_dir, meta_k, tasks_per_gpu=1):
     orig_final = solver._final_meta_update
 
     def final_spy(n_tasks=None):
-        mg = (solver._updates / solver._counter).cpu()
+        if solver._updates is not None:
+            mg = (solver._updates / solver._counter).cpu()
+        else:                                                      # fused meta update: the tasks' gradient buffers, summed in task order
+            acc = torch.zeros_like(solver._task_grads[0])
+            for g_ in solver._task_grads:
+                acc += g_
+            mg = (acc / solver._counter).cpu()
         orig_final(n_tasks)
         torch.cuda.synchronize()
         steps.append((mg, solver._original.cpu().clone()))
