@@ -34,10 +34,9 @@ def _ptr(t):
 
 
 class PendingStats:
-    """stats block of one batch on its way to the host (MasrEngine.read_stats_async).  Completion is detected by POLLING the
-    page-locked words themselves (pre-set to a NaN bit pattern no kernel produces): on this ROCm, synchronising an event that was
-    recorded earlier on a stream which has had more work queued since waits for that later work too, i.e. it would hand the host
-    back exactly the lock-step this class exists to avoid (measured: tools/gap_analysis.py on the pretrain loop)."""
+    """stats block of one batch on its way to the host (MasrEngine.read_stats_async).  Completion is detected by polling the
+    page-locked words themselves, pre-set to a NaN bit pattern no kernel produces: no event object per task and no HIP call from
+    the waiting thread (the task threads are inside the launch path at that moment; the runtime serialises callers)."""
     SENTINEL = 0x7FC0DEAD                                     # a quiet NaN with a payload
 
     def __init__(self, buf):
@@ -48,10 +47,14 @@ class PendingStats:
         return not bool((self.bits == self.SENTINEL).any())
 
     def get(self):
-        n = 0
+        n, t0 = 0, None
         while not self.ready():
             n += 1
             time.sleep(0 if n < 50 else 5e-5)                 # (releases the interpreter to the task threads either way)
+            if n % 4096 == 0:
+                t0 = t0 or time.monotonic()
+                if time.monotonic() - t0 > 300.0:
+                    raise RuntimeError("the stats of a queued batch never reached the host (stream wedged, or the batch failed to launch)")
         b = self.buf
         return {"loss": float(b[0]), "n_correct": float(b[1]), "n_total": float(b[2]), "grad_norm": float(b[3])}
 
