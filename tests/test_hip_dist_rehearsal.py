@@ -69,6 +69,8 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert d["config"]["tasks"] == 4 and d["long_run"]["seconds"] >= 0.2
     ms = d["meta_step"]
     assert ms["tasks"] == 4 and ms["allreduces_per_meta_step"] == 2 and ms["ms"] >= ms["ms_without_exchange"] > 0 and ms["allreduce_ms_isolated"] > 0
+    cs = ms["concurrent_slots"]                                                       # 2 ranks x 2 task slots, one all-reduce of the local sum
+    assert cs["tasks_per_gpu"] == 2 and cs["tasks"] == 4 and cs["allreduces_per_meta_step"] == 1 and cs["ms"] > 0
     assert "roofline" in d and d["roofline"]["slot"] in d["roofline"]["launches"]
     bad = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1"], cwd=tmp_path, env=dict(env, WORLD_SIZE="1"),
                          capture_output=True, text=True, timeout=120)
