@@ -156,10 +156,13 @@ class FOMetaASRInterface(PretrainInterface):
 
     def _task_on_slot(self, slot, tr_batches, val_batch, out, i):
         """one task = run_task + val-batch gradient + clip, entirely on the slot's stream (host thread body)"""
-        with torch.cuda.stream(slot['stream']):
-            self.run_task(tr_batches, engine=slot['engine'])
-            info = self._train(val_batch[0], *val_batch[1], accent_idx=val_batch[0], engine=slot['engine'], want_info=False)
-            out[i] = self._clip_and_stats(info, engine=slot['engine'])
+        try:
+            with torch.cuda.stream(slot['stream']):
+                self.run_task(tr_batches, engine=slot['engine'])
+                info = self._train(val_batch[0], *val_batch[1], accent_idx=val_batch[0], engine=slot['engine'], want_info=False)
+                out[i] = self._clip_and_stats(info, engine=slot['engine'])
+        except BaseException as e:                                # re-raised on the main thread after the join
+            out[i] = e
 
     def _clip_and_stats(self, info, engine=None):
         """clip_grad_norm_(GRAD_CLIP) of the val-batch gradient + the task's {loss, acc} and norm, as a handle: with a trainer that
@@ -213,6 +216,9 @@ class FOMetaASRInterface(PretrainInterface):
                 while_running(); while_running = None
             for t in threads:
                 t.join()
+            for o in out:
+                if isinstance(o, BaseException):
+                    raise o
             for i, (accent_id, tr, val) in enumerate(wave):
                 sl = self._slots[i]
                 if sl['stream'] != main:
