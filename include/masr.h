@@ -79,7 +79,10 @@ int masr_last_logits(masr_model* m, const float** logits, const int32_t** gold, 
 
 /* nn.utils.clip_grad_norm_(parameters, max_norm) (fo_meta_interface.py:148-149,242-243): norm only */
 int masr_grad_norm(masr_model* m, void* stream);
-/* ... followed by `if not isnan(norm): SGD(lr, momentum, nesterov).step()` (fo_meta_interface.py:228-248) */
+/* ... followed by `if not isnan(norm): SGD(lr, momentum, nesterov).step()` (fo_meta_interface.py:228-248).
+   first_step: bit 0 = the optimiser's first step (torch creates the momentum buffer as a copy of the gradient: the buffer is not
+   read); bit 1 = its last step (run_task drops its SGD after k steps, :228-250: the buffer is not written).  With both bits set
+   (meta_k = 1) momentum_buf is not touched and may be null. */
 int masr_clip_sgd_step(masr_model* m, float* momentum_buf, float max_norm, float lr, float momentum, int nesterov,
                        int first_step, void* stream);
 /* clip in place (multi_interface.py:108-109, mono fine-tune) */

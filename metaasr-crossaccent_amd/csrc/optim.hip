@@ -52,7 +52,10 @@ __device__ __forceinline__ float clip_coef(float norm, float max_norm) {
 // torch.optim.SGD(momentum, nesterov, dampening 0): buf = first ? g : m*buf + g; p -= lr*(nesterov ? g + m*buf : buf)
 __global__ void clip_sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom, long n,
                                 const float* __restrict__ norm, float max_norm, float lr, float momentum, int nesterov,
-                                int first_step, int vec) {
+                                int step_flags, int vec) {
+    // step_flags: bit 0 = first step of this optimiser (no buffer yet: buf = g); bit 1 = its LAST step (the optimiser is dropped
+    // afterwards, as run_task drops its SGD after k steps: the buffer update would be a dead 4 B/param store and is skipped)
+    const int first_step = step_flags & 1;
     float coef = 1.f;
     if (norm) {
         const float nv = norm[0];
@@ -72,19 +75,19 @@ __global__ void clip_sgd_kernel(float* __restrict__ p, const float* __restrict__
     // 16 bytes per lane and stream (the flat buffers are 16-byte aligned allocations): a 4-byte-per-lane pass needs four times
     // the vector-memory instructions for the same bytes
     const long n4 = vec ? n >> 2 : 0, stride = (long)gridDim.x * blockDim.x;
-    const bool use_m = momentum != 0.f, rd_m = use_m && !first_step;
+    const bool use_m = momentum != 0.f, rd_m = use_m && !first_step, wr_m = use_m && !(step_flags & 2);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         const float4 pv = reinterpret_cast<const float4*>(p)[i], gv = reinterpret_cast<const float4*>(g)[i];
         float4 mv = rd_m ? reinterpret_cast<const float4*>(mom)[i] : float4{0.f, 0.f, 0.f, 0.f};
         float4 o;
         o.x = upd(pv.x, gv.x, mv.x, mv.x); o.y = upd(pv.y, gv.y, mv.y, mv.y); o.z = upd(pv.z, gv.z, mv.z, mv.z); o.w = upd(pv.w, gv.w, mv.w, mv.w);
         reinterpret_cast<float4*>(p)[i] = o;
-        if (use_m) reinterpret_cast<float4*>(mom)[i] = mv;
+        if (wr_m) reinterpret_cast<float4*>(mom)[i] = mv;
     }
     for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {      // tail (n % 4 elements)
         float mo = rd_m ? mom[i] : 0.f;
         p[i] = upd(p[i], g[i], mo, mo);
-        if (use_m) mom[i] = mo;
+        if (wr_m) mom[i] = mo;
     }
 }
 // element-wise passes over flat fp32 buffers, 16 bytes per lane and stream when every pointer is 16-byte aligned (vec), with a

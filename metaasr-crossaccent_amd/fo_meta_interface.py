@@ -385,7 +385,8 @@ class FOMetaASRInterface(PretrainInterface):
         mp = self.config['asr_model']
         if mp['inner_optimizer_cls'] != 'SGD':
             raise NotImplementedError(f"inner optimizer {mp['inner_optimizer_cls']}")
-        opt = FlatSGD(eng, self.inner_lr, mp['inner_optimizer_opt']['momentum'], mp['inner_optimizer_opt']['nesterov'])
+        opt = FlatSGD(eng, self.inner_lr, mp['inner_optimizer_opt']['momentum'], mp['inner_optimizer_opt']['nesterov'],
+                      total_steps=len(batches))          # (dropped after these k steps, :228-250)
         if engine is None:
             self.asr_opt = opt
         for idx, (x, ilens, ys, olens) in batches:

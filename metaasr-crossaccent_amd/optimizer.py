@@ -68,10 +68,13 @@ class FlatRAdam(FlatAdam):
 class FlatSGD:
     """torch.optim.SGD(lr, momentum, nesterov) on the engine's own params/grads; `clip` fuses clip_grad_norm_."""
 
-    def __init__(self, engine, lr, momentum=0.0, nesterov=False):
+    def __init__(self, engine, lr, momentum=0.0, nesterov=False, total_steps=None):
+        """total_steps: the optimiser is known to be dropped after that many steps (run_task's per-task SGD): its last step does
+        not write the momentum buffer, and with total_steps == 1 there is no buffer at all"""
         self.engine, self.lr, self.momentum, self.nesterov = engine, lr, momentum, nesterov
         self.param_groups = [{'lr': lr}]
-        self.buf = torch.zeros_like(engine.params) if momentum != 0 else None
+        self.total_steps, self.n_steps = total_steps, 0
+        self.buf = torch.zeros_like(engine.params) if momentum != 0 and total_steps != 1 else None
         self.first = True
 
     def zero_grad(self):
@@ -86,7 +89,10 @@ class FlatSGD:
     def clip_and_step(self, max_norm):
         """clip_grad_norm_(max_norm) + `if not isnan(norm): step()` in one pass (fo_meta_interface.py:242-248)."""
         e = self.engine
-        e.clip_sgd_step(self.buf, max_norm, self.param_groups[0]['lr'], self.momentum, self.nesterov, self.first)
+        self.n_steps += 1
+        flags = (1 if self.first else 0) | (2 if self.total_steps is not None and self.n_steps >= self.total_steps else 0)
+        assert self.buf is not None or self.momentum == 0 or flags == 3, "FlatSGD: more steps than total_steps"
+        e.clip_sgd_step(self.buf, max_norm, self.param_groups[0]['lr'], self.momentum, self.nesterov, flags)
         self.first = False
 
     def state_dict(self):

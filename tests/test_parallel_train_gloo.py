@@ -75,11 +75,10 @@ class CpuEngine:
     def clip_sgd_step(self, buf, max_norm, lr, momentum, nesterov, first):
         self.clip_grads(max_norm)
         g = self.grads
-        if first:
-            buf.copy_(g)
-        else:
-            buf.mul_(momentum).add_(g)
-        self.params.sub_(lr * (g + momentum * buf if nesterov else buf))
+        b = g.clone() if int(first) & 1 else buf * momentum + g          # bit 0: first step; bit 1: last step (buffer not kept)
+        if buf is not None and not int(first) & 2:
+            buf.copy_(b)
+        self.params.sub_(lr * (g + momentum * b if nesterov else b))
 
     def adam_step(self, p, g, m, v, lr, b1, b2, eps, t, weight_decay=0.0, decoupled=False):
         m.mul_(b1).add_(g, alpha=1 - b1)
