@@ -160,6 +160,10 @@ class MasrEngine:
         ilens/olens: int64 host tensors; ys: list of int64 host tensors."""
         if xs.device != self.device:
             xs = xs.to(self.device, non_blocking=True)
+        elif xs.is_cuda:
+            # made on another stream (HBM-resident shards are gathered on the main stream a meta-step ahead): tell the allocator it
+            # is read on this one, or the block could be handed out again while this stream's backward still needs it
+            xs.record_stream(torch.cuda.current_stream(self.device))
         xs = xs.contiguous().float()
         B, T, D = xs.shape
         assert D == self.cfg.idim, f"idim mismatch {D} vs {self.cfg.idim}"
