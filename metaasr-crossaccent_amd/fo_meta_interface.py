@@ -334,7 +334,7 @@ class FOMetaASRInterface(PretrainInterface):
             eng.axpy(contrib, eng.params, -1.0)
         else:
             contrib = eng.grads.clone()                                   # per-task buffer handed to the side stream
-        self.sharder.reduce_async(contrib)
+        self.sharder.reduce_async(contrib, side_stream=getattr(self, 'tasks_per_gpu', 1) == 1)
         self._updates.append(contrib)
 
     def _pad_rounds(self, n_tasks, n_local):

@@ -69,9 +69,11 @@ class TaskSharder:
             self._side = torch.cuda.Stream(device=device)
         return self._side
 
-    def reduce_async(self, buf):
+    def reduce_async(self, buf, side_stream=True):
         """all-reduce(sum) `buf` in place, overlapped with whatever the caller enqueues next on the main stream.
-        The caller must not touch `buf` until wait_all()."""
+        The caller must not touch `buf` until wait_all().  side_stream=False: issued from the current stream (RCCL still runs it on
+        its own stream) -- for callers that already keep four streams busy, where one more stream with work queued displaces a
+        task's and nothing is left to overlap with anyway."""
         if self.world == 1:
             return
         import torch.distributed as dist
@@ -83,7 +85,9 @@ class TaskSharder:
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
             buf.copy_(host)
             return
-        if buf.device.type == "cuda":
+        if buf.device.type == "cuda" and not side_stream:
+            self._pending.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), None))
+        elif buf.device.type == "cuda":
             side = self._side_stream(buf.device)
             side.wait_stream(torch.cuda.current_stream(buf.device))
             with torch.cuda.stream(side):
