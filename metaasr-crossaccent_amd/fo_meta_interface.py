@@ -195,7 +195,7 @@ class FOMetaASRInterface(PretrainInterface):
         # slot 0 runs ON the main stream: K streams in all.  The chip serves four compute queues at a time; with the host
         # running ahead, a fifth queue holding nothing but the meta-update behind its waits on the task streams still takes
         # one of the four places, and one task stream then only gets served once the other three have drained (measured:
-        # three tasks done after 14.8 ms, the fourth after 23.3 ms; tools/_prof_e2e.py)
+        # three tasks done after 14.8 ms, the fourth after 23.3 ms; tools/e2e_gpu_timeline.py)
         self._slots[0]['stream'] = main
         K = self.tasks_per_gpu
         # every task of the meta-step on a slot of its own: the meta update reads the K gradient buffers directly (one pass
