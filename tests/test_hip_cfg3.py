@@ -198,3 +198,40 @@ def test_cfg3_concurrent_slots_bit_identical(golden_dir, tmp_path, monkeypatch):
         outs.append((steps[-1][1], (solver.log_dir / "train_loss").read_text(), sorted(round(c[4]["loss"], 6) for c in calls if c[1])))
     assert torch.equal(outs[0][0], outs[1][0])
     assert outs[0][2] == outs[1][2]
+
+
+@pytest.mark.parametrize("k", [1, 4])
+def test_host_running_ahead_books_the_same_stats(golden_dir, tmp_path, monkeypatch, k):
+    """default: the task stats come back asynchronously and are booked a meta-step later (the host queues the next meta-step
+    meanwhile); --sync_stats: read back per task.  Same meta weights bit for bit, same running averages, same train_* / dev_* log
+    files (evaluate() runs for real after meta-step 4, the first reader of train_info in this run)."""
+    monkeypatch.chdir(tmp_path)
+    runs = []
+    for sync in (True, False):
+        cfg = cfg3_workspace(tmp_path, golden_dir)
+        cfg["solver"].update(log_ival=1000, eval_ival=4, save_ival=1000)
+        paras = cfg3_paras(1, device="cuda:0", tasks_per_gpu=k, cuda=True, no_cuda=False, njobs=2, sync_stats=sync)
+        random.seed(531); np.random.seed(531); torch.manual_seed(531)
+        solver = get_trainer(FOMetaASRInterface, cfg, paras, dict(CFG3_ACCENTS + [("ca", "canada")]))
+        solver.load_data(); solver.set_model()
+        solver.asr_model.load_state_dict(ref_cpu.deterministic_state_dict(cfg["asr_model"], ODIM, seed=7))
+        solver.load_model()
+        made, booked_at = [], []
+        orig = solver._clip_and_stats
+
+        def clip_and_stats(info, engine=None):
+            h = orig(info, engine=engine)
+            made.append(type(h).__name__)
+            return h
+        solver._clip_and_stats = clip_and_stats
+        orig_add = solver.train_info.add
+        solver.train_info.add = lambda info, n=1: (booked_at.append(solver.global_step), orig_add(info, n))[1]
+        solver.exec()
+        torch.cuda.synchronize()
+        logs = {p.name: p.read_text() for p in sorted(solver.log_dir.iterdir()) if p.name.startswith(("train_", "dev_"))}
+        runs.append((solver._original.clone(), dict(solver.train_info), logs, set(made), booked_at))
+        assert not solver._pending
+    assert runs[0][3] == {"_Resolved"} and runs[1][3] == {"_H"}             # the two paths were really taken
+    assert torch.equal(runs[0][0], runs[1][0])
+    assert runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2] and any(n.startswith("dev_") for n in runs[0][2])
+    assert runs[1][4] == runs[0][4] and runs[1][4][:4] == [2, 2, 2, 2]      # meta-step 1's four tasks are booked during meta-step 2
