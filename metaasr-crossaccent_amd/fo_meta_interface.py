@@ -192,9 +192,9 @@ class FOMetaASRInterface(PretrainInterface):
         concurrently, one replica + stream + host thread each; gradients are accumulated in task order -> deterministic."""
         fetched = [(a, [(i, f.result()) for i, f in tr], (val[0], val[1].result())) for a, tr, val in drawn]
         main = torch.cuda.current_stream()
-        # slot 0 runs ON the main stream: K streams in all.  The chip serves four compute queues at a time; with the host
-        # running ahead, a fifth queue holding nothing but the meta-update behind its waits on the task streams still takes
-        # one of the four places, and one task stream then only gets served once the other three have drained (measured:
+        # slot 0 runs ON the main stream: K streams in all.  Four streams run side by side without loss (tools/queue_probe.py);
+        # with the host running ahead, a fifth queue holding nothing but the meta-update behind its waits on the task streams
+        # shares a place with one task stream, which then only gets served once the other three have drained (measured:
         # three tasks done after 14.8 ms, the fourth after 23.3 ms; tools/e2e_gpu_timeline.py)
         self._slots[0]['stream'] = main
         K = self.tasks_per_gpu
