@@ -32,7 +32,7 @@ def chain(k, s):
 
 
 print(f"GPU_MAX_HW_QUEUES={os.environ['GPU_MAX_HW_QUEUES']}, chains of {N} single-workgroup kernels")
-for K in (1, 2, 3, 4, 5, 6, 8):
+for K in ([int(os.environ['PROBE_STREAMS'])] if os.environ.get('PROBE_STREAMS') else (1, 2, 3, 4, 5, 6, 8)):
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(K - 1)]
     for rep in range(2):
         torch.cuda.synchronize()
