@@ -179,12 +179,23 @@ class CommonVoiceDataset:
         return xs, lens.to(torch.int64), ys, olens
 
 
+_PREFETCH_POOL = None
+
+
+def _prefetch_pool():
+    global _PREFETCH_POOL
+    if _PREFETCH_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _PREFETCH_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="masr-prefetch")
+    return _PREFETCH_POOL
+
+
 class Loader:
     """In-process stand-in for the reference's DataLoader(batch_sampler=..., collate_fn=...)."""
 
-    def __init__(self, dset, batch_sampler=None, batch_size=1, shuffle=False, drop_last=False, indices=None):
+    def __init__(self, dset, batch_sampler=None, batch_size=1, shuffle=False, drop_last=False, indices=None, prefetch=False):
         self.dset, self.batch_sampler, self.batch_size = dset, batch_sampler, batch_size
-        self.shuffle, self.drop_last = shuffle, drop_last
+        self.shuffle, self.drop_last, self.prefetch = shuffle, drop_last, prefetch
         self.indices = list(range(len(dset))) if indices is None else list(indices)
 
     def _batches(self):
@@ -216,7 +227,24 @@ class Loader:
         return collate_rows(self.dset, idxs)
 
     def __iter__(self):
-        return (self.materialize(idxs) for idxs in self.iter_indices())
+        it = self.iter_indices()
+        if not (self.prefetch and self.batch_sampler is not None and not self.dset.on_device):
+            return (self.materialize(idxs) for idxs in it)
+        return self._prefetched(it)
+
+    def _prefetched(self, it):
+        """bucketed host shards with num_workers > 0: the next batch is assembled (into pinned memory) by a background thread
+        while the caller's step runs on the GPU -- what the reference's DataLoader workers do.  Its indices are drawn one batch
+        early: the bucket sampler reads `np.random` only, which nothing else in the train loops touches between two batches
+        (evaluate()'s dev loaders and the RandomSampler read the torch stream, hence bucketed loaders only)."""
+        fut = None
+        for idxs in it:
+            nxt = _prefetch_pool().submit(self.materialize, idxs)
+            if fut is not None:
+                yield fut.result()
+            fut = nxt
+        if fut is not None:
+            yield fut.result()
 
     def __len__(self):
         if self.batch_sampler is not None:
@@ -228,7 +256,8 @@ class Loader:
 def get_loader(data_dir, batch_size, is_memmap, is_bucket, num_workers=0, split_rate=1.0, split_seed=531,
                min_ilen=None, max_ilen=None, half_batch_ilen=None, bucket_reverse=False, shuffle=True,
                read_file=False, drop_last=False, pin_memory=True, device=None, lazy_upload=False):
-    """dataset.py:156-198.  num_workers / pin_memory are accepted for signature parity and ignored."""
+    """dataset.py:156-198.  pin_memory is accepted for signature parity; num_workers > 0 = batches of a bucketed loader are assembled
+    one ahead by a background thread (Loader._prefetched; the DataContainer has its own collate pool)."""
     assert not read_file, "Load from Kaldi ark haven't been implemented yet"
     dset = CommonVoiceDataset(data_dir, is_memmap)
     if device is not None:
@@ -242,7 +271,7 @@ def get_loader(data_dir, batch_size, is_memmap, is_bucket, num_workers=0, split_
         sampler = BucketSampler(dset.ilens, min_ilen=min_ilen, max_ilen=max_ilen, half_batch_ilen=half_batch_ilen,
                                 batch_size=batch_size, bucket_size=BUCKET_SIZE, bucket_reverse=bucket_reverse,
                                 drop_last=drop_last)
-        return Loader(dset, batch_sampler=sampler)
+        return Loader(dset, batch_sampler=sampler, prefetch=bool(num_workers and num_workers > 0))
     return Loader(dset, batch_size=batch_size, shuffle=shuffle, drop_last=drop_last, indices=indices)
 
 

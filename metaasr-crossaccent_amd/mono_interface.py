@@ -14,7 +14,7 @@ from .marcos import *  # noqa: F401,F403
 from .monitor import logger
 from .monitor.dashboard import Dashboard
 from .monitor.stat import RunningAvgDict
-from .optimizer import TransformerOptimizer
+from .optimizer import FlatSGD, TransformerOptimizer
 from .parallel import TaskSharder
 from .pretrain_interface import load_units
 
@@ -126,6 +126,7 @@ class MonoASRInterface(TrainInterface):
 
     def save_per_epoch(self):
         """mono_interface.py:34-59: snapshot.latest, optimizer.latest, info_dict.latest, epoch, global_step (+ snapshot.ep.N)."""
+        getattr(self, '_drain_stats', lambda: None)()
         torch.save(self._sd_cpu(), self.log_dir.joinpath("snapshot.latest"))
         opt = self.asr_opt.optimizer if isinstance(self.asr_opt, TransformerOptimizer) else self.asr_opt
         state = {'opt': opt.state_dict(), 'step_num': getattr(self.asr_opt, 'step_num', None)}
@@ -189,6 +190,21 @@ class MonoASRInterface(TrainInterface):
         try:
             if self.save_verbose:                                            # save_init (:124-127)
                 torch.save(self._sd_cpu(), self.log_dir.joinpath("snapshot.init"))
+            # SGD fine-tuning (the shipped adapt configs): clip, the NaN test and the step are ONE device pass (FlatSGD.clip_and_step skips
+            # the step on a NaN norm by itself, and SGD has no step counter that a skipped step would have to leave alone), so nothing
+            # has to come back before the next batch is queued: {loss, acc, norm} are copied asynchronously and booked a step later
+            # (train.py --sync_stats: off).  Adam / Noam keep the read-back: their step count must not advance on a NaN step.
+            run_ahead = (isinstance(self.asr_opt, FlatSGD) and hasattr(self, 'stats_async') and not getattr(self.paras, 'sync_stats', False))
+            pending = self._pending = []
+
+            def drain(keep=0):
+                while len(pending) > keep:
+                    step, handle, n = pending.pop(0)
+                    info, grad_norm = handle.get()
+                    if math.isnan(grad_norm):
+                        logger.warning(f"grad norm NaN @ step {step}")
+                    self.train_info.add(info, n)
+            self._drain_stats = drain
             while self.ep < self.max_epoch:
                 for cur_b, (x, ilens, ys, olens) in enumerate(self.train_set):
                     # one host sync per step where the trainer can defer the batch's {loss, acc} to the copy that brings the
@@ -197,18 +213,25 @@ class MonoASRInterface(TrainInterface):
                     info = self._train(cur_b, x, ilens, ys, olens, want_info=False) if one_sync else self._train(cur_b, x, ilens, ys, olens)
                     if self.frozen_mask is not None:
                         eng.grads.mul_(self.frozen_mask)
-                    grad_norm = self.clip_grad_norm_(GRAD_CLIP)
-                    if info is None:
-                        info = self.info_from_stats()
-                    self.train_info.add(info, len(ys))
-                    if math.isnan(grad_norm):
-                        logger.warning(f"grad norm NaN @ step {self.global_step}")
+                    if run_ahead and info is None:
+                        self.asr_opt.clip_and_step(GRAD_CLIP)
+                        pending.append((self.global_step, self.stats_async(), len(ys)))
+                        drain(keep=0 if (self.global_step % self.log_ival == 0 or self.global_step % self.eval_ival == 0) else 1)
                     else:
-                        self.opt_step()
+                        drain()
+                        grad_norm = self.clip_grad_norm_(GRAD_CLIP)
+                        if info is None:
+                            info = self.info_from_stats()
+                        self.train_info.add(info, len(ys))
+                        if math.isnan(grad_norm):
+                            logger.warning(f"grad norm NaN @ step {self.global_step}")
+                        else:
+                            self.opt_step()
                     self.log_msg(self.asr_opt.lr if isinstance(self.asr_opt, TransformerOptimizer) else None)
                     self.check_evaluate()
                     self.global_step += 1
                     self.dashboard.step()
+                drain()
                 self.ep += 1
                 self.save_per_epoch()
                 if getattr(self.paras, 'eval_every_epoch', False):           # train.py --eval_every_epoch (:169-170)
@@ -222,6 +245,7 @@ class MonoASRInterface(TrainInterface):
             self.dashboard.set_status('trained')
 
     def evaluate(self):
+        getattr(self, '_drain_stats', lambda: None)()                 # (train_info is written out below)
         self.asr_model.eval()
         dev_info = RunningAvgDict(decay_rate=1.)
         for x, ilens, ys, olens in self.dev_set:

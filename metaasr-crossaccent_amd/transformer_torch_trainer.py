@@ -93,6 +93,17 @@ def get_trainer(cls, config, paras, id2accent):
             eng.clip_grads(max_norm)
             return eng.read_stats()['grad_norm']
 
+        def stats_async(self, engine=None):
+            """{loss, acc} and the gradient norm of what is queued, as a handle: .get() -> (info, grad_norm) once the copy has
+            landed (for loops whose clip + step already ran on the device, e.g. FlatSGD.clip_and_step)"""
+            pend = (engine if engine is not None else self.asr_model.engine).read_stats_async()
+
+            class _H:
+                def get(self_):
+                    st = pend.get()
+                    return {'loss': st['loss'], 'acc': st['n_correct'] / st['n_total']}, st['grad_norm']
+            return _H()
+
         def clip_stats_async(self, max_norm, engine=None):
             """clip_grad_norm_ without the host sync: the clip is queued, and so is the copy of {loss, counts, norm} to the host;
             returns a handle, .get() -> (info, grad_norm) once that copy has landed (used by the meta loops to stay one

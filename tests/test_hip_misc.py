@@ -324,6 +324,39 @@ def test_mono_interface_finetunes_from_pretrain_snapshot(tmp_path, monkeypatch):
     assert (s.log_dir / "epoch").read_text().strip() == "2"
 
 
+def test_sgd_finetune_with_the_host_running_ahead_books_the_same_stats(tmp_path, monkeypatch):
+    """train.py with SGD: clip + NaN test + step are one device pass, the per-step stats come back asynchronously and are booked a
+    step later; --sync_stats reads them back every step.  Same weights bit for bit, same running averages at every evaluation."""
+    from masr_amd.mono_interface import MonoASRInterface
+    from masr_amd.transformer_torch_trainer import get_trainer
+    monkeypatch.chdir(tmp_path)
+    runs = []
+    for sync in (True, False):
+        cfg, id2accent = _common(tmp_path, {"optimizer_cls": "SGD", "optimizer_opt": {"lr": 0.05, "momentum": 0.9, "nesterov": True}})
+        cfg["solver"]["freeze_module"] = ["feat_extractor"]
+        cfg["solver"]["eval_ival"] = 5
+        snap = tmp_path / "pre.snapshot"
+        torch.save(ref_cpu.deterministic_state_dict(cfg["asr_model"], ODIM, seed=7), snap)
+        paras = SimpleNamespace(accent="af", algo="fomaml", model_name="transformer", eval_suffix="e", runs=0, overwrite=True, seed=531,
+                                resume=False, use_tensorboard=False, save_verbose=False, split_rate=1.0, freeze_layer=None, pretrain=True,
+                                pretrain_suffix="p", pretrain_setting=None, pretrain_runs=0, pretrain_step=0, pretrain_tgt_accent="ca",
+                                pretrain_model_path=str(snap), njobs=2, is_bucket=True, is_memmap=True, device="cuda:0", sync_stats=sync)
+        random.seed(531); np.random.seed(531); torch.manual_seed(531)
+        s = get_trainer(MonoASRInterface, cfg, paras, id2accent)
+        s.load_data(); s.set_model()
+        seen = []
+        s.evaluate = lambda: (getattr(s, "_drain_stats", lambda: None)(), seen.append((s.global_step, dict(s.train_info))))
+        handles = []
+        orig = s.stats_async
+        s.stats_async = lambda engine=None: (handles.append(1), orig(engine))[1]
+        s.exec()
+        torch.cuda.synchronize()
+        runs.append((s.asr_model.engine.params.clone(), dict(s.train_info), seen, len(handles), s.global_step))
+    assert runs[0][3] == 0 and runs[1][3] >= 20                                  # read-back per step / asynchronous copies
+    assert torch.equal(runs[0][0], runs[1][0]) and runs[0][4] == runs[1][4]
+    assert runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2] and len(runs[0][2]) >= 4
+
+
 def test_mono_finetune_matches_reference_golden(golden_dir, tmp_path, monkeypatch):
     """train.py path of the reference (TrainInterface + MonoASRInterface) captured through get_trainer: init from a
     pretraining snapshot, feat_extractor frozen, SGD(0.05, momentum 0.9, nesterov), 2 epochs = 26 batches in the same order."""
