@@ -65,15 +65,27 @@ class MultiASRInterface(PretrainInterface):
 
     def train(self):
         eng = self.asr_model.engine
+
+        def draw():
+            # N ranks = N consecutive draws of the ONE shared accent/batch stream per step (rank r keeps draw r, the
+            # others are replayed index-only): N different random-accent batches, same stream as a single process
+            mine = None
+            for r in range(self.sharder.world):
+                item = self.data_container.get_item(materialize='async' if r == self.sharder.rank else False)[0]
+                if r == self.sharder.rank:
+                    mine = item
+            return mine
+        # the next step's batch is drawn (np.random accent + bucket sampler: nothing else reads that stream in between) and
+        # assembled by the collate pool while this step runs; bucketed loaders with a pool only, as in the FOMAML loop
+        ahead = self.is_bucket and self.data_container.pool is not None
+        nxt = None
         try:
             while self.global_step < self.max_step:
-                for _ in range(self.eval_ival):
-                    # N ranks = N consecutive draws of the ONE shared accent/batch stream per step (rank r keeps draw r, the
-                    # others are replayed index-only): N different random-accent batches, same stream as a single process
-                    for r in range(self.sharder.world):
-                        item = self.data_container.get_item(materialize=(r == self.sharder.rank))[0]
-                        if r == self.sharder.rank:
-                            idx, (x, ilens, ys, olens) = item
+                for it in range(self.eval_ival):
+                    idx, fut = nxt if nxt is not None else draw()
+                    more = it + 1 < self.eval_ival or self.global_step + 1 < self.max_step
+                    nxt = draw() if ahead and more else None
+                    x, ilens, ys, olens = fut.result()
                     one_sync = hasattr(self, 'info_from_stats')            # {loss, acc} ride on the copy that brings the norm back
                     info = self._train(idx, x, ilens, ys, olens, accent_idx=idx, **({'want_info': False} if one_sync else {}))
                     if self.sharder.world > 1:                            # DP: mean gradient over ranks
