@@ -96,6 +96,13 @@ int masr_adam_step(float* params, const float* grads, float* exp_avg, float* exp
 /* torch.optim.AdamW (decoupled != 0: p *= 1 - lr*weight_decay, then the Adam update) or torch.optim.Adam with its L2
  * weight_decay (decoupled == 0: g += weight_decay*p) -- config/transformer/adapt/hkust-adamw.yaml through
  * getattr(torch.optim, cls) (src/transformer_torch_trainer.py:44-46) */
+/* Adam / AdamW step guarded ON THE DEVICE by the gradient norm of the model's stats block (masr_clip_grads leaves it there): a NaN
+   norm skips the step, as `if math.isnan(grad_norm): warn else: step()` does (mono_interface.py:141-148, multi_interface.py:108-114),
+   without the host having to read the norm first.  The host may be ONE step ahead: (lr_a, t_a) are learning rate and Adam step
+   count if the previous guarded step was applied, (lr_b, t_b) if it was skipped -- the previous launch recorded which; pass the same
+   pair twice when the previous outcome is known.  `slot` alternates 0 / 1 from step to step. */
+int masr_adam_step_guarded(masr_model* m, float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float lr_a, int t_a,
+                           float lr_b, int t_b, float b1, float b2, float eps, float weight_decay, int decoupled, int slot, void* stream);
 /* the meta update of one meta-step in ONE pass: Adam on g = (((g_0 + g_1) + ...) + g_{n-1}) * gscale, the per-task gradients read
    straight from n <= 8 device buffers (`grads` is a HOST array of device pointers).  Replaces the accumulator of
    fo_meta_interface.py:180-202 (zero + n axpy passes + scale pass + Adam pass) with the same additions in the same order. */

@@ -917,6 +917,12 @@ int masr_clip_accumulate(masr_model* m, float* updates, float max_norm, void* st
 int masr_adam_step(float* p, const float* g, float* ea, float* eas, int64_t n, float lr, float b1, float b2, float eps, int step, void* stream) {
     return mk_adam(p, g, ea, eas, n, lr, b1, b2, eps, step, 0.f, 0, (hipStream_t)stream);
 }
+int masr_adam_step_guarded(masr_model* m, float* p, const float* g, float* ea, float* eas, int64_t n, float lr_a, int t_a, float lr_b, int t_b,
+                           float b1, float b2, float eps, float weight_decay, int decoupled, int slot, void* stream) {
+    Prof pr(m, MASR_PROF_OPTIM, (hipStream_t)stream);
+    return mk_adam_guarded(p, g, ea, eas, n, lr_a, t_a, lr_b, t_b, b1, b2, eps, weight_decay, decoupled, m->stats + 3,
+                           reinterpret_cast<int*>(m->stats + 16), slot, (hipStream_t)stream);
+}
 int masr_adam_sum_step(float* p, const float* const* grads, int n_grads, float gscale, float* ea, float* eas, int64_t n, float lr, float b1,
                        float b2, float eps, int step, void* stream) {
     return mk_adam_sum(p, grads, n_grads, gscale, ea, eas, n, lr, b1, b2, eps, step, (hipStream_t)stream);

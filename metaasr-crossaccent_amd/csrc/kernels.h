@@ -162,6 +162,8 @@ int mk_clip_scale(float* g, long n, const float* norm, float max_norm, hipStream
 int mk_clip_axpy(float* acc, const float* g, long n, const float* norm, float max_norm, hipStream_t s); // acc += coef*g
 int mk_scale(float* x, long n, float a, hipStream_t s);
 // weight_decay: decoupled != 0 -> AdamW (p *= 1 - lr*wd first), else torch.optim.Adam's L2 term (g += wd*p); 0 = plain Adam
+int mk_adam_guarded(float* p, const float* g, float* m, float* v, long n, float lr_a, int t_a, float lr_b, int t_b, float b1, float b2, float eps,
+                    float weight_decay, int decoupled, const float* norm, int* flags, int slot, hipStream_t s);
 int mk_adam_sum(float* p, const float* const* grads, int n_grads, float gscale, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                 int t, hipStream_t s);
 int mk_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int t, float weight_decay,

@@ -139,6 +139,33 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
                             one(pv.x, gv.x, mv.x, vv.x); one(pv.y, gv.y, mv.y, vv.y); one(pv.z, gv.z, mv.z, vv.z); one(pv.w, gv.w, mv.w, vv.w);
                             F4P(p)[i] = pv; F4P(m)[i] = mv; F4P(v)[i] = vv; });
 }
+// Adam step that the DEVICE skips when the gradient norm is NaN (`if math.isnan(grad_norm): warn else: step()` of the training loops,
+// mono_interface.py:141-148, multi_interface.py:108-114) so that the host need not wait for the norm.  The host is at most ONE step
+// ahead: when it queues this step it does not know yet whether the previous one was skipped, i.e. whether this is the optimiser's
+// step number n+1 or n.  It passes the scalars for both (A: the previous step was applied, B: it was skipped); the previous launch left
+// its verdict in flags[slot ^ 1], this one leaves its own in flags[slot].
+struct AdamCand { float step_size, inv_sqrt_bc2, decay_mul, l2; };
+__global__ void adam_guarded_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                                    float b1, float b2, float eps, AdamCand A, AdamCand B, const float* __restrict__ norm,
+                                    int* __restrict__ flags, int slot, int vec) {
+    const float nv = norm[0];
+    const bool skip = nv != nv;
+    const bool prev_skipped = flags[slot ^ 1] != 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) flags[slot] = skip ? 1 : 0;
+    if (skip) return;
+    const AdamCand c = prev_skipped ? B : A;
+    auto one = [&](float& pp, float gg, float& mm, float& vv) {
+        const float pi = pp * c.decay_mul;
+        const float gi = gg + c.l2 * pi;
+        mm = mm + (gi - mm) * (1.f - b1);
+        vv = b2 * vv + (1.f - b2) * gi * gi;
+        pp = pi - c.step_size * mm / (sqrtf(vv) * c.inv_sqrt_bc2 + eps);
+    };
+    flat_pass(n, vec, [&](long i) { one(p[i], g[i], m[i], v[i]); },
+              [&](long i) { float4 pv = F4C(p)[i], mv = F4C(m)[i], vv = F4C(v)[i]; const float4 gv = F4C(g)[i];
+                            one(pv.x, gv.x, mv.x, vv.x); one(pv.y, gv.y, mv.y, vv.y); one(pv.z, gv.z, mv.z, vv.z); one(pv.w, gv.w, mv.w, vv.w);
+                            F4P(p)[i] = pv; F4P(m)[i] = mv; F4P(v)[i] = vv; });
+}
 // the same step on g = (((g0 + g1) + g2) + ...) * scale, the sum the meta loop used to build with one axpy pass per task and a
 // scale pass (same additions in the same order: bit-identical), read straight from the task slots' gradient buffers
 struct GradList { const float* g[8]; int n; float scale; };
@@ -352,6 +379,16 @@ int mk_adam(float* p, const float* g, float* m, float* v, long n, float lr, floa
     const double bc1 = 1.0 - pow((double)b1, t), bc2 = 1.0 - pow((double)b2, t);
     hipLaunchKernelGGL(adam_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, s, p, g, m, v, n, (float)(lr / bc1), b1, b2, eps,
                        (float)(1.0 / sqrt(bc2)), decoupled ? 1.f - lr * weight_decay : 1.f, decoupled ? 0.f : weight_decay, aligned16(p, g, m, v));
+    return LAUNCH_OK();
+}
+int mk_adam_guarded(float* p, const float* g, float* m, float* v, long n, float lr_a, int t_a, float lr_b, int t_b, float b1, float b2, float eps,
+                    float weight_decay, int decoupled, const float* norm, int* flags, int slot, hipStream_t s) {
+    auto cand = [&](float lr, int t) {
+        const double bc1 = 1.0 - pow((double)b1, t), bc2 = 1.0 - pow((double)b2, t);
+        return AdamCand{(float)(lr / bc1), (float)(1.0 / sqrt(bc2)), decoupled ? 1.f - lr * weight_decay : 1.f, decoupled ? 0.f : weight_decay};
+    };
+    hipLaunchKernelGGL(adam_guarded_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, s, p, g, m, v, n, b1, b2, eps, cand(lr_a, t_a), cand(lr_b, t_b),
+                       norm, flags, slot & 1, aligned16(p, g, m, v));
     return LAUNCH_OK();
 }
 int mk_adam_sum(float* p, const float* const* grads, int n_grads, float gscale, float* m, float* v, long n, float lr, float b1, float b2, float eps,

@@ -254,6 +254,11 @@ class MasrEngine:
         else:
             check(self._l.masr_adam_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, b1, b2, eps, step, self.stream()), "masr_adam_step")
 
+    def adam_step_guarded(self, params, grads, m, v, lr_a, t_a, lr_b, t_b, b1, b2, eps, weight_decay, decoupled, slot):
+        """Adam / AdamW step skipped on the device when the stats block's gradient norm is NaN (include/masr.h masr_adam_step_guarded)"""
+        check(self._l.masr_adam_step_guarded(self.h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr_a, t_a, lr_b, t_b, b1, b2, eps,
+                                             weight_decay, int(decoupled), slot, self.stream()), "masr_adam_step_guarded")
+
     def adam_sum_step(self, params, grad_list, gscale, m, v, lr, b1, b2, eps, step):
         """Adam on (sum of grad_list, in order) * gscale in one pass (include/masr.h masr_adam_sum_step)"""
         arr = (C.c_void_p * len(grad_list))(*[g.data_ptr() for g in grad_list])

@@ -14,7 +14,7 @@ from .marcos import *  # noqa: F401,F403
 from .monitor import logger
 from .monitor.dashboard import Dashboard
 from .monitor.stat import RunningAvgDict
-from .optimizer import FlatSGD, TransformerOptimizer
+from .optimizer import FlatAdam, FlatSGD, TransformerOptimizer
 from .parallel import TaskSharder
 from .pretrain_interface import load_units
 
@@ -190,11 +190,14 @@ class MonoASRInterface(TrainInterface):
         try:
             if self.save_verbose:                                            # save_init (:124-127)
                 torch.save(self._sd_cpu(), self.log_dir.joinpath("snapshot.init"))
-            # SGD fine-tuning (the shipped adapt configs): clip, the NaN test and the step are ONE device pass (FlatSGD.clip_and_step skips
-            # the step on a NaN norm by itself, and SGD has no step counter that a skipped step would have to leave alone), so nothing
-            # has to come back before the next batch is queued: {loss, acc, norm} are copied asynchronously and booked a step later
-            # (train.py --sync_stats: off).  Adam / Noam keep the read-back: their step count must not advance on a NaN step.
-            run_ahead = (isinstance(self.asr_opt, FlatSGD) and hasattr(self, 'stats_async') and not getattr(self.paras, 'sync_stats', False))
+            # Nothing has to come back from the GPU before the next batch is queued: the NaN test of the gradient norm runs on the
+            # device -- SGD (the shipped adapt configs): clip + test + step are one pass (FlatSGD.clip_and_step); Adam / AdamW / Noam:
+            # the step kernel skips itself on a NaN norm and is given the scalars for both "the step before was applied" and "was
+            # skipped" (FlatAdam.step_guarded) -- and {loss, acc, norm} are copied asynchronously and booked ONE step later, when the
+            # optimiser's counters are confirmed too.  train.py --sync_stats: a read-back per step instead.  Same weights either way.
+            inner = self.asr_opt.optimizer if isinstance(self.asr_opt, TransformerOptimizer) else self.asr_opt
+            mode = 'sgd' if isinstance(self.asr_opt, FlatSGD) else 'adam' if type(inner) is FlatAdam else None
+            run_ahead = mode is not None and hasattr(self, 'stats_async') and not getattr(self.paras, 'sync_stats', False)
             pending = self._pending = []
 
             def drain(keep=0):
@@ -203,6 +206,8 @@ class MonoASRInterface(TrainInterface):
                     info, grad_norm = handle.get()
                     if math.isnan(grad_norm):
                         logger.warning(f"grad norm NaN @ step {step}")
+                    if mode == 'adam':
+                        self.asr_opt.confirm(not math.isnan(grad_norm))
                     self.train_info.add(info, n)
             self._drain_stats = drain
             while self.ep < self.max_epoch:
@@ -214,7 +219,11 @@ class MonoASRInterface(TrainInterface):
                     if self.frozen_mask is not None:
                         eng.grads.mul_(self.frozen_mask)
                     if run_ahead and info is None:
-                        self.asr_opt.clip_and_step(GRAD_CLIP)
+                        if mode == 'sgd':
+                            self.asr_opt.clip_and_step(GRAD_CLIP)
+                        else:
+                            eng.clip_grads(GRAD_CLIP)
+                            self.opt_step_guarded()
                         pending.append((self.global_step, self.stats_async(), len(ys)))
                         drain(keep=0 if (self.global_step % self.log_ival == 0 or self.global_step % self.eval_ival == 0) else 1)
                     else:

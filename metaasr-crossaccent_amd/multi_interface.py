@@ -10,7 +10,7 @@ import torch
 from .marcos import *  # noqa: F401,F403
 from .monitor import logger
 from .monitor.stat import RunningAvgDict
-from .optimizer import TransformerOptimizer
+from .optimizer import FlatAdam, FlatSGD, TransformerOptimizer
 from .pretrain_interface import PretrainInterface
 
 
@@ -35,6 +35,7 @@ class MultiASRInterface(PretrainInterface):
             print('{} {}'.format(self.global_step, getattr(self, f'best_{tpe}')), file=fout)
 
     def save_per_steps(self):
+        getattr(self, '_drain_stats', lambda: None)()
         if self.sharder.rank != 0:
             return
         sd = self._sd_cpu()
@@ -79,6 +80,22 @@ class MultiASRInterface(PretrainInterface):
         # assembled by the collate pool while this step runs; bucketed loaders with a pool only, as in the FOMAML loop
         ahead = self.is_bucket and self.data_container.pool is not None
         nxt = None
+        # the NaN test of the gradient norm on the device, stats booked one step later (see MonoASRInterface.train)
+        inner = self.asr_opt.optimizer if isinstance(self.asr_opt, TransformerOptimizer) else self.asr_opt
+        mode = 'sgd' if isinstance(self.asr_opt, FlatSGD) else 'adam' if type(inner) is FlatAdam else None
+        run_ahead = mode is not None and hasattr(self, 'stats_async') and not getattr(self.paras, 'sync_stats', False)
+        pending = self._pending = []
+
+        def drain(keep=0):
+            while len(pending) > keep:
+                step, handle, n = pending.pop(0)
+                info, grad_norm = handle.get()
+                if math.isnan(grad_norm):
+                    logger.warning(f"grad norm NaN @ step {step}")
+                if mode == 'adam':
+                    self.asr_opt.confirm(not math.isnan(grad_norm))
+                self.train_info.add(info, n)
+        self._drain_stats = drain
         try:
             while self.global_step < self.max_step:
                 for it in range(self.eval_ival):
@@ -91,22 +108,35 @@ class MultiASRInterface(PretrainInterface):
                     if self.sharder.world > 1:                            # DP: mean gradient over ranks
                         self.sharder.all_reduce(eng.grads)
                         eng.scale(eng.grads, 1.0 / self.sharder.world)
-                    grad_norm = self.clip_grad_norm_(GRAD_CLIP)
-                    if info is None:
-                        info = self.info_from_stats()
-                    self.train_info.add(info, len(ys))
-                    if math.isnan(grad_norm):
-                        logger.warning(f"grad norm NaN @ step {self.global_step}")
+                    if run_ahead and info is None:
+                        if mode == 'sgd':
+                            self.asr_opt.clip_and_step(GRAD_CLIP)
+                        else:
+                            eng.clip_grads(GRAD_CLIP)
+                            self.opt_step_guarded()
+                        pending.append((self.global_step, self.stats_async(), len(ys)))
+                        due = self.global_step % self.log_ival == 0 or self.global_step % self.eval_ival == 0 or (self.global_step + 1) % self.save_ival == 0
+                        drain(keep=0 if due else 1)
                     else:
-                        self.opt_step()
+                        drain()
+                        grad_norm = self.clip_grad_norm_(GRAD_CLIP)
+                        if info is None:
+                            info = self.info_from_stats()
+                        self.train_info.add(info, len(ys))
+                        if math.isnan(grad_norm):
+                            logger.warning(f"grad norm NaN @ step {self.global_step}")
+                        else:
+                            self.opt_step()
                     self.log_msg(self.asr_opt.lr if isinstance(self.asr_opt, TransformerOptimizer) else None)
                     self.check_evaluate()
                     self.global_step += 1
                     self.dashboard.step()
                     if self.global_step % self.save_ival == 0:
                         self.save_per_steps()
+            drain()
         except KeyboardInterrupt:
             logger.warning("Pretraining stopped")
+            drain()
             self.save_per_steps()
             self.dashboard.set_status('pretrained(SIGINT)')
         else:
@@ -114,6 +144,7 @@ class MultiASRInterface(PretrainInterface):
             self.dashboard.set_status('pretrained')
 
     def evaluate(self):
+        getattr(self, '_drain_stats', lambda: None)()
         self.asr_model.eval()
         self.write_tr_logs()
         dev_info_ls = [RunningAvgDict(decay_rate=1.) for _ in range(self.num_pretrain)]

@@ -18,12 +18,36 @@ class FlatAdam:
         self.t = 0
         self.grad = None                      # set by the caller before step()
         self.grad_list, self.grad_scale = None, 1.0     # ... or: several buffers whose (in-order) sum * grad_scale is the gradient
+        self.inflight, self._slot = 0, 0                # guarded steps queued whose outcome (applied / skipped on NaN) is not known yet
 
     def zero_grad(self):
         self.grad = None
         self.grad_list = None
 
+    def step_guarded(self, lr_applied=None, lr_skipped=None):
+        """queue a step that the device skips if the gradient norm is NaN; the host learns the outcome later (`confirm`).  With one
+        earlier guarded step still unconfirmed this may be step t+2 (it was applied) or t+1 (it was skipped): both sets of scalars go
+        to the kernel, the earlier launch left its verdict on the device.  lr_*: the learning rate for either case (Noam)."""
+        assert self.grad is not None and self.inflight <= 1, "guarded steps: at most one unconfirmed step may be in flight"
+        lr = self.param_groups[0]['lr']
+        self.engine.adam_step_guarded(self.params, self.grad, self.exp_avg, self.exp_avg_sq,
+                                      lr if lr_applied is None else lr_applied, self.t + self.inflight + 1,
+                                      lr if lr_skipped is None else lr_skipped, self.t + 1,
+                                      self.betas[0], self.betas[1], self.eps, self.weight_decay, self.decoupled, self._slot)
+        self._slot ^= 1
+        self.inflight += 1
+        if self.params.data_ptr() == self.engine.params.data_ptr():
+            self.engine.mark_dirty()
+
+    def confirm(self, applied):
+        """the oldest unconfirmed guarded step was applied (its norm was a number) / skipped"""
+        assert self.inflight > 0
+        self.inflight -= 1
+        if applied:
+            self.t += 1
+
     def step(self):
+        assert self.inflight == 0, "FlatAdam.step(): guarded steps still unconfirmed"
         if self.grad_list:
             assert not self.weight_decay, "summed-gradient step: plain Adam only"
             self.t += 1
@@ -121,11 +145,23 @@ class TransformerOptimizer:
         self._update_lr()
         self.optimizer.step()
 
+    def _lr_at(self, n):
+        return self.k * self.init_lr * min(n ** (-0.5), n * (self.warmup_steps ** (-1.5)))
+
     def _update_lr(self):
         self.step_num += 1
-        self.lr = self.k * self.init_lr * min(self.step_num ** (-0.5), self.step_num * (self.warmup_steps ** (-1.5)))
+        self.lr = self._lr_at(self.step_num)
         for g in self.optimizer.param_groups:
             g['lr'] = self.lr
+
+    def step_guarded(self):
+        """FlatAdam.step_guarded with the schedule's learning rate for either outcome of the step still in flight"""
+        self.optimizer.step_guarded(self._lr_at(self.step_num + self.optimizer.inflight + 1), self._lr_at(self.step_num + 1))
+
+    def confirm(self, applied):
+        self.optimizer.confirm(applied)
+        if applied:
+            self._update_lr()
 
     def load_state_dict(self, state_dict):
         self.optimizer.load_state_dict(state_dict)

@@ -87,6 +87,12 @@ def get_trainer(cls, config, paras, id2accent):
                 inner.grad = self.asr_model.engine.grads
             self.asr_opt.step()
 
+        def opt_step_guarded(self):
+            """opt_step() for Adam-family optimisers with the NaN test on the device (FlatAdam.step_guarded); confirm() later"""
+            inner = self.asr_opt.optimizer if isinstance(self.asr_opt, TransformerOptimizer) else self.asr_opt
+            inner.grad = self.asr_model.engine.grads
+            self.asr_opt.step_guarded()
+
         def clip_grad_norm_(self, max_norm, engine=None):
             """nn.utils.clip_grad_norm_(self.asr_model.parameters(), max_norm) -> python float (host sync)."""
             eng = engine if engine is not None else self.asr_model.engine

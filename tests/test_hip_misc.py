@@ -324,16 +324,25 @@ def test_mono_interface_finetunes_from_pretrain_snapshot(tmp_path, monkeypatch):
     assert (s.log_dir / "epoch").read_text().strip() == "2"
 
 
-def test_sgd_finetune_with_the_host_running_ahead_books_the_same_stats(tmp_path, monkeypatch):
-    """train.py with SGD: clip + NaN test + step are one device pass, the per-step stats come back asynchronously and are booked a
-    step later; --sync_stats reads them back every step.  Same weights bit for bit, same running averages at every evaluation."""
+@pytest.mark.parametrize("opt,poison", [("SGD", None), ("noam", None), ("AdamW", None), ("noam", 3), ("AdamW", 7), ("SGD", 4), ("noam", 0)])
+def test_finetune_with_the_host_running_ahead_books_the_same_stats(tmp_path, monkeypatch, opt, poison):
+    """train.py without a read-back per step: the NaN test of the gradient norm runs on the device (SGD: inside the fused clip + step;
+    Adam / AdamW / Noam: the step kernel skips itself and is given the scalars for both outcomes of the step still in flight), the
+    per-step stats are copied asynchronously and booked a step later; --sync_stats reads them back every step.  Same weights bit for
+    bit, same optimiser counters, same running averages at every evaluation -- also when a step IS skipped (`poison`: the gradient
+    of that batch is made NaN in both runs)."""
+    from functools import partial
     from masr_amd.mono_interface import MonoASRInterface
     from masr_amd.transformer_torch_trainer import get_trainer
     monkeypatch.chdir(tmp_path)
+    model = {"SGD": {"optimizer_cls": "SGD", "optimizer_opt": {"lr": 0.05, "momentum": 0.9, "nesterov": True}},
+             "noam": {"optimizer_cls": "noam", "optimizer_opt": {"k": 1.0, "warmup_steps": 6}},
+             "AdamW": {"optimizer_cls": "AdamW", "optimizer_opt": {"lr": 1e-3, "weight_decay": 0.01}}}[opt]
     runs = []
     for sync in (True, False):
-        cfg, id2accent = _common(tmp_path, {"optimizer_cls": "SGD", "optimizer_opt": {"lr": 0.05, "momentum": 0.9, "nesterov": True}})
-        cfg["solver"]["freeze_module"] = ["feat_extractor"]
+        cfg, id2accent = _common(tmp_path, model)
+        if opt == "SGD":
+            cfg["solver"]["freeze_module"] = ["feat_extractor"]
         cfg["solver"]["eval_ival"] = 5
         snap = tmp_path / "pre.snapshot"
         torch.save(ref_cpu.deterministic_state_dict(cfg["asr_model"], ODIM, seed=7), snap)
@@ -346,15 +355,30 @@ def test_sgd_finetune_with_the_host_running_ahead_books_the_same_stats(tmp_path,
         s.load_data(); s.set_model()
         seen = []
         s.evaluate = lambda: (getattr(s, "_drain_stats", lambda: None)(), seen.append((s.global_step, dict(s.train_info))))
-        handles = []
+        handles, calls = [], [0]
         orig = s.stats_async
         s.stats_async = lambda engine=None: (handles.append(1), orig(engine))[1]
+        orig_rb = s.run_batch
+
+        def rb(*a, **k):
+            r = orig_rb(*a, **k)
+            if k.get("train") and calls[0] == poison:
+                s.asr_model.engine.grads[:3].fill_(float("nan"))
+            calls[0] += k.get("train", False)
+            return r
+        s._train = partial(rb, train=True)
         s.exec()
         torch.cuda.synchronize()
-        runs.append((s.asr_model.engine.params.clone(), dict(s.train_info), seen, len(handles), s.global_step))
+        inner = s.asr_opt.optimizer if hasattr(s.asr_opt, "optimizer") else s.asr_opt
+        counters = (getattr(s.asr_opt, "step_num", None), getattr(inner, "t", None), getattr(inner, "inflight", 0))
+        runs.append((s.asr_model.engine.params.clone(), dict(s.train_info), seen, len(handles), s.global_step, counters, calls[0]))
     assert runs[0][3] == 0 and runs[1][3] >= 20                                  # read-back per step / asynchronous copies
-    assert torch.equal(runs[0][0], runs[1][0]) and runs[0][4] == runs[1][4]
-    assert runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2] and len(runs[0][2]) >= 4
+    assert torch.isfinite(runs[0][0]).all() and torch.equal(runs[0][0], runs[1][0]) and runs[0][4] == runs[1][4]
+    assert runs[0][5] == runs[1][5] and runs[0][5][2] == 0
+    if opt != "SGD":
+        assert runs[0][5][1] == runs[0][6] - (poison is not None)                # every batch stepped Adam except the poisoned one
+    assert {k: v for k, v in runs[0][1].items()} == {k: v for k, v in runs[1][1].items()} or poison is not None
+    assert len(runs[0][2]) >= 4 and (poison is not None or runs[0][2] == runs[1][2])
 
 
 def test_mono_finetune_matches_reference_golden(golden_dir, tmp_path, monkeypatch):
