@@ -49,8 +49,8 @@ def build_parser():
     p.add_argument('--lm_model_path', default=None, type=str)
     p.add_argument('--njobs', default=-1, type=int)
     p.add_argument('--hbm_shards', action='store_true')
-    p.add_argument('--sync_stats', action='store_true', help='read loss / accuracy / gradient norm back every step (default with SGD: the host queues the '
-                   'next step meanwhile and books them a step later -- same numbers)')
+    p.add_argument('--sync_stats', action='store_true', help='read loss / accuracy / gradient norm back every step (default: the NaN test runs on the device, the host '
+                   'queues the next step meanwhile and books them a step later -- same weights, same numbers)')
     return p
 
 
