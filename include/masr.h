@@ -54,6 +54,9 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
 /* rebuild the bf16 operand shadows after ANY change of params (load_state_dict, optimizer step) */
 int masr_refresh(masr_model* m, void* stream);
 void masr_set_seed(masr_model* m, uint64_t seed);      /* dropout stream */
+/* the dropout stream's position: state[0] = seed, state[1] = batches run since masr_set_seed (every run_batch derives its masks
+ * from both); set != 0 writes it.  For checkpoints: a resumed run continues the mask stream where the saved one stopped. */
+void masr_dropout_state(masr_model* m, uint64_t state[2], int set);
 
 /* TransformerTrainer.run_batch (src/transformer_torch_trainer.py:59-99) = MyTransformer.forward
  * (:178-208) + label-smoothed CE (:64-84) + (train) zero_grad/backward.  xs: device fp32 [B][T][idim];
@@ -70,10 +73,17 @@ void masr_set_step_graphs(masr_model* m, int on);
 void masr_step_counters(const masr_model* m, int64_t out[3]);
 /* out[0]=loss, out[1]=n_correct, out[2]=n_total, out[3]=last grad norm.  Synchronises the stream. */
 int masr_read_stats(masr_model* m, float out[4], void* stream);
-/* the same four floats copied to host_out by the stream, WITHOUT waiting: host_out must be page-locked memory that stays valid until
-   the caller has seen the copy complete (an event recorded on the stream after this call).  Lets the host queue the next tasks while
-   these run: the reference reads loss / accuracy / norm only for its log lines (fo_meta_interface.py:147-151). */
-int masr_read_stats_async(masr_model* m, float* host_out, void* stream);
+/* the same four floats WITHOUT waiting: masr_stats_post queues their copy into a page-locked block owned by the handle (a ring of
+   64) and records an event behind it; it returns a ticket >= 0.  masr_stats_wait(ticket) waits for that event (completion and
+   host visibility of the copy) and hands the floats out; a ticket may simply be dropped -- its block is only reused after its
+   event has completed.  masr_stats_peek returns the block itself, whose four words hold MASR_STATS_PENDING until the copy lands:
+   a host thread may poll them without entering the HIP runtime (the task threads are inside its launch path meanwhile) and call
+   masr_stats_wait once they have changed.  Tickets expire after 64 newer posts.  Lets the host queue the next tasks while these
+   run: the reference reads loss / accuracy / norm only for its log lines (fo_meta_interface.py:147-151). */
+#define MASR_STATS_PENDING 0x7FC0DEADu            /* a quiet NaN with a payload no kernel produces */
+int64_t masr_stats_post(masr_model* m, void* stream);
+const float* masr_stats_peek(masr_model* m, int64_t ticket);
+int masr_stats_wait(masr_model* m, int64_t ticket, float out[4]);
 /* device view of the last forward's logits: fp32 [rows = B*L][ld], first odim columns valid; and gold */
 int masr_last_logits(masr_model* m, const float** logits, const int32_t** gold, int* rows, int* L, int* ld);
 
@@ -108,13 +118,21 @@ int masr_adam_step_guarded(masr_model* m, float* p, const float* g, float* exp_a
    fo_meta_interface.py:180-202 (zero + n axpy passes + scale pass + Adam pass) with the same additions in the same order. */
 int masr_adam_sum_step(float* p, const float* const* grads, int n_grads, float gscale, float* exp_avg, float* exp_avg_sq, int64_t n,
                        float lr, float b1, float b2, float eps, int step, void* stream);
+/* out = (((g_0 + g_1) + ...) + g_{n-1}) * scale over n <= 8 device buffers (`grads` is a HOST array of device pointers): the
+   rank-local sum of the task gradients of one wave of concurrent tasks = the payload of that wave's ONE RCCL all-reduce
+   (the `_updates[n] += p.grad` of fo_meta_interface.py:190-196 for the tasks this rank ran) */
+int masr_sum_n(float* out, const float* const* grads, int n_grads, float scale, int64_t n, void* stream);
 int masr_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                     float beta1, float beta2, float eps, float weight_decay, int decoupled, int step, void* stream);
 /* optimizer_cls 'RAdam' of set_model (src/transformer_torch_trainer.py:36-41).  The reference takes it from `torch_optimizer`, an
- * un-vendored third-party package that is absent from its tree (parity unpinned against that); this entry follows the published
- * algorithm as torch.optim.RAdam implements it (pinned by tests/test_hip_misc.py against torch.optim.RAdam on the CPU). */
+ * un-vendored third-party package absent from its tree.  variant 1 = that package's conventions (its authors' published
+ * implementation: rectification once N_sma >= 5, denom = sqrt(v) + eps with sqrt(1 - b2^t) folded into the step size, weight decay
+ * applied to the weight: p -= lr * wd * p) -- what FlatRAdam uses; pinned against a restatement of that algorithm in the oracle,
+ * "parity unpinned" against the package itself.  variant 0 = torch.optim.RAdam's (rho_t > 5, bias-corrected denominator, L2 decay),
+ * pinned against torch.optim.RAdam on the CPU (tests/test_hip_misc.py). */
 int masr_radam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float b1, float b2,
-                    float eps, float weight_decay, int step, void* stream);      /* torch.optim.Adam, optimizer.py:19-21 */
+                    float eps, float weight_decay, int step, int variant, void* stream);
+/* torch.optim.SGD(momentum, nesterov) on arbitrary flat buffers */
 int masr_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr, float momentum,
                   int nesterov, int first_step, void* stream);
 int masr_scale(float* x, int64_t n, float a, void* stream);                           /* _updates /= counter (:201-202) */

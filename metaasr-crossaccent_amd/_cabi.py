@@ -28,11 +28,14 @@ _SIGS = {
     "masr_bind": (i32, [vp, vp, vp, vp, vp, i64]),
     "masr_refresh": (i32, [vp, vp]),
     "masr_set_seed": (None, [vp, C.c_uint64]),
+    "masr_dropout_state": (None, [vp, C.POINTER(C.c_uint64), i32]),
     "masr_run_batch": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "masr_set_step_graphs": (None, [vp, i32]),
     "masr_step_counters": (None, [vp, C.POINTER(i64)]),
     "masr_read_stats": (i32, [vp, C.POINTER(f32), vp]),
-    "masr_read_stats_async": (i32, [vp, vp, vp]),
+    "masr_stats_post": (i64, [vp, vp]),
+    "masr_stats_peek": (C.POINTER(C.c_uint32), [vp, i64]),
+    "masr_stats_wait": (i32, [vp, i64, C.POINTER(f32)]),
     "masr_last_logits": (i32, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "masr_grad_norm": (i32, [vp, vp]),
     "masr_clip_sgd_step": (i32, [vp, vp, f32, f32, f32, i32, i32, vp]),
@@ -40,9 +43,10 @@ _SIGS = {
     "masr_clip_accumulate": (i32, [vp, vp, f32, vp]),
     "masr_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]),
     "masr_adam_step_guarded": (i32, [vp, vp, vp, vp, vp, i64, f32, i32, f32, i32, f32, f32, f32, f32, i32, i32, vp]),
+    "masr_sum_n": (i32, [vp, vp, i32, f32, i64, vp]),
     "masr_adam_sum_step": (i32, [vp, vp, i32, f32, vp, vp, i64, f32, f32, f32, f32, i32, vp]),
     "masr_adamw_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, i32, vp]),
-    "masr_radam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
+    "masr_radam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, i32, vp]),
     "masr_sgd_step": (i32, [vp, vp, vp, i64, f32, f32, i32, i32, vp]),
     "masr_scale": (i32, [vp, i64, f32, vp]),
     "masr_axpy": (i32, [vp, vp, i64, f32, vp]),

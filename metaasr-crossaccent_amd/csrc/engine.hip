@@ -89,10 +89,14 @@ struct masr_model {
     // reduction-major GEMM with M = ND*2E (segmented output rows).  kv_k16 [ND*2E][E], kvT [E][ND*2E], kv_bias [ND*2E].
     bf16 *kv_k16 = nullptr, *kvT = nullptr; float* kv_bias = nullptr; int NK = 0;
     long* d_ranges = nullptr; int nranges = 0;            // split-K combine table: (offset, length) of every Linear weight / bias
-    ShadowJobs shadows{};                                  // job list of the one-launch operand-shadow refresh
+    std::vector<ShadowJobs> shadows;                       // job list(s) of the operand-shadow refresh: one launch per <= SHADOW_JOBS_MAX jobs (hkust: one)
     float* stats = nullptr;                   // device [8]: loss, n_correct, n_total, grad_norm
     unsigned* conv_sched = nullptr;           // tile counters of the streaming conv kernel (this model's stream only)
     float* h_stats = nullptr;                 // pinned
+    // ring of page-locked stats blocks owned by the handle, one event each (masr_stats_post / masr_stats_wait): a block is only
+    // handed out again after its previous copy's event has completed, whatever became of the ticket
+    static constexpr int RING = 64;
+    float* h_ring = nullptr; hipEvent_t ring_ev[RING]; bool ring_used[RING]; int64_t ring_next = 0;
     int* h_stage = nullptr; int64_t stage_ints = 0; int stage_slot = 0; hipEvent_t stage_ev[4];
     uint64_t seed = 0x1234; uint64_t step = 0;
     Acts acts; bool have_acts = false;
@@ -463,12 +467,12 @@ masr_model* masr_create(const masr_config* cfg) {
         d.n1 = add_norm(m, pre + ".norm1"); d.n2 = add_norm(m, pre + ".norm2"); d.n3 = add_norm(m, pre + ".norm3");
     }
     m->dec_norm = add_norm(m, "decoder.norm");
-    if (5 + 4 * m->NE + 8 * m->ND > SHADOW_JOBS_MAX) { mk_set_error("masr_create", "too many layers for the shadow job list (4*enc + 8*dec <= 51)"); delete m; return nullptr; }
     Arena ar{nullptr, 0, 0};
     plan_persistent(m, ar);
     m->persist_bytes = ar.off;
     m->stage_ints = 1 << 16;
     for (auto& e : m->stage_ev) e = nullptr;
+    for (int i = 0; i < masr_model::RING; ++i) { m->ring_ev[i] = nullptr; m->ring_used[i] = false; }
     return m;
 }
 
@@ -476,6 +480,8 @@ void masr_destroy(masr_model* m) {
     if (!m) return;
     if (m->h_stage) hipHostFree(m->h_stage);
     if (m->h_stats) hipHostFree(m->h_stats);
+    for (int i = 0; i < masr_model::RING; ++i) if (m->ring_ev[i]) { if (m->ring_used[i]) hipEventSynchronize(m->ring_ev[i]); hipEventDestroy(m->ring_ev[i]); }
+    if (m->h_ring) hipHostFree(m->h_ring);
     if (m->dec_done) { hipEventSynchronize(m->dec_done); hipEventDestroy(m->dec_done); }
     if (m->dec_exec) hipGraphExecDestroy(m->dec_exec);
     if (m->dec_graph) hipGraphDestroy(m->dec_graph);
@@ -513,14 +519,19 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
         HIP_CHECK_RET(hipHostMalloc((void**)&m->h_stage, sizeof(int) * m->stage_ints * 4, hipHostMallocDefault));
         HIP_CHECK_RET(hipHostMalloc((void**)&m->h_stats, sizeof(float) * 64, hipHostMallocDefault));
         for (auto& e : m->stage_ev) HIP_CHECK_RET(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_CHECK_RET(hipHostMalloc((void**)&m->h_ring, sizeof(float) * 4 * masr_model::RING, hipHostMallocDefault));
+        for (auto& e : m->ring_ev) HIP_CHECK_RET(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     {   // device tables: split-K combine ranges and the job list of the one-launch shadow refresh
         std::vector<long> ranges = split_chunks(m);
-        ShadowJobs& J = m->shadows; J.n = 0;
-        int blocks = 0;
+        // the list travels BY VALUE in the kernel arguments (kernels.h), which caps one launch at SHADOW_JOBS_MAX jobs: deeper
+        // models (8e4d = 69 jobs) simply take a second launch
+        m->shadows.clear();
         auto job = [&](int type, long src, int N, int K, int ldt, int a0, int a1, void* p0, void* p1) {
-            ShadowDesc d{}; d.src = src; d.type = type; d.N = N; d.K = K; d.ldt = ldt; d.a0 = a0; d.a1 = a1; d.tile_start = blocks;
-            blocks += mk_shadow_blocks(d);
+            if (m->shadows.empty() || m->shadows.back().n == SHADOW_JOBS_MAX) { m->shadows.emplace_back(); m->shadows.back().n = 0; m->shadows.back().blocks = 0; }
+            ShadowJobs& J = m->shadows.back();
+            ShadowDesc d{}; d.src = src; d.type = type; d.N = N; d.K = K; d.ldt = ldt; d.a0 = a0; d.a1 = a1; d.tile_start = J.blocks;
+            J.blocks += mk_shadow_blocks(d);
             J.d[J.n] = d; J.p[2 * J.n] = (bf16*)p0; J.p[2 * J.n + 1] = (bf16*)p1; ++J.n;
         };
         auto lin = [&](const Lin& l) { job(SH_LINEAR, l.w, l.N, l.K, (l.N + 7) / 8 * 8, 0, 0, l.k16, l.t16); };
@@ -536,7 +547,7 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
             job(SH_LINEAR, d.ca.in.w + (long)E * E, 2 * E, E, m->NK, 0, 0, m->kv_k16 + (long)l * 2 * E * E, m->kvT + (long)l * 2 * E);   // key|value thirds
             job(SH_COPY32, d.ca.in.b + E, 2 * E, 0, 0, 0, 0, m->kv_bias + (long)l * 2 * E, nullptr);
         }
-        m->nranges = (int)ranges.size() / 2; J.blocks = blocks;
+        m->nranges = (int)ranges.size() / 2;
         HIP_CHECK_RET(hipMemcpy(m->d_ranges, ranges.data(), sizeof(long) * ranges.size(), hipMemcpyHostToDevice));
     }
     // pads of the char_trans shadows must be zero (rows/cols >= odim); the refresh kernels only write the odim part
@@ -548,6 +559,9 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
 }
 
 void masr_set_seed(masr_model* m, uint64_t seed) { m->seed = seed; m->step = 0; }
+void masr_dropout_state(masr_model* m, uint64_t state[2], int set) {
+    if (set) { m->seed = state[0]; m->step = state[1]; } else { state[0] = m->seed; state[1] = m->step; }
+}
 
 int masr_refresh(masr_model* m, void* stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -555,7 +569,8 @@ int masr_refresh(masr_model* m, void* stream) {
     Prof p(m, MASR_PROF_SHADOWS, s);
     // every bf16 operand shadow (conv forward/dgrad layouts, permuted vgg2enc, all Linear weights and their transposes, the
     // gathered cross-attention K/V operand) in ONE launch; the pads of the char_trans shadows are zeroed once in masr_bind
-    return mk_all_shadows(m->P, m->shadows, s);
+    for (const ShadowJobs& J : m->shadows) CK(mk_all_shadows(m->P, J, s));
+    return 0;
 }
 
 static int forward_encoder(Ctx& c, const float* xs) {
@@ -877,9 +892,26 @@ int masr_read_stats(masr_model* m, float out[4], void* stream) {
     return 0;
 }
 
-int masr_read_stats_async(masr_model* m, float* host_out, void* stream) {
-    if (!host_out) { mk_set_error("masr_read_stats_async", "null destination"); return -1; }
-    HIP_CHECK_RET(hipMemcpyAsync(host_out, m->stats, sizeof(float) * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+int64_t masr_stats_post(masr_model* m, void* stream) {
+    if (!m->h_ring) { mk_set_error("masr_stats_post", "not bound"); return -1; }
+    const int slot = (int)(m->ring_next % masr_model::RING);
+    if (m->ring_used[slot]) HIP_CHECK_RET(hipEventSynchronize(m->ring_ev[slot]));     // the block's previous copy has landed (ticket long dropped or read)
+    uint32_t* w = reinterpret_cast<uint32_t*>(m->h_ring + 4 * slot);
+    for (int i = 0; i < 4; ++i) w[i] = MASR_STATS_PENDING;
+    HIP_CHECK_RET(hipMemcpyAsync(m->h_ring + 4 * slot, m->stats, sizeof(float) * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_CHECK_RET(hipEventRecord(m->ring_ev[slot], (hipStream_t)stream));
+    m->ring_used[slot] = true;
+    return m->ring_next++;
+}
+const float* masr_stats_peek(masr_model* m, int64_t ticket) {
+    if (!m->h_ring || ticket < 0 || ticket >= m->ring_next || m->ring_next - ticket > masr_model::RING) { mk_set_error("masr_stats_peek", "unknown or expired ticket"); return nullptr; }
+    return m->h_ring + 4 * (ticket % masr_model::RING);
+}
+int masr_stats_wait(masr_model* m, int64_t ticket, float out[4]) {
+    const float* p = masr_stats_peek(m, ticket);
+    if (!p) return -1;
+    HIP_CHECK_RET(hipEventSynchronize(m->ring_ev[ticket % masr_model::RING]));          // completion AND host visibility of the copy
+    for (int i = 0; i < 4; ++i) out[i] = p[i];
     return 0;
 }
 
@@ -927,13 +959,16 @@ int masr_adam_sum_step(float* p, const float* const* grads, int n_grads, float g
                        float b2, float eps, int step, void* stream) {
     return mk_adam_sum(p, grads, n_grads, gscale, ea, eas, n, lr, b1, b2, eps, step, (hipStream_t)stream);
 }
+int masr_sum_n(float* out, const float* const* grads, int n_grads, float scale, int64_t n, void* stream) {
+    return mk_sum_n(out, grads, n_grads, scale, n, (hipStream_t)stream);
+}
 int masr_adamw_step(float* p, const float* g, float* ea, float* eas, int64_t n, float lr, float b1, float b2, float eps, float weight_decay,
                     int decoupled, int step, void* stream) {
     return mk_adam(p, g, ea, eas, n, lr, b1, b2, eps, step, weight_decay, decoupled, (hipStream_t)stream);
 }
 int masr_radam_step(float* p, const float* g, float* ea, float* eas, int64_t n, float lr, float b1, float b2, float eps, float weight_decay,
-                    int step, void* stream) {
-    return mk_radam(p, g, ea, eas, n, lr, b1, b2, eps, step, weight_decay, (hipStream_t)stream);
+                    int step, int variant, void* stream) {
+    return mk_radam(p, g, ea, eas, n, lr, b1, b2, eps, step, weight_decay, variant, (hipStream_t)stream);
 }
 int masr_sgd_step(float* p, const float* g, float* mom, int64_t n, float lr, float momentum, int nesterov, int first_step, void* stream) {
     return mk_clip_sgd(p, g, mom, n, nullptr, 0.f, lr, momentum, nesterov, first_step, (hipStream_t)stream);

@@ -168,7 +168,8 @@ int mk_adam_sum(float* p, const float* const* grads, int n_grads, float gscale, 
                 int t, hipStream_t s);
 int mk_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int t, float weight_decay,
             int decoupled, hipStream_t s);
-int mk_radam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int t, float weight_decay, hipStream_t s);
+int mk_sum_n(float* out, const float* const* grads, int n_grads, float scale, long n, hipStream_t s);     // out = (g0 + g1 + ...) * scale, n_grads <= 8
+int mk_radam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int t, float weight_decay, int variant, hipStream_t s);
 int mk_axpy(float* y, const float* x, long n, float a, hipStream_t s);
 int mk_cast_bf16(const float* x, bf16* y, long n, hipStream_t s);
 int mk_transpose_cast_bf16(const float* x /*[R][C]*/, bf16* y /*[C][ldy]*/, int R, int C, long ldy, hipStream_t s);

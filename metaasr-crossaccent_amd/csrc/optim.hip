@@ -184,6 +184,16 @@ __global__ void adam_sum_kernel(float* __restrict__ p, GradList gl, float* __res
                             one(pv.z, gv.z * gl.scale, mv.z, vv.z); one(pv.w, gv.w * gl.scale, mv.w, vv.w);
                             F4P(p)[i] = pv; F4P(m)[i] = mv; F4P(v)[i] = vv; });
 }
+// out = ((g0 + g1) + ...) + g_{n-1}: the rank-local sum of a wave's task gradients, the payload of the wave's ONE all-reduce
+// (same additions in the same order as zero + n axpy passes)
+__global__ void sum_n_kernel(float* __restrict__ out, GradList gl, long n, int vec) {
+    flat_pass(n, vec, [&](long i) { float gg = 0.f + gl.g[0][i]; for (int k = 1; k < gl.n; ++k) gg += gl.g[k][i]; out[i] = gg * gl.scale; },
+              [&](long i) { float4 gv = F4C(gl.g[0])[i];
+                            gv.x = 0.f + gv.x; gv.y = 0.f + gv.y; gv.z = 0.f + gv.z; gv.w = 0.f + gv.w;
+                            for (int k = 1; k < gl.n; ++k) { const float4 t = F4C(gl.g[k])[i]; gv.x += t.x; gv.y += t.y; gv.z += t.z; gv.w += t.w; }
+                            gv.x *= gl.scale; gv.y *= gl.scale; gv.z *= gl.scale; gv.w *= gl.scale;
+                            F4P(out)[i] = gv; });
+}
 __global__ void cast_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, long n) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = (bf16)x[i];
@@ -402,19 +412,33 @@ int mk_adam_sum(float* p, const float* const* grads, int n_grads, float gscale, 
                        (float)(1.0 / sqrt(bc2)), al ? 1 : 0);
     return LAUNCH_OK();
 }
-// RAdam (Liu et al. 2020, as torch.optim.RAdam): Adam moments; while the variance estimate is unreliable (rho_t <= 5) the step is
-// the bias-corrected momentum alone, afterwards Adam's step times the rectification r_t.  All of that is scalar work on the host:
-// the update itself is adam_kernel with step_size = lr (r_t) / (1 - b1^t) and, in the unrectified phase, a denominator of 1
-// (inv_sqrt_bc2 = 0, eps = 1).  weight_decay = L2 term added to the gradient (torch's default, decoupled_weight_decay=False).
-int mk_radam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int t, float weight_decay, hipStream_t s) {
+int mk_sum_n(float* out, const float* const* grads, int n_grads, float scale, long n, hipStream_t s) {
+    if (n_grads < 1 || n_grads > 8) { mk_set_error("mk_sum_n", "1 to 8 buffers"); return -1; }
+    GradList gl{}; gl.n = n_grads; gl.scale = scale;
+    bool al = aligned16(out);
+    for (int k = 0; k < n_grads; ++k) { gl.g[k] = grads[k]; al = al && !((uintptr_t)grads[k] & 15); }
+    hipLaunchKernelGGL(sum_n_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, s, out, gl, n, al ? 1 : 0);
+    return LAUNCH_OK();
+}
+// RAdam (Liu et al. 2020): Adam moments; while the variance estimate is unreliable the step is the bias-corrected momentum alone,
+// afterwards Adam's step times the rectification r_t.  All of that is scalar work on the host: the update itself is adam_kernel
+// with a folded step size and, in the unrectified phase, a denominator of 1 (inv_sqrt_bc2 = 0, eps = 1).  Two sets of conventions:
+//   variant 1 = `torch_optimizer.RAdam`, the package the reference imports (src/transformer_torch_trainer.py:36-41; the authors'
+//     published implementation): rectified once N_sma >= 5; sqrt(1 - b2^t) folded into the step size, i.e. denom = sqrt(v) + eps
+//     (eps NOT scaled by the bias correction); weight decay applied to the WEIGHT (p -= lr * wd * p) before the update;
+//   variant 0 = torch.optim.RAdam: rectified once rho_t > 5; denom = sqrt(v) / sqrt(1 - b2^t) + eps; weight decay = L2 term on the gradient.
+int mk_radam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int t, float weight_decay, int variant, hipStream_t s) {
     const double bc1 = 1.0 - pow((double)b1, t), bc2 = 1.0 - pow((double)b2, t);
     const double rho_inf = 2.0 / (1.0 - b2) - 1.0, rho_t = rho_inf - 2.0 * t * pow((double)b2, t) / bc2;
+    const bool rect = variant ? rho_t >= 5.0 : rho_t > 5.0;
     double step = lr / bc1; float inv_sqrt_bc2 = 0.f, e = 1.f;
-    if (rho_t > 5.0) {
+    if (rect) {
         step *= sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t));
-        inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2)); e = eps;
+        if (variant) { step *= sqrt(bc2); inv_sqrt_bc2 = 1.f; } else inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+        e = eps;
     }
-    hipLaunchKernelGGL(adam_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, s, p, g, m, v, n, (float)step, b1, b2, e, inv_sqrt_bc2, 1.f, weight_decay, aligned16(p, g, m, v));
+    const float decay_mul = variant ? 1.f - lr * weight_decay : 1.f, l2 = variant ? 0.f : weight_decay;
+    hipLaunchKernelGGL(adam_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, s, p, g, m, v, n, (float)step, b1, b2, e, inv_sqrt_bc2, decay_mul, l2, aligned16(p, g, m, v));
     return LAUNCH_OK();
 }
 int mk_cast_bf16(const float* x, bf16* y, long n, hipStream_t s) {

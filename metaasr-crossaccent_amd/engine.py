@@ -34,17 +34,19 @@ def _ptr(t):
 
 
 class PendingStats:
-    """stats block of one batch on its way to the host (MasrEngine.read_stats_async).  Completion is detected by polling the
-    page-locked words themselves, pre-set to a NaN bit pattern no kernel produces: no event object per task and no HIP call from
-    the waiting thread (the task threads are inside the launch path at that moment; the runtime serialises callers)."""
-    SENTINEL = 0x7FC0DEAD                                     # a quiet NaN with a payload
+    """stats block of one batch on its way to the host (MasrEngine.read_stats_async): a ticket of the engine's ring of page-locked
+    blocks (include/masr.h masr_stats_post).  The waiting thread first polls the block's words -- they hold MASR_STATS_PENDING until
+    the copy lands -- WITHOUT entering the HIP runtime (the task threads are inside its launch path at that moment and the runtime
+    serialises callers), then confirms through the event recorded behind the copy (masr_stats_wait: completion + host visibility).
+    The block belongs to the engine and is only handed out again once that event has completed, so a dropped handle is harmless."""
+    SENTINEL = 0x7FC0DEAD
 
-    def __init__(self, buf):
-        self.buf = buf
-        self.bits = buf.view(torch.int32)
+    def __init__(self, engine, ticket, words):
+        self.engine, self.ticket, self.words = engine, ticket, words
 
     def ready(self):
-        return not bool((self.bits == self.SENTINEL).any())
+        w = self.words
+        return not (w[0] == self.SENTINEL or w[1] == self.SENTINEL or w[2] == self.SENTINEL or w[3] == self.SENTINEL)
 
     def get(self):
         n, t0 = 0, None
@@ -55,8 +57,9 @@ class PendingStats:
                 t0 = t0 or time.monotonic()
                 if time.monotonic() - t0 > 300.0:
                     raise RuntimeError("the stats of a queued batch never reached the host (stream wedged, or the batch failed to launch)")
-        b = self.buf
-        return {"loss": float(b[0]), "n_correct": float(b[1]), "n_total": float(b[2]), "grad_norm": float(b[3])}
+        out = (C.c_float * 4)()
+        check(self.engine._l.masr_stats_wait(self.engine.h, self.ticket, out), "masr_stats_wait")
+        return {"loss": float(out[0]), "n_correct": float(out[1]), "n_total": float(out[2]), "grad_norm": float(out[3])}
 
 
 class MasrEngine:
@@ -154,6 +157,16 @@ class MasrEngine:
     def set_seed(self, seed: int):
         self._l.masr_set_seed(self.h, C.c_uint64(seed & (2 ** 64 - 1)))
 
+    def dropout_state(self):
+        """(seed, batches run since set_seed): the position of the dropout mask stream (include/masr.h masr_dropout_state)"""
+        st = (C.c_uint64 * 2)()
+        self._l.masr_dropout_state(self.h, st, 0)
+        return int(st[0]), int(st[1])
+
+    def set_dropout_state(self, state):
+        st = (C.c_uint64 * 2)(int(state[0]), int(state[1]))
+        self._l.masr_dropout_state(self.h, st, 1)
+
     # ------------------------------------------------------------------ the operator
     def run_batch(self, xs: torch.Tensor, ilens, ys, olens, train: bool):
         """forward + loss (+ backward).  xs: device fp32 [B,T,idim] (host tensors are uploaded);
@@ -202,13 +215,13 @@ class MasrEngine:
         return self._last_stats
 
     def read_stats_async(self):
-        """the same block, copied into page-locked memory by the stream WITHOUT waiting for it (include/masr.h
-        masr_read_stats_async): returns a handle whose .get() waits for that copy only.  The host can then queue the next tasks
-        while these run; the stats are what the log lines need one meta-step later."""
-        buf = torch.empty(4, dtype=torch.float32, pin_memory=True)
-        buf.view(torch.int32).fill_(PendingStats.SENTINEL)
-        check(self._l.masr_read_stats_async(self.h, C.c_void_p(buf.data_ptr()), self.stream()), "masr_read_stats_async")
-        return PendingStats(buf)
+        """the same block, copied into page-locked memory by the stream WITHOUT waiting for it (include/masr.h masr_stats_post):
+        returns a handle whose .get() waits for that copy only.  The host can then queue the next tasks while these run; the stats
+        are what the log lines need one meta-step later."""
+        ticket = int(self._l.masr_stats_post(self.h, self.stream()))
+        if ticket < 0:
+            raise _cabi.MasrError("masr_stats_post: " + self._l.masr_last_error().decode())
+        return PendingStats(self, ticket, self._l.masr_stats_peek(self.h, ticket))
 
     def set_step_graphs(self, on: bool):
         """opt-in graph replay of repeated batch shapes (include/masr.h masr_set_step_graphs)"""
@@ -265,9 +278,15 @@ class MasrEngine:
         check(self._l.masr_adam_sum_step(_ptr(params), arr, len(grad_list), gscale, _ptr(m), _ptr(v), params.numel(), lr, b1, b2, eps, step,
                                          self.stream()), "masr_adam_sum_step")
 
-    def radam_step(self, params, grads, m, v, lr, b1, b2, eps, step, weight_decay=0.0):
-        check(self._l.masr_radam_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, b1, b2, eps, weight_decay, step, self.stream()),
-              "masr_radam_step")
+    def sum_n(self, out, grad_list, scale=1.0):
+        """out = (sum of grad_list, in order) * scale in one pass (include/masr.h masr_sum_n)"""
+        arr = (C.c_void_p * len(grad_list))(*[g.data_ptr() for g in grad_list])
+        check(self._l.masr_sum_n(_ptr(out), arr, len(grad_list), scale, out.numel(), self.stream()), "masr_sum_n")
+
+    def radam_step(self, params, grads, m, v, lr, b1, b2, eps, step, weight_decay=0.0, variant=1):
+        """variant 1: torch_optimizer.RAdam's conventions (the reference's import), 0: torch.optim.RAdam's (include/masr.h)"""
+        check(self._l.masr_radam_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, b1, b2, eps, weight_decay, step, int(variant),
+                                      self.stream()), "masr_radam_step")
 
     def sgd_step(self, params, grads, mom, lr, momentum, nesterov, first_step):
         check(self._l.masr_sgd_step(_ptr(params), _ptr(grads), _ptr(mom), params.numel(), lr, momentum, int(nesterov), int(first_step), self.stream()), "masr_sgd_step")

@@ -8,6 +8,7 @@ flat HBM buffers of the HIP engine.
 Multi-GPU: tasks of a meta-step are split round-robin over ranks and `_updates` is all-reduced (parallel.py).
 Reference quirks kept by default: snapshots hold the LAST TASK's adapted weights (Q1/F8),
 evaluation runs on them too (Q2), a NaN val gradient is still accumulated (Q5); --fix_* flags opt out."""
+import contextlib
 import math
 import pickle
 import random
@@ -68,7 +69,19 @@ class FOMetaASRInterface(PretrainInterface):
         # (one model replica + HIP stream + host thread per slot).  A B=16 inner step leaves ~40 % of the 256 CUs idle
         # (small decoder GEMMs, kernel tails); three concurrent tasks raise the throughput ~1.6x.  1 = reference order.
         self.tasks_per_gpu = max(1, int(getattr(paras, 'tasks_per_gpu', 1) or 1))
+        if self.tasks_per_gpu > 8:
+            # the one-pass meta update / wave sum read at most 8 gradient buffers (include/masr.h masr_adam_sum_step, masr_sum_n),
+            # and more than four streams with work queued take turns on the hardware queues anyway
+            raise ValueError(f"--tasks_per_gpu {self.tasks_per_gpu}: at most 8 task slots per GPU (4 is the most that pays)")
+        rounds = -(-self.meta_batch_size // self.sharder.world)
+        if self.sharder.collective and self.tasks_per_gpu > 3 and rounds > self.tasks_per_gpu and not getattr(paras, 'no_slot_cap', False):
+            # several ranks AND several waves per meta-step: the all-reduce of wave w (RCCL's own stream) runs beside the tasks of
+            # wave w+1, i.e. a fifth stream with work queued -- three task slots keep the total at the four that run side by side
+            logger.notice(f"tasks_per_gpu {self.tasks_per_gpu} -> 3: {rounds} tasks per rank and meta-step run as several waves whose "
+                          f"all-reduce overlaps the next wave (four-queue rule, DESIGN 6.2; --no_slot_cap keeps the setting)")
+            self.tasks_per_gpu = 3
         self._slots = None
+        self._n_reduces = 0                                          # all-reduces this rank has issued in the current meta-step
         # task order: the reference's global `random` stream (:136).  Every rank consumes that stream identically (data
         # draws of non-owned tasks are replayed index-only, see train()), so the order is the same on all ranks and the
         # same as in the single-process run.
@@ -102,8 +115,15 @@ class FOMetaASRInterface(PretrainInterface):
             print(self.global_step, file=f)
         torch.save(sd, self.log_dir.joinpath(f"snapshot.step.{self.global_step}"))
         # extension (not in the reference, which cannot resume pretraining): meta weights + meta-Adam state
+        # ... and everything else an exact continuation needs: the three RNG streams and the per-accent sampler state that decide
+        # which batches come next, the best-so-far error rates, the dropout streams' positions.  (The look-ahead never crosses a
+        # save boundary, see train(), so no drawn-but-unused batch is lost here.)
+        from .io.dataset import capture_rng
         torch.save({'original': self._original.cpu(), 'adam': self.meta_opt.optimizer.state_dict(),
-                    'step_num': self.meta_opt.step_num}, self.log_dir.joinpath("meta_state.latest"))
+                    'step_num': self.meta_opt.step_num, 'rng': capture_rng(), 'data': self.data_container.state_dict(),
+                    'best': (self.best_wer, self.best_cer),
+                    'dropout': [sl['engine'].dropout_state() for sl in (self._slots or []) if hasattr(sl['engine'], 'dropout_state')]},
+                   self.log_dir.joinpath("meta_state.latest"))
         self.dashboard.log_step()
 
     def load_model(self):
@@ -120,10 +140,18 @@ class FOMetaASRInterface(PretrainInterface):
         self._make_slots()
         ms = self.log_dir.joinpath("meta_state.latest")
         if self.paras.resume and ms.exists():
-            st = torch.load(ms)
+            st = torch.load(ms, weights_only=False)
             self._original.copy_(st['original'])
             self.meta_opt.optimizer.load_state_dict(st['adam'])
             self.meta_opt.step_num = st['step_num']
+            self.meta_opt.lr = st['adam']['lr']
+            if 'rng' in st:                                              # exact continuation of the data / task-order streams
+                from .io.dataset import restore_rng
+                self.data_container.load_state_dict(st['data'])
+                self.best_wer, self.best_cer = st['best']
+                for sl, d in zip(self._slots or [], st['dropout']):
+                    sl['engine'].set_dropout_state(d)
+                restore_rng(st['rng'])                                   # last: everything above (and set_model) consumed the streams
 
     def _make_slots(self):
         """slot 0 is the trainer's own model; further slots are replicas of the same architecture"""
@@ -157,7 +185,7 @@ class FOMetaASRInterface(PretrainInterface):
     def _task_on_slot(self, slot, tr_batches, val_batch, out, i):
         """one task = run_task + val-batch gradient + clip, entirely on the slot's stream (host thread body)"""
         try:
-            with torch.cuda.stream(slot['stream']):
+            with (torch.cuda.stream(slot['stream']) if slot['stream'] is not None else contextlib.nullcontext()):
                 self.run_task(tr_batches, engine=slot['engine'])
                 info = self._train(val_batch[0], *val_batch[1], accent_idx=val_batch[0], engine=slot['engine'], want_info=False)
                 out[i] = self._clip_and_stats(info, engine=slot['engine'])
@@ -191,7 +219,8 @@ class FOMetaASRInterface(PretrainInterface):
         the main thread in the reference's order, batches being assembled by the collate pool).  Waves of K tasks run
         concurrently, one replica + stream + host thread each; gradients are accumulated in task order -> deterministic."""
         fetched = [(a, [(i, f.result()) for i, f in tr], (val[0], val[1].result())) for a, tr, val in drawn]
-        main = torch.cuda.current_stream()
+        cuda = self._slots[0]['engine'].device.type == 'cuda'
+        main = torch.cuda.current_stream() if cuda else None       # (CPU engines: the doubles of the gloo tests; no streams)
         # slot 0 runs ON the main stream: K streams in all.  Four streams run side by side without loss (tools/queue_probe.py);
         # with the host running ahead, a fifth queue holding nothing but the meta-update behind its waits on the task streams
         # shares a place with one task stream, which then only gets served once the other three have drained (measured:
@@ -200,7 +229,7 @@ class FOMetaASRInterface(PretrainInterface):
         K = self.tasks_per_gpu
         # every task of the meta-step on a slot of its own: the meta update reads the K gradient buffers directly (one pass
         # instead of zero + K accumulations + scale + Adam; same additions in the same order)
-        fused = (len(fetched) <= K and self.sharder.world == 1 and self.paras.algo == 'fomaml' and self._updates is None
+        fused = (len(fetched) <= min(K, 8) and not self.sharder.collective and self.paras.algo == 'fomaml' and self._updates is None
                  and hasattr(self._slots[0]['engine'], 'adam_sum_step') and not getattr(self.paras, 'no_fused_meta_update', False))
         for w0 in range(0, len(fetched), K):
             wave = fetched[w0:w0 + K]
@@ -208,7 +237,7 @@ class FOMetaASRInterface(PretrainInterface):
             threads = []
             for i, (accent_id, tr, val) in enumerate(wave):
                 sl = self._slots[i]
-                if sl['stream'] != main:
+                if cuda and sl['stream'] != main:
                     sl['stream'].wait_stream(main)                  # meta weights / previous accumulation are ready
                 t = threading.Thread(target=self._task_on_slot, args=(sl, tr, val, out, i))
                 t.start(); threads.append(t)
@@ -221,16 +250,47 @@ class FOMetaASRInterface(PretrainInterface):
                     raise o
             for i, (accent_id, tr, val) in enumerate(wave):
                 sl = self._slots[i]
-                if sl['stream'] != main:
+                if cuda and sl['stream'] != main:
                     main.wait_stream(sl['stream'])
                 self._counter += 1                                   # counted here (main thread), not in the worker
                 if fused:
                     self._task_grads.append(sl['engine'].grads)
-                else:
+                elif not self.sharder.collective:
                     self._partial_meta_update(engine=sl['engine'])
                 self._pending.append((self.global_step, accent_id, out[i], len(val[1][2])))
                 self.asr_model = sl['model']                         # quirk Q1/Q2: the LAST task's adapted weights are "the model"
+            if self.sharder.collective:
+                self._exchange_wave([self._slots[i]['engine'] for i in range(len(wave))])
         return len(fetched)
+
+    def _exchange_wave(self, engines):
+        """several ranks, K task slots: the wave's task gradients are summed on this rank first (task order, one pass) and the sum
+        goes out as ONE all-reduce -- the sum is linear, so this is the `_updates[n] += p.grad` of every task of every rank
+        (:190-196) with K times less xGMI traffic than an all-reduce per task.  Issued from the main stream (RCCL runs it on its
+        own): with one wave per meta-step nothing is left to overlap with, with several it overlaps the next wave."""
+        if self.paras.algo != 'fomaml' and not (self.paras.algo == 'reptile' and self.fix_reptile):
+            raise ValueError(f"Not support meta algo {self.paras.algo}")
+        eng = engines[0]
+        contrib = torch.empty_like(eng.params)
+        if self.paras.algo == 'reptile':                               # sum_k (theta_meta - theta_k) = n theta_meta - sum_k theta_k
+            self._sum_n(eng, contrib, [e.params for e in engines], -1.0)
+            eng.axpy(contrib, self._original, float(len(engines)))
+        else:
+            self._sum_n(eng, contrib, [e.grads for e in engines], 1.0)
+        self.sharder.reduce_async(contrib, side_stream=False)
+        self._n_reduces += 1
+        if self._updates is None:
+            self._updates = []
+        self._updates.append(contrib)
+
+    @staticmethod
+    def _sum_n(eng, out, bufs, scale):
+        if hasattr(eng, 'sum_n'):
+            eng.sum_n(out, bufs, scale)                                # one pass (include/masr.h masr_sum_n)
+        else:
+            out.zero_()
+            for b in bufs:
+                eng.axpy(out, b, scale)
 
     def _draw_meta_batch(self, meta_batch):
         """Batch INDICES of every task of the meta-step, drawn in the reference's order (per task: k inner batches, then the
@@ -257,15 +317,18 @@ class FOMetaASRInterface(PretrainInterface):
         task_ids = list(range(self.num_pretrain))
         nxt = None
         try:
+            first_it = (self.global_step - 1) % self.eval_ival          # (a resumed run re-enters the chunk it was saved in)
             while self.global_step < self.max_step:
-                for it in range(self.eval_ival):
+                for it in range(first_it, self.eval_ival):
+                    first_it = 0
                     meta_batch, drawn = nxt if nxt is not None else self._shuffle_and_draw(task_ids)
                     # look-ahead: the NEXT meta-step's task order and batch indices are drawn now (same RNG order as drawing
                     # them after this step: nothing in between consumes `random` / `np.random`), so that its batches are
                     # assembled in pinned memory by the collate pool while this step runs on the GPU.  Bucketed loaders only:
                     # a RandomSampler also reads the torch stream, which evaluate()'s dev loaders touch in between.
                     more = it + 1 < self.eval_ival or self.global_step + 1 < self.max_step
-                    ahead = more and self.is_bucket and self.data_container.pool is not None
+                    # (not across a checkpoint: save_per_steps records the RNG / sampler state "nothing drawn beyond this step")
+                    ahead = more and self.is_bucket and self.data_container.pool is not None and (self.global_step + 1) % self.save_ival != 0
                     nxt = None
 
                     def look_ahead():                                   # runs once the first task's launches are queued: its host
@@ -318,7 +381,7 @@ class FOMetaASRInterface(PretrainInterface):
         reptile = self.paras.algo == 'reptile' and self.fix_reptile
         if self.paras.algo != 'fomaml' and not reptile:
             raise ValueError(f"Not support meta algo {self.paras.algo}")    # reptile/maml: no reference implementation
-        if self.sharder.world == 1:
+        if not self.sharder.collective:
             if self._updates is None:
                 self._updates = torch.zeros_like(eng.params)
             if reptile:                                                    # pseudo-gradient theta_meta - theta_k
@@ -334,32 +397,40 @@ class FOMetaASRInterface(PretrainInterface):
             eng.axpy(contrib, eng.params, -1.0)
         else:
             contrib = eng.grads.clone()                                   # per-task buffer handed to the side stream
-        self.sharder.reduce_async(contrib, side_stream=getattr(self, 'tasks_per_gpu', 1) == 1)
+        self.sharder.reduce_async(contrib)                              # side stream: overlaps this rank's next task
+        self._n_reduces += 1
         self._updates.append(contrib)
 
     def _pad_rounds(self, n_tasks, n_local):
         """every rank must issue the same number of all-reduces per meta-step: ranks that own fewer tasks than
         ceil(n_tasks / world) contribute zero buffers for the missing rounds"""
-        if self.sharder.world == 1:
+        if not self.sharder.collective:
             return
-        rounds = (n_tasks + self.sharder.world - 1) // self.sharder.world
-        for _ in range(rounds - n_local):
+        rounds = (n_tasks + self.sharder.world - 1) // self.sharder.world          # tasks of the busiest rank ...
+        rounds = (rounds + self.tasks_per_gpu - 1) // self.tasks_per_gpu             # ... = its waves = its all-reduces
+        for _ in range(rounds - self._n_reduces):
             z = torch.zeros_like(self.asr_model.engine.params)
-            self.sharder.reduce_async(z)
+            self.sharder.reduce_async(z, side_stream=self.tasks_per_gpu == 1)
             if self._updates is None:
                 self._updates = []
             self._updates.append(z)
+        self._n_reduces = 0
 
     def _final_meta_update(self, n_tasks=None):
         """_updates /= counter; attach as .grad of the meta weights; Noam-Adam step; reset (:200-221).
         counter = number of tasks of the whole meta-step (all ranks)."""
         eng = self.asr_model.engine
-        if self.sharder.world > 1:
+        if self.sharder.collective:
             self.sharder.wait_all()
-            total = torch.zeros_like(eng.params)
-            for c in self._updates:
-                eng.axpy(total, c, 1.0)
-            self._updates = total
+            if len(self._updates) == 1:
+                self._updates = self._updates[0]
+            elif len(self._updates) <= 8 and hasattr(eng, 'adam_sum_step'):
+                self._task_grads = self._updates                        # Adam reads the reduced buffers directly (one pass)
+            else:
+                total = torch.zeros_like(eng.params)
+                for c in self._updates:
+                    eng.axpy(total, c, 1.0)
+                self._updates = total
             counter = n_tasks
         else:
             counter = self._counter
@@ -410,13 +481,25 @@ class FOMetaASRInterface(PretrainInterface):
             eng = self.asr_model.engine
             eng.copy(eng.params, self._original)
             eng.mark_dirty()
-            self._evaluate_accents(range(sh.rank, self.num_pretrain, sh.world), gather=sh.world > 1)
+            mine = range(sh.rank, self.num_pretrain, sh.world)
+            self._skip_dev_draws(set(range(self.num_pretrain)) - set(mine))
+            self._evaluate_accents(mine, gather=sh.world > 1)
         elif sh.world > 1:
             if sh.rank == 0:
                 self._evaluate_accents(range(self.num_pretrain))
+            else:
+                self._skip_dev_draws(range(self.num_pretrain))
             sh.barrier()
         else:
             self._evaluate_accents(range(self.num_pretrain))
+
+    def _skip_dev_draws(self, accent_ids):
+        """every dev iterator draws a base seed from the torch default generator when it is created (Loader.iter_indices, as torch's
+        DataLoader does).  A rank that does not evaluate an accent takes the same draws, so that the torch stream -- which the
+        non-bucketed train loaders' RandomSampler reads -- stays identical on all ranks (the index-only replay of task sharding
+        relies on identical RNG consumption everywhere)."""
+        for idx in accent_ids:
+            self.data_container.dev_loaders[idx].iter_indices()
 
     def _evaluate_accents(self, accent_ids, gather=False):
         self.asr_model.eval()

@@ -81,17 +81,16 @@ class BucketSampler:
         return max(1, self.batch_size // 2) if halved else self.batch_size
 
     def __iter__(self):
-        for bin_idx, members in self.buckets:
-            bs = self._bs(bin_idx)
-            np.random.shuffle(members)
-            cur = []
-            for i in members:
-                cur.append(int(i))
-                if len(cur) == bs:
-                    yield cur
-                    cur = []
-            if cur and not self.drop_last:
-                yield cur
+        return _BucketIter(self)
+
+    # ---- resumable state (extension: the reference restarts its data stream on --resume).  A bucket's members are shuffled IN
+    # PLACE when an epoch reaches it, so the arrangement left by one epoch is the input of the next one's shuffle: the state is
+    # the bucket order + every bucket's current arrangement (+ the cursor of a running iterator, _BucketIter.state)
+    def state_dict(self):
+        return {'buckets': [(int(b), np.array(m, copy=True)) for b, m in self.buckets]}
+
+    def load_state_dict(self, st):
+        self.buckets = [(int(b), np.array(m, copy=True)) for b, m in st['buckets']]
 
     def __len__(self):
         n = 0
@@ -99,6 +98,58 @@ class BucketSampler:
             bs = self._bs(bin_idx)
             n += len(members) // bs if self.drop_last else (len(members) + bs - 1) // bs
         return n
+
+
+class _BucketIter:
+    """one epoch of a BucketSampler (dataset.py:98-110 as an explicit cursor instead of a generator, so that a half-consumed
+    epoch can be saved and resumed): entering a bucket shuffles it (np.random), batches are consecutive runs of its members"""
+
+    def __init__(self, sampler, b=0, off=0):
+        self.s, self.b, self.off = sampler, b, off
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        s = self.s
+        while self.b < len(s.buckets):
+            bin_idx, members = s.buckets[self.b]
+            bs = s._bs(bin_idx)
+            if self.off == 0:
+                np.random.shuffle(members)
+            if self.off < len(members):
+                cur = [int(i) for i in members[self.off:self.off + bs]]
+                self.off += bs
+                if len(cur) == bs or not s.drop_last:
+                    if self.off >= len(members):
+                        self.b, self.off = self.b + 1, 0
+                    return cur
+            self.b, self.off = self.b + 1, 0
+        raise StopIteration
+
+    def state(self):
+        return {'kind': 'bucket', 'b': self.b, 'off': self.off}
+
+
+class _ListIter:
+    """one epoch of a plain (sequential / RandomSampler) loader: a fixed order cut into batches"""
+
+    def __init__(self, order, batch_size, drop_last, pos=0):
+        self.order, self.batch_size, self.drop_last, self.pos = order, batch_size, drop_last, pos
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        while self.pos < len(self.order):
+            chunk = self.order[self.pos:self.pos + self.batch_size]
+            self.pos += self.batch_size
+            if len(chunk) == self.batch_size or not self.drop_last:
+                return chunk
+        raise StopIteration
+
+    def state(self):
+        return {'kind': 'list', 'order': list(self.order), 'pos': self.pos}
 
 
 class CommonVoiceDataset:
@@ -179,6 +230,32 @@ class CommonVoiceDataset:
         return xs, lens.to(torch.int64), ys, olens
 
 
+class _LazyListIter:
+    """plain loader: like the generator it replaces, the order (and the RandomSampler's seed draw from the torch stream) is only
+    made when the first batch is asked for"""
+
+    def __init__(self, loader):
+        self.loader, self.it = loader, None
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self.it is None:
+            ld = self.loader
+            order = list(ld.indices)
+            if ld.shuffle:
+                # torch.utils.data.RandomSampler: draw a seed from the default generator, permute with a private one
+                g = torch.Generator()
+                g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
+                order = [order[i] for i in torch.randperm(len(order), generator=g).tolist()]
+            self.it = _ListIter(order, ld.batch_size, ld.drop_last)
+        return next(self.it)
+
+    def state(self):
+        return {'kind': 'lazy'} if self.it is None else self.it.state()
+
+
 _PREFETCH_POOL = None
 
 
@@ -200,18 +277,16 @@ class Loader:
 
     def _batches(self):
         if self.batch_sampler is not None:
-            yield from self.batch_sampler
-            return
-        order = list(self.indices)
-        if self.shuffle:
-            # torch.utils.data.RandomSampler: draw a seed from the default generator, permute with a private one
-            g = torch.Generator()
-            g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
-            order = [order[i] for i in torch.randperm(len(order), generator=g).tolist()]
-        for i in range(0, len(order), self.batch_size):
-            chunk = order[i:i + self.batch_size]
-            if len(chunk) == self.batch_size or not self.drop_last:
-                yield chunk
+            return iter(self.batch_sampler)
+        return _LazyListIter(self)
+
+    def restore_iter(self, st):
+        """the index iterator a saved state (`.state()` of a running one) describes"""
+        if st['kind'] == 'bucket':
+            return _BucketIter(self.batch_sampler, st['b'], st['off'])
+        if st['kind'] == 'lazy':
+            return _LazyListIter(self)
+        return _ListIter(list(st['order']), self.batch_size, self.drop_last, st['pos'])
 
     def iter_indices(self):
         """the batch INDEX stream alone: consumes the RNG streams exactly like __iter__ but touches no features.
@@ -339,6 +414,31 @@ class DataContainer:
             else:
                 out.append((a, ld.materialize(idxs) if materialize else None))
         return out
+
+
+    # ---- resumable state of the train streams (extension; restored AFTER construction, which consumes the RNG streams itself)
+    def state_dict(self):
+        return {'reload_cnt': self.reload_cnt,
+                'samplers': [ld.batch_sampler.state_dict() if ld.batch_sampler is not None else None for ld in self.loaders],
+                'iters': [it.state() for it in self.loader_iters]}
+
+    def load_state_dict(self, st):
+        self.reload_cnt = st['reload_cnt']
+        for a, (ld, ss, its) in enumerate(zip(self.loaders, st['samplers'], st['iters'])):
+            if ss is not None:
+                ld.batch_sampler.load_state_dict(ss)
+            self.loader_iters[a] = ld.restore_iter(its)
+
+
+def capture_rng():
+    """the three global streams that drive batching and task order (python `random`, np.random, torch default generator)"""
+    return {'random': random.getstate(), 'numpy': np.random.get_state(), 'torch': torch.get_rng_state()}
+
+
+def restore_rng(st):
+    random.setstate(st['random'])
+    np.random.set_state(st['numpy'])
+    torch.set_rng_state(st['torch'])
 
 
 class _Ready:

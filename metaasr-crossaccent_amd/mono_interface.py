@@ -129,7 +129,14 @@ class MonoASRInterface(TrainInterface):
         getattr(self, '_drain_stats', lambda: None)()
         torch.save(self._sd_cpu(), self.log_dir.joinpath("snapshot.latest"))
         opt = self.asr_opt.optimizer if isinstance(self.asr_opt, TransformerOptimizer) else self.asr_opt
-        state = {'opt': opt.state_dict(), 'step_num': getattr(self.asr_opt, 'step_num', None)}
+        # beyond the reference's file (optimiser only): the RNG streams + the train sampler's bucket arrangement, which together
+        # decide the next epoch's batches, and the dropout stream's position -- `--resume` then continues the run exactly
+        from .io.dataset import capture_rng
+        bs = getattr(self.train_set, 'batch_sampler', None)
+        eng = self.asr_model.engine
+        state = {'opt': opt.state_dict(), 'step_num': getattr(self.asr_opt, 'step_num', None), 'rng': capture_rng(),
+                 'sampler': bs.state_dict() if bs is not None else None,
+                 'dropout': eng.dropout_state() if hasattr(eng, 'dropout_state') else None}
         with open(self.log_dir.joinpath("optimizer.latest"), 'wb') as f:
             pickle.dump(state, f)
         with open(self.log_dir.joinpath("info_dict.latest"), 'wb') as f:
@@ -162,7 +169,14 @@ class MonoASRInterface(TrainInterface):
             opt = self.asr_opt.optimizer if isinstance(self.asr_opt, TransformerOptimizer) else self.asr_opt
             opt.load_state_dict(st['opt'])
             if st.get('step_num') is not None:
-                self.asr_opt.step_num = st['step_num']
+                self.asr_opt.step_num, self.asr_opt.lr = st['step_num'], st['opt']['lr']
+            if 'rng' in st:
+                from .io.dataset import restore_rng
+                if st['sampler'] is not None:
+                    self.train_set.batch_sampler.load_state_dict(st['sampler'])
+                if st['dropout'] is not None:
+                    eng.set_dropout_state(st['dropout'])
+                restore_rng(st['rng'])
             self.dashboard.set_step(self.global_step)
         elif self.paras.pretrain:
             cur = eng.state_dict()
@@ -186,7 +200,15 @@ class MonoASRInterface(TrainInterface):
 
     def train(self):
         eng = self.asr_model.engine
-        self.evaluate()
+        if self.paras.resume:
+            # the reference evaluates at every start (:131), also of a resumed run; an uninterrupted run has no evaluation at this
+            # point, so the draws its dev iterator takes from the torch stream are given back (exact continuation of the data order)
+            from .io.dataset import capture_rng, restore_rng
+            rng = capture_rng()
+            self.evaluate()
+            restore_rng(rng)
+        else:
+            self.evaluate()
         try:
             if self.save_verbose:                                            # save_init (:124-127)
                 torch.save(self._sd_cpu(), self.log_dir.joinpath("snapshot.init"))

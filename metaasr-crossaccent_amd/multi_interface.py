@@ -45,12 +45,34 @@ class MultiASRInterface(PretrainInterface):
         with open(self.log_dir.joinpath("global_step"), 'w') as f:
             print(self.global_step, file=f)
         torch.save(sd, self.log_dir.joinpath(f"snapshot.step.{self.global_step}"))
+        # extension (the reference's pretraining cannot resume): optimiser state + the RNG streams and
+        # sampler state that decide the next batches, for an exact continuation (same layout as the FOMAML interface's file)
+        from .io.dataset import capture_rng
+        inner = self.asr_opt.optimizer if isinstance(self.asr_opt, TransformerOptimizer) else self.asr_opt
+        eng = self.asr_model.engine
+        torch.save({'opt': inner.state_dict(), 'step_num': getattr(self.asr_opt, 'step_num', None), 'rng': capture_rng(),
+                    'data': self.data_container.state_dict(), 'best': (self.best_wer, self.best_cer),
+                    'dropout': [eng.dropout_state()] if hasattr(eng, 'dropout_state') else []},
+                   self.log_dir.joinpath("meta_state.latest"))
         self.dashboard.log_step()
 
     def load_model(self):
         if self.paras.resume:
             self.asr_model.load_state_dict(torch.load(self.resume_model_path))
             self.dashboard.set_step(self.global_step)
+            ms = self.log_dir.joinpath("meta_state.latest")
+            if ms.exists():
+                from .io.dataset import restore_rng
+                st = torch.load(ms, weights_only=False)
+                inner = self.asr_opt.optimizer if isinstance(self.asr_opt, TransformerOptimizer) else self.asr_opt
+                inner.load_state_dict(st['opt'])
+                if st.get('step_num') is not None:
+                    self.asr_opt.step_num, self.asr_opt.lr = st['step_num'], st['opt']['lr']
+                self.data_container.load_state_dict(st['data'])
+                self.best_wer, self.best_cer = st['best']
+                for d in st['dropout']:
+                    self.asr_model.engine.set_dropout_state(d)
+                restore_rng(st['rng'])
 
     def write_tr_logs(self):
         for k, v in self.train_info.items():
@@ -97,11 +119,14 @@ class MultiASRInterface(PretrainInterface):
                 self.train_info.add(info, n)
         self._drain_stats = drain
         try:
+            first_it = (self.global_step - 1) % self.eval_ival          # (a resumed run re-enters the chunk it was saved in)
             while self.global_step < self.max_step:
-                for it in range(self.eval_ival):
+                for it in range(first_it, self.eval_ival):
+                    first_it = 0
                     idx, fut = nxt if nxt is not None else draw()
                     more = it + 1 < self.eval_ival or self.global_step + 1 < self.max_step
-                    nxt = draw() if ahead and more else None
+                    # (no draw across a checkpoint: save_per_steps records "nothing drawn beyond this step")
+                    nxt = draw() if ahead and more and (self.global_step + 1) % self.save_ival != 0 else None
                     x, ilens, ys, olens = fut.result()
                     one_sync = hasattr(self, 'info_from_stats')            # {loss, acc} ride on the copy that brings the norm back
                     info = self._train(idx, x, ilens, ys, olens, accent_idx=idx, **({'want_info': False} if one_sync else {}))

@@ -74,17 +74,20 @@ class FlatAdam:
 
 
 class FlatRAdam(FlatAdam):
-    """optimizer_cls 'RAdam' (src/transformer_torch_trainer.py:36-41, there from the un-vendored `torch_optimizer`): the published
-    algorithm with torch.optim.RAdam's conventions (rectification once rho_t > 5, L2 weight decay)."""
+    """optimizer_cls 'RAdam' (src/transformer_torch_trainer.py:36-41): `torch_optimizer.RAdam(**optimizer_opt)` in the reference, an
+    un-vendored package.  Default = that package's conventions (its authors' published implementation): rectified once N_sma >= 5,
+    denom = sqrt(v) + eps (bias correction of v folded into the step size), weight decay applied to the weight (p -= lr*wd*p).
+    torch_conventions=True selects torch.optim.RAdam's instead (rho_t > 5, sqrt(v)/sqrt(1-b2^t) + eps, L2 weight decay)."""
 
-    def __init__(self, engine, params_flat, betas=(0.9, 0.999), eps=1e-8, lr=1e-3, weight_decay=0.0):
-        super().__init__(engine, params_flat, betas=betas, eps=eps, lr=lr, weight_decay=weight_decay, decoupled=False)
+    def __init__(self, engine, params_flat, betas=(0.9, 0.999), eps=1e-8, lr=1e-3, weight_decay=0.0, torch_conventions=False):
+        super().__init__(engine, params_flat, betas=betas, eps=eps, lr=lr, weight_decay=weight_decay, decoupled=not torch_conventions)
+        self.variant = 0 if torch_conventions else 1
 
     def step(self):
         assert self.grad is not None, "FlatRAdam.step(): no gradient attached"
         self.t += 1
         self.engine.radam_step(self.params, self.grad, self.exp_avg, self.exp_avg_sq, self.param_groups[0]['lr'], self.betas[0],
-                               self.betas[1], self.eps, self.t, self.weight_decay)
+                               self.betas[1], self.eps, self.t, self.weight_decay, self.variant)
         if self.params.data_ptr() == self.engine.params.data_ptr():
             self.engine.mark_dirty()
 

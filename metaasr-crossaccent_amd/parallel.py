@@ -18,8 +18,12 @@ import torch
 
 
 class TaskSharder:
-    def __init__(self, rank=0, world=1, backend=None):
+    def __init__(self, rank=0, world=1, backend=None, collective=None):
         self.rank, self.world, self.backend = rank, world, backend
+        # does the meta-gradient go through the collective?  Always with several ranks; with ONE rank only when a process group
+        # exists and MASR_FORCE_COLLECTIVE=1 asks for it (an all-reduce over one rank is the identity): that runs RCCL init, the
+        # side-stream ordering and work.wait() on a single MI355X (tests/test_hip_rccl_world1.py)
+        self.collective = (world > 1) if collective is None else bool(collective)
         self._side = None
         self._pending = []
 
@@ -27,7 +31,8 @@ class TaskSharder:
     def from_env(cls):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
-            return cls(dist.get_rank(), dist.get_world_size(), dist.get_backend())
+            world = dist.get_world_size()
+            return cls(dist.get_rank(), world, dist.get_backend(), collective=world > 1 or os.environ.get("MASR_FORCE_COLLECTIVE") == "1")
         return cls()
 
     @staticmethod
@@ -35,8 +40,11 @@ class TaskSharder:
         """one process per GPU; reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment."""
         import torch.distributed as dist
         world = int(os.environ.get("WORLD_SIZE", "1"))
-        if world <= 1 or dist.is_initialized():
+        if (world <= 1 and os.environ.get("MASR_FORCE_COLLECTIVE") != "1") or dist.is_initialized():
             return
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
@@ -74,7 +82,7 @@ class TaskSharder:
         The caller must not touch `buf` until wait_all().  side_stream=False: issued from the current stream (RCCL still runs it on
         its own stream) -- for callers that already keep four streams busy, where one more stream with work queued displaces a
         task's and nothing is left to overlap with anyway."""
-        if self.world == 1:
+        if not self.collective:
             return
         import torch.distributed as dist
         if buf.device.type == "cuda" and self.backend == "gloo":

@@ -611,3 +611,31 @@ def ctc_loss_np(log_probs, targets, input_lengths, target_lengths, blank=0):
                 if np.isfinite(ab):
                     grad[t, b, ext[s]] -= np.exp(ab - lp[t, b, ext[s]] - ll) * scale
     return total, grad
+
+
+def radam_torch_optimizer_step(p, g, state, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """One step of `torch_optimizer.RAdam` -- the class the reference's `optimizer_cls: RAdam` resolves to
+    (src/transformer_torch_trainer.py:36-41).  The package (jettify/pytorch-optimizer, which carries the RAdam authors' published
+    implementation) is NOT vendored in /root/reference and not installed here: this restates its published update rule, **parity
+    unpinned** against the package itself.  Differences from torch.optim.RAdam: rectification from N_sma >= 5 (not > 5), eps added to
+    sqrt(v) WITHOUT the bias correction of v (that factor sits in the step size), weight decay applied to the weight
+    (p += -wd * lr * p) instead of to the gradient.  `state` = {'step', 'exp_avg', 'exp_avg_sq'}, updated in place; p in place."""
+    b1, b2 = betas
+    state['step'] += 1
+    t = state['step']
+    state['exp_avg_sq'].mul_(b2).addcmul_(g, g, value=1 - b2)
+    state['exp_avg'].mul_(b1).add_(g, alpha=1 - b1)
+    beta2_t = b2 ** t
+    n_sma_max = 2 / (1 - b2) - 1
+    n_sma = n_sma_max - 2 * t * beta2_t / (1 - beta2_t)
+    if n_sma >= 5:
+        step_size = lr * math.sqrt((1 - beta2_t) * (n_sma - 4) / (n_sma_max - 4) * (n_sma - 2) / n_sma * n_sma_max / (n_sma_max - 2)) / (1 - b1 ** t)
+    else:
+        step_size = lr / (1 - b1 ** t)
+    if weight_decay != 0:
+        p.add_(p, alpha=-weight_decay * lr)
+    if n_sma >= 5:
+        p.addcdiv_(state['exp_avg'], state['exp_avg_sq'].sqrt().add_(eps), value=-step_size)
+    else:
+        p.add_(state['exp_avg'], alpha=-step_size)
+    return p

@@ -50,6 +50,8 @@ def build_parser():
     p.add_argument('--hbm_shards', action='store_true', help='keep the fbank shards resident in HBM (GPU gather+pad)')
     p.add_argument('--tasks_per_gpu', type=int, default=1, help='FOMAML: accent-tasks of a meta-step run concurrently on one GPU '
                    '(replica + HIP stream + host thread each); results are identical to 1 (tasks are independent)')
+    p.add_argument('--no_slot_cap', action='store_true', help='several ranks: keep --tasks_per_gpu above 3 even when a rank runs several waves of '
+                   'tasks per meta-step (their all-reduce then competes with the next wave for the four hardware queues)')
     p.add_argument('--sync_stats', action='store_true', help='FOMAML: read every task\'s loss / accuracy / gradient norm back before the next '
                    'task is queued (the reference\'s timing of its log lines); default: the host runs one meta-step ahead of the GPU and books '
                    'them then -- same numbers, same order')

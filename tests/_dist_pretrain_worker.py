@@ -24,10 +24,12 @@ def main():
         torch.cuda.synchronize()
         captured["meta"] = self._original.cpu().clone()
         captured["step"] = self.global_step
+        captured["collective"] = bool(self.sharder.collective)
+        captured["backend"] = self.sharder.backend
     fo_meta_interface.FOMetaASRInterface.train = train
     pretrain.main(["--config", "cfg3.yaml", "--pretrain_suffix", suffix, "--pretrain_accents", "af", "au", "en", "us", "--num_pretrain", "4",
                    "--tgt_accent", "ca", "--algo", "fomaml", "--meta_k", "1", "--meta_batch_size", "4", "--max_step", "5", "--njobs", "2",
-                   "--overwrite"])
+                   "--overwrite"] + sys.argv[3:])
     torch.save(captured, os.path.join(out_dir, f"{suffix}_r{os.environ.get('RANK', '0')}.pt"))
 
 

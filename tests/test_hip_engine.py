@@ -325,3 +325,32 @@ def test_graph_replayed_steps_equal_direct_launches(sd):
         torch.cuda.current_stream().synchronize()
     assert engs[0].step_counters() == {"direct": 2, "captured": 2, "replayed": 7}, engs[0].step_counters()
     assert engs[1].step_counters()["replayed"] == 0
+
+
+def test_eight_encoder_layers_build_and_step():
+    """config/transformer/mono-test.yaml / mono-test-new-trick-8e4d.yaml geometry (8 encoder / 4 decoder layers = 69 shadow
+    jobs, more than one by-value job list holds): the engine is created, the shadow refresh takes two launches, and a training
+    step matches the CPU oracle like the 2e2d model does."""
+    cfg = dict(TINY, encoder={"nlayers": 8}, decoder={"nlayers": 4})
+    sd8 = ref_cpu.deterministic_state_dict(cfg, ODIM, seed=5)
+    xs, il, ys, ol = synth_batch(21, [64, 52, 40, 33], [9, 7, 5, 3])
+    eng = MasrEngine(cfg, ODIM, label_smoothing=0.2)
+    eng.load_state_dict(sd8)
+    eng.run_batch(xs, il, ys, ol, train=True)
+    g_all = {k: v.clone() for k, v in eng.state_dict(flat=eng.grads).items()}
+    mom = torch.zeros_like(eng.params)
+    eng.clip_sgd_step(mom, 5.0, 0.05, 0.9, True, True)
+    st = eng.read_stats()
+    with ref_cpu.bf16_emulation():
+        pq = ref_cpu.leafify(sd8, cfg)
+        infoq, gradsq, _, _ = ref_cpu.run_batch_train(pq, cfg, (xs, il, ys, ol.clone()), 0.2)
+    p = ref_cpu.leafify(sd8, cfg)
+    info, _, _, _ = ref_cpu.run_batch_train(p, cfg, (xs, il, ys, ol.clone()), 0.2)
+    assert abs(st["loss"] - info["loss"]) <= 1e-3 * info["loss"], (st["loss"], info["loss"])
+    for n in ("encoder.layers.7.linear1.weight", "encoder.layers.0.self_attn.in_proj_weight", "decoder.layers.3.multihead_attn.out_proj.weight",
+              "decoder.layers.3.linear2.weight", "vgg2enc.weight"):
+        assert rel_l2(g_all[n].cpu(), gradsq[n]) < 8e-2, n
+    # the second step reads the shadows of EVERY layer refreshed by the (two-launch) refresh after the update
+    eng.run_batch(xs, il, ys, ol, train=True)
+    st2 = eng.read_stats()
+    assert math.isfinite(st2["loss"]) and st2["loss"] < st["loss"]

@@ -182,9 +182,9 @@ def test_flat_passes_vector_and_scalar_paths():
 
 
 def test_flat_radam_matches_torch_radam():
-    """optimizer_cls 'RAdam' (transformer_torch_trainer.py:36-41): 12 steps against torch.optim.RAdam on the CPU -- the first
-    five run in the unrectified phase (rho_t <= 5 at beta2 = 0.999), the rest with the rectification term; with and without the
-    L2 weight-decay term."""
+    """optimizer_cls 'RAdam' (transformer_torch_trainer.py:36-41), torch.optim.RAdam's conventions (FlatRAdam(torch_conventions=True)):
+    12 steps against torch.optim.RAdam on the CPU -- the first five run in the unrectified phase (rho_t <= 5 at beta2 = 0.999), the
+    rest with the rectification term; with and without the L2 weight-decay term."""
     from masr_amd.optimizer import FlatRAdam
     eng = MasrEngine(TINY, ODIM)
     g = torch.Generator().manual_seed(2)
@@ -194,7 +194,7 @@ def test_flat_radam_matches_torch_radam():
         w = torch.nn.Parameter(p0.clone())
         ref = torch.optim.RAdam([w], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
         p = p0.clone().cuda()
-        opt = FlatRAdam(eng, p, betas=(0.9, 0.999), eps=1e-8, lr=1e-3, weight_decay=wd)
+        opt = FlatRAdam(eng, p, betas=(0.9, 0.999), eps=1e-8, lr=1e-3, weight_decay=wd, torch_conventions=True)
         for t in range(12):
             gr = torch.randn(n, generator=g)
             w.grad = gr.clone()
@@ -202,6 +202,33 @@ def test_flat_radam_matches_torch_radam():
             opt.grad = gr.cuda()
             opt.step()
             torch.testing.assert_close(p.cpu(), w.detach(), rtol=3e-6, atol=3e-7, msg=f"step {t + 1}, weight_decay {wd}")
+
+
+def test_flat_radam_default_follows_torch_optimizer_conventions():
+    """the DEFAULT FlatRAdam = `torch_optimizer.RAdam`, the class the reference instantiates (un-vendored, absent here: checked
+    against the oracle's restatement of its published update rule, parity unpinned against the package).  With weight decay, a
+    large eps (where "sqrt(v) + eps" and "sqrt(v)/sqrt(bc2) + eps" part visibly) and the N_sma >= 5 threshold crossed in the run;
+    and it must NOT coincide with torch.optim.RAdam's trajectory when weight decay is on."""
+    from masr_amd.optimizer import FlatRAdam
+    eng = MasrEngine(TINY, ODIM)
+    g = torch.Generator().manual_seed(3)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    for wd, eps in ((0.0, 1e-8), (0.1, 1e-3)):
+        ref_p = p0.clone().double()
+        st = {"step": 0, "exp_avg": torch.zeros(n, dtype=torch.float64), "exp_avg_sq": torch.zeros(n, dtype=torch.float64)}
+        w = torch.nn.Parameter(p0.clone())
+        tref = torch.optim.RAdam([w], lr=1e-2, betas=(0.9, 0.999), eps=eps, weight_decay=wd)
+        p = p0.clone().cuda()
+        opt = FlatRAdam(eng, p, betas=(0.9, 0.999), eps=eps, lr=1e-2, weight_decay=wd)
+        for t in range(12):
+            gr = torch.randn(n, generator=g)
+            ref_cpu.radam_torch_optimizer_step(ref_p, gr.double(), st, lr=1e-2, betas=(0.9, 0.999), eps=eps, weight_decay=wd)
+            w.grad = gr.clone(); tref.step()
+            opt.grad = gr.cuda(); opt.step()
+            torch.testing.assert_close(p.cpu().double(), ref_p, rtol=3e-6, atol=3e-7, msg=f"step {t + 1}, weight_decay {wd}")
+        if wd:
+            assert float((p.cpu() - w.detach()).abs().max()) > 1e-4          # the two conventions are different optimisers
 
 
 def _common(tmp_path, extra_model):

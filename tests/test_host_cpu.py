@@ -202,3 +202,37 @@ def test_cli_level_init_parity_after_load_data(golden_dir, tmp_path, monkeypatch
                   is_memmap=True, is_bucket=True, min_ilen=sv["min_ilen"], max_ilen=sv["max_ilen"], half_batch_ilen=sv["half_batch_ilen"])
     sd = reference_init_state_dict(pre["asr_model"], ODIM)
     np.testing.assert_allclose(flat_checks(sd["vgg2enc.weight"]), g["pre/init/fp/vgg2enc.weight"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("is_bucket", [True, False])
+def test_data_stream_state_round_trip(tmp_path, is_bucket):
+    """what `--resume` relies on: DataContainer.state_dict() + the three RNG streams, taken in the middle of an epoch, and restored
+    into a FRESH container (whose construction consumed the streams on its own), reproduce the batch stream that followed --
+    through several epoch roll-overs (sampler rebuilt with `random`, buckets re-shuffled with np.random / RandomSampler seeds
+    from the torch stream)."""
+    import pickle
+    from masr_amd.io.dataset import capture_rng, restore_rng
+    for ai, a in enumerate(["african", "australia"]):
+        write_toy_shard(tmp_path, a, "train", 16, seed=100 + ai)
+        write_toy_shard(tmp_path, a, "dev", 4, seed=200 + ai)
+    mk = lambda: DataContainer([tmp_path / "african", tmp_path / "australia"], batch_size=4, dev_batch_size=4, is_memmap=True,
+                               is_bucket=is_bucket, min_ilen=10, max_ilen=50, half_batch_ilen=30)
+    random.seed(531); np.random.seed(531); torch.manual_seed(531)
+    dc = mk()
+
+    def draw(c, n):
+        out = []
+        for _ in range(n):
+            for acc, (x, il, ys, ol) in c.get_item(None, 1) + c.get_item(1, 2):
+                out.append((int(acc), il.tolist(), [y.tolist() for y in ys], round(float(x.sum()), 3)))
+        return out
+    draw(dc, 3)                                                    # somewhere inside the first epoch
+    saved = pickle.loads(pickle.dumps({"data": dc.state_dict(), "rng": capture_rng()}))
+    cnt = dc.reload_cnt
+    after = draw(dc, 12)                                           # rolls over several epochs
+    assert dc.reload_cnt > cnt
+    random.seed(1); np.random.seed(2); torch.manual_seed(3)        # a new process: different streams ...
+    dc2 = mk()                                                     # ... consumed by the construction
+    dc2.load_state_dict(saved["data"])
+    restore_rng(saved["rng"])
+    assert draw(dc2, 12) == after

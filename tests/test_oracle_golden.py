@@ -311,3 +311,29 @@ def test_fomaml_cfg3_oracle_matches_reference(golden_dir, tmp_path, monkeypatch,
             ref = g[f"{pre}step{si}/metagrad/full/{n}"]
             err = np.linalg.norm(mg[n].numpy() - ref) / np.linalg.norm(ref)
             assert err < 2e-4, (si, n, err)
+
+
+def test_radam_restatement_coincides_with_torch_radam_where_the_conventions_agree():
+    """oracle.ref_cpu.radam_torch_optimizer_step restates the un-vendored torch_optimizer.RAdam (parity unpinned against the package).
+    Where its conventions and torch.optim.RAdam's describe the same algorithm -- no weight decay, eps -> 0 -- the two must produce
+    the same trajectory through both the unrectified and the rectified phase; the known differences (eps placement, decay on the
+    weight) must show up when switched on."""
+    import torch
+    from oracle import ref_cpu
+    g = torch.Generator().manual_seed(5)
+    n = 257
+    p0 = torch.randn(n, generator=g, dtype=torch.float64)
+    w = torch.nn.Parameter(p0.clone())
+    ref = torch.optim.RAdam([w], lr=1e-2, betas=(0.9, 0.999), eps=1e-30)
+    p = p0.clone()
+    st = {"step": 0, "exp_avg": torch.zeros(n, dtype=torch.float64), "exp_avg_sq": torch.zeros(n, dtype=torch.float64)}
+    for t in range(12):
+        gr = torch.randn(n, generator=g, dtype=torch.float64)
+        w.grad = gr.clone(); ref.step()
+        ref_cpu.radam_torch_optimizer_step(p, gr, st, lr=1e-2, eps=1e-30)
+        torch.testing.assert_close(p, w.detach(), rtol=1e-9, atol=1e-12, msg=f"step {t + 1}")
+    q = p0.clone()
+    st2 = {"step": 0, "exp_avg": torch.zeros(n, dtype=torch.float64), "exp_avg_sq": torch.zeros(n, dtype=torch.float64)}
+    ref_cpu.radam_torch_optimizer_step(q, torch.ones(n, dtype=torch.float64), st2, lr=1e-2, weight_decay=0.5)
+    # decay on the weight: p * (1 - lr * wd) - lr * g / (1 - b1) * (1 - b1)  (unrectified first step: exp_avg / bias correction = g)
+    torch.testing.assert_close(q, p0 * (1 - 1e-2 * 0.5) - 1e-2, rtol=1e-12, atol=1e-14)

@@ -101,13 +101,21 @@ def get_cpu_trainer(cls, config, paras, id2accent, log):
             super().load_model()
 
         def _make_slots(self):
-            self._slots = None
+            """task slots as the product makes them (replica + engine per slot), without HIP streams"""
+            if self.tasks_per_gpu == 1:
+                self._slots = None
+                return
+            models = [self.asr_model]
+            for _ in range(self.tasks_per_gpu - 1):
+                e = CpuEngine(log)
+                models.append(SimpleNamespace(engine=e, train=lambda: None, eval=lambda: None, load_state_dict=e.load_state_dict))
+            self._slots = [{'model': m, 'engine': m.engine, 'stream': None} for m in models]
 
         def exec(self):
             self.train()
 
         def run_batch(self, cur_b, x, ilens, ys, olens, train, accent_idx=None, engine=None, want_info=True):
-            eng = self.asr_model.engine
+            eng = engine if engine is not None else self.asr_model.engine
             eng.run_batch(x, ilens, ys, olens, train)
             olens += 1
             st = eng.read_stats()
@@ -122,8 +130,9 @@ def get_cpu_trainer(cls, config, paras, id2accent, log):
             self.asr_opt.step()
 
         def clip_grad_norm_(self, max_norm, engine=None):
-            self.asr_model.engine.clip_grads(max_norm)
-            return self.asr_model.engine.read_stats()['grad_norm']
+            eng = engine if engine is not None else self.asr_model.engine
+            eng.clip_grads(max_norm)
+            return eng.read_stats()['grad_norm']
 
     return CpuTrainer(config, paras, id2accent)
 
@@ -141,7 +150,7 @@ def make_workspace(root):
 
 
 def run(root, algo, world, rank, fix_snapshot=False, meta_batch=3, steps=5, accents=("af", "au", "en", "us"), meta_k=2, fix_reptile=False,
-        deferred=False, log_ival=1, eval_ival=2, save_ival=2):
+        deferred=False, log_ival=1, eval_ival=2, save_ival=2, tasks_per_gpu=1, is_bucket=True):
     os.chdir(root)
     model = {"d_model": 64}
     if algo in ("fomaml", "reptile"):
@@ -155,8 +164,8 @@ def run(root, algo, world, rank, fix_snapshot=False, meta_batch=3, steps=5, acce
                       "min_ilen": 10, "max_ilen": 50, "dev_max_ilen": 3000, "half_batch_ilen": 30}}
     paras = SimpleNamespace(pretrain_suffix=f"w{world}", pretrain_accents=list(accents), num_pretrain=len(accents), tgt_accent="ca", runs=0,
                             overwrite=True, seed=531, meta_k=meta_k, meta_batch_size=meta_batch, sample_strategy="normal", max_step=steps,
-                            resume=False, model_name="transformer", algo=algo, njobs=2 if world > 1 else 0, is_bucket=True, is_memmap=True,
-                            use_tensorboard=False, fix_snapshot_meta_weights=fix_snapshot, tasks_per_gpu=1, fix_reptile=fix_reptile)
+                            resume=False, model_name="transformer", algo=algo, njobs=2 if world > 1 else 0, is_bucket=is_bucket, is_memmap=True,
+                            use_tensorboard=False, fix_snapshot_meta_weights=fix_snapshot, tasks_per_gpu=tasks_per_gpu, fix_reptile=fix_reptile)
     random.seed(531); np.random.seed(531); torch.manual_seed(531)
     if algo in ("fomaml", "reptile"):
         from masr_amd.fo_meta_interface import FOMetaASRInterface as Iface
@@ -183,13 +192,16 @@ def run(root, algo, world, rank, fix_snapshot=False, meta_batch=3, steps=5, acce
                     return {'loss': st['loss'], 'acc': 0.5}, st['grad_norm']
             return H()
         solver.clip_stats_async = clip_stats_async
+    n_reduces = []
+    plain_reduce = solver.sharder.reduce_async
+    solver.sharder.reduce_async = lambda buf, **k: (n_reduces.append(solver.global_step), plain_reduce(buf, **k))[1]
     solver.load_data()
     solver.set_model()
     solver.exec()
     weights = solver._original.clone() if algo in ("fomaml", "reptile") else solver.asr_model.engine.params.clone()
     files = sorted(p.name for p in solver.log_dir.iterdir()) if rank == 0 else []
     dev_log = (solver.log_dir / "dev_avg_wer").read_text() if rank == 0 and (solver.log_dir / "dev_avg_wer").exists() else ""
-    return {"weights": weights, "train_fps": [fp for tr, fp in log if tr], "files": files, "dev_avg_wer": dev_log,
+    return {"n_reduces": n_reduces, "tasks_per_gpu": getattr(solver, "tasks_per_gpu", 1), "weights": weights, "train_fps": [fp for tr, fp in log if tr], "files": files, "dev_avg_wer": dev_log,
             "global_step": solver.global_step, "train_info": {k: float(v) for k, v in solver.train_info.items()}, "booked": booked,
             "train_loss_log": (solver.log_dir / "train_loss").read_text() if rank == 0 and (solver.log_dir / "train_loss").exists() else ""}
 
@@ -297,3 +309,39 @@ def test_eight_accents_one_task_per_rank_on_eight_ranks(workspace, algo, meta_k)
     n_meta = len(single["train_fps"]) // (8 * per_step)              # (the loop runs whole eval_ival rounds: 4 meta-steps)
     assert n_meta == 4 and all(len(r["train_fps"]) == n_meta * per_step for r in ranks)
     assert sorted(fp for r in ranks for fp in r["train_fps"]) == sorted(single["train_fps"])
+
+
+@pytest.mark.parametrize("algo,meta_batch,K,waves", [("fomaml", 4, 2, 1), ("fomaml", 7, 2, 2), ("fomaml", 7, 3, 2), ("reptile", 7, 3, 2)])
+def test_task_slots_on_two_ranks_issue_one_allreduce_per_wave(workspace, algo, meta_batch, K, waves):
+    """--tasks_per_gpu K on several ranks: the K task gradients of a wave are summed on the rank and go out as ONE all-reduce
+    (K times less traffic than one per task; what bench.py's meta_step.concurrent_slots leg times).  Every rank issues the same
+    number of all-reduces per meta-step -- the waves of the busiest rank, ranks with fewer waves pad with zeros -- and the ranks
+    end with the single-process, one-task-at-a-time meta weights.  meta_batch 7 on 2 ranks: 4 + 3 tasks, i.e. 2 + 2 waves at
+    K = 2 and 2 + 1 (one padded) at K = 3."""
+    kw = dict(meta_batch=meta_batch, steps=4, accents=EIGHT, meta_k=2, fix_reptile=(algo == "reptile"))
+    single = run(workspace, algo, 1, 0, **kw)
+    slots1 = run(workspace, algo, 1, 0, tasks_per_gpu=K, **kw)
+    torch.testing.assert_close(slots1["weights"], single["weights"], rtol=1e-9, atol=1e-11)
+    r0, r1 = _ranks(workspace, algo, world=2, tasks_per_gpu=K, **kw)
+    assert r0["tasks_per_gpu"] == K
+    assert torch.equal(r0["weights"], r1["weights"])
+    torch.testing.assert_close(r0["weights"], single["weights"], rtol=1e-9, atol=1e-11)
+    assert sorted(r0["train_fps"] + r1["train_fps"]) == sorted(single["train_fps"])
+    for r in (r0, r1):
+        per_step = [r["n_reduces"].count(st) for st in sorted(set(r["n_reduces"]))]
+        assert per_step == [waves] * 4, per_step
+
+
+
+@pytest.mark.parametrize("fix_snapshot", [False, True])
+def test_no_bucket_loaders_stay_rank_consistent_across_evaluations(workspace, fix_snapshot):
+    """--no_bucket: the train loaders' RandomSampler reads the TORCH default stream, and so does every dev iterator evaluate()
+    creates (base seed).  Ranks that skip an accent's evaluation take the same draws, otherwise an accent that lands on another rank
+    after an evaluation would be served a different permutation there: with 6 meta-steps and an evaluation every 2, the two ranks
+    together must still consume exactly the single-process batch list and end on its meta weights."""
+    kw = dict(steps=7, is_bucket=False, meta_batch=3)
+    single = run(workspace, "fomaml", 1, 0, fix_snapshot, **kw)
+    r0, r1 = _ranks(workspace, "fomaml", fix_snapshot, 2, **kw)
+    assert torch.equal(r0["weights"], r1["weights"])
+    assert sorted(r0["train_fps"] + r1["train_fps"]) == sorted(single["train_fps"])
+    torch.testing.assert_close(r0["weights"], single["weights"], rtol=1e-9, atol=1e-11)
