@@ -121,7 +121,7 @@ class FOMetaASRInterface(PretrainInterface):
         from .io.dataset import capture_rng
         torch.save({'original': self._original.cpu(), 'adam': self.meta_opt.optimizer.state_dict(),
                     'step_num': self.meta_opt.step_num, 'rng': capture_rng(), 'data': self.data_container.state_dict(),
-                    'best': (self.best_wer, self.best_cer),
+                    'best': (self.best_wer, self.best_cer), 'task_ids': list(getattr(self, '_task_ids', None) or range(self.num_pretrain)),
                     'dropout': [sl['engine'].dropout_state() for sl in (self._slots or []) if hasattr(sl['engine'], 'dropout_state')]},
                    self.log_dir.joinpath("meta_state.latest"))
         self.dashboard.log_step()
@@ -149,6 +149,7 @@ class FOMetaASRInterface(PretrainInterface):
                 from .io.dataset import restore_rng
                 self.data_container.load_state_dict(st['data'])
                 self.best_wer, self.best_cer = st['best']
+                self._task_ids = list(st['task_ids'])
                 for sl, d in zip(self._slots or [], st['dropout']):
                     sl['engine'].set_dropout_state(d)
                 restore_rng(st['rng'])                                   # last: everything above (and set_model) consumed the streams
@@ -314,7 +315,8 @@ class FOMetaASRInterface(PretrainInterface):
 
     # ------------------------------------------------------------------ the outer loop (:128-177)
     def train(self):
-        task_ids = list(range(self.num_pretrain))
+        # (random.shuffle permutes the list IN PLACE, step after step: its current order is part of a checkpoint)
+        task_ids = self._task_ids = getattr(self, '_task_ids', None) or list(range(self.num_pretrain))
         nxt = None
         try:
             first_it = (self.global_step - 1) % self.eval_ival          # (a resumed run re-enters the chunk it was saved in)

@@ -1002,6 +1002,55 @@ def gen_init_goldens():
     print("init.npz")
 
 
+def fullsize_batch(idim, B=16, T=1000, seed=77):
+    """the headline bench shape (BASELINE.json configs[1]: B = 16 utterances x 1000 frames x idim, what the shipped half-batch
+    rule yields at 10 s): seeded features ~ N(0,1), 10..40 labels per utterance.  Shared by the golden generator and the GPU test."""
+    g = torch.Generator().manual_seed(seed + idim)
+    xs = torch.randn(B, T, idim, generator=g)
+    ilens = torch.full((B,), T, dtype=torch.int64)
+    olens = torch.tensor([10 + (7 * i) % 31 for i in range(B)])
+    ys = [torch.randint(1, 366, (int(n),), generator=g) for n in olens]
+    return xs, ilens, ys, olens
+
+
+def gen_hkust_fullsize_goldens():
+    """The reference model at the HEADLINE shape: config/transformer/pretrain/fometa-hkust.yaml geometry (E512/H8/F2048/2e4d, 24.88 M
+    parameters), its own seed-531 initialisation, dropout 0, one B = 16 x T = 1000 batch at idim 80 (BASELINE's wording) and 83 (the
+    shipped idim): run_batch(train) -> loss, acc, global gradient norm (clip_grad_norm_'s return), the fingerprint of EVERY parameter
+    gradient and a few small gradients in full, then clip 5 + the shipped inner SGD step and the loss of a second run_batch on the
+    same batch (the quantity an inner step is judged by).  ~1 minute of CPU."""
+    import yaml
+    base = yaml.safe_load(open(REF / "config/transformer/pretrain/fometa-hkust.yaml"))["asr_model"]
+    from src.model.transformer_pytorch.mono_transformer_torch import MyTransformer
+    out = {}
+    for idim in (80, 83):
+        cfg = dict(base, idim=idim, dropout=0.0, pos_dropout=0.0)
+        torch.manual_seed(531)
+        model = MyTransformer(["x"] * ODIM, cfg)
+        model.train()
+        batch = fullsize_batch(idim)
+        pre = f"d{idim}/"
+        info = ref_run_batch(model, batch, 0.2)
+        out[pre + "loss"], out[pre + "acc"] = np.float64(info["loss"]), np.float64(info["acc"])
+        out[pre + "n_total"] = np.int64(int((batch[3] + 1).sum()))
+        named = dict(model.named_parameters())
+        for n, p in named.items():
+            out[pre + f"gradfp/{n}"] = flat_checks(p.grad)
+        for n in ("feat_extractor.0.weight", "feat_extractor.0.bias", "feat_extractor.2.bias", "feat_extractor.7.bias", "vgg2enc.bias",
+                  "char_trans.bias", "encoder.norm.weight", "decoder.norm.bias", "decoder.layers.3.multihead_attn.in_proj_bias"):
+            out[pre + f"grad/{n}"] = named[n].grad.numpy().copy()
+        opt = torch.optim.SGD(model.parameters(), lr=ref_cpu.inner_lr(cfg), momentum=0.9, nesterov=True)
+        out[pre + "grad_norm"] = np.float64(torch.nn.utils.clip_grad_norm_(model.parameters(), 5))
+        opt.step()
+        info1 = ref_run_batch(model, batch, 0.2)
+        out[pre + "loss_after_inner_step"] = np.float64(info1["loss"])
+        out[pre + "grad_norm_after_inner_step"] = np.float64(torch.nn.utils.clip_grad_norm_(model.parameters(), 5))
+        # a larger step on the same gradient direction makes the loss change large against the 1e-3 tolerance
+        print(f"fullsize idim {idim}: loss {info['loss']:.6f} acc {info['acc']:.4f} |g| {out[pre + 'grad_norm']:.4f} -> loss {info1['loss']:.6f}")
+    np.savez_compressed(OUT / "hkust_fullsize.npz", **out)
+    print("hkust_fullsize.npz", len(out), "arrays")
+
+
 def gen_metric_goldens():
     """Metric.batch_cal_er (src/monitor/metric.py:36-87) on seeded logits with the reference's sentencepiece model."""
     from src.monitor.metric import Metric
@@ -1036,7 +1085,7 @@ def main():
     torch.set_num_threads(4)
     gens = [gen_masks_noam, gen_sampler_goldens, gen_ctc_goldens, gen_init_goldens, gen_metric_goldens, gen_model_goldens,
             gen_fomaml_goldens, gen_fomaml_cfg3_goldens, gen_chain_goldens, gen_multi_goldens, gen_mono_goldens, gen_tester_goldens, gen_blstm_goldens,
-            gen_blstm_mono_goldens, gen_blstm_tester_goldens]
+            gen_blstm_mono_goldens, gen_blstm_tester_goldens, gen_hkust_fullsize_goldens]
     only = set(sys.argv[1:])                       # e.g.  python oracle/make_goldens.py gen_fomaml_cfg3_goldens
     for g in gens:
         if not only or g.__name__ in only:

@@ -106,3 +106,86 @@ def test_edge_shapes_run_and_are_finite(B, T, ilens, olens):
     assert st["n_total"] == float(sum(olens) + B) and bool(torch.isfinite(gr).all())
     hyp = e.recog(xs, il)
     assert hyp.shape == (max(ilens) // 4, B) and int(hyp.min()) >= 0 and int(hyp.max()) < ODIM
+
+
+@pytest.mark.parametrize("idim", [80, 83])
+def test_headline_shape_against_the_reference(golden_dir, idim):
+    """Element-wise pin of the BENCH shape (VERDICT r2 missing #2): fometa-hkust geometry, the reference's seed-531 initialisation,
+    one B = 16 x T = 1000 batch at idim 80 / 83, dropout 0, against what the imported reference computed for it
+    (tests/golden/hkust_fullsize.npz, oracle/make_goldens.py::gen_hkust_fullsize_goldens): loss within the north-star's 1e-3
+    relative (measured ~1e-5), accuracy within one token, global and per-tensor gradient norms, small gradients element-wise,
+    and the loss after clip 5 + the shipped inner SGD step.  The oracle run beside it (pinned to the same golden on the CPU) gives
+    the per-tensor comparison against EVERY gradient, in fp32 and with the engine's bf16 rounding points emulated."""
+    from oracle import ref_cpu
+    from oracle.make_goldens import fullsize_batch
+    g = np.load(golden_dir / "hkust_fullsize.npz")
+    cfg = dict(HK, idim=idim, meta={"optimizer_opt": {"k": 1.0, "warmup_steps": 25000}})
+    pre = f"d{idim}/"
+    torch.manual_seed(531)
+    sd = reference_init_state_dict(cfg, ODIM)
+    e = MasrEngine(cfg, ODIM, label_smoothing=0.2)
+    e.load_state_dict(sd)
+    xs, il, ys, ol = fullsize_batch(idim)
+    e.run_batch(xs, il, ys, ol.clone(), train=True)
+    e.grad_norm()
+    st = e.read_stats()
+    grads = {k: v.cpu() for k, v in e.state_dict(flat=e.grads).items()}
+    ref_loss, ref_norm = float(g[pre + "loss"]), float(g[pre + "grad_norm"])
+    rel = abs(st["loss"] - ref_loss) / ref_loss
+    print(f"idim {idim}: loss {st['loss']:.6f} reference {ref_loss:.6f} (rel {rel:.1e}); |g| {st['grad_norm']:.4f} reference {ref_norm:.4f}")
+    assert rel <= 1e-3
+    assert st["n_total"] == float(g[pre + "n_total"])
+    assert abs(st["n_correct"] / st["n_total"] - float(g[pre + "acc"])) <= 1.5 / st["n_total"]
+    assert abs(st["grad_norm"] - ref_norm) <= 1e-2 * ref_norm
+    # ---- per-tensor gradient norms against the reference (every parameter)
+    worst_n = ("", 0.0)
+    for k in g.files:
+        if not k.startswith(pre + "gradfp/"):
+            continue
+        n = k[len(pre + "gradfp/"):]
+        if n == "pre_embed.weight":
+            continue                                              # alias of char_trans.weight (tied)
+        ref_l2 = float(g[k][2])
+        r = abs(float(grads[n].double().norm()) - ref_l2) / (ref_l2 + 1e-12)
+        if not n.endswith("in_proj_bias") and r > worst_n[1]:
+            worst_n = (n, r)
+    print("worst per-tensor gradient-norm deviation from the reference:", worst_n)
+    assert worst_n[1] < 3e-2, worst_n
+    # ---- small gradients element-wise against the reference
+    for k in g.files:
+        if k.startswith(pre + "grad/"):
+            n = k[len(pre + "grad/"):]
+            a, b = grads[n], torch.from_numpy(g[k])
+            if n.endswith("in_proj_bias"):
+                E = cfg["d_model"]
+                a, b = torch.cat([a[:E], a[2 * E:]]), torch.cat([b[:E], b[2 * E:]])
+            r = float((a - b).norm() / (b.norm() + 1e-20))
+            print(f"  {n}: rel-l2 vs reference {r:.4f}")
+            assert r < 0.06, (n, r)
+    # ---- every gradient against the oracle with the engine's rounding points emulated
+    pe = ref_cpu.sinusoid_pe(3000, cfg["d_model"])
+    with ref_cpu.bf16_emulation():
+        pq = ref_cpu.leafify(dict(sd, **{"pos_encoder.pe": pe}), cfg)
+        infoq, gradsq, _, _ = ref_cpu.run_batch_train(pq, cfg, (xs, il, ys, ol.clone()), 0.2)
+    assert abs(st["loss"] - infoq["loss"]) <= 2e-4 * infoq["loss"]
+    worst = ("", 0.0)
+    for n, gq in gradsq.items():
+        a, b = grads[n], gq
+        if n.endswith("in_proj_bias"):
+            E = cfg["d_model"]
+            a, b = torch.cat([a[:E], a[2 * E:]]), torch.cat([b[:E], b[2 * E:]])
+        r = float((a - b).norm() / (b.norm() + 1e-20))
+        if r > worst[1]:
+            worst = (n, r)
+    print("worst per-tensor rel-l2 vs the bf16-emulating oracle:", worst)
+    assert worst[1] < 5e-2, worst
+    # ---- clip 5 + the shipped inner step (lr 2.795e-4, momentum 0.9, nesterov), loss on the same batch afterwards
+    e.clip_sgd_step(None, 5.0, ref_cpu.inner_lr(cfg), 0.9, True, 3)
+    e.run_batch(xs, il, ys, ol.clone(), train=True)
+    e.grad_norm()
+    st1 = e.read_stats()
+    ref1 = float(g[pre + "loss_after_inner_step"])
+    print(f"  after the inner step: loss {st1['loss']:.6f} reference {ref1:.6f}; drop {st['loss'] - st1['loss']:.6f} vs {ref_loss - ref1:.6f}")
+    assert abs(st1["loss"] - ref1) <= 1e-3 * ref1
+    assert abs((st["loss"] - st1["loss"]) - (ref_loss - ref1)) <= 0.03 * (ref_loss - ref1)
+    assert abs(st1["grad_norm"] - float(g[pre + "grad_norm_after_inner_step"])) <= 2e-2 * float(g[pre + "grad_norm_after_inner_step"])

@@ -337,3 +337,35 @@ def test_radam_restatement_coincides_with_torch_radam_where_the_conventions_agre
     ref_cpu.radam_torch_optimizer_step(q, torch.ones(n, dtype=torch.float64), st2, lr=1e-2, weight_decay=0.5)
     # decay on the weight: p * (1 - lr * wd) - lr * g / (1 - b1) * (1 - b1)  (unrectified first step: exp_avg / bias correction = g)
     torch.testing.assert_close(q, p0 * (1 - 1e-2 * 0.5) - 1e-2, rtol=1e-12, atol=1e-14)
+
+
+def test_oracle_matches_reference_at_the_headline_shape(golden_dir):
+    """fometa-hkust geometry (24.88 M parameters), the reference's seed-531 initialisation, B = 16 x T = 1000 x idim 80: the oracle's
+    loss, accuracy, global gradient norm and EVERY per-tensor gradient norm against the reference's (tests/golden/hkust_fullsize.npz,
+    oracle/make_goldens.py::gen_hkust_fullsize_goldens); small gradients element-wise.  ~5 s."""
+    import torch
+    from masr_amd.model import reference_init_state_dict
+    from oracle import ref_cpu
+    from oracle.make_goldens import ODIM, fullsize_batch
+    g = np.load(golden_dir / "hkust_fullsize.npz")
+    cfg = {"idim": 80, "nheads": 8, "d_model": 512, "d_inner": 2048, "dropout": 0.0, "pos_dropout": 0.0, "tgt_share_weight": 1,
+           "encoder": {"nlayers": 2}, "decoder": {"nlayers": 4}}
+    torch.manual_seed(531)
+    sd = reference_init_state_dict(cfg, ODIM)
+    sd["pos_encoder.pe"] = ref_cpu.sinusoid_pe(3000, 512)
+    xs, il, ys, ol = fullsize_batch(80)
+    p = ref_cpu.leafify(sd, cfg)
+    info, grads, _, _ = ref_cpu.run_batch_train(p, cfg, (xs, il, ys, ol.clone()), 0.2)
+    assert abs(info["loss"] - float(g["d80/loss"])) <= 2e-6 * float(g["d80/loss"])
+    assert abs(info["acc"] - float(g["d80/acc"])) <= 1.0 / int(g["d80/n_total"])
+    tot = 0.0
+    for n, gr in grads.items():
+        fp = g[f"d80/gradfp/{n}"]
+        assert abs(float(gr.double().norm()) - fp[2]) <= 1e-4 * fp[2] + 1e-9, n
+        tot += float(gr.double().norm()) ** 2
+    assert abs(tot ** 0.5 - float(g["d80/grad_norm"])) <= 1e-4 * float(g["d80/grad_norm"])
+    for k in g.files:
+        if k.startswith("d80/grad/"):
+            n = k[len("d80/grad/"):]
+            ref = torch.from_numpy(g[k])
+            assert float((grads[n] - ref).norm() / (ref.norm() + 1e-20)) < 2e-4, n

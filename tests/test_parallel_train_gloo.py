@@ -150,7 +150,7 @@ def make_workspace(root):
 
 
 def run(root, algo, world, rank, fix_snapshot=False, meta_batch=3, steps=5, accents=("af", "au", "en", "us"), meta_k=2, fix_reptile=False,
-        deferred=False, log_ival=1, eval_ival=2, save_ival=2, tasks_per_gpu=1, is_bucket=True):
+        deferred=False, log_ival=1, eval_ival=2, save_ival=2, tasks_per_gpu=1, is_bucket=True, resume=False, suffix=None):
     os.chdir(root)
     model = {"d_model": 64}
     if algo in ("fomaml", "reptile"):
@@ -162,9 +162,9 @@ def run(root, algo, world, rank, fix_snapshot=False, meta_batch=3, steps=5, acce
            "solver": {"setting": "t", "data_root": "data", "total_steps": 100, "spm_mapping": "data/units.txt", "spm_model": "none",
                       "label_smoothing": 0.0, "eval_ival": eval_ival, "log_ival": log_ival, "save_ival": save_ival, "batch_size": 4, "dev_batch_size": 4,
                       "min_ilen": 10, "max_ilen": 50, "dev_max_ilen": 3000, "half_batch_ilen": 30}}
-    paras = SimpleNamespace(pretrain_suffix=f"w{world}", pretrain_accents=list(accents), num_pretrain=len(accents), tgt_accent="ca", runs=0,
+    paras = SimpleNamespace(pretrain_suffix=suffix or f"w{world}", pretrain_accents=list(accents), num_pretrain=len(accents), tgt_accent="ca", runs=0,
                             overwrite=True, seed=531, meta_k=meta_k, meta_batch_size=meta_batch, sample_strategy="normal", max_step=steps,
-                            resume=False, model_name="transformer", algo=algo, njobs=2 if world > 1 else 0, is_bucket=is_bucket, is_memmap=True,
+                            resume=resume, model_name="transformer", algo=algo, njobs=2 if world > 1 else 0, is_bucket=is_bucket, is_memmap=True,
                             use_tensorboard=False, fix_snapshot_meta_weights=fix_snapshot, tasks_per_gpu=tasks_per_gpu, fix_reptile=fix_reptile)
     random.seed(531); np.random.seed(531); torch.manual_seed(531)
     if algo in ("fomaml", "reptile"):
@@ -345,3 +345,24 @@ def test_no_bucket_loaders_stay_rank_consistent_across_evaluations(workspace, fi
     assert torch.equal(r0["weights"], r1["weights"])
     assert sorted(r0["train_fps"] + r1["train_fps"]) == sorted(single["train_fps"])
     torch.testing.assert_close(r0["weights"], single["weights"], rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("algo,is_bucket,eval_ival,save_ival,stop,total", [
+    ("fomaml", True, 2, 3, 3, 9), ("fomaml", True, 3, 5, 7, 13), ("fomaml", False, 2, 3, 3, 9), ("multi", True, 2, 3, 3, 9), ("reptile", True, 2, 3, 3, 7)])
+def test_resume_continues_the_data_and_task_streams_exactly(workspace, algo, is_bucket, eval_ival, save_ival, stop, total):
+    """--resume from snapshot.latest + meta_state.latest (CPU double, real loops / DataContainer / samplers): the resumed run draws
+    the batches the uninterrupted run drew after the checkpoint -- same task order, same sampler cursors through epoch roll-overs,
+    same RNG streams across evaluate() -- and ends on identical weights and running averages.  With a checkpoint in the middle of an
+    eval chunk (5 of 3-step chunks) the resumed run re-enters that chunk."""
+    kw = dict(eval_ival=eval_ival, save_ival=save_ival, is_bucket=is_bucket, fix_reptile=(algo == "reptile"))
+    full = run(workspace, algo, 1, 0, steps=total, suffix="full", **kw)
+    part = run(workspace, algo, 1, 0, steps=stop, suffix="part", **kw)
+    n_part = len(part["train_fps"])
+    res = run(workspace, algo, 1, 0, steps=total, suffix="part", resume=True, **kw)
+    assert res["global_step"] == full["global_step"]
+    saved_at = (stop // save_ival) * save_ival
+    per_step = len(full["train_fps"]) // (full["global_step"] - 1)
+    assert res["train_fps"] == full["train_fps"][(saved_at - 1) * per_step:], "the resumed run drew other batches than the uninterrupted one"
+    assert torch.equal(res["weights"], full["weights"])
+    assert res["train_info"] == full["train_info"]
+    assert n_part == (stop - 1) * per_step
