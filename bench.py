@@ -92,6 +92,16 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("MASR_CPU_THREADS", "16"))))
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(cfg, B, T, D, steps=6):
     """The oracle's inner step (fp32 torch on the host cores) on a bounded sample of the same workload."""
     from oracle import ref_cpu
@@ -111,7 +121,7 @@ def cpu_baseline(cfg, B, T, D, steps=6):
         ref_cpu.inner_step(p, c, (batch[0], batch[1], batch[2], batch[3].clone()), 0.2, bufs, lr)
         log("cpu step done")
     dt = time.perf_counter() - t0
-    return {"value": B * steps / dt, "unit": "utt/s", "cores": n, "kind": "port",
+    return {"value": B * steps / dt, "unit": "utt/s", "cores": n, "cpu_model": cpu_model(), "kind": "port",
             "sample": f"{steps} timed + 1 warm-up inner steps, B={B} x T={T} x D={D}, same model/config, fp32 torch CPU oracle, dropout 0"}
 
 
@@ -127,8 +137,10 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16, help="utterances per step of the CPU baseline leg (same B as the GPU leg by default)")
     ap.add_argument("--cpu-steps", type=int, default=6)
-    ap.add_argument("--long-seconds", type=float, default=2.0, help="also time a region of at least this many seconds (\"long_run\"); 0 = skip")
-    ap.add_argument("--mixed", action="store_true", help="also time a mixed-length leg (ilens ~ U{200..1500}), reported as \"mixed_lengths\"")
+    ap.add_argument("--long-seconds", type=float, default=6.0, help="also time a region of at least this many seconds (\"long_run\"); 0 = skip")
+    ap.add_argument("--mixed", action="store_true", help="(default now) time the mixed-length leg (ilens ~ U{200..1500}), reported as \"mixed_lengths\"")
+    ap.add_argument("--no-mixed", action="store_true", help="skip the mixed-length leg")
+    ap.add_argument("--no-matrix", action="store_true", help="skip the SURVEY 8(d) matrix legs (idim 83, B 32, the 4e2d / E256 geometry), reported as \"matrix\"")
     ap.add_argument("--no-stagger", action="store_true", help="start all concurrent tasks at the same instant (lock-step)")
     ap.add_argument("--no-meta-step", action="store_true", help="skip the whole-meta-step leg (\"meta_step\" in the output)")
     ap.add_argument("--meta-rounds", type=int, default=2, help="task rounds per rank in the meta-step leg (>= 2 shows the all-reduce overlap)")
@@ -204,7 +216,7 @@ def main():
     sd0 = reference_init_state_dict(cfg, ODIM)                   # random-init weights exactly as the reference draws them
 
     class Task:                                                  # one accent-task slot: replica + stream + resident batch
-        def __init__(self, k):
+        def __init__(self, k, cfg=cfg, sd0=sd0, B=B, T=T, D=D):
             self.eng = MasrEngine(cfg, ODIM, label_smoothing=0.2, device=dev)
             self.eng.load_state_dict(sd0)
             self.eng.set_seed(531 + rank * 64 + k)
@@ -294,7 +306,7 @@ def main():
     # utterances of a batch share one length (what the reference's BucketSampler yields) and the half-batch rule applies
     # above 512 frames (B/1 or B*2 utterances, batch_size 32 of the shipped configs = 2 * B here)
     mixed = None
-    if args.mixed:
+    if not args.no_mixed:
         rng = np.random.RandomState(1234 + rank)
         pools = []
         for t in tasks:
@@ -323,6 +335,27 @@ def main():
         log(f"mixed lengths: {mixed['value']:.1f} utt/s, {mixed['frames_per_s'] / 1e6:.2f} M frames/s")
         for t in tasks:
             del t.step                                           # back to the fixed-shape step of the class
+
+    # ---- SURVEY 8(d) matrix: the same K-task measurement at the shipped idim 83, at B = 32 (the reference's full-batch rule below 512
+    # frames; not the headline shape) and on the 4e2d / E256 / H4 geometry -- one number each, short regions
+    matrix = None
+    if not args.no_matrix:
+        matrix = {}
+        nmx = max(6, args.steps // 3)
+        for name, over, Bm, Dm in (("idim83", {}, B, 83), ("batch32", {}, 2 * B, D),
+                                   ("geometry_4e2d_E256", {"d_model": 256, "nheads": 4, "encoder": {"nlayers": 4}, "decoder": {"nlayers": 2}}, B, D)):
+            c2 = dict(cfg, idim=Dm, **over)
+            torch.manual_seed(531)
+            sdm = reference_init_state_dict(c2, ODIM)
+            tm = [Task(k, c2, sdm, Bm, T, Dm) for k in range(K)]
+            for t_, t0_ in zip(tm, tasks):
+                t_.stream = t0_.stream
+            dtm_ = timed(tm, nmx, 3, stagger)
+            matrix[name] = {"value": world * K * Bm * nmx / dtm_, "unit": "utt/s", "ms_per_step": dtm_ / nmx * 1e3, "steps": nmx, "batch_per_task": Bm,
+                            "idim": Dm, "tasks_per_gpu": K, **({"model": over} if over else {})}
+            log(f"matrix {name}: {matrix[name]['value']:.1f} utt/s")
+            del tm
+            torch.cuda.empty_cache()
 
     def step(i):
         tasks[0].step()
@@ -519,6 +552,28 @@ def main():
             t_ = per_class[c_]["ms_per_step"] * 1e-3
             per_class[c_].update({"algorithmic_gflop_per_step": g_, "tflops": g_ / 1e3 / t_, "frac_of_bf16_peak": g_ / 1e3 / t_ / PEAK_BF16_TFLOPS})
         per_class["other"]["note"] = "HBM-bound passes: LayerNorm, pools, loss/embedding, grad-norm + clip + SGD (24 B/param), operand shadows"
+        # the HBM-bound class against the HBM roofline: ALGORITHMIC bytes of each pass (what it must read + write once) over its measured time
+        NP = eng.numel
+        E_, Tp_ = cfg["d_model"], T // 4
+        rows_e, rows_d = B * Tp_, B * Lmax
+        n_ln_e, n_ln_d = 2 * cfg["encoder"]["nlayers"] + 1, 3 * cfg["decoder"]["nlayers"] + 1
+        ln_elems = (n_ln_e * rows_e + n_ln_d * rows_d) * E_
+        hbm_bytes = {
+            "optim": NP * (4 + 20),              # grad-norm reads g; clip + SGD reads p, g, momentum and writes p, momentum
+            "shadows": NP * (4 + 2 + 2),         # fp32 weights in, bf16 operand + its transpose out
+            "layernorm": ln_elems * (10 + 14),   # fwd: x in, y fp32 + bf16 out; bwd: dy + x in, dx fp32 + bf16 out
+            "pool": B * (H2 * W2 * 64 * 3 + T * D * 64 * 2 + (H2 // 2) * (W2 // 2) * 128 * 3 + H2 * W2 * 128 * 2),   # pooled gradient + codes in, dense map out
+            "conv1_fwd": B * T * D * (4 + 64 * 2),   # fp32 input in, 64-channel bf16 map out
+        }
+        t_hbm = sum(prof_all[k][0] for k in hbm_bytes) / nprof * 1e-3
+        b_hbm = float(sum(hbm_bytes.values()))
+        per_class["other"].update({
+            "bytes_per_step": b_hbm, "achieved_TBps": b_hbm / t_hbm / 1e12, "frac_of_8TBps": b_hbm / t_hbm / 8e12,
+            "passes": {k: {"algorithmic_bytes": v, "ms_per_step": prof_all[k][0] / nprof, "TBps": v / (prof_all[k][0] / nprof * 1e-3) / 1e12}
+                       for k, v in hbm_bytes.items()},
+            "bytes_note": "algorithmic bytes per step of the passes listed under `passes` (each tensor read / written once) over their event-timed "
+                          "duration; conv1_fwd (HBM-bound, listed with the conv class above) is included here, the `misc` slot (loss, embedding, "
+                          "casts, split-K combine: ~0.1 ms of small launches) is not"})
         tot_ms = sum(v["ms_per_step"] for v in per_class.values())
         roof["per_class"] = per_class
         roof["single_task_step"] = {"kernel_ms": tot_ms, "algorithmic_gflop": sum(gf.values()),
@@ -542,6 +597,7 @@ def main():
             "long_run": long_run,
             "rccl_ranks": world if (dist is not None and backend == "nccl") else 0,
             "mixed_lengths": mixed,
+            "matrix": matrix,
             "loss": st["loss"], "grad_norm": st["grad_norm"],
         }
         if roof:
