@@ -1539,6 +1539,290 @@ __global__ __launch_bounds__(320) void conv3x3_resw_w1_kernel(ConvArgs a, int nt
     }
 }
 
+// 16 x 16-pixel tiles for the same launch (VERDICT r2 next #1a).  The 8 x 16 kernel above pays 0.75 LDS fragment reads per MFMA (two
+// pixel fragments against four weight fragments per half-tap); 16 x 16 pays 0.5, like the forward kernel -- but two 41 KiB patches and
+// the 72 KiB filter bank leave 6 KiB of the CU's 160 KiB, not the 45 KiB the epilogue's staging took.  So:
+//   * the masked bf16 tile [256 pixels][64 + 8 channels] (36 KiB) is staged in the patch buffer the tile has just CONSUMED (no wave
+//     reads patch k after barrier k); a third barrier per tile (E3, in place of the old "tap image built" one) keeps the patch
+//     wave from refilling that buffer before the contraction has read it;
+//   * the tap image of the 1-channel network input ([9 taps][256 pixels] bf16, 4.6 KiB, kappa-ordered for frag_rm) is built by the
+//     PATCH wave -- idle between its DMA issue and the hand-over barrier -- from the fp32 neighbourhood that travels with the patch
+//     (one 4-pixel group per lane: three 8-byte reads and three 8-byte writes per tap row), while the MFMA waves run the tap loop:
+//     the MFMA waves' epilogue, every instruction of which is on the critical path, loses the 16 + 16 LDS accesses per lane and one
+//     barrier; the row of ones (bias gradient) is a register constant.
+template <bool PROF = false>
+__global__ __launch_bounds__(320) void conv3x3_resw_w1x_kernel(ConvArgs a, int ntiles, int tiles_x, int tiles_y, int chunk) {
+    constexpr int CIN = 64, COUT = 64, TH = 16, TW = 16;
+    constexpr int PW = TW + 2, PH = TH + 2, RPT = 16 / TW;
+    constexpr int MF = TH * TW / 64, NF = COUT / 16, NH = NF / 2;
+    constexpr int KTOT = 9 * CIN;
+    constexpr int PPIECES = (PH * PW + 7) / 8;             // 1 KiB DMA pieces per patch (8 pixels x 128 B)
+    constexpr int PBYTES = PPIECES * 1024, WBYTES = COUT * 128;
+    constexpr int OS = COUT + 8;                           // row stride of the masked bf16 tile [pixel][channel] (frag_rm reads)
+    constexpr int NPIX = TH * TW, XS = NPIX + 8;           // tap-major input image [9 taps][XS]
+    constexpr int XT_BYTES = 9 * XS * 2, XP_FLOATS = (PH * PW + 7) / 8 * 8;
+    static_assert(NPIX * OS * 2 <= PBYTES, "the masked tile must fit into a consumed patch buffer");
+    static_assert(2 * PBYTES + 9 * WBYTES + XT_BYTES + XP_FLOATS * 4 + 16 <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(1024))) char lds[2 * PBYTES + 9 * WBYTES + XT_BYTES + XP_FLOATS * 4 + 16];
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    typedef __attribute__((ext_vector_type(2))) short short2_t;
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    char* const pbuf = lds;
+    char* const wres = lds + 2 * PBYTES;
+    bf16* const sxt = reinterpret_cast<bf16*>(wres + 9 * WBYTES);
+    float* const sxp = reinterpret_cast<float*>(wres + 9 * WBYTES + XT_BYTES);
+    int* const tileq = reinterpret_cast<int*>(wres + 9 * WBYTES + XT_BYTES + XP_FLOATS * 4);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int H = a.H, W = a.W;
+    auto read_tileq = [&](int k) { return __builtin_amdgcn_readfirstlane(*(volatile int*)&tileq[k & 3]); };
+
+    {   // the filter bank: 72 pieces of 8 rows, dealt round-robin to the 5 waves
+        const int sub = lane >> 3, sl = lane & 7;
+#pragma unroll
+        for (int n = 0; n < (72 + 4) / 5; ++n) {
+            const int pc = n * 5 + wave;
+            if (pc < 72) {
+                const int tap = pc >> 3, i = pc & 7;
+                const int r = i * 8 + sub, j = r >> 4, m = r & 15;
+                const int co = (j >> 1) * 32 + (m >> 2) * 8 + (j & 1) * 4 + (m & 3);
+                const bf16* src = a.wk + (long)co * KTOT + tap * CIN + ((sl ^ (r & 7)) * 8);
+                __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(wres + pc * 1024), 16, 0, 0);
+            }
+        }
+    }
+
+    if (wave == 4) {
+        // ---------------- patch stream + tap image; barrier k hands patch k+1 and tap image k over, E3 frees patch k's buffer
+        const int sub = lane >> 3, sl = lane & 7;
+        int rel[PPIECES], pij[PPIECES];
+#pragma unroll
+        for (int i = 0; i < PPIECES; ++i) {
+            int p = i * 8 + sub;
+            if (p >= PH * PW) p = PH * PW - 1;
+            const int pi = p / PW, pj = p % PW;
+            rel[i] = ((pi - 1) * W + (pj - 1)) * CIN + (sl ^ (pj & 7)) * 8;
+            pij[i] = pi << 8 | pj;
+        }
+        const bf16* zsrc = g_zero_line + sl * 8;
+        const float* zx = reinterpret_cast<const float*>(g_zero_line);
+        auto issue_patch = [&](int tile, int g) {
+            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+            const int d0 = tx * TW, t0 = ty * TH;
+            {   // the (TH+2) x 18 neighbourhood of the 1-channel network input (4-byte LDS-DMA, zeros outside the image), ONE buffer:
+                // issued after the tap image of the running tile has been built from the previous content
+                const float* x_b = a.x1 + (long)b * H * W;
+#pragma unroll
+                for (int i = 0; i < (PH * PW + 63) / 64; ++i) {
+                    const int e = i * 64 + lane, pi = e / PW, pj = e % PW;
+                    const int t = t0 + pi - 1, d = d0 + pj - 1;
+                    const float* src = (t >= 0 && t < H && d >= 0 && d < W) ? x_b + (long)t * W + d : zx;
+                    if (e < PH * PW) __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(sxp + i * 64), 4, 0, 0);
+                }
+            }
+            const bf16* org = a.in + ((long)b * H * W + (long)t0 * W + d0) * CIN;
+            const bool interior = t0 >= 1 && t0 + TH + 1 <= H && d0 >= 1 && d0 + TW + 1 <= W;
+            char* dst = pbuf + (g & 1) * PBYTES;
+            if (interior) {
+#pragma unroll
+                for (int i = 0; i < PPIECES; ++i)
+                    __builtin_amdgcn_global_load_lds((gptr_t*)(org + rel[i]), (lptr_t*)(dst + i * 1024), 16, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < PPIECES; ++i) {
+                    const int t = t0 + (pij[i] >> 8) - 1, d = d0 + (pij[i] & 255) - 1;
+                    const bf16* src = (t >= 0 && t < H && d >= 0 && d < W) ? org + rel[i] : zsrc;
+                    __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(dst + i * 1024), 16, 0, 0);
+                }
+            }
+        };
+        // tap image of the tile whose neighbourhood sits in sxp: lane = pixel row pr, columns 4c .. 4c+3.  Column kappa(pixel) of the
+        // image undoes the k-permutation of frag_rm (MFMA k index 8g+j <-> slab row 4g+j for j < 4, 16+4g+(j-4) for j >= 4): the four
+        // pixels of a group are four CONSECUTIVE columns.  Pixels beyond the image edge need no masking: their dY rows are zero.
+        const int gpr = lane >> 2, gc = lane & 3;
+        const int xt_off = (gpr >> 1) * 32 + 8 * gc + 4 * (gpr & 1);
+        auto build_tap_image = [&]() {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const f32x2* row = reinterpret_cast<const f32x2*>(sxp + (gpr + dy) * PW + 4 * gc);
+                const f32x2 v0 = row[0], v1 = row[1], v2 = row[2];
+                const float w[6] = {v0[0], v0[1], v1[0], v1[1], v2[0], v2[1]};
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    bf16x4 o;
+                    o[0] = (bf16)w[dx]; o[1] = (bf16)w[dx + 1]; o[2] = (bf16)w[dx + 2]; o[3] = (bf16)w[dx + 3];
+                    *reinterpret_cast<bf16x4*>(sxt + (dy * 3 + dx) * XS + xt_off) = o;
+                }
+            }
+        };
+        bool dry = false;
+        // Tiles are dealt by a STATIC stride (workgroup w: tiles w, w + G, ...), not by the tile counter: the wave-level partial sums
+        // run over all tiles of a workgroup, so the assignment fixes the summation order -- the gradient is bit-reproducible.
+        unsigned own = blockIdx.x;
+        const unsigned lim = (unsigned)ntiles;
+        auto issue_fetch = [&]() -> unsigned { const unsigned t = own; own += gridDim.x; return t; };
+        int cur, nxt;
+        {
+            const unsigned t0f = issue_fetch(), t1f = issue_fetch();
+            cur = t0f < lim ? (int)t0f : -1;
+            nxt = t1f < lim ? (int)t1f : -1;
+            if (nxt < 0) dry = true;
+        }
+        if (lane == 0) { tileq[0] = cur; tileq[1] = nxt; }
+        if (cur >= 0) issue_patch(cur, 0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");           // opening barrier: weights (every wave's share), patch 0, tileq[0..1]
+        for (int k = 0; cur >= 0; ++k) {
+            // tile k is being computed: its tap image first (frees sxp), then tile k+1's patch + neighbourhood, publish, hand over
+            const unsigned raw = issue_fetch();
+            build_tap_image();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (nxt >= 0) issue_patch(nxt, k + 1);
+            int nn = -1;
+            if (!dry) {
+                if (raw >= lim) dry = true; else nn = (int)raw;
+            }
+            if (lane == 0) tileq[(k + 2) & 3] = nn;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");       // barrier k (middle of tile k's last tap)
+            asm volatile("s_barrier" ::: "memory");       // E1: the masked tile is staged (in patch k's buffer)
+            asm volatile("s_barrier" ::: "memory");       // E3: contraction done -- patch k's buffer and the tap image are free again
+            cur = nxt; nxt = nn;
+        }
+        return;
+    }
+
+    // ---------------- MFMA waves
+    const int rr = lane & 15, q = lane >> 4;
+    const int pcol0 = rr % TW, prow0 = wave * MF * RPT + rr / TW;
+    int poff[3][2], woff[2];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+        woff[kc] = rr * 128 + (((kc * 4 + q) ^ (rr & 7)) * 16);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) poff[dx][kc] = (prow0 * PW + pcol0 + dx) * 128 + (((kc * 4 + q) ^ ((pcol0 + dx) & 7)) * 16);
+    }
+    struct Frags { bf16x8 a[MF], b[NF]; };
+    typedef __attribute__((address_space(3))) const char lds_cchar;
+    const unsigned wbase = (unsigned)(size_t)((lds_cchar*)wres);
+    f32x4 acc[MF][NF];
+    // half_tap: MF*NF MFMAs on `use`, the reads of `ld` issued in their shadow (see the streaming kernel)
+    auto half_tap = [&](const Frags& use, Frags& ld, const char* pl, int tap, int kc) {
+        const int dy = tap / 3, dx = tap % 3;
+        const unsigned pa = (unsigned)(size_t)((lds_cchar*)pl) + poff[dx][kc];
+        const unsigned wa = wbase + woff[kc] + tap * WBYTES;   // (the DS offset field is 16 bits: the tap's 8 KiB stride goes here)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MF * NF; ++m) {
+            const int i = m / NF, j = m % NF;
+            acc[i][j] = mma16(use.b[j], use.a[i], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (m < MF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ld.a[m < MF ? m : 0]) : "v"(pa), "n"(((m < MF ? m : 0) * RPT + dy) * PW * 128));
+            else if (m < MF + NF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ld.b[m < MF + NF ? m - MF : 0]) : "v"(wa), "n"((m < MF + NF ? m - MF : 0) * 2048));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    Frags f0, f1;
+    f32x4 cw = {0.f, 0.f, 0.f, 0.f};                    // conv1 weight-gradient partial of this wave over all its tiles
+    const int wtap = lane & 15;
+    bf16x8 cfrag;                                         // B fragment of the rows that are not in LDS: tap 9 = ones (bias gradient), 10.. = zeros
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cfrag[e] = (bf16)(wtap == 9 ? 1.f : 0.f);
+    const bf16* const xt_row = sxt + (wtap < 9 ? wtap : 8) * XS + q * 8;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of the weights
+    asm volatile("s_barrier" ::: "memory");               // opening barrier
+    int tile = read_tileq(0);
+    {   // fragments of (tap 0, first k-half)
+        const unsigned pa = (unsigned)(size_t)((lds_cchar*)pbuf) + poff[0][0];
+        const unsigned wa = wbase + woff[0];
+#pragma unroll
+        for (int i = 0; i < MF; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f0.a[i]) : "v"(pa), "n"(i * RPT * PW * 128));
+#pragma unroll
+        for (int j = 0; j < NF; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f0.b[j]) : "v"(wa), "n"(j * 2048));
+    }
+    for (int k = 0; tile >= 0; ++k) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int d0 = tx * TW, t0 = ty * TH;
+        const int tl = t0 + prow0, dl = d0 + pcol0;
+        const unsigned voff = (unsigned)((tl * W + dl) * COUT + q * 8) * 2u;
+        const char* mask_b = reinterpret_cast<const char*>(a.mask) + (long)b * H * W * COUT * 2;
+        auto row_ok = [&](int i) { return tl + i * RPT < H && dl < W; };
+        auto row_off = [&](int i) { return voff + (unsigned)(i * RPT) * (unsigned)(W * COUT * 2); };
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        char* const pcur = pbuf + (k & 1) * PBYTES;
+        const char* pnext = pbuf + ((k + 1) & 1) * PBYTES;
+        u32x4 mk[MF][NH];                                 // ReLU mask of this lane's outputs, requested three taps before use
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap == 6) {
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) {
+                        const u32x4 z = {0u, 0u, 0u, 0u};
+                        mk[i][h] = row_ok(i) ? *reinterpret_cast<const u32x4*>(mask_b + row_off(i) + h * 64) : z;
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            half_tap(f0, f1, pcur, tap, 1);
+            if (tap < 8) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                half_tap(f1, f0, pcur, tap + 1, 0);
+            } else {
+                // barrier k: the next tile's patch, this tile's tap image and tileq[k+1..k+2] are in; no wave reads patch k again
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                half_tap(f1, f0, pnext, 0, 0);            // (after the last tile: stale LDS, never used)
+            }
+        }
+        tile = read_tileq(k + 1);
+
+        // epilogue: the masked bf16 tile (zeros outside the image) goes into the consumed patch buffer and is contracted there with
+        // the tap image: [64 channels] x [9 taps + ones] over the tile's 256 pixels, on the MFMA
+        bf16* const otile = reinterpret_cast<bf16*>(pcur);
+        const short2_t zero2 = {0, 0}, one2 = {1, 1};
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const bool ok = row_ok(i);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                u32x4 ov;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const f32x4& c = acc[i][2 * h + (kk >> 1)];
+                    unsigned r;
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(c[2 * (kk & 1)]), "v"(c[2 * (kk & 1) + 1]));
+                    const unsigned mw = mk[i][h][kk];       // (bit_cast straight from a vector element reads element 0: clang 22)
+                    short2_t m = __builtin_bit_cast(short2_t, mw);
+                    m = __builtin_elementwise_min(__builtin_elementwise_max(m, zero2), one2);   // 1 where mask > 0
+                    const short2_t pk = __builtin_bit_cast(short2_t, r) & (zero2 - m);
+                    ov[kk] = ok ? __builtin_bit_cast(unsigned, pk) : 0u;
+                }
+                *reinterpret_cast<u32x4*>(otile + ((wave * MF + i) * 16 + rr) * OS + h * 32 + q * 8) = ov;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // E1
+        // wave w: output channels 16w .. 16w+15 x 16 taps, contraction over the tile's pixels (slabs of 32)
+#pragma unroll
+        for (int sl = 0; sl < NPIX / 32; ++sl) {
+            const bf16x8 af = frag_rm<OS>(otile + sl * 32 * OS, wave * 16, lane);
+            const bf16x8 xb = ld8(xt_row + sl * 32);
+            cw = mma16(af, wtap < 9 ? xb : cfrag, cw);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // E3
+    }
+    if ((lane & 15) < 10) {                                // one row of 640 partial sums per workgroup (mk_conv1_wgrad_fused_reduce)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.w1_slab[(long)blockIdx.x * 640 + (wave * 16 + 4 * (lane >> 4) + r) * 10 + (lane & 15)] = cw[r];
+    }
+}
+
 // ------------------------------------------------------------------ wgrad (reduction over pixels)
 
 template <int CIN, int COUT>
@@ -2057,8 +2341,10 @@ static bool use_resw_w1() {
                            !(getenv("MASR_CONV_RESW_W1") && atoi(getenv("MASR_CONV_RESW_W1")) == 0);
     return on;
 }
+static bool w1_th8() { static const bool v = getenv("MASR_CONV_W1_TH8") != nullptr; return v; }     // the 8 x 16-tile kernel, for A/B runs
 static int resw_w1_rows(int B, int H, int W) {
-    const long ntiles = (long)B * ((H + 7) / 8) * ((W + 15) / 16);
+    const int th = w1_th8() ? 8 : 16;
+    const long ntiles = (long)B * ((H + th - 1) / th) * ((W + 15) / 16);
     return (int)(ntiles < conv_ncu() ? ntiles : conv_ncu());
 }
 long mk_conv1_wgrad_fused_slab_floats(int B, int H, int W) {
@@ -2078,14 +2364,16 @@ static int stream_chunk() {
     return c;
 }
 static void launch_resw_w1(const ConvArgs& a, hipStream_t s) {
-    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 7) / 8, ntiles = tiles_x * tiles_y * a.B;
+    const int th = w1_th8() ? 8 : 16;
+    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + th - 1) / th, ntiles = tiles_x * tiles_y * a.B;
     ConvArgs b = a;
     if (!b.sched) {
         static unsigned* fallback = nullptr;
         if (!fallback) hipGetSymbolAddress((void**)&fallback, HIP_SYMBOL(g_conv_sched));
         b.sched = fallback;
     }
-    hipLaunchKernelGGL((conv3x3_resw_w1_kernel<false>), dim3((unsigned)resw_w1_rows(a.B, a.H, a.W)), dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, 0);
+    if (w1_th8()) hipLaunchKernelGGL((conv3x3_resw_w1_kernel<false>), dim3((unsigned)resw_w1_rows(a.B, a.H, a.W)), dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, 0);
+    else hipLaunchKernelGGL((conv3x3_resw_w1x_kernel<false>), dim3((unsigned)resw_w1_rows(a.B, a.H, a.W)), dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, 0);
 }
 template <bool PROF = false>
 static void launch_resw(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
