@@ -49,9 +49,16 @@ __device__ __forceinline__ s16x2 lane_xor1(s16x2 v) { return __builtin_bit_cast(
 __device__ __forceinline__ s16x2 lane_xor8(s16x2 v) { return __builtin_bit_cast(s16x2, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false)); }
 
 // ------------------------------------------------------------------ conv1 (CIN = 1), direct fp32
+// bits (optional): the ReLU mask of this map as one 64-bit word per pixel [B][H][W], bit c = (out[..][c] > 0) -- all the masked
+// dgrad of the NEXT conv needs of the map (conv3x3_resw_w1x_kernel, ConvArgs::mask_bits): 8 bytes per pixel instead of 128, and half
+// the vector-memory instructions that launch is bound by.  Here it costs ONE more store instruction per 16-pixel segment: a thread
+// owns 8 channels of two pixels, i.e. one byte of each pixel's word; the four bytes of a half-word sit in a quad of lanes and are
+// OR-ed together by two DPP moves; the lanes with (cg & 3) < 2 then store the segment's 32 dwords (128 contiguous bytes).
+// (Tried instead: the patch wave of conv2's forward launch derives the words from the patches it streams -- 32 LDS reads + ~500
+// VALU per tile on a wave that shares its SIMD with an MFMA wave: conv2 forward 93 -> 133 us.)
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, bf16* __restrict__ out,
-                                                        int B, int H, int W, int cstride) {
+                                                        int B, int H, int W, int cstride, unsigned* __restrict__ bits) {
     // one launch = 64 output channels of a map with `cstride` channels (w, bias, out pre-offset by the caller).
     // The launch is bound by vector-memory wave-instructions (~70 cycles each at the CU's one texture addresser; measured:
     // loads + arithmetic 45 us, arithmetic + stores 32 us, everything 66 us with 2 loads + 1 store per 8 pixels), so a wave
@@ -72,6 +79,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     const int wrow = lane / 18, wcol = lane % 18;          // window element this lane loads (lanes 0..53)
     for (int sg = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); sg < total; sg += gstride) {
         const int row = sg / nseg, d0 = (sg - row * nseg) * 16, t = row % H;
+        int part[2] = {0, 0};                              // this thread's sign byte of its two pixels, at its place in the half-word
         float wv = 0.f;
         {
             const int tt = t + wrow - 1, dd = d0 + wcol - 1;
@@ -94,6 +102,28 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
             }
             const int d = d0 + px;
             if (d < W) st8(out + ((long)row * W + d) * cstride + cg * 8, o);
+            if (bits) {                                    // (uniform) per 16-bit half min(max(v, 0), 1) = 1 for a positive, non-zero bf16
+                typedef __attribute__((ext_vector_type(2))) short s2_t;
+                typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
+                const u4_t ov = __builtin_bit_cast(u4_t, o);
+                unsigned e = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned dw = ov[j];             // (copy: bit_cast straight from a vector element reads element 0, clang 22)
+                    const s2_t f = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(s2_t, dw), s2_t{0, 0}), s2_t{1, 1});
+                    e |= __builtin_bit_cast(unsigned, f) << (2 * j);       // flags at bits 2j and 16 + 2j
+                }
+                part[k] = (int)(((e | e >> 15) & 0xFFu) << (8 * (cg & 3)));
+            }
+        }
+        if (bits) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                part[k] |= __builtin_amdgcn_mov_dpp(part[k], 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+                part[k] |= __builtin_amdgcn_mov_dpp(part[k], 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]: the quad's four bytes in every lane
+            }
+            const int kk = cg & 1, px = pg * 2 + kk;        // lanes cg = 0, 1 (channels 0..31) and 4, 5 (32..63) of a pixel pair store
+            if ((cg & 3) < 2 && d0 + px < W) bits[((long)row * W + d0 + px) * 2 + (cg >> 2)] = (unsigned)(kk ? part[1] : part[0]);
         }
     }
 }
@@ -623,7 +653,9 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
     long pt[3] = {0, 0, 0};
     long tprev = PROF ? clock64() : 0;
     auto stamp = [&](int k) { if constexpr (PROF) { const long now = clock64(); pt[k] += now - tprev; tprev = now; } };
-    auto read_tileq = [&](int k) { return __builtin_amdgcn_readfirstlane(*(volatile int*)&tileq[k & 3]); };
+    // (an LDS-qualified volatile read: through a generic `volatile int*` hipcc emits flat_load_dword sc0 sc1 + s_waitcnt vmcnt(0), i.e.
+    // the read queues at the texture addresser behind the patch wave's DMA pieces and waits for all of this wave's stores)
+    auto read_tileq = [&](int k) { return __builtin_amdgcn_readfirstlane(*(volatile __attribute__((address_space(3))) int*)&tileq[k & 3]); };
 
     if (wave == 4) {
         // ---------------- weight stream: slice (slab, tap) = [COUT rows][64 ci], LDS row r holds channel perm(r).
@@ -1002,7 +1034,9 @@ __global__ __launch_bounds__(320) void conv3x3_resw_kernel(ConvArgs a, int ntile
     long pt[3] = {0, 0, 0};
     long tprev = PROF ? clock64() : 0;
     auto stamp = [&](int k) { if constexpr (PROF) { const long now = clock64(); pt[k] += now - tprev; tprev = now; } };
-    auto read_tileq = [&](int k) { return __builtin_amdgcn_readfirstlane(*(volatile int*)&tileq[k & 3]); };
+    // (an LDS-qualified volatile read: through a generic `volatile int*` hipcc emits flat_load_dword sc0 sc1 + s_waitcnt vmcnt(0), i.e.
+    // the read queues at the texture addresser behind the patch wave's DMA pieces and waits for all of this wave's stores)
+    auto read_tileq = [&](int k) { return __builtin_amdgcn_readfirstlane(*(volatile __attribute__((address_space(3))) int*)&tileq[k & 3]); };
 
     {   // the filter bank: 72 pieces of 8 rows, dealt round-robin to the 5 waves
         const int sub = lane >> 3, sl = lane & 7;
@@ -1288,7 +1322,9 @@ __global__ __launch_bounds__(320) void conv3x3_resw_w1_kernel(ConvArgs a, int nt
     long pt[3] = {0, 0, 0};
     long tprev = PROF ? clock64() : 0;
     auto stamp = [&](int k) { if constexpr (PROF) { const long now = clock64(); pt[k] += now - tprev; tprev = now; } };
-    auto read_tileq = [&](int k) { return __builtin_amdgcn_readfirstlane(*(volatile int*)&tileq[k & 3]); };
+    // (an LDS-qualified volatile read: through a generic `volatile int*` hipcc emits flat_load_dword sc0 sc1 + s_waitcnt vmcnt(0), i.e.
+    // the read queues at the texture addresser behind the patch wave's DMA pieces and waits for all of this wave's stores)
+    auto read_tileq = [&](int k) { return __builtin_amdgcn_readfirstlane(*(volatile __attribute__((address_space(3))) int*)&tileq[k & 3]); };
 
     {   // the filter bank: 72 pieces of 8 rows, dealt round-robin to the 5 waves
         const int sub = lane >> 3, sl = lane & 7;
@@ -1550,8 +1586,11 @@ __global__ __launch_bounds__(320) void conv3x3_resw_w1_kernel(ConvArgs a, int nt
 //     (one 4-pixel group per lane: three 8-byte reads and three 8-byte writes per tap row), while the MFMA waves run the tap loop:
 //     the MFMA waves' epilogue, every instruction of which is on the critical path, loses the 16 + 16 LDS accesses per lane and one
 //     barrier; the row of ones (bias gradient) is a register constant.
-template <bool PROF = false>
+// ABL (ablation builds for timing only, MASR_W1_ABL): bit 0 = no epilogue arithmetic (staging + contraction skipped, barriers kept),
+// bit 1 = no mask loads, bits 2.. = tap at which the mask is requested (default 6)
+template <int ABL = 0>
 __global__ __launch_bounds__(320) void conv3x3_resw_w1x_kernel(ConvArgs a, int ntiles, int tiles_x, int tiles_y, int chunk) {
+    constexpr int MASK_TAP = (ABL >> 2) ? (ABL >> 2) - 1 : 0;
     constexpr int CIN = 64, COUT = 64, TH = 16, TW = 16;
     constexpr int PW = TW + 2, PH = TH + 2, RPT = 16 / TW;
     constexpr int MF = TH * TW / 64, NF = COUT / 16, NH = NF / 2;
@@ -1578,7 +1617,9 @@ __global__ __launch_bounds__(320) void conv3x3_resw_w1x_kernel(ConvArgs a, int n
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int H = a.H, W = a.W;
-    auto read_tileq = [&](int k) { return __builtin_amdgcn_readfirstlane(*(volatile int*)&tileq[k & 3]); };
+    // (an LDS-qualified volatile read: through a generic `volatile int*` hipcc emits flat_load_dword sc0 sc1 + s_waitcnt vmcnt(0), i.e.
+    // the read queues at the texture addresser behind the patch wave's DMA pieces and waits for all of this wave's stores)
+    auto read_tileq = [&](int k) { return __builtin_amdgcn_readfirstlane(*(volatile __attribute__((address_space(3))) int*)&tileq[k & 3]); };
 
     {   // the filter bank: 72 pieces of 8 rows, dealt round-robin to the 5 waves
         const int sub = lane >> 3, sl = lane & 7;
@@ -1748,27 +1789,24 @@ __global__ __launch_bounds__(320) void conv3x3_resw_w1x_kernel(ConvArgs a, int n
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
         const int d0 = tx * TW, t0 = ty * TH;
         const int tl = t0 + prow0, dl = d0 + pcol0;
-        const unsigned voff = (unsigned)((tl * W + dl) * COUT + q * 8) * 2u;
-        const char* mask_b = reinterpret_cast<const char*>(a.mask) + (long)b * H * W * COUT * 2;
+        // ReLU mask of conv1's output as one 64-bit word per pixel (bit c = channel c passed; written by conv1's forward
+        // launch, mk_conv1_fwd): this lane's pixel of row i, requested at the first tap -- four 8-byte loads per wave
+        // and tile where the bf16 map itself cost eight 16-byte loads, in a launch that is bound by vector-memory instructions at the
+        // CU's one texture addresser (measured: 122 us with the map, 77 us with no mask at all, 89 us with the words)
+        const uint2* bits_b = reinterpret_cast<const uint2*>(a.mask_bits) + (long)b * H * W + (long)tl * W + dl;
         auto row_ok = [&](int i) { return tl + i * RPT < H && dl < W; };
-        auto row_off = [&](int i) { return voff + (unsigned)(i * RPT) * (unsigned)(W * COUT * 2); };
 #pragma unroll
         for (int i = 0; i < MF; ++i)
 #pragma unroll
             for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         char* const pcur = pbuf + (k & 1) * PBYTES;
         const char* pnext = pbuf + ((k + 1) & 1) * PBYTES;
-        u32x4 mk[MF][NH];                                 // ReLU mask of this lane's outputs, requested three taps before use
+        uint2 mb[MF];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            if (tap == 6) {
+            if (tap == MASK_TAP) {
 #pragma unroll
-                for (int i = 0; i < MF; ++i)
-#pragma unroll
-                    for (int h = 0; h < NH; ++h) {
-                        const u32x4 z = {0u, 0u, 0u, 0u};
-                        mk[i][h] = row_ok(i) ? *reinterpret_cast<const u32x4*>(mask_b + row_off(i) + h * 64) : z;
-                    }
+                for (int i = 0; i < MF; ++i) mb[i] = (row_ok(i) && !(ABL & 2)) ? bits_b[(long)i * RPT * W] : uint2{0u, 0u};
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             half_tap(f0, f1, pcur, tap, 1);
@@ -1786,35 +1824,36 @@ __global__ __launch_bounds__(320) void conv3x3_resw_w1x_kernel(ConvArgs a, int n
         // epilogue: the masked bf16 tile (zeros outside the image) goes into the consumed patch buffer and is contracted there with
         // the tap image: [64 channels] x [9 taps + ones] over the tile's 256 pixels, on the MFMA
         bf16* const otile = reinterpret_cast<bf16*>(pcur);
-        const short2_t zero2 = {0, 0}, one2 = {1, 1};
+        if constexpr (!(ABL & 1)) {
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
-            const bool ok = row_ok(i);
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
                 u32x4 ov;
+                // byte q of the word's half h = this lane's 8 channels; bits 2kk, 2kk+1 -> the two halves of a packed pair
+                const int byte = (int)((h ? mb[i].y : mb[i].x) >> (8 * q));
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const f32x4& c = acc[i][2 * h + (kk >> 1)];
                     unsigned r;
                     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(c[2 * (kk & 1)]), "v"(c[2 * (kk & 1) + 1]));
-                    const unsigned mw = mk[i][h][kk];       // (bit_cast straight from a vector element reads element 0: clang 22)
-                    short2_t m = __builtin_bit_cast(short2_t, mw);
-                    m = __builtin_elementwise_min(__builtin_elementwise_max(m, zero2), one2);   // 1 where mask > 0
-                    const short2_t pk = __builtin_bit_cast(short2_t, r) & (zero2 - m);
-                    ov[kk] = ok ? __builtin_bit_cast(unsigned, pk) : 0u;
+                    const unsigned lo = (unsigned)__builtin_amdgcn_sbfe(byte, 2 * kk, 1), hi = (unsigned)__builtin_amdgcn_sbfe(byte, 2 * kk + 1, 1);
+                    ov[kk] = r & ((lo & 0xFFFFu) | (hi & 0xFFFF0000u));      // (rows outside the image: their word is 0)
                 }
                 *reinterpret_cast<u32x4*>(otile + ((wave * MF + i) * 16 + rr) * OS + h * 32 + q * 8) = ov;
             }
         }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // E1
         // wave w: output channels 16w .. 16w+15 x 16 taps, contraction over the tile's pixels (slabs of 32)
+        if constexpr (!(ABL & 1)) {
 #pragma unroll
         for (int sl = 0; sl < NPIX / 32; ++sl) {
             const bf16x8 af = frag_rm<OS>(otile + sl * 32 * OS, wave * 16, lane);
             const bf16x8 xb = ld8(xt_row + sl * 32);
             cw = mma16(af, wtap < 9 ? xb : cfrag, cw);
         }
+        } else { cw[0] += acc[0][0][0] + acc[1][1][1] + acc[2][2][2] + acc[3][3][3] + __builtin_bit_cast(float, mb[0].x ^ mb[1].y ^ mb[2].x ^ mb[3].y); }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // E3
     }
     if ((lane & 15) < 10) {                                // one row of 640 partial sums per workgroup (mk_conv1_wgrad_fused_reduce)
@@ -2294,10 +2333,10 @@ static long conv1_grid(int B, int H, int W) {
     const long blocks = ((long)B * H * ((W + 15) / 16) + 3) / 4;
     return blocks < 2048 ? blocks : 2048;
 }
-int mk_conv1_fwd(const float* x, const float* w, const float* bias, bf16* out, int B, int H, int W, hipStream_t s) {
+int mk_conv1_fwd(const float* x, const float* w, const float* bias, bf16* out, int B, int H, int W, hipStream_t s, unsigned long long* relu_bits) {
     const long P = (long)B * H * W;
     if (P >= (1L << 31) - 65536) { mk_set_error("mk_conv1_fwd", "map too large"); return -1; }
-    hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)conv1_grid(B, H, W)), dim3(256), 0, s, x, w, bias, out, B, H, W, 64);
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)conv1_grid(B, H, W)), dim3(256), 0, s, x, w, bias, out, B, H, W, 64, reinterpret_cast<unsigned*>(relu_bits));
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 long mk_conv1_wgrad_slab_floats(int B, int H, int W) { return (((long)B * H * W + C1_PIX - 1) / C1_PIX + C1_RSPLIT) * 640; }
@@ -2315,7 +2354,7 @@ int mk_conv1_fwd_n(const float* x, const float* w, const float* bias, bf16* out,
     const long P = (long)B * H * W;
     if (P >= (1L << 31) - 65536) { mk_set_error("mk_conv1_fwd_n", "map too large"); return -1; }
     for (int c0 = 0; c0 < COUT; c0 += 64)
-        hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)conv1_grid(B, H, W)), dim3(256), 0, s, x, w + c0 * 9, bias + c0, out + c0, B, H, W, COUT);
+        hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)conv1_grid(B, H, W)), dim3(256), 0, s, x, w + c0 * 9, bias + c0, out + c0, B, H, W, COUT, (unsigned*)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int mk_conv1_wgrad_n(const float* x, const bf16* dy, float* dw, float* db, float* slab, int B, int H, int W, int COUT, hipStream_t s) {
@@ -2341,7 +2380,7 @@ static bool use_resw_w1() {
                            !(getenv("MASR_CONV_RESW_W1") && atoi(getenv("MASR_CONV_RESW_W1")) == 0);
     return on;
 }
-static bool w1_th8() { static const bool v = getenv("MASR_CONV_W1_TH8") != nullptr; return v; }     // the 8 x 16-tile kernel, for A/B runs
+static bool w1_th8() { static const bool v = getenv("MASR_CONV_W1_TH8") != nullptr; return v; }     // the 8 x 16-tile kernel (reads the bf16 map as its mask), for A/B runs
 static int resw_w1_rows(int B, int H, int W) {
     const int th = w1_th8() ? 8 : 16;
     const long ntiles = (long)B * ((H + th - 1) / th) * ((W + 15) / 16);
@@ -2372,8 +2411,20 @@ static void launch_resw_w1(const ConvArgs& a, hipStream_t s) {
         if (!fallback) hipGetSymbolAddress((void**)&fallback, HIP_SYMBOL(g_conv_sched));
         b.sched = fallback;
     }
+    if (!w1_th8() && !a.mask_bits) { mk_set_error("mk_conv3x3", "fused conv1 wgrad (16 x 16 tiles) needs ConvArgs::mask_bits"); return; }
     if (w1_th8()) hipLaunchKernelGGL((conv3x3_resw_w1_kernel<false>), dim3((unsigned)resw_w1_rows(a.B, a.H, a.W)), dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, 0);
-    else hipLaunchKernelGGL((conv3x3_resw_w1x_kernel<false>), dim3((unsigned)resw_w1_rows(a.B, a.H, a.W)), dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, 0);
+    else {
+        static const int abl = getenv("MASR_W1_ABL") ? atoi(getenv("MASR_W1_ABL")) : 0;
+        const dim3 g((unsigned)resw_w1_rows(a.B, a.H, a.W));
+        switch (abl) {
+            case 1: hipLaunchKernelGGL((conv3x3_resw_w1x_kernel<1>), g, dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, 0); break;
+            case 2: hipLaunchKernelGGL((conv3x3_resw_w1x_kernel<2>), g, dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, 0); break;
+            case 3: hipLaunchKernelGGL((conv3x3_resw_w1x_kernel<3>), g, dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, 0); break;
+            case 4: hipLaunchKernelGGL((conv3x3_resw_w1x_kernel<4>), g, dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, 0); break;      // mask at tap 0
+            case 12: hipLaunchKernelGGL((conv3x3_resw_w1x_kernel<12>), g, dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, 0); break;    // mask at tap 2
+            default: hipLaunchKernelGGL((conv3x3_resw_w1x_kernel<0>), g, dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, 0);
+        }
+    }
 }
 template <bool PROF = false>
 static void launch_resw(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {

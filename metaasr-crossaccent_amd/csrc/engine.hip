@@ -52,6 +52,7 @@ struct Acts {
     uint32_t* meta;                                        // [8] behind enc_lens, same upload: [0] dropout seed of the step, [1] 1/n_total (float bits)
     bf16* step_qkv;                                        // incremental decode: the newest position's q|k|v [B][3E]
     bf16 *a1, *a2, *p1, *a3, *a4, *p2;
+    unsigned long long* a1_bits;                           // ReLU mask of a1, one word per pixel (written by conv1's forward, read by conv2's fused dgrad)
     uint8_t *i1, *i2;                                  // ConvArgs::pool_idx of the two pools (a2 / a4 are only written by conv kernels that cannot emit them)
     std::vector<float*> x32; std::vector<bf16*> x16;        // encoder layer inputs/outputs [NE+1]
     std::vector<EncAct> enc;
@@ -197,6 +198,7 @@ void plan_acts(const masr_model* m, Arena& ar, Acts& a, int B, int T, int L, boo
     a.step_qkv = ar.get<bf16>((int64_t)B * 3 * E);
     const int64_t P1 = (int64_t)B * T * m->D, P2 = (int64_t)B * a.H2 * a.W2;
     a.a1 = ar.get<bf16>(P1 * 64); a.a2 = ar.get<bf16>(P1 * 64); a.p1 = ar.get<bf16>(P2 * 64);
+    a.a1_bits = ar.get<unsigned long long>(P1);
     a.a3 = ar.get<bf16>(P2 * 128); a.a4 = ar.get<bf16>(P2 * 128); a.p2 = ar.get<bf16>(re * m->F);
     a.i1 = ar.get<uint8_t>(P2 * 64); a.i2 = ar.get<uint8_t>(re * m->F);
     a.x32.resize(m->NE + 1); a.x16.resize(m->NE + 1); a.enc.resize(m->NE);
@@ -579,7 +581,7 @@ static int forward_encoder(Ctx& c, const float* xs) {
     uint32_t site = 1;
     {
         Prof p(m, MASR_PROF_CONV1_FWD, s);
-        CK(mk_conv1_fwd(xs, P + m->conv[0].w, P + m->conv[0].b, a.a1, B, T, D, s));
+        CK(mk_conv1_fwd(xs, P + m->conv[0].w, P + m->conv[0].b, a.a1, B, T, D, s, c.train ? a.a1_bits : nullptr));
     }
     static const bool fuse_pool = !getenv("MASR_NO_FUSED_POOL");      // MaxPool2d written by the producing conv's epilogue
     // the maps in front of the two pools are needed by nothing but the pool + ReLU backward, and that needs one byte per POOLED
@@ -777,7 +779,7 @@ static int backward(Ctx& c, const float* xs) {
     if (fuse_w1) {
         // d(conv1 output) is consumed only by conv1's weight gradient: contract it inside the dgrad epilogue, never store it
         { Prof p(m, MASR_PROF_CONV2_DGRAD, s);
-          ConvArgs ca{}; ca.sched = m->conv_sched; ca.in = a.da2; ca.wk = m->conv[1].d16; ca.mask = a.a1; ca.out = a.da1; ca.B = B; ca.H = a.T; ca.W = a.D;
+          ConvArgs ca{}; ca.sched = m->conv_sched; ca.in = a.da2; ca.wk = m->conv[1].d16; ca.mask = a.a1; ca.mask_bits = a.a1_bits; ca.out = a.da1; ca.B = B; ca.H = a.T; ca.W = a.D;
           ca.CIN = 64; ca.COUT = 64; ca.x1 = xs; ca.w1_slab = a.slab;
           CK(mk_conv3x3(ca, s)); }
         { Prof p(m, MASR_PROF_CONV1_WGRAD, s); CK(mk_conv1_wgrad_fused_reduce(a.slab, B, a.T, a.D, G + m->conv[0].w, G + m->conv[0].b, s)); }

@@ -41,13 +41,17 @@ inline GemmArgs gemm_args() { GemmArgs g{}; g.alpha = 1.f; g.mask_scale = 1.f; r
 
 // ---------------------------------------------------------------- conv front-end (conv.hip)
 // activations NHWC bf16: [B][H][W][C]; x input fp32 [B][H][W] (C=1)
-int mk_conv1_fwd(const float* x, const float* w /*[64][9]*/, const float* bias, bf16* out, int B, int H, int W, hipStream_t s);
+// relu_bits (optional): [B][H][W] 64-bit words, bit c = (out[..][c] > 0) -- ConvArgs::mask_bits of the next conv's fused dgrad
+int mk_conv1_fwd(const float* x, const float* w /*[64][9]*/, const float* bias, bf16* out, int B, int H, int W, hipStream_t s, unsigned long long* relu_bits = nullptr);
 int mk_conv1_wgrad(const float* x, const bf16* dy, float* dw /*[64][9]*/, float* db, float* slab, int B, int H, int W, hipStream_t s);
 long mk_conv1_wgrad_slab_floats(int B, int H, int W);
 // implicit-GEMM 3x3 pad 1: out[p][co] = epi( sum_{tap,ci} in[p+off(tap)][ci] * wk[co][tap*CIN+ci] )
 struct ConvArgs {
     const bf16* in; const bf16* wk; const float* bias; int relu;
     const bf16* mask;             // optional ReLU mask source (same shape as out): out = mask>0 ? v : 0
+    // the same mask as one 64-bit word per pixel [B][H][W] (bit c = mask[..][c] > 0, written by mk_conv1_fwd): what the
+    // fused-conv1-wgrad dgrad reads instead of the map (16 x 16 tiles)
+    const unsigned long long* mask_bits;
     bf16* out; int B, H, W, CIN, COUT;
     // 64->64 dgrad of the second conv only: fuse the weight gradient of conv1 (x1 = fp32 network input [B][H][W]) into the
     // epilogue; `out` is then never written, w1_slab receives 640 partial sums per workgroup (mk_conv1_wgrad_fused_reduce)
