@@ -509,7 +509,8 @@ def main():
             "conv2_fwd": ("conv3x3_resw_kernel<16,16> (64->64 forward + fused 2x2 max-pool, pooled map + codes out)", c2, B * T * D * 64 * 2 + B * H2 * W2 * 64 * 3),
             "conv3_fwd": ("conv3x3_stream_kernel<64,128> (64->128 forward)", c3, B * H2 * W2 * (64 + 128) * 2),
             "conv4_fwd": ("conv3x3_stream_kernel<128,128> (128->128 forward + fused 2x2 max-pool, pooled map + codes out)", c4, B * H2 * W2 * 128 * 2 + B * (H2 // 2) * (W2 // 2) * 128 * 3),
-            "conv2_dgrad": ("conv3x3_resw_w1_kernel (64<-64 dgrad + fused conv1 weight gradient)", c2, B * T * D * (64 + 64) * 2 + B * T * D * 4),
+            # (reads d(conv2 out), the ReLU mask of conv1's output as one 64-bit word per pixel, the fp32 network input; writes 640 sums per workgroup)
+            "conv2_dgrad": ("conv3x3_resw_w1x_kernel (64<-64 dgrad on 16x16 tiles + fused conv1 weight gradient)", c2, B * T * D * 64 * 2 + B * T * D * (8 + 4)),
             "conv3_dgrad": ("conv3x3_stream_kernel<128,64> (64<-128 dgrad)", c3, B * H2 * W2 * (128 + 64) * 2),
             "conv4_dgrad": ("conv3x3_stream_kernel<128,128,mask> (128<-128 dgrad through the ReLU mask)", c4, B * H2 * W2 * 384 * 2),
             "conv2_wgrad": ("conv3x3_wgrad2_kernel<64,64>", c2, 2 * B * T * D * 64 * 2),
@@ -563,7 +564,7 @@ def main():
             "shadows": NP * (4 + 2 + 2),         # fp32 weights in, bf16 operand + its transpose out
             "layernorm": ln_elems * (10 + 14),   # fwd: x in, y fp32 + bf16 out; bwd: dy + x in, dx fp32 + bf16 out
             "pool": B * (H2 * W2 * 64 * 3 + T * D * 64 * 2 + (H2 // 2) * (W2 // 2) * 128 * 3 + H2 * W2 * 128 * 2),   # pooled gradient + codes in, dense map out
-            "conv1_fwd": B * T * D * (4 + 64 * 2),   # fp32 input in, 64-channel bf16 map out
+            "conv1_fwd": B * T * D * (4 + 64 * 2 + 8),   # fp32 input in, 64-channel bf16 map + one 64-bit word of ReLU sign bits per pixel out
         }
         t_hbm = sum(prof_all[k][0] for k in hbm_bytes) / nprof * 1e-3
         b_hbm = float(sum(hbm_bytes.values()))

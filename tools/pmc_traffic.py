@@ -17,7 +17,7 @@ SLOTS = {   # bench.py roofline slot -> substring of the kernel name
     "conv2_fwd": "conv3x3_resw_kernel<16, 16, false>",
     "conv3_fwd": "conv3x3_stream_kernel<64, 128, 16, 8, false, false>",
     "conv4_fwd": "conv3x3_stream_kernel<128, 128, 32, 8, false, false>",
-    "conv2_dgrad": "conv3x3_resw_w1_kernel",
+    "conv2_dgrad": "conv3x3_resw_w1x_kernel",
     "conv3_dgrad": "conv3x3_stream_kernel<128, 64, 32, 8, false, false>",
     "conv4_dgrad": "conv3x3_stream_kernel<128, 128, 16, 8, true, false>",
     "conv2_wgrad": "conv3x3_wgrad2_kernel<64, 64,",
@@ -51,7 +51,7 @@ def main():
                       "means over the dispatches of the traced steps",
           "workload": {"batch": 16, "frames": 1000, "idim": 80},
           "collected": f"{tag} @ {sha}",
-          "command": "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --tasks-per-gpu 1",
+          "command": "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --no-matrix --no-mixed --tasks-per-gpu 1",
           "kernels": kernels,
           "raw_KiB": {"FETCH_SIZE": fetch, "WRITE_SIZE": write}}
     Path("profiles/pmc_traffic.json").write_text(json.dumps(js, indent=1) + "\n")
