@@ -467,7 +467,7 @@ def run_batch_eval(p, cfg, batch, eps):
     return {"loss": float(loss), "acc": float(n_correct) / n_total}, logit, gold
 
 
-def reptile_meta_step(meta, cfg, tasks, eps, adam_state, meta_step_num, momentum=0.9, nesterov=True):
+def reptile_meta_step(meta, cfg, tasks, eps, adam_state, meta_step_num, momentum=0.9, nesterov=True, keep=None):
     """Reptile outer step.  NOT in the reference: `--algo reptile` reaches `raise ValueError` in
     fo_meta_interface.py:197-198, so this restates the published algorithm (Nichol et al. 2018, eq. 5) inside
     the reference's loop structure and is "parity unpinned": per task the pseudo-gradient is
@@ -489,6 +489,8 @@ def reptile_meta_step(meta, cfg, tasks, eps, adam_state, meta_step_num, momentum
         infos.append(info)
     for n in names:
         updates[n] /= len(tasks)
+    if keep is not None:
+        keep["meta_grad"] = {n: u.clone() for n, u in updates.items()}          # the pseudo-gradient mean_k (theta_meta - theta_k), before Adam
     o = cfg["meta"]["optimizer_opt"]
     lr = noam_lr(meta_step_num, o["k"], cfg["d_model"], o["warmup_steps"])
     adam_step(meta, updates, adam_state, lr)

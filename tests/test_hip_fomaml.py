@@ -133,23 +133,54 @@ def test_reptile_behind_fix_flag_matches_oracle(tmp_path, monkeypatch):
         rec.append((batch, dict(info)))
         return info
     solver._train = partial(spy, train=True)
+    captured = {}
+    orig_final = solver._final_meta_update
+
+    def final_spy(n_tasks=None):
+        captured["pseudo"] = (solver._updates / solver._counter).cpu()             # mean_k (theta_meta - theta_k), before Adam
+        orig_final(n_tasks)
+    solver._final_meta_update = final_spy
     solver.exec()
     assert len(rec) == 6 and solver.meta_opt.step_num == 1          # 2 tasks x (2 inner + 1 val)
     tasks = [([rec[0][0], rec[1][0]], rec[2][0]), ([rec[3][0], rec[4][0]], rec[5][0])]
     mcfg = cfg["asr_model"]
+    keep = {}
     with ref_cpu.bf16_emulation():
         meta = OrderedDict((k, v.clone()) for k, v in sd0.items())
-        infos, lr = ref_cpu.reptile_meta_step(meta, mcfg, tasks, 0.2, {}, 1)
+        infos, lr = ref_cpu.reptile_meta_step(meta, mcfg, tasks, 0.2, {}, 1, keep=keep)
     assert abs(lr - solver.meta_opt.lr) < 1e-12
     for (b, got), want in zip([rec[2], rec[5]], infos):
-        assert abs(got["loss"] - want["loss"]) < 3e-3 * want["loss"], (got, want)
-    got = solver.asr_model.engine.state_dict(flat=solver._original)
-    # Adam's first step is lr * sign(g): compare the direction of the meta update on tensors with a clear signal
-    for n in ("vgg2enc.bias", "char_trans.bias", "decoder.norm.weight", "encoder.layers.0.linear1.bias"):
-        du = (got[n].cpu() - sd0[n]).double(); dr = (meta[n] - sd0[n]).double()
-        agree = float((torch.sign(du) == torch.sign(dr)).double().mean())
-        print(n, "sign agreement of the reptile update", agree)
-        assert agree > 0.9
+        assert abs(got["loss"] - want["loss"]) < 1e-3 * want["loss"], (got, want)
+    # ---- the pseudo-gradient, EVERY tensor: theta_meta - theta_k is the inner learning rate times the Nesterov sum of two clipped
+    # gradients, so it inherits their agreement with the oracle (the per-tensor bound of the single-batch and config-3 checks)
+    eng = solver.asr_model.engine
+    pseudo = eng.state_dict(flat=captured["pseudo"])
+    worst, E = ("", 0.0), mcfg["d_model"]
+    for n, want in keep["meta_grad"].items():
+        a, b = pseudo[n].cpu(), want
+        if n.endswith("in_proj_bias"):                               # key third: exactly zero true gradient (softmax shift invariance)
+            a, b = torch.cat([a[:E], a[2 * E:]]), torch.cat([b[:E], b[2 * E:]])
+        r = float((a - b).norm() / (b.norm() + 1e-30))
+        if r > worst[1]:
+            worst = (n, r)
+        assert r < 0.10, (n, r)
+    print("reptile pseudo-gradient, worst per-tensor rel-l2 vs the bf16-emulating oracle:", worst)
+    fa = torch.cat([pseudo[n].cpu().reshape(-1) for n in keep["meta_grad"] if not n.endswith("in_proj_bias")]).double()
+    fb = torch.cat([keep["meta_grad"][n].reshape(-1) for n in keep["meta_grad"] if not n.endswith("in_proj_bias")]).double()
+    assert float((fa * fb).sum() / (fa.norm() * fb.norm())) > 0.999
+    assert abs(float(fa.norm()) - float(fb.norm())) < 2e-2 * float(fb.norm())
+    # ---- the meta weights after the Noam-Adam step on it, every tensor: Adam normalises each element's first step to lr * sign(g),
+    # so two runs differ by at most 2 lr per element where the pseudo-gradient's sign differs (elements within noise of zero), + 1 ulp
+    got = eng.state_dict(flat=solver._original)
+    for n in keep["meta_grad"]:
+        d = (got[n].cpu() - meta[n]).abs()
+        assert float(d.max()) <= 2.5 * lr + 1.2e-7 * float(meta[n].abs().max() + 1.0), (n, float(d.max()), lr)
+        if not n.endswith("in_proj_bias"):
+            du, dr = (got[n].cpu() - sd0[n]).double(), (meta[n] - sd0[n]).double()
+            mag = keep["meta_grad"][n].abs()
+            clear = mag > 0.05 * mag.max()                            # elements with a clear pseudo-gradient: the update direction must agree
+            if int(clear.sum()) >= 8:
+                assert float((torch.sign(du[clear]) == torch.sign(dr[clear])).double().mean()) > 0.97, n
 
 
 def test_concurrent_task_slots_reproduce_sequential_run(tmp_path, monkeypatch):
