@@ -198,6 +198,18 @@ int masr_blstm_clip_sgd_step(masr_blstm* m, float* momentum_buf, float max_norm,
 int masr_fbank(const float* wav, const int64_t* wav_off, const int64_t* row_off, int B, int max_frames, int n_mel,
                float* feat, void* stream);
 
+/* The shipped 83-dim rows: n_mel log-mel bins | 3 Kaldi pitch dims (config/transformer/pretrain/fometa-hkust.yaml:13 `idim: 83`,
+ * README.md:24).  The pitch dims follow ESPnet's make_fbank_pitch.sh = compute-kaldi-pitch-feats | process-kaldi-pitch-feats
+ * with Kaldi's default options (4 kHz resampling, NCCF at 417 log-spaced lags between 1/400 s and 1/50 s, Viterbi, then
+ * [2 * pov feature, 2 * POV-normalised log pitch, 10 * delta log pitch]; oracle/pitch_np.py; the dithering noise Kaldi adds to the
+ * delta is omitted).  feat: device [sum T_b][n_mel + 3] with T_b = min(fbank frames, pitch frames of utterance b) -- the pitch
+ * tracker needs (ceil(n_b / 4) - 182) / 40 + 1 frames' worth of samples -- as `paste-feats --length-tolerance=2` truncates them;
+ * row_off from those T_b; max_frames >= max T_b; total_samples = wav_off[B], max_samples = max n_b (host values);
+ * work: masr_fbank_pitch_work_bytes(total_samples, B, max_frames) bytes of device memory. */
+int64_t masr_fbank_pitch_work_bytes(int64_t total_samples, int B, int max_frames);
+int masr_fbank_pitch(const float* wav, const int64_t* wav_off, const int64_t* row_off, int64_t total_samples, int64_t max_samples, int B, int max_frames,
+                     int n_mel, float* feat, void* work, int64_t work_bytes, void* stream);
+
 /* collate_fn zero-padding of CommonVoiceDataset rows (src/io/dataset.py:21-33,147-153) done on the GPU:
  * feat fp32 [sum T_i][D] resident in HBM, row_start int64 [B] (device), lens int32 [B] (device). */
 int masr_gather_pad(const float* feat, const int64_t* row_start, const int32_t* lens, float* xs, int B, int Tmax, int D, void* stream);

@@ -69,6 +69,8 @@ _SIGS = {
     "masr_blstm_clip_grads": (i32, [vp, f32, vp]),
     "masr_blstm_clip_sgd_step": (i32, [vp, vp, f32, f32, f32, i32, i32, vp]),
     "masr_fbank": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
+    "masr_fbank_pitch_work_bytes": (i64, [i64, i32, i32]),
+    "masr_fbank_pitch": (i32, [vp, vp, vp, i64, i64, i32, i32, i32, vp, vp, i64, vp]),
     "masr_gather_pad": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "masr_ctc_work_floats": (i64, [i32, i32, i32]),
     "masr_ctc_loss": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]),

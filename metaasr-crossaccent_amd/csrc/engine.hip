@@ -1137,6 +1137,12 @@ int masr_gather_pad(const float* feat, const int64_t* row_start, const int32_t* 
 int masr_fbank(const float* wav, const int64_t* wav_off, const int64_t* row_off, int B, int max_frames, int n_mel, float* feat, void* stream) {
     return mk_fbank(wav, (const long*)wav_off, (const long*)row_off, B, max_frames, n_mel, feat, (hipStream_t)stream);
 }
+int64_t masr_fbank_pitch_work_bytes(int64_t total_samples, int B, int max_frames) { return mk_pitch_work_bytes(total_samples, B, max_frames); }
+int masr_fbank_pitch(const float* wav, const int64_t* wav_off, const int64_t* row_off, int64_t total_samples, int64_t max_samples, int B, int max_frames,
+                     int n_mel, float* feat, void* work, int64_t work_bytes, void* stream) {
+    if (mk_fbank(wav, (const long*)wav_off, (const long*)row_off, B, max_frames, n_mel, feat, (hipStream_t)stream, 1) != 0) return -1;
+    return mk_pitch(wav, (const long*)wav_off, (const long*)row_off, total_samples, max_samples, B, max_frames, n_mel, feat, work, work_bytes, (hipStream_t)stream);
+}
 int64_t masr_ctc_work_floats(int T, int B, int maxS) { return mk_ctc_work_floats(T, B, maxS); }
 int masr_ctc_loss(const float* logits, const int32_t* targets, const int32_t* tgt_off, const int32_t* in_len, const int32_t* tgt_len, int T,
                   int B, int C, int blank, float* nll, float* loss, float* grad, float* work, int maxS, void* stream) {

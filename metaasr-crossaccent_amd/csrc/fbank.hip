@@ -18,13 +18,18 @@ __device__ __forceinline__ float melf(float f) { return 1127.0f * logf(1.0f + f 
 __device__ __forceinline__ int bitrev9(int x) { return (int)(__brev((unsigned)x) >> 23); }
 
 __global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ wav, const long* __restrict__ wav_off,
-                                                    const long* __restrict__ row_off, float* __restrict__ feat, int n_mel) {
+                                                    const long* __restrict__ row_off, float* __restrict__ feat, int n_mel, int ld, int cap_to_pitch) {
     __shared__ float s_re[NFFT], s_im[NFFT];
     __shared__ float s_twr[NBIN], s_twi[NBIN];
     __shared__ float s_red[4];
     const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long w0 = wav_off[b], n = wav_off[b + 1] - w0;
-    const int T = n < FLEN ? 0 : 1 + (int)((n - FLEN) / FSHIFT);
+    int T = n < FLEN ? 0 : 1 + (int)((n - FLEN) / FSHIFT);
+    if (cap_to_pitch) {                                    // rows shared with the pitch dims: the shorter of the two streams (paste-feats --length-tolerance=2)
+        const long n4 = (n + 3) / 4;
+        const int Tp = n4 < 182 ? 0 : (int)((n4 - 182) / 40) + 1;
+        T = Tp < T ? Tp : T;
+    }
     if (t >= T) return;
     const float* x = wav + w0 + (long)t * FSHIFT;
 
@@ -89,16 +94,16 @@ __global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ wa
             const float wgt = fm <= center ? (fm - left) / (center - left) : (right - fm) / (right - center);
             e = fmaf(wgt, s_twr[i], e);
         }
-        feat[(row_off[b] + t) * n_mel + tid] = logf(fmaxf(e, 1.1920929e-07f));
+        feat[(row_off[b] + t) * ld + tid] = logf(fmaxf(e, 1.1920929e-07f));
     }
 }
 
 }  // namespace
 
-int mk_fbank(const float* wav, const long* wav_off, const long* row_off, int B, int max_frames, int n_mel, float* feat, hipStream_t s) {
+int mk_fbank(const float* wav, const long* wav_off, const long* row_off, int B, int max_frames, int n_mel, float* feat, hipStream_t s, int with_pitch) {
     if (n_mel < 1 || n_mel > 256) { mk_set_error("mk_fbank", "1 <= n_mel <= 256"); return -1; }
     if (B <= 0 || max_frames <= 0) return 0;
-    hipLaunchKernelGGL(fbank_kernel, dim3(max_frames, B), dim3(256), 0, s, wav, wav_off, row_off, feat, n_mel);
+    hipLaunchKernelGGL(fbank_kernel, dim3(max_frames, B), dim3(256), 0, s, wav, wav_off, row_off, feat, n_mel, with_pitch ? n_mel + 3 : n_mel, with_pitch);
     if (hipGetLastError() != hipSuccess) { mk_set_error("mk_fbank", "launch failed"); return -1; }
     return 0;
 }

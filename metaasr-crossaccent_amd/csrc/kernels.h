@@ -233,7 +233,12 @@ int mk_mask_rows(float* x32, bf16* x16, const int* lens, int B, int T, int C, hi
 // ---------------------------------------------------------------- features (fbank.hip)
 // Kaldi-style log-mel filterbank: wav fp32 (PCM scale, utterances concatenated), wav_off [B+1], row_off [B] (first output
 // row of each utterance), feat [sum T_b][n_mel]; T_b = 1 + (n_b - 400) / 160; grid covers max_frames frames per utterance
-int mk_fbank(const float* wav, const long* wav_off, const long* row_off, int B, int max_frames, int n_mel, float* feat, hipStream_t s);
+// with_pitch: rows have n_mel + 3 columns (the pitch dims are mk_pitch's) and an utterance has min(fbank, pitch) frames
+int mk_fbank(const float* wav, const long* wav_off, const long* row_off, int B, int max_frames, int n_mel, float* feat, hipStream_t s, int with_pitch = 0);
+// Kaldi pitch features (pitch.hip): columns n_mel .. n_mel+2 of the same rows
+long mk_pitch_work_bytes(long total_samples, int B, int max_frames);
+int mk_pitch(const float* wav, const long* wav_off, const long* row_off, long total_samples, long max_samples, int B, int max_frames, int n_mel, float* feat,
+             void* work, long work_bytes, hipStream_t s);
 
 // ---------------------------------------------------------------- CTC (ctc.hip)
 // logits fp32 [T][B][C] (pre-softmax); targets concatenated int [sum tl]; per-sample offsets tgt_off [B]

@@ -487,3 +487,49 @@ def test_fbank_matches_kaldi_style_oracle(tmp_path):
     back = np.load(tmp_path / "us" / "train" / "feat.dat", mmap_mode="r")
     assert back.shape == got.shape and np.array_equal(np.asarray(back), feat.cpu().numpy())
     assert np.load(tmp_path / "us" / "train" / "ilens.npy").tolist() == ilens.tolist()
+
+
+def test_fbank_pitch_matches_kaldi_style_oracle(tmp_path):
+    """masr_fbank_pitch: the shipped 83-dim rows = 80 log-mel bins | 3 Kaldi pitch dims (fometa-hkust.yaml:13 `idim: 83`, SURVEY F6;
+    no extraction code in the reference -> oracle/pitch_np.py restates compute-kaldi-pitch-feats | process-kaldi-pitch-feats, parity
+    unpinned).  Voiced glides with harmonics + noise tails, ragged lengths incl. one too short for the pitch tracker and one too
+    short for anything; the rows feed an idim-83 engine."""
+    from masr_amd.io import fbank as gf
+    from oracle import fbank_np as F
+    from oracle import pitch_np as P
+    rng = np.random.default_rng(7)
+    lens = [24000, 700, 12345, 399, 16000]
+    wavs = []
+    for i, n in enumerate(lens):
+        t = np.arange(n) / 16000.0
+        f0 = 110 + 35 * i + (30 + 10 * i) * t
+        ph = 2 * np.pi * np.cumsum(f0) / 16000.0
+        w = 2500 * sum(np.sin(k * ph) / k for k in range(1, 7)) + 120 * rng.standard_normal(n) + 40.0
+        w[int(0.7 * n):] = 600 * rng.standard_normal(n - int(0.7 * n))
+        wavs.append(np.round(w).astype(np.float32))
+    feat, ilens = gf.extract(wavs, n_mel=80, pitch=True)
+    want_T = [min(F.num_frames(n), P.num_frames(n)) for n in lens]
+    assert ilens.tolist() == want_T and want_T[1] == 0 and want_T[3] == 0 and want_T[0] == 146
+    got = feat.cpu().numpy().astype(np.float64)
+    assert got.shape == (sum(want_T), 83)
+    ref = np.concatenate([P.fbank_pitch(w) for w, T in zip(wavs, want_T) if T])
+    assert np.abs(got[:, :80] - ref[:, :80]).max() < 2e-3               # the fbank columns, now with row stride 83
+    d = np.abs(got[:, 80:] - ref[:, 80:])
+    # the tracker is a discrete decision per frame (one of 417 lags): fp32 NCCF interpolation vs float64 may pick a neighbouring lag
+    # on a few frames (0.5 % in pitch -> 0.01 in 2 * log pitch; the delta then moves by up to 0.1)
+    same = (d < np.array([2e-3, 2e-3, 2e-2])).all(1).mean()
+    print(f"pitch dims: {same:.3f} of the frames agree with the oracle; max |diff| pov {d[:, 0].max():.2e}, log-pitch {d[:, 1].max():.2e}, delta {d[:, 2].max():.2e}")
+    assert same > 0.97 and d[:, 0].max() < 0.05 and d[:, 1].max() < 0.05 and d[:, 2].max() < 0.3
+    # voiced part of the first utterance: pov feature strongly negative, delta log pitch = its slope
+    assert got[10:90, 80].max() < -1.0
+    # end to end: the rows are a valid input of an idim-83 model
+    gf.write_feat_shard(tmp_path / "us" / "train", feat, ilens)
+    back = np.load(tmp_path / "us" / "train" / "feat.dat", mmap_mode="r")
+    assert back.shape == (sum(want_T), 83)
+    eng = MasrEngine(TINY, ODIM, label_smoothing=0.2)                     # TINY has idim 83
+    eng.load_state_dict(ref_cpu.deterministic_state_dict(TINY, ODIM, seed=7))
+    T0 = want_T[0]
+    xs = torch.from_numpy(np.asarray(back[:T0])).unsqueeze(0)
+    xs = (xs - xs.mean(1, keepdim=True)) / (xs.std(1, keepdim=True) + 1e-3)
+    eng.run_batch(xs, torch.tensor([T0]), [torch.tensor([5, 9, 2])], torch.tensor([3]), train=True)
+    assert np.isfinite(eng.read_stats()["loss"])

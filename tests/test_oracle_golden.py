@@ -238,6 +238,54 @@ def test_fbank_oracle_properties():
     np.testing.assert_allclose(F.fbank(tone + 1234.0, 80), f, atol=1e-6)                         # remove_dc_offset
 
 
+def _voiced(f0_fn, dur, sr=16000, amp=3000.0, harmonics=7):
+    t = np.arange(int(dur * sr)) / sr
+    ph = 2 * np.pi * np.cumsum(f0_fn(t)) / sr
+    return amp * sum(np.sin(k * ph) / k for k in range(1, harmonics + 1))
+
+
+def test_pitch_oracle_properties():
+    """oracle/pitch_np.py restates Kaldi's compute-kaldi-pitch-feats | process-kaldi-pitch-feats (the 3 pitch dims of the shipped
+    83-dim rows); nothing in the container can pin it (no Kaldi, torchaudio, ... -- parity unpinned), so the published algorithm's
+    invariants are checked: lag grid, frame count against the fbank stream (the recipe's paste-feats tolerance), tracking of a known
+    f0 glide, voicing separation, gain invariance, the shape of the three processed dims."""
+    from oracle import fbank_np as F
+    from oracle import pitch_np as P
+    lg = P.lags()
+    assert len(lg) == 417 and abs(lg[0] - 1 / 400) < 1e-12 and lg[-1] <= 1 / 50 < lg[-1] * 1.005
+    assert (P.OUTER_MIN_LAG, P.OUTER_MAX_LAG, P.NLAG_IN, P.FULL) == (8, 82, 75, 182)
+    for n in (0, 724, 725, 885, 16000, 160000):
+        tp, tf = P.num_frames(n), F.num_frames(n)
+        assert tp <= tf and (tf - tp <= 2 or tp == 0), (n, tp, tf)
+    assert [P.num_frames(n) for n in (724, 725, 884, 885, 160000)] == [0, 1, 1, 2, 996]
+    W = P.upsample_matrix(lg)
+    assert W.shape == (417, 75) and (np.count_nonzero(W, axis=1) <= 11).all()
+    np.testing.assert_allclose(W.sum(1), 1.0, atol=0.02)                 # the windowed sinc interpolates a constant to (almost) itself
+    # resampling: a 300 Hz tone passes the 1 kHz low-pass with its amplitude, a 3 kHz tone does not
+    t = np.arange(8000) / 16000.0
+    lo, hi = P.downsample(1000 * np.sin(2 * np.pi * 300 * t)), P.downsample(1000 * np.sin(2 * np.pi * 3000 * t))
+    assert len(lo) == 2000 and 700 < np.abs(lo[100:-100]).max() < 1050 and np.abs(hi[100:-100]).max() < 60      # (one zero crossing: a soft filter, 0.78 at 300 Hz)
+    # a glide 120 -> 180 Hz with harmonics, then noise
+    wav = _voiced(lambda t: 120 + 40 * t, 1.5)
+    wav[16000:] = np.random.RandomState(0).randn(len(wav) - 16000) * 800
+    raw = P.compute_kaldi_pitch(wav)
+    assert raw.shape == (P.num_frames(len(wav)), 2)
+    centre = np.arange(len(raw)) * 0.01 + 0.0125 + 0.02                 # window centre + half the average lag span: within the tolerance below
+    v = slice(5, 90)
+    assert np.abs(raw[v, 1] - (120 + 40 * centre[v])).max() < 2.5       # Hz (the lag grid is 0.5 % wide)
+    assert raw[v, 0].min() > 0.95 and np.abs(raw[108:, 0]).mean() < 0.3  # NCCF ~ 1 on voiced frames, small on noise
+    np.testing.assert_allclose(P.compute_kaldi_pitch(0.1 * wav), raw, atol=1e-6)     # the ballast scales with the signal: gain invariant
+    f3 = P.process_kaldi_pitch(raw)
+    assert f3.shape == (len(raw), 3)
+    assert f3[v, 0].max() < -1.0 and f3[110:, 0].min() > -0.4            # pov feature 2 ((1.0001 - nccf)^0.15 - 1): -> -1.5 voiced, -> 0 unvoiced
+    slope = np.log(180 / 120) / 150 * 10.0                              # d log f0 per frame, times delta_pitch_scale
+    assert np.abs(f3[10:80, 2] - slope).max() < 0.03
+    const = P.process_kaldi_pitch(np.stack([np.full(50, 0.9), np.full(50, 200.0)], 1))
+    assert np.abs(const[:, 1]).max() < 1e-12 and np.abs(const[:, 2]).max() < 1e-12      # constant pitch: zero normalised log pitch and delta
+    rows = P.fbank_pitch(wav[:8000])
+    assert rows.shape == (min(F.num_frames(8000), P.num_frames(8000)), 83)
+
+
 @pytest.mark.parametrize("tag,ilens,olens", [("ragged", [61, 50, 38, 30], [7, 5, 4, 3]), ("single", [45], [6])])
 def test_blstm_oracle_matches_reference(golden_dir, tag, ilens, olens):
     """oracle/blstm_cpu.py (explicit LSTM recurrence with own packed-sequence handling) vs the real MonoBLSTM +
