@@ -519,7 +519,10 @@ def test_fbank_pitch_matches_kaldi_style_oracle(tmp_path):
     # on a few frames (0.5 % in pitch -> 0.01 in 2 * log pitch; the delta then moves by up to 0.1)
     same = (d < np.array([2e-3, 2e-3, 2e-2])).all(1).mean()
     print(f"pitch dims: {same:.3f} of the frames agree with the oracle; max |diff| pov {d[:, 0].max():.2e}, log-pitch {d[:, 1].max():.2e}, delta {d[:, 2].max():.2e}")
-    assert same > 0.97 and d[:, 0].max() < 0.05 and d[:, 1].max() < 0.05 and d[:, 2].max() < 0.3
+    # measured: 0.93 identical, every difference within ONE lag step (0.5 % of the pitch = 0.01 in 2 log pitch), all of them on the
+    # noise tails where the NCCF is flat and neighbouring lags are near-ties; the voiced frames agree throughout
+    assert same > 0.9 and d[:, 0].max() < 0.02 and d[:, 1].max() < 0.0105 and d[:, 2].max() < 0.06
+    assert (d[10:90] < np.array([2e-3, 2e-3, 2e-2])).all(1).mean() > 0.98
     # voiced part of the first utterance: pov feature strongly negative, delta log pitch = its slope
     assert got[10:90, 80].max() < -1.0
     # end to end: the rows are a valid input of an idim-83 model
