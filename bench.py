@@ -180,9 +180,15 @@ def main():
     ndev = torch.cuda.device_count()
     if backend != "nccl":
         local = local % max(ndev, 1)
-    if world > 1:
+    # MASR_FORCE_COLLECTIVE=1 with one rank: the process group, barriers, max-over-ranks reductions and the meta-step exchange legs all
+    # go through the collective backend (RCCL) although an all-reduce over one rank is the identity -- the N-GPU code path, executed
+    # on a 1-GPU box (tests/test_hip_rccl_world1.py)
+    if world > 1 or os.environ.get("MASR_FORCE_COLLECTIVE") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         if backend == "nccl":

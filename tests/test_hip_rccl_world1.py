@@ -61,3 +61,21 @@ def test_pretrain_cli_meta_steps_through_rccl_with_one_rank(golden_dir, tmp_path
     assert d <= (0.0 if tasks_per_gpu == 1 else 4 * 2.5 * 3.2e-8 + 1.2e-7), d
     log_dir = tmp_path / "testing-logs" / "pretrain" / "cfg3" / "fomaml" / "rccl" / "canada" / "0"
     assert (log_dir / "snapshot.step.4").exists() and len((log_dir / "dev_avg_wer").read_text().splitlines()) == 2
+
+
+def test_bench_collective_legs_through_rccl_with_one_rank(tmp_path):
+    """bench.py with MASR_FORCE_COLLECTIVE=1: init_process_group("nccl", device_id=...), the barriers, the max-over-ranks reduction
+    of the timed region and the meta-step legs with their all-reduces (per round on the side stream; one per wave of task slots) run
+    through RCCL with one rank -- what the driver's multi-GPU bench will execute first, minus the other ranks."""
+    import json
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "4", "--warmup", "2", "--tasks-per-gpu", "2", "--no-cpu-baseline",
+                        "--long-seconds", "0", "--meta-steps", "2", "--no-matrix", "--no-mixed"], cwd=tmp_path, env=_env(MASR_FORCE_COLLECTIVE="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["value"] > 0
+    ms = d["meta_step"]
+    assert ms["backend"] == "rccl" and ms["allreduces_per_meta_step"] == 2 and ms["allreduce_ms_isolated"] > 0 and ms["ms"] > 0
+    assert ms["concurrent_slots"]["allreduces_per_meta_step"] == 1 and ms["concurrent_slots"]["ms"] > 0
