@@ -532,7 +532,7 @@ def test_fbank_pitch_matches_kaldi_style_oracle(tmp_path):
     eng = MasrEngine(TINY, ODIM, label_smoothing=0.2)                     # TINY has idim 83
     eng.load_state_dict(ref_cpu.deterministic_state_dict(TINY, ODIM, seed=7))
     T0 = want_T[0]
-    xs = torch.from_numpy(np.asarray(back[:T0])).unsqueeze(0)
+    xs = torch.from_numpy(np.array(back[:T0])).unsqueeze(0)
     xs = (xs - xs.mean(1, keepdim=True)) / (xs.std(1, keepdim=True) + 1e-3)
     eng.run_batch(xs, torch.tensor([T0]), [torch.tensor([5, 9, 2])], torch.tensor([3]), train=True)
     assert np.isfinite(eng.read_stats()["loss"])
