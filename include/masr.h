@@ -235,7 +235,7 @@ int masr_ctc_loss(const float* logits, const int32_t* targets, const int32_t* tg
 #define MASR_PROF_CONV2_WGRAD 7
 #define MASR_PROF_CONV3_WGRAD 8
 #define MASR_PROF_CONV4_WGRAD 9
-#define MASR_PROF_CONV1_WGRAD 10  /* fold of the fused conv1 weight-gradient partials */
+#define MASR_PROF_CONV1_WGRAD 10  /* folds of the per-workgroup weight-gradient partials: conv1's fused sums and the slab reduces of conv2..4 */
 #define MASR_PROF_GEMM_ENC 11     /* Linear forward / dgrad over the B*T' encoder rows (incl. vgg2enc, grouped cross-attention K/V) */
 #define MASR_PROF_GEMM_DEC 12     /* ... over the B*L decoder rows */
 #define MASR_PROF_WGRAD_ENC 13    /* Linear weight gradients reducing over encoder rows (split-K) */

@@ -2588,7 +2588,8 @@ long mk_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT) {
     const long v2 = (long)wgrad2_nwg(CIN, COUT) * (COUT * 9 * CIN + COUT);
     return v1 > v2 ? v1 : v2;
 }
-int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s) {
+int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s, int phase) {
+    // phase 0: both launches; 1: the partial-slab kernel only; 2: the slab reduce only (the engine times them in separate slots)
     const long P = (long)a.B * a.H * a.W;
     int splits;
     if (getenv("MASR_WGRAD_V1")) {                         // first-generation one-tap-per-workgroup kernel (kept for A/B runs)
@@ -2596,7 +2597,8 @@ int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s) {
         long pps = (P + splits - 1) / splits;
         pps = (pps + 63) / 64 * 64;
         dim3 grid(9 * (a.CIN / 64), splits);
-        if (a.CIN == 64 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_wgrad_kernel<64, 64>), grid, dim3(256), 0, s, a, pps);
+        if (phase == 2) {}
+        else if (a.CIN == 64 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_wgrad_kernel<64, 64>), grid, dim3(256), 0, s, a, pps);
         else if (a.CIN == 64 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_wgrad_kernel<64, 128>), grid, dim3(256), 0, s, a, pps);
         else if (a.CIN == 128 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_wgrad_kernel<128, 128>), grid, dim3(256), 0, s, a, pps);
         else { mk_set_error("mk_conv3x3_wgrad", "unsupported channel counts"); return -1; }
@@ -2615,7 +2617,8 @@ int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s) {
 #define W2(CI, CO) \
         if (occ == 1) { if (narrow) W2T(CI, CO, 1, 8); else W2T(CI, CO, 1, 16); } \
         else { if (narrow) W2T(CI, CO, 2, 8); else W2T(CI, CO, 2, 16); }
-        if (a.CIN == 64 && a.COUT == 64) { W2(64, 64) }
+        if (phase == 2) {}
+        else if (a.CIN == 64 && a.COUT == 64) { W2(64, 64) }
         else if (a.CIN == 64 && a.COUT == 128) { W2(64, 128) }
         else if (a.CIN == 128 && a.COUT == 128) { W2(128, 128) }
         else if (a.CIN == 128 && a.COUT == 256) { W2(128, 256) }
@@ -2625,7 +2628,7 @@ int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s) {
 #undef W2
     }
     const int n = a.COUT * 9 * a.CIN + a.COUT;
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((n + 63) / 64), dim3(256), 0, s, a.slab, splits, a.dw, a.db, a.CIN, a.COUT);
+    if (phase != 1) hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((n + 63) / 64), dim3(256), 0, s, a.slab, splits, a.dw, a.db, a.CIN, a.COUT);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

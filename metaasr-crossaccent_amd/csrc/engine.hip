@@ -72,8 +72,10 @@ struct Acts {
     float* wg_slab;                                        // split-K partials: (WG_SPLIT-1) x nparams
 };
 constexpr int WG_SPLIT_MAX = 4;
-// split-K factor of the encoder-row weight gradients (MASR_WG_SPLIT = 1..4 for A/B runs)
-static const int WG_SPLIT = [] { const char* e = getenv("MASR_WG_SPLIT"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > WG_SPLIT_MAX ? WG_SPLIT_MAX : v); }();
+// split-K factor of the encoder-row weight gradients (MASR_WG_SPLIT = 1..4 for A/B runs).  2: with four task slots per GPU the chip is
+// full anyway and every extra partial slab is 90 MB written and read again by the combine pass -- measured, 4 tasks / single task
+// utt/s: split 4: 8 440 / 5 485, split 2: 8 530 / 5 435, no split: 8 460-8 490 / 5 380
+static const int WG_SPLIT = [] { const char* e = getenv("MASR_WG_SPLIT"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > WG_SPLIT_MAX ? WG_SPLIT_MAX : v); }();
 
 }  // namespace
 
@@ -756,9 +758,9 @@ static int backward(Ctx& c, const float* xs) {
     // ---- VGG
     const int64_t P1 = (int64_t)B * a.T * a.D, P2 = (int64_t)B * a.H2 * a.W2;
     auto wgrad = [&](const bf16* in, const bf16* dy, const Conv& cv, int H, int W, int64_t P) -> int {
-        { Prof p(m, MASR_PROF_CONV2_WGRAD + (int)(&cv - &m->conv[1]), s);
-          ConvWgradArgs wa{}; wa.in = in; wa.dy = dy; wa.dw = G + cv.w; wa.db = G + cv.b; wa.slab = a.slab; wa.B = B; wa.H = H; wa.W = W; wa.CIN = cv.CI; wa.COUT = cv.CO;
-          CK(mk_conv3x3_wgrad(wa, s)); }
+        ConvWgradArgs wa{}; wa.in = in; wa.dy = dy; wa.dw = G + cv.w; wa.db = G + cv.b; wa.slab = a.slab; wa.B = B; wa.H = H; wa.W = W; wa.CIN = cv.CI; wa.COUT = cv.CO;
+        { Prof p(m, MASR_PROF_CONV2_WGRAD + (int)(&cv - &m->conv[1]), s); CK(mk_conv3x3_wgrad(wa, s, 1)); }     // ONE launch per slot:
+        { Prof p(m, MASR_PROF_CONV1_WGRAD, s); CK(mk_conv3x3_wgrad(wa, s, 2)); }                                 // the slab reduce is timed with the other folds
         (void)P;
         return 0;
     };
