@@ -271,6 +271,11 @@ int masr_test_conv3x3(const uint16_t* in, const uint16_t* wk, const float* bias,
    pool_out (optional, [B][H/2][W/2][COUT]) receives MaxPool2d(2,2) of the ReLU'd output */
 int masr_test_conv3x3_ex(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, const uint16_t* mask, uint16_t* out,
                          uint16_t* pool_out, int B, int H, int W, int CIN, int COUT, void* stream);
+/* 128-channel ReLU masks as sign bits (four dwords per pixel, dword q = the sign bytes of channel groups 8q.., 32+8q.., 64+8q.., 96+8q..):
+   a forward launch with 128 output channels writes them for its output (out_sign_bits), a masked 128 <- 128 dgrad reads them
+   (mask_bits, next to the bf16 mask it replaces on the streaming path) */
+int masr_test_conv3x3_sign_bits(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, const uint16_t* mask, const uint32_t* mask_bits,
+                                uint16_t* out, uint32_t* out_sign_bits, int B, int H, int W, int CIN, int COUT, void* stream);
 /* the pooling forward conv as the engine launches it: pool_idx ([B][H/2][W/2][COUT] bytes) receives, per pooled element, the
    window position 0..3 (row-major) of its first maximum, or 4 where nothing passed the ReLU; drop_out != 0 allows the launch to
    leave `out` unwritten (the streaming kernels then never store the full-resolution map; the others still do).

@@ -83,6 +83,7 @@ _SIGS = {
     "masr_test_gemm_epi": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, i32, f32, vp, vp, vp, vp, vp]),
     "masr_test_conv3x3": (i32, [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     "masr_test_conv3x3_ex": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "masr_test_conv3x3_sign_bits": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "masr_test_conv3x3_pool_idx": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "masr_test_maxpool_idx_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "masr_test_conv3x3_prof": (i32, [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp]),

@@ -611,9 +611,12 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
 __device__ __attribute__((aligned(128))) bf16 g_zero_line[64];
 __device__ unsigned g_conv_sched[2];                      // tile counter of launches that bring none (single-stream tools and tests)
 
-// MASK = false: forward flavour (bias, ReLU flag, optional fused pool); MASK = true: dgrad flavour (outputs zeroed where
-// a.mask <= 0; no bias / ReLU / pool)
-template <int CIN, int COUT, int TH, int TW, bool MASK, bool PROF = false>
+// MASK = 0: forward flavour (bias, ReLU flag, optional fused pool); MASK = 1: dgrad flavour (outputs zeroed where a.mask <= 0;
+// no bias / ReLU / pool); MASK = 2: the same with the mask read as SIGN BITS (a.mask_bits: four dwords per pixel, dword q = the
+// bytes of channel groups 8q.., 32+8q.., 64+8q.., 96+8q.. -- exactly what lane (rr, q) masks, so ONE 4-byte load per pixel where the
+// bf16 map costs four 16-byte ones, and 4 mask registers instead of 64: room for the 32-row tiles of the unmasked kernels).
+// The forward flavour with 128 output channels writes those words for ITS output when a.out_sign_bits is set.
+template <int CIN, int COUT, int TH, int TW, int MASK, bool PROF = false>
 __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int ntiles, int tiles_x, int tiles_y, int chunk) {
     constexpr int PW = TW + 2, PH = TH + 2, RPT = 16 / TW;
     constexpr int MF = TH * TW / 64, NF = COUT / 16, NH = NF / 2;
@@ -879,8 +882,10 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
         char* out_b = reinterpret_cast<char*>(a.out) + (long)b * H * W * COUT * 2;
         auto row_ok = [&](int i) { return tl + i * RPT < H && dl < W; };
         auto row_off = [&](int i) { return voff + (unsigned)(i * RPT) * (unsigned)(W * COUT * 2); };
-        const char* mask_b = MASK ? reinterpret_cast<const char*>(a.mask) + (long)b * H * W * COUT * 2 : nullptr;
-        u32x4 mk[MASK ? MF : 1][MASK ? NH : 1];           // ReLU mask of this lane's outputs, requested three taps before the epilogue
+        const char* mask_b = MASK == 1 ? reinterpret_cast<const char*>(a.mask) + (long)b * H * W * COUT * 2 : nullptr;
+        u32x4 mk[MASK == 1 ? MF : 1][MASK == 1 ? NH : 1]; // ReLU mask of this lane's outputs, requested three taps before the epilogue
+        unsigned mb[MASK == 2 ? MF : 1];                  // ... as sign bits: this lane's dword of its pixel's four
+        const unsigned* bits_b = MASK == 2 ? reinterpret_cast<const unsigned*>(a.mask_bits) + (((long)b * H + tl) * W + dl) * 4 + q : nullptr;
         int next_tile = -1;
 #pragma unroll 1
         for (int slab = 0; slab < NSLAB; ++slab, ++g) {
@@ -894,7 +899,7 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
             const char* pnext = pbuf + ((g + 1) & 1) * PBYTES;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                if constexpr (MASK) {
+                if constexpr (MASK == 1) {
                     if (tap == 6 && slab == NSLAB - 1) {
 #pragma unroll
                         for (int i = 0; i < MF; ++i)
@@ -903,6 +908,12 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
                                 const u32x4 z = {0u, 0u, 0u, 0u};
                                 mk[i][h] = row_ok(i) ? *reinterpret_cast<const u32x4*>(mask_b + row_off(i) + h * 64) : z;
                             }
+                    }
+                }
+                if constexpr (MASK == 2) {
+                    if (tap == 0 && slab == NSLAB - 1) {
+#pragma unroll
+                        for (int i = 0; i < MF; ++i) mb[i] = row_ok(i) ? bits_b[(long)i * RPT * W * 4] : 0u;
                     }
                 }
                 const char* wcur = wbuf + ((g + tap) & (D - 1)) * WBYTES;          // 9 g + tap = g + tap (mod 4)
@@ -932,6 +943,9 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
         const short2_t floor2 = {fl, fl};
         const bool store_dense = MASK || !(a.out_optional && a.pool_out), want_idx = a.pool_idx != nullptr;
         short2_t pm[NH][4];
+        unsigned sgn[(MASK == 0 && COUT == 128) ? MF : 1];
+#pragma unroll
+        for (int i = 0; i < ((MASK == 0 && COUT == 128) ? MF : 1); ++i) sgn[i] = 0u;
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             const bool ok = row_ok(i);
@@ -948,7 +962,7 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
                     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(v[0]), "v"(v[1]));
                     pk[kk] = __builtin_elementwise_max(__builtin_bit_cast(short2_t, r), floor2);   // ReLU (or a no-op)
                 }
-                if constexpr (MASK) {
+                if constexpr (MASK == 1) {
                     const short2_t zero2 = {0, 0}, one2 = {1, 1};
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) {
@@ -956,6 +970,22 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
                         short2_t m = __builtin_bit_cast(short2_t, mw);
                         m = __builtin_elementwise_min(__builtin_elementwise_max(m, zero2), one2);   // 1 where mask > 0
                         pk[kk] = pk[kk] & (zero2 - m);
+                    }
+                }
+                if constexpr (MASK == 2) {
+                    const int byte = (int)(mb[i] >> (8 * h));   // bits 2kk, 2kk+1 -> the two halves of packed pair kk
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const unsigned lo = (unsigned)__builtin_amdgcn_sbfe(byte, 2 * kk, 1), hi = (unsigned)__builtin_amdgcn_sbfe(byte, 2 * kk + 1, 1);
+                        pk[kk] = __builtin_bit_cast(short2_t, __builtin_bit_cast(unsigned, pk[kk]) & ((lo & 0xFFFFu) | (hi & 0xFFFF0000u)));
+                    }
+                }
+                if constexpr (MASK == 0 && COUT == 128) {
+                    if (a.out_sign_bits) {                     // (uniform) sign byte of this lane's 8 ReLU'd channels: per half min(v, 1) = 1 for v > 0
+                        unsigned e = 0;
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) e |= __builtin_bit_cast(unsigned, __builtin_elementwise_min(pk[kk], short2_t{1, 1})) << (2 * kk);
+                        sgn[i] |= ((e | e >> 15) & 0xFFu) << (8 * h);
                     }
                 }
                 if (ok && store_dense) {
@@ -993,6 +1023,10 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
                         }
                     }
                 }
+            }
+            if constexpr (MASK == 0 && COUT == 128) {
+                // this lane's dword of the pixel's sign words: one 4-byte store per pixel tile
+                if (a.out_sign_bits && ok) reinterpret_cast<unsigned*>(a.out_sign_bits)[(((long)b * H + tl + i * RPT) * W + dl) * 4 + q] = sgn[i];
             }
         }
         stamp(2);
@@ -2446,7 +2480,7 @@ static void launch_resw(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t
     const int grid = chunk > 0 ? (ntiles + chunk - 1) / chunk : (ntiles < resident ? ntiles : resident);
     hipLaunchKernelGGL((conv3x3_resw_kernel<16, 16, PROF>), dim3((unsigned)grid), dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, chunk);
 }
-template <int CI, int CO, int TWV, bool MASK, bool PROF = false, int THV = 16>
+template <int CI, int CO, int TWV, int MASK, bool PROF = false, int THV = 16>
 static void launch_stream_t(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
     static int resident = 0;
     if (!resident) {
@@ -2472,13 +2506,35 @@ static void launch_stream_t(const ConvArgs& a, int tiles_x, int tiles_y, hipStre
 }
 template <int CI, int CO, int TWV, bool PROF = false, int THV = 16>
 static void launch_stream(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
-    if (a.mask) launch_stream_t<CI, CO, TWV, true, PROF, THV>(a, tiles_x, tiles_y, s);
-    else launch_stream_t<CI, CO, TWV, false, PROF, THV>(a, tiles_x, tiles_y, s);
+    if (a.mask) launch_stream_t<CI, CO, TWV, 1, PROF, THV>(a, tiles_x, tiles_y, s);
+    else launch_stream_t<CI, CO, TWV, 0, PROF, THV>(a, tiles_x, tiles_y, s);
+}
+// ConvArgs::out_sign_bits for launches whose epilogue does not write them: from the stored 128-channel map, thread = (pixel, dword q)
+__global__ void sign_bits128_kernel(const bf16* __restrict__ map, unsigned* __restrict__ bits, long npix) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * 4) return;
+    const long pix = i >> 2; const int q = (int)(i & 3);
+    unsigned w = 0;
+    for (int h = 0; h < 4; ++h) {
+        const bf16x8 v = ld8(map + pix * 128 + h * 32 + q * 8);
+        for (int j = 0; j < 8; ++j) w |= ((float)v[j] > 0.f ? 1u : 0u) << (8 * h + j);
+    }
+    bits[i] = w;
+}
+// will a masked 128 <- 128 dgrad on a map of this width read its mask as sign bits (ConvArgs::mask_bits / out_sign_bits)?  Only the
+// streaming kernel on 8-wide, 32-row tiles does; elsewhere the words would be written for nothing.
+bool mk_conv3x3_mask_bits_used(int W) {
+    static const bool allow_narrow = !getenv("MASR_CONV_NO_TW8");
+    static const bool stream = !(getenv("MASR_CONV_STREAM") && atoi(getenv("MASR_CONV_STREAM")) == 0);
+    static const bool th32 = !(getenv("MASR_CONV_TH32") && atoi(getenv("MASR_CONV_TH32")) == 0);
+    static const bool v1 = getenv("MASR_CONV_V1") != nullptr;
+    return allow_narrow && stream && th32 && !v1 && (W + 7) / 8 * 8 < (W + 15) / 16 * 16;
 }
 static int conv3x3_dispatch(const ConvArgs& a, hipStream_t s);
 int mk_conv3x3(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     uint8_t* idx_after = nullptr;
+    unsigned long long* sign_after = nullptr;
     {   // pool_idx / out_optional are honoured by the epilogues of the streaming kernels only: everywhere else the launch
         // stores the map and the codes are computed from it afterwards
         static const bool allow_narrow = !getenv("MASR_CONV_NO_TW8");
@@ -2487,9 +2543,15 @@ int mk_conv3x3(const ConvArgs& a0, hipStream_t s) {
         const bool in_epilogue = !getenv("MASR_CONV_V1") && !a.prof && stream && !a.x1 && !a.mask && a.CIN <= 128 && a.COUT <= 128 &&
                                  (narrow || (a.CIN == 64 && a.COUT == 64));
         if (!in_epilogue) { idx_after = a.pool_idx; a.pool_idx = nullptr; a.out_optional = 0; }
+        if (a.out_sign_bits && (a.COUT != 128 || !a.out)) { mk_set_error("mk_conv3x3", "out_sign_bits: 128 output channels, stored map"); return -1; }
+        if (a.out_sign_bits && !in_epilogue) { sign_after = a.out_sign_bits; a.out_sign_bits = nullptr; }
         if ((a.pool_idx && !a.pool_out) || (!a.out && !(a.out_optional && a.pool_out))) { mk_set_error("mk_conv3x3", "pool_idx needs pool_out, and out may only be dropped when the launch pools"); return -1; }
     }
     const int rc = conv3x3_dispatch(a, s);
+    if (rc == 0 && sign_after) {
+        const long npix = (long)a.B * a.H * a.W;
+        hipLaunchKernelGGL(sign_bits128_kernel, dim3((unsigned)((npix * 4 + 255) / 256)), dim3(256), 0, s, a.out, reinterpret_cast<unsigned*>(sign_after), npix);
+    }
     if (rc == 0 && idx_after) return mk_maxpool_idx(a.out, idx_after, a.B, a.H, a.W, a.COUT, s);
     return rc;
 }
@@ -2547,7 +2609,9 @@ static int conv3x3_dispatch(const ConvArgs& a, hipStream_t s) {
             static const bool th32 = !(getenv("MASR_CONV_TH32") && atoi(getenv("MASR_CONV_TH32")) == 0);
             const int ty32 = (a.H + 31) / 32;
             if (a.CIN == 128 && a.COUT == 128) {
-                if (th32 && !a.mask) launch_stream_t<128, 128, 8, false, false, 32>(a, tiles_x, ty32, s);
+                // (the masked dgrad too once its mask comes as sign bits: 4 mask registers instead of 64)
+                if (th32 && !a.mask) launch_stream_t<128, 128, 8, 0, false, 32>(a, tiles_x, ty32, s);
+                else if (th32 && a.mask_bits) launch_stream_t<128, 128, 8, 2, false, 32>(a, tiles_x, ty32, s);
                 else launch_stream<128, 128, 8>(a, tiles_x, tiles_y, s);
             } else if (th32) launch_stream<128, 64, 8, false, 32>(a, tiles_x, ty32, s);
             else launch_stream<128, 64, 8>(a, tiles_x, tiles_y, s);

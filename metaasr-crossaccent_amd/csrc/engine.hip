@@ -52,7 +52,7 @@ struct Acts {
     uint32_t* meta;                                        // [8] behind enc_lens, same upload: [0] dropout seed of the step, [1] 1/n_total (float bits)
     bf16* step_qkv;                                        // incremental decode: the newest position's q|k|v [B][3E]
     bf16 *a1, *a2, *p1, *a3, *a4, *p2;
-    unsigned long long* a1_bits;                           // ReLU mask of a1, one word per pixel (written by conv1's forward, read by conv2's fused dgrad)
+    unsigned long long *a1_bits, *a3_bits;                           // ReLU mask of a1, one word per pixel (written by conv1's forward, read by conv2's fused dgrad)
     uint8_t *i1, *i2;                                  // ConvArgs::pool_idx of the two pools (a2 / a4 are only written by conv kernels that cannot emit them)
     std::vector<float*> x32; std::vector<bf16*> x16;        // encoder layer inputs/outputs [NE+1]
     std::vector<EncAct> enc;
@@ -200,7 +200,7 @@ void plan_acts(const masr_model* m, Arena& ar, Acts& a, int B, int T, int L, boo
     a.step_qkv = ar.get<bf16>((int64_t)B * 3 * E);
     const int64_t P1 = (int64_t)B * T * m->D, P2 = (int64_t)B * a.H2 * a.W2;
     a.a1 = ar.get<bf16>(P1 * 64); a.a2 = ar.get<bf16>(P1 * 64); a.p1 = ar.get<bf16>(P2 * 64);
-    a.a1_bits = ar.get<unsigned long long>(P1);
+    a.a1_bits = ar.get<unsigned long long>(P1); a.a3_bits = ar.get<unsigned long long>(P2 * 2);      // (64 / 128 sign bits per pixel)
     a.a3 = ar.get<bf16>(P2 * 128); a.a4 = ar.get<bf16>(P2 * 128); a.p2 = ar.get<bf16>(re * m->F);
     a.i1 = ar.get<uint8_t>(P2 * 64); a.i2 = ar.get<uint8_t>(re * m->F);
     a.x32.resize(m->NE + 1); a.x16.resize(m->NE + 1); a.enc.resize(m->NE);
@@ -593,6 +593,7 @@ static int forward_encoder(Ctx& c, const float* xs) {
         ConvArgs ca{}; ca.sched = m->conv_sched; ca.in = in; ca.wk = cv.k16; ca.bias = P + cv.b; ca.relu = 1; ca.mask = nullptr; ca.out = out;
         ca.B = B; ca.H = H; ca.W = W; ca.CIN = cv.CI; ca.COUT = cv.CO; ca.pool_out = fuse_pool ? pooled : nullptr;
         if (ca.pool_out) { ca.pool_idx = c.train ? idx : nullptr; ca.out_optional = 1; }
+        if (&cv == &m->conv[2] && c.train && mk_conv3x3_mask_bits_used(W)) ca.out_sign_bits = a.a3_bits;      // conv3's ReLU mask as sign bits for conv4's masked dgrad
         return mk_conv3x3(ca, s);
     };
     CK(conv(a.a1, m->conv[1], a.a2, T, D, a.p1, a.i1));
@@ -768,6 +769,7 @@ static int backward(Ctx& c, const float* xs) {
         Prof p(m, MASR_PROF_CONV2_DGRAD + (int)(&cv - &m->conv[1]), s);
         ConvArgs ca{}; ca.sched = m->conv_sched; ca.in = dy; ca.wk = cv.d16; ca.bias = nullptr; ca.relu = 0; ca.mask = mask; ca.out = out; ca.B = B; ca.H = H; ca.W = W;
         ca.CIN = cv.CO; ca.COUT = cv.CI;
+        if (mask == a.a3 && mk_conv3x3_mask_bits_used(W)) ca.mask_bits = a.a3_bits;                           // written by conv3's forward launch (128-channel sign words)
         return mk_conv3x3(ca, s);
     };
     { Prof p(m, MASR_PROF_POOL, s); CK(mk_maxpool_idx_bwd(a.i2, a.dp2, a.da4, B, a.H2, a.W2, 128, s)); }
@@ -1214,6 +1216,13 @@ int masr_test_conv3x3_ex(const uint16_t* in, const uint16_t* wk, const float* bi
                          uint16_t* pool_out, int B, int H, int W, int CIN, int COUT, void* stream) {
     ConvArgs a{}; a.in = (const bf16*)in; a.wk = (const bf16*)wk; a.bias = bias; a.relu = relu; a.mask = (const bf16*)mask; a.out = (bf16*)out;
     a.pool_out = (bf16*)pool_out; a.B = B; a.H = H; a.W = W; a.CIN = CIN; a.COUT = COUT;
+    return mk_conv3x3(a, (hipStream_t)stream);
+}
+int masr_test_conv3x3_sign_bits(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, const uint16_t* mask, const uint32_t* mask_bits,
+                                uint16_t* out, uint32_t* out_sign_bits, int B, int H, int W, int CIN, int COUT, void* stream) {
+    ConvArgs a{}; a.in = (const bf16*)in; a.wk = (const bf16*)wk; a.bias = bias; a.relu = relu; a.mask = (const bf16*)mask;
+    a.mask_bits = (const unsigned long long*)mask_bits; a.out = (bf16*)out; a.out_sign_bits = (unsigned long long*)out_sign_bits;
+    a.B = B; a.H = H; a.W = W; a.CIN = CIN; a.COUT = COUT;
     return mk_conv3x3(a, (hipStream_t)stream);
 }
 int masr_test_conv3x3_pool_idx(const uint16_t* in, const uint16_t* wk, const float* bias, uint16_t* out, uint16_t* pool_out, uint8_t* pool_idx,

@@ -52,6 +52,10 @@ struct ConvArgs {
     // the same mask as one 64-bit word per pixel [B][H][W] (bit c = mask[..][c] > 0, written by mk_conv1_fwd): what the
     // fused-conv1-wgrad dgrad reads instead of the map (16 x 16 tiles)
     const unsigned long long* mask_bits;
+    // the 128-channel layout of the same idea: FOUR dwords per pixel [B][H][W][4], dword q = the sign bytes of channel groups
+    // 8q.., 32+8q.., 64+8q.., 96+8q.. (a lane of the streaming kernels masks exactly those).  out_sign_bits: a 128-output-channel
+    // forward launch writes them for its ReLU'd output; a masked 128 <- 128 dgrad given them as mask_bits runs on 32-row tiles
+    unsigned long long* out_sign_bits;
     bf16* out; int B, H, W, CIN, COUT;
     // 64->64 dgrad of the second conv only: fuse the weight gradient of conv1 (x1 = fp32 network input [B][H][W]) into the
     // epilogue; `out` is then never written, w1_slab receives 640 partial sums per workgroup (mk_conv1_wgrad_fused_reduce)
@@ -65,6 +69,7 @@ struct ConvArgs {
     int out_optional;             // the caller does not need `out`: a launch that pools in its epilogue may skip storing it
 };
 int mk_conv3x3(const ConvArgs& a, hipStream_t s);
+bool mk_conv3x3_mask_bits_used(int W);      // does the masked 128 <- 128 dgrad at this map width take mask_bits (else: do not ask for out_sign_bits)
 long mk_conv1_wgrad_fused_slab_floats(int B, int H, int W);
 int mk_conv1_wgrad_fused_reduce(float* slab, int B, int H, int W, float* dw, float* db, hipStream_t s);
 // wgrad: dw[co][ci][3][3] (+ db[co]) from in (NHWC, CIN) and dy (NHWC, COUT)

@@ -115,6 +115,43 @@ def test_conv3x3_mask_and_pool(L, B_, H, W, CIN, COUT):
     assert torch.equal(pool.float(), pref)                       # pooling the stored map is exact
 
 
+def _sign_words(m):
+    """[B,H,W,128] map -> [B,H,W,4] dwords: dword q, byte h, bit j = (channel 32 h + 8 q + j > 0)"""
+    B_, H, W, _ = m.shape
+    pos = (m.float() > 0).reshape(B_, H, W, 4, 4, 8).permute(0, 1, 2, 4, 3, 5).to(torch.int64)        # [.., q, h, j]
+    sh = (8 * torch.arange(4, device=m.device).view(4, 1) + torch.arange(8, device=m.device).view(1, 8)).view(1, 1, 1, 1, 4, 8)
+    return (pos << sh).sum((-1, -2))
+
+
+@pytest.mark.parametrize("B_,H,W", [(2, 37, 40), (1, 64, 21), (3, 250, 40), (2, 33, 41)])     # (41: not an 8-wide-tile width -> fallback paths)
+def test_conv3x3_relu_mask_as_sign_bits(L, B_, H, W):
+    """conv3's forward (64 -> 128) leaves the ReLU mask of its output as four dwords per pixel; conv4's masked dgrad (128 <- 128) reads
+    those instead of the bf16 map and runs on 32-row tiles.  The words must equal the stored map's signs exactly, and the dgrad's output
+    must be identical to the bf16-masked launch's."""
+    g = torch.Generator(device="cuda").manual_seed(H + W)
+    x = torch.randn(B_, H, W, 64, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(128, 64, 3, 3, device="cuda", generator=g) * 0.05).bfloat16()
+    bias = torch.randn(128, device="cuda", generator=g) * 0.3
+    wk = w.permute(0, 2, 3, 1).reshape(128, 9 * 64).contiguous()
+    out = torch.zeros(B_, H, W, 128, device="cuda").bfloat16()
+    bits = torch.full((B_, H, W, 4), -1, device="cuda", dtype=torch.int32)
+    _cabi.check(L.masr_test_conv3x3_sign_bits(P(x), P(wk), P(bias), 1, None, None, P(out), P(bits), B_, H, W, 64, 128, S()))
+    ref = torch.relu(torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias, padding=1)).permute(0, 2, 3, 1)
+    torch.testing.assert_close(out.float(), ref, rtol=1e-2, atol=1e-2)
+    assert torch.equal(bits.to(torch.int64) & 0xFFFFFFFF, _sign_words(out))
+    # the masked dgrad with that map as its mask: bf16 mask vs sign words
+    dy = torch.randn(B_, H, W, 128, device="cuda", generator=g).bfloat16()
+    wd = (torch.randn(128, 128, 3, 3, device="cuda", generator=g) * 0.05).bfloat16()
+    wdk = wd.permute(0, 2, 3, 1).reshape(128, 9 * 128).contiguous()
+    o1 = torch.full((B_, H, W, 128), 7.0, device="cuda").bfloat16()
+    o2 = torch.full((B_, H, W, 128), 9.0, device="cuda").bfloat16()
+    _cabi.check(L.masr_test_conv3x3_sign_bits(P(dy), P(wdk), None, 0, P(out), None, P(o1), None, B_, H, W, 128, 128, S()))
+    _cabi.check(L.masr_test_conv3x3_sign_bits(P(dy), P(wdk), None, 0, P(out), P(bits), P(o2), None, B_, H, W, 128, 128, S()))
+    assert torch.equal(o1, o2)
+    conv = torch.nn.functional.conv2d(dy.float().permute(0, 3, 1, 2), wd.float(), None, padding=1).permute(0, 2, 3, 1)
+    torch.testing.assert_close(o2.float(), torch.where(out.float() > 0, conv, torch.zeros_like(conv)), rtol=1e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("B_,H,W,CIN,COUT", [(2, 38, 80, 64, 64), (3, 50, 40, 128, 128), (2, 301, 80, 64, 64), (1, 17, 48, 128, 128),
                                              (2, 45, 83, 64, 64), (2, 27, 41, 64, 128), (2, 64, 40, 64, 128), (1, 33, 20, 128, 128)])
 def test_conv3x3_pool_codes_and_their_backward(L, B_, H, W, CIN, COUT):
