@@ -513,12 +513,13 @@ def main():
         # pooled map (2 B) and one code byte per pooled element instead of the full-resolution map)
         conv_launch = {
             "conv2_fwd": ("conv3x3_resw_kernel<16,16> (64->64 forward + fused 2x2 max-pool, pooled map + codes out)", c2, B * T * D * 64 * 2 + B * H2 * W2 * 64 * 3),
-            "conv3_fwd": ("conv3x3_stream_kernel<64,128> (64->128 forward)", c3, B * H2 * W2 * (64 + 128) * 2),
+            "conv3_fwd": ("conv3x3_stream_kernel<64,128> (64->128 forward; + the ReLU mask of its output as 16 bytes of sign bits per pixel)", c3, B * H2 * W2 * ((64 + 128) * 2 + 16)),
             "conv4_fwd": ("conv3x3_stream_kernel<128,128> (128->128 forward + fused 2x2 max-pool, pooled map + codes out)", c4, B * H2 * W2 * 128 * 2 + B * (H2 // 2) * (W2 // 2) * 128 * 3),
             # (reads d(conv2 out), the ReLU mask of conv1's output as one 64-bit word per pixel, the fp32 network input; writes 640 sums per workgroup)
             "conv2_dgrad": ("conv3x3_resw_w1x_kernel (64<-64 dgrad on 16x16 tiles + fused conv1 weight gradient)", c2, B * T * D * 64 * 2 + B * T * D * (8 + 4)),
             "conv3_dgrad": ("conv3x3_stream_kernel<128,64> (64<-128 dgrad)", c3, B * H2 * W2 * (128 + 64) * 2),
-            "conv4_dgrad": ("conv3x3_stream_kernel<128,128,mask> (128<-128 dgrad through the ReLU mask)", c4, B * H2 * W2 * 384 * 2),
+            "conv4_dgrad": ("conv3x3_stream_kernel<128,128,32-row tiles,sign-bit mask> (128<-128 dgrad through the ReLU mask)", c4, B * H2 * W2 * (256 * 2 + 16)),
+            # (the wgrad slots time the partial-slab kernel alone; the slab reduces are under conv1_wgrad, "weight-gradient folds")
             "conv2_wgrad": ("conv3x3_wgrad2_kernel<64,64>", c2, 2 * B * T * D * 64 * 2),
             "conv3_wgrad": ("conv3x3_wgrad2_kernel<64,128>", c3, B * H2 * W2 * (64 + 128) * 2),
             "conv4_wgrad": ("conv3x3_wgrad2_kernel<128,128>", c4, B * H2 * W2 * 256 * 2),

@@ -2521,6 +2521,14 @@ __global__ void sign_bits128_kernel(const bf16* __restrict__ map, unsigned* __re
     }
     bits[i] = w;
 }
+// 8-wide tiles for every map width (CIN, COUT <= 128; 64 -> 64 keeps its resident-weight kernel on 16-wide tiles): the streaming
+// kernels of the 128-channel shapes exist on 8-wide tiles only, and they beat the 16-wide patch kernel also where both pad the
+// width alike -- W = 41, the pooled map of the SHIPPED idim 83: conv4 forward 143 -> 100 us, its masked dgrad 134 -> 90 us.
+// MASR_CONV_TW8_STRICT=1: only where 8-wide tiles pad less (W = 40: 40 vs 48 columns), the rule until round 3.
+static bool narrow_w(int W) {
+    static const bool strict = getenv("MASR_CONV_TW8_STRICT") != nullptr;
+    return strict ? (W + 7) / 8 * 8 < (W + 15) / 16 * 16 : true;
+}
 // will a masked 128 <- 128 dgrad on a map of this width read its mask as sign bits (ConvArgs::mask_bits / out_sign_bits)?  Only the
 // streaming kernel on 8-wide, 32-row tiles does; elsewhere the words would be written for nothing.
 bool mk_conv3x3_mask_bits_used(int W) {
@@ -2528,7 +2536,7 @@ bool mk_conv3x3_mask_bits_used(int W) {
     static const bool stream = !(getenv("MASR_CONV_STREAM") && atoi(getenv("MASR_CONV_STREAM")) == 0);
     static const bool th32 = !(getenv("MASR_CONV_TH32") && atoi(getenv("MASR_CONV_TH32")) == 0);
     static const bool v1 = getenv("MASR_CONV_V1") != nullptr;
-    return allow_narrow && stream && th32 && !v1 && (W + 7) / 8 * 8 < (W + 15) / 16 * 16;
+    return allow_narrow && stream && th32 && !v1 && narrow_w(W);
 }
 static int conv3x3_dispatch(const ConvArgs& a, hipStream_t s);
 int mk_conv3x3(const ConvArgs& a0, hipStream_t s) {
@@ -2539,7 +2547,7 @@ int mk_conv3x3(const ConvArgs& a0, hipStream_t s) {
         // stores the map and the codes are computed from it afterwards
         static const bool allow_narrow = !getenv("MASR_CONV_NO_TW8");
         static const bool stream = !(getenv("MASR_CONV_STREAM") && atoi(getenv("MASR_CONV_STREAM")) == 0);
-        const bool narrow = allow_narrow && (a.W + 7) / 8 * 8 < (a.W + 15) / 16 * 16 && a.CIN <= 128 && a.COUT <= 128;
+        const bool narrow = allow_narrow && narrow_w(a.W) && a.CIN <= 128 && a.COUT <= 128;
         const bool in_epilogue = !getenv("MASR_CONV_V1") && !a.prof && stream && !a.x1 && !a.mask && a.CIN <= 128 && a.COUT <= 128 &&
                                  (narrow || (a.CIN == 64 && a.COUT == 64));
         if (!in_epilogue) { idx_after = a.pool_idx; a.pool_idx = nullptr; a.out_optional = 0; }
@@ -2589,7 +2597,7 @@ static int conv3x3_dispatch(const ConvArgs& a, hipStream_t s) {
     }
     // 8-wide tiles when they cover the width with fewer padded columns than 16-wide ones (e.g. W = 40: 40 vs 48)
     static const bool allow_narrow = !getenv("MASR_CONV_NO_TW8");
-    const bool narrow = allow_narrow && (a.W + 7) / 8 * 8 < (a.W + 15) / 16 * 16 && a.CIN <= 128 && a.COUT <= 128;
+    const bool narrow = allow_narrow && narrow_w(a.W) && a.CIN <= 128 && a.COUT <= 128;
     static const bool stream = !(getenv("MASR_CONV_STREAM") && atoi(getenv("MASR_CONV_STREAM")) == 0);
     // (a forward flavour -- bias / ReLU / pool -- and a dgrad flavour -- mask only; anything else takes the patch kernel)
     if (stream && !a.x1 && !(a.mask && (a.bias || a.relu || a.pool_out)) && a.CIN <= 128 && a.COUT <= 128 && (narrow || (a.CIN == 64 && a.COUT == 64))) {
