@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--mixed", action="store_true", help="(default now) time the mixed-length leg (ilens ~ U{200..1500}), reported as \"mixed_lengths\"")
     ap.add_argument("--no-mixed", action="store_true", help="skip the mixed-length leg")
     ap.add_argument("--no-matrix", action="store_true", help="skip the SURVEY 8(d) matrix legs (idim 83, B 32, the 4e2d / E256 geometry), reported as \"matrix\"")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (\"e2e_pretrain\": the pretrain.py --algo fomaml loop WITH its data path, "
+                    "shards on disk -> BucketSampler -> pinned collate -> upload -> tasks -> meta update; tools/bench_pretrain.py in a child process)")
     ap.add_argument("--no-stagger", action="store_true", help="start all concurrent tasks at the same instant (lock-step)")
     ap.add_argument("--no-meta-step", action="store_true", help="skip the whole-meta-step leg (\"meta_step\" in the output)")
     ap.add_argument("--meta-rounds", type=int, default=2, help="task rounds per rank in the meta-step leg (>= 2 shows the all-reduce overlap)")
@@ -613,6 +615,25 @@ def main():
             out["kernel_ms_per_step"] = {k: v[0] / nprof for k, v in prof_all.items()}
         if meta:
             out["meta_step"] = meta
+        if not args.no_e2e and world == 1 and dist is None:
+            # the product loop end to end (not part of `value`, whose inputs are resident in HBM): a child process, because this one
+            # holds K engines and the loop wants the same streams; synthetic shards of the bench shape on local disk
+            import subprocess
+            import tempfile
+            with tempfile.TemporaryDirectory(prefix="masr_e2e_") as td:
+                log("end-to-end pretrain loop (child process) ...")
+                cmd = [sys.executable, str(ROOT / "tools" / "bench_pretrain.py"), "--utts", "512", "--frames", str(T), "--idim", str(D), "--meta-steps", "40",
+                       "--warm", "5", "--configs", f"host:{K}", "--root", td]
+                try:
+                    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                    e2e = json.loads(r.stdout.strip().splitlines()[-1])
+                    res = e2e["results"][0]
+                    out["e2e_pretrain"] = {"value": res["utt_per_s"], "unit": "utt/s", "ms_per_meta_step": res["ms_per_meta_step"], "meta_steps": res["meta_steps"],
+                                           "tasks_per_gpu": res["tasks_per_gpu"], "shards": "host memmap (local disk), pinned collate, one DMA per batch",
+                                           "workload": e2e["workload"], "command": " ".join(cmd[1:-2])}
+                    log(f"end-to-end: {res['utt_per_s']:.0f} utt/s")
+                except Exception as ex:                              # never fail the bench line over the extra leg
+                    out["e2e_pretrain"] = {"error": f"{type(ex).__name__}: {ex}"}
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline (oracle on host cores) ...")
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch, T, D, args.cpu_steps)

@@ -59,7 +59,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--tasks-per-gpu", "2",
-                        "--no-cpu-baseline", "--long-seconds", "0.3", "--meta-steps", "2", "--no-matrix", "--no-mixed"], cwd=tmp_path, env=env, capture_output=True, text=True,
+                        "--no-cpu-baseline", "--long-seconds", "0.3", "--meta-steps", "2", "--no-matrix", "--no-mixed", "--no-e2e"], cwd=tmp_path, env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]

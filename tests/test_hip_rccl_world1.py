@@ -69,7 +69,7 @@ def test_bench_collective_legs_through_rccl_with_one_rank(tmp_path):
     through RCCL with one rank -- what the driver's multi-GPU bench will execute first, minus the other ranks."""
     import json
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "4", "--warmup", "2", "--tasks-per-gpu", "2", "--no-cpu-baseline",
-                        "--long-seconds", "0", "--meta-steps", "2", "--no-matrix", "--no-mixed"], cwd=tmp_path, env=_env(MASR_FORCE_COLLECTIVE="1"),
+                        "--long-seconds", "0", "--meta-steps", "2", "--no-matrix", "--no-mixed", "--no-e2e"], cwd=tmp_path, env=_env(MASR_FORCE_COLLECTIVE="1"),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]

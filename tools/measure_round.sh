@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 O=gpurun_out
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err && echo "bench done" && tail -c 400 $O/bench_default.json
 rm -rf $O/prof_k4 $O/prof_single $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
-Q="--no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --no-matrix --no-mixed"
+Q="--no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --no-matrix --no-mixed --no-e2e"
 rocprofv3 --kernel-trace --stats -d $O/prof_k4 -o k4 --output-format csv -- python3 bench.py --steps 30 --warmup 5 $Q > $O/prof_k4.log 2>&1 && echo "k4 profile done"
 rocprofv3 --kernel-trace --stats -d $O/prof_single -o s --output-format csv -- python3 bench.py --steps 30 --warmup 5 $Q --tasks-per-gpu 1 > $O/prof_single.log 2>&1 && echo "single profile done"
 for C in FETCH_SIZE WRITE_SIZE; do

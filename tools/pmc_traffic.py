@@ -51,7 +51,7 @@ def main():
                       "means over the dispatches of the traced steps",
           "workload": {"batch": 16, "frames": 1000, "idim": 80},
           "collected": f"{tag} @ {sha}",
-          "command": "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --no-matrix --no-mixed --tasks-per-gpu 1",
+          "command": "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --no-matrix --no-mixed --no-e2e --tasks-per-gpu 1",
           "kernels": kernels,
           "raw_KiB": {"FETCH_SIZE": fetch, "WRITE_SIZE": write}}
     Path("profiles/pmc_traffic.json").write_text(json.dumps(js, indent=1) + "\n")

@@ -31,9 +31,9 @@ sg = glob.glob(str(g / "prof_single/**/*kernel_stats.csv"), recursive=True)[0]
 shutil.copy(k4, out / f"{tag}_bench_kernel_stats.csv")
 shutil.copy(sg, out / f"{tag}_single_task_kernel_stats.csv")
 summary(k4, 35 * 4 + 15,
-        "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --no-matrix --no-mixed  (MI355X, default = 4 concurrent tasks; + the 10+5-step single-task leg)",
+        "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --no-matrix --no-mixed --no-e2e  (MI355X, default = 4 concurrent tasks; + the 10+5-step single-task leg)",
         out / f"{tag}_bench_kernel_stats.txt")
 summary(sg, 35,
-        "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --no-matrix --no-mixed --tasks-per-gpu 1  (MI355X, one task per GPU)",
+        "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --no-matrix --no-mixed --no-e2e --tasks-per-gpu 1  (MI355X, one task per GPU)",
         out / f"{tag}_single_task_kernel_stats.txt")
 print("saved")
