@@ -228,6 +228,7 @@ def main():
             self.eng = MasrEngine(cfg, ODIM, label_smoothing=0.2, device=dev)
             self.eng.load_state_dict(sd0)
             self.eng.set_seed(531 + rank * 64 + k)
+            self.eng.set_concurrency(K)
             xs, self.il, self.ys, self.ol = synth_batch(B, T, D, seed=rank * 64 + k)   # numpy seed 0 + task index
             self.xs = xs.to(dev)
             self.mom = torch.zeros_like(self.eng.params)
@@ -292,7 +293,9 @@ def main():
     single = None
     if K > 1:
         n1 = max(5, args.steps // 3)
+        tasks[0].eng.set_concurrency(1)                          # (a model that has the GPU to itself: masr_set_concurrency)
         dt1 = timed(tasks[:1], n1, args.warmup)
+        tasks[0].eng.set_concurrency(K)
         single = {"value": world * B * n1 / dt1, "ms_per_step": dt1 / n1 * 1e3, "steps": n1}
         log(f"single task per GPU: {single['value']:.1f} utt/s")
     stagger = 0.0
@@ -504,6 +507,7 @@ def main():
     prof_all = None
     nprof = 5
     if rank == 0 and not args.no_profile:
+        eng.set_concurrency(1)
         eng.profile(True)
         for i in range(nprof):
             step(i)

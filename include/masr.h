@@ -54,6 +54,9 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
 /* rebuild the bf16 operand shadows after ANY change of params (load_state_dict, optimizer step) */
 int masr_refresh(masr_model* m, void* stream);
 void masr_set_seed(masr_model* m, uint64_t seed);      /* dropout stream */
+/* hint: this model is one of `slots` task slots running concurrently on the GPU (pretrain.py --tasks_per_gpu).  Results do not depend
+ * on it beyond the summation order of the encoder-row weight gradients (split-K 2 instead of 4 when the chip is shared). */
+void masr_set_concurrency(masr_model* m, int slots);
 /* the dropout stream's position: state[0] = seed, state[1] = batches run since masr_set_seed (every run_batch derives its masks
  * from both); set != 0 writes it.  For checkpoints: a resumed run continues the mask stream where the saved one stopped. */
 void masr_dropout_state(masr_model* m, uint64_t state[2], int set);

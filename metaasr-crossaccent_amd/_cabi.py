@@ -28,6 +28,7 @@ _SIGS = {
     "masr_bind": (i32, [vp, vp, vp, vp, vp, i64]),
     "masr_refresh": (i32, [vp, vp]),
     "masr_set_seed": (None, [vp, C.c_uint64]),
+    "masr_set_concurrency": (None, [vp, i32]),
     "masr_dropout_state": (None, [vp, C.POINTER(C.c_uint64), i32]),
     "masr_run_batch": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "masr_set_step_graphs": (None, [vp, i32]),

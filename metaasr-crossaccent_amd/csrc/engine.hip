@@ -72,10 +72,11 @@ struct Acts {
     float* wg_slab;                                        // split-K partials: (WG_SPLIT-1) x nparams
 };
 constexpr int WG_SPLIT_MAX = 4;
-// split-K factor of the encoder-row weight gradients (MASR_WG_SPLIT = 1..4 for A/B runs).  2: with four task slots per GPU the chip is
-// full anyway and every extra partial slab is 90 MB written and read again by the combine pass -- measured, 4 tasks / single task
-// utt/s: split 4: 8 440 / 5 485, split 2: 8 530 / 5 435, no split: 8 460-8 490 / 5 380
-static const int WG_SPLIT = [] { const char* e = getenv("MASR_WG_SPLIT"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > WG_SPLIT_MAX ? WG_SPLIT_MAX : v); }();
+// split-K factor of the encoder-row weight gradients: per model (masr_set_concurrency), 4 for a model that has the GPU to itself, 2 for
+// one of several task slots -- with four slots the chip is full anyway and every extra partial slab is 90 MB written and read again
+// by the combine pass.  Measured, 4 tasks / single task utt/s: split 4: 8 440 / 5 485, split 2: 8 530 / 5 435, none: 8 475 / 5 380.
+// MASR_WG_SPLIT = 1..4 overrides both (A/B runs).
+static const int WG_SPLIT_ENV = [] { const char* e = getenv("MASR_WG_SPLIT"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > WG_SPLIT_MAX ? WG_SPLIT_MAX : v); }();
 
 }  // namespace
 
@@ -102,6 +103,7 @@ struct masr_model {
     float* h_ring = nullptr; hipEvent_t ring_ev[RING]; bool ring_used[RING]; int64_t ring_next = 0;
     int* h_stage = nullptr; int64_t stage_ints = 0; int stage_slot = 0; hipEvent_t stage_ev[4];
     uint64_t seed = 0x1234; uint64_t step = 0;
+    int wg_split = WG_SPLIT_ENV ? WG_SPLIT_ENV : 4;       // split-K of the encoder-row weight gradients (masr_set_concurrency)
     Acts acts; bool have_acts = false;
     LnReduceGroup lng; int64_t ln_slab_used = 0;           // LayerNorm dgamma/dbeta partials, folded by one grouped launch
     WgradGroup wg; bool wg_defer = false;                  // decoder-row weight gradients collected for one grouped launch
@@ -318,7 +320,7 @@ int lin_wgrad(Ctx& c, const bf16* dy, long lddy, const bf16* x, long ldx, int ro
     // long reductions (encoder rows B*T') are split over WG_SPLIT workgroups with slab partials that
     // mk_split_reduce combines in fixed order; decoder-row reductions (B*L) are short and stay whole
     if (split && dW >= m->G && dW < m->G + m->nparams) {
-        g.split_k = WG_SPLIT; g.split_delta = m->acts.wg_slab - m->G; g.split_stride = m->nparams;
+        g.split_k = m->wg_split; g.split_delta = m->acts.wg_slab - m->G; g.split_stride = m->nparams;
     }
     CK(gemm(c, g));
     return 0;
@@ -563,6 +565,7 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
 }
 
 void masr_set_seed(masr_model* m, uint64_t seed) { m->seed = seed; m->step = 0; }
+void masr_set_concurrency(masr_model* m, int slots) { if (!WG_SPLIT_ENV) m->wg_split = slots > 1 ? 2 : 4; }
 void masr_dropout_state(masr_model* m, uint64_t state[2], int set) {
     if (set) { m->seed = state[0]; m->step = state[1]; } else { state[0] = m->seed; state[1] = m->step; }
 }
@@ -705,7 +708,7 @@ static int memory_kv_bwd(Ctx& c) {
     g.reduction_major = 1; g.A = a.gkv_all; g.lda = m->NK; g.B = a.mem16; g.ldb = E; g.M = m->NK; g.N = E; g.K = a.rows_e;
     g.C32 = G + d0.ca.in.w + (long)E * E; g.ldc = E; g.colsum = G + d0.ca.in.b + E;
     g.cseg_rows = 2 * E; g.cseg_stride = m->ND > 1 ? m->dec[1].ca.in.w - d0.ca.in.w : 0;
-    g.split_k = WG_SPLIT; g.split_delta = a.wg_slab - G; g.split_stride = m->nparams;
+    g.split_k = m->wg_split; g.split_delta = a.wg_slab - G; g.split_stride = m->nparams;
     CK(gemm(c, g));
     GemmArgs h = lin_dgrad_args(a.gkv_all, m->NK, m->kvT, m->NK, a.rows_e, m->NK, E);
     h.C32 = a.dmem32; h.ldc = E;
@@ -794,7 +797,7 @@ static int backward(Ctx& c, const float* xs) {
     CK(flush_ln_reduce(c));
     // ---- combine the split-K partials of all Linear gradients, then add the embedding rows into the (tied) table
     { Prof p(m, MASR_PROF_MISC, s);
-      if (WG_SPLIT > 1) CK(mk_split_reduce(G, a.wg_slab, WG_SPLIT - 1, m->nparams, m->d_ranges, m->nranges, s));
+      if (m->wg_split > 1) CK(mk_split_reduce(G, a.wg_slab, m->wg_split - 1, m->nparams, m->d_ranges, m->nranges, s));
       CK(mk_embed_bwd(a.tok_in, g_dec_in, G + m->embed_w, a.rows_d, m->C, E, m->cfg.tie_weights ? 1 : 0, c.p_pos, c.seed, a.site_emb, s, c.seed_ptr)); }
     return 0;
 }

@@ -157,6 +157,10 @@ class MasrEngine:
     def set_seed(self, seed: int):
         self._l.masr_set_seed(self.h, C.c_uint64(seed & (2 ** 64 - 1)))
 
+    def set_concurrency(self, slots: int):
+        """this engine is one of `slots` task slots sharing the GPU (include/masr.h masr_set_concurrency)"""
+        self._l.masr_set_concurrency(self.h, int(slots))
+
     def dropout_state(self):
         """(seed, batches run since set_seed): the position of the dropout mask stream (include/masr.h masr_dropout_state)"""
         st = (C.c_uint64 * 2)()

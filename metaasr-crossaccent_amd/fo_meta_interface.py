@@ -170,6 +170,8 @@ class FOMetaASRInterface(PretrainInterface):
         self._slots = [{'model': m, 'engine': m.engine, 'stream': st} for m, st in zip(models, streams)]
         for i, sl in enumerate(self._slots):                                 # one dropout stream per (rank, slot)
             sl['engine'].set_seed(getattr(self.paras, 'seed', 531) + 7919 * (self.sharder.rank * self.tasks_per_gpu + i))
+            if hasattr(sl['engine'], 'set_concurrency'):
+                sl['engine'].set_concurrency(self.tasks_per_gpu)
 
     def write_tr_logs(self):
         for k, v in self.train_info.items():

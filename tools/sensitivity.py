@@ -26,7 +26,7 @@ def run(cfg, B, T, K, steps, warm=5):
     tasks = []
     for k in range(K):
         e = MasrEngine(cfg, ODIM, label_smoothing=0.2, device=dev)
-        e.load_state_dict(sd); e.set_seed(531 + k)
+        e.load_state_dict(sd); e.set_seed(531 + k); e.set_concurrency(K)
         xs, il, ys, ol = synth_batch(B, T, cfg["idim"], seed=k)
         tasks.append(dict(e=e, xs=xs.to(dev), il=il, ys=ys, ol=ol, mom=torch.zeros_like(e.params),
                           st=torch.cuda.current_stream(dev) if k == 0 else STREAMS[k - 1]))
