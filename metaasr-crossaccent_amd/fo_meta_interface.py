@@ -281,7 +281,7 @@ class FOMetaASRInterface(PretrainInterface):
         else:
             self._sum_n(eng, contrib, [e.grads for e in engines], 1.0)
         self.sharder.reduce_async(contrib, side_stream=False)
-        self._n_reduces += 1
+        self._n_reduces = getattr(self, '_n_reduces', 0) + 1
         if self._updates is None:
             self._updates = []
         self._updates.append(contrib)
@@ -402,7 +402,7 @@ class FOMetaASRInterface(PretrainInterface):
         else:
             contrib = eng.grads.clone()                                   # per-task buffer handed to the side stream
         self.sharder.reduce_async(contrib)                              # side stream: overlaps this rank's next task
-        self._n_reduces += 1
+        self._n_reduces = getattr(self, '_n_reduces', 0) + 1
         self._updates.append(contrib)
 
     def _pad_rounds(self, n_tasks, n_local):
@@ -410,11 +410,12 @@ class FOMetaASRInterface(PretrainInterface):
         ceil(n_tasks / world) contribute zero buffers for the missing rounds"""
         if not self.sharder.collective:
             return
+        K = getattr(self, 'tasks_per_gpu', 1)
         rounds = (n_tasks + self.sharder.world - 1) // self.sharder.world          # tasks of the busiest rank ...
-        rounds = (rounds + self.tasks_per_gpu - 1) // self.tasks_per_gpu             # ... = its waves = its all-reduces
-        for _ in range(rounds - self._n_reduces):
+        rounds = (rounds + K - 1) // K                                               # ... = its waves = its all-reduces
+        for _ in range(rounds - getattr(self, '_n_reduces', 0)):
             z = torch.zeros_like(self.asr_model.engine.params)
-            self.sharder.reduce_async(z, side_stream=self.tasks_per_gpu == 1)
+            self.sharder.reduce_async(z, side_stream=K == 1)
             if self._updates is None:
                 self._updates = []
             self._updates.append(z)
