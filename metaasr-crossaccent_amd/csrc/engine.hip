@@ -46,6 +46,7 @@ struct DecAct {
 };
 // per-decoder-layer bf16 gradient operands of the deferred (grouped) weight-gradient launch
 struct DecGrad { bf16 *g3, *g2, *g1, *gf, *gq, *gqkv; };
+struct EncGrad { bf16 *g2, *g1, *gf, *gqkv; };          // per-layer gradient operands of the encoder-row weight gradients (kept for the grouped launch)
 struct Acts {
     int B, T, D, H2, W2, Tp, Dp, L, rows_e, rows_d;
     int *tok_in, *gold, *enc_lens, *step_dev;
@@ -67,6 +68,7 @@ struct Acts {
     bf16 *ge16, *gqkv_e, *gf_e, *gao_e, *gao_d, *gkv_all, *dp2, *da4, *da3, *dp1, *da2, *da1;
     float *delta_e, *delta_d;
     std::vector<DecGrad> dgr;
+    std::vector<EncGrad> egr;
     float* slab; int64_t slab_floats;
     float* ln_slab; int64_t ln_slab_floats;                // one region per LayerNorm backward (grouped reduce)
     float* wg_slab;                                        // split-K partials: (WG_SPLIT-1) x nparams
@@ -107,6 +109,9 @@ struct masr_model {
     Acts acts; bool have_acts = false;
     LnReduceGroup lng; int64_t ln_slab_used = 0;           // LayerNorm dgamma/dbeta partials, folded by one grouped launch
     WgradGroup wg; bool wg_defer = false;                  // decoder-row weight gradients collected for one grouped launch
+    // ... and the encoder-row ones (reduction over B*T' rows): ONE grid of 128 x 128 tiles over all of them at the end of the backward
+    // pass instead of ten split-K launches of 64-192 workgroups each + a combine pass over the partial slabs
+    WgradGroup wge; bool wge_defer = false;
     // captured training / evaluation steps (masr_run_batch, opt-in): a batch shape that repeats is replayed as ONE graph launch
     // instead of ~150 kernel launches.  Measured: host enqueue 0.61 -> 0.11 ms per step, step time unchanged (the GPU, not the
     // launch path, bounds both the single-task and the 4-task mode: tools/host_launch_cost.py) -- hence off by default
@@ -255,6 +260,8 @@ void plan_acts(const masr_model* m, Arena& ar, Acts& a, int B, int T, int L, boo
         a.gao_e = ar.get<bf16>(re * E); a.gao_d = ar.get<bf16>(rd * E);
         a.gkv_all = ar.get<bf16>(re * m->NK);
         a.delta_e = ar.get<float>((int64_t)B * H * a.Tp); a.delta_d = ar.get<float>((int64_t)B * H * L);
+        a.egr.resize(m->NE);
+        for (auto& g : a.egr) { g.g2 = ar.get<bf16>(re * E); g.g1 = ar.get<bf16>(re * E); g.gf = ar.get<bf16>(re * Fi); g.gqkv = ar.get<bf16>(re * 3 * E); }
         a.dgr.resize(m->ND);
         for (auto& g : a.dgr) {
             g.g3 = ar.get<bf16>(rd * E); g.g2 = ar.get<bf16>(rd * E); g.g1 = ar.get<bf16>(rd * E);
@@ -309,6 +316,11 @@ int gemm(Ctx& c, const GemmArgs& g) {
 int lin_wgrad(Ctx& c, const bf16* dy, long lddy, const bf16* x, long ldx, int rows, int N, int K, float* dW, float* db, bool split = false,
               int accumulate = 0) {
     masr_model* m = c.m;
+    if (split && m->wge_defer && !accumulate && m->wge.n < WGRAD_GROUP_MAX) {      // encoder rows: joins the grouped launch of flush_enc_wgrads
+        WgradDesc& d = m->wge.p[m->wge.n++];
+        d.dy = dy; d.x = x; d.dW = dW; d.db = db; d.lddy = (int)lddy; d.ldx = (int)ldx; d.rows = rows; d.N = N; d.K = K; d.tile_start = 0;
+        return 0;
+    }
     if (m->wg_defer && !split && !accumulate && m->wg.n < WGRAD_GROUP_MAX) {      // joins the grouped launch (flush_wgrads)
         WgradDesc& d = m->wg.p[m->wg.n++];
         d.dy = dy; d.x = x; d.dW = dW; d.db = db; d.lddy = (int)lddy; d.ldx = (int)ldx; d.rows = rows; d.N = N; d.K = K; d.tile_start = 0;
@@ -319,11 +331,20 @@ int lin_wgrad(Ctx& c, const bf16* dy, long lddy, const bf16* x, long ldx, int ro
     g.C32 = dW; g.ldc = K; g.accumulate = accumulate; g.colsum = db;
     // long reductions (encoder rows B*T') are split over WG_SPLIT workgroups with slab partials that
     // mk_split_reduce combines in fixed order; decoder-row reductions (B*L) are short and stay whole
-    if (split && dW >= m->G && dW < m->G + m->nparams) {
+    if (split && !m->wge_defer && dW >= m->G && dW < m->G + m->nparams) {      // (with the grouped launch on, an overflowing group member runs whole)
         g.split_k = m->wg_split; g.split_delta = m->acts.wg_slab - m->G; g.split_stride = m->nparams;
     }
     CK(gemm(c, g));
     return 0;
+}
+int flush_enc_wgrads(Ctx& c) {
+    masr_model* m = c.m;
+    if (m->wge.n == 0) return 0;
+    Prof p(m, MASR_PROF_WGRAD_ENC, c.s);
+    static const int tile = getenv("MASR_ENC_WGRAD_TILE") ? atoi(getenv("MASR_ENC_WGRAD_TILE")) : 128;      // (A/B: 64)
+    const int rc = mk_gemm_wgrad_grouped(m->wge, c.s, tile);
+    m->wge.n = 0;
+    return rc;
 }
 int flush_wgrads(Ctx& c) {
     masr_model* m = c.m;
@@ -704,12 +725,18 @@ static int memory_kv_bwd(Ctx& c) {
     masr_model* m = c.m; Acts& a = m->acts; float* G = m->G;
     const int E = m->E;
     const DecL& d0 = m->dec[0];
-    GemmArgs g = gemm_args();
-    g.reduction_major = 1; g.A = a.gkv_all; g.lda = m->NK; g.B = a.mem16; g.ldb = E; g.M = m->NK; g.N = E; g.K = a.rows_e;
-    g.C32 = G + d0.ca.in.w + (long)E * E; g.ldc = E; g.colsum = G + d0.ca.in.b + E;
-    g.cseg_rows = 2 * E; g.cseg_stride = m->ND > 1 ? m->dec[1].ca.in.w - d0.ca.in.w : 0;
-    g.split_k = m->wg_split; g.split_delta = a.wg_slab - G; g.split_stride = m->nparams;
-    CK(gemm(c, g));
+    if (m->wge_defer && m->wge.n + m->ND <= WGRAD_GROUP_MAX) {
+        // one descriptor per decoder layer in the grouped encoder-row launch (gkv_all stays untouched until the end of the pass)
+        for (int l = 0; l < m->ND; ++l)
+            CK(lin_wgrad(c, a.gkv_all + (int64_t)l * 2 * E, m->NK, a.mem16, E, a.rows_e, 2 * E, E, G + m->dec[l].ca.in.w + (long)E * E, G + m->dec[l].ca.in.b + E, true));
+    } else {
+        GemmArgs g = gemm_args();
+        g.reduction_major = 1; g.A = a.gkv_all; g.lda = m->NK; g.B = a.mem16; g.ldb = E; g.M = m->NK; g.N = E; g.K = a.rows_e;
+        g.C32 = G + d0.ca.in.w + (long)E * E; g.ldc = E; g.colsum = G + d0.ca.in.b + E;
+        g.cseg_rows = 2 * E; g.cseg_stride = m->ND > 1 ? m->dec[1].ca.in.w - d0.ca.in.w : 0;
+        if (!m->wge_defer) { g.split_k = m->wg_split; g.split_delta = a.wg_slab - G; g.split_stride = m->nparams; }
+        CK(gemm(c, g));
+    }
     GemmArgs h = lin_dgrad_args(a.gkv_all, m->NK, m->kvT, m->NK, a.rows_e, m->NK, E);
     h.C32 = a.dmem32; h.ldc = E;
     CK(gemm(c, h));
@@ -723,6 +750,8 @@ static int backward(Ctx& c, const float* xs) {
     // launched one by one: their operands are kept per layer and ONE grouped launch computes them after the layer loop
     static const bool group_wgrads = !getenv("MASR_NO_GROUPED_WGRAD");
     m->wg.n = 0; m->wg_defer = group_wgrads;
+    static const bool group_enc = !getenv("MASR_NO_GROUPED_ENC_WGRAD");
+    m->wge.n = 0; m->wge_defer = group_enc;
     m->lng.n = 0; m->ln_slab_used = 0;
     CK(lin_wgrad(c, a.dlogits, m->Cp, a.yf16, E, a.rows_d, m->C, E, G + m->ct.w, G + m->ct.b));
     { GemmArgs g = lin_dgrad_args(a.dlogits, m->Cp, m->ct.t16, m->Cp, a.rows_d, m->Cp, E); g.C32 = a.gd_a; g.ldc = E; CK(gemm(c, g)); }
@@ -748,15 +777,18 @@ static int backward(Ctx& c, const float* xs) {
     CK(ln_bwd(c, m->enc_norm, a.dmem32, a.x32[m->NE], a.mf, a.rf, gcur, nullptr, 0, a.rows_e));
     for (int l = m->NE - 1; l >= 0; --l) {
         EncAct& e = a.enc[l]; const EncL& w = m->enc[l];
-        CK(ln_bwd(c, w.n2, gcur, e.s2, e.m2, e.r2, gs, a.ge16, e.site[3], a.rows_e));
-        CK(ffn_bwd(c, w.l1, w.l2, e.x1_16, e.f, gs, a.ge16, a.rows_e, a.gf_e, gcur, true));
-        CK(ln_bwd(c, w.n1, gcur, e.s1, e.m1, e.r1, gs, a.ge16, e.site[1], a.rows_e));
-        CK(attn_block_bwd(c, w.sa, a.x16[l], nullptr, a.rows_e, 0, a.Tp, a.Tp, true, false, a.enc_lens, e.qkv, nullptr, e.ao, e.lse, gs, a.ge16,
-                          a.gao_e, a.gqkv_e, nullptr, a.delta_e, gcur, nullptr, 0, e.site[0], true));
+        // (grouped weight gradients read their dY operands at the END of the pass: every layer keeps its own)
+        const EncGrad eg = m->wge_defer ? a.egr[l] : EncGrad{a.ge16, a.ge16, a.gf_e, a.gqkv_e};
+        CK(ln_bwd(c, w.n2, gcur, e.s2, e.m2, e.r2, gs, eg.g2, e.site[3], a.rows_e));
+        CK(ffn_bwd(c, w.l1, w.l2, e.x1_16, e.f, gs, eg.g2, a.rows_e, eg.gf, gcur, true));
+        CK(ln_bwd(c, w.n1, gcur, e.s1, e.m1, e.r1, gs, eg.g1, e.site[1], a.rows_e));
+        CK(attn_block_bwd(c, w.sa, a.x16[l], nullptr, a.rows_e, 0, a.Tp, a.Tp, true, false, a.enc_lens, e.qkv, nullptr, e.ao, e.lse, gs, eg.g1,
+                          a.gao_e, eg.gqkv, nullptr, a.delta_e, gcur, nullptr, 0, e.site[0], true));
     }
     // ---- vgg2enc (through the positional dropout)
     { Prof p(m, MASR_PROF_MISC, s); CK(mk_cast_dropout(gcur, a.ge16, (long)a.rows_e * E, c.p_pos, c.seed, a.site_v2e, s, c.seed_ptr)); }
-    CK(lin_wgrad(c, a.ge16, E, a.p2, m->F, a.rows_e, E, m->F, a.v2e_g32, G + m->v2e.b));
+    CK(lin_wgrad(c, a.ge16, E, a.p2, m->F, a.rows_e, E, m->F, a.v2e_g32, G + m->v2e.b, m->wge_defer));
+    CK(flush_enc_wgrads(c));                                 // every encoder-row weight gradient of the step, one grid
     { Prof p(m, MASR_PROF_MISC, s); CK(mk_vgg2enc_grad_unpermute(a.v2e_g32, G + m->v2e.w, E, 128, m->Dp, s)); }
     { GemmArgs g = lin_dgrad_args(a.ge16, E, m->v2e.t16, E, a.rows_e, E, m->F); g.C16 = a.dp2; g.ldc16 = m->F; CK(gemm(c, g)); }
     // ---- VGG
@@ -797,7 +829,7 @@ static int backward(Ctx& c, const float* xs) {
     CK(flush_ln_reduce(c));
     // ---- combine the split-K partials of all Linear gradients, then add the embedding rows into the (tied) table
     { Prof p(m, MASR_PROF_MISC, s);
-      if (m->wg_split > 1) CK(mk_split_reduce(G, a.wg_slab, m->wg_split - 1, m->nparams, m->d_ranges, m->nranges, s));
+      if (m->wg_split > 1 && !m->wge_defer) CK(mk_split_reduce(G, a.wg_slab, m->wg_split - 1, m->nparams, m->d_ranges, m->nranges, s));
       CK(mk_embed_bwd(a.tok_in, g_dec_in, G + m->embed_w, a.rows_d, m->C, E, m->cfg.tie_weights ? 1 : 0, c.p_pos, c.seed, a.site_emb, s, c.seed_ptr)); }
     return 0;
 }

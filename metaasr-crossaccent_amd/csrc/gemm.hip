@@ -563,8 +563,9 @@ int launch_tile(const GemmArgs& g_in, hipStream_t s) {
 
 }  // namespace
 
-int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s) {
+int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s, int tile) {
     if (grp.n <= 0) return 0;
+    if (tile != 64 && tile != 128) { mk_set_error("mk_gemm_wgrad_grouped", "tile 64 or 128"); return -1; }
     int tiles = 0;
     for (int i = 0; i < grp.n; ++i) {
         WgradDesc& d = grp.p[i];
@@ -572,9 +573,10 @@ int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s) {
             mk_set_error("mk_gemm_wgrad_grouped", "operands must be 16-byte aligned with padded rows"); return -1;
         }
         d.tile_start = tiles;
-        tiles += ((d.N + 63) / 64) * ((d.K + 63) / 64);
+        tiles += ((d.N + tile - 1) / tile) * ((d.K + tile - 1) / tile);
     }
-    hipLaunchKernelGGL((gemm_wgrad_grouped_kernel<64, 64>), dim3(tiles), dim3(256), 0, s, grp);
+    if (tile == 64) hipLaunchKernelGGL((gemm_wgrad_grouped_kernel<64, 64>), dim3(tiles), dim3(256), 0, s, grp);
+    else hipLaunchKernelGGL((gemm_wgrad_grouped_kernel<128, 128>), dim3(tiles), dim3(256), 0, s, grp);
     if (hipGetLastError() != hipSuccess) { mk_set_error("mk_gemm_wgrad_grouped", "launch failed"); return -1; }
     return 0;
 }

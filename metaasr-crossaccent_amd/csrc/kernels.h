@@ -36,7 +36,7 @@ int mk_gemm(const GemmArgs& g, hipStream_t s);
 struct WgradDesc { const bf16* dy; const bf16* x; float* dW; float* db; int lddy, ldx, rows, N, K, tile_start; };
 constexpr int WGRAD_GROUP_MAX = 40;
 struct WgradGroup { int n; WgradDesc p[WGRAD_GROUP_MAX]; };
-int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s);       // fills tile_start
+int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s, int tile = 64);       // fills tile_start; tile = 64 (short reductions) or 128
 inline GemmArgs gemm_args() { GemmArgs g{}; g.alpha = 1.f; g.mask_scale = 1.f; return g; }
 
 // ---------------------------------------------------------------- conv front-end (conv.hip)
