@@ -546,12 +546,24 @@ def main():
             launches[name] = {"kernel": kern, "avg_launch_ms": per, "gflop_per_launch": flops / 1e9, "tflops": flops / (per * 1e-3) / 1e12,
                               "frac_of_bf16_peak": flops / (per * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "algorithmic_bytes": abytes,
                               "traffic_bytes": pmc.get(name)}
+        # the encoder-row Linear weight gradients are ONE launch since round 3 (gemm_wgrad_grouped_kernel<128,128>): a candidate too
+        ms_w, n_w = prof_all["wgrad_enc"]
+        if n_w == nprof:                                         # (one launch per step: the grouped path is on)
+            E_, F_, Tp_ = cfg["d_model"], cfg["d_inner"], T // 4
+            shapes = [(3 * E_, E_), (E_, E_), (F_, E_), (E_, F_)] * cfg["encoder"]["nlayers"] + [(E_, 128 * (D // 4))] + [(2 * E_, E_)] * cfg["decoder"]["nlayers"]
+            rows = B * Tp_
+            fl = sum(2.0 * rows * n_ * k_ for n_, k_ in shapes)
+            by = sum(rows * (n_ + k_) * 2 + n_ * k_ * 4 for n_, k_ in shapes)
+            per = ms_w / n_w
+            launches["wgrad_enc"] = {"kernel": "gemm_wgrad_grouped_kernel<128,128> (ALL encoder-row Linear weight gradients of the step, %d GEMMs dW = dY^T X over %d rows, one grid of 128x128 tiles)" % (len(shapes), rows),
+                                     "avg_launch_ms": per, "gflop_per_launch": fl / 1e9, "tflops": fl / (per * 1e-3) / 1e12,
+                                     "frac_of_bf16_peak": fl / (per * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "algorithmic_bytes": by, "traffic_bytes": pmc.get("wgrad_enc")}
         dom = max(launches, key=lambda k: launches[k]["avg_launch_ms"])
         d = launches[dom]
         roof = {"bound": "mfma", "kernel": d["kernel"], "slot": dom, "achieved": d["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": d["frac_of_bf16_peak"], "traffic": d["traffic_bytes"], "traffic_source": pmc_src if d["traffic_bytes"] else None,
                 "algorithmic_bytes": d["algorithmic_bytes"], "avg_launch_ms": d["avg_launch_ms"], "flops_per_launch": d["gflop_per_launch"] * 1e9,
-                "selection": "longest single launch of the step at this commit (all conv launches are listed under \"launches\")",
+                "selection": "longest single launch of the step at this commit (every chip-filling launch that is timed alone is listed under \"launches\": the nine conv launches and the grouped encoder-row weight-gradient GEMM)",
                 "launches": launches}
         # per-class table of ONE single-task step: algorithmic FLOPs (forward x 3; conv1 has no dgrad) vs measured kernel time
         Lmax = int(max(tasks[0].ol)) + 1

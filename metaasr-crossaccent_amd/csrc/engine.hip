@@ -787,7 +787,8 @@ static int backward(Ctx& c, const float* xs) {
     }
     // ---- vgg2enc (through the positional dropout)
     { Prof p(m, MASR_PROF_MISC, s); CK(mk_cast_dropout(gcur, a.ge16, (long)a.rows_e * E, c.p_pos, c.seed, a.site_v2e, s, c.seed_ptr)); }
-    CK(lin_wgrad(c, a.ge16, E, a.p2, m->F, a.rows_e, E, m->F, a.v2e_g32, G + m->v2e.b, m->wge_defer));
+    static const bool v2e_sep = getenv("MASR_V2E_SEPARATE") != nullptr;                // (A/B: keep vgg2enc's 80 tiles out of the 512-slot grid)
+    CK(lin_wgrad(c, a.ge16, E, a.p2, m->F, a.rows_e, E, m->F, a.v2e_g32, G + m->v2e.b, m->wge_defer && !v2e_sep));
     CK(flush_enc_wgrads(c));                                 // every encoder-row weight gradient of the step, one grid
     { Prof p(m, MASR_PROF_MISC, s); CK(mk_vgg2enc_grad_unpermute(a.v2e_g32, G + m->v2e.w, E, 128, m->Dp, s)); }
     { GemmArgs g = lin_dgrad_args(a.ge16, E, m->v2e.t16, E, a.rows_e, E, m->F); g.C16 = a.dp2; g.ldc16 = m->F; CK(gemm(c, g)); }

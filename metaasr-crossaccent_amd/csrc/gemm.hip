@@ -384,13 +384,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 // they fill the chip.  The descriptors travel in the kernel-argument segment (uniform scalar loads, no table upload).
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_wgrad_grouped_kernel(WgradGroup grp) {
+    // XCD-aware order (workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2): every XCD takes a CONTIGUOUS run of
+    // the tile list, so the tiles that share a dY column block / an X column block meet in one L2 instead of eight (the long
+    // encoder-row reductions: 670 MB of HBM traffic for 243 MB of operands before)
+    const int total = gridDim.x, l = blockIdx.x, xc = l & 7, q = total >> 3, r = total & 7;
+    const int tlin = BM >= 128 ? xc * q + (xc < r ? xc : r) + (l >> 3) : l;
     int p = 0;
-    while (p + 1 < grp.n && (int)blockIdx.x >= grp.p[p + 1].tile_start) ++p;
+    while (p + 1 < grp.n && tlin >= grp.p[p + 1].tile_start) ++p;
     const WgradDesc& d = grp.p[p];
     GemmArgs g{};
     g.A = d.dy; g.lda = d.lddy; g.B = d.x; g.ldb = d.ldx; g.M = d.N; g.N = d.K; g.K = d.rows; g.reduction_major = 1;
     g.alpha = 1.f; g.mask_scale = 1.f; g.C32 = d.dW; g.ldc = d.K; g.colsum = d.db;
-    const int t = blockIdx.x - d.tile_start, tiles_x = (d.K + BN - 1) / BN;
+    const int t = tlin - d.tile_start, tiles_x = (d.K + BN - 1) / BN;
     gemm_body<BM, BN, true, E_C32>(g, t % tiles_x, t / tiles_x, 0);
 }
 #undef HAS
