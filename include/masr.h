@@ -292,6 +292,11 @@ int masr_test_conv3x3_prof(const uint16_t* in, const uint16_t* wk, const float* 
 int masr_test_conv3x3_wgrad(const uint16_t* in, const uint16_t* dy, float* dw, float* slab, int64_t slab_floats,
                             int B, int H, int W, int CIN, int COUT, void* stream);
 int64_t masr_test_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT);
+/* LayerNorm forward + backward of one [rows][E] fp32 matrix (nn.LayerNorm inside nn.Transformer*Layer, mono_transformer_torch.py:74-98):
+ * y, y16 (bf16), mean / rstd per row; dx, dgamma, dbeta from dy.  slab: masr_test_layernorm_slab_floats(rows, E) floats of scratch. */
+int64_t masr_test_layernorm_slab_floats(int rows, int E);
+int masr_test_layernorm(const float* x, const float* gamma, const float* beta, const float* dy, float* y, uint16_t* y16, float* mean,
+                        float* rstd, float* dx, uint16_t* dx16, float* dgamma, float* dbeta, float* slab, int rows, int E, void* stream);
 int masr_test_attention(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* dout, uint16_t* o,
                         uint16_t* dq, uint16_t* dk, uint16_t* dv, float* lse, float* delta, const int32_t* klens,
                         int B, int H, int Tq, int Tk, int hd, int causal, void* stream);

@@ -406,7 +406,7 @@ int ln_bwd(Ctx& c, const Norm& n, const float* dy, const float* x, const float* 
     Prof p(c.m, MASR_PROF_LAYERNORM, c.s);
     masr_model* m = c.m;
     // the dgamma/dbeta partials of every LayerNorm go to their own slab region; flush_ln_reduce folds them all at once
-    const int64_t need = mk_layernorm_bwd_slab_floats(rows, m->E);
+    const int64_t need = (int64_t)mk_layernorm_bwd_blocks(rows) * 2 * m->E;
     if (m->lng.n < LN_GROUP_MAX && m->ln_slab_used + need <= m->acts.ln_slab_floats) {
         float* slab = m->acts.ln_slab + m->ln_slab_used;
         m->ln_slab_used += need;
@@ -1282,6 +1282,12 @@ int masr_test_conv3x3_wgrad(const uint16_t* in, const uint16_t* dy, float* dw, f
     if (slab_floats < mk_conv3x3_wgrad_slab_floats(B, H, W, CIN, COUT)) { mk_set_error("masr_test_conv3x3_wgrad", "slab too small"); return -1; }
     ConvWgradArgs a{}; a.in = (const bf16*)in; a.dy = (const bf16*)dy; a.dw = dw; a.slab = slab; a.B = B; a.H = H; a.W = W; a.CIN = CIN; a.COUT = COUT;
     return mk_conv3x3_wgrad(a, (hipStream_t)stream);
+}
+int64_t masr_test_layernorm_slab_floats(int rows, int E) { return mk_layernorm_bwd_slab_floats(rows, E); }
+int masr_test_layernorm(const float* x, const float* gamma, const float* beta, const float* dy, float* y, uint16_t* y16, float* mean,
+                        float* rstd, float* dx, uint16_t* dx16, float* dgamma, float* dbeta, float* slab, int rows, int E, void* stream) {
+    if (mk_layernorm_fwd(x, gamma, beta, y, (bf16*)y16, mean, rstd, rows, E, (hipStream_t)stream)) return -1;
+    return mk_layernorm_bwd(dy, x, gamma, mean, rstd, dx, (bf16*)dx16, 0.f, 0, 0, dgamma, dbeta, slab, rows, E, (hipStream_t)stream, nullptr);
 }
 int masr_test_attention(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* dout, uint16_t* o, uint16_t* dq, uint16_t* dk,
                         uint16_t* dv, float* lse, float* delta, const int32_t* klens, int B, int H, int Tq, int Tk, int hd, int causal,

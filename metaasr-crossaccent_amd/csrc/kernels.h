@@ -133,7 +133,8 @@ int mk_layernorm_fwd(const float* x, const float* gamma, const float* beta, floa
 int mk_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        float* dx32, bf16* dx16, float drop_p, uint32_t seed, uint32_t site,
                        float* dgamma, float* dbeta, float* slab, int rows, int E, hipStream_t s, const uint32_t* seed_ptr = nullptr);
-long mk_layernorm_bwd_slab_floats(int rows, int E);
+long mk_layernorm_bwd_slab_floats(int rows, int E);     // capacity for any row count <= rows
+int mk_layernorm_bwd_blocks(int rows);                    // partial-sum blocks a launch over `rows` rows writes
 // dgamma == null: only the per-block partials are written to `slab` (each LayerNorm its own region) and
 // mk_layernorm_bwd_reduce_grouped folds all of them in one launch at the end of the backward pass
 struct LnReduceDesc { const float* slab; float* dgamma; float* dbeta; int nblocks; };

@@ -8,86 +8,127 @@ namespace {
 // ---------------------------------------------------------------- LayerNorm (eps 1e-5, torch semantics)
 // one wave per row, E = 64 * PT exactly (compile-time): every load of a row is issued unconditionally and up front --
 // a bounds check around the loads makes hipcc serialise them on s_waitcnt vmcnt(0).
+// These kernels are bound by the NUMBER of vector-memory wave-instructions (one texture addresser per CU, ~40-90 cycles each whatever
+// their width): with 4-byte lanes a 512-wide row cost 8 instructions per stream (backward: 32 per row -> 9-11 us for 4000 rows, 3 us of
+// bytes); a lane now owns 4 consecutive columns per 256-column group (16-byte loads / stores, 8-byte bf16 stores): 7 per row.
+template <int VW> struct LnVec;
+template <> struct LnVec<4> {
+    static __device__ __forceinline__ void ld(const float* p, float (&o)[4]) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3]; }
+    static __device__ __forceinline__ void st(float* p, const float (&o)[4]) { *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]}; }
+    static __device__ __forceinline__ void st16(bf16* p, const float (&o)[4]) { bf16x4 t; t[0] = (bf16)o[0]; t[1] = (bf16)o[1]; t[2] = (bf16)o[2]; t[3] = (bf16)o[3]; *reinterpret_cast<bf16x4*>(p) = t; }
+};
+template <> struct LnVec<1> {
+    static __device__ __forceinline__ void ld(const float* p, float (&o)[1]) { o[0] = p[0]; }
+    static __device__ __forceinline__ void st(float* p, const float (&o)[1]) { p[0] = o[0]; }
+    static __device__ __forceinline__ void st16(bf16* p, const float (&o)[1]) { p[0] = (bf16)o[0]; }
+};
+// lane's columns: group i (of NV) holds columns (i * 64 + lane) * VW .. + VW - 1
 template <int PT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ y32,
                                                      bf16* __restrict__ y16, float* __restrict__ mean,
                                                      float* __restrict__ rstd, int rows) {
-    constexpr int E = 64 * PT;
+    constexpr int E = 64 * PT, VW = PT % 4 == 0 ? 4 : 1, NV = PT / VW;
+    using V = LnVec<VW>;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + (long)row * E;
-    float v[PT], gm[PT], bt[PT];
+    float v[NV][VW], gm[NV][VW], bt[NV][VW];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < PT; ++i) { v[i] = xr[lane + i * 64]; gm[i] = gamma[lane + i * 64]; bt[i] = beta[lane + i * 64]; }
+    for (int i = 0; i < NV; ++i) { const int c = (i * 64 + lane) * VW; V::ld(xr + c, v[i]); V::ld(gamma + c, gm[i]); V::ld(beta + c, bt[i]); }
 #pragma unroll
-    for (int i = 0; i < PT; ++i) s += v[i];
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < VW; ++e) s += v[i][e];
     const float mu = wave_sum(s) / E;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < PT; ++i) { const float d = v[i] - mu; q += d * d; }
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < VW; ++e) { const float d = v[i][e] - mu; q += d * d; }
     const float rs = rsqrtf(wave_sum(q) / E + 1e-5f);
 #pragma unroll
-    for (int i = 0; i < PT; ++i) {
-        const float o = (v[i] - mu) * rs * gm[i] + bt[i];
-        if (y32) y32[(long)row * E + lane + i * 64] = o;
-        if (y16) y16[(long)row * E + lane + i * 64] = (bf16)o;
+    for (int i = 0; i < NV; ++i) {
+        float o[VW];
+#pragma unroll
+        for (int e = 0; e < VW; ++e) o[e] = (v[i][e] - mu) * rs * gm[i][e] + bt[i][e];
+        const long idx = (long)row * E + (i * 64 + lane) * VW;
+        if (y32) V::st(y32 + idx, o);
+        if (y16) V::st16(y16 + idx, o);
     }
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-// backward: each block handles LN_ROWS rows (one wave per row, looping), accumulating dgamma/dbeta
-// partials per thread-column, written to slab[block][2][E]; reduced by ln_bwd_reduce.
-constexpr int LN_ROWS = 16;
-template <int PT>
+// backward: a workgroup handles 4 * R rows (a wave R consecutive rows, all of their loads issued up front), accumulating dgamma/dbeta
+// partials per thread-column, written to slab[block][2][E]; reduced by ln_bwd_reduce.  R = 4 for the encoder's rows (250 workgroups for
+// 4000 rows), 1 for the decoder's few hundred (148 workgroups instead of 37).
+__host__ __device__ inline int ln_rows_per_wave(int rows) { return rows >= 2048 ? 4 : 1; }
+template <int PT, int R>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx32,
                                                      bf16* __restrict__ dx16, float drop_p, uint32_t seed, uint32_t site,
                                                      float* __restrict__ slab, int rows, const uint32_t* __restrict__ seed_ptr) {
-    constexpr int E = 64 * PT;
+    constexpr int E = 64 * PT, VW = PT % 4 == 0 ? 4 : 1, NV = PT / VW;
+    using V = LnVec<VW>;
     if (seed_ptr) seed = *seed_ptr;                           // replayed (graph-captured) step: the seed of THIS step lives on the device
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float dg[PT], db[PT], gm[PT];
+    float dg[NV][VW], db[NV][VW], gm[NV][VW];
 #pragma unroll
-    for (int i = 0; i < PT; ++i) { dg[i] = 0.f; db[i] = 0.f; gm[i] = gamma[lane + i * 64]; }
+    for (int i = 0; i < NV; ++i) {
+        V::ld(gamma + (i * 64 + lane) * VW, gm[i]);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
+    }
     const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    for (int rr = wave; rr < LN_ROWS; rr += 4) {
-        const int row = blockIdx.x * LN_ROWS + rr;
-        if (row >= rows) break;
-        const float mu = mean[row], rs = rstd[row];
-        float d[PT], xv[PT];
+    const int row0 = (blockIdx.x * 4 + wave) * R;
+    float d[R][NV][VW], xv[R][NV][VW], mu[R], rs[R];
 #pragma unroll
-        for (int i = 0; i < PT; ++i) { d[i] = dy[(long)row * E + lane + i * 64]; xv[i] = x[(long)row * E + lane + i * 64]; }
-        float g[PT], xh[PT];
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r < rows ? row0 + r : rows - 1;               // (clamped: loads stay unconditional)
+        mu[r] = mean[row]; rs[r] = rstd[row];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { const long idx = (long)row * E + (i * 64 + lane) * VW; V::ld(dy + idx, d[r][i]); V::ld(x + idx, xv[r][i]); }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r;
+        if (row >= rows) break;
+        float g[NV][VW], xh[NV][VW];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < PT; ++i) {
-            xh[i] = (xv[i] - mu) * rs;
-            g[i] = d[i] * gm[i];
-            dg[i] += d[i] * xh[i];
-            db[i] += d[i];
-            s1 += g[i];
-            s2 += g[i] * xh[i];
-        }
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+                xh[i][e] = (xv[r][i][e] - mu[r]) * rs[r];
+                g[i][e] = d[r][i][e] * gm[i][e];
+                dg[i][e] += d[r][i][e] * xh[i][e];
+                db[i][e] += d[r][i][e];
+                s1 += g[i][e];
+                s2 += g[i][e] * xh[i][e];
+            }
         s1 = wave_sum(s1) / E;
         s2 = wave_sum(s2) / E;
 #pragma unroll
-        for (int i = 0; i < PT; ++i) {
-            const float o = (g[i] - s1 - xh[i] * s2) * rs;
-            const long idx = (long)row * E + lane + i * 64;
-            if (dx32) dx32[idx] = o;
+        for (int i = 0; i < NV; ++i) {
+            float o[VW];
+#pragma unroll
+            for (int e = 0; e < VW; ++e) o[e] = (g[i][e] - s1 - xh[i][e] * s2) * rs[r];
+            const long idx = (long)row * E + (i * 64 + lane) * VW;
+            if (dx32) V::st(dx32 + idx, o);
             if (dx16) {
-                float od = o;
-                if (drop_p > 0.f) od *= dropout_scale(seed, site, (uint32_t)idx, drop_p, inv_keep);
-                dx16[idx] = (bf16)od;
+                if (drop_p > 0.f) {
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) o[e] *= dropout_scale(seed, site, (uint32_t)(idx + e), drop_p, inv_keep);
+                }
+                V::st16(dx16 + idx, o);
             }
         }
     }
-    __shared__ float red[4][2][E];
+    __shared__ __attribute__((aligned(16))) float red[4][2][E];
 #pragma unroll
-    for (int i = 0; i < PT; ++i) { red[wave][0][lane + i * 64] = dg[i]; red[wave][1][lane + i * 64] = db[i]; }
+    for (int i = 0; i < NV; ++i) { V::st(&red[wave][0][(i * 64 + lane) * VW], dg[i]); V::st(&red[wave][1][(i * 64 + lane) * VW], db[i]); }
     __syncthreads();
     for (int c = threadIdx.x; c < E; c += 256) {
         slab[((long)blockIdx.x * 2 + 0) * E + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
@@ -343,7 +384,10 @@ static void ln_fwd_launch(const float* x, const float* gamma, const float* beta,
 template <int PT>
 static void ln_bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx32, bf16* dx16,
                           float drop_p, uint32_t seed, uint32_t site, float* slab, int rows, int nb, hipStream_t s, const uint32_t* seed_ptr) {
-    hipLaunchKernelGGL(ln_bwd_kernel<PT>, dim3(nb), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx32, dx16, drop_p, seed, site, slab, rows, seed_ptr);
+    if (ln_rows_per_wave(rows) == 4)
+        hipLaunchKernelGGL((ln_bwd_kernel<PT, 4>), dim3(nb), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx32, dx16, drop_p, seed, site, slab, rows, seed_ptr);
+    else
+        hipLaunchKernelGGL((ln_bwd_kernel<PT, 1>), dim3(nb), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx32, dx16, drop_p, seed, site, slab, rows, seed_ptr);
 }
 #define LN_DISPATCH(E, CALL)                                                                      \
     switch ((E) / 64) {                                                                           \
@@ -359,12 +403,18 @@ int mk_layernorm_fwd(const float* x, const float* gamma, const float* beta, floa
 #undef CALL
     return LAUNCH_OK();
 }
-long mk_layernorm_bwd_slab_floats(int rows, int E) { return (long)((rows + LN_ROWS - 1) / LN_ROWS) * 2 * E; }
+static int ln_bwd_blocks(int rows) { const int per = 4 * ln_rows_per_wave(rows); return (rows + per - 1) / per; }
+int mk_layernorm_bwd_blocks(int rows) { return ln_bwd_blocks(rows); }
+// capacity for ANY row count up to `rows` (the block count is not monotone in the rows: few rows take 4 per workgroup, many 16)
+long mk_layernorm_bwd_slab_floats(int rows, int E) {
+    const int small = ln_bwd_blocks(rows < 2047 ? rows : 2047), here = ln_bwd_blocks(rows);
+    return (long)(small > here ? small : here) * 2 * E;
+}
 int mk_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        float* dx32, bf16* dx16, float drop_p, uint32_t seed, uint32_t site, float* dgamma, float* dbeta,
                        float* slab, int rows, int E, hipStream_t s, const uint32_t* seed_ptr) {
     if (E % 64) { mk_set_error("mk_layernorm_bwd", "d_model must be a multiple of 64"); return -1; }
-    const int nb = (rows + LN_ROWS - 1) / LN_ROWS;
+    const int nb = ln_bwd_blocks(rows);
 #define CALL(P) ln_bwd_launch<P>(dy, x, gamma, mean, rstd, dx32, dx16, drop_p, seed, site, slab, rows, nb, s, seed_ptr)
     LN_DISPATCH(E, CALL)
 #undef CALL

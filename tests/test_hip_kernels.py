@@ -261,6 +261,35 @@ def test_attention(L, B_, H, Tq, Tk, hd, causal, masked):
             assert torch.all(dk[b, int(klens[b]):] == 0) and torch.all(dv[b, int(klens[b]):] == 0)
 
 
+@pytest.mark.parametrize("rows,E", [(592, 512), (4000, 512), (2051, 512), (37, 256), (70, 384), (5, 64), (2048, 1024)])
+def test_layernorm_fwd_bwd(L, rows, E):
+    """nn.LayerNorm (eps 1e-5) forward + backward on one [rows][E] matrix (mono_transformer_torch.py:74-98 via nn.Transformer*Layer):
+    both row partitions of the backward (4 / 16 rows per workgroup), ragged last workgroups, the 16-byte (E % 256 == 0) and the
+    4-byte lane layouts."""
+    g = torch.Generator(device="cuda").manual_seed(rows + E)
+    x = (torch.randn(rows, E, device="cuda", generator=g) * 1.7 + 0.3).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(E, device="cuda", generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(E, device="cuda", generator=g)).requires_grad_(True)
+    dy = torch.randn(rows, E, device="cuda", generator=g)
+    ref = torch.nn.functional.layer_norm(x, (E,), gamma, beta, 1e-5)
+    ref.backward(dy)
+    y = torch.zeros(rows, E, device="cuda"); y16 = torch.zeros(rows, E, device="cuda").bfloat16()
+    mean = torch.zeros(rows, device="cuda"); rstd = torch.zeros(rows, device="cuda")
+    dx = torch.full((rows + 1, E), 7.0, device="cuda"); dx16 = torch.zeros(rows, E, device="cuda").bfloat16()
+    dgm = torch.zeros(E, device="cuda"); dbt = torch.zeros(E, device="cuda")
+    slab = torch.zeros(int(L.masr_test_layernorm_slab_floats(rows, E)), device="cuda")
+    _cabi.check(L.masr_test_layernorm(P(x.detach()), P(gamma.detach()), P(beta.detach()), P(dy), P(y), P(y16), P(mean), P(rstd), P(dx), P(dx16),
+                                      P(dgm), P(dbt), P(slab), rows, E, S()))
+    torch.testing.assert_close(y, ref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(y16.float(), ref.detach().bfloat16().float(), rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(mean, x.detach().mean(1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dx[:rows], x.grad, rtol=1e-4, atol=2e-5)
+    assert torch.all(dx[rows] == 7.0)                                    # nothing written behind the last row
+    torch.testing.assert_close(dx16.float(), x.grad.bfloat16().float(), rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(dgm, gamma.grad, rtol=1e-4, atol=1e-4 * rows ** 0.5)
+    torch.testing.assert_close(dbt, beta.grad, rtol=1e-4, atol=1e-4 * rows ** 0.5)
+
+
 def test_dropout_keep_rate_and_scale_per_site():
     """nn.Dropout semantics at every site of the engine (PE dropout 1 / 100, attention probabilities, attention out-proj,
     FFN inner, FFN out: sites 1.. and 100.. in csrc/engine.hip): an element is kept with probability 1 - p and scaled by
