@@ -542,7 +542,7 @@ def chain_workspace(root, spm_dir):
            "solver": dict(base, setting="chain", total_steps=10, label_smoothing=0.1, eval_ival=2, log_ival=1, save_ival=2, batch_size=4,
                           dev_batch_size=4)}
     ft_model = {k: v for k, v in TINY.items() if k not in ("inner_optimizer_cls", "inner_optimizer_opt", "meta_opt_cls", "meta")}
-    ft_model.update({"optimizer_cls": "noam", "optimizer_opt": {"k": 0.5, "warmup_steps": 50}})
+    ft_model.update({"optimizer_cls": "noam", "optimizer_opt": {"k": 0.2, "warmup_steps": 100}})
     ft = {"asr_model": ft_model,
           "solver": dict(base, setting="chain-ft", total_epochs=20, label_smoothing=0.1, eval_ival=50, log_ival=1000, batch_size=8,
                          dev_batch_size=8, pretrain_module=["feat_extractor", "vgg2enc", "char_trans", "pre_embed", "encoder", "decoder"],

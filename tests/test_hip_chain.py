@@ -96,11 +96,14 @@ def test_chain_fomaml_matches_reference_chain(golden_dir, tmp_path, monkeypatch)
     assert abs(dl[0][1] - rl[0][1]) <= 1e-3 * rl[0][1]                    # evaluation of the loaded snapshot, before any step
     print("fine-tune dev_loss ours/ref:", [(s, round(a, 4), round(b, 4)) for (s, a), (_, b) in zip(dl, rl)])
     print("fine-tune dev_acc  ours/ref:", [(s, round(a, 3), round(b, 3)) for (s, a), (_, b) in zip(da, ra)])
-    # the target accent is a two-class toy: both runs reach accuracy 1 within the first hundreds of Noam-Adam steps and then sit
-    # on the label-smoothing floor of the loss -- an end point that does not depend on the (chaotic) path taken to it
+    # Noam-Adam with k = 0.2, warmup 100 (at the k = 0.5 / warmup 50 of the first version of this golden the fine-tune was chaotic: runs that
+    # differ in fp32 summation order alone were 40 % apart at step 50 and could end on different plateaus).  Here the whole trajectory is
+    # comparable: every evaluation within 0.5 % in loss and one dev token in accuracy (measured: 0.15 %, one token at step 50)
+    for (st, a), (_, b) in zip(dl, rl):
+        assert abs(a - b) <= 5e-3 * b, (st, a, b)
+    for (st, a), (_, b) in zip(da, ra):
+        assert abs(a - b) <= 1.0 / 27 + 1e-6, (st, a, b)
     assert all(a == 1.0 for _, a in da[-4:]) and all(b == 1.0 for _, b in ra[-4:])
-    for (_, a), (_, b) in zip(dl[-4:], rl[-4:]):
-        assert abs(a - b) <= 5e-3 * b, (a, b)
     best_o, best_r = _log(ft_dir / "best_wer")[0], _glog(g, "ft/log/best_wer")[0]
     assert best_o[1] == best_r[1] == 0.0
     sd = torch.load(ft_dir / "snapshot.latest")

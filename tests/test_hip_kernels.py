@@ -290,6 +290,33 @@ def test_layernorm_fwd_bwd(L, rows, E):
     torch.testing.assert_close(dbt, beta.grad, rtol=1e-4, atol=1e-4 * rows ** 0.5)
 
 
+@pytest.mark.parametrize("B_,H,T,hd,mag", [(4, 4, 3, 16, 3e4), (2, 8, 250, 64, 3e3), (2, 4, 37, 64, 1e4), (1, 2, 130, 32, 1e3)])
+def test_attention_huge_scores(L, B_, H, T, hd, mag):
+    """A diverging run (train.py with an aggressive Noam schedule: |q|, |k| ~ 3e4, scores ~ 1e9) must still get torch's one-hot softmax
+    and its vanishing gradients: the exponent is formed as a DIFFERENCE (s - m, s scale - lse) before any scaling -- with s sc2 - fl(m sc2)
+    the rounding of the product alone is 2^16 at such scores (seen as gradients of 1e13 and a NaN run)."""
+    g = torch.Generator(device="cuda").manual_seed(B_ + T)
+    mk = lambda m: (torch.randn(B_, T, H, hd, device="cuda", generator=g) * m).bfloat16()
+    q, k, v, dout = mk(mag), mk(mag), mk(mag), mk(1e-3)
+    klens = torch.full((B_,), T, device="cuda", dtype=torch.int32)
+    o = torch.zeros_like(q); dq = torch.zeros_like(q); dk = torch.zeros_like(k); dv = torch.zeros_like(v)
+    lse = torch.zeros(B_, H, T, device="cuda"); delta = torch.zeros(B_, H, T, device="cuda")
+    _cabi.check(L.masr_test_attention(P(q), P(k), P(v), P(dout), P(o), P(dq), P(dk), P(dv), P(lse), P(delta), P(klens), B_, H, T, T, hd, 0, S()))
+    ro, rdq, rdk, rdv = _attn_ref(q, k, v, klens.long(), 0, dout)
+    for t in (o, dq, dk, dv, lse):
+        assert torch.isfinite(t.float()).all()
+    torch.testing.assert_close(o.float(), ro, rtol=2e-2, atol=2e-2 * mag)
+    # with a one-hot softmax dS vanishes: what is left in dq / dk is p (dP - delta) with delta taken from the bf16 output, i.e. bounded by
+    # bf16 rounding x |dO| |v| |k|; the same bound holds for torch's own result
+    bound = 2.0 ** -7 * float(dout.float().abs().max()) * mag * mag * hd ** 0.5
+    assert float((dq.float() - rdq).abs().max()) <= bound and float((dk.float() - rdk).abs().max()) <= bound
+    # dV = P^T dO: rows whose two best keys lie within a few units of each other are not one-hot, and at scores of 1e6..1e9 the fp32
+    # accumulation order of q.k alone moves the exponent by an ulp of the score (0.06..64): those P differ between ANY two implementations.
+    # Bounded by |dO| everywhere, equal where the softmax is one-hot (the bulk)
+    dvd = (dv.float() - rdv).abs()
+    assert float(dvd.max()) <= 1.01 * float(dout.float().abs().max()) * 2 and float((dvd > 3e-2 * float(dout.float().abs().max())).float().mean()) < 0.1
+
+
 def test_dropout_keep_rate_and_scale_per_site():
     """nn.Dropout semantics at every site of the engine (PE dropout 1 / 100, attention probabilities, attention out-proj,
     FFN inner, FFN out: sites 1.. and 100.. in csrc/engine.hip): an element is kept with probability 1 - p and scaled by
