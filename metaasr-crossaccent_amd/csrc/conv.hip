@@ -2041,7 +2041,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(ConvWgradArgs a, lon
 // FLOP is 9x lower than one-tap-per-workgroup.  The 9 x 64 x 64 fp32 partial stays in registers (144 VGPRs/lane) across
 // all tiles of the workgroup and is written once; a fixed-order slab reduce makes the result deterministic.
 constexpr int W2_PS = 80, W2_LDY = 80;   // 160-B rows: tr-reads conflict-free
-constexpr int W2_TOTAL_WG = 512;    // two persistent workgroups per CU: one multiplies while the other loads / stages its next tile
+constexpr int W2_TOTAL_WG = 256;    // one persistent workgroup per CU (see mk_conv3x3_wgrad)
 
 // W2_TW: tile width in pixels (16, or 8 for maps whose width pads badly to 16 -- see conv3x3_patch_kernel); tile = 128 pixels
 template <int CIN, int COUT, int OCC, int W2_TW>
@@ -2680,11 +2680,16 @@ int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s, int phase) {
         const int tw = narrow ? 8 : 16, th = 128 / tw;
         const int tiles_x = (a.W + tw - 1) / tw, tiles_y = (a.H + th - 1) / th;
         const int ntiles = tiles_x * tiles_y * a.B;
+        // ONE persistent workgroup per CU with the next tile prefetched in registers (256 partial slabs: 37 MB written and read again per
+        // layer).  Two per CU (one multiplies while the other loads and stages; MASR_WGRAD_WGS=512 MASR_WGRAD_OCC=2) is 2 % faster for a
+        // model that has the chip to itself but doubles the slabs, and under concurrent task slots the other slots' launches fill the gaps
+        // anyway.  Measured, utt/s single task / four slots: 512 x 2: 6 107 / 8 926; 256 x 1: 5 980 / 9 155.  One configuration for both
+        // modes: the partition of the pixels into partial sums is part of the result's bits (slots = sequential run, bit for bit).
+        static const int occ = getenv("MASR_WGRAD_OCC") ? atoi(getenv("MASR_WGRAD_OCC")) : 1;
         int nwg = wgrad2_nwg(a.CIN, a.COUT);
         if (nwg > ntiles) nwg = ntiles;
         splits = nwg;
         dim3 grid(nwg, (a.CIN / 64) * (a.COUT / 64));
-        static const int occ = getenv("MASR_WGRAD_OCC") ? atoi(getenv("MASR_WGRAD_OCC")) : 2;
 #define W2T(CI, CO, OC, TWV) hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CI, CO, OC, TWV>), grid, dim3(256), 0, s, a, nwg, ntiles, tiles_x, tiles_y)
 #define W2(CI, CO) \
         if (occ == 1) { if (narrow) W2T(CI, CO, 1, 8); else W2T(CI, CO, 1, 16); } \

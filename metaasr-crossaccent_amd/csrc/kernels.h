@@ -73,7 +73,9 @@ bool mk_conv3x3_mask_bits_used(int W);      // does the masked 128 <- 128 dgrad 
 long mk_conv1_wgrad_fused_slab_floats(int B, int H, int W);
 int mk_conv1_wgrad_fused_reduce(float* slab, int B, int H, int W, float* dw, float* db, hipStream_t s);
 // wgrad: dw[co][ci][3][3] (+ db[co]) from in (NHWC, CIN) and dy (NHWC, COUT)
-struct ConvWgradArgs { const bf16* in; const bf16* dy; float* dw; float* db; float* slab; int B, H, W, CIN, COUT; };
+struct ConvWgradArgs {
+    const bf16* in; const bf16* dy; float* dw; float* db; float* slab; int B, H, W, CIN, COUT;
+};
 int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s, int phase = 0);     // phase 1 / 2: the partial-slab kernel / the slab reduce alone
 long mk_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT);
 int mk_maxpool_fwd(const bf16* in, bf16* out, int B, int H, int W, int C, hipStream_t s, int ceil_mode = 0);
