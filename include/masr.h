@@ -292,6 +292,10 @@ int masr_test_conv3x3_prof(const uint16_t* in, const uint16_t* wk, const float* 
 int masr_test_conv3x3_wgrad(const uint16_t* in, const uint16_t* dy, float* dw, float* slab, int64_t slab_floats,
                             int B, int H, int W, int CIN, int COUT, void* stream);
 int64_t masr_test_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT);
+/* the same with dy given as the pooled gradient [B][H/2][W/2][COUT] + the pool codes of masr_test_conv3x3_pool_idx (the weight-gradient kernel
+ * expands the 2x2 max-pool + ReLU backward while staging; 64->64 and 128->128 channels); db may be null */
+int masr_test_conv3x3_wgrad_pooled(const uint16_t* in, const uint16_t* dy_pooled, const uint8_t* pool_idx, float* dw, float* db, float* slab,
+                                   int64_t slab_floats, int B, int H, int W, int CIN, int COUT, void* stream);
 /* LayerNorm forward + backward of one [rows][E] fp32 matrix (nn.LayerNorm inside nn.Transformer*Layer, mono_transformer_torch.py:74-98):
  * y, y16 (bf16), mean / rstd per row; dx, dgamma, dbeta from dy.  slab: masr_test_layernorm_slab_floats(rows, E) floats of scratch. */
 int64_t masr_test_layernorm_slab_floats(int rows, int E);

@@ -2044,7 +2044,9 @@ constexpr int W2_PS = 80, W2_LDY = 80;   // 160-B rows: tr-reads conflict-free
 constexpr int W2_TOTAL_WG = 256;    // one persistent workgroup per CU (see mk_conv3x3_wgrad)
 
 // W2_TW: tile width in pixels (16, or 8 for maps whose width pads badly to 16 -- see conv3x3_patch_kernel); tile = 128 pixels
-template <int CIN, int COUT, int OCC, int W2_TW>
+// POOLED: the dy tile comes from ConvWgradArgs::dy_pooled + pool_idx: a thread fetches ONE pooled cell x 8 channels (16 B + 8 B of codes) and
+// stages the four positions of its window (4 + 0 instead of 4 x 16-byte loads per thread and tile)
+template <int CIN, int COUT, int OCC, int W2_TW, bool POOLED = false>
 __global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs a, int nwg, int ntiles, int tiles_x, int tiles_y) {
     constexpr int W2_TH = 128 / W2_TW, W2_PH = W2_TH + 2, W2_PW = W2_TW + 2, RPS = 32 / W2_TW;      // RPS = pixel rows per 32-pixel slab
     constexpr int KTOT = 9 * CIN;
@@ -2058,6 +2060,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs 
     const int H = a.H, W = a.W;
 
     bf16x8 pr[NPCH], dr[NDCH];
+    uint2 pcode = {0u, 0u};
     unsigned okp = 0, okd = 0;
     auto load_tile = [&](int tile) {
         const int tc = tile < ntiles ? tile : ntiles - 1;
@@ -2075,6 +2078,14 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs 
             if (ok) okp |= 1u << i;
             pr[i] = ld8(in_b + (ok ? ((long)t * W + d) : 0) * CIN + (c & 7) * 8);
         }
+        if constexpr (POOLED) {
+            const int pp = tid >> 3, t2 = t0 / 2 + pp / (W2_TW / 2), d2 = d0 / 2 + pp % (W2_TW / 2);
+            const bool ok = t2 < H / 2 && d2 < W / 2;                       // (floor mode: the cropped last row / column gets no gradient)
+            if (ok) okd = 1u;
+            const long pe = (((long)b * (H / 2) + (ok ? t2 : 0)) * (W / 2) + (ok ? d2 : 0)) * COUT + ch * 64 + (tid & 7) * 8;
+            dr[0] = ld8(a.dy_pooled + pe);
+            pcode = *reinterpret_cast<const uint2*>(a.pool_idx + pe);
+        } else {
 #pragma unroll
         for (int i = 0; i < NDCH; ++i) {
             const int c = tid + i * 256;
@@ -2082,6 +2093,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs 
             const bool ok = t < H && d < W;
             if (ok) okd |= 1u << i;
             dr[i] = ld8(dy_b + (ok ? ((long)t * W + d) : 0) * COUT + (c & 7) * 8);
+        }
         }
     };
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -2092,6 +2104,20 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs 
             const int c = tid + i * 256;
             if (c < W2_PH * W2_PW * 8) st8(patch + (c >> 3) * W2_PS + (c & 7) * 8, (okp >> i) & 1 ? pr[i] : zero8());
         }
+        if constexpr (POOLED) {
+            const int pp = tid >> 3, pr2 = pp / (W2_TW / 2), pc2 = pp % (W2_TW / 2);
+            bf16x8 o[4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned cj = ((j < 4 ? pcode.x : pcode.y) >> (8 * (j & 3))) & 0xffu;
+                const bf16 gj = okd ? dr[0][j] : (bf16)0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k][j] = cj == (unsigned)k ? gj : (bf16)0.f;
+                if (do_db) csum[j] += cj < 4u ? (float)gj : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) st8(dyt + ((2 * pr2 + (k >> 1)) * W2_TW + 2 * pc2 + (k & 1)) * W2_LDY + (tid & 7) * 8, o[k]);
+        } else {
 #pragma unroll
         for (int i = 0; i < NDCH; ++i) {
             const int c = tid + i * 256;
@@ -2101,6 +2127,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) csum[j] += (float)v[j];
             }
+        }
         }
     };
 
@@ -2691,10 +2718,16 @@ int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s, int phase) {
         splits = nwg;
         dim3 grid(nwg, (a.CIN / 64) * (a.COUT / 64));
 #define W2T(CI, CO, OC, TWV) hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CI, CO, OC, TWV>), grid, dim3(256), 0, s, a, nwg, ntiles, tiles_x, tiles_y)
+#define W2P(CI, CO) { if (occ == 1) hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CI, CO, 1, 16, true>), grid, dim3(256), 0, s, a, nwg, ntiles, tiles_x, tiles_y); \
+                     else hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CI, CO, 2, 16, true>), grid, dim3(256), 0, s, a, nwg, ntiles, tiles_x, tiles_y); }
 #define W2(CI, CO) \
         if (occ == 1) { if (narrow) W2T(CI, CO, 1, 8); else W2T(CI, CO, 1, 16); } \
         else { if (narrow) W2T(CI, CO, 2, 8); else W2T(CI, CO, 2, 16); }
+        const bool pooled = a.dy_pooled && a.pool_idx && !narrow;
+        if (pooled && !((a.CIN == 64 && a.COUT == 64) || (a.CIN == 128 && a.COUT == 128))) { mk_set_error("mk_conv3x3_wgrad", "pooled dy: 64->64 and 128->128 only"); return -1; }
         if (phase == 2) {}
+        else if (pooled && a.CIN == 64) W2P(64, 64)
+        else if (pooled) W2P(128, 128)
         else if (a.CIN == 64 && a.COUT == 64) { W2(64, 64) }
         else if (a.CIN == 64 && a.COUT == 128) { W2(64, 128) }
         else if (a.CIN == 128 && a.COUT == 128) { W2(128, 128) }
@@ -2702,6 +2735,7 @@ int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s, int phase) {
         else if (a.CIN == 256 && a.COUT == 256) { W2(256, 256) }
         else { mk_set_error("mk_conv3x3_wgrad", "unsupported channel counts"); return -1; }
 #undef W2T
+#undef W2P
 #undef W2
     }
     const int n = a.COUT * 9 * a.CIN + a.COUT;

@@ -794,8 +794,10 @@ static int backward(Ctx& c, const float* xs) {
     { GemmArgs g = lin_dgrad_args(a.ge16, E, m->v2e.t16, E, a.rows_e, E, m->F); g.C16 = a.dp2; g.ldc16 = m->F; CK(gemm(c, g)); }
     // ---- VGG
     const int64_t P1 = (int64_t)B * a.T * a.D, P2 = (int64_t)B * a.H2 * a.W2;
-    auto wgrad = [&](const bf16* in, const bf16* dy, const Conv& cv, int H, int W, int64_t P) -> int {
+    static const bool wgrad_pooled = !getenv("MASR_WGRAD_NO_POOLED");
+    auto wgrad = [&](const bf16* in, const bf16* dy, const Conv& cv, int H, int W, int64_t P, const bf16* dy_pooled = nullptr, const uint8_t* idx = nullptr) -> int {
         ConvWgradArgs wa{}; wa.in = in; wa.dy = dy; wa.dw = G + cv.w; wa.db = G + cv.b; wa.slab = a.slab; wa.B = B; wa.H = H; wa.W = W; wa.CIN = cv.CI; wa.COUT = cv.CO;
+        if (wgrad_pooled) { wa.dy_pooled = dy_pooled; wa.pool_idx = idx; }      // (the pooled gradient + codes: a quarter of the bytes of dy)
         { Prof p(m, MASR_PROF_CONV2_WGRAD + (int)(&cv - &m->conv[1]), s); CK(mk_conv3x3_wgrad(wa, s, 1)); }     // ONE launch per slot:
         { Prof p(m, MASR_PROF_CONV1_WGRAD, s); CK(mk_conv3x3_wgrad(wa, s, 2)); }                                 // the slab reduce is timed with the other folds
         (void)P;
@@ -809,12 +811,12 @@ static int backward(Ctx& c, const float* xs) {
         return mk_conv3x3(ca, s);
     };
     { Prof p(m, MASR_PROF_POOL, s); CK(mk_maxpool_idx_bwd(a.i2, a.dp2, a.da4, B, a.H2, a.W2, 128, s)); }
-    CK(wgrad(a.a3, a.da4, m->conv[3], a.H2, a.W2, P2));
+    CK(wgrad(a.a3, a.da4, m->conv[3], a.H2, a.W2, P2, a.dp2, a.i2));
     CK(dgrad(a.da4, m->conv[3], a.a3, a.da3, a.H2, a.W2));
     CK(wgrad(a.p1, a.da3, m->conv[2], a.H2, a.W2, P2));
     CK(dgrad(a.da3, m->conv[2], nullptr, a.dp1, a.H2, a.W2));
     { Prof p(m, MASR_PROF_POOL, s); CK(mk_maxpool_idx_bwd(a.i1, a.dp1, a.da2, B, a.T, a.D, 64, s)); }
-    CK(wgrad(a.a1, a.da2, m->conv[1], a.T, a.D, P1));
+    CK(wgrad(a.a1, a.da2, m->conv[1], a.T, a.D, P1, a.dp1, a.i1));
     static const bool fuse_w1 = !getenv("MASR_NO_FUSED_CONV1_WGRAD");
     if (fuse_w1) {
         // d(conv1 output) is consumed only by conv1's weight gradient: contract it inside the dgrad epilogue, never store it
@@ -1288,6 +1290,13 @@ int masr_test_layernorm(const float* x, const float* gamma, const float* beta, c
                         float* rstd, float* dx, uint16_t* dx16, float* dgamma, float* dbeta, float* slab, int rows, int E, void* stream) {
     if (mk_layernorm_fwd(x, gamma, beta, y, (bf16*)y16, mean, rstd, rows, E, (hipStream_t)stream)) return -1;
     return mk_layernorm_bwd(dy, x, gamma, mean, rstd, dx, (bf16*)dx16, 0.f, 0, 0, dgamma, dbeta, slab, rows, E, (hipStream_t)stream, nullptr);
+}
+int masr_test_conv3x3_wgrad_pooled(const uint16_t* in, const uint16_t* dy_pooled, const uint8_t* pool_idx, float* dw, float* db, float* slab,
+                                   int64_t slab_floats, int B, int H, int W, int CIN, int COUT, void* stream) {
+    if (slab_floats < mk_conv3x3_wgrad_slab_floats(B, H, W, CIN, COUT)) { mk_set_error("masr_test_conv3x3_wgrad_pooled", "slab too small"); return -1; }
+    ConvWgradArgs a{}; a.in = (const bf16*)in; a.dy_pooled = (const bf16*)dy_pooled; a.pool_idx = pool_idx; a.dw = dw; a.db = db; a.slab = slab;
+    a.B = B; a.H = H; a.W = W; a.CIN = CIN; a.COUT = COUT;
+    return mk_conv3x3_wgrad(a, (hipStream_t)stream);
 }
 int masr_test_attention(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* dout, uint16_t* o, uint16_t* dq, uint16_t* dk,
                         uint16_t* dv, float* lse, float* delta, const int32_t* klens, int B, int H, int Tq, int Tk, int hd, int causal,

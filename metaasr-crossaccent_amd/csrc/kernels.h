@@ -75,6 +75,9 @@ int mk_conv1_wgrad_fused_reduce(float* slab, int B, int H, int W, float* dw, flo
 // wgrad: dw[co][ci][3][3] (+ db[co]) from in (NHWC, CIN) and dy (NHWC, COUT)
 struct ConvWgradArgs {
     const bf16* in; const bf16* dy; float* dw; float* db; float* slab; int B, H, W, CIN, COUT;
+    // optional: dy = the 2x2 max-pool (+ ReLU) backward of dy_pooled [B][H/2][W/2][COUT] under the codes of ConvArgs::pool_idx -- the kernel
+    // expands it while staging (a quarter of the gradient bytes + one code byte per pooled element instead of the full-resolution map)
+    const bf16* dy_pooled; const uint8_t* pool_idx;
 };
 int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s, int phase = 0);     // phase 1 / 2: the partial-slab kernel / the slab reduce alone
 long mk_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT);

@@ -221,6 +221,28 @@ def test_conv3x3_wgrad(L, B_, H, W, CIN, COUT):
     torch.testing.assert_close(dw, wref.grad, rtol=1e-3, atol=2e-2)
 
 
+@pytest.mark.parametrize("B_,H,W,C", [(2, 10, 9, 64), (2, 40, 20, 128), (1, 21, 47, 128), (1, 33, 80, 64), (3, 16, 32, 64)])
+def test_conv3x3_wgrad_from_pooled_gradient(L, B_, H, W, C):
+    """ConvWgradArgs::dy_pooled: the weight-gradient kernel of the conv in FRONT of a MaxPool2d(2, 2) (mono_transformer_torch.py:49-60) expands
+    pooled gradient + pool codes itself.  Same bits as staging the map that masr_test_maxpool_idx_bwd writes (the LDS tile is identical);
+    odd H / W: the cropped last row / column gets no gradient; the bias gradient (summed in another order) within rounding."""
+    g = torch.Generator(device="cuda").manual_seed(C + H + W)
+    x = torch.randn(B_, H, W, C, device="cuda", generator=g).bfloat16()
+    H2, W2 = H // 2, W // 2
+    dyp = torch.randn(B_, H2, W2, C, device="cuda", generator=g).bfloat16()
+    codes = torch.randint(0, 5, (B_, H2, W2, C), device="cuda", generator=g).to(torch.uint8)           # 4 = nothing passed the ReLU
+    dy = torch.full((B_, H, W, C), 9.0, device="cuda").bfloat16()
+    _cabi.check(L.masr_test_maxpool_idx_bwd(P(codes), P(dyp), P(dy), B_, H, W, C, S()))
+    n = int(L.masr_test_conv3x3_wgrad_slab_floats(B_, H, W, C, C))
+    slab = torch.zeros(n, device="cuda")
+    dw0 = torch.zeros(C, C, 3, 3, device="cuda"); dw1 = torch.zeros_like(dw0); db = torch.zeros(C, device="cuda")
+    _cabi.check(L.masr_test_conv3x3_wgrad(P(x), P(dy), P(dw0), P(slab), n, B_, H, W, C, C, S()))
+    _cabi.check(L.masr_test_conv3x3_wgrad_pooled(P(x), P(dyp), P(codes), P(dw1), P(db), P(slab), n, B_, H, W, C, C, S()))
+    assert torch.equal(dw0, dw1)
+    torch.testing.assert_close(db, dy.float().sum((0, 1, 2)), rtol=1e-4, atol=1e-3)
+    assert float(dw1.abs().max()) > 0
+
+
 def _attn_ref(q, k, v, klens, causal, dout):
     B_, Tq, H, hd = q.shape
     Tk = k.shape[1]
