@@ -292,6 +292,10 @@ int masr_test_conv3x3_prof(const uint16_t* in, const uint16_t* wk, const float* 
 int masr_test_conv3x3_wgrad(const uint16_t* in, const uint16_t* dy, float* dw, float* slab, int64_t slab_floats,
                             int B, int H, int W, int CIN, int COUT, void* stream);
 int64_t masr_test_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT);
+/* Linear weight gradients as a grouped launch (mk_gemm_wgrad_grouped): dW[N][K] = dy[rows][N]^T x[rows][K], db[N] = column sums of dy (or null); a second
+ * member with the same operands when dW2 is given; tile = 64 or 128 */
+int masr_test_wgrad_grouped(const uint16_t* dy, int64_t lddy, const uint16_t* x, int64_t ldx, float* dW, float* db, float* dW2, float* db2,
+                            int rows, int N, int K, int tile, void* stream);
 /* the same with dy given as the pooled gradient [B][H/2][W/2][COUT] + the pool codes of masr_test_conv3x3_pool_idx (the weight-gradient kernel
  * expands the 2x2 max-pool + ReLU backward while staging; 64->64 and 128->128 channels); db may be null */
 int masr_test_conv3x3_wgrad_pooled(const uint16_t* in, const uint16_t* dy_pooled, const uint8_t* pool_idx, float* dw, float* db, float* slab,

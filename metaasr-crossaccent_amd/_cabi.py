@@ -90,6 +90,7 @@ _SIGS = {
     "masr_test_conv3x3_prof": (i32, [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp]),
     "masr_test_conv3x3_wgrad": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     "masr_test_conv3x3_wgrad_slab_floats": (i64, [i32, i32, i32, i32, i32]),
+    "masr_test_wgrad_grouped": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "masr_test_conv3x3_wgrad_pooled": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     "masr_test_layernorm_slab_floats": (i64, [i32, i32]),
     "masr_test_layernorm": (i32, [vp] * 13 + [i32, i32, vp]),

@@ -2052,8 +2052,11 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs 
     constexpr int KTOT = 9 * CIN;
     constexpr int NPCH = (W2_PH * W2_PW * 8 + 255) / 256;   // patch chunks per thread (6)
     constexpr int NDCH = W2_TH * W2_TW * 8 / 256;           // dy chunks per thread (4)
-    __shared__ __attribute__((aligned(16))) bf16 patch[W2_PH * W2_PW * W2_PS];
-    __shared__ __attribute__((aligned(16))) bf16 dyt[W2_TH * W2_TW * W2_LDY];
+    // one workgroup per CU (OCC 1): TWO tile buffers -- the next tile is written to LDS at the start of a tile's MFMA phase instead of behind
+    // it (staging between two barriers with the MFMA pipes idle cost a third of the launch: 135 us against 90 for 128 -> 128 channels)
+    constexpr int NB = OCC == 1 ? 2 : 1, PATCH_EL = W2_PH * W2_PW * W2_PS, DYT_EL = W2_TH * W2_TW * W2_LDY;
+    __shared__ __attribute__((aligned(16))) bf16 patch_[NB * PATCH_EL];
+    __shared__ __attribute__((aligned(16))) bf16 dyt_[NB * DYT_EL];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cs = blockIdx.y % (CIN / 64), ch = blockIdx.y / (CIN / 64);
@@ -2062,43 +2065,65 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs 
     bf16x8 pr[NPCH], dr[NDCH];
     uint2 pcode = {0u, 0u};
     unsigned okp = 0, okd = 0;
+    // Per-thread constants of the tile fetch: chunk i of the patch is pixel (ppi, ppj) relative to the tile origin (t0, d0) and sits prel
+    // elements behind that pixel's address; per tile only the origin (wave-uniform: scalar ALU) and two range tests per chunk remain.  (With
+    // the divisions, 64-bit multiplies and selects of the first version the fetch cost ~200 vector instructions per tile, which a lone
+    // workgroup per CU has nobody to hide behind: 135 us against 90 with two per CU on the 128 -> 128 layer.)
+    int ppi[NPCH], ppj[NPCH], prel[NPCH];
+#pragma unroll
+    for (int i = 0; i < NPCH; ++i) {
+        const int c = tid + i * 256, pix = c >> 3;
+        ppi[i] = pix / W2_PW - 1; ppj[i] = pix % W2_PW - 1;
+        prel[i] = (ppi[i] * W + ppj[i]) * CIN + (c & 7) * 8;
+        if (c >= W2_PH * W2_PW * 8) { ppi[i] = -(1 << 20); prel[i] = 0; }    // (past the patch: never in range)
+    }
+    int dpi[NDCH], dpj[NDCH], drel[NDCH];
+#pragma unroll
+    for (int i = 0; i < NDCH; ++i) {
+        const int c = tid + i * 256, pix = c >> 3;
+        dpi[i] = pix / W2_TW; dpj[i] = pix % W2_TW;
+        drel[i] = (dpi[i] * W + dpj[i]) * COUT + (c & 7) * 8;
+    }
+    const int pp_r = (tid >> 3) / (W2_TW / 2), pp_c = (tid >> 3) % (W2_TW / 2), H2 = H / 2, W2p = W / 2;
+    const int pprel = (pp_r * W2p + pp_c) * COUT + (tid & 7) * 8;
     auto load_tile = [&](int tile) {
         const int tc = tile < ntiles ? tile : ntiles - 1;
         const int tx = tc % tiles_x, ty = (tc / tiles_x) % tiles_y, b = tc / (tiles_x * tiles_y);
         const int t0 = ty * W2_TH, d0 = tx * W2_TW;
-        const bf16* in_b = a.in + (long)b * H * W * CIN + cs * 64;
-        const bf16* dy_b = a.dy + (long)b * H * W * COUT + ch * 64;
+        const bf16* in_o = a.in + (((long)b * H + t0) * W + d0) * CIN + cs * 64;             // the tile's origin pixel (always inside the map)
         okp = 0; okd = 0;
 #pragma unroll
         for (int i = 0; i < NPCH; ++i) {
-            const int c = tid + i * 256;
-            const int pix = c >> 3, pi = pix / W2_PW, pj = pix % W2_PW;
-            const int t = t0 + pi - 1, d = d0 + pj - 1;
-            const bool ok = c < W2_PH * W2_PW * 8 && t >= 0 && t < H && d >= 0 && d < W;
+            const bool ok = (unsigned)(t0 + ppi[i]) < (unsigned)H && (unsigned)(d0 + ppj[i]) < (unsigned)W;
             if (ok) okp |= 1u << i;
-            pr[i] = ld8(in_b + (ok ? ((long)t * W + d) : 0) * CIN + (c & 7) * 8);
+            pr[i] = ld8(in_o + (ok ? prel[i] : (tid & 7) * 8));
         }
         if constexpr (POOLED) {
-            const int pp = tid >> 3, t2 = t0 / 2 + pp / (W2_TW / 2), d2 = d0 / 2 + pp % (W2_TW / 2);
-            const bool ok = t2 < H / 2 && d2 < W / 2;                       // (floor mode: the cropped last row / column gets no gradient)
+            const int t2 = t0 / 2 + pp_r, d2 = d0 / 2 + pp_c;
+            const bool ok = t2 < H2 && d2 < W2p;                            // (floor mode: the cropped last row / column gets no gradient)
             if (ok) okd = 1u;
-            const long pe = (((long)b * (H / 2) + (ok ? t2 : 0)) * (W / 2) + (ok ? d2 : 0)) * COUT + ch * 64 + (tid & 7) * 8;
-            dr[0] = ld8(a.dy_pooled + pe);
-            pcode = *reinterpret_cast<const uint2*>(a.pool_idx + pe);
+            // (origin cell of the tile: inside the pooled map unless the map's last row / column is the cropped one -- then ok is false for
+            // every cell of the tile and the clamped origin is read)
+            const int t2o = t0 / 2 < H2 ? t0 / 2 : H2 - 1, d2o = d0 / 2 < W2p ? d0 / 2 : W2p - 1;
+            const long po = (((long)b * H2 + t2o) * W2p + d2o) * COUT + ch * 64;
+            const int rel = ok ? pprel : (tid & 7) * 8;
+            dr[0] = ld8(a.dy_pooled + po + rel);
+            pcode = *reinterpret_cast<const uint2*>(a.pool_idx + po + rel);
         } else {
+            const bf16* dy_o = a.dy + (((long)b * H + t0) * W + d0) * COUT + ch * 64;
 #pragma unroll
-        for (int i = 0; i < NDCH; ++i) {
-            const int c = tid + i * 256;
-            const int pix = c >> 3, t = t0 + pix / W2_TW, d = d0 + pix % W2_TW;
-            const bool ok = t < H && d < W;
-            if (ok) okd |= 1u << i;
-            dr[i] = ld8(dy_b + (ok ? ((long)t * W + d) : 0) * COUT + (c & 7) * 8);
-        }
+            for (int i = 0; i < NDCH; ++i) {
+                const bool ok = t0 + dpi[i] < H && d0 + dpj[i] < W;
+                if (ok) okd |= 1u << i;
+                dr[i] = ld8(dy_o + (ok ? drel[i] : (tid & 7) * 8));
+            }
         }
     };
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bool do_db = a.db != nullptr && cs == 0;
-    auto store_tile = [&]() {
+    // dbm: 1.0 when this tile's dy counts towards the bias gradient (branch-free: the fetch / staging / MFMA code of a tile is ONE basic block, so
+    // that the scheduler can spread the vector work of the staging over the MFMA phase)
+    auto store_tile = [&](bf16* patch, bf16* dyt, float dbm) {
 #pragma unroll
         for (int i = 0; i < NPCH; ++i) {
             const int c = tid + i * 256;
@@ -2113,7 +2138,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs 
                 const bf16 gj = okd ? dr[0][j] : (bf16)0.f;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k][j] = cj == (unsigned)k ? gj : (bf16)0.f;
-                if (do_db) csum[j] += cj < 4u ? (float)gj : 0.f;
+                csum[j] = fmaf(dbm, cj < 4u ? (float)gj : 0.f, csum[j]);
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) st8(dyt + ((2 * pr2 + (k >> 1)) * W2_TW + 2 * pc2 + (k & 1)) * W2_LDY + (tid & 7) * 8, o[k]);
@@ -2123,10 +2148,8 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs 
             const int c = tid + i * 256;
             const bf16x8 v = (okd >> i) & 1 ? dr[i] : zero8();
             st8(dyt + (c >> 3) * W2_LDY + (c & 7) * 8, v);
-            if (do_db) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) csum[j] += (float)v[j];
-            }
+            for (int j = 0; j < 8; ++j) csum[j] = fmaf(dbm, (float)v[j], csum[j]);
         }
         }
     };
@@ -2143,23 +2166,27 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs 
     typedef __attribute__((address_space(3))) bf16x4 lds_b4;
     const int g = lane >> 4, q = (lane & 15) >> 2, p4 = (lane & 3) * 4;
 
-    int tile = blockIdx.x;
-    if (OCC == 1 && tile < ntiles) { load_tile(tile); store_tile(); }
+    int tile = blockIdx.x, it = 0;
+    const float dbm1 = do_db ? 1.f : 0.f;
+    if (OCC == 1 && tile < ntiles) { load_tile(tile); store_tile(patch_, dyt_, dbm1); load_tile(tile + nwg); }
     __syncthreads();
-    for (; tile < ntiles; tile += nwg) {
+    for (; tile < ntiles; tile += nwg, ++it) {
         const bool has_next = tile + nwg < ntiles;
+        const bf16* patch = patch_ + (OCC == 1 ? (it & 1) * PATCH_EL : 0);
+        const bf16* dyt = dyt_ + (OCC == 1 ? (it & 1) * DYT_EL : 0);
         if constexpr (OCC == 1) {
-            load_tile(tile + nwg);                               // in flight during the MFMAs (clamped when past the end)
-            __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch ahead of the MFMAs (hipcc would sink it)
+            // the registers hold tile + nwg (requested a whole MFMA phase ago): into the OTHER buffer now (last read before the barrier that
+            // ended the previous tile), then request tile + 2 nwg; both run under this tile's MFMAs
+            // (behind the last tile the registers hold a clamped re-read: staged into the buffer nobody reads any more, not counted)
+            store_tile(patch_ + ((it + 1) & 1) * PATCH_EL, dyt_ + ((it + 1) & 1) * DYT_EL, has_next ? dbm1 : 0.f);
+            load_tile(tile + 2 * nwg);                           // (clamped when past the end)
         } else {
             // two workgroups per CU: no register prefetch (it would spill at 256 VGPRs); the co-resident workgroup's MFMA
             // phase covers this one's load + staging
-            load_tile(tile); store_tile();
+            load_tile(tile); store_tile(patch_, dyt_, dbm1);
             __syncthreads();
         }
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {                         // slab of 32 pixels = RPS pixel rows
-            bf16x8 af[4];
+        auto read_a = [&](int kc, bf16x8 (&af)[4]) {
 #pragma unroll
             for (int fm = 0; fm < 4; ++fm) {
                 const bf16* a0 = dyt + (kc * 32 + 4 * g + q) * W2_LDY + fm * 16 + p4;
@@ -2168,27 +2195,53 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs 
                 af[fm][0] = lo[0]; af[fm][1] = lo[1]; af[fm][2] = lo[2]; af[fm][3] = lo[3];
                 af[fm][4] = hi[0]; af[fm][5] = hi[1]; af[fm][6] = hi[2]; af[fm][7] = hi[3];
             }
+        };
+        auto read_b = [&](int kc, int tap) {
+            const int dyi = tap / 3, dxj = tap % 3;
+            const int pi = 4 * g + q;                           // pixel of the slab's first half this lane addresses
+            const bf16* b0 = patch + ((RPS * kc + pi / W2_TW + dyi) * W2_PW + pi % W2_TW + dxj) * W2_PS + wave * 16 + p4;
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)b0);
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(b0 + (16 / W2_TW) * W2_PW * W2_PS));
+            bf16x8 bfr;
+            bfr[0] = lo[0]; bfr[1] = lo[1]; bfr[2] = lo[2]; bfr[3] = lo[3];
+            bfr[4] = hi[0]; bfr[5] = hi[1]; bfr[6] = hi[2]; bfr[7] = hi[3];
+            return bfr;
+        };
+        if constexpr (OCC == 1) {
+            // one wave per SIMD: nobody else covers the LDS latency in front of each tap's four MFMAs, so the x fragment of the NEXT tap (and the
+            // dy fragments of the next pixel slab) are requested before the current tap's MFMAs issue
+            bf16x8 af[2][4];
+            read_a(0, af[0]);
+            bf16x8 bcur = read_b(0, 0);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int dyi = tap / 3, dxj = tap % 3;
-                {
-                    const int pi = 4 * g + q;                   // pixel of the slab's first half this lane addresses
-                    const bf16* b0 = patch + ((RPS * kc + pi / W2_TW + dyi) * W2_PW + pi % W2_TW + dxj) * W2_PS + wave * 16 + p4;
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)b0);
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(b0 + (16 / W2_TW) * W2_PW * W2_PS));
-                    bf16x8 bfr;
-                    bfr[0] = lo[0]; bfr[1] = lo[1]; bfr[2] = lo[2]; bfr[3] = lo[3];
-                    bfr[4] = hi[0]; bfr[5] = hi[1]; bfr[6] = hi[2]; bfr[7] = hi[3];
+            for (int kc = 0; kc < 4; ++kc) {
 #pragma unroll
-                    for (int fm = 0; fm < 4; ++fm) acc[tap][fm] = mma16(af[fm], bfr, acc[tap][fm]);
+                for (int tap = 0; tap < 9; ++tap) {
+                    bf16x8 bnext = bcur;
+                    if (tap < 8) bnext = read_b(kc, tap + 1);
+                    else if (kc < 3) bnext = read_b(kc + 1, 0);
+                    if (tap == 4 && kc < 3) read_a(kc + 1, af[(kc + 1) & 1]);
+#pragma unroll
+                    for (int fm = 0; fm < 4; ++fm) acc[tap][fm] = mma16(af[kc & 1][fm], bcur, acc[tap][fm]);
+                    bcur = bnext;
                 }
             }
+            // (sched_group_barrier pipelines -- 36 groups of 4 MFMAs + 3 fragment reads + 8 vector instructions, the LDS writes and global loads
+            // spread over the first groups -- ran 10-20 % slower than hipcc's own order: 138-146 us against 121.)
+        } else {
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {                         // slab of 32 pixels = RPS pixel rows
+            bf16x8 af[4];
+            read_a(kc, af);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const bf16x8 bfr = read_b(kc, tap);
+#pragma unroll
+                for (int fm = 0; fm < 4; ++fm) acc[tap][fm] = mma16(af[fm], bfr, acc[tap][fm]);
+            }
+        }
         }
         __syncthreads();
-        if constexpr (OCC == 1) {
-            if (has_next) store_tile();
-            __syncthreads();
-        }
     }
 
     float* out = a.slab + (long)blockIdx.x * COUT * KTOT;
@@ -2204,7 +2257,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs 
             }
     if (do_db) {
         // threads with equal tid % 8 own the same 8 output channels
-        float* red = reinterpret_cast<float*>(patch);                 // [256][8] floats = 8 KB
+        float* red = reinterpret_cast<float*>(patch_);                // [256][8] floats = 8 KB
 #pragma unroll
         for (int j = 0; j < 8; ++j) red[tid * 8 + j] = csum[j];
         __syncthreads();

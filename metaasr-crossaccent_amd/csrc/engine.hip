@@ -1291,6 +1291,17 @@ int masr_test_layernorm(const float* x, const float* gamma, const float* beta, c
     if (mk_layernorm_fwd(x, gamma, beta, y, (bf16*)y16, mean, rstd, rows, E, (hipStream_t)stream)) return -1;
     return mk_layernorm_bwd(dy, x, gamma, mean, rstd, dx, (bf16*)dx16, 0.f, 0, 0, dgamma, dbeta, slab, rows, E, (hipStream_t)stream, nullptr);
 }
+int masr_test_wgrad_grouped(const uint16_t* dy, int64_t lddy, const uint16_t* x, int64_t ldx, float* dW, float* db, float* dW2, float* db2,
+                            int rows, int N, int K, int tile, void* stream) {
+    // two members over the same operands (the second one optional): exercises the descriptor walk of the grouped grid
+    WgradGroup grp{};
+    grp.n = dW2 ? 2 : 1;
+    for (int i = 0; i < grp.n; ++i) {
+        WgradDesc& d = grp.p[i];
+        d.dy = (const bf16*)dy; d.x = (const bf16*)x; d.dW = i ? dW2 : dW; d.db = i ? db2 : db; d.lddy = (int)lddy; d.ldx = (int)ldx; d.rows = rows; d.N = N; d.K = K;
+    }
+    return mk_gemm_wgrad_grouped(grp, (hipStream_t)stream, tile);
+}
 int masr_test_conv3x3_wgrad_pooled(const uint16_t* in, const uint16_t* dy_pooled, const uint8_t* pool_idx, float* dw, float* db, float* slab,
                                    int64_t slab_floats, int B, int H, int W, int CIN, int COUT, void* stream) {
     if (slab_floats < mk_conv3x3_wgrad_slab_floats(B, H, W, CIN, COUT)) { mk_set_error("masr_test_conv3x3_wgrad_pooled", "slab too small"); return -1; }

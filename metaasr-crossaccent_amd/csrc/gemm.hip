@@ -398,6 +398,7 @@ __global__ __launch_bounds__(256) void gemm_wgrad_grouped_kernel(WgradGroup grp)
     const int t = tlin - d.tile_start, tiles_x = (d.K + BN - 1) / BN;
     gemm_body<BM, BN, true, E_C32>(g, t % tiles_x, t / tiles_x, 0);
 }
+
 #undef HAS
 
 // ---- NT form with LDS-DMA staging (global_load_lds_dwordx4): tiles go HBM/L2 -> LDS without touching VGPRs, the next
@@ -580,6 +581,10 @@ int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s, int tile) {
         d.tile_start = tiles;
         tiles += ((d.N + tile - 1) / tile) * ((d.K + tile - 1) / tile);
     }
+    // (Tried: the 128 x 128 form with LDS-DMA staging -- reduction-major tiles are lane-linear per DMA piece as they are, chunk c of row k
+    // at c ^ (k & 15) for the transposing reads, zero line behind the last row, bias gradient as one more MFMA column against ones: 202 us
+    // against this kernel's 160 on the encoder-row launch.  Eight DMA pieces per wave and k tile cost more issue time than the 32 MFMAs
+    // they feed (100-185 cycles each beside fragment reads), and the register path spreads its loads and LDS writes over the whole gap.)
     if (tile == 64) hipLaunchKernelGGL((gemm_wgrad_grouped_kernel<64, 64>), dim3(tiles), dim3(256), 0, s, grp);
     else hipLaunchKernelGGL((gemm_wgrad_grouped_kernel<128, 128>), dim3(tiles), dim3(256), 0, s, grp);
     if (hipGetLastError() != hipSuccess) { mk_set_error("mk_gemm_wgrad_grouped", "launch failed"); return -1; }

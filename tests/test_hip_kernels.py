@@ -59,6 +59,26 @@ def test_gemm_reduction_major(L, M, N, K):
     torch.testing.assert_close(Cc, ref, rtol=2e-4, atol=2e-3 * (K ** 0.5) / 8)
 
 
+@pytest.mark.parametrize("rows,N,K,tile", [(4000, 512, 512, 128), (1000, 1536, 512, 128), (777, 256, 2048, 128), (63, 128, 128, 128), (592, 512, 2048, 64),
+                                         (500, 200, 328, 128), (4000, 2560, 512, 128)])
+def test_wgrad_grouped(L, rows, N, K, tile):
+    """mk_gemm_wgrad_grouped (the Linear weight gradients of a backward pass as one grid, lin_wgrad / flush_enc_wgrads): dW = dY^T X and
+    the fused bias gradient, two members per launch; reductions that are not multiples of the 64-row k tile (4000, 777, 63), output dims
+    that are not multiples of the tile (200 x 328)."""
+    g = torch.Generator(device="cuda").manual_seed(rows + N + K)
+    lddy, ldx = (N + 7) // 8 * 8 + 8, (K + 7) // 8 * 8
+    dy = torch.zeros(rows, lddy, device="cuda").bfloat16(); dy[:, :N] = torch.randn(rows, N, device="cuda", generator=g).bfloat16()
+    x = torch.zeros(rows, ldx, device="cuda").bfloat16(); x[:, :K] = torch.randn(rows, K, device="cuda", generator=g).bfloat16()
+    dW = torch.full((N + 1, K), 7.0, device="cuda"); db = torch.zeros(N, device="cuda")
+    dW2 = torch.zeros(N, K, device="cuda"); db2 = torch.zeros(N, device="cuda")
+    _cabi.check(L.masr_test_wgrad_grouped(P(dy), lddy, P(x), ldx, P(dW), P(db), P(dW2), P(db2), rows, N, K, tile, S()))
+    ref = dy[:, :N].float().t() @ x[:, :K].float()
+    torch.testing.assert_close(dW[:N], ref, rtol=2e-4, atol=2e-3 * (rows ** 0.5) / 8)
+    assert torch.all(dW[N] == 7.0) and torch.equal(dW[:N], dW2)
+    torch.testing.assert_close(db, dy[:, :N].float().sum(0), rtol=1e-4, atol=1e-3 * rows ** 0.5)
+    assert torch.equal(db, db2)
+
+
 def test_gemm_exact_integers(L):
     """A = I check with an asymmetric B (catches transposed fragment maps exactly)."""
     M = N = K = 64
