@@ -526,9 +526,11 @@ def main():
             "conv3_dgrad": ("conv3x3_stream_kernel<128,64> (64<-128 dgrad)", c3, B * H2 * W2 * (128 + 64) * 2),
             "conv4_dgrad": ("conv3x3_stream_kernel<128,128,32-row tiles,sign-bit mask> (128<-128 dgrad through the ReLU mask)", c4, B * H2 * W2 * (256 * 2 + 16)),
             # (the wgrad slots time the partial-slab kernel alone; the slab reduces are under conv1_wgrad, "weight-gradient folds")
-            "conv2_wgrad": ("conv3x3_wgrad2_kernel<64,64>", c2, 2 * B * T * D * 64 * 2),
-            "conv3_wgrad": ("conv3x3_wgrad2_kernel<64,128>", c3, B * H2 * W2 * (64 + 128) * 2),
-            "conv4_wgrad": ("conv3x3_wgrad2_kernel<128,128>", c4, B * H2 * W2 * 256 * 2),
+            # (the two in front of a max-pool read their dy as pooled gradient (2 B) + pool code (1 B) per pooled element; every launch
+            # writes 256 partial slabs of 9*CIN*COUT fp32 per 64x64 channel block: 37.7 MB)
+            "conv2_wgrad": ("conv3x3_wgrad2_kernel<64,64,pooled dy> (one workgroup per CU)", c2, B * T * D * 64 * 2 + B * H2 * W2 * 64 * 3 + 256 * 9 * 64 * 64 * 4),
+            "conv3_wgrad": ("conv3x3_wgrad2_kernel<64,128>", c3, B * H2 * W2 * (64 + 128) * 2 + 128 * 2 * 9 * 64 * 64 * 4),
+            "conv4_wgrad": ("conv3x3_wgrad2_kernel<128,128,pooled dy>", c4, B * H2 * W2 * 128 * 2 + B * (H2 // 2) * (W2 // 2) * 128 * 3 + 64 * 4 * 9 * 64 * 64 * 4),
         }
         pmc, pmc_src = {}, None
         try:                                                     # HBM bytes per launch from this round's PMC passes (tools/pmc_traffic.py)
