@@ -305,6 +305,11 @@ int masr_test_conv3x3_wgrad_pooled(const uint16_t* in, const uint16_t* dy_pooled
 int64_t masr_test_layernorm_slab_floats(int rows, int E);
 int masr_test_layernorm(const float* x, const float* gamma, const float* beta, const float* dy, float* y, uint16_t* y16, float* mean,
                         float* rstd, float* dx, uint16_t* dx16, float* dgamma, float* dbeta, float* slab, int rows, int E, void* stream);
+/* forward + backward of one attention with dropout on the probabilities (keep-scale of element ((b H + h) Tq + i) Tk + j at `site`,
+ * masr_test_dropout_mask): the backward regenerates the masks of the forward from (seed, site, index) */
+int masr_test_attention_dropout_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* dout, uint16_t* o, uint16_t* dq, uint16_t* dk,
+                                    uint16_t* dv, float* lse, const int32_t* klens, int B, int H, int Tq, int Tk, int hd, int causal, float drop_p,
+                                    uint32_t seed, uint32_t site, void* stream);
 int masr_test_attention(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* dout, uint16_t* o,
                         uint16_t* dq, uint16_t* dk, uint16_t* dv, float* lse, float* delta, const int32_t* klens,
                         int B, int H, int Tq, int Tk, int hd, int causal, void* stream);

@@ -1309,6 +1309,17 @@ int masr_test_conv3x3_wgrad_pooled(const uint16_t* in, const uint16_t* dy_pooled
     a.B = B; a.H = H; a.W = W; a.CIN = CIN; a.COUT = COUT;
     return mk_conv3x3_wgrad(a, (hipStream_t)stream);
 }
+int masr_test_attention_dropout_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* dout, uint16_t* o, uint16_t* dq, uint16_t* dk,
+                                    uint16_t* dv, float* lse, const int32_t* klens, int B, int H, int Tq, int Tk, int hd, int causal, float drop_p,
+                                    uint32_t seed, uint32_t site, void* stream) {
+    const long E = (long)H * hd;
+    AttnArgs a{};
+    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ldq = a.ldk = a.ldv = E; a.o = (bf16*)o; a.ldo = E; a.lse = lse;
+    a.klens = klens; a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.causal = causal; a.drop_p = drop_p; a.seed = seed; a.site = site;
+    CK(mk_attn_fwd(a, (hipStream_t)stream));
+    a.dout = (const bf16*)dout; a.lddo = E; a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.lddq = a.lddk = a.lddv = E;
+    return mk_attn_bwd(a, (hipStream_t)stream);
+}
 int masr_test_attention(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* dout, uint16_t* o, uint16_t* dq, uint16_t* dk,
                         uint16_t* dv, float* lse, float* delta, const int32_t* klens, int B, int H, int Tq, int Tk, int hd, int causal,
                         void* stream) {

@@ -359,6 +359,43 @@ def test_attention_huge_scores(L, B_, H, T, hd, mag):
     assert float(dvd.max()) <= 1.01 * float(dout.float().abs().max()) * 2 and float((dvd > 3e-2 * float(dout.float().abs().max())).float().mean()) < 0.1
 
 
+@pytest.mark.parametrize("B_,H,Tq,Tk,hd,causal,masked", [
+    (2, 8, 250, 250, 64, 0, True), (3, 8, 37, 250, 64, 0, True), (2, 8, 37, 37, 64, 1, False), (2, 4, 150, 40, 64, 0, True), (2, 4, 130, 130, 64, 1, False),
+    (2, 4, 70, 90, 16, 0, True), (2, 2, 33, 33, 32, 1, False)])
+def test_attention_dropout_forward_backward(L, B_, H, Tq, Tk, hd, causal, masked):
+    """Dropout on the attention probabilities (nn.MultiheadAttention(dropout=p), mono_transformer_torch.py:74-98), forward AND backward, in every
+    kernel variant (head dim 64: 8-wave / 4-wave ring forward, 4 x 2 / 4 x 1 row-tile backward bodies on either side; head dim 16 / 32:
+    register-staged): the backward regenerates the forward's masks from (seed, site, ((b H + h) Tq + i) Tk + j).  Reference: torch autograd
+    through softmax -> (mask from masr_test_dropout_mask) -> P V on the same bf16 operands."""
+    p, seed, site = 0.2, 4321, 7
+    g = torch.Generator(device="cuda").manual_seed(Tq * 3 + Tk + hd)
+    mk = lambda T: torch.randn(B_, T, H, hd, device="cuda", generator=g).bfloat16()
+    q, k, v, dout = mk(Tq), mk(Tk), mk(Tk), mk(Tq)
+    klens = torch.randint(max(1, Tk // 3), Tk + 1, (B_,), device="cuda", generator=g).int() if masked else None
+    o = torch.zeros_like(q); dq = torch.zeros_like(q); dk = torch.zeros_like(k); dv = torch.zeros_like(v)
+    lse = torch.zeros(B_, H, Tq, device="cuda")
+    _cabi.check(L.masr_test_attention_dropout_bwd(P(q), P(k), P(v), P(dout), P(o), P(dq), P(dk), P(dv), P(lse), P(klens) if masked else None,
+                                                  B_, H, Tq, Tk, hd, causal, p, seed, site, S()))
+    keep = torch.empty(B_ * H * Tq * Tk, device="cuda")
+    _cabi.check(L.masr_test_dropout_mask(seed, site, keep.numel(), p, P(keep), S()))
+    keep = keep.view(B_, H, Tq, Tk)
+    qf, kf, vf = [t.float().requires_grad_(True) for t in (q, k, v)]
+    sc = torch.einsum("bqhd,bkhd->bhqk", qf, kf) / hd ** 0.5
+    msk = torch.zeros(B_, 1, Tq, Tk, dtype=torch.bool, device="cuda")
+    if masked:
+        for b in range(B_):
+            msk[b, :, :, int(klens[b]):] = True
+    if causal:
+        msk = msk | torch.triu(torch.ones(Tq, Tk, dtype=torch.bool, device="cuda"), 1)
+    pr = torch.softmax(sc.masked_fill(msk, float("-inf")), -1) * keep
+    ro = torch.einsum("bhqk,bkhd->bqhd", pr, vf)
+    ro.backward(dout.float())
+    rms = lambda t: float(t.pow(2).mean().sqrt())
+    for name, a, r in (("o", o, ro.detach()), ("dq", dq, qf.grad), ("dk", dk, kf.grad), ("dv", dv, vf.grad)):
+        err = rms(a.float() - r) / rms(r)
+        assert err < 0.012, f"{name}: rel rms error {err:.4f}"           # (bf16 rounding of P, dS, O and the outputs: 0.002-0.006; a wrong mask: > 0.3)
+
+
 def test_dropout_keep_rate_and_scale_per_site():
     """nn.Dropout semantics at every site of the engine (PE dropout 1 / 100, attention probabilities, attention out-proj,
     FFN inner, FFN out: sites 1.. and 100.. in csrc/engine.hip): an element is kept with probability 1 - p and scaled by
