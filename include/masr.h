@@ -304,7 +304,8 @@ int masr_test_conv3x3_wgrad_pooled(const uint16_t* in, const uint16_t* dy_pooled
  * y, y16 (bf16), mean / rstd per row; dx, dgamma, dbeta from dy.  slab: masr_test_layernorm_slab_floats(rows, E) floats of scratch. */
 int64_t masr_test_layernorm_slab_floats(int rows, int E);
 int masr_test_layernorm(const float* x, const float* gamma, const float* beta, const float* dy, float* y, uint16_t* y16, float* mean,
-                        float* rstd, float* dx, uint16_t* dx16, float* dgamma, float* dbeta, float* slab, int rows, int E, void* stream);
+                        float* rstd, float* dx, uint16_t* dx16, float* dgamma, float* dbeta, float* slab, int rows, int E, float drop_p,
+                        uint32_t seed, uint32_t site, void* stream);   /* dx16 = bf16(dx * keep-scale of element row * E + col at `site`) */
 /* forward + backward of one attention with dropout on the probabilities (keep-scale of element ((b H + h) Tq + i) Tk + j at `site`,
  * masr_test_dropout_mask): the backward regenerates the masks of the forward from (seed, site, index) */
 int masr_test_attention_dropout_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* dout, uint16_t* o, uint16_t* dq, uint16_t* dk,

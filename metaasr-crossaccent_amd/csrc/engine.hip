@@ -1287,9 +1287,10 @@ int masr_test_conv3x3_wgrad(const uint16_t* in, const uint16_t* dy, float* dw, f
 }
 int64_t masr_test_layernorm_slab_floats(int rows, int E) { return mk_layernorm_bwd_slab_floats(rows, E); }
 int masr_test_layernorm(const float* x, const float* gamma, const float* beta, const float* dy, float* y, uint16_t* y16, float* mean,
-                        float* rstd, float* dx, uint16_t* dx16, float* dgamma, float* dbeta, float* slab, int rows, int E, void* stream) {
+                        float* rstd, float* dx, uint16_t* dx16, float* dgamma, float* dbeta, float* slab, int rows, int E, float drop_p,
+                        uint32_t seed, uint32_t site, void* stream) {
     if (mk_layernorm_fwd(x, gamma, beta, y, (bf16*)y16, mean, rstd, rows, E, (hipStream_t)stream)) return -1;
-    return mk_layernorm_bwd(dy, x, gamma, mean, rstd, dx, (bf16*)dx16, 0.f, 0, 0, dgamma, dbeta, slab, rows, E, (hipStream_t)stream, nullptr);
+    return mk_layernorm_bwd(dy, x, gamma, mean, rstd, dx, (bf16*)dx16, drop_p, seed, site, dgamma, dbeta, slab, rows, E, (hipStream_t)stream, nullptr);
 }
 int masr_test_wgrad_grouped(const uint16_t* dy, int64_t lddy, const uint16_t* x, int64_t ldx, float* dW, float* db, float* dW2, float* db2,
                             int rows, int N, int K, int tile, void* stream) {

@@ -321,7 +321,7 @@ def test_layernorm_fwd_bwd(L, rows, E):
     dgm = torch.zeros(E, device="cuda"); dbt = torch.zeros(E, device="cuda")
     slab = torch.zeros(int(L.masr_test_layernorm_slab_floats(rows, E)), device="cuda")
     _cabi.check(L.masr_test_layernorm(P(x.detach()), P(gamma.detach()), P(beta.detach()), P(dy), P(y), P(y16), P(mean), P(rstd), P(dx), P(dx16),
-                                      P(dgm), P(dbt), P(slab), rows, E, S()))
+                                      P(dgm), P(dbt), P(slab), rows, E, 0.0, 0, 0, S()))
     torch.testing.assert_close(y, ref.detach(), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(y16.float(), ref.detach().bfloat16().float(), rtol=1e-2, atol=1e-2)
     torch.testing.assert_close(mean, x.detach().mean(1), rtol=1e-5, atol=1e-5)
@@ -330,6 +330,13 @@ def test_layernorm_fwd_bwd(L, rows, E):
     torch.testing.assert_close(dx16.float(), x.grad.bfloat16().float(), rtol=1e-2, atol=1e-2)
     torch.testing.assert_close(dgm, gamma.grad, rtol=1e-4, atol=1e-4 * rows ** 0.5)
     torch.testing.assert_close(dbt, beta.grad, rtol=1e-4, atol=1e-4 * rows ** 0.5)
+    # the bf16 copy of dx carries the dropout of the sublayer output that feeds this LayerNorm's residual sum (keep-scale of element row * E + col)
+    dxd = torch.full((rows + 1, E), 7.0, device="cuda"); dx16d = torch.zeros(rows, E, device="cuda").bfloat16()
+    _cabi.check(L.masr_test_layernorm(P(x.detach()), P(gamma.detach()), P(beta.detach()), P(dy), P(y), P(y16), P(mean), P(rstd), P(dxd), P(dx16d),
+                                      P(dgm), P(dbt), P(slab), rows, E, 0.25, 99, 4, S()))
+    keep = torch.empty(rows * E, device="cuda")
+    _cabi.check(L.masr_test_dropout_mask(99, 4, rows * E, 0.25, P(keep), S()))
+    assert torch.equal(dxd[:rows], dx[:rows]) and torch.equal(dx16d, (dx[:rows] * keep.view(rows, E)).bfloat16())
 
 
 @pytest.mark.parametrize("B_,H,T,hd,mag", [(4, 4, 3, 16, 3e4), (2, 8, 250, 64, 3e3), (2, 4, 37, 64, 1e4), (1, 2, 130, 32, 1e3)])
