@@ -2777,6 +2777,7 @@ int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s, int phase) {
         if (occ == 1) { if (narrow) W2T(CI, CO, 1, 8); else W2T(CI, CO, 1, 16); } \
         else { if (narrow) W2T(CI, CO, 2, 8); else W2T(CI, CO, 2, 16); }
         const bool pooled = a.dy_pooled && a.pool_idx && !narrow;
+        if (!pooled && !a.dy) { mk_set_error("mk_conv3x3_wgrad", "dy missing (the pooled form needs 16-wide tiles)"); return -1; }
         if (pooled && !((a.CIN == 64 && a.COUT == 64) || (a.CIN == 128 && a.COUT == 128))) { mk_set_error("mk_conv3x3_wgrad", "pooled dy: 64->64 and 128->128 only"); return -1; }
         if (phase == 2) {}
         else if (pooled && a.CIN == 64) W2P(64, 64)
