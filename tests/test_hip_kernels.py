@@ -281,7 +281,10 @@ def _attn_ref(q, k, v, klens, causal, dout):
 
 @pytest.mark.parametrize("B_,H,Tq,Tk,hd,causal,masked", [
     (2, 2, 31, 31, 64, 1, False), (3, 4, 250, 250, 64, 0, True), (2, 8, 31, 250, 64, 0, True),
-    (2, 4, 12, 16, 16, 0, True), (2, 4, 10, 10, 16, 1, False), (1, 2, 70, 130, 32, 0, True), (2, 2, 100, 100, 32, 1, False)])
+    (2, 4, 12, 16, 16, 0, True), (2, 4, 10, 10, 16, 1, False), (1, 2, 70, 130, 32, 0, True), (2, 2, 100, 100, 32, 1, False),
+    # long sequences (3000-frame dev utterances: T' = 750): more than 8 query blocks, i.e. the dK/dV workgroups refresh their block of
+    # log-sum-exp / rowsum(dO O) statistics inside the loop; ring depth << number of blocks; causal block skipping at a distance
+    (1, 2, 750, 750, 64, 0, True), (1, 2, 700, 700, 64, 1, False), (2, 2, 40, 1100, 64, 0, True), (1, 2, 1100, 48, 64, 0, False), (1, 2, 600, 600, 32, 1, False)])
 def test_attention(L, B_, H, Tq, Tk, hd, causal, masked):
     g = torch.Generator(device="cuda").manual_seed(Tq * 7 + Tk + hd)
     q = torch.randn(B_, Tq, H, hd, device="cuda", generator=g).bfloat16()
@@ -368,7 +371,7 @@ def test_attention_huge_scores(L, B_, H, T, hd, mag):
 
 @pytest.mark.parametrize("B_,H,Tq,Tk,hd,causal,masked", [
     (2, 8, 250, 250, 64, 0, True), (3, 8, 37, 250, 64, 0, True), (2, 8, 37, 37, 64, 1, False), (2, 4, 150, 40, 64, 0, True), (2, 4, 130, 130, 64, 1, False),
-    (2, 4, 70, 90, 16, 0, True), (2, 2, 33, 33, 32, 1, False)])
+    (2, 4, 70, 90, 16, 0, True), (2, 2, 33, 33, 32, 1, False), (1, 2, 600, 640, 64, 0, True)])
 def test_attention_dropout_forward_backward(L, B_, H, Tq, Tk, hd, causal, masked):
     """Dropout on the attention probabilities (nn.MultiheadAttention(dropout=p), mono_transformer_torch.py:74-98), forward AND backward, in every
     kernel variant (head dim 64: 8-wave / 4-wave ring forward, 4 x 2 / 4 x 1 row-tile backward bodies on either side; head dim 16 / 32:
