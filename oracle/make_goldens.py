@@ -519,6 +519,24 @@ def gen_fomaml_cfg3_goldens():
 
 
 
+def _chain_cfgs():
+    """the chain's two YAML-shaped configs (pretrain: cfg3's model; fine-tune: the adapt/*.yaml shape)"""
+    base = {"data_root": "data", "spm_mapping": "data/toy_spm_units.txt", "spm_model": "data/toy_spm.model", "dev_max_ilen": 3000,
+            "min_ilen": 10, "max_ilen": 60, "half_batch_ilen": 100}
+    pre_model = dict(TINY)
+    pre_model["meta"] = {"optimizer_opt": {"k": 1.0, "warmup_steps": 25000}}
+    pre = {"asr_model": pre_model,
+           "solver": dict(base, setting="chain", total_steps=10, label_smoothing=0.1, eval_ival=2, log_ival=1, save_ival=2, batch_size=4,
+                          dev_batch_size=4)}
+    ft_model = {k: v for k, v in TINY.items() if k not in ("inner_optimizer_cls", "inner_optimizer_opt", "meta_opt_cls", "meta")}
+    ft_model.update({"optimizer_cls": "noam", "optimizer_opt": {"k": 0.2, "warmup_steps": 100}})
+    ft = {"asr_model": ft_model,
+          "solver": dict(base, setting="chain-ft", total_epochs=20, label_smoothing=0.1, eval_ival=50, log_ival=1000, batch_size=8,
+                         dev_batch_size=8, pretrain_module=["feat_extractor", "vgg2enc", "char_trans", "pre_embed", "encoder", "decoder"],
+                         freeze_module=["feat_extractor"], beam_decode={"beam_size": 1})}
+    return pre, ft
+
+
 def chain_workspace(root, spm_dir):
     """BASELINE configs[4] in miniature: learnable toy shards for 4 pretraining accents and the target accent (canada:
     train / dev / test), the toy SentencePiece model, and the two YAML-shaped configs (pretrain: cfg3's; fine-tune: the
@@ -534,20 +552,103 @@ def chain_workspace(root, spm_dir):
     write_learnable_shard(root / "data", "canada", "train", 96, seed=801, n_class=2)
     write_learnable_shard(root / "data", "canada", "dev", 8, seed=802, n_class=2)
     write_learnable_shard(root / "data", "canada", "test", 12, seed=803, n_class=2)
-    base = {"data_root": "data", "spm_mapping": "data/toy_spm_units.txt", "spm_model": "data/toy_spm.model", "dev_max_ilen": 3000,
-            "min_ilen": 10, "max_ilen": 60, "half_batch_ilen": 100}
-    pre_model = dict(TINY)
-    pre_model["meta"] = {"optimizer_opt": {"k": 1.0, "warmup_steps": 25000}}
-    pre = {"asr_model": pre_model,
-           "solver": dict(base, setting="chain", total_steps=10, label_smoothing=0.1, eval_ival=2, log_ival=1, save_ival=2, batch_size=4,
-                          dev_batch_size=4)}
-    ft_model = {k: v for k, v in TINY.items() if k not in ("inner_optimizer_cls", "inner_optimizer_opt", "meta_opt_cls", "meta")}
-    ft_model.update({"optimizer_cls": "noam", "optimizer_opt": {"k": 0.2, "warmup_steps": 100}})
-    ft = {"asr_model": ft_model,
-          "solver": dict(base, setting="chain-ft", total_epochs=20, label_smoothing=0.1, eval_ival=50, log_ival=1000, batch_size=8,
-                         dev_batch_size=8, pretrain_module=["feat_extractor", "vgg2enc", "char_trans", "pre_embed", "encoder", "decoder"],
-                         freeze_module=["feat_extractor"], beam_decode={"beam_size": 1})}
+    return _chain_cfgs()
+
+
+EIGHT_ACCENTS = [("af", "african"), ("au", "australia"), ("en", "england"), ("us", "us"), ("hk", "hongkong"), ("in", "indian"),
+                 ("ir", "ireland"), ("nz", "newzealand")]
+
+
+def eight_workspace(root, spm_dir):
+    """BASELINE configs[3] / configs[4] at toy size: EIGHT pretraining accents (learnable shards, 32 train / 4 dev utterances
+    each) + the target accent canada (train / dev / test), the toy SentencePiece model, the pretrain YAML (cfg3's model, the
+    shipped Noam schedule) and the chain's fine-tune YAML.  Shared by gen_fomaml_8acc_goldens and tests/test_hip_cfg45.py."""
+    root = Path(root)
+    (root / "data").mkdir(parents=True, exist_ok=True)
+    json.dump(dict(EIGHT_ACCENTS + [("ca", "canada")]), open(root / "data" / "accent-code.json", "w"))
+    for f in ("toy_spm.model", "toy_spm_units.txt"):
+        shutil.copy(Path(spm_dir) / f, root / "data" / f)
+    for ai, (_, a) in enumerate(EIGHT_ACCENTS):
+        write_learnable_shard(root / "data", a, "train", 32, seed=900 + ai)
+        write_learnable_shard(root / "data", a, "dev", 4, seed=950 + ai)
+    write_learnable_shard(root / "data", "canada", "train", 96, seed=801, n_class=2)
+    write_learnable_shard(root / "data", "canada", "dev", 8, seed=802, n_class=2)
+    write_learnable_shard(root / "data", "canada", "test", 12, seed=803, n_class=2)
+    pre, ft = _chain_cfgs()
+    pre["solver"]["setting"], ft["solver"]["setting"] = "eight", "eight-ft"
     return pre, ft
+
+
+def eight_paras(algo="fomaml", meta_k=1, **extra):
+    p = vars(cfg3_paras(meta_k, pretrain_suffix="eight", pretrain_accents=[c for c, _ in EIGHT_ACCENTS], num_pretrain=8, meta_batch_size=8,
+                        max_step=3, algo=algo))
+    p.update(extra)
+    return SimpleNamespace(**p)
+
+
+def gen_fomaml_8acc_goldens():
+    """BASELINE configs[3] as far as one process goes: `pretrain.py --algo fomaml --num_pretrain 8 --meta_batch_size 8 --meta_k 1`
+    run by the REFERENCE (its own seed-531 initialisation after load_data(), as its CLI does): two meta-steps of eight tasks,
+    evaluate() on the eight dev sets after the second.  Captured: every run_batch call (batch identity, loss, acc, cer, wer), per
+    meta-step the fingerprints of the meta-gradient and of the post-Adam meta weights (+ a few small tensors in full), the
+    fingerprint of every initial tensor, every log file, the snapshot."""
+    from src.fo_meta_interface import FOMetaASRInterface
+    from src.transformer_torch_trainer import get_trainer
+    from functools import partial
+    tmp = Path(tempfile.mkdtemp(prefix="masr_gold_"))
+    cwd = os.getcwd()
+    out = {}
+    try:
+        cfg, _ = eight_workspace(tmp, OUT)
+        os.chdir(tmp)
+        id2accent = json.load(open("data/accent-code.json"))
+        random.seed(531); np.random.seed(531); torch.manual_seed(531)
+        solver = get_trainer(FOMetaASRInterface, cfg, eight_paras(), id2accent)
+        solver.load_data(); solver.set_model()
+        for n, t in solver._original.items():
+            out[f"init/fp/{n}"] = flat_checks(t)
+        rec, steps = [], []
+        orig = solver.run_batch
+
+        def spy(idx, x, ilens, ys, olens, train, accent_idx=None):
+            info = orig(idx, x, ilens.clone(), [y.clone() for y in ys], olens.clone(), train=train, accent_idx=accent_idx)
+            rec.append((int(idx), bool(train), ilens.numpy().copy(), np.concatenate([y.numpy() for y in ys]), dict(info)))
+            return info
+        solver._train, solver._eval = partial(spy, train=True), partial(spy, train=False)
+        orig_final = solver._final_meta_update
+
+        def final_spy():
+            mg = {n: (u / solver._counter).clone() for n, u in solver._updates.items()}
+            orig_final()
+            steps.append((mg, {n: t.detach().clone() for n, t in solver._original.items()}))
+        solver._final_meta_update = final_spy
+        solver.exec()
+        out["n_calls"] = np.int64(len(rec))
+        for i, (idx, train, il, ys, info) in enumerate(rec):
+            out[f"call{i}/accent"], out[f"call{i}/train"], out[f"call{i}/ilens"], out[f"call{i}/ys"] = np.int64(idx), np.int64(train), il, ys
+            for k, v in info.items():
+                out[f"call{i}/{k}"] = np.float64(v)
+        out["n_meta_steps"] = np.int64(len(steps))
+        for si, (mg, meta) in enumerate(steps):
+            for n in mg:
+                out[f"step{si}/metagrad/fp/{n}"] = flat_checks(mg[n])
+                out[f"step{si}/meta/fp/{n}"] = flat_checks(meta[n])
+            for n in ("vgg2enc.bias", "decoder.norm.weight", "char_trans.bias", "feat_extractor.0.weight", "encoder.layers.1.linear2.bias"):
+                out[f"step{si}/metagrad/full/{n}"] = mg[n].numpy().copy()
+        out["meta/step_num"], out["meta/lr"] = np.int64(solver.meta_opt.step_num), np.float64(solver.meta_opt.lr)
+        out["global_step"], out["inner_lr"] = np.int64(solver.global_step), np.float64(solver.inner_lr)
+        out["files"] = np.array(sorted(p.name for p in solver.log_dir.iterdir()))
+        for f in solver.log_dir.iterdir():
+            if f.name.startswith(("dev_", "train_", "best_")) or f.name == "global_step":
+                out[f"log/{f.name}"] = np.array(open(f).read())
+        for n, t in torch.load(solver.log_dir / "snapshot.latest").items():
+            out[f"snap/fp/{n}"] = flat_checks(t)
+        np.savez_compressed(OUT / "fomaml_8acc.npz", **out)
+        print(f"fomaml_8acc.npz: {len(rec)} calls ({sum(1 for r in rec if not r[1])} eval), {len(steps)} meta-steps, {len(out)} arrays")
+        print("   task order:", [r[0] for r in rec if r[1]][::2], "dev_avg_wer", repr(str(out["log/dev_avg_wer"])))
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def chain_paras(stage, **extra):
@@ -1084,7 +1185,7 @@ def main():
     sys.path.insert(0, str(REF))
     torch.set_num_threads(4)
     gens = [gen_masks_noam, gen_sampler_goldens, gen_ctc_goldens, gen_init_goldens, gen_metric_goldens, gen_model_goldens,
-            gen_fomaml_goldens, gen_fomaml_cfg3_goldens, gen_chain_goldens, gen_multi_goldens, gen_mono_goldens, gen_tester_goldens, gen_blstm_goldens,
+            gen_fomaml_goldens, gen_fomaml_cfg3_goldens, gen_fomaml_8acc_goldens, gen_chain_goldens, gen_multi_goldens, gen_mono_goldens, gen_tester_goldens, gen_blstm_goldens,
             gen_blstm_mono_goldens, gen_blstm_tester_goldens, gen_hkust_fullsize_goldens]
     only = set(sys.argv[1:])                       # e.g.  python oracle/make_goldens.py gen_fomaml_cfg3_goldens
     for g in gens:

@@ -476,13 +476,13 @@ def reptile_meta_step(meta, cfg, tasks, eps, adam_state, meta_step_num, momentum
     """
     names = grad_param_names(meta, cfg)
     updates = {n: torch.zeros_like(meta[n]) for n in names}
-    infos = []
+    infos, inner_infos = [], []
     lr_in = inner_lr(cfg)
+    p = None
     for tr_batches, val_batch in tasks:
         p = leafify(meta, cfg)
         bufs = {}
-        for b in tr_batches:
-            inner_step(p, cfg, b, eps, bufs, lr_in, momentum, nesterov)
+        inner_infos.append([inner_step(p, cfg, b, eps, bufs, lr_in, momentum, nesterov) for b in tr_batches])
         info, _, _, _ = run_batch_train(p, cfg, val_batch, eps)
         for n in names:
             updates[n] += meta[n].detach() - p[n].detach()
@@ -490,7 +490,9 @@ def reptile_meta_step(meta, cfg, tasks, eps, adam_state, meta_step_num, momentum
     for n in names:
         updates[n] /= len(tasks)
     if keep is not None:
+        keep["inner_infos"] = inner_infos
         keep["meta_grad"] = {n: u.clone() for n, u in updates.items()}          # the pseudo-gradient mean_k (theta_meta - theta_k), before Adam
+        keep["last_adapted"] = p
     o = cfg["meta"]["optimizer_opt"]
     lr = noam_lr(meta_step_num, o["k"], cfg["d_model"], o["warmup_steps"])
     adam_step(meta, updates, adam_state, lr)

@@ -309,6 +309,48 @@ def test_blstm_oracle_matches_reference(golden_dir, tag, ilens, olens):
                                g[f"{tag}/gradfull/encoder.blstm.rnn0.weight_hh_l0_reverse"], rtol=1e-3, atol=1e-7)
 
 
+def test_fomaml_8acc_oracle_matches_reference(golden_dir, tmp_path, monkeypatch):
+    """BASELINE configs[3] in one process (pretrain.py --algo fomaml, EIGHT accents, meta_batch_size 8, meta_k 1), run by the
+    reference from its own seed-531 initialisation (tests/golden/fomaml_8acc.npz): the oracle's meta loop over the product's
+    DataContainer, started from the product's init replay, reproduces it -- initial weights, same 16 tasks in the same order,
+    every train / eval loss within 2e-5, every meta-gradient tensor, the meta weights after both Adam steps."""
+    from replay import eight_accent_setup, oracle_fomaml_run
+    g = np.load(golden_dir / "fomaml_8acc.npz")
+    monkeypatch.chdir(tmp_path)
+    cfg, _, dc, init = eight_accent_setup(tmp_path, golden_dir)
+    for n, t in init.items():
+        if f"init/fp/{n}" in g.files:
+            _fp_close(flat_checks(t), g[f"init/fp/{n}"], rtol=1e-6)
+
+    def on_batch(i, accent, train, batch):
+        assert accent == int(g[f"call{i}/accent"]) and int(train) == int(g[f"call{i}/train"]), i
+        np.testing.assert_array_equal(batch[1].numpy(), g[f"call{i}/ilens"])
+        np.testing.assert_array_equal(np.concatenate([y.numpy() for y in batch[2]]), g[f"call{i}/ys"])
+
+    run = oracle_fomaml_run(cfg, dc, 1, 8, 3, cfg["solver"]["label_smoothing"], on_batch=on_batch, init_sd=init)
+    assert len(run["calls"]) == int(g["n_calls"]) == 40 and len(run["steps"]) == int(g["n_meta_steps"]) == 2
+    for i, (accent, train, info) in enumerate(run["calls"]):
+        for k in ("loss", "acc"):
+            ref = float(g[f"call{i}/{k}"])
+            assert abs(info[k] - ref) <= 2e-5 * abs(ref) + 1e-12, (i, k, info[k], ref)
+    assert abs(run["lr"] - float(g["meta/lr"])) <= 1e-15
+    names = ref_cpu.grad_param_names(run["steps"][0][1], cfg["asr_model"])
+    for si, (mg, meta) in enumerate(run["steps"]):
+        for n in names:
+            a, b = flat_checks(mg[n]), g[f"step{si}/metagrad/fp/{n}"]
+            if not n.endswith("in_proj_bias"):
+                assert abs(a[2] - b[2]) <= 1e-4 * b[2] + 1e-9, (si, n, a[2], b[2])
+            wa, wb = flat_checks(meta[n]), g[f"step{si}/meta/fp/{n}"]
+            # (the reference's in_proj_bias starts at exactly 0 and its key third has an exactly-zero true gradient: Adam turns that
+            # third's rounding noise into +-lr steps, in the reference too -- one lr of slack on the norm for it)
+            assert abs(wa[2] - wb[2]) <= 1e-6 * wb[2] + (run["lr"] if n.endswith("in_proj_bias") else 0.0), (si, n)
+        for n in ("vgg2enc.bias", "decoder.norm.weight", "char_trans.bias", "feat_extractor.0.weight", "encoder.layers.1.linear2.bias"):
+            ref = torch.from_numpy(g[f"step{si}/metagrad/full/{n}"])
+            # 5e-4 (cfg3: 2e-4): the learnable shards' frames are one codebook vector + 10 % noise, so conv1's weight gradient sums
+            # thousands of near-equal terms -- the fp32 summation order of torch's conv backward vs the oracle's shows (measured 2.1e-4)
+            assert float((mg[n] - ref).norm()) <= 5e-4 * float(ref.norm()) + 1e-9, (si, n)
+
+
 @pytest.mark.parametrize("meta_k", [1, 2])
 def test_fomaml_cfg3_oracle_matches_reference(golden_dir, tmp_path, monkeypatch, meta_k):
     """BASELINE configs[2] literally (pretrain.py --algo fomaml, 4 accents, inner_steps = meta_k, shipped warmup 25000; plus

@@ -311,6 +311,25 @@ def test_eight_accents_one_task_per_rank_on_eight_ranks(workspace, algo, meta_k)
     assert sorted(fp for r in ranks for fp in r["train_fps"]) == sorted(single["train_fps"])
 
 
+def test_meta_batch_five_on_eight_ranks_three_ranks_pad(workspace):
+    """--meta_batch_size 5 of 8 accents on 8 ranks: task position p of a meta-step runs on rank p % 8, so ranks 5..7 own nothing in
+    any meta-step -- they still draw every task's batch INDICES (shared RNG streams), contribute a zero buffer to the one all-reduce
+    per meta-step and apply the replicated Noam-Adam step.  All eight end on the single-process meta weights; ranks 0..4 together
+    consumed the single-process batch list, ranks 5..7 materialised no batch at all."""
+    kw = dict(meta_batch=5, steps=4, accents=EIGHT, meta_k=1)
+    single = run(workspace, "fomaml", 1, 0, **kw)
+    ranks = _ranks(workspace, "fomaml", world=8, **kw)
+    for r in ranks[1:]:
+        assert torch.equal(ranks[0]["weights"], r["weights"])
+    torch.testing.assert_close(ranks[0]["weights"], single["weights"], rtol=1e-9, atol=1e-11)
+    n_meta = len(single["train_fps"]) // (5 * 2)
+    assert n_meta == 4
+    assert all(len(r["train_fps"]) == n_meta * 2 for r in ranks[:5]) and all(not r["train_fps"] for r in ranks[5:])
+    assert sorted(fp for r in ranks for fp in r["train_fps"]) == sorted(single["train_fps"])
+    for r in ranks:                                                    # one all-reduce per meta-step on EVERY rank (the idle ones pad)
+        assert [r["n_reduces"].count(st) for st in sorted(set(r["n_reduces"]))] == [1] * n_meta
+
+
 @pytest.mark.parametrize("algo,meta_batch,K,waves", [("fomaml", 4, 2, 1), ("fomaml", 7, 2, 2), ("fomaml", 7, 3, 2), ("reptile", 7, 3, 2)])
 def test_task_slots_on_two_ranks_issue_one_allreduce_per_wave(workspace, algo, meta_batch, K, waves):
     """--tasks_per_gpu K on several ranks: the K task gradients of a wave are summed on the rank and go out as ONE all-reduce
