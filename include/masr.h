@@ -54,8 +54,8 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
 /* rebuild the bf16 operand shadows after ANY change of params (load_state_dict, optimizer step) */
 int masr_refresh(masr_model* m, void* stream);
 void masr_set_seed(masr_model* m, uint64_t seed);      /* dropout stream */
-/* hint: this model is one of `slots` task slots running concurrently on the GPU (pretrain.py --tasks_per_gpu).  Results do not depend
- * on it beyond the summation order of the encoder-row weight gradients (split-K 2 instead of 4 when the chip is shared). */
+/* hint: this model is one of `slots` task slots running concurrently on the GPU (pretrain.py --tasks_per_gpu).  Results do NOT depend
+ * on it, bit for bit (no launch partition that enters a summation order follows the slot count; kept for launch-geometry hints). */
 void masr_set_concurrency(masr_model* m, int slots);
 /* the dropout stream's position: state[0] = seed, state[1] = batches run since masr_set_seed (every run_batch derives its masks
  * from both); set != 0 writes it.  For checkpoints: a resumed run continues the mask stream where the saved one stopped. */
@@ -81,7 +81,9 @@ int masr_read_stats(masr_model* m, float out[4], void* stream);
    host visibility of the copy) and hands the floats out; a ticket may simply be dropped -- its block is only reused after its
    event has completed.  masr_stats_peek returns the block itself, whose four words hold MASR_STATS_PENDING until the copy lands:
    a host thread may poll them without entering the HIP runtime (the task threads are inside its launch path meanwhile) and call
-   masr_stats_wait once they have changed.  Tickets expire after 64 newer posts.  Lets the host queue the next tasks while these
+   masr_stats_wait once they have changed.  Tickets EXPIRE after 64 newer posts on the same handle (masr_stats_wait / _peek then fail
+   with "unknown or expired ticket"): a caller that keeps more than that outstanding must read the oldest first (the Python engine
+   does so at 48).  Lets the host queue the next tasks while these
    run: the reference reads loss / accuracy / norm only for its log lines (fo_meta_interface.py:147-151). */
 #define MASR_STATS_PENDING 0x7FC0DEADu            /* a quiet NaN with a payload no kernel produces */
 int64_t masr_stats_post(masr_model* m, void* stream);
@@ -221,6 +223,11 @@ int masr_gather_pad(const float* feat, const int64_t* row_start, const int32_t* 
  * logits (src/blstm_trainer.py:22,62-70).  logits fp32 [T][B][C] device; targets/tgt_off/in_len/tgt_len int32 device.
  * nll [B], loss [1], grad [T][B][C] device outputs; work: masr_ctc_work_floats(T,B,maxS) floats. */
 int64_t masr_ctc_work_floats(int T, int B, int maxS);
+/* The lengths are DEVICE arrays, so they are vetted by the kernel: an utterance with in_len < 0 or > T, tgt_len < 0 or
+ * 2 tgt_len + 1 > maxS is not run -- its nll (hence the mean loss) is NaN, its gradient rows are zero.  in_len == 0 is torch's
+ * "no path" case: nll 0, zero gradient (zero_infinity).  masr_ctc_status(stream) synchronises and returns 0, or (index + 1) of
+ * the last refused utterance with the text in masr_last_error(), and clears the mark. */
+int masr_ctc_status(void* stream);
 int masr_ctc_loss(const float* logits, const int32_t* targets, const int32_t* tgt_off, const int32_t* in_len,
                   const int32_t* tgt_len, int T, int B, int C, int blank, float* nll, float* loss, float* grad,
                   float* work, int maxS, void* stream);

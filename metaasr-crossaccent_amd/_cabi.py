@@ -74,6 +74,7 @@ _SIGS = {
     "masr_fbank_pitch": (i32, [vp, vp, vp, i64, i64, i32, i32, i32, vp, vp, i64, vp]),
     "masr_gather_pad": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "masr_ctc_work_floats": (i64, [i32, i32, i32]),
+    "masr_ctc_status": (i32, [vp]),
     "masr_ctc_loss": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]),
     "masr_profile_enable": (i32, [vp, i32]),
     "masr_profile_read": (i32, [vp, C.POINTER(f32), C.POINTER(i32)]),

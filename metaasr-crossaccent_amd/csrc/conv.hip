@@ -2516,7 +2516,7 @@ static int stream_chunk() {
     static const int c = getenv("MASR_CONV_CHUNK") ? atoi(getenv("MASR_CONV_CHUNK")) : 0;
     return c;
 }
-static void launch_resw_w1(const ConvArgs& a, hipStream_t s) {
+static int launch_resw_w1(const ConvArgs& a, hipStream_t s) {
     const int th = w1_th8() ? 8 : 16;
     const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + th - 1) / th, ntiles = tiles_x * tiles_y * a.B;
     ConvArgs b = a;
@@ -2525,7 +2525,7 @@ static void launch_resw_w1(const ConvArgs& a, hipStream_t s) {
         if (!fallback) hipGetSymbolAddress((void**)&fallback, HIP_SYMBOL(g_conv_sched));
         b.sched = fallback;
     }
-    if (!w1_th8() && !a.mask_bits) { mk_set_error("mk_conv3x3", "fused conv1 wgrad (16 x 16 tiles) needs ConvArgs::mask_bits"); return; }
+    if (!w1_th8() && !a.mask_bits) { mk_set_error("mk_conv3x3", "fused conv1 wgrad (16 x 16 tiles) needs ConvArgs::mask_bits"); return -1; }
     if (w1_th8()) hipLaunchKernelGGL((conv3x3_resw_w1_kernel<false>), dim3((unsigned)resw_w1_rows(a.B, a.H, a.W)), dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, 0);
     else {
         static const int abl = getenv("MASR_W1_ABL") ? atoi(getenv("MASR_W1_ABL")) : 0;
@@ -2539,6 +2539,7 @@ static void launch_resw_w1(const ConvArgs& a, hipStream_t s) {
             default: hipLaunchKernelGGL((conv3x3_resw_w1x_kernel<0>), g, dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, 0);
         }
     }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 template <bool PROF = false>
 static void launch_resw(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
@@ -2708,7 +2709,7 @@ static int conv3x3_dispatch(const ConvArgs& a, hipStream_t s) {
     }
     if (a.x1) {
         if (!(a.CIN == 64 && a.COUT == 64) || !a.w1_slab || !a.mask) { mk_set_error("mk_conv3x3", "fused conv1 wgrad needs the 64->64 dgrad with a mask"); return -1; }
-        if (use_resw_w1()) { launch_resw_w1(a, s); return hipGetLastError() == hipSuccess ? 0 : -1; }
+        if (use_resw_w1()) return launch_resw_w1(a, s);          // (-1 without launching when mask_bits is missing: da1 / w1_slab stay unwritten)
         hipLaunchKernelGGL((conv3x3_patch_kernel<64, 64, 16, true>), grid(16), dim3(256), 0, s, a);
     } else if (a.CIN == 64 && a.COUT == 64) {
         static const bool th8 = getenv("MASR_CONV_TH8") != nullptr;

@@ -9,6 +9,10 @@
 namespace {
 constexpr int MAXS = 2048;
 constexpr float NINF = -INFINITY;
+// lengths arrive in DEVICE arrays, so the launch cannot vet them on the host: an utterance whose lengths do not fit the call
+// (in_len < 0 or > T, tgt_len < 0, 2 tgt_len + 1 > the lattice width the work buffer was sized for) is not run -- its nll becomes
+// NaN (so does the mean: loud), its gradient rows stay zero, and its index + 1 is left here for mk_ctc_status
+__device__ int g_ctc_bad = 0;
 
 __device__ __forceinline__ float lae(float a, float b) {          // log(exp a + exp b)
     if (a == NINF) return b;
@@ -24,6 +28,7 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
                                                   float* __restrict__ work, int Spad, long st_t, long st_b) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Tb = in_len[b], Lb = tgt_len[b], S = 2 * Lb + 1;
+    const bool bad = Tb < 0 || Tb > T || Lb < 0 || S > Spad;
     const int* tg = targets + tgt_off[b];
     float* walpha = work + (long)b * T * Spad;                    // [T][Spad]
     float* wlse = work + (long)B * T * Spad + (long)b * T;        // [T]
@@ -38,6 +43,12 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
     // zero the gradient of this utterance (frames >= Tb stay zero)
     // element (t, b, c) of logits / grad sits at ((t * st_t + b * st_b) * C + c): time-major [T][B][C] or batch-first [B][T][C]
     for (long i = tid; i < (long)T * C; i += 256) grad[((i / C) * st_t + b * st_b) * C + (i % C)] = 0.f;
+    if (bad || Tb == 0) {
+        // no frames: torch's lattice has no path unless the target is empty too (nll 0); with a target the likelihood is 0,
+        // i.e. nll = inf, which zero_infinity turns into 0 with a zero gradient -- 0 either way
+        if (tid == 0) { nll[b] = bad ? __int_as_float(0x7fc00000) : 0.f; if (bad) atomicMax(&g_ctc_bad, b + 1); }
+        return;
+    }
     // log-softmax normalisers
     for (int t = wave; t < Tb; t += 4) {
         const float* z = logits + ((long)t * st_t + b * st_b) * C;
@@ -151,10 +162,26 @@ __global__ void ctc_mean_kernel(const float* __restrict__ nll, const int* __rest
 }
 }  // namespace
 
+int mk_ctc_status(hipStream_t s) {
+    // > 0: (index + 1) of the last utterance a CTC launch on this stream refused (see g_ctc_bad); reads and clears, synchronises `s`
+    int h = 0;
+    const int zero = 0;
+    if (hipMemcpyFromSymbolAsync(&h, HIP_SYMBOL(g_ctc_bad), sizeof(int), 0, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    if (h > 0) {
+        hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ctc_bad), &zero, sizeof(int), 0, hipMemcpyHostToDevice, s);
+        hipStreamSynchronize(s);
+        char msg[160];
+        snprintf(msg, sizeof msg, "utterance %d: in_len outside [0, T] or target longer than the lattice the work buffer holds (its nll is NaN)", h - 1);
+        mk_set_error("mk_ctc_loss", msg);
+    }
+    return h;
+}
 long mk_ctc_work_floats(int T, int B, int maxS) { return (long)B * T * ((maxS + 3) / 4 * 4) + (long)B * T; }
 int mk_ctc_loss(const float* logits, const int* targets, const int* tgt_off, const int* in_len, const int* tgt_len, int T,
                   int B, int C, int blank, float* nll, float* loss_out, float* grad, float* work, int maxS, hipStream_t s, int batch_first) {
     if (maxS > MAXS || C > 4096) { mk_set_error("mk_ctc_loss", "lattice wider than 2048 states or > 4096 classes"); return -1; }
+    if (T <= 0 || B <= 0 || C <= 0 || maxS < 1 || blank < 0 || blank >= C) { mk_set_error("mk_ctc_loss", "T, B, C, maxS must be positive and 0 <= blank < C"); return -1; }
     hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(256), 0, s, logits, targets, tgt_off, in_len, tgt_len, T, B, C, blank, nll, grad,
                        work, (maxS + 3) / 4 * 4, batch_first ? 1L : (long)B, batch_first ? (long)T : 1L);
     hipLaunchKernelGGL(ctc_mean_kernel, dim3(1), dim3(64), 0, s, nll, tgt_len, B, loss_out);

@@ -164,6 +164,25 @@ __global__ __launch_bounds__(256) void recog_argmax_step_kernel(int* step, const
         if (atomicAdd(step + 1, 1) == B - 1) { step[1] = 0; step[0] = st + 1; }
     }
 }
+// fp32 logits of the greedy decode: z[r][c] = bias[c] + sum_k y[r][k] W[c][k] on the fp32 MASTER weights and the fp32 LayerNorm output
+// (the training forward's bf16 operands are fine for a loss, but an arg-max is an index: the last projection is where two near-tied
+// classes are told apart, and it is 0.4 MFLOP per row).  grid (rows, ceil(C / 64)), a wave = 16 classes, fixed summation order.
+__global__ __launch_bounds__(256) void logits_f32_kernel(const float* __restrict__ y, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, float* __restrict__ z, long ldz, int C, int E) {
+    const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = blockIdx.y * 64 + wave * 16;
+    const float* yr = y + (long)r * E;
+    for (int c = c0; c < c0 + 16 && c < C; ++c) {
+        const float* w = W + (long)c * E;
+        float acc = 0.f;
+        for (int k = lane * 4; k < E; k += 256) {
+            const float4 a = *reinterpret_cast<const float4*>(yr + k), b = *reinterpret_cast<const float4*>(w + k);
+            acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) z[(long)r * ldz + c] = acc + bias[c];
+    }
+}
 __global__ void recog_step_set_kernel(int* step, int value, int inc) {
     if (inc) { step[0] += 1; } else { step[0] = value; step[1] = 0; }     // step[1] = arg-max ticket counter
 }
@@ -196,6 +215,11 @@ int mk_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
 int mk_recog_embed_step(const int* step, const int* out, const float* table, const float* pe, float* y32, bf16* y16, int B, int E, int sos,
                         hipStream_t s) {
     hipLaunchKernelGGL(recog_embed_step_kernel, dim3(B), dim3(256), 0, s, step, out, table, pe, y32, y16, B, E, sos);
+    return LAUNCH_OK();
+}
+int mk_logits_f32(const float* y32, const float* W32, const float* bias, float* logits, long ld, int rows, int C, int E, hipStream_t s) {
+    if (E % 4 != 0 || rows <= 0) { mk_set_error("mk_logits_f32", "E % 4 == 0 and rows >= 1 required"); return -1; }
+    hipLaunchKernelGGL(logits_f32_kernel, dim3(rows, (C + 63) / 64), dim3(256), 0, s, y32, W32, bias, logits, ld, C, E);
     return LAUNCH_OK();
 }
 int mk_recog_argmax_step(int* step, const float* logits, long ld, int* out, int B, int C, hipStream_t s) {

@@ -74,10 +74,9 @@ struct Acts {
     float* wg_slab;                                        // split-K partials: (WG_SPLIT-1) x nparams
 };
 constexpr int WG_SPLIT_MAX = 4;
-// split-K factor of the encoder-row weight gradients: per model (masr_set_concurrency), 4 for a model that has the GPU to itself, 2 for
-// one of several task slots -- with four slots the chip is full anyway and every extra partial slab is 90 MB written and read again
-// by the combine pass.  Measured, 4 tasks / single task utt/s: split 4: 8 440 / 5 485, split 2: 8 530 / 5 435, none: 8 475 / 5 380.
-// MASR_WG_SPLIT = 1..4 overrides both (A/B runs).
+// split-K factor of the encoder-row weight gradients on the ungrouped path (MASR_NO_GROUPED_ENC_WGRAD=1; the default grouped launch is
+// unsplit): 4 for every model, whatever the number of task slots (see masr_set_concurrency).  Measured when it followed the slot count,
+// 4 tasks / single task utt/s: split 4: 8 440 / 5 485, split 2: 8 530 / 5 435, none: 8 475 / 5 380.  MASR_WG_SPLIT = 1..4 overrides it.
 static const int WG_SPLIT_ENV = [] { const char* e = getenv("MASR_WG_SPLIT"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > WG_SPLIT_MAX ? WG_SPLIT_MAX : v); }();
 
 }  // namespace
@@ -586,7 +585,10 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
 }
 
 void masr_set_seed(masr_model* m, uint64_t seed) { m->seed = seed; m->step = 0; }
-void masr_set_concurrency(masr_model* m, int slots) { if (!WG_SPLIT_ENV) m->wg_split = slots > 1 ? 2 : 4; }
+// The split factor is part of the weight gradients' fp32 summation order, i.e. of the result's BITS, and "K task slots == the sequential
+// run, bit for bit" is a guarantee of --tasks_per_gpu: so it no longer follows the slot count (it did: 2 for a shared chip, 4 alone --
+// only visible with MASR_NO_GROUPED_ENC_WGRAD=1, the grouped launch being unsplit).  MASR_WG_SPLIT still sets it for A/B runs.
+void masr_set_concurrency(masr_model* m, int slots) { (void)m; (void)slots; }
 void masr_dropout_state(masr_model* m, uint64_t state[2], int set) {
     if (set) { m->seed = state[0]; m->step = state[1]; } else { state[0] = m->seed; state[1] = m->step; }
 }
@@ -653,7 +655,7 @@ static int project_memory_kv(Ctx& c) {
     return gemm(c, h);
 }
 
-static int forward_decoder(Ctx& c, bool project_kv = true) {
+static int forward_decoder(Ctx& c, bool project_kv = true, bool logits_f32 = false) {
     masr_model* m = c.m; Acts& a = m->acts; hipStream_t s = c.s; const float* P = m->P;
     const int E = m->E, L = a.L;
     uint32_t site = 100;
@@ -671,6 +673,12 @@ static int forward_decoder(Ctx& c, bool project_kv = true) {
         CK(ln_fwd(c, w.n2, d.s2, d.y2_32, d.y2_16, d.m2, d.r2, a.rows_d));
         CK(ffn_fwd(c, w.l1, w.l2, d.y2_16, d.y2_32, a.rows_d, d.f, d.s3, d.site[4], d.site[5]));
         CK(ln_fwd(c, w.n3, d.s3, a.y32[l + 1], a.y16[l + 1], d.m3, d.r3, a.rows_d));
+    }
+    if (logits_f32) {
+        // greedy decode: the last projection in fp32 on the master weights (see mk_logits_f32); layer 0's pre-LayerNorm sum is free by now
+        float* yf32 = a.dec[0].s1;
+        CK(ln_fwd(c, m->dec_norm, a.y32[m->ND], yf32, nullptr, a.mdf, a.rdf, a.rows_d));
+        return mk_logits_f32(yf32, P + m->ct.w, P + m->ct.b, a.logits, m->Cp, a.rows_d, m->C, E, c.s);
     }
     CK(ln_fwd(c, m->dec_norm, a.y32[m->ND], nullptr, a.yf16, a.mdf, a.rdf, a.rows_d));
     GemmArgs g = lin_fwd_args(a.yf16, E, m->ct.k16, a.rows_d, m->C, E, P + m->ct.b);
@@ -1062,9 +1070,10 @@ static int decode_step(Ctx& c, int* out) {
         CK(mk_skinny_gemm(g, s));
         CK(ln_fwd(c, w.n3, d.s3, a.y32[l + 1], a.y16[l + 1], d.m3, d.r3, B));
     }
-    CK(ln_fwd(c, m->dec_norm, a.y32[m->ND], nullptr, a.yf16, a.mdf, a.rdf, B));
-    SkinnyArgs g = lin(a.yf16, E, m->ct.k16, m->C, E, P + m->ct.b); g.C32 = a.logits; g.ldc = m->Cp;
-    CK(mk_skinny_gemm(g, s));
+    // the last projection in fp32 on the master weights (an arg-max follows: mk_logits_f32); layer 0's pre-LayerNorm sum is free by now
+    float* yf32 = a.dec[0].s1;
+    CK(ln_fwd(c, m->dec_norm, a.y32[m->ND], yf32, nullptr, a.mdf, a.rdf, B));
+    CK(mk_logits_f32(yf32, P + m->ct.w, P + m->ct.b, a.logits, m->Cp, B, m->C, E, s));
     CK(mk_recog_argmax_step(a.step_dev, a.logits, m->Cp, out, B, m->C, s));       // also advances *step_dev
     return 0;
 }
@@ -1107,7 +1116,7 @@ int masr_recog_full(masr_model* m, const float* xs, const int64_t* ilens, int B,
     for (int step = 1; step <= Ldec; ++step) {
         a.L = step; a.rows_d = B * step;
         CK(mk_recog_build_tok(a.tok_in, out, B, step, 0, s));
-        CK(forward_decoder(c, false));
+        CK(forward_decoder(c, false, true));
         CK(mk_recog_argmax(a.logits, m->Cp, out, B, step, m->C, s));
     }
     m->have_acts = false;                                   // logits/gold views are not meaningful after a decode
@@ -1186,6 +1195,7 @@ int masr_fbank_pitch(const float* wav, const int64_t* wav_off, const int64_t* ro
     return mk_pitch(wav, (const long*)wav_off, (const long*)row_off, total_samples, max_samples, B, max_frames, n_mel, feat, work, work_bytes, (hipStream_t)stream);
 }
 int64_t masr_ctc_work_floats(int T, int B, int maxS) { return mk_ctc_work_floats(T, B, maxS); }
+int masr_ctc_status(void* stream) { return mk_ctc_status((hipStream_t)stream); }
 int masr_ctc_loss(const float* logits, const int32_t* targets, const int32_t* tgt_off, const int32_t* in_len, const int32_t* tgt_len, int T,
                   int B, int C, int blank, float* nll, float* loss, float* grad, float* work, int maxS, void* stream) {
     return mk_ctc_loss(logits, targets, tgt_off, in_len, tgt_len, T, B, C, blank, nll, loss, grad, work, maxS, (hipStream_t)stream);

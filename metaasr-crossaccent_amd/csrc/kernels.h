@@ -130,6 +130,8 @@ int mk_recog_embed_step(const int* step, const int* out, const float* table, con
 // also advances step[0] once all B rows are done (ticket counter in step[1])
 int mk_recog_argmax_step(int* step, const float* logits, long ld, int* out, int B, int C, hipStream_t s);
 int mk_recog_step_set(int* step, int value, int inc, hipStream_t s);     // inc ? *step += 1 : *step = value
+// logits[r][c] = bias[c] + <y32[r], W32[c]> in fp32 on the master weights (the decode's last projection: an arg-max follows)
+int mk_logits_f32(const float* y32, const float* W32, const float* bias, float* logits, long ld, int rows, int C, int E, hipStream_t s);
 
 // ---------------------------------------------------------------- row ops (rowops.hip)
 int mk_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y32, bf16* y16,
@@ -257,4 +259,5 @@ int mk_pitch(const float* wav, const long* wav_off, const long* row_off, long to
 int mk_ctc_loss(const float* logits, const int* targets, const int* tgt_off, const int* in_len, const int* tgt_len,
                   int T, int B, int C, int blank, float* nll /*[B]*/, float* loss_out, float* grad, float* work,
                   int maxS, hipStream_t s, int batch_first = 0);      // batch_first: logits / grad are [B][T][C]
+int mk_ctc_status(hipStream_t s);                              // > 0: (index + 1) of an utterance a CTC launch refused (bad lengths); clears
 long mk_ctc_work_floats(int T, int B, int maxS);

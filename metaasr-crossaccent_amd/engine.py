@@ -43,12 +43,15 @@ class PendingStats:
 
     def __init__(self, engine, ticket, words):
         self.engine, self.ticket, self.words = engine, ticket, words
+        self._result = None
 
     def ready(self):
         w = self.words
         return not (w[0] == self.SENTINEL or w[1] == self.SENTINEL or w[2] == self.SENTINEL or w[3] == self.SENTINEL)
 
     def get(self):
+        if self._result is not None:                              # (already brought in, e.g. by the engine before its ring wrapped)
+            return self._result
         n, t0 = 0, None
         while not self.ready():
             n += 1
@@ -59,7 +62,8 @@ class PendingStats:
                     raise RuntimeError("the stats of a queued batch never reached the host (stream wedged, or the batch failed to launch)")
         out = (C.c_float * 4)()
         check(self.engine._l.masr_stats_wait(self.engine.h, self.ticket, out), "masr_stats_wait")
-        return {"loss": float(out[0]), "n_correct": float(out[1]), "n_total": float(out[2]), "grad_norm": float(out[3])}
+        self._result = {"loss": float(out[0]), "n_correct": float(out[1]), "n_total": float(out[2]), "grad_norm": float(out[3])}
+        return self._result
 
 
 class MasrEngine:
@@ -225,7 +229,15 @@ class MasrEngine:
         ticket = int(self._l.masr_stats_post(self.h, self.stream()))
         if ticket < 0:
             raise _cabi.MasrError("masr_stats_post: " + self._l.masr_last_error().decode())
-        return PendingStats(self, ticket, self._l.masr_stats_peek(self.h, ticket))
+        h = PendingStats(self, ticket, self._l.masr_stats_peek(self.h, ticket))
+        # a ticket expires after 64 newer posts (the ring of include/masr.h).  A loop that keeps a whole meta-step of handles per
+        # engine (FOMAML, many tasks on one slot) could get there: handles still unread when the ring is 3/4 around are read NOW
+        # (their copies are dozens of batches old) and keep the numbers, so the limit never reaches a caller
+        out = self.__dict__.setdefault("_outstanding", [])
+        out.append(h)
+        while len(out) > 48:
+            out.pop(0).get()
+        return h
 
     def set_step_graphs(self, on: bool):
         """opt-in graph replay of repeated batch shapes (include/masr.h masr_set_step_graphs)"""

@@ -103,8 +103,18 @@ class FOMetaASRInterface(PretrainInterface):
         with open(self.log_dir.joinpath(f'best_{tpe}'), 'w') as fout:
             print('{} {}'.format(self.global_step, getattr(self, f'best_{tpe}')), file=fout)
 
-    def save_per_steps(self):
+    def _stream_state(self):
+        """what decides the NEXT batches and task order: the three RNG streams, every sampler's arrangement + cursor, the task list"""
+        from .io.dataset import capture_rng
+        return {'rng': capture_rng(), 'data': self.data_container.state_dict(),
+                'task_ids': list(getattr(self, '_task_ids', None) or range(self.num_pretrain))}
+
+    def save_per_steps(self, gather=True):
         self._drain_stats()
+        # the dropout streams are per (rank, slot): every rank's positions go into rank 0's file (a resumed rank restores ITS OWN;
+        # gather=False -- the SIGINT path, where the other ranks may not be in this call -- keeps this rank's only)
+        mine = [sl['engine'].dropout_state() for sl in (self._slots or []) if hasattr(sl['engine'], 'dropout_state')]
+        dropout = dict(enumerate(self.sharder.all_gather_object(mine))) if gather else {self.sharder.rank: mine}
         if self.sharder.rank != 0:
             return
         sd = {k: v.cpu() for k, v in self._snapshot_sd().items()}
@@ -117,12 +127,12 @@ class FOMetaASRInterface(PretrainInterface):
         # extension (not in the reference, which cannot resume pretraining): meta weights + meta-Adam state
         # ... and everything else an exact continuation needs: the three RNG streams and the per-accent sampler state that decide
         # which batches come next, the best-so-far error rates, the dropout streams' positions.  (The look-ahead never crosses a
-        # save boundary, see train(), so no drawn-but-unused batch is lost here.)
-        from .io.dataset import capture_rng
+        # save boundary, see train(), so no drawn-but-unused batch is lost here.  A SIGINT can land while a look-ahead is
+        # outstanding: the streams are then saved as they stood BEFORE that draw, `_ahead_state`, so the resumed run draws it again.)
+        stream = getattr(self, '_ahead_state', None) or self._stream_state()
         torch.save({'original': self._original.cpu(), 'adam': self.meta_opt.optimizer.state_dict(),
-                    'step_num': self.meta_opt.step_num, 'rng': capture_rng(), 'data': self.data_container.state_dict(),
-                    'best': (self.best_wer, self.best_cer), 'task_ids': list(getattr(self, '_task_ids', None) or range(self.num_pretrain)),
-                    'dropout': [sl['engine'].dropout_state() for sl in (self._slots or []) if hasattr(sl['engine'], 'dropout_state')]},
+                    'step_num': self.meta_opt.step_num, 'rng': stream['rng'], 'data': stream['data'],
+                    'best': (self.best_wer, self.best_cer), 'task_ids': stream['task_ids'], 'dropout': dropout},
                    self.log_dir.joinpath("meta_state.latest"))
         self.dashboard.log_step()
 
@@ -150,7 +160,12 @@ class FOMetaASRInterface(PretrainInterface):
                 self.data_container.load_state_dict(st['data'])
                 self.best_wer, self.best_cer = st['best']
                 self._task_ids = list(st['task_ids'])
-                for sl, d in zip(self._slots or [], st['dropout']):
+                dropout = st['dropout']
+                if isinstance(dropout, dict):                            # per rank; a rank the file does not know keeps its own seeds
+                    dropout = dropout.get(self.sharder.rank, [])
+                elif self.sharder.rank != 0:                             # (files written before the streams were saved per rank: rank 0's)
+                    dropout = []
+                for sl, d in zip(self._slots or [], dropout):
                     sl['engine'].set_dropout_state(d)
                 restore_rng(st['rng'])                                   # last: everything above (and set_model) consumed the streams
 
@@ -326,6 +341,7 @@ class FOMetaASRInterface(PretrainInterface):
                 for it in range(first_it, self.eval_ival):
                     first_it = 0
                     meta_batch, drawn = nxt if nxt is not None else self._shuffle_and_draw(task_ids)
+                    self._ahead_state = None                            # (whatever was drawn ahead is being used now)
                     # look-ahead: the NEXT meta-step's task order and batch indices are drawn now (same RNG order as drawing
                     # them after this step: nothing in between consumes `random` / `np.random`), so that its batches are
                     # assembled in pinned memory by the collate pool while this step runs on the GPU.  Bucketed loaders only:
@@ -338,6 +354,7 @@ class FOMetaASRInterface(PretrainInterface):
                     def look_ahead():                                   # runs once the first task's launches are queued: its host
                         nonlocal nxt                                    # time (index draws, HBM gathers) overlaps GPU work
                         if ahead:
+                            self._ahead_state = self._stream_state()    # what a SIGINT checkpoint must hold while `nxt` is unused
                             nxt = self._shuffle_and_draw(task_ids)
                         # ... and the host now WAITS for the previous meta-step's stats, i.e. it stays at most one meta-step
                         # ahead of the GPU, which always has this step's launches queued behind the previous one's
@@ -371,7 +388,7 @@ class FOMetaASRInterface(PretrainInterface):
         except KeyboardInterrupt:
             logger.warning("Pretraining stopped")
             self._drain_stats()
-            self.save_per_steps()
+            self.save_per_steps(gather=False)
             self.dashboard.set_status('pretrained(SIGINT)')
         else:
             self._drain_stats()

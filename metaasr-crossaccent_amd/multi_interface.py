@@ -34,8 +34,16 @@ class MultiASRInterface(PretrainInterface):
         with open(self.log_dir.joinpath(f'best_{tpe}'), 'w') as fout:
             print('{} {}'.format(self.global_step, getattr(self, f'best_{tpe}')), file=fout)
 
-    def save_per_steps(self):
+    def _stream_state(self):
+        from .io.dataset import capture_rng
+        return {'rng': capture_rng(), 'data': self.data_container.state_dict()}
+
+    def save_per_steps(self, gather=True):
         getattr(self, '_drain_stats', lambda: None)()
+        eng = self.asr_model.engine
+        # one dropout stream per rank: all of them go into rank 0's file (gather=False: the SIGINT path, this rank's only)
+        mine = [eng.dropout_state()] if hasattr(eng, 'dropout_state') else []
+        dropout = dict(enumerate(self.sharder.all_gather_object(mine))) if gather else {self.sharder.rank: mine}
         if self.sharder.rank != 0:
             return
         sd = self._sd_cpu()
@@ -47,12 +55,11 @@ class MultiASRInterface(PretrainInterface):
         torch.save(sd, self.log_dir.joinpath(f"snapshot.step.{self.global_step}"))
         # extension (the reference's pretraining cannot resume): optimiser state + the RNG streams and
         # sampler state that decide the next batches, for an exact continuation (same layout as the FOMAML interface's file)
-        from .io.dataset import capture_rng
+        # (a SIGINT can land while the next step's batch is drawn but unused: `_ahead_state` = the streams before that draw)
         inner = self.asr_opt.optimizer if isinstance(self.asr_opt, TransformerOptimizer) else self.asr_opt
-        eng = self.asr_model.engine
-        torch.save({'opt': inner.state_dict(), 'step_num': getattr(self.asr_opt, 'step_num', None), 'rng': capture_rng(),
-                    'data': self.data_container.state_dict(), 'best': (self.best_wer, self.best_cer),
-                    'dropout': [eng.dropout_state()] if hasattr(eng, 'dropout_state') else []},
+        stream = getattr(self, '_ahead_state', None) or self._stream_state()
+        torch.save({'opt': inner.state_dict(), 'step_num': getattr(self.asr_opt, 'step_num', None), 'rng': stream['rng'],
+                    'data': stream['data'], 'best': (self.best_wer, self.best_cer), 'dropout': dropout},
                    self.log_dir.joinpath("meta_state.latest"))
         self.dashboard.log_step()
 
@@ -70,7 +77,12 @@ class MultiASRInterface(PretrainInterface):
                     self.asr_opt.step_num, self.asr_opt.lr = st['step_num'], st['opt']['lr']
                 self.data_container.load_state_dict(st['data'])
                 self.best_wer, self.best_cer = st['best']
-                for d in st['dropout']:
+                dropout = st['dropout']
+                if isinstance(dropout, dict):                            # per rank (older files: rank 0's list)
+                    dropout = dropout.get(self.sharder.rank, [])
+                elif self.sharder.rank != 0:
+                    dropout = []
+                for d in dropout:
                     self.asr_model.engine.set_dropout_state(d)
                 restore_rng(st['rng'])
 
@@ -125,8 +137,12 @@ class MultiASRInterface(PretrainInterface):
                     first_it = 0
                     idx, fut = nxt if nxt is not None else draw()
                     more = it + 1 < self.eval_ival or self.global_step + 1 < self.max_step
-                    # (no draw across a checkpoint: save_per_steps records "nothing drawn beyond this step")
-                    nxt = draw() if ahead and more and (self.global_step + 1) % self.save_ival != 0 else None
+                    # (no draw across a checkpoint: save_per_steps records "nothing drawn beyond this step"; a SIGINT checkpoint
+                    # taken while `nxt` is unused holds the streams as they stood before its draw)
+                    self._ahead_state = nxt = None
+                    if ahead and more and (self.global_step + 1) % self.save_ival != 0:
+                        self._ahead_state = self._stream_state()
+                        nxt = draw()
                     x, ilens, ys, olens = fut.result()
                     one_sync = hasattr(self, 'info_from_stats')            # {loss, acc} ride on the copy that brings the norm back
                     info = self._train(idx, x, ilens, ys, olens, accent_idx=idx, **({'want_info': False} if one_sync else {}))
@@ -162,7 +178,7 @@ class MultiASRInterface(PretrainInterface):
         except KeyboardInterrupt:
             logger.warning("Pretraining stopped")
             drain()
-            self.save_per_steps()
+            self.save_per_steps(gather=False)
             self.dashboard.set_status('pretrained(SIGINT)')
         else:
             logger.notice("Pretraining completed")

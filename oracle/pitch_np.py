@@ -133,14 +133,75 @@ def viterbi(nccf_pitch: np.ndarray, lg: np.ndarray) -> np.ndarray:
     return best
 
 
-def compute_kaldi_pitch(wav: np.ndarray) -> np.ndarray:
-    """-> [T, 2]: (NCCF at the chosen lag, computed without ballast; pitch in Hz)"""
+def viterbi_f32(nccf_pitch: np.ndarray, lg: np.ndarray) -> np.ndarray:
+    """viterbi() in the arithmetic of the GPU kernel (csrc/pitch.hip pitch_viterbi_kernel): NCCF and lags rounded to fp32, local
+    cost fma(10 lag, n, 1 - n), candidate fma((i - j)^2, factor, prev[j]) scanned over j with a strict <, forward costs kept as fp32
+    remainders.  Neighbouring lags of the 1.005-ratio grid differ by ~1e-7 in path cost (viterbi_margins), i.e. by about one fp32
+    ulp of a forward cost on a noise frame: THIS, not the algorithm, is what a float64 and an fp32 tracker disagree about."""
+    f32, f64 = np.float32, np.float64
+    n32 = nccf_pitch.astype(f32)
+    T, N = n32.shape
+    if T == 0:
+        return np.zeros(0, dtype=np.int64)
+    lag = lg.astype(f32)
+    factor = f32(0.1 * math.log(1.005) * math.log(1.005))
+    d2 = ((np.arange(N)[:, None] - np.arange(N)[None, :]) ** 2).astype(f64)          # [to i, from j], exact
+    tl = (f32(10.0) * lag).astype(f32)
+    local = (tl[None, :].astype(f64) * n32.astype(f64) + (f32(1.0) - n32).astype(f64)).astype(f32)    # one rounding: fma
+    fwd = local[0].copy()
+    back = np.zeros((T, N), dtype=np.int64)
+    idx = np.arange(N)
+    for t in range(1, T):
+        cand = (d2 * f64(factor) + fwd[None, :].astype(f64)).astype(f32)              # fma(d2, factor, prev[j])
+        back[t] = np.argmin(cand, axis=1)                                              # first minimum == strict < scan
+        best = (cand[idx, back[t]] + local[t]).astype(f32)
+        fwd = (best - best.min()).astype(f32)
+    out = np.zeros(T, dtype=np.int64)
+    out[-1] = int(np.argmin(fwd))
+    for t in range(T - 1, 0, -1):
+        out[t - 1] = back[t, out[t]]
+    return out
+
+
+def viterbi_margins(nccf_pitch: np.ndarray, lg: np.ndarray) -> np.ndarray:
+    """how well defined the tracker's decision is, per frame: the cost of the best lag path that passes through a DIFFERENT lag at
+    frame t, minus the cost of the optimal path (forward + backward min-sum over the same local / transition costs as viterbi()).
+    A margin of 1e-7 means two lags are tied to within float rounding at that frame -- an implementation in another precision may
+    legitimately take the other one there; frames with a clear margin admit one answer."""
+    T, N = nccf_pitch.shape
+    if T == 0:
+        return np.zeros(0)
+    factor = PENALTY * math.log(1.0 + DELTA_PITCH) ** 2
+    idx = np.arange(N)
+    trans = factor * (idx[:, None] - idx[None, :]) ** 2
+    local = 1.0 - nccf_pitch + SOFT_MIN_F0 * lg[None, :] * nccf_pitch
+    F = np.zeros((T, N)); B = np.zeros((T, N))
+    F[0] = local[0]
+    for t in range(1, T):
+        F[t] = (F[t - 1][None, :] + trans).min(axis=1) + local[t]
+    for t in range(T - 2, -1, -1):
+        B[t] = (B[t + 1][None, :] + local[t + 1][None, :] + trans.T).min(axis=1)
+    tot = F + B                                                       # cost of the best path through (t, i)
+    srt = np.sort(tot, axis=1)
+    return srt[:, 1] - srt[:, 0]
+
+
+def pitch_decision_margins(wav: np.ndarray) -> np.ndarray:
+    """viterbi_margins of one utterance's tracker problem, [T]"""
+    lg = lags()
+    a, _ = nccf_frames(downsample(wav))
+    return viterbi_margins(a @ upsample_matrix(lg).T, lg)
+
+
+def compute_kaldi_pitch(wav: np.ndarray, fp32_tracker: bool = False) -> np.ndarray:
+    """-> [T, 2]: (NCCF at the chosen lag, computed without ballast; pitch in Hz).  fp32_tracker: the Viterbi recursion in the GPU
+    kernel's fp32 arithmetic (viterbi_f32) instead of float64."""
     x4 = downsample(wav)
     lg = lags()
     W = upsample_matrix(lg)
     a, b = nccf_frames(x4)
     ap, bp = a @ W.T, b @ W.T
-    best = viterbi(ap, lg)
+    best = viterbi_f32(ap, lg) if fp32_tracker else viterbi(ap, lg)
     T = len(best)
     return np.stack([bp[np.arange(T), best], 1.0 / lg[best]], axis=1) if T else np.zeros((0, 2))
 
@@ -174,8 +235,8 @@ def process_kaldi_pitch(raw: np.ndarray, delta_noise=None) -> np.ndarray:
     return out
 
 
-def pitch_feats(wav: np.ndarray, delta_noise=None) -> np.ndarray:
-    return process_kaldi_pitch(compute_kaldi_pitch(wav), delta_noise)
+def pitch_feats(wav: np.ndarray, delta_noise=None, fp32_tracker: bool = False) -> np.ndarray:
+    return process_kaldi_pitch(compute_kaldi_pitch(wav, fp32_tracker), delta_noise)
 
 
 def fbank_pitch(wav: np.ndarray, n_mel: int = 80) -> np.ndarray:

@@ -276,9 +276,12 @@ def model_forward(p, cfg, xs_pad, ilens, ys, olens):
     return logit, ys_out
 
 
-def recog_greedy(p, cfg, xs_pad, ilens):
+def recog_greedy(p, cfg, xs_pad, ilens, margins=False):
     """MyTransformer.recog (mono_transformer_torch.py:143-176): encoder once, then
-    max(enc_lens) full re-decodes, argmax of EVERY position each step -> [Ldec,B]."""
+    max(enc_lens) full re-decodes, argmax of EVERY position each step -> [Ldec,B].
+    margins=True: also the decision margin of every emitted token, [Ldec,B]: (best logit - second best) / std of that
+    position's logits -- how well defined the reference's own arg-max is there (the causal mask makes the last re-decode's
+    logits at position t the ones that decided token t)."""
     odim = p["char_trans.weight"].shape[0]
     B = xs_pad.shape[0]
     enc, enc_lens = extract_feat(p, xs_pad, ilens)
@@ -293,7 +296,11 @@ def recog_greedy(p, cfg, xs_pad, ilens):
         y = p["pre_embed.weight"][tok] + p["pos_encoder.pe"][:tok.shape[0]]
         causal = generate_square_subsequent_mask(tok.shape[0])
         h = decoder_forward(p, cfg, y, memory, causal, pad_mask)
-        out = torch.argmax(h @ p["char_trans.weight"].t() + p["char_trans.bias"], dim=-1)
+        z = h @ p["char_trans.weight"].t() + p["char_trans.bias"]
+        out = torch.argmax(z, dim=-1)
+    if margins:
+        top = z.topk(2, dim=-1).values
+        return out, (top[..., 0] - top[..., 1]) / z.std(dim=-1)
     return out
 
 

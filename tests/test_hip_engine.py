@@ -193,6 +193,38 @@ def test_recog_matches_reference_tokens(sd, G):
     assert agree_ref >= 0.9 and agree_q >= 0.9
 
 
+def test_recog_tokens_exact_where_the_reference_arg_max_is_well_defined(sd, G):
+    """An arg-max is an index: where the reference's own decision is well defined the tokens must be IDENTICAL, not 90 % alike.
+    The decode's last projection runs in fp32 on the master weights (mk_logits_f32), so what can still move a decision is the
+    bf16 rounding inherited from the layers below -- a relative 2^-9 per operand, far less than the spread of a position's
+    logits.  Per utterance: every token up to the first position whose reference margin (best - second logit, in units of that
+    position's logit std, from the fp32 oracle == the golden's tokens) is below MARGIN must equal the reference's; a divergence
+    may only start AT such a near-tie (after it the prefixes differ and nothing is comparable)."""
+    MARGIN = 0.05
+    n_checked = n_total = 0
+    for case, seed in (("ragged", 11), ("same", 12), ("single", 13)):
+        ilens, olens = CASES[case]
+        xs, il, ys, ol = synth_batch(seed, ilens, olens)
+        eng = MasrEngine(TINY, ODIM)
+        eng.load_state_dict(sd)
+        hyp = eng.recog(xs, il).cpu()
+        with torch.no_grad():
+            ref, margin = ref_cpu.recog_greedy(ref_cpu.leafify(sd, TINY), TINY, xs, il, margins=True)
+        if case == "ragged":
+            assert torch.equal(ref, torch.from_numpy(G["recog/hyp"]))       # the oracle's tokens ARE the reference's (golden)
+        for b in range(len(ilens)):
+            tie = (margin[:, b] < MARGIN).nonzero()
+            stop = int(tie[0]) if len(tie) else ref.shape[0]              # first near-tie of the reference's own decisions
+            n_checked += stop; n_total += ref.shape[0]
+            assert torch.equal(hyp[:stop, b], ref[:stop, b]), (case, b, stop, hyp[:, b].tolist(), ref[:, b].tolist(), margin[:, b].tolist())
+            diff = (hyp[:, b] != ref[:, b]).nonzero()
+            if len(diff):
+                first = int(diff[0])
+                assert float(margin[first, b]) < MARGIN, f"{case} utt {b}: tokens diverge at step {first} where the reference's margin is {float(margin[first, b]):.3f}"
+    print(f"greedy decode: {n_checked} of {n_total} tokens lie before the reference's first near-tie (margin < {MARGIN} logit std) -- all identical")
+    assert n_checked >= 0.5 * n_total
+
+
 def test_recog_cached_equals_full_redecode(sd):
     """the KV-cached incremental decode (direct launches on the default stream, hipGraph replay on a
     side stream) emits exactly the tokens of the reference's literal schedule (whole prefix decoded again per step)."""

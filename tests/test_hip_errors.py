@@ -77,3 +77,53 @@ def test_nan_gradient_skips_the_inner_step(eng):
     st = eng.read_stats()
     assert np.isfinite(st["grad_norm"]) and not torch.equal(eng.params, before)
     eng.load_state_dict(ref_cpu.deterministic_state_dict(TINY, ODIM, seed=7))
+
+
+def test_ctc_lengths_outside_the_call_are_refused_by_the_kernel():
+    """masr_ctc_loss takes its lengths as DEVICE arrays (src/blstm_trainer.py:62-70 hands torch tensors to nn.CTCLoss), so the
+    kernel vets them: in_len > T, a negative length or a target wider than the lattice the work buffer holds -> that utterance is
+    not run (NaN nll -> NaN mean: loud; zero gradient rows; nothing read or written out of bounds) and masr_ctc_status names it;
+    in_len == 0 is torch's no-path case (loss 0, zero gradient) -- the rest of the batch is what torch computes."""
+    L = _cabi.lib()
+    P = lambda t: C.c_void_p(t.data_ptr())
+    S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(9)
+    T, B, Cc = 24, 4, 23
+    logits = torch.randn(T, B, Cc, generator=g)
+    tl = torch.tensor([5, 3, 4, 2])
+    tgt = torch.randint(1, Cc, (int(tl.sum()),), generator=g)
+    off = torch.cat([torch.zeros(1, dtype=torch.int64), tl.cumsum(0)[:-1]])
+    d = lambda t: t.to(torch.int32).cuda()
+    maxS = int(2 * tl.max() + 1)
+    lg = logits.cuda().contiguous()
+
+    def run(il, tl_=tl):
+        work = torch.zeros(int(L.masr_ctc_work_floats(T, B, maxS)), device="cuda")
+        nll, loss, grad = torch.zeros(B, device="cuda"), torch.zeros(1, device="cuda"), torch.full_like(lg, 3.0)
+        tg, of, ild, tld = d(tgt), d(off), d(il), d(tl_)
+        _cabi.check(L.masr_ctc_loss(P(lg), P(tg), P(of), P(ild), P(tld), T, B, Cc, 0, P(nll), P(loss), P(grad), P(work), maxS, S()))
+        return L.masr_ctc_status(S()), nll.cpu(), float(loss), grad.cpu()
+
+    # ---- in_len == 0 on utterance 1: torch says inf -> 0 (zero_infinity), zero gradient; the others as torch computes them
+    il = torch.tensor([24, 0, 20, 18])
+    st, nll, loss, grad = run(il)
+    lr = logits.clone().requires_grad_(True)
+    ref = torch.nn.CTCLoss(blank=0, reduction="mean", zero_infinity=True)(torch.log_softmax(lr, -1), tgt, il, tl)
+    ref.backward()
+    assert st == 0 and float(nll[1]) == 0.0 and abs(loss - float(ref)) <= 2e-5 * float(ref)
+    assert float(grad[:, 1].abs().max()) == 0.0
+    torch.testing.assert_close(grad, lr.grad, rtol=2e-3, atol=2e-6)
+    # ---- in_len > T on utterance 2, negative on 0, a target wider than maxS on 3: refused, named, NaN; utterance 1 is still right
+    for il_bad, tl_bad, who in ((torch.tensor([24, 22, 25, 18]), tl, 2), (torch.tensor([-1, 22, 20, 18]), tl, 0),
+                                (torch.tensor([24, 22, 20, 18]), torch.tensor([5, 3, 4, 9]), 3)):
+        st, nll, loss, grad = run(il_bad, tl_bad)
+        assert st == who + 1 and b"mk_ctc_loss" in L.masr_last_error() and str(who).encode() in L.masr_last_error()
+        assert np.isnan(float(nll[who])) and np.isnan(loss) and float(grad[:, who].abs().max()) == 0.0
+        ok = [b for b in range(B) if b != who]
+        assert all(np.isfinite(float(nll[b])) and float(nll[b]) > 0 for b in ok) and bool(torch.isfinite(grad).all())
+        assert L.masr_ctc_status(S()) == 0                                       # the mark was cleared by the read
+    # ---- arguments the host CAN see are refused before anything is launched
+    work = torch.zeros(int(L.masr_ctc_work_floats(T, B, maxS)), device="cuda")
+    z = torch.zeros(B, device="cuda")
+    assert L.masr_ctc_loss(P(lg), P(d(tgt)), P(d(off)), P(d(il)), P(d(tl)), T, B, Cc, Cc, P(z), P(z), P(torch.zeros_like(lg)), P(work), maxS, S()) != 0
+    assert b"blank" in L.masr_last_error()

@@ -523,6 +523,31 @@ def test_fbank_pitch_matches_kaldi_style_oracle(tmp_path):
     # noise tails where the NCCF is flat and neighbouring lags are near-ties; the voiced frames agree throughout
     assert same > 0.9 and d[:, 0].max() < 0.02 and d[:, 1].max() < 0.0105 and d[:, 2].max() < 0.06
     assert (d[10:90] < np.array([2e-3, 2e-3, 2e-2])).all(1).mean() > 0.98
+    # ---- WHY the tail frames differ, and that nothing else does.  Neighbouring lags of the 1.005-ratio grid differ by ~1e-7 in
+    # path cost EVERYWHERE (oracle/pitch_np.viterbi_margins: printed below), about one fp32 ulp of a forward cost on a noise frame,
+    # so a float64 and an fp32 Viterbi recursion part ways there -- the oracle itself does when its recursion is run in the kernel's
+    # fp32 arithmetic (pitch_np.viterbi_f32: 22 of these 315 frames move, all on the noise tails).  Hence:
+    #  (i)  against the oracle WITH the fp32 recursion the kernels must agree on (almost) every frame -- the NCCF values can still
+    #       differ in the last fp32 bit (double sums in another order, then rounded), so one flipped near-tie is tolerated;
+    #  (ii) against the float64 oracle every VOICED stretch (the harmonic glide: first 70 % of each signal) agrees, all three of them.
+    ref32 = np.concatenate([np.concatenate([F.fbank(w, 80)[:T_], P.pitch_feats(w, fp32_tracker=True)[:T_]], axis=1) for w, T_ in zip(wavs, want_T) if T_])
+    d32 = np.abs(got[:, 80:] - ref32[:, 80:])
+    same32 = (d32 < np.array([2e-3, 2e-3, 2e-2])).all(1)
+    row0, margins = 0, []
+    for w, T_ in zip(wavs, want_T):
+        if not T_:
+            continue
+        voiced = slice(row0 + 5, row0 + int(0.7 * T_) - 5)
+        assert (d[voiced] < np.array([2e-3, 2e-3, 2e-2])).all(), f"a voiced frame of the utterance at row {row0} differs from the float64 oracle"
+        assert got[voiced, 80].max() < -1.0                                # (voiced indeed: pov feature strongly negative)
+        margins.append(P.pitch_decision_margins(w)[:T_])
+        row0 += T_
+    margins = np.concatenate(margins)
+    lag_differs = d[:, 1] > 5e-3                                            # one lag step = 2 ln 1.005 = 0.00998 in this column
+    print(f"pitch tracker: {int(lag_differs.sum())} of {len(d)} frames carry another lag than the float64 oracle (decision margins there "
+          f"<= {margins[lag_differs].max() if lag_differs.any() else 0:.1e}; median margin over all frames {np.median(margins):.1e}); "
+          f"against the oracle with the fp32 recursion {int((~same32).sum())} frames differ")
+    assert same32.mean() >= 0.97 and (margins[lag_differs] < 1e-5).all()
     # voiced part of the first utterance: pov feature strongly negative, delta log pitch = its slope
     assert got[10:90, 80].max() < -1.0
     # end to end: the rows are a valid input of an idim-83 model

@@ -44,11 +44,14 @@ class CpuEngine:
         self.params = torch.linspace(-1, 1, N, dtype=torch.float64)
         self.grads = torch.zeros(N, dtype=torch.float64)
         self._norm, self._loss, self.log = 0.0, 0.0, log
+        self.interrupt_at = None
         self.device = torch.device("cpu")
 
     def copy(self, dst, src): dst.copy_(src)
     def mark_dirty(self): pass
-    def set_seed(self, s): pass
+    def set_seed(self, s): self._drop = [int(s), 0]                    # the dropout stream: (seed, position), as masr_dropout_state
+    def dropout_state(self): return tuple(getattr(self, "_drop", [0, 0]))
+    def set_dropout_state(self, d): self._drop = list(d)
     def axpy(self, y, x, a): y.add_(x, alpha=a)
     def scale(self, x, a): x.mul_(a)
 
@@ -60,7 +63,12 @@ class CpuEngine:
 
     def run_batch(self, x, ilens, ys, olens, train):
         fp = batch_fingerprint(x, ys)
+        if train and self.interrupt_at is not None and sum(1 for t, _ in self.log if t) == self.interrupt_at:
+            self.interrupt_at = None
+            raise KeyboardInterrupt
         self.log.append((bool(train), fp))
+        if train:
+            self._drop = [getattr(self, "_drop", [0, 0])[0], getattr(self, "_drop", [0, 0])[1] + 1]
         ph = (fp % 7.0) + 0.5
         self.grads = self.params * (0.1 + 0.01 * (fp % 3.0)) + 0.4 * torch.sin(torch.arange(N, dtype=torch.float64) * ph)
         self._loss = float(self.grads.abs().mean())
@@ -92,6 +100,7 @@ def get_cpu_trainer(cls, config, paras, id2accent, log):
     class CpuTrainer(cls):
         def set_model(self):
             eng = CpuEngine(log)
+            eng.set_seed(531 + 7919 * 64 * self.sharder.rank)
             self.asr_model = SimpleNamespace(engine=eng, train=lambda: None, eval=lambda: None,
                                              load_state_dict=eng.load_state_dict)
             self.label_smooth_rate = 0.0
@@ -102,14 +111,13 @@ def get_cpu_trainer(cls, config, paras, id2accent, log):
 
         def _make_slots(self):
             """task slots as the product makes them (replica + engine per slot), without HIP streams"""
-            if self.tasks_per_gpu == 1:
-                self._slots = None
-                return
             models = [self.asr_model]
             for _ in range(self.tasks_per_gpu - 1):
                 e = CpuEngine(log)
                 models.append(SimpleNamespace(engine=e, train=lambda: None, eval=lambda: None, load_state_dict=e.load_state_dict))
             self._slots = [{'model': m, 'engine': m.engine, 'stream': None} for m in models]
+            for i, sl in enumerate(self._slots):                         # one dropout stream per (rank, slot), as the product seeds them
+                sl['engine'].set_seed(531 + 7919 * (self.sharder.rank * self.tasks_per_gpu + i))
 
         def exec(self):
             self.train()
@@ -150,7 +158,8 @@ def make_workspace(root):
 
 
 def run(root, algo, world, rank, fix_snapshot=False, meta_batch=3, steps=5, accents=("af", "au", "en", "us"), meta_k=2, fix_reptile=False,
-        deferred=False, log_ival=1, eval_ival=2, save_ival=2, tasks_per_gpu=1, is_bucket=True, resume=False, suffix=None):
+        deferred=False, log_ival=1, eval_ival=2, save_ival=2, tasks_per_gpu=1, is_bucket=True, resume=False, suffix=None, njobs=None,
+        interrupt_at=None):
     os.chdir(root)
     model = {"d_model": 64}
     if algo in ("fomaml", "reptile"):
@@ -164,7 +173,7 @@ def run(root, algo, world, rank, fix_snapshot=False, meta_batch=3, steps=5, acce
                       "min_ilen": 10, "max_ilen": 50, "dev_max_ilen": 3000, "half_batch_ilen": 30}}
     paras = SimpleNamespace(pretrain_suffix=suffix or f"w{world}", pretrain_accents=list(accents), num_pretrain=len(accents), tgt_accent="ca", runs=0,
                             overwrite=True, seed=531, meta_k=meta_k, meta_batch_size=meta_batch, sample_strategy="normal", max_step=steps,
-                            resume=resume, model_name="transformer", algo=algo, njobs=2 if world > 1 else 0, is_bucket=is_bucket, is_memmap=True,
+                            resume=resume, model_name="transformer", algo=algo, njobs=njobs if njobs is not None else (2 if world > 1 else 0), is_bucket=is_bucket, is_memmap=True,
                             use_tensorboard=False, fix_snapshot_meta_weights=fix_snapshot, tasks_per_gpu=tasks_per_gpu, fix_reptile=fix_reptile)
     random.seed(531); np.random.seed(531); torch.manual_seed(531)
     if algo in ("fomaml", "reptile"):
@@ -197,11 +206,14 @@ def run(root, algo, world, rank, fix_snapshot=False, meta_batch=3, steps=5, acce
     solver.sharder.reduce_async = lambda buf, **k: (n_reduces.append(solver.global_step), plain_reduce(buf, **k))[1]
     solver.load_data()
     solver.set_model()
+    solver.asr_model.engine.interrupt_at = interrupt_at
     solver.exec()
+    slots = getattr(solver, "_slots", None) or [{"engine": solver.asr_model.engine}]
+    dropout = [sl["engine"].dropout_state() for sl in slots]
     weights = solver._original.clone() if algo in ("fomaml", "reptile") else solver.asr_model.engine.params.clone()
     files = sorted(p.name for p in solver.log_dir.iterdir()) if rank == 0 else []
     dev_log = (solver.log_dir / "dev_avg_wer").read_text() if rank == 0 and (solver.log_dir / "dev_avg_wer").exists() else ""
-    return {"n_reduces": n_reduces, "tasks_per_gpu": getattr(solver, "tasks_per_gpu", 1), "weights": weights, "train_fps": [fp for tr, fp in log if tr], "files": files, "dev_avg_wer": dev_log,
+    return {"dropout": dropout, "n_reduces": n_reduces, "tasks_per_gpu": getattr(solver, "tasks_per_gpu", 1), "weights": weights, "train_fps": [fp for tr, fp in log if tr], "files": files, "dev_avg_wer": dev_log,
             "global_step": solver.global_step, "train_info": {k: float(v) for k, v in solver.train_info.items()}, "booked": booked,
             "train_loss_log": (solver.log_dir / "train_loss").read_text() if rank == 0 and (solver.log_dir / "train_loss").exists() else ""}
 
@@ -385,3 +397,36 @@ def test_resume_continues_the_data_and_task_streams_exactly(workspace, algo, is_
     assert torch.equal(res["weights"], full["weights"])
     assert res["train_info"] == full["train_info"]
     assert n_part == (stop - 1) * per_step
+
+
+@pytest.mark.parametrize("algo,K", [("fomaml", 1), ("fomaml", 2), ("multi", 1)])
+def test_two_rank_resume_restores_each_ranks_own_dropout_streams(workspace, algo, K):
+    """the dropout streams are per (rank, slot).  A checkpoint written by rank 0 holds EVERY rank's stream positions and a resumed
+    rank restores its own: after stop + resume both ranks sit where the uninterrupted two-rank run left them (seed and position),
+    the two ranks' streams differ from each other, and the meta weights are those of the uninterrupted run."""
+    kw = dict(meta_batch=4, eval_ival=2, save_ival=3, tasks_per_gpu=K)
+    full = _ranks(workspace, algo, world=2, steps=9, suffix="full", **kw)
+    _ranks(workspace, algo, world=2, steps=4, suffix="part", **kw)               # saved at global_step 3
+    res = _ranks(workspace, algo, world=2, steps=9, suffix="part", resume=True, **kw)
+    for r in (0, 1):
+        assert res[r]["dropout"] == full[r]["dropout"], (r, res[r]["dropout"], full[r]["dropout"])
+        assert torch.equal(res[r]["weights"], full[r]["weights"])
+    assert full[0]["dropout"] != full[1]["dropout"]
+    assert {seed for seed, _ in full[0]["dropout"]}.isdisjoint({seed for seed, _ in full[1]["dropout"]})
+
+
+@pytest.mark.parametrize("algo", ["fomaml", "multi"])
+def test_sigint_checkpoint_does_not_lose_the_batches_drawn_ahead(workspace, algo):
+    """Ctrl-C while the NEXT step's batches are already drawn (look-ahead, collate pool): the checkpoint holds the RNG / sampler /
+    task-order state as it stood BEFORE that draw, so the resumed run draws those batches again -- exactly what a loop without
+    look-ahead (the reference's) leaves behind: the interrupted step's own batches are spent, nothing after them is skipped."""
+    per_step = 3 * 3 if algo == "fomaml" else 1                        # meta_batch 3 x (2 inner + val) | one batch per step
+    kw = dict(eval_ival=5, save_ival=50, njobs=2)                      # (the loops run whole eval_ival chunks, as the reference's do)
+    full = run(workspace, algo, 1, 0, steps=16, suffix="full", **kw)
+    # a train call in the middle of (meta-)step 4; FOMAML: in its SECOND task (the look-ahead runs once the first task is queued)
+    hit = 3 * per_step + (4 if algo == "fomaml" else 0)
+    part = run(workspace, algo, 1, 0, steps=9, suffix="part", interrupt_at=hit, **kw)
+    assert part["global_step"] == 4 and len(part["train_fps"]) == hit
+    res = run(workspace, algo, 1, 0, steps=9, suffix="part", resume=True, **kw)
+    assert res["train_fps"][:per_step] == full["train_fps"][4 * per_step:5 * per_step], "the step drawn ahead of the SIGINT was skipped"
+    assert res["train_fps"] == full["train_fps"][4 * per_step:4 * per_step + len(res["train_fps"])]
