@@ -144,6 +144,38 @@ int masr_scale(float* x, int64_t n, float a, void* stream);                     
 int masr_axpy(float* y, const float* x, int64_t n, float a, void* stream);
 int masr_copy(float* dst, const float* src, int64_t n, void* stream);                 /* load_state_dict(_original) (:226) */
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * The exchange step of sharded meta-training: all-reduce(sum) of the flat meta-gradient over the ranks' GPUs with
+ * RCCL over xGMI.  The reference is one process: its `_updates[n] += p.grad` over the tasks of a meta-step and `_updates[n] /=
+ * counter` (src/fo_meta_interface.py:190-196,200-202) become, with the tasks sharded one per GPU, local gradient -> all-reduce(sum)
+ * -> the same division and the same (replicated) Noam-Adam step on every rank.  librccl is bound with dlopen at init: libmasr has
+ * no link-time dependency on it and single-GPU runs never load it.
+ *   masr_allreduce_unique_id : rank 0 draws the communicator id (MASR_UNIQUE_ID_BYTES bytes); the caller ships it to the other
+ *                              ranks over any side channel (torch.distributed's store, a file, MPI ...).
+ *   masr_allreduce_init      : ncclCommInitRank on the CURRENT HIP device (one process per GPU); the communicator owns a
+ *                              non-blocking side stream.  NULL + masr_last_error() on failure.
+ *   masr_allreduce           : buf[0..n) (device fp32) is summed over all ranks IN PLACE, on the communicator's side stream,
+ *                              ordered behind everything queued so far on `producer_stream` -- the caller goes on queueing the
+ *                              next task's inner forward on `producer_stream` meanwhile and must not touch buf before
+ *                              masr_allreduce_wait.  norm != NULL: buf is first scaled by clip_grad_norm_'s coefficient
+ *                              min(1, max_norm / (*norm + 1e-6)) (`norm` = device float, e.g. masr_stats_device(m) + 3 after
+ *                              masr_grad_norm; the reference clips every task's gradient before accumulating it, :148-149).  The
+ *                              coefficient exists only once the whole backward is done, so the scale pass cannot be bucketed into
+ *                              the backward: it is PIPELINED with the collective instead, chunk by chunk (chunk k+1 is scaled on
+ *                              the producer stream while chunk k is on the wire).  nchunks (1..16): a few LARGE chunks -- xGMI is
+ *                              point-to-point, a ring is bound by one ~153 GB/s link, small buckets only add launch latency.
+ *   masr_allreduce_wait      : `stream` waits (on the device, no host sync) for every exchange issued so far.
+ * Not thread-safe per communicator; calls on one communicator must come in the same order on every rank (RCCL's rule). */
+#define MASR_UNIQUE_ID_BYTES 128
+typedef struct masr_comm masr_comm;
+int masr_allreduce_unique_id(char* id);
+masr_comm* masr_allreduce_init(int rank, int world, const char* id);
+void masr_allreduce_destroy(masr_comm* c);
+int masr_allreduce(masr_comm* c, float* buf, int64_t n, const float* norm, float max_norm, int nchunks, void* producer_stream);
+int masr_allreduce_wait(masr_comm* c, void* stream);
+/* device view of the model's stats block: [0] loss, [1] n_correct, [2] n_total, [3] gradient norm (after masr_grad_norm / masr_clip_*) */
+const float* masr_stats_device(masr_model* m);
+
 /* MyTransformer.recog (mono_transformer_torch.py:143-176): greedy decode, out int32 [Ldec][B] (device),
  * Ldec = max(floor(ilens/4)).  Needs workspace for L = Ldec.
  * masr_recog      : KV-cached incremental decode (one new position per step, the step replayed as a hipGraph);

@@ -52,6 +52,12 @@ _SIGS = {
     "masr_scale": (i32, [vp, i64, f32, vp]),
     "masr_axpy": (i32, [vp, vp, i64, f32, vp]),
     "masr_copy": (i32, [vp, vp, i64, vp]),
+    "masr_allreduce_unique_id": (i32, [C.c_char_p]),
+    "masr_allreduce_init": (vp, [i32, i32, C.c_char_p]),
+    "masr_allreduce_destroy": (None, [vp]),
+    "masr_allreduce": (i32, [vp, vp, i64, vp, f32, i32, vp]),
+    "masr_allreduce_wait": (i32, [vp, vp]),
+    "masr_stats_device": (vp, [vp]),
     "masr_recog": (i32, [vp, vp, vp, i32, i32, vp, vp]),
     "masr_recog_full": (i32, [vp, vp, vp, i32, i32, vp, vp]),
     "masr_edit_distance": (i64, [vp, i32, vp, i32]),

@@ -944,6 +944,7 @@ int masr_read_stats(masr_model* m, float out[4], void* stream) {
     return 0;
 }
 
+const float* masr_stats_device(masr_model* m) { return m ? m->stats : nullptr; }
 int64_t masr_stats_post(masr_model* m, void* stream) {
     if (!m->h_ring) { mk_set_error("masr_stats_post", "not bound"); return -1; }
     const int slot = (int)(m->ring_next % masr_model::RING);

@@ -276,6 +276,10 @@ class MasrEngine:
     def grad_norm(self):
         check(self._l.masr_grad_norm(self.h, self.stream()), "masr_grad_norm")
 
+    def grad_norm_device_ptr(self):
+        """address of the device float that holds the gradient norm after grad_norm() / clip_grads() (include/masr.h masr_stats_device)"""
+        return int(self._l.masr_stats_device(self.h)) + 3 * 4
+
     def adam_step(self, params, grads, m, v, lr, b1, b2, eps, step, weight_decay=0.0, decoupled=False):
         if weight_decay:
             check(self._l.masr_adamw_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, b1, b2, eps, weight_decay,

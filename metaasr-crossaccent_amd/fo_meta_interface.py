@@ -215,12 +215,23 @@ class FOMetaASRInterface(PretrainInterface):
         can copy them to the host asynchronously (`clip_stats_async`) nothing waits here -- the reference uses these numbers for
         log lines only (:147-151) -- and `_drain_stats` collects them one meta-step later, in task order.  Otherwise (or when
         run_batch already returned an info): the one host sync of the task, as before."""
+        self._wire_clip = False
         if info is None and hasattr(self, 'clip_stats_async') and not getattr(self.paras, 'sync_stats', False):
+            # native exchange, one task at a time: only the NORM is formed here -- the scale by the clip coefficient rides on the
+            # all-reduce of _partial_meta_update, chunk by chunk beside the collective (include/masr.h masr_allreduce)
+            if self._clip_on_the_wire(engine):
+                self._wire_clip = True
+                return self.clip_stats_async(GRAD_CLIP, engine=engine, norm_only=True)
             return self.clip_stats_async(GRAD_CLIP, engine=engine)
         grad_norm = self.clip_grad_norm_(GRAD_CLIP, engine=engine) if engine is not None else self.clip_grad_norm_(GRAD_CLIP)
         if info is None:
             info = self.info_from_stats(engine) if engine is not None else self.info_from_stats()
         return _Resolved(info, grad_norm)
+
+    def _clip_on_the_wire(self, engine=None):
+        sh = self.sharder
+        return (engine is None and getattr(sh, 'native', False) and self.tasks_per_gpu == 1 and self.paras.algo == 'fomaml'
+                and hasattr(self.asr_model.engine, 'grad_norm_device_ptr'))
 
     def _drain_stats(self, keep_steps=0):
         """book the pending task stats (all but those of the newest `keep_steps` meta-steps): NaN warning + train_info.add, in
@@ -418,6 +429,12 @@ class FOMetaASRInterface(PretrainInterface):
             eng.axpy(contrib, eng.params, -1.0)
         else:
             contrib = eng.grads.clone()                                   # per-task buffer handed to the side stream
+        if not reptile and getattr(self, '_wire_clip', False):           # (_clip_and_stats left the gradient unscaled, norm on the device)
+            self._wire_clip = False
+            self.sharder.reduce_async(contrib, clip=(eng.grad_norm_device_ptr(), GRAD_CLIP))
+            self._n_reduces = getattr(self, '_n_reduces', 0) + 1
+            self._updates.append(contrib)
+            return
         self.sharder.reduce_async(contrib)                              # side stream: overlaps this rank's next task
         self._n_reduces = getattr(self, '_n_reduces', 0) + 1
         self._updates.append(contrib)

@@ -26,6 +26,14 @@ class TaskSharder:
         self.collective = (world > 1) if collective is None else bool(collective)
         self._side = None
         self._pending = []
+        # the exchange itself goes through the C ABI (include/masr.h masr_allreduce: librccl bound directly, our own side stream and
+        # event ordering, clip-scale pipelined with the collective) whenever the ranks sit on GPUs with the RCCL backend;
+        # torch.distributed then only carries the control plane (the communicator id, barriers, gathered eval numbers) and stays
+        # the transport of the gloo rehearsals.  MASR_NO_NATIVE_ALLREDUCE=1: ProcessGroupNCCL's all_reduce instead (A/B).
+        self.native = self.collective and backend == "nccl" and os.environ.get("MASR_NO_NATIVE_ALLREDUCE") != "1"
+        self.nchunks = int(os.environ.get("MASR_ALLREDUCE_CHUNKS", "4"))
+        self._comm = None
+        self._native_issued = False
 
     @classmethod
     def from_env(cls):
@@ -77,13 +85,51 @@ class TaskSharder:
             self._side = torch.cuda.Stream(device=device)
         return self._side
 
-    def reduce_async(self, buf, side_stream=True):
+    def _native_comm(self, device):
+        """the C-ABI communicator of this rank (made on first use: rank 0 draws the RCCL id, the process group ships its 128 bytes)"""
+        if self._comm is None:
+            import ctypes as C
+            import torch.distributed as dist
+            from . import _cabi
+            L = _cabi.lib()
+            torch.cuda.set_device(device)
+            box = [None]
+            if self.rank == 0:
+                raw = C.create_string_buffer(128)
+                _cabi.check(L.masr_allreduce_unique_id(raw), "masr_allreduce_unique_id")
+                box[0] = raw.raw
+            if self.world > 1:
+                dist.broadcast_object_list(box, src=0)
+            self._comm = L.masr_allreduce_init(self.rank, self.world, box[0])
+            if not self._comm:
+                raise _cabi.MasrError("masr_allreduce_init: " + L.masr_last_error().decode())
+            self._L = L
+        return self._comm
+
+    def close(self):
+        if self._comm is not None:
+            self._L.masr_allreduce_destroy(self._comm)
+            self._comm = None
+
+    def reduce_async(self, buf, side_stream=True, clip=None):
         """all-reduce(sum) `buf` in place, overlapped with whatever the caller enqueues next on the main stream.
         The caller must not touch `buf` until wait_all().  side_stream=False: issued from the current stream (RCCL still runs it on
         its own stream) -- for callers that already keep four streams busy, where one more stream with work queued displaces a
-        task's and nothing is left to overlap with anyway."""
+        task's and nothing is left to overlap with anyway.
+        clip=(address of a device float holding buf's L2 norm, max_norm): buf is scaled by clip_grad_norm_'s coefficient on the
+        way out, chunk by chunk beside the collective (native path; elsewhere the scale pass runs first)."""
         if not self.collective:
             return
+        if self.native and buf.device.type == "cuda":
+            from . import _cabi
+            comm = self._native_comm(buf.device)
+            norm, max_norm = clip if clip is not None else (None, 0.0)
+            _cabi.check(self._L.masr_allreduce(comm, buf.data_ptr(), buf.numel(), norm, max_norm, self.nchunks,
+                                               torch.cuda.current_stream(buf.device).cuda_stream), "masr_allreduce")
+            self._native_issued = True
+            return
+        if clip is not None:
+            raise ValueError("clip= needs the native exchange (callers clip in place first on the other transports)")
         import torch.distributed as dist
         if buf.device.type == "cuda" and self.backend == "gloo":
             # rehearsal of the multi-rank path on a box with fewer GPUs than ranks (gloo has no device collectives worth the
@@ -105,6 +151,10 @@ class TaskSharder:
             self._pending.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), None))
 
     def wait_all(self):
+        if self._native_issued:                                  # a device-side wait: the host does not block
+            from . import _cabi
+            _cabi.check(self._L.masr_allreduce_wait(self._comm, torch.cuda.current_stream().cuda_stream), "masr_allreduce_wait")
+            self._native_issued = False
         for work, side in self._pending:
             work.wait()
             if side is not None:

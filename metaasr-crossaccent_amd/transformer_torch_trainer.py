@@ -110,12 +110,16 @@ def get_trainer(cls, config, paras, id2accent):
                     return {'loss': st['loss'], 'acc': st['n_correct'] / st['n_total']}, st['grad_norm']
             return _H()
 
-        def clip_stats_async(self, max_norm, engine=None):
+        def clip_stats_async(self, max_norm, engine=None, norm_only=False):
             """clip_grad_norm_ without the host sync: the clip is queued, and so is the copy of {loss, counts, norm} to the host;
             returns a handle, .get() -> (info, grad_norm) once that copy has landed (used by the meta loops to stay one
-            meta-step ahead of the GPU)"""
+            meta-step ahead of the GPU).  norm_only: the norm is formed, the gradient is left unscaled (the caller's all-reduce
+            applies the coefficient on the way out, include/masr.h masr_allreduce)"""
             eng = engine if engine is not None else self.asr_model.engine
-            eng.clip_grads(max_norm)
+            if norm_only:
+                eng.grad_norm()
+            else:
+                eng.clip_grads(max_norm)
             pend = eng.read_stats_async()
 
             class _H:

@@ -26,6 +26,7 @@ def main():
         captured["step"] = self.global_step
         captured["collective"] = bool(self.sharder.collective)
         captured["backend"] = self.sharder.backend
+        captured["native"] = bool(getattr(self.sharder, "native", False))
     fo_meta_interface.FOMetaASRInterface.train = train
     pretrain.main(["--config", "cfg3.yaml", "--pretrain_suffix", suffix, "--pretrain_accents", "af", "au", "en", "us", "--num_pretrain", "4",
                    "--tgt_accent", "ca", "--algo", "fomaml", "--meta_k", "1", "--meta_batch_size", "4", "--max_step", "5", "--njobs", "2",

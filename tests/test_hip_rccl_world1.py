@@ -35,8 +35,12 @@ def _env(**kw):
     return env
 
 
-def test_tasksharder_exchange_through_rccl_with_one_rank(tmp_path):
-    r = subprocess.run([sys.executable, str(ROOT / "tests" / "_rccl_world1_worker.py")], cwd=tmp_path, env=_env(), capture_output=True, text=True,
+@pytest.mark.parametrize("native", [True, False])
+def test_tasksharder_exchange_through_rccl_with_one_rank(tmp_path, native):
+    """native: the exchange through the C ABI (masr_allreduce: librccl bound directly, own side stream, clip pipelined with the
+    collective); otherwise ProcessGroupNCCL's all_reduce (MASR_NO_NATIVE_ALLREDUCE=1, the A/B transport)"""
+    env = _env() if native else _env(MASR_NO_NATIVE_ALLREDUCE="1")
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "_rccl_world1_worker.py")], cwd=tmp_path, env=env, capture_output=True, text=True,
                        timeout=420)
     assert r.returncode == 0 and "rccl-world1-ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
@@ -54,6 +58,7 @@ def test_pretrain_cli_meta_steps_through_rccl_with_one_rank(golden_dir, tmp_path
     assert rccl.returncode == 0, rccl.stderr[-3000:]
     a, b = torch.load(tmp_path / "plain_r0.pt"), torch.load(tmp_path / "rccl_r0.pt")
     assert not a["collective"] and b["collective"] and b["backend"] == "nccl"
+    assert b["native"] and not a["native"]                     # the exchange went through the C ABI (masr_allreduce), clip on the wire at K = 1
     assert a["step"] == b["step"] == 5
     # the same four task gradients; summed as (((0 + g0) + g1) + g2) + g3 either way at one task per GPU, as (g0 + g1) + (g2 + g3)
     # through the per-wave sums at two: fp32 rounding of the gradient only, Adam's step is <= lr = 3.2e-8 per element and meta-step
