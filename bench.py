@@ -102,6 +102,62 @@ def cpu_model():
     return "unknown"
 
 
+class ClockSampler:
+    """shader / memory clock and board power of the local GPU, read from sysfs by a background thread while a leg runs (no child
+    process, no HIP call): pp_dpm_sclk marks the current DPM level with '*', hwmon power1_average is in microwatts.  What the driver's
+    record needs to carry for "MFMA busy 0.5 vs 0.42 of nominal peak = clock": the reading UNDER LOAD.  (MI355X_MICROARCH.md: the
+    in-kernel clock runs up to ~10 % below this reading; it is an upper bound.)"""
+
+    def __init__(self, local=0, period=0.25):
+        import glob
+        self.period, self.samples, self._stop, self._th = period, [], threading.Event(), None
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.dev = os.path.dirname(cards[min(local, len(cards) - 1)]) if cards else None
+
+    @staticmethod
+    def _cur(path):
+        try:
+            for line in open(path):
+                if line.rstrip().endswith("*"):
+                    return float(line.split(":")[1].strip().split("Mhz")[0].split("MHz")[0])
+        except Exception:
+            return None
+        return None
+
+    def _power(self):
+        import glob
+        for f in glob.glob(os.path.join(self.dev, "hwmon", "hwmon*", "power1_average")) + glob.glob(os.path.join(self.dev, "hwmon", "hwmon*", "power1_input")):
+            try:
+                return float(open(f).read()) / 1e6
+            except Exception:
+                pass
+        return None
+
+    def _run(self):
+        while not self._stop.wait(self.period):
+            self.samples.append((self._cur(os.path.join(self.dev, "pp_dpm_sclk")), self._cur(os.path.join(self.dev, "pp_dpm_mclk")), self._power()))
+
+    def __enter__(self):
+        if self.dev:
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self._th:
+            self._th.join()
+
+    def summary(self):
+        col = lambda i: [x[i] for x in self.samples if x[i] is not None]
+        s_, m_, p_ = col(0), col(1), col(2)
+        if not s_:
+            return {"available": False, "note": "pp_dpm_sclk not readable on this box"}
+        return {"available": True, "samples": len(s_), "sclk_mhz_min": min(s_), "sclk_mhz_median": float(np.median(s_)), "sclk_mhz_max": max(s_),
+                "mclk_mhz_median": float(np.median(m_)) if m_ else None, "power_w_median": float(np.median(p_)) if p_ else None,
+                "source": "sysfs pp_dpm_sclk / pp_dpm_mclk (current DPM level) and hwmon power1_average, sampled every %.2f s during the leg" % self.period}
+
+
 def cpu_baseline(cfg, B, T, D, steps=6):
     """The oracle's inner step (fp32 torch on the host cores) on a bounded sample of the same workload."""
     from oracle import ref_cpu
@@ -143,6 +199,7 @@ def main():
     ap.add_argument("--no-matrix", action="store_true", help="skip the SURVEY 8(d) matrix legs (idim 83, B 32, the 4e2d / E256 geometry), reported as \"matrix\"")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (\"e2e_pretrain\": the pretrain.py --algo fomaml loop WITH its data path, "
                     "shards on disk -> BucketSampler -> pinned collate -> upload -> tasks -> meta update; tools/bench_pretrain.py in a child process)")
+    ap.add_argument("--single-seconds", type=float, default=1.0, help="length of the one-task-per-GPU regions (\"single_task\")")
     ap.add_argument("--no-stagger", action="store_true", help="start all concurrent tasks at the same instant (lock-step)")
     ap.add_argument("--no-meta-step", action="store_true", help="skip the whole-meta-step leg (\"meta_step\" in the output)")
     ap.add_argument("--meta-rounds", type=int, default=2, help="task rounds per rank in the meta-step leg (>= 2 shows the all-reduce overlap)")
@@ -290,17 +347,26 @@ def main():
             dt = float(tt.item())
         return dt
 
-    single = None
+    F_step = 3 * fwd_flops_per_utt(T, D)
+
+    def time_single(task_list, Bs, flops_per_utt, seconds):
+        """one task per GPU over a region of at least `seconds` (a first short region sizes it): value, ms per step, model FLOPs / peak"""
+        dtp = timed(task_list[:1], 8, args.warmup)
+        n1 = max(8, int(seconds / (dtp / 8)) + 1)
+        dt1 = timed(task_list[:1], n1, 2)
+        v = world * Bs * n1 / dt1
+        return {"value": v, "unit": "utt/s", "ms_per_step": dt1 / n1 * 1e3, "steps": n1, "seconds": dt1,
+                "model_frac_of_bf16_peak": v * flops_per_utt / 1e12 / (PEAK_BF16_TFLOPS * world)}
+    single = single_first = None
     if K > 1:
-        n1 = max(5, args.steps // 3)
-        tasks[0].eng.set_concurrency(1)                          # (a model that has the GPU to itself: masr_set_concurrency)
-        dt1 = timed(tasks[:1], n1, args.warmup)
-        tasks[0].eng.set_concurrency(K)
-        single = {"value": world * B * n1 / dt1, "ms_per_step": dt1 / n1 * 1e3, "steps": n1}
-        log(f"single task per GPU: {single['value']:.1f} utt/s")
+        # >= 1 s, BEFORE the headline region: it also brings the clocks up, and the stagger of the K-task legs is derived from a
+        # number that one ramp hiccup cannot halve (round 3: 6 steps = 16 ms as the first timed region of the process read 2 800 utt/s
+        # on the driver's box against 5 900 here).  The figure reported as "single_task" is measured again AFTER the long run.
+        single_first = time_single(tasks, B, F_step, args.single_seconds)
+        log(f"single task per GPU (first, {single_first['seconds']:.2f} s): {single_first['value']:.1f} utt/s")
     stagger = 0.0
-    if K > 1 and not args.no_stagger and single is not None:
-        stagger = single["ms_per_step"] * 1e-3 / K              # spread the K task phases over one single-task step
+    if K > 1 and not args.no_stagger and single_first is not None:
+        stagger = single_first["ms_per_step"] * 1e-3 / K         # spread the K task phases over one single-task step
     dt = timed(tasks, args.steps, args.warmup, stagger)
     st = eng.read_stats()
     assert np.isfinite(st["loss"]) and np.isfinite(st["grad_norm"]), st
@@ -309,9 +375,17 @@ def main():
     if args.long_seconds > 0:
         # the driver's K-step region is ~0.2 s (clock ramp and jitter are a visible part of it): the same measurement over >= 2 s
         nlong = max(args.steps, int(1.1 * args.long_seconds / (dt / args.steps)) + 1)      # (+10 %: the short region includes the ramp)
-        dtl = timed(tasks, nlong, 2, stagger)
-        long_run = {"steps": nlong, "seconds": dtl, "value": world * K * B * nlong / dtl, "ms_per_step": dtl / nlong * 1e3}
-        log(f"long run: {dtl:.2f} s for {nlong} steps -> {long_run['value']:.1f} utt/s")
+        with ClockSampler(local) as clk:
+            dtl = timed(tasks, nlong, 2, stagger)
+        long_run = {"steps": nlong, "seconds": dtl, "value": world * K * B * nlong / dtl, "ms_per_step": dtl / nlong * 1e3,
+                    "clocks_under_load": clk.summary()}
+        log(f"long run: {dtl:.2f} s for {nlong} steps -> {long_run['value']:.1f} utt/s; clocks {long_run['clocks_under_load']}")
+    if K > 1:
+        with ClockSampler(local) as clk1:
+            single = time_single(tasks, B, F_step, args.single_seconds)      # warm clocks: right behind the long run
+        single["clocks_under_load"] = clk1.summary()
+        single["first_measurement"] = single_first
+        log(f"single task per GPU (after the long run, {single['seconds']:.2f} s): {single['value']:.1f} utt/s = {single['model_frac_of_bf16_peak']:.3f} of the bf16 peak")
 
     # ---- mixed-length leg (ilens ~ U{200..1500}): every task cycles through 8 batches of its own; all
     # utterances of a batch share one length (what the reference's BucketSampler yields) and the half-batch rule applies
@@ -365,6 +439,9 @@ def main():
             matrix[name] = {"value": world * K * Bm * nmx / dtm_, "unit": "utt/s", "ms_per_step": dtm_ / nmx * 1e3, "steps": nmx, "batch_per_task": Bm,
                             "idim": Dm, "tasks_per_gpu": K, **({"model": over} if over else {})}
             log(f"matrix {name}: {matrix[name]['value']:.1f} utt/s")
+            if name == "idim83" and K > 1:                       # the shipped feature width with one task per GPU (what configs[3] runs per GPU)
+                matrix[name]["single_task"] = time_single(tm, Bm, 3 * fwd_flops_per_utt(T, Dm), 0.5 * args.single_seconds)
+                log(f"matrix {name}, one task per GPU: {matrix[name]['single_task']['value']:.1f} utt/s")
             del tm
             torch.cuda.empty_cache()
 
@@ -652,6 +729,20 @@ def main():
                     log(f"end-to-end: {res['utt_per_s']:.0f} utt/s")
                 except Exception as ex:                              # never fail the bench line over the extra leg
                     out["e2e_pretrain"] = {"error": f"{type(ex).__name__}: {ex}"}
+            # BASELINE configs[1]: train.py mono-accent on one GPU, WITH its data path (tools/bench_train.py: one 2048-utterance shard on disk ->
+            # BucketSampler -> collate -> one step per batch, SGD as in the shipped adapt configs and Noam-Adam), a child process as above
+            out["e2e_train"] = {}
+            for opt_name in ("SGD", "noam"):
+                with tempfile.TemporaryDirectory(prefix="masr_e2e_train_") as td:
+                    cmd = [sys.executable, str(ROOT / "tools" / "bench_train.py"), "--utts", "2048", "--steps", "200", "--warm", "20", "--optimizer", opt_name, "--root", td]
+                    try:
+                        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                        res = json.loads(r.stdout.strip().splitlines()[-1])
+                        out["e2e_train"][opt_name] = {"value": res["utt_per_s"], "unit": "utt/s", "ms_per_step": res["ms_per_step"], "steps": res["steps"],
+                                                      "workload": res["workload"], "command": " ".join(cmd[1:-2])}
+                        log(f"end-to-end train.py ({opt_name}): {res['utt_per_s']:.0f} utt/s")
+                    except Exception as ex:
+                        out["e2e_train"][opt_name] = {"error": f"{type(ex).__name__}: {ex}"}
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline (oracle on host cores) ...")
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch, T, D, args.cpu_steps)
