@@ -111,8 +111,16 @@ class ClockSampler:
     def __init__(self, local=0, period=0.25):
         import glob
         self.period, self.samples, self._stop, self._th = period, [], threading.Event(), None
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        self.dev = os.path.dirname(cards[min(local, len(cards) - 1)]) if cards else None
+        # the box may hold 8 GPUs of which this job sees one: find OUR card by its PCI address; failing that, sample every card and
+        # report the one that draws the most power (the busy one)
+        self.dev, self.cands = None, [os.path.dirname(f) for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))]
+        try:
+            pr = torch.cuda.get_device_properties(local)
+            addr = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            if os.path.exists(f"/sys/bus/pci/devices/{addr}/pp_dpm_sclk"):
+                self.dev, self.how = f"/sys/bus/pci/devices/{addr}", f"PCI {addr}"
+        except Exception:
+            pass
 
     @staticmethod
     def _cur(path):
@@ -124,21 +132,31 @@ class ClockSampler:
             return None
         return None
 
-    def _power(self):
+    @staticmethod
+    def _power(dev):
         import glob
-        for f in glob.glob(os.path.join(self.dev, "hwmon", "hwmon*", "power1_average")) + glob.glob(os.path.join(self.dev, "hwmon", "hwmon*", "power1_input")):
+        for f in glob.glob(os.path.join(dev, "hwmon", "hwmon*", "power1_average")) + glob.glob(os.path.join(dev, "hwmon", "hwmon*", "power1_input")):
             try:
                 return float(open(f).read()) / 1e6
             except Exception:
                 pass
         return None
 
+    def _read(self, dev):
+        return (self._cur(os.path.join(dev, "pp_dpm_sclk")), self._cur(os.path.join(dev, "pp_dpm_mclk")), self._power(dev))
+
     def _run(self):
         while not self._stop.wait(self.period):
-            self.samples.append((self._cur(os.path.join(self.dev, "pp_dpm_sclk")), self._cur(os.path.join(self.dev, "pp_dpm_mclk")), self._power()))
+            if self.dev:
+                self.samples.append(self._read(self.dev))
+            else:                                                # no PCI match: the card under the highest power is ours
+                rows = [self._read(d) for d in self.cands]
+                rows = [r for r in rows if r[0] is not None]
+                if rows:
+                    self.samples.append(max(rows, key=lambda r: (r[2] or 0.0, r[0])))
 
     def __enter__(self):
-        if self.dev:
+        if self.dev or self.cands:
             self._th = threading.Thread(target=self._run, daemon=True)
             self._th.start()
         return self
@@ -155,6 +173,7 @@ class ClockSampler:
             return {"available": False, "note": "pp_dpm_sclk not readable on this box"}
         return {"available": True, "samples": len(s_), "sclk_mhz_min": min(s_), "sclk_mhz_median": float(np.median(s_)), "sclk_mhz_max": max(s_),
                 "mclk_mhz_median": float(np.median(m_)) if m_ else None, "power_w_median": float(np.median(p_)) if p_ else None,
+                "card": getattr(self, "how", "busiest of %d cards (by power)" % len(self.cands)),
                 "source": "sysfs pp_dpm_sclk / pp_dpm_mclk (current DPM level) and hwmon power1_average, sampled every %.2f s during the leg" % self.period}
 
 
