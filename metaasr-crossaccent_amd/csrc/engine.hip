@@ -340,7 +340,7 @@ int flush_enc_wgrads(Ctx& c) {
     masr_model* m = c.m;
     if (m->wge.n == 0) return 0;
     Prof p(m, MASR_PROF_WGRAD_ENC, c.s);
-    static const int tile = getenv("MASR_ENC_WGRAD_TILE") ? atoi(getenv("MASR_ENC_WGRAD_TILE")) : 128;      // (A/B: 64)
+    static const int tile = getenv("MASR_ENC_WGRAD_TILE") ? atoi(getenv("MASR_ENC_WGRAD_TILE")) : 256;      // 256 = 128 x 256 on eight waves (A/B: 128, 64)
     const int rc = mk_gemm_wgrad_grouped(m->wge, c.s, tile);
     m->wge.n = 0;
     return rc;

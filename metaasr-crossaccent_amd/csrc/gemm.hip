@@ -399,6 +399,159 @@ __global__ __launch_bounds__(256) void gemm_wgrad_grouped_kernel(WgradGroup grp)
     gemm_body<BM, BN, true, E_C32>(g, t % tiles_x, t / tiles_x, 0);
 }
 
+// ---- the encoder-row weight gradients on EIGHT-wave tiles (round 4).  What bounds the 128 x 128 four-wave launch above is operand
+// intake: every tile streams a [rows x 128] panel of dY and one of X through its CU (1.21 GB of tile operands for 244 MB of distinct
+// bytes, ~28 GB/s per CU: L2-miss territory), MFMA pipes busy 0.21.  A 128 x 256 tile on eight waves (2 x 4, 64 x 64 per wave: the same
+// per-wave work) takes in (128 + 256) / (128 * 256) bytes per FLOP instead of (128 + 128) / (128 * 128): -25 %.  One workgroup per CU
+// (106 KB of LDS, two waves per SIMD as two four-wave workgroups had).  The tile list of the hkust geometry is 296 such tiles for 256
+// CUs: a second round at 16 % occupancy would cost what the intake saves, so only a whole number of rounds runs as big tiles
+// (n_big = the largest multiple of 256 <= the tile count) and the remaining big tiles are cut into 128 x 128 halves that the SAME
+// eight waves take (2 x 4 waves of 64 x 32) as the CUs come free.  Every output element is still reduced by ONE workgroup over the rows in
+// order, so dW is bit-identical to the four-wave kernel's; the bias gradient (column sums, folded over 512 threads) differs in fp32
+// rounding only.  MASR_ENC_WGRAD_TILE=128 restores the four-wave launch.
+template <int ROWS, int NT>
+struct StagerRMT {
+    static constexpr int LDT = ROWS + 16;
+    static constexpr int RC = ROWS / 8;
+    static constexpr int CHUNKS = BK * RC;
+    static constexpr int PT = CHUNKS / NT;
+    static_assert(CHUNKS % NT == 0 && NT % RC == 0, "tile must be a multiple of NT chunks; a thread must keep its rows");
+    bf16x8 regs[PT];
+    unsigned ok;
+    __device__ __forceinline__ void load(const bf16* __restrict__ src, long ld, int r0, int k0, int nrows, int nk, int tid) {
+        ok = 0;
+        const int rmax = (nrows + 7) / 8 * 8 - 8;
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int c = tid + i * NT;
+            const int k = k0 + c / RC, r = r0 + (c % RC) * 8;
+            if (k < nk && r < nrows) ok |= 1u << i;
+            const int kc = k < nk ? k : nk - 1, rc = r < nrows ? r : rmax;
+            regs[i] = ld8(src + (long)kc * ld + rc);
+        }
+    }
+    __device__ __forceinline__ void store(bf16* __restrict__ dst, int tid) {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int c = tid + i * NT;
+            st8(dst + (c / RC) * LDT + (c % RC) * 8, (ok >> i) & 1 ? regs[i] : zero8());
+        }
+    }
+    __device__ __forceinline__ void accumulate(float (&acc)[8]) {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const float m = (ok >> i) & 1 ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(m, (float)regs[i][j], acc[j]);
+        }
+    }
+};
+constexpr int W8_LDS = 2 * (int)sizeof(TileRM<128>) + 2 * (int)sizeof(TileRM<256>);
+
+// dW[m0 .. m0+128)[n0 .. n0+BN) of one group member; 512 threads = 8 waves as 2 (rows) x 4 (columns)
+template <int BN>
+__device__ __forceinline__ void wgrad8_tile(const WgradDesc& d, const int m0, const int n0, const bool do_colsum, char* smem) {
+    constexpr int BM = 128, WM = 64, WN = BN / 4, FM = WM / 16, FN = WN / 16, NT = 512;
+    using SA = StagerRMT<BM, NT>;
+    using SB = StagerRMT<BN, NT>;
+    TileRM<BM>* sa_ = reinterpret_cast<TileRM<BM>*>(smem);
+    TileRM<BN>* sb_ = reinterpret_cast<TileRM<BN>*>(smem + 2 * sizeof(TileRM<BM>));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+    const int M = d.N, N = d.K, K = d.rows;                        // dW is [M = out features][N = in features], reduced over the K rows
+    constexpr int DEPTH = 2;
+    SA sa[DEPTH]; SB sb[DEPTH];
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int nk = (K + BK - 1) / BK;
+#pragma unroll
+    for (int dd = 0; dd < DEPTH; ++dd) {
+        sa[dd].load(d.dy, d.lddy, m0, dd * BK, M, K, tid);
+        sb[dd].load(d.x, d.ldx, n0, dd * BK, N, K, tid);
+    }
+    if (do_colsum) sa[0].accumulate(csum);
+    sa[0].store(sa_[0].d, tid);
+    sb[0].store(sb_[0].d, tid);
+    __syncthreads();
+    for (int kt0 = 0; kt0 < nk; kt0 += DEPTH) {
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            const int kt = kt0 + u;
+            if (kt >= nk) break;
+            const int cur = u & 1;
+            sa[u].load(d.dy, d.lddy, m0, (kt + DEPTH) * BK, M, K, tid);
+            sb[u].load(d.x, d.ldx, n0, (kt + DEPTH) * BK, N, K, tid);
+#pragma unroll
+            for (int kc = 0; kc < BK / 32; ++kc) {
+                bf16x8 af[FM], bfr[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i) af[i] = frag_rm<BM + 16>(sa_[cur].d, wm * WM + i * 16, lane, kc * 32);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) bfr[j] = frag_rm<BN + 16>(sb_[cur].d, wn * WN + j * 16, lane, kc * 32);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
+            }
+            if (kt + 1 < nk) {
+                const int nx = (u + 1) % DEPTH;
+                if (do_colsum) sa[nx].accumulate(csum);
+                sa[nx].store(sa_[cur ^ 1].d, tid);
+                sb[nx].store(sb_[cur ^ 1].d, tid);
+            }
+            __syncthreads();
+        }
+    }
+    if (do_colsum) {                                             // threads tid, tid + 16, ... own the same 8 rows of the dY tile
+        constexpr int RC = BM / 8;
+        float* red = reinterpret_cast<float*>(smem);              // [512][8] floats = 16 KB
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid * 8 + j] = csum[j];
+        __syncthreads();
+        if (tid < BM) {
+            const int rc = tid / 8, j = tid % 8;
+            float sum = 0.f;
+            for (int t = rc; t < NT; t += RC) sum += red[t * 8 + j];
+            if (m0 + tid < M) d.db[m0 + tid] = sum;
+        }
+    }
+    // accumulators straight to dW: lane (fq, fr) holds rows fq * 4 + r, column fr of every 16 x 16 block -- 16 lanes write 64 contiguous
+    // bytes of a row (the 39.5 MB of dW are written once per step: not what bounds this launch)
+    const int fq = lane >> 4, fr = lane & 15;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * WM + i * 16 + fq * 4 + r;
+            if (m >= M) continue;
+            float* row = d.dW + (long)m * N;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + fr;
+                if (n < N) row[n] = acc[i][j][r];
+            }
+        }
+}
+__global__ __launch_bounds__(512) void gemm_wgrad_grouped8_kernel(WgradGroup grp, int n_big) {
+    __shared__ __attribute__((aligned(16))) char smem[W8_LDS];
+    // blocks [0, n_big): big tiles in XCD-contiguous runs (n_big is a multiple of 256, hence of 8); the rest: 128 x 128 halves of the
+    // big tiles n_big, n_big + 1, ... in list order
+    const int l = blockIdx.x;
+    int tbig, half = -1;
+    if (l < n_big) tbig = (l & 7) * (n_big >> 3) + (l >> 3);
+    else { tbig = n_big + ((l - n_big) >> 1); half = (l - n_big) & 1; }
+    int p = 0;
+    while (p + 1 < grp.n && tbig >= grp.p[p + 1].tile_start) ++p;
+    const WgradDesc& d = grp.p[p];
+    const int t = tbig - d.tile_start, tiles_x = (d.K + 255) / 256;
+    const int bx = t % tiles_x, by = t / tiles_x;
+    if (half < 0) wgrad8_tile<256>(d, by * 128, bx * 256, d.db != nullptr && bx == 0, smem);
+    else if (bx * 256 + half * 128 < d.K) wgrad8_tile<128>(d, by * 128, bx * 256 + half * 128, d.db != nullptr && bx == 0 && half == 0, smem);
+}
+
 #undef HAS
 
 // ---- NT form with LDS-DMA staging (global_load_lds_dwordx4): tiles go HBM/L2 -> LDS without touching VGPRs, the next
@@ -571,7 +724,7 @@ int launch_tile(const GemmArgs& g_in, hipStream_t s) {
 
 int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s, int tile) {
     if (grp.n <= 0) return 0;
-    if (tile != 64 && tile != 128) { mk_set_error("mk_gemm_wgrad_grouped", "tile 64 or 128"); return -1; }
+    if (tile != 64 && tile != 128 && tile != 256) { mk_set_error("mk_gemm_wgrad_grouped", "tile 64, 128 or 256 (= 128 x 256 on eight waves)"); return -1; }
     int tiles = 0;
     for (int i = 0; i < grp.n; ++i) {
         WgradDesc& d = grp.p[i];
@@ -579,7 +732,15 @@ int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s, int tile) {
             mk_set_error("mk_gemm_wgrad_grouped", "operands must be 16-byte aligned with padded rows"); return -1;
         }
         d.tile_start = tiles;
-        tiles += ((d.N + tile - 1) / tile) * ((d.K + tile - 1) / tile);
+        tiles += tile == 256 ? ((d.N + 127) / 128) * ((d.K + 255) / 256) : ((d.N + tile - 1) / tile) * ((d.K + tile - 1) / tile);
+    }
+    if (tile == 256) {
+        // whole rounds of the 256 CUs as 128 x 256 tiles, the rest as their 128 x 128 halves (see gemm_wgrad_grouped8_kernel)
+        static const int ncu = [] { int dev = 0, n = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n / 8 * 8 : 256; }();
+        const int n_big = tiles / ncu * ncu;
+        hipLaunchKernelGGL(gemm_wgrad_grouped8_kernel, dim3(n_big + 2 * (tiles - n_big)), dim3(512), 0, s, grp, n_big);
+        if (hipGetLastError() != hipSuccess) { mk_set_error("mk_gemm_wgrad_grouped", "launch failed"); return -1; }
+        return 0;
     }
     // (Tried: the 128 x 128 form with LDS-DMA staging -- reduction-major tiles are lane-linear per DMA piece as they are, chunk c of row k
     // at c ^ (k & 15) for the transposing reads, zero line behind the last row, bias gradient as one more MFMA column against ones: 202 us

@@ -60,7 +60,12 @@ def test_gemm_reduction_major(L, M, N, K):
 
 
 @pytest.mark.parametrize("rows,N,K,tile", [(4000, 512, 512, 128), (1000, 1536, 512, 128), (777, 256, 2048, 128), (63, 128, 128, 128), (592, 512, 2048, 64),
-                                         (500, 200, 328, 128), (4000, 2560, 512, 128)])
+                                         (500, 200, 328, 128), (4000, 2560, 512, 128),
+                                         # tile 256 = 128 x 256 tiles on eight waves (the encoder-row launch since round 4): fewer tiles than CUs (all of
+                                         # them cut into 128 x 128 halves), ragged edges, and two members of 144 tiles each = one whole round of 256 big
+                                         # tiles + 32 big tiles as 64 halves
+                                         (4000, 512, 512, 256), (1000, 1536, 512, 256), (777, 256, 2048, 256), (63, 128, 128, 256), (500, 200, 328, 256),
+                                         (4000, 2560, 512, 256), (1000, 2048, 2304, 256), (300, 2048, 2100, 256)])
 def test_wgrad_grouped(L, rows, N, K, tile):
     """mk_gemm_wgrad_grouped (the Linear weight gradients of a backward pass as one grid, lin_wgrad / flush_enc_wgrads): dW = dY^T X and
     the fused bias gradient, two members per launch; reductions that are not multiples of the 64-row k tile (4000, 777, 63), output dims
@@ -77,6 +82,13 @@ def test_wgrad_grouped(L, rows, N, K, tile):
     assert torch.all(dW[N] == 7.0) and torch.equal(dW[:N], dW2)
     torch.testing.assert_close(db, dy[:, :N].float().sum(0), rtol=1e-4, atol=1e-3 * rows ** 0.5)
     assert torch.equal(db, db2)
+    if tile == 256:
+        # every element of dW is reduced by one workgroup over the rows in order whatever the tile: the eight-wave launch equals the
+        # four-wave one bit for bit (the bias gradient is folded over 512 instead of 256 threads: fp32 rounding only)
+        dW3 = torch.zeros(N, K, device="cuda"); db3 = torch.zeros(N, device="cuda")
+        _cabi.check(L.masr_test_wgrad_grouped(P(dy), lddy, P(x), ldx, P(dW3), P(db3), None, None, rows, N, K, 128, S()))
+        assert torch.equal(dW3, dW2)
+        torch.testing.assert_close(db3, db, rtol=1e-5, atol=1e-5 * rows ** 0.5)
 
 
 def test_gemm_exact_integers(L):
