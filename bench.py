@@ -370,11 +370,9 @@ def main():
 
     def time_single(task_list, Bs, flops_per_utt, seconds):
         """one task per GPU over a region of at least `seconds` (a first short region sizes it): value, ms per step, model FLOPs / peak"""
-        task_list[0].eng.set_concurrency(1)                      # (a model that has the GPU to itself: masr_set_concurrency)
         dtp = timed(task_list[:1], 8, args.warmup)
         n1 = max(8, int(seconds / (dtp / 8)) + 1)
         dt1 = timed(task_list[:1], n1, 2)
-        task_list[0].eng.set_concurrency(K)
         v = world * Bs * n1 / dt1
         return {"value": v, "unit": "utt/s", "ms_per_step": dt1 / n1 * 1e3, "steps": n1, "seconds": dt1,
                 "model_frac_of_bf16_peak": v * flops_per_utt / 1e12 / (PEAK_BF16_TFLOPS * world)}

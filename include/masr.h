@@ -55,10 +55,7 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
 int masr_refresh(masr_model* m, void* stream);
 void masr_set_seed(masr_model* m, uint64_t seed);      /* dropout stream */
 /* hint: this model is one of `slots` task slots running concurrently on the GPU (pretrain.py --tasks_per_gpu).  Results do NOT depend
- * on it, bit for bit (no launch partition that enters a summation order follows the slot count).  slots == 1 (the GPU to itself):
- * masr_refresh / masr_clip_sgd_step rebuild the Linear operand shadows on an internal side stream beside the next batch's conv
- * forward (which needs the conv shadows only); every reader or writer of the parameters on the caller's stream is ordered behind
- * it by the library.  Without the hint, or with slots > 1, everything stays on the caller's stream. */
+ * on it, bit for bit (no launch partition that enters a summation order follows the slot count; kept for launch-geometry hints). */
 void masr_set_concurrency(masr_model* m, int slots);
 /* the dropout stream's position: state[0] = seed, state[1] = batches run since masr_set_seed (every run_batch derives its masks
  * from both); set != 0 writes it.  For checkpoints: a resumed run continues the mask stream where the saved one stopped. */

@@ -105,11 +105,6 @@ struct masr_model {
     int* h_stage = nullptr; int64_t stage_ints = 0; int stage_slot = 0; hipEvent_t stage_ev[4];
     uint64_t seed = 0x1234; uint64_t step = 0;
     int wg_split = WG_SPLIT_ENV ? WG_SPLIT_ENV : 4;       // split-K of the encoder-row weight gradients (masr_set_concurrency)
-    // a model that has the GPU to itself (masr_set_concurrency(1)) refreshes its Linear operand shadows on a side stream, beside the
-    // conv forward of the next batch (which needs the conv shadows only): see masr_refresh
-    int slots = 0;                                          // 0 = no hint: everything on the caller's stream
-    std::vector<ShadowJobs> shadows_conv;                   // the jobs the conv forward needs (SH_CONV); `shadows` holds the rest
-    hipStream_t side = nullptr; hipEvent_t sh_fork = nullptr, sh_done = nullptr; bool sh_pending = false;
     Acts acts; bool have_acts = false;
     LnReduceGroup lng; int64_t ln_slab_used = 0;           // LayerNorm dgamma/dbeta partials, folded by one grouped launch
     WgradGroup wg; bool wg_defer = false;                  // decoder-row weight gradients collected for one grouped launch
@@ -518,7 +513,6 @@ void masr_destroy(masr_model* m) {
     if (m->dec_graph) hipGraphDestroy(m->dec_graph);
     for (auto& sg : m->step_graphs) { hipGraphExecDestroy(sg.e); hipGraphDestroy(sg.g); }
     for (auto& e : m->stage_ev) if (e) hipEventDestroy(e);
-    if (m->side) { hipStreamSynchronize(m->side); hipStreamDestroy(m->side); hipEventDestroy(m->sh_fork); hipEventDestroy(m->sh_done); }
     for (auto& v : m->prof_ev) for (auto& p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     delete m;
 }
@@ -558,11 +552,10 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
         std::vector<long> ranges = split_chunks(m);
         // the list travels BY VALUE in the kernel arguments (kernels.h), which caps one launch at SHADOW_JOBS_MAX jobs: deeper
         // models (8e4d = 69 jobs) simply take a second launch
-        m->shadows.clear(); m->shadows_conv.clear();
+        m->shadows.clear();
         auto job = [&](int type, long src, int N, int K, int ldt, int a0, int a1, void* p0, void* p1) {
-            std::vector<ShadowJobs>& list = type == SH_CONV ? m->shadows_conv : m->shadows;
-            if (list.empty() || list.back().n == SHADOW_JOBS_MAX) { list.emplace_back(); list.back().n = 0; list.back().blocks = 0; }
-            ShadowJobs& J = list.back();
+            if (m->shadows.empty() || m->shadows.back().n == SHADOW_JOBS_MAX) { m->shadows.emplace_back(); m->shadows.back().n = 0; m->shadows.back().blocks = 0; }
+            ShadowJobs& J = m->shadows.back();
             ShadowDesc d{}; d.src = src; d.type = type; d.N = N; d.K = K; d.ldt = ldt; d.a0 = a0; d.a1 = a1; d.tile_start = J.blocks;
             J.blocks += mk_shadow_blocks(d);
             J.d[J.n] = d; J.p[2 * J.n] = (bf16*)p0; J.p[2 * J.n + 1] = (bf16*)p1; ++J.n;
@@ -595,56 +588,18 @@ void masr_set_seed(masr_model* m, uint64_t seed) { m->seed = seed; m->step = 0; 
 // The split factor is part of the weight gradients' fp32 summation order, i.e. of the result's BITS, and "K task slots == the sequential
 // run, bit for bit" is a guarantee of --tasks_per_gpu: so it no longer follows the slot count (it did: 2 for a shared chip, 4 alone --
 // only visible with MASR_NO_GROUPED_ENC_WGRAD=1, the grouped launch being unsplit).  MASR_WG_SPLIT still sets it for A/B runs.
-void masr_set_concurrency(masr_model* m, int slots) { m->slots = slots; }
+void masr_set_concurrency(masr_model* m, int slots) { (void)m; (void)slots; }
 void masr_dropout_state(masr_model* m, uint64_t state[2], int set) {
     if (set) { m->seed = state[0]; m->step = state[1]; } else { state[0] = m->seed; state[1] = m->step; }
 }
 
-static int join_shadows(masr_model* m, hipStream_t s);
-static int join_shadows_fwd(masr_model* m, hipStream_t s) { return join_shadows(m, s); }
 int masr_refresh(masr_model* m, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!m->P) { mk_set_error("masr_refresh", "not bound"); return -1; }
+    Prof p(m, MASR_PROF_SHADOWS, s);
     // every bf16 operand shadow (conv forward/dgrad layouts, permuted vgg2enc, all Linear weights and their transposes, the
-    // gathered cross-attention K/V operand); the pads of the char_trans shadows are zeroed once in masr_bind.  Two launches: the conv
-    // layouts (0.3 M weights) and everything else (24.6 M).  The first consumer of the second group is the vgg2enc GEMM BEHIND the four
-    // conv forwards (~0.3 ms of MFMA-bound kernels), and this pass is HBM-bound: a model that has the GPU to itself (slots == 1) runs it
-    // on a side stream beside them -- forward_encoder waits for sh_done before that GEMM.  With several task slots everything stays
-    // on the caller's stream (never more than four streams with work queued: DESIGN 6.2), and so it does under stream capture
-    // (a captured step must not leave work pending on another stream) and while profiling (the slot times one launch).
-    static const bool no_side = getenv("MASR_NO_SIDE_SHADOWS") != nullptr;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (s) hipStreamIsCapturing(s, &cap);
-    const bool side = m->slots == 1 && !no_side && !m->prof && s != nullptr && cap == hipStreamCaptureStatusNone;
-    CK(join_shadows_fwd(m, s));                           // a previous refresh still in flight on the side stream: keep the order
-    {
-        Prof p(m, MASR_PROF_SHADOWS, s);
-        for (const ShadowJobs& J : m->shadows_conv) CK(mk_all_shadows(m->P, J, s));
-        if (!side) for (const ShadowJobs& J : m->shadows) CK(mk_all_shadows(m->P, J, s));
-    }
-    if (side) {
-        if (!m->side) {
-            HIP_CHECK_RET(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
-            HIP_CHECK_RET(hipEventCreateWithFlags(&m->sh_fork, hipEventDisableTiming));
-            HIP_CHECK_RET(hipEventCreateWithFlags(&m->sh_done, hipEventDisableTiming));
-        }
-        HIP_CHECK_RET(hipEventRecord(m->sh_fork, s));                  // the parameter update queued before this call
-        HIP_CHECK_RET(hipStreamWaitEvent(m->side, m->sh_fork, 0));
-        for (const ShadowJobs& J : m->shadows) CK(mk_all_shadows(m->P, J, m->side));
-        HIP_CHECK_RET(hipEventRecord(m->sh_done, m->side));
-        m->sh_pending = true;
-    }
-    return 0;
-}
-// everything that reads a Linear shadow or WRITES the parameters on stream `s` comes behind the side-stream refresh
-static int join_shadows(masr_model* m, hipStream_t s) {
-    if (!m->sh_pending) return 0;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (s) hipStreamIsCapturing(s, &cap);
-    // (a capturing stream cannot wait for an event recorded outside the capture: the host waits instead, once)
-    if (cap != hipStreamCaptureStatusNone) HIP_CHECK_RET(hipEventSynchronize(m->sh_done));
-    else HIP_CHECK_RET(hipStreamWaitEvent(s, m->sh_done, 0));
-    m->sh_pending = false;
+    // gathered cross-attention K/V operand) in ONE launch; the pads of the char_trans shadows are zeroed once in masr_bind
+    for (const ShadowJobs& J : m->shadows) CK(mk_all_shadows(m->P, J, s));
     return 0;
 }
 
@@ -673,7 +628,6 @@ static int forward_encoder(Ctx& c, const float* xs) {
     CK(conv(a.a3, m->conv[3], a.a4, a.H2, a.W2, a.p2, a.i2));
     if (!fuse_pool) { Prof p(m, MASR_PROF_POOL, s); CK(mk_maxpool_fwd(a.a4, a.p2, B, a.H2, a.W2, 128, s)); if (c.train) CK(mk_maxpool_idx(a.a4, a.i2, B, a.H2, a.W2, 128, s)); }
     // vgg2enc + positional encoding + pos dropout
-    CK(join_shadows(m, s));                                // the Linear shadows may have been refreshed beside the convs above (masr_refresh)
     {
         GemmArgs g = lin_fwd_args(a.p2, m->F, m->v2e_k, a.rows_e, E, m->F, P + m->v2e.b);
         g.pe = m->pe; g.pe_period = a.Tp; g.drop_p = c.p_pos; g.seed = c.seed; g.site = a.site_v2e = site++;
@@ -1032,7 +986,6 @@ int masr_grad_norm(masr_model* m, void* stream) {
     return mk_sumsq(m->G, m->nparams, slab, m->stats + 3, (hipStream_t)stream);
 }
 int masr_clip_sgd_step(masr_model* m, float* mom, float max_norm, float lr, float momentum, int nesterov, int first_step, void* stream) {
-    CK(join_shadows(m, (hipStream_t)stream));
     CK(masr_grad_norm(m, stream));
     { Prof p(m, MASR_PROF_OPTIM, (hipStream_t)stream);
       CK(mk_clip_sgd(m->P, m->G, mom, m->nparams, m->stats + 3, max_norm, lr, momentum, nesterov, first_step, (hipStream_t)stream)); }

@@ -23,7 +23,6 @@ def get_trainer(cls, config, paras, id2accent):
             self.asr_model = MyTransformer(self.id2ch, mp, self.label_smooth_rate, device=device).cuda()
             eng = self.asr_model.engine
             eng.set_seed(getattr(self.paras, 'seed', 531) + 7919 * 64 * self.sharder.rank)      # dropout stream: one per rank
-            eng.set_concurrency(1)               # one model on the GPU (the meta loop's task slots override this in _make_slots)
             if 'inner_optimizer_cls' not in mp:                              # multi-task or mono (:27)
                 cls_name = mp['optimizer_cls']
                 if cls_name == 'noam':
