@@ -73,6 +73,11 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
  * the host's enqueue time 6x and leaves the step time unchanged -- the step is GPU-bound -- hence off by default.
  * counters: out[0] = steps launched kernel by kernel, out[1] = graphs captured, out[2] = steps replayed from a graph. */
 void masr_set_step_graphs(masr_model* m, int on);
+/* LayerNorms on few rows (the decoder's B x L: <= 1024 rows, d_model in {64, 128, 256, 512}) are not launched on their own: the GEMM
+ * that consumes their bf16 output (forward: the next projection; backward: the next dgrad) normalises the rows in its prologue.  Same
+ * arithmetic, hence the same results (the LayerNorm weight gradients are folded over 64-row instead of 4-row partials: fp32 rounding).
+ * Default on (MASR_NO_LN_FUSION=1 in the environment: off); this switch exists for A/B runs and tests. */
+void masr_set_ln_fusion(masr_model* m, int on);
 void masr_step_counters(const masr_model* m, int64_t out[3]);
 /* out[0]=loss, out[1]=n_correct, out[2]=n_total, out[3]=last grad norm.  Synchronises the stream. */
 int masr_read_stats(masr_model* m, float out[4], void* stream);

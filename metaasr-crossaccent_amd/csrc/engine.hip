@@ -111,6 +111,12 @@ struct masr_model {
     // ... and the encoder-row ones (reduction over B*T' rows): ONE grid of 128 x 128 tiles over all of them at the end of the backward
     // pass instead of ten split-K launches of 64-192 workgroups each + a combine pass over the partial slabs
     WgradGroup wge; bool wge_defer = false;
+    // a LayerNorm (forward) / LayerNorm backward on few rows that has been ASKED for but not launched: the next GEMM that takes its bf16
+    // output as the A operand computes it in its own prologue (kernels.h mk_gemm_lnfwd / mk_gemm_lnbwd); anything else flushes it first
+    bool ln_fusion = getenv("MASR_NO_LN_FUSION") == nullptr;       // masr_set_ln_fusion
+    struct PendF { bool on = false; Norm n; const float* x; float* y32; bf16* y16; float* mean; float* rstd; int rows; } pend_f;
+    struct PendB { bool on = false; Norm n; const float* dy; const float* x; const float* mean; const float* rstd; float* dx32; bf16* dx16;
+                   uint32_t site; int rows; float* slab; int desc; } pend_b;
     // captured training / evaluation steps (masr_run_batch, opt-in): a batch shape that repeats is replayed as ONE graph launch
     // instead of ~150 kernel launches.  Measured: host enqueue 0.61 -> 0.11 ms per step, step time unchanged (the GPU, not the
     // launch path, bounds both the single-task and the 4-task mode: tools/host_launch_cost.py) -- hence off by default
@@ -300,11 +306,36 @@ GemmArgs lin_fwd_args(const bf16* x, long ldx, const bf16* wk, int M, int N, int
 
 // seed_ptr / inv_ptr: non-null while a step is being captured into a graph -- the dropout seed and 1/n_total of the step
 // then live in device memory (Acts::meta, uploaded with the tokens), so one captured launch sequence serves every step
-struct Ctx { masr_model* m; hipStream_t s; uint32_t seed; bool train; float p_drop, p_pos; const uint32_t* seed_ptr = nullptr; const float* inv_ptr = nullptr; };
+struct Ctx { masr_model* m; hipStream_t s; uint32_t seed; bool train; float p_drop, p_pos; const uint32_t* seed_ptr = nullptr; const float* inv_ptr = nullptr;
+             bool fuse_ln = false; };      // masr_run_batch only: LayerNorms on few rows ride in the prologue of their consumer GEMM
+int flush_ln_pending(Ctx& c);
 
 int gemm(Ctx& c, const GemmArgs& g) {
     const int re = c.m->acts.rows_e;
     const int cat = g.reduction_major ? (g.K == re ? MASR_PROF_WGRAD_ENC : MASR_PROF_WGRAD_DEC) : (g.M == re ? MASR_PROF_GEMM_ENC : MASR_PROF_GEMM_DEC);
+    masr_model* m = c.m;
+    if (m->pend_f.on || m->pend_b.on) {
+        const bool shape = !g.reduction_major && g.K == m->E && g.lda == m->E;
+        if (m->pend_f.on && shape && g.A == m->pend_f.y16 && g.M == m->pend_f.rows) {
+            const masr_model::PendF& q = m->pend_f;
+            LnFwdA ln{q.x, m->P + q.n.w, m->P + q.n.b, q.y32, q.y16, q.mean, q.rstd};
+            GemmArgs h = g; h.seed_ptr = c.seed_ptr;
+            int rc;
+            { Prof p(m, cat, c.s); rc = mk_gemm_lnfwd(h, ln, c.s); }
+            if (rc <= 0) { m->pend_f.on = false; return rc; }
+        } else if (m->pend_b.on && shape && g.A == m->pend_b.dx16 && g.M == m->pend_b.rows) {
+            const masr_model::PendB& q = m->pend_b;
+            LnBwdA ln{q.dy, q.x, m->P + q.n.w, q.mean, q.rstd, q.dx32, q.dx16, c.p_drop, c.seed, q.site, c.seed_ptr, q.slab};
+            GemmArgs h = g; h.seed_ptr = c.seed_ptr;
+            int rc;
+            { Prof p(m, cat, c.s); rc = mk_gemm_lnbwd(h, ln, c.s); }
+            if (rc <= 0) {
+                if (rc == 0 && q.desc >= 0) m->lng.p[q.desc].nblocks = mk_gemm_ln_blocks(q.rows);     // one partial per 64-row block
+                m->pend_b.on = false; return rc;
+            }
+        }
+        CK(flush_ln_pending(c));                               // not the consumer we hoped for (or a shape the fused form does not cover)
+    }
     Prof p(c.m, cat, c.s);
     if (!c.seed_ptr) return mk_gemm(g, c.s);
     GemmArgs h = g; h.seed_ptr = c.seed_ptr;
@@ -396,16 +427,35 @@ int ffn_fwd(Ctx& c, const Lin& l1, const Lin& l2, const bf16* x16, const float* 
     CK(gemm(c, h));
     return 0;
 }
+static bool ln_fusable(const Ctx& c, int rows) {
+    const int E = c.m->E;
+    return c.fuse_ln && rows <= 1024 && (E == 64 || E == 128 || E == 256 || E == 512);
+}
 int ln_fwd(Ctx& c, const Norm& n, const float* x, float* y32, bf16* y16, float* mean, float* rstd, int rows) {
+    masr_model* m = c.m;
+    CK(flush_ln_pending(c));                                   // (a LayerNorm of a LayerNorm output: the inner one runs now)
+    if (y16 && mean && rstd && ln_fusable(c, rows)) { m->pend_f = {true, n, x, y32, y16, mean, rstd, rows}; return 0; }
     Prof p(c.m, MASR_PROF_LAYERNORM, c.s);
     return mk_layernorm_fwd(x, c.m->P + n.w, c.m->P + n.b, y32, y16, mean, rstd, rows, c.m->E, c.s);
 }
 int ln_bwd(Ctx& c, const Norm& n, const float* dy, const float* x, const float* mean, const float* rstd, float* dx32, bf16* dx16,
            uint32_t site, int rows) {
-    Prof p(c.m, MASR_PROF_LAYERNORM, c.s);
     masr_model* m = c.m;
+    CK(flush_ln_pending(c));
     // the dgamma/dbeta partials of every LayerNorm go to their own slab region; flush_ln_reduce folds them all at once
     const int64_t need = (int64_t)mk_layernorm_bwd_blocks(rows) * 2 * m->E;
+    if (dx16 && ln_fusable(c, rows) && m->lng.n < LN_GROUP_MAX && m->ln_slab_used + need <= m->acts.ln_slab_floats) {
+        // deferred: the dgrad GEMM that takes dx16 as its A operand computes this backward in its prologue (gemm() above); the slab
+        // region is sized for the standalone kernel (4 rows per partial), the fused form uses the first rows / 64 blocks of it
+        float* slab = m->acts.ln_slab + m->ln_slab_used;
+        m->ln_slab_used += need;
+        const int di = m->lng.n++;
+        LnReduceDesc& d = m->lng.p[di];
+        d.slab = slab; d.dgamma = m->G + n.w; d.dbeta = m->G + n.b; d.nblocks = (int)(need / (2 * m->E));
+        m->pend_b = {true, n, dy, x, mean, rstd, dx32, dx16, site, rows, slab, di};
+        return 0;
+    }
+    Prof p(c.m, MASR_PROF_LAYERNORM, c.s);
     if (m->lng.n < LN_GROUP_MAX && m->ln_slab_used + need <= m->acts.ln_slab_floats) {
         float* slab = m->acts.ln_slab + m->ln_slab_used;
         m->ln_slab_used += need;
@@ -417,8 +467,25 @@ int ln_bwd(Ctx& c, const Norm& n, const float* dy, const float* x, const float* 
     return mk_layernorm_bwd(dy, x, m->P + n.w, mean, rstd, dx32, dx16, dx16 ? c.p_drop : 0.f, c.seed, site, m->G + n.w, m->G + n.b,
                             m->acts.slab, rows, m->E, c.s, c.seed_ptr);
 }
+// launch whatever LayerNorm is still pending as the standalone kernel (its consumer turned out not to be a GEMM on its bf16 output)
+int flush_ln_pending(Ctx& c) {
+    masr_model* m = c.m;
+    if (m->pend_f.on) {
+        const masr_model::PendF q = m->pend_f; m->pend_f.on = false;
+        Prof p(m, MASR_PROF_LAYERNORM, c.s);
+        CK(mk_layernorm_fwd(q.x, m->P + q.n.w, m->P + q.n.b, q.y32, q.y16, q.mean, q.rstd, q.rows, m->E, c.s));
+    }
+    if (m->pend_b.on) {
+        const masr_model::PendB q = m->pend_b; m->pend_b.on = false;
+        Prof p(m, MASR_PROF_LAYERNORM, c.s);
+        CK(mk_layernorm_bwd(q.dy, q.x, m->P + q.n.w, q.mean, q.rstd, q.dx32, q.dx16, c.p_drop, c.seed, q.site, nullptr, nullptr, q.slab, q.rows,
+                            m->E, c.s, c.seed_ptr));
+    }
+    return 0;
+}
 int flush_ln_reduce(Ctx& c) {
     masr_model* m = c.m;
+    CK(flush_ln_pending(c));
     Prof p(m, MASR_PROF_LAYERNORM, c.s);
     const int rc = mk_layernorm_bwd_reduce_grouped(m->lng, m->E, c.s);
     m->lng.n = 0; m->ln_slab_used = 0;
@@ -882,6 +949,8 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
     }
     Ctx c{m, s, (uint32_t)(m->seed * 0x9E3779B97F4A7C15ull >> 32) + (uint32_t)m->step * 7919u, train,
           train ? m->cfg.dropout : 0.f, train ? m->cfg.pos_dropout : 0.f};
+    c.fuse_ln = m->ln_fusion;
+    m->pend_f.on = m->pend_b.on = false;
     m->step++;
     const float inv_ntot = 1.0f / (float)ntot;
     std::memcpy(h_len + B, &c.seed, 4); std::memcpy(h_len + B + 1, &inv_ntot, 4);     // Acts::meta
@@ -890,7 +959,9 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
 
     auto run = [&](Ctx& cc) -> int {
         CK(forward_encoder(cc, xs));
+        CK(flush_ln_pending(cc));                              // (encoder memory: read by more than the K|V projection)
         CK(forward_decoder(cc));
+        CK(flush_ln_pending(cc));
         { Prof p(m, MASR_PROF_MISC, s);
           CK(mk_ls_ce(a.logits, m->Cp, a.gold, a.rows_d, m->C, m->cfg.label_smoothing, inv_ntot, a.dlogits, a.row_loss, a.row_correct,
                       m->stats, s, cc.inv_ptr)); }
@@ -934,6 +1005,7 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
 }
 
 void masr_set_step_graphs(masr_model* m, int on) { m->step_graphs_on = on != 0; }
+void masr_set_ln_fusion(masr_model* m, int on) { m->ln_fusion = on != 0; }
 void masr_step_counters(const masr_model* m, int64_t out[3]) { out[0] = m->n_direct; out[1] = m->n_captured; out[2] = m->n_replayed; }
 
 int masr_read_stats(masr_model* m, float out[4], void* stream) {

@@ -32,6 +32,18 @@ struct GemmArgs {
     int cseg_rows; long cseg_stride;
 };
 int mk_gemm(const GemmArgs& g, hipStream_t s);
+// NT GEMMs whose A operand is a LayerNorm OUTPUT (forward) or a LayerNorm input-GRADIENT (backward) that the GEMM computes itself
+// from the fp32 rows, K == the LayerNorm width E: the few-hundred-row decoder LayerNorms are 5 us launches for 1 us of work, and every
+// consumer GEMM workgroup holds complete rows of its A tile anyway (gemm.hip gemm_lnfwd_kernel / gemm_lnbwd_kernel).  g.A is ignored.
+// The workgroups of the first column tile also write what the standalone LayerNorm kernels write (y32 / y16 / mean / rstd; dx32 /
+// dx16 / one dgamma|dbeta partial per 64-row block in `slab`).  Return 1 when the shape is not covered (the caller launches the
+// LayerNorm and the plain GEMM instead), 0 when launched, -1 on error.
+struct LnFwdA { const float* x; const float* gamma; const float* beta; float* y32; bf16* y16; float* mean; float* rstd; };
+struct LnBwdA { const float* dy; const float* x; const float* gamma; const float* mean; const float* rstd; float* dx32; bf16* dx16;
+                float drop_p; uint32_t seed, site; const uint32_t* seed_ptr; float* slab; };
+int mk_gemm_lnfwd(const GemmArgs& g, const LnFwdA& ln, hipStream_t s);
+int mk_gemm_lnbwd(const GemmArgs& g, const LnBwdA& ln, hipStream_t s);
+inline int mk_gemm_ln_blocks(int rows) { return (rows + 63) / 64; }      // dgamma|dbeta partial blocks mk_gemm_lnbwd writes
 // Linear weight gradients as one grouped launch: dW[N][K] = dy[rows][N]^T x[rows][K], db[N] = column sums of dy (or null)
 struct WgradDesc { const bf16* dy; const bf16* x; float* dW; float* db; int lddy, ldx, rows, N, K, tile_start; };
 constexpr int WGRAD_GROUP_MAX = 40;

@@ -243,6 +243,10 @@ class MasrEngine:
         """opt-in graph replay of repeated batch shapes (include/masr.h masr_set_step_graphs)"""
         self._l.masr_set_step_graphs(self.h, int(bool(on)))
 
+    def set_ln_fusion(self, on: bool):
+        """decoder-row LayerNorms inside their consumer GEMMs (include/masr.h masr_set_ln_fusion); default on"""
+        self._l.masr_set_ln_fusion(self.h, int(bool(on)))
+
     def step_counters(self):
         """{'direct', 'captured', 'replayed'}: how run_batch calls reached the GPU (kernel by kernel / graph capture / graph replay)"""
         out = (C.c_int64 * 3)()

@@ -386,3 +386,41 @@ def test_eight_encoder_layers_build_and_step():
     eng.run_batch(xs, il, ys, ol, train=True)
     st2 = eng.read_stats()
     assert math.isfinite(st2["loss"]) and st2["loss"] < st["loss"]
+
+
+@pytest.mark.parametrize("cfg_name", ["tiny", "hkust"])
+def test_layernorm_in_the_gemm_prologue_gives_the_same_step(cfg_name):
+    """Round 4: the decoder-row LayerNorms (and, on the tiny model, the encoder's: few rows there too) are computed in the prologue of
+    the GEMM that consumes them -- forward: the next projection, backward: the next dgrad (csrc/gemm.hip gemm_lnfwd_kernel /
+    gemm_lnbwd_kernel).  Same arithmetic in the same order: loss, logits and EVERY gradient of a training step equal the step with
+    standalone LayerNorm launches bit for bit, except the LayerNorm weight / bias gradients themselves, which are folded over 64-row
+    instead of 4-row partial sums (fp32 rounding).  With dropout on (the masks are functions of (seed, site, index): identical)."""
+    cfg = dict(TINY if cfg_name == "tiny" else HKUST)
+    cfg["dropout"] = cfg["pos_dropout"] = 0.1
+    sd = ref_cpu.deterministic_state_dict(cfg, ODIM, seed=5)
+    ilens, olens = ([64, 52, 40, 33], [9, 7, 5, 3]) if cfg_name == "tiny" else ([203, 160, 121, 96, 90], [12, 9, 7, 30, 2])
+    xs, il, ys, ol = synth_batch(21, ilens, olens)
+    outs = []
+    for fused in (True, False):
+        eng = MasrEngine(cfg, ODIM, label_smoothing=0.2)
+        eng.load_state_dict(sd)
+        eng.set_seed(99)
+        eng.set_ln_fusion(fused)
+        for _ in range(2):                                            # two steps: the second one starts from updated weights
+            eng.run_batch(xs, il, ys, ol.clone(), train=True)
+            logits = eng.last_logits()[0].clone()
+            st = dict(eng.read_stats())
+            grads = eng.grads.clone()
+            eng.clip_sgd_step(torch.zeros_like(eng.params), 5.0, 0.05, 0.9, True, True)
+        outs.append((st, logits, grads, eng.params.clone(), eng))
+    (sa, la, ga, pa, eng), (sb, lb, gb, pb, _) = outs
+    assert sa["loss"] == sb["loss"] and sa["n_correct"] == sb["n_correct"] and torch.equal(la, lb)
+    ln_names = [n for n in eng.table if ".norm" in n]
+    assert len(ln_names) >= 2 * (2 * cfg["encoder"]["nlayers"] + 3 * cfg["decoder"]["nlayers"] + 2)
+    for n, (off, shape) in eng.table.items():
+        k = int(np.prod(shape))
+        a, b = ga[off:off + k], gb[off:off + k]
+        if n in ln_names:
+            torch.testing.assert_close(a, b, rtol=2e-5, atol=1e-6 * float(b.abs().max() + 1e-30))
+        else:
+            assert torch.equal(a, b), f"{n}: gradient differs between the fused and the standalone LayerNorm path"
