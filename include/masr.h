@@ -76,7 +76,8 @@ void masr_set_step_graphs(masr_model* m, int on);
 /* LayerNorms on few rows (the decoder's B x L: <= 1024 rows, d_model in {64, 128, 256, 512}) are not launched on their own: the GEMM
  * that consumes their bf16 output (forward: the next projection; backward: the next dgrad) normalises the rows in its prologue.  Same
  * arithmetic, hence the same results (the LayerNorm weight gradients are folded over 64-row instead of 4-row partials: fp32 rounding).
- * Default on (MASR_NO_LN_FUSION=1 in the environment: off); this switch exists for A/B runs and tests. */
+ * Default OFF -- it measured slower (every column-tile workgroup of a row block repeats the row work and they all hit the same L2
+ * lines at once: DESIGN 6.0); MASR_LN_FUSION=1 in the environment or this switch turn it on for A/B runs and the parity test. */
 void masr_set_ln_fusion(masr_model* m, int on);
 void masr_step_counters(const masr_model* m, int64_t out[3]);
 /* out[0]=loss, out[1]=n_correct, out[2]=n_total, out[3]=last grad norm.  Synchronises the stream. */

@@ -113,7 +113,11 @@ struct masr_model {
     WgradGroup wge; bool wge_defer = false;
     // a LayerNorm (forward) / LayerNorm backward on few rows that has been ASKED for but not launched: the next GEMM that takes its bf16
     // output as the A operand computes it in its own prologue (kernels.h mk_gemm_lnfwd / mk_gemm_lnbwd); anything else flushes it first
-    bool ln_fusion = getenv("MASR_NO_LN_FUSION") == nullptr;       // masr_set_ln_fusion
+    // OFF by default: measured SLOWER (round 4, rocprofv3, hkust decoder rows): the fused q-projection 17.9 us against 6.6 (GEMM) + 5.2
+    // (LayerNorm), the fused FFN-1 34.5 us against 8 + 5 -- every one of the 8 .. 32 column-tile workgroups of a row block re-reads the
+    // same 128 KB of fp32 rows at the same moment (the same L2 channels) and only then starts its k loop; single task 6 160 -> 5 420
+    // utt/s, four slots 9 160 -> 8 510.  Kept as an A/B switch with its parity test (MASR_LN_FUSION=1 / masr_set_ln_fusion).
+    bool ln_fusion = getenv("MASR_LN_FUSION") != nullptr && atoi(getenv("MASR_LN_FUSION")) != 0;
     struct PendF { bool on = false; Norm n; const float* x; float* y32; bf16* y16; float* mean; float* rstd; int rows; } pend_f;
     struct PendB { bool on = false; Norm n; const float* dy; const float* x; const float* mean; const float* rstd; float* dx32; bf16* dx16;
                    uint32_t site; int rows; float* slab; int desc; } pend_b;

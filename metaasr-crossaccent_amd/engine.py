@@ -244,7 +244,7 @@ class MasrEngine:
         self._l.masr_set_step_graphs(self.h, int(bool(on)))
 
     def set_ln_fusion(self, on: bool):
-        """decoder-row LayerNorms inside their consumer GEMMs (include/masr.h masr_set_ln_fusion); default on"""
+        """decoder-row LayerNorms inside their consumer GEMMs (include/masr.h masr_set_ln_fusion); default off (measured slower)"""
         self._l.masr_set_ln_fusion(self.h, int(bool(on)))
 
     def step_counters(self):

@@ -390,7 +390,8 @@ def test_eight_encoder_layers_build_and_step():
 
 @pytest.mark.parametrize("cfg_name", ["tiny", "hkust"])
 def test_layernorm_in_the_gemm_prologue_gives_the_same_step(cfg_name):
-    """Round 4: the decoder-row LayerNorms (and, on the tiny model, the encoder's: few rows there too) are computed in the prologue of
+    """Round 4 (an A/B path, off by default: it measured slower): the decoder-row LayerNorms (and, on the tiny model, the encoder's:
+    few rows there too) CAN be computed in the prologue of
     the GEMM that consumes them -- forward: the next projection, backward: the next dgrad (csrc/gemm.hip gemm_lnfwd_kernel /
     gemm_lnbwd_kernel).  Same arithmetic in the same order: loss, logits and EVERY gradient of a training step equal the step with
     standalone LayerNorm launches bit for bit, except the LayerNorm weight / bias gradients themselves, which are folded over 64-row
