@@ -79,11 +79,6 @@ void masr_set_step_graphs(masr_model* m, int on);
  * Default OFF -- it measured slower (every column-tile workgroup of a row block repeats the row work and they all hit the same L2
  * lines at once: DESIGN 6.0); MASR_LN_FUSION=1 in the environment or this switch turn it on for A/B runs and the parity test. */
 void masr_set_ln_fusion(masr_model* m, int on);
-/* The GEMMs on the decoder's few hundred rows (M = B x L <= 1024) are one 64 x 64 tile per workgroup and as slow as ONE tile's chain
- * of K / 64 dependent k steps; by default 2 (K < 1024) or 4 groups of four waves split that chain and fold their partial sums in a
- * fixed order (csrc/gemm.hip gemm_glds_ks_kernel).  Deterministic; the fp32 summation order over k differs from the unsplit kernels',
- * which this switch (or MASR_GEMM_KSPLIT=0 in the environment) brings back. */
-void masr_set_gemm_ksplit(masr_model* m, int on);
 void masr_step_counters(const masr_model* m, int64_t out[3]);
 /* out[0]=loss, out[1]=n_correct, out[2]=n_total, out[3]=last grad norm.  Synchronises the stream. */
 int masr_read_stats(masr_model* m, float out[4], void* stream);

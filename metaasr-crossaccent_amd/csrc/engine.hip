@@ -118,7 +118,6 @@ struct masr_model {
     // same 128 KB of fp32 rows at the same moment (the same L2 channels) and only then starts its k loop; single task 6 160 -> 5 420
     // utt/s, four slots 9 160 -> 8 510.  Kept as an A/B switch with its parity test (MASR_LN_FUSION=1 / masr_set_ln_fusion).
     bool ln_fusion = getenv("MASR_LN_FUSION") != nullptr && atoi(getenv("MASR_LN_FUSION")) != 0;
-    bool gemm_ksplit = true;                                       // masr_set_gemm_ksplit: few-row GEMMs split their k tiles over wave groups
     struct PendF { bool on = false; Norm n; const float* x; float* y32; bf16* y16; float* mean; float* rstd; int rows; } pend_f;
     struct PendB { bool on = false; Norm n; const float* dy; const float* x; const float* mean; const float* rstd; float* dx32; bf16* dx16;
                    uint32_t site; int rows; float* slab; int desc; } pend_b;
@@ -342,8 +341,8 @@ int gemm(Ctx& c, const GemmArgs& g) {
         CK(flush_ln_pending(c));                               // not the consumer we hoped for (or a shape the fused form does not cover)
     }
     Prof p(c.m, cat, c.s);
-    if (!c.seed_ptr && m->gemm_ksplit) return mk_gemm(g, c.s);
-    GemmArgs h = g; h.seed_ptr = c.seed_ptr; h.no_ksplit = !m->gemm_ksplit;
+    if (!c.seed_ptr) return mk_gemm(g, c.s);
+    GemmArgs h = g; h.seed_ptr = c.seed_ptr;
     return mk_gemm(h, c.s);
 }
 
@@ -1011,7 +1010,6 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
 
 void masr_set_step_graphs(masr_model* m, int on) { m->step_graphs_on = on != 0; }
 void masr_set_ln_fusion(masr_model* m, int on) { m->ln_fusion = on != 0; }
-void masr_set_gemm_ksplit(masr_model* m, int on) { m->gemm_ksplit = on != 0; }
 void masr_step_counters(const masr_model* m, int64_t out[3]) { out[0] = m->n_direct; out[1] = m->n_captured; out[2] = m->n_replayed; }
 
 int masr_read_stats(masr_model* m, float out[4], void* stream) {

@@ -125,22 +125,18 @@ enum { E_BIAS = 1, E_PE = 2, E_RELU = 4, E_MASK = 8, E_DROP = 16, E_RES = 32, E_
 #define HAS(flag, runtime) (EPI >= 0 ? bool(EPI & (flag)) : bool(runtime))
 
 // ---- shared epilogue (see the comment inside): consumes the accumulators of one BM x BN tile
-// `tid` / `active`: workgroups of more than 256 threads (gemm_glds_ks_kernel) hand the tile to their first 256 threads; the others only
-// take part in the barrier
 template <int BM, int BN, int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM / 32][BN / 32], char* smem, int m0, int n0, long out_delta,
-                                              const int tid = threadIdx.x, const bool active = true) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM / 32][BN / 32], char* smem, int m0, int n0, long out_delta) {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int FM = WM / 16, FN = WN / 16;
     constexpr int LDC = BN + 4;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     // epilogue: alpha -> bias -> pe -> relu -> mask -> dropout -> residual -> (accumulate) -> store.
     // The accumulators go through an fp32 LDS tile so that every global access of the epilogue is a 16-byte (fp32) or
     // 8-byte (bf16) row segment, and each optional input is fetched with ONE batched load per 4 outputs (per-element
     // branches around loads serialise on s_waitcnt vmcnt(0) and used to dominate the small decoder GEMMs).
     float* ct = reinterpret_cast<float*>(smem);
-    if (active) {
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -148,9 +144,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 ct[(wm * WM + i * 16 + (lane >> 4) * 4 + r) * LDC + wn * WN + j * 16 + (lane & 15)] = acc[i][j][r] * g.alpha;
-    }
     __syncthreads();
-    if (!active) return;
     // A thread owns strips of SW columns.  The epilogue is bound by the NUMBER of vector-memory wave-instructions (one
     // texture addresser per CU, ~70 cycles each whatever their width), so epilogues with 16-bit streams (bf16 output, ReLU
     // mask) use 8-column strips = 16 bytes per lane; pure fp32 epilogues keep 4 columns (same instruction count, fewer LDS
@@ -907,106 +901,6 @@ __global__ __launch_bounds__(256) void gemm_lnbwd_kernel(GemmArgs g, LnBwdA ln) 
     lnA_mainloop<BN, EPI>(g, sa, LDA, ring, smem, m0, n0);
 }
 
-// ---- the few-hundred-row GEMMs of the decoder (M = B x L): one 64 x 64 tile per workgroup, 64 .. 256 workgroups, and what a launch
-// takes is ONE tile's latency -- a chain of K / 64 dependent k steps (load by LDS-DMA, wait, 2 x 8 MFMAs) of ~0.35 us each: 5.8 us at
-// K = 512, 11-12 us at K = 2048 (rocprofv3, round 3).  Here KS groups of four waves split the k tiles of the SAME output tile
-// (group j takes tiles j, j + KS, ...; its own pair of LDS buffers; all groups step together, so the workgroup barrier serves them
-// all), the partial accumulators are folded through LDS in group order (fixed: deterministic) and the first group runs the epilogue.
-// The chain is KS times shorter; the bytes per CU are the same.  K % (64 KS) == 0.
-template <int EPI, int KS>
-__global__ __launch_bounds__(256 * KS) void gemm_glds_ks_kernel(GemmArgs g) {
-    constexpr int BM = 64, BN = 64, WM = 32, WN = 32, FM = 2, FN = 2, LDC = BN + 4;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES, GROUP = 2 * BUF;
-    constexpr int RED = 4 * BM * LDC;                          // one fp32 partial tile
-    static_assert(KS * GROUP >= KS * RED, "the partial tiles reuse the staging buffers");
-    __shared__ __attribute__((aligned(16))) char smem[KS * GROUP];
-    typedef __attribute__((address_space(1))) const void gptr_t;
-    typedef __attribute__((address_space(3))) void lptr_t;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, lw = wave & 3, ltid = tid & 255;
-    const int wm = lw >> 1, wn = lw & 1;
-    int bx_ = blockIdx.x, by_ = blockIdx.y, bz_ = 0;
-    if (g.xcd_order) xcd_tile(bx_, by_, bz_);
-    const int m0 = by_ * BM, n0 = bx_ * BN;
-    char* mine = smem + grp * GROUP;
-    constexpr int CH = 2;                                      // 16-byte chunks per thread and operand tile (64 rows x 8 chunks / 256 threads)
-    const bf16* asrc[CH]; const bf16* bsrc[CH];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-        const int c = ltid + i * 256, r = c >> 3, ch = (c & 7) ^ (r & 7);
-        asrc[i] = g.A + (long)(m0 + r < g.M ? m0 + r : g.M - 1) * g.lda + ch * 8;
-        bsrc[i] = g.B + (long)(n0 + r < g.N ? n0 + r : g.N - 1) * g.ldb + ch * 8;
-    }
-    auto stage = [&](int buf, int kt) {
-        char* ab = mine + buf * BUF;
-        char* bb = ab + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < CH; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(asrc[i] + kt * 64), (lptr_t*)(ab + (lw * 64 + i * 256) * 16), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < CH; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(bsrc[i] + kt * 64), (lptr_t*)(bb + (lw * 64 + i * 256) * 16), 16, 0, 0);
-    };
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nkg = g.K / (64 * KS);                            // k tiles per group
-    const int rr = lane & 15, q = lane >> 4;
-    stage(0, grp);
-    for (int t = 0; t < nkg; ++t) {
-        const int cur = t & 1;
-        __syncthreads();                                        // (vmcnt(0): this group's tile t has landed) + everyone is done with buffer cur ^ 1
-        if (t + 1 < nkg) stage(cur ^ 1, grp + (t + 1) * KS);
-        const bf16* ab = reinterpret_cast<const bf16*>(mine + cur * BUF);
-        const bf16* bb = reinterpret_cast<const bf16*>(mine + cur * BUF + A_BYTES);
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
-            bf16x8 af[FM], bfr[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) { const int row = wm * WM + i * 16 + rr; af[i] = ld8(ab + row * 64 + (((kc * 4 + q) ^ (row & 7)) * 8)); }
-#pragma unroll
-            for (int j = 0; j < FN; ++j) { const int row = wn * WN + j * 16 + rr; bfr[j] = ld8(bb + row * 64 + (((kc * 4 + q) ^ (row & 7)) * 8)); }
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
-        }
-    }
-    __syncthreads();                                            // every fragment read is done: the buffers become the partial tiles
-    // groups 1 .. KS-1 park their partial sums (fp32 [64][LDC], group j at smem + j * GROUP); group 0 adds them in group order
-    if (grp > 0) {
-        float* pt = reinterpret_cast<float*>(mine);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pt[(wm * WM + i * 16 + q * 4 + r) * LDC + wn * WN + j * 16 + rr] = acc[i][j][r];
-    }
-    __syncthreads();
-    if (grp == 0) {
-#pragma unroll
-        for (int k = 1; k < KS; ++k) {
-            const float* pt = reinterpret_cast<const float*>(smem + k * GROUP);
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][j][r] += pt[(wm * WM + i * 16 + q * 4 + r) * LDC + wn * WN + j * 16 + rr];
-        }
-    }
-    gemm_epilogue<BM, BN, EPI>(g, acc, smem, m0, n0, 0, ltid, grp == 0);     // (group 0's own staging buffers: 32 KB >= the 17 KB fp32 tile)
-}
-template <int EPI>
-void launch_glds_ks(const GemmArgs& g, dim3 grid, int ks, hipStream_t s) {
-    if (ks == 4) hipLaunchKernelGGL((gemm_glds_ks_kernel<EPI, 4>), grid, dim3(1024), 0, s, g);
-    else hipLaunchKernelGGL((gemm_glds_ks_kernel<EPI, 2>), grid, dim3(512), 0, s, g);
-}
-
 template <int BM, int BN, int EPI>
 void launch_glds(const GemmArgs& g, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, EPI>), grid, dim3(256), 0, s, g);
@@ -1032,15 +926,8 @@ int launch_tile(const GemmArgs& g_in, hipStream_t s) {
     } else {
         static const bool use_glds = !getenv("MASR_GEMM_NO_GLDS");
         const bool glds = use_glds && (g.K % 64 == 0);
-        // few rows (the decoder's B x L): split the k tiles of a 64 x 64 tile over 2 (K < 1024) or 4 wave groups (gemm_glds_ks_kernel)
-        static const int ks_env = getenv("MASR_GEMM_KSPLIT") ? atoi(getenv("MASR_GEMM_KSPLIT")) : -1;       // 0 = off, 2 / 4 = forced
-        int ks = 0;
-        if (BM == 64 && BN == 64 && glds && g.M <= 1024 && ks_env != 0 && !g.no_ksplit) {
-            ks = ks_env > 0 ? ks_env : (g.K >= 1024 ? 4 : 2);
-            if (g.K % (64 * ks) || g.K / (64 * ks) < 2) ks = (ks == 4 && g.K % 128 == 0 && g.K / 128 >= 2) ? 2 : 0;
-        }
         switch (epi & ~E_DROP) {                       // dropout stays a run-time test inside the specialised kernels
-#define CASE(mask) case (mask): if (ks) launch_glds_ks<(mask) | E_DROP>(g, grid, ks, s); else if (glds) launch_glds<BM, BN, (mask) | E_DROP>(g, grid, s); else launch_epi<BM, BN, false, (mask) | E_DROP>(g, grid, s); break;
+#define CASE(mask) case (mask): if (glds) launch_glds<BM, BN, (mask) | E_DROP>(g, grid, s); else launch_epi<BM, BN, false, (mask) | E_DROP>(g, grid, s); break;
             CASE(E_BIAS | E_C16)                       // q/k/v projections
             CASE(E_BIAS | E_RES | E_C32)               // attention out-proj, FFN second layer
             CASE(E_BIAS | E_RELU | E_C16)              // FFN first layer

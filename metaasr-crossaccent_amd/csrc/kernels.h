@@ -30,7 +30,6 @@ struct GemmArgs {
     // (m % cseg_rows) * ldc, colsum[m] at colsum + (m / cseg_rows) * cseg_stride + m % cseg_rows.  cseg_rows = 0: plain rows;
     // otherwise a multiple of the 128-row tile.
     int cseg_rows; long cseg_stride;
-    int no_ksplit;                // 1: never split the k tiles of a tile over wave groups (summation order of the plain kernels)
 };
 int mk_gemm(const GemmArgs& g, hipStream_t s);
 // NT GEMMs whose A operand is a LayerNorm OUTPUT (forward) or a LayerNorm input-GRADIENT (backward) that the GEMM computes itself

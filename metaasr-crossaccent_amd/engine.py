@@ -247,10 +247,6 @@ class MasrEngine:
         """decoder-row LayerNorms inside their consumer GEMMs (include/masr.h masr_set_ln_fusion); default off (measured slower)"""
         self._l.masr_set_ln_fusion(self.h, int(bool(on)))
 
-    def set_gemm_ksplit(self, on: bool):
-        """few-row GEMMs split their k tiles over wave groups (include/masr.h masr_set_gemm_ksplit); default on"""
-        self._l.masr_set_gemm_ksplit(self.h, int(bool(on)))
-
     def step_counters(self):
         """{'direct', 'captured', 'replayed'}: how run_batch calls reached the GPU (kernel by kernel / graph capture / graph replay)"""
         out = (C.c_int64 * 3)()

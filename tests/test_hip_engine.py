@@ -407,7 +407,6 @@ def test_layernorm_in_the_gemm_prologue_gives_the_same_step(cfg_name):
         eng.load_state_dict(sd)
         eng.set_seed(99)
         eng.set_ln_fusion(fused)
-        eng.set_gemm_ksplit(False)            # (the fused kernels reduce over k in one chain: compare with the unsplit standalone GEMMs)
         # (one step: the LayerNorm weight gradients differ in the last bit, so a SECOND step would start from weights that differ there)
         eng.run_batch(xs, il, ys, ol.clone(), train=True)
         logits = eng.last_logits()[0].clone()
@@ -428,30 +427,3 @@ def test_layernorm_in_the_gemm_prologue_gives_the_same_step(cfg_name):
             torch.testing.assert_close(a, b, rtol=2e-5, atol=1e-6 * float(b.abs().max() + 1e-30))
         else:
             assert torch.equal(a, b), f"{n}: gradient differs between the fused and the standalone LayerNorm path"
-
-
-def test_few_row_gemms_split_over_wave_groups_match_the_unsplit_kernels():
-    """gemm_glds_ks_kernel (the decoder-row GEMMs: 2 or 4 groups of four waves split the k tiles of one 64 x 64 tile and fold their
-    partial sums in group order): a training step with the split on equals the step with it off up to the fp32 summation order over k
-    -- loss within 1e-6 relative, every gradient tensor within 1e-4 of its norm -- and repeats bit for bit (deterministic fold)."""
-    cfg = dict(HKUST); cfg["dropout"] = cfg["pos_dropout"] = 0.1
-    sd = ref_cpu.deterministic_state_dict(cfg, ODIM, seed=5)
-    xs, il, ys, ol = synth_batch(21, [203, 160, 121, 96, 90], [12, 9, 7, 30, 2])
-    outs = []
-    for split in (True, True, False):
-        eng = MasrEngine(cfg, ODIM, label_smoothing=0.2)
-        eng.load_state_dict(sd); eng.set_seed(99); eng.set_gemm_ksplit(split)
-        eng.run_batch(xs, il, ys, ol.clone(), train=True)
-        outs.append((eng.read_stats()["loss"], eng.grads.clone(), eng))
-    (l1, g1, eng), (l2, g2, _), (l0, g0, _) = outs
-    assert l1 == l2 and torch.equal(g1, g2), "the split-k fold is not deterministic"
-    assert abs(l1 - l0) <= 1e-6 * abs(l0), (l1, l0)
-    worst = ("", 0.0)
-    for n, (off, shape) in eng.table.items():
-        k = int(np.prod(shape))
-        a, b = g1[off:off + k].double(), g0[off:off + k].double()
-        r = float((a - b).norm() / (b.norm() + 1e-30))
-        if r > worst[1]:
-            worst = (n, r)
-        assert r < 2e-3, (n, r)
-    print("split-k decoder GEMMs vs unsplit: worst per-tensor gradient rel-L2", worst)
