@@ -405,8 +405,8 @@ __global__ __launch_bounds__(256) void gemm_wgrad_grouped_kernel(WgradGroup grp)
 // per-wave work) takes in (128 + 256) / (128 * 256) bytes per FLOP instead of (128 + 128) / (128 * 128): -25 %.  One workgroup per CU
 // (106 KB of LDS, two waves per SIMD as two four-wave workgroups had).  The tile list of the hkust geometry is 296 such tiles for 256
 // CUs: a second round at 16 % occupancy would cost what the intake saves, so only a whole number of rounds runs as big tiles
-// (n_big = the largest multiple of 256 <= the tile count) and the remaining big tiles are cut into 128 x 128 halves that the SAME
-// eight waves take (2 x 4 waves of 64 x 32) as the CUs come free.  Every output element is still reduced by ONE workgroup over the rows in
+// (n_big = the largest multiple of 256 <= the tile count) and the remaining big tiles are cut into W8_PARTS column pieces (128 x 64
+// quarters: 2 x 4 waves of 64 x 16) that the SAME eight waves take as the CUs come free.  Every output element is still reduced by ONE workgroup over the rows in
 // order, so dW is bit-identical to the four-wave kernel's; the bias gradient (column sums, folded over 512 threads) differs in fp32
 // rounding only.  MASR_ENC_WGRAD_TILE=128 restores the four-wave launch.
 template <int ROWS, int NT>
@@ -447,6 +447,10 @@ struct StagerRMT {
     }
 };
 constexpr int W8_LDS = 2 * (int)sizeof(TileRM<128>) + 2 * (int)sizeof(TileRM<256>);
+#ifndef MASR_W8_PARTS
+#define MASR_W8_PARTS 4
+#endif
+constexpr int W8_PARTS = MASR_W8_PARTS;            // pieces a big tile of the last, partial round is cut into (2: 128 x 128, 4: 128 x 64)
 
 // dW[m0 .. m0+128)[n0 .. n0+BN) of one group member; 512 threads = 8 waves as 2 (rows) x 4 (columns)
 template <int BN>
@@ -458,7 +462,11 @@ __device__ __forceinline__ void wgrad8_tile(const WgradDesc& d, const int m0, co
     TileRM<BN>* sb_ = reinterpret_cast<TileRM<BN>*>(smem + 2 * sizeof(TileRM<BM>));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
     const int M = d.N, N = d.K, K = d.rows;                        // dW is [M = out features][N = in features], reduced over the K rows
-    constexpr int DEPTH = 2;
+#ifndef MASR_W8_DEPTH
+#define MASR_W8_DEPTH 2
+#endif
+    constexpr int DEPTH = MASR_W8_DEPTH;                          // k tiles of global loads in flight per thread (register ring)
+    static_assert(DEPTH % 2 == 0, "the LDS buffer parity of ring slot u must be static");
     SA sa[DEPTH]; SB sb[DEPTH];
     f32x4 acc[FM][FN];
 #pragma unroll
@@ -540,16 +548,17 @@ __global__ __launch_bounds__(512) void gemm_wgrad_grouped8_kernel(WgradGroup grp
     // blocks [0, n_big): big tiles in XCD-contiguous runs (n_big is a multiple of 256, hence of 8); the rest: 128 x 128 halves of the
     // big tiles n_big, n_big + 1, ... in list order
     const int l = blockIdx.x;
-    int tbig, half = -1;
+    int tbig, part = -1;
     if (l < n_big) tbig = (l & 7) * (n_big >> 3) + (l >> 3);
-    else { tbig = n_big + ((l - n_big) >> 1); half = (l - n_big) & 1; }
+    else { tbig = n_big + (l - n_big) / W8_PARTS; part = (l - n_big) % W8_PARTS; }
     int p = 0;
     while (p + 1 < grp.n && tbig >= grp.p[p + 1].tile_start) ++p;
     const WgradDesc& d = grp.p[p];
     const int t = tbig - d.tile_start, tiles_x = (d.K + 255) / 256;
     const int bx = t % tiles_x, by = t / tiles_x;
-    if (half < 0) wgrad8_tile<256>(d, by * 128, bx * 256, d.db != nullptr && bx == 0, smem);
-    else if (bx * 256 + half * 128 < d.K) wgrad8_tile<128>(d, by * 128, bx * 256 + half * 128, d.db != nullptr && bx == 0 && half == 0, smem);
+    constexpr int PW = 256 / W8_PARTS;
+    if (part < 0) wgrad8_tile<256>(d, by * 128, bx * 256, d.db != nullptr && bx == 0, smem);
+    else if (bx * 256 + part * PW < d.K) wgrad8_tile<PW>(d, by * 128, bx * 256 + part * PW, d.db != nullptr && bx == 0 && part == 0, smem);
 }
 
 #undef HAS
@@ -964,7 +973,7 @@ int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s, int tile) {
         // whole rounds of the 256 CUs as 128 x 256 tiles, the rest as their 128 x 128 halves (see gemm_wgrad_grouped8_kernel)
         static const int ncu = [] { int dev = 0, n = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n / 8 * 8 : 256; }();
         const int n_big = tiles / ncu * ncu;
-        hipLaunchKernelGGL(gemm_wgrad_grouped8_kernel, dim3(n_big + 2 * (tiles - n_big)), dim3(512), 0, s, grp, n_big);
+        hipLaunchKernelGGL(gemm_wgrad_grouped8_kernel, dim3(n_big + W8_PARTS * (tiles - n_big)), dim3(512), 0, s, grp, n_big);
         if (hipGetLastError() != hipSuccess) { mk_set_error("mk_gemm_wgrad_grouped", "launch failed"); return -1; }
         return 0;
     }
