@@ -377,7 +377,14 @@ def main():
         return {"value": v, "unit": "utt/s", "ms_per_step": dt1 / n1 * 1e3, "steps": n1, "seconds": dt1,
                 "model_frac_of_bf16_peak": v * flops_per_utt / 1e12 / (PEAK_BF16_TFLOPS * world)}
     single = single_first = None
-    if K > 1:
+    if K > 1 and args.single_seconds <= 0:
+        # (profiling runs: a short one-task leg only, for the stagger -- 10 + warm-up steps in the trace, as tools/save_profiles.py assumes)
+        n1 = max(5, args.steps // 3)
+        dt1 = timed(tasks[:1], n1, args.warmup)
+        single_first = {"value": world * B * n1 / dt1, "unit": "utt/s", "ms_per_step": dt1 / n1 * 1e3, "steps": n1, "seconds": dt1,
+                        "model_frac_of_bf16_peak": world * B * n1 / dt1 * F_step / 1e12 / (PEAK_BF16_TFLOPS * world)}
+        single = single_first
+    elif K > 1:
         # >= 1 s, BEFORE the headline region: it also brings the clocks up, and the stagger of the K-task legs is derived from a
         # number that one ramp hiccup cannot halve (round 3: 6 steps = 16 ms as the first timed region of the process read 2 800 utt/s
         # on the driver's box against 5 900 here).  The figure reported as "single_task" is measured again AFTER the long run.
@@ -399,7 +406,7 @@ def main():
         long_run = {"steps": nlong, "seconds": dtl, "value": world * K * B * nlong / dtl, "ms_per_step": dtl / nlong * 1e3,
                     "clocks_under_load": clk.summary()}
         log(f"long run: {dtl:.2f} s for {nlong} steps -> {long_run['value']:.1f} utt/s; clocks {long_run['clocks_under_load']}")
-    if K > 1:
+    if K > 1 and args.single_seconds > 0:
         with ClockSampler(local) as clk1:
             single = time_single(tasks, B, F_step, args.single_seconds)      # warm clocks: right behind the long run
         single["clocks_under_load"] = clk1.summary()

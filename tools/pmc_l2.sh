@@ -1,7 +1,7 @@
 # L2 hit / miss counts per kernel of the single-task step (rocprofv3 PMC pass): bash tools/pmc_l2.sh [kernel-name-substring ...]
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 O=gpurun_out
-Q="--no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --no-matrix --no-mixed --no-e2e"
+Q="--no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --single-seconds 0 --no-matrix --no-mixed --no-e2e"
 rm -rf $O/pmc_l2
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace -d $O/pmc_l2 -o p --output-format csv -- python3 bench.py --steps 3 --warmup 2 $Q --tasks-per-gpu 1 > $O/pmc_l2.log 2>&1
 python3 - "$@" <<'PY'

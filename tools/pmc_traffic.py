@@ -23,7 +23,7 @@ SLOTS = {   # bench.py roofline slot -> substring of the kernel name
     "conv2_wgrad": "conv3x3_wgrad2_kernel<64, 64,",
     "conv3_wgrad": "conv3x3_wgrad2_kernel<64, 128,",
     "conv4_wgrad": "conv3x3_wgrad2_kernel<128, 128,",
-    "wgrad_enc": "gemm_wgrad_grouped_kernel<128, 128>",
+    "wgrad_enc": "gemm_wgrad_grouped8_kernel",
 }
 
 
@@ -52,7 +52,7 @@ def main():
                       "means over the dispatches of the traced steps",
           "workload": {"batch": 16, "frames": 1000, "idim": 80},
           "collected": f"{tag} @ {sha}",
-          "command": "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --no-matrix --no-mixed --no-e2e --tasks-per-gpu 1",
+          "command": "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --single-seconds 0 --no-matrix --no-mixed --no-e2e --tasks-per-gpu 1",
           "kernels": kernels,
           "raw_KiB": {"FETCH_SIZE": fetch, "WRITE_SIZE": write}}
     Path("profiles/pmc_traffic.json").write_text(json.dumps(js, indent=1) + "\n")

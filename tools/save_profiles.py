@@ -31,9 +31,17 @@ sg = glob.glob(str(g / "prof_single/**/*kernel_stats.csv"), recursive=True)[0]
 shutil.copy(k4, out / f"{tag}_bench_kernel_stats.csv")
 shutil.copy(sg, out / f"{tag}_single_task_kernel_stats.csv")
 summary(k4, 35 * 4 + 15,
-        "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --no-matrix --no-mixed --no-e2e  (MI355X, default = 4 concurrent tasks; + the 10+5-step single-task leg)",
+        "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --single-seconds 0 --no-matrix --no-mixed --no-e2e  (MI355X, default = 4 concurrent tasks; + the 10+5-step single-task leg)",
         out / f"{tag}_bench_kernel_stats.txt")
 summary(sg, 35,
-        "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --no-matrix --no-mixed --no-e2e --tasks-per-gpu 1  (MI355X, one task per GPU)",
+        "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --single-seconds 0 --no-matrix --no-mixed --no-e2e --tasks-per-gpu 1  (MI355X, one task per GPU)",
         out / f"{tag}_single_task_kernel_stats.txt")
+bl = glob.glob(str(g / "prof_blstm/**/*kernel_stats.csv"), recursive=True)
+if bl:
+    shutil.copy(bl[0], out / f"{tag}_blstm_kernel_stats.csv")
+    summary(bl[0], 23, "rocprofv3 --kernel-trace --stats -- python3 tools/bench_blstm.py --steps 20 --warm 3  (MI355X; BASELINE configs[0]: BLSTM-CTC training "
+                       "step, B = 8 x 400 frames, 3 x BLSTM-P(360); the CTC lattice = ctc_kernel, the recurrence = lstm_fwd_step / lstm_bwd_step)",
+            out / f"{tag}_blstm_kernel_stats.txt")
+    if (g / "blstm.json").exists():
+        shutil.copy(g / "blstm.json", out / f"{tag}_blstm.json")
 print("saved")

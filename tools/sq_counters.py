@@ -3,7 +3,7 @@
 On the GPU box (repo root):
     cd /tmp && export TMPDIR=/tmp && cd - && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
         SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAIT_INST_LDS --kernel-trace -d gpurun_out/pmc_sq -o p --output-format csv \
-        -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --no-matrix --no-mixed --no-e2e --tasks-per-gpu 1
+        -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --single-seconds 0 --no-matrix --no-mixed --no-e2e --tasks-per-gpu 1
 then here:  python tools/sq_counters.py <round-tag>   ->  profiles/<tag>_sq_counters_single_task.txt
 mfma_busy = (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (SQ_BUSY_CYCLES / 32 shader engines); the other fractions are of SQ_WAVE_CYCLES."""
 import csv
@@ -29,7 +29,7 @@ for k, c in acc.items():
 rows.sort(reverse=True)
 with open(f"profiles/{tag}_sq_counters_single_task.txt", "w") as out:
     out.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAIT_INST_LDS --kernel-trace\n")
-    out.write("#   -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --no-matrix --no-mixed --no-e2e --tasks-per-gpu 1   (MI355X; means per kernel, sorted by total busy time)\n")
+    out.write("#   -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-meta-step --long-seconds 0 --single-seconds 0 --no-matrix --no-mixed --no-e2e --tasks-per-gpu 1   (MI355X; means per kernel, sorted by total busy time)\n")
     out.write("# mfma_busy = (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (SQ_BUSY_CYCLES / 32 shader engines); the other fractions are of SQ_WAVE_CYCLES\n")
     out.write(f"{'kernel':84s} calls mfma_busy wait_any wait_lds lds_conflict issuing\n")
     for _, k, n, mf, wa, wl, lc, iss in rows:
