@@ -341,6 +341,8 @@ int64_t masr_test_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int CO
  * member with the same operands when dW2 is given; tile = 64 or 128 */
 int masr_test_wgrad_grouped(const uint16_t* dy, int64_t lddy, const uint16_t* x, int64_t ldx, float* dW, float* db, float* dW2, float* db2,
                             int rows, int N, int K, int tile, void* stream);
+int masr_test_wgrad_grouped_n(const uint16_t* dy, int64_t lddy, const uint16_t* x, int64_t ldx, float* dW, int64_t member_stride, int members,
+                              int rows, int N, int K, int tile, void* stream);
 /* the same with dy given as the pooled gradient [B][H/2][W/2][COUT] + the pool codes of masr_test_conv3x3_pool_idx (the weight-gradient kernel
  * expands the 2x2 max-pool + ReLU backward while staging; 64->64 and 128->128 channels); db may be null */
 int masr_test_conv3x3_wgrad_pooled(const uint16_t* in, const uint16_t* dy_pooled, const uint8_t* pool_idx, float* dw, float* db, float* slab,

@@ -99,6 +99,7 @@ _SIGS = {
     "masr_test_conv3x3_wgrad": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     "masr_test_conv3x3_wgrad_slab_floats": (i64, [i32, i32, i32, i32, i32]),
     "masr_test_wgrad_grouped": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "masr_test_wgrad_grouped_n": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp]),
     "masr_test_conv3x3_wgrad_pooled": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     "masr_test_layernorm_slab_floats": (i64, [i32, i32]),
     "masr_test_layernorm": (i32, [vp] * 13 + [i32, i32, f32, C.c_uint32, C.c_uint32, vp]),

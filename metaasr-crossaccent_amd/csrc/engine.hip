@@ -1390,6 +1390,18 @@ int masr_test_wgrad_grouped(const uint16_t* dy, int64_t lddy, const uint16_t* x,
     }
     return mk_gemm_wgrad_grouped(grp, (hipStream_t)stream, tile);
 }
+int masr_test_wgrad_grouped_n(const uint16_t* dy, int64_t lddy, const uint16_t* x, int64_t ldx, float* dW, int64_t member_stride, int members,
+                              int rows, int N, int K, int tile, void* stream) {
+    // `members` group members over the SAME operands (member i writes dW + i * member_stride; 0 = all into one buffer): what the grouped
+    // launch costs when every panel is resident in L2 / the Infinity Cache (tools/wgrad_probe.py)
+    WgradGroup grp{};
+    grp.n = members < WGRAD_GROUP_MAX ? members : WGRAD_GROUP_MAX;
+    for (int i = 0; i < grp.n; ++i) {
+        WgradDesc& d = grp.p[i];
+        d.dy = (const bf16*)dy; d.x = (const bf16*)x; d.dW = dW + (int64_t)i * member_stride; d.db = nullptr; d.lddy = (int)lddy; d.ldx = (int)ldx; d.rows = rows; d.N = N; d.K = K;
+    }
+    return mk_gemm_wgrad_grouped(grp, (hipStream_t)stream, tile);
+}
 int masr_test_conv3x3_wgrad_pooled(const uint16_t* in, const uint16_t* dy_pooled, const uint8_t* pool_idx, float* dw, float* db, float* slab,
                                    int64_t slab_floats, int B, int H, int W, int CIN, int COUT, void* stream) {
     if (slab_floats < mk_conv3x3_wgrad_slab_floats(B, H, W, CIN, COUT)) { mk_set_error("masr_test_conv3x3_wgrad_pooled", "slab too small"); return -1; }

@@ -409,6 +409,10 @@ __global__ __launch_bounds__(256) void gemm_wgrad_grouped_kernel(WgradGroup grp)
 // quarters: 2 x 4 waves of 64 x 16) that the SAME eight waves take as the CUs come free.  Every output element is still reduced by ONE workgroup over the rows in
 // order, so dW is bit-identical to the four-wave kernel's; the bias gradient (column sums, folded over 512 threads) differs in fp32
 // rounding only.  MASR_ENC_WGRAD_TILE=128 restores the four-wave launch.
+// What bounds a full round (tools/wgrad_probe.py: 256 big tiles, one per CU): 88-92 us whether the operands are 8 MB (resident in every
+// cache) or 49 MB, 40 us per tile when only 64 CUs have one -- i.e. not HBM, not the L2 hit rate, not latency (a four-deep register ring:
+// -1 %) and not sharers walking a panel in lock-step (a start skew of the XCD's tiles only added its own delay): the CUs together take in
+// ~8.7 TB/s from the L2s at this access shape, and the way to fewer microseconds is fewer operand bytes per FLOP (256 x 256 tiles: -33 %).
 template <int ROWS, int NT>
 struct StagerRMT {
     static constexpr int LDT = ROWS + 16;
