@@ -451,15 +451,16 @@ struct StagerRMT {
     }
 };
 constexpr int W8_LDS = 2 * (int)sizeof(TileRM<128>) + 2 * (int)sizeof(TileRM<256>);
+constexpr int W16_LDS = 4 * (int)sizeof(TileRM<256>);
 #ifndef MASR_W8_PARTS
 #define MASR_W8_PARTS 4
 #endif
 constexpr int W8_PARTS = MASR_W8_PARTS;            // pieces a big tile of the last, partial round is cut into (2: 128 x 128, 4: 128 x 64)
 
 // dW[m0 .. m0+128)[n0 .. n0+BN) of one group member; 512 threads = 8 waves as 2 (rows) x 4 (columns)
-template <int BN>
+template <int BN, int BM = 128>
 __device__ __forceinline__ void wgrad8_tile(const WgradDesc& d, const int m0, const int n0, const bool do_colsum, char* smem) {
-    constexpr int BM = 128, WM = 64, WN = BN / 4, FM = WM / 16, FN = WN / 16, NT = 512;
+    constexpr int WM = BM / 2, WN = BN / 4, FM = WM / 16, FN = WN / 16, NT = 512;
     using SA = StagerRMT<BM, NT>;
     using SB = StagerRMT<BN, NT>;
     TileRM<BM>* sa_ = reinterpret_cast<TileRM<BM>*>(smem);
@@ -479,11 +480,13 @@ __device__ __forceinline__ void wgrad8_tile(const WgradDesc& d, const int m0, co
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int nk = (K + BK - 1) / BK;
+    // (tried: unclamped loads from per-thread base pointers for interior tiles -- the clamping arithmetic is ~10 vector instructions per
+    // 16-byte load; with both paths in the kernel it needed 8 more registers (the 256 x 256 form spilled) and ran 8 % SLOWER)
+    auto fetch = [&](SA& a_, SB& b_, int kt) {
+        a_.load(d.dy, d.lddy, m0, kt * BK, M, K, tid); b_.load(d.x, d.ldx, n0, kt * BK, N, K, tid);
+    };
 #pragma unroll
-    for (int dd = 0; dd < DEPTH; ++dd) {
-        sa[dd].load(d.dy, d.lddy, m0, dd * BK, M, K, tid);
-        sb[dd].load(d.x, d.ldx, n0, dd * BK, N, K, tid);
-    }
+    for (int dd = 0; dd < DEPTH; ++dd) fetch(sa[dd], sb[dd], dd);
     if (do_colsum) sa[0].accumulate(csum);
     sa[0].store(sa_[0].d, tid);
     sb[0].store(sb_[0].d, tid);
@@ -494,19 +497,24 @@ __device__ __forceinline__ void wgrad8_tile(const WgradDesc& d, const int m0, co
             const int kt = kt0 + u;
             if (kt >= nk) break;
             const int cur = u & 1;
-            sa[u].load(d.dy, d.lddy, m0, (kt + DEPTH) * BK, M, K, tid);
-            sb[u].load(d.x, d.ldx, n0, (kt + DEPTH) * BK, N, K, tid);
+            fetch(sa[u], sb[u], kt + DEPTH);
 #pragma unroll
             for (int kc = 0; kc < BK / 32; ++kc) {
-                bf16x8 af[FM], bfr[FN];
-#pragma unroll
-                for (int i = 0; i < FM; ++i) af[i] = frag_rm<BM + 16>(sa_[cur].d, wm * WM + i * 16, lane, kc * 32);
+                bf16x8 bfr[FN];
 #pragma unroll
                 for (int j = 0; j < FN; ++j) bfr[j] = frag_rm<BN + 16>(sb_[cur].d, wn * WN + j * 16, lane, kc * 32);
+                // (the dY fragments four at a time: a 256-row tile has eight per wave, and all of them live at once would not fit beside
+                // its 128 accumulator registers)
 #pragma unroll
-                for (int i = 0; i < FM; ++i)
+                for (int i0 = 0; i0 < FM; i0 += 4) {
+                    bf16x8 af[4];
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
+                    for (int i = 0; i < 4; ++i) af[i] = frag_rm<BM + 16>(sa_[cur].d, wm * WM + (i0 + i) * 16, lane, kc * 32);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) acc[i0 + i][j] = mma16(af[i], bfr[j], acc[i0 + i][j]);
+                }
             }
             if (kt + 1 < nk) {
                 const int nx = (u + 1) % DEPTH;
@@ -517,7 +525,7 @@ __device__ __forceinline__ void wgrad8_tile(const WgradDesc& d, const int m0, co
             __syncthreads();
         }
     }
-    if (do_colsum) {                                             // threads tid, tid + 16, ... own the same 8 rows of the dY tile
+    if (do_colsum) {                                             // threads tid, tid + BM / 8, ... own the same 8 rows of the dY tile
         constexpr int RC = BM / 8;
         float* red = reinterpret_cast<float*>(smem);              // [512][8] floats = 16 KB
 #pragma unroll
@@ -529,6 +537,7 @@ __device__ __forceinline__ void wgrad8_tile(const WgradDesc& d, const int m0, co
             for (int t = rc; t < NT; t += RC) sum += red[t * 8 + j];
             if (m0 + tid < M) d.db[m0 + tid] = sum;
         }
+        __syncthreads();
     }
     // accumulators straight to dW: lane (fq, fr) holds rows fq * 4 + r, column fr of every 16 x 16 block -- 16 lanes write 64 contiguous
     // bytes of a row (the 39.5 MB of dW are written once per step: not what bounds this launch)
@@ -563,6 +572,19 @@ __global__ __launch_bounds__(512) void gemm_wgrad_grouped8_kernel(WgradGroup grp
     constexpr int PW = 256 / W8_PARTS;
     if (part < 0) wgrad8_tile<256>(d, by * 128, bx * 256, d.db != nullptr && bx == 0, smem);
     else if (bx * 256 + part * PW < d.K) wgrad8_tile<PW>(d, by * 128, bx * 256 + part * PW, d.db != nullptr && bx == 0 && part == 0, smem);
+}
+
+// 256 x 256 tiles (2 x 4 waves of 128 x 64): taken when the whole group is at most ONE round of the CUs in such tiles (hkust: 148).
+// A third fewer operand bytes per FLOP than 128 x 256, no partial round, and fewer CUs drawing on the L2s at once.
+__global__ __launch_bounds__(512) void gemm_wgrad_grouped16_kernel(WgradGroup grp) {
+    __shared__ __attribute__((aligned(16))) char smem[W16_LDS];
+    const int t_ = blockIdx.x;
+    int p = 0;
+    while (p + 1 < grp.n && t_ >= grp.p[p + 1].tile_start) ++p;
+    const WgradDesc& d = grp.p[p];
+    const int t = t_ - d.tile_start, tiles_x = (d.K + 255) / 256;
+    const int bx = t % tiles_x, by = t / tiles_x;
+    wgrad8_tile<256, 256>(d, by * 256, bx * 256, d.db != nullptr && bx == 0, smem);
 }
 
 #undef HAS
@@ -976,6 +998,16 @@ int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s, int tile) {
     if (tile == 256) {
         // whole rounds of the 256 CUs as 128 x 256 tiles, the rest as their 128 x 128 halves (see gemm_wgrad_grouped8_kernel)
         static const int ncu = [] { int dev = 0, n = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n / 8 * 8 : 256; }();
+        static const bool no16 = getenv("MASR_ENC_WGRAD_NO_256SQ") != nullptr;
+        int t16 = 0;
+        for (int i = 0; i < grp.n; ++i) t16 += ((grp.p[i].N + 255) / 256) * ((grp.p[i].K + 255) / 256);
+        if (!no16 && t16 <= ncu) {                            // one round (or less) of 256 x 256 tiles
+            int acc_t = 0;
+            for (int i = 0; i < grp.n; ++i) { grp.p[i].tile_start = acc_t; acc_t += ((grp.p[i].N + 255) / 256) * ((grp.p[i].K + 255) / 256); }
+            hipLaunchKernelGGL(gemm_wgrad_grouped16_kernel, dim3(t16), dim3(512), 0, s, grp);
+            if (hipGetLastError() != hipSuccess) { mk_set_error("mk_gemm_wgrad_grouped", "launch failed"); return -1; }
+            return 0;
+        }
         const int n_big = tiles / ncu * ncu;
         hipLaunchKernelGGL(gemm_wgrad_grouped8_kernel, dim3(n_big + W8_PARTS * (tiles - n_big)), dim3(512), 0, s, grp, n_big);
         if (hipGetLastError() != hipSuccess) { mk_set_error("mk_gemm_wgrad_grouped", "launch failed"); return -1; }
