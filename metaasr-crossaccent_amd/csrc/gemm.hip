@@ -481,7 +481,10 @@ __device__ __forceinline__ void wgrad8_tile(const WgradDesc& d, const int m0, co
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int nk = (K + BK - 1) / BK;
     // (tried: unclamped loads from per-thread base pointers for interior tiles -- the clamping arithmetic is ~10 vector instructions per
-    // 16-byte load; with both paths in the kernel it needed 8 more registers (the 256 x 256 form spilled) and ran 8 % SLOWER)
+    // 16-byte load; with both paths in the kernel it needed 8 more registers (the 256 x 256 form spilled) and ran 8 % SLOWER.  Tried: the
+    // second half of the waves writes tile kt + 1 BEFORE it multiplies tile kt, so that SIMD partners alternate between the matrix pipe and
+    // the LDS (MI355X_MICROARCH.md "two waves per SIMD", item 9): 132 -> 182 us on the 256 x 256 form (7 spilled registers), 133 -> 153 on
+    // the 128 x 256 one -- the register ring of the global loads is consumed a phase earlier and the compiler serialises on it)
     auto fetch = [&](SA& a_, SB& b_, int kt) {
         a_.load(d.dy, d.lddy, m0, kt * BK, M, K, tid); b_.load(d.x, d.ldx, n0, kt * BK, N, K, tid);
     };
