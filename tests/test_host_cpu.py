@@ -14,7 +14,6 @@ from masr_amd import _cabi
 from masr_amd.io.dataset import BucketSampler, DataContainer, collate_fn, get_loader
 from masr_amd.model import reference_init_state_dict
 from masr_amd.monitor.metric import levenshtein
-from masr_amd.nets_utils import generate_square_subsequent_mask, make_bool_pad_mask
 from masr_amd.optimizer import TransformerOptimizer
 from oracle.make_goldens import TINY, flat_checks, write_toy_shard
 
@@ -61,10 +60,10 @@ def test_init_replay_matches_reference_seed_531(golden_dir, tag):
         np.testing.assert_allclose(flat_checks(t), g[f"{tag}/fp/{n}"], rtol=1e-6, atol=1e-9, err_msg=n)
 
 
-def test_masks_and_noam(golden_dir):
+def test_noam_schedule(golden_dir):
+    """(the reference's mask helpers have no host-side mirror in the product: key-padding and causal masks are applied analytically
+    inside attention.hip -- tests/test_hip_kernels.py::test_attention; the oracle's own are pinned in tests/test_oracle_golden.py)"""
     g = np.load(golden_dir / "masks_noam.npz")
-    np.testing.assert_array_equal(make_bool_pad_mask(torch.tensor([7, 3, 5])).numpy(), g["pad_mask"])
-    np.testing.assert_array_equal(generate_square_subsequent_mask(5).numpy(), g["causal5"])
 
     class _Opt:
         param_groups = [{"lr": 0.0}]
