@@ -651,7 +651,7 @@ def main():
             launches[name] = {"kernel": kern, "avg_launch_ms": per, "gflop_per_launch": flops / 1e9, "tflops": flops / (per * 1e-3) / 1e12,
                               "frac_of_bf16_peak": flops / (per * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "algorithmic_bytes": abytes,
                               "traffic_bytes": pmc.get(name)}
-        # the encoder-row Linear weight gradients are ONE launch since round 3 (gemm_wgrad_grouped_kernel<128,128>): a candidate too
+        # the encoder-row Linear weight gradients are ONE launch since round 3 (round 4: gemm_wgrad_grouped16_kernel / grouped8): a candidate too
         ms_w, n_w = prof_all["wgrad_enc"]
         if n_w == nprof:                                         # (one launch per step: the grouped path is on)
             E_, F_, Tp_ = cfg["d_model"], cfg["d_inner"], T // 4
@@ -660,7 +660,7 @@ def main():
             fl = sum(2.0 * rows * n_ * k_ for n_, k_ in shapes)
             by = sum(rows * (n_ + k_) * 2 + n_ * k_ * 4 for n_, k_ in shapes)
             per = ms_w / n_w
-            launches["wgrad_enc"] = {"kernel": "gemm_wgrad_grouped_kernel<128,128> (ALL encoder-row Linear weight gradients of the step, %d GEMMs dW = dY^T X over %d rows, one grid of 128x128 tiles)" % (len(shapes), rows),
+            launches["wgrad_enc"] = {"kernel": "gemm_wgrad_grouped16_kernel (ALL encoder-row Linear weight gradients of the step, %d GEMMs dW = dY^T X over %d rows, one grid of 256x256 tiles on eight waves; 128x256 tiles + quarters when the group exceeds one round of the CUs)" % (len(shapes), rows),
                                      "avg_launch_ms": per, "gflop_per_launch": fl / 1e9, "tflops": fl / (per * 1e-3) / 1e12,
                                      "frac_of_bf16_peak": fl / (per * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "algorithmic_bytes": by, "traffic_bytes": pmc.get("wgrad_enc")}
         dom = max(launches, key=lambda k: launches[k]["avg_launch_ms"])

@@ -23,7 +23,7 @@ SLOTS = {   # bench.py roofline slot -> substring of the kernel name
     "conv2_wgrad": "conv3x3_wgrad2_kernel<64, 64,",
     "conv3_wgrad": "conv3x3_wgrad2_kernel<64, 128,",
     "conv4_wgrad": "conv3x3_wgrad2_kernel<128, 128,",
-    "wgrad_enc": "gemm_wgrad_grouped8_kernel",
+    "wgrad_enc": "gemm_wgrad_grouped16_kernel",
 }
 
 
