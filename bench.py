@@ -481,128 +481,133 @@ def main():
     # of the all-reduce that is NOT hidden.  (The metric itself counts inner steps, which have no exchange.)
     meta = None
     if not args.no_meta_step:
-        from masr_amd.parallel import TaskSharder
-        sharder = TaskSharder.from_env() if dist is not None else TaskSharder()
-        t0_ = tasks[0]
-        R, nmeta = args.meta_rounds, args.meta_steps
-        orig = eng.params.clone()
-        ea, eas = torch.zeros_like(orig), torch.zeros_like(orig)
-        contribs = [torch.zeros_like(orig) for _ in range(R)]
-        total = torch.zeros_like(orig)
+      try:
+          from masr_amd.parallel import TaskSharder
+          sharder = TaskSharder.from_env() if dist is not None else TaskSharder()
+          t0_ = tasks[0]
+          R, nmeta = args.meta_rounds, args.meta_steps
+          orig = eng.params.clone()
+          ea, eas = torch.zeros_like(orig), torch.zeros_like(orig)
+          contribs = [torch.zeros_like(orig) for _ in range(R)]
+          total = torch.zeros_like(orig)
 
-        def meta_step(i, exchange):
-            for r in range(R):
-                eng.copy(eng.params, orig)
-                eng.mark_dirty()
-                eng.run_batch(t0_.xs, t0_.il, t0_.ys, t0_.ol, train=True)
-                eng.clip_sgd_step(t0_.mom, 5.0, lr, 0.9, True, first_step=True)
-                eng.run_batch(t0_.xs, t0_.il, t0_.ys, t0_.ol, train=True)        # val batch at the adapted weights
-                contribs[r].zero_()
-                eng.clip_accumulate(contribs[r], 5.0)
-                if exchange and dist is not None:
-                    if backend == "nccl":
-                        sharder.reduce_async(contribs[r])
-                    else:
-                        all_reduce_(contribs[r])
-            if exchange:
-                sharder.wait_all()
-            total.zero_()
-            for c in contribs:
-                eng.axpy(total, c, 1.0)
-            eng.scale(total, 1.0 / (R * world))
-            eng.adam_step(orig, total, ea, eas, 1e-7, 0.9, 0.98, 1e-9, i + 1)
+          def meta_step(i, exchange):
+              for r in range(R):
+                  eng.copy(eng.params, orig)
+                  eng.mark_dirty()
+                  eng.run_batch(t0_.xs, t0_.il, t0_.ys, t0_.ol, train=True)
+                  eng.clip_sgd_step(t0_.mom, 5.0, lr, 0.9, True, first_step=True)
+                  eng.run_batch(t0_.xs, t0_.il, t0_.ys, t0_.ol, train=True)        # val batch at the adapted weights
+                  contribs[r].zero_()
+                  eng.clip_accumulate(contribs[r], 5.0)
+                  if exchange and dist is not None:
+                      if backend == "nccl":
+                          sharder.reduce_async(contribs[r])
+                      else:
+                          all_reduce_(contribs[r])
+              if exchange:
+                  sharder.wait_all()
+              total.zero_()
+              for c in contribs:
+                  eng.axpy(total, c, 1.0)
+              eng.scale(total, 1.0 / (R * world))
+              eng.adam_step(orig, total, ea, eas, 1e-7, 0.9, 0.98, 1e-9, i + 1)
 
-        def time_meta(exchange):
-            meta_step(0, exchange)
-            barrier()
-            t1 = time.perf_counter()
-            for i in range(nmeta):
-                meta_step(1 + i, exchange)
-            barrier()
-            d = time.perf_counter() - t1
-            if dist is not None:
-                tt = torch.tensor([d], device=coll_dev, dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                d = float(tt.item())
-            return d / nmeta * 1e3
-        ms_no = time_meta(False)
-        ms_ex = time_meta(True) if dist is not None else ms_no
-        ar_ms = None
-        if dist is not None:
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(5):
-                all_reduce_(contribs[0])
-            torch.cuda.synchronize(dev)
-            ar_ms = (time.perf_counter() - t1) / 5 * 1e3
-        meta = {"rounds_per_rank": R, "inner_steps": 1, "tasks": R * world, "ms": ms_ex, "ms_without_exchange": ms_no,
-                "exposed_exchange_ms": ms_ex - ms_no, "allreduce_ms_isolated": ar_ms, "allreduces_per_meta_step": R if dist is not None else 0,
-                "payload_mb": orig.numel() * 4 / 1e6, "backend": ("rccl" if backend == "nccl" else backend) if dist is not None else None,
-                "utt_per_s": world * R * 2 * B / (ms_ex * 1e-3)}
-        log(f"meta-step: {ms_ex:.2f} ms with exchange, {ms_no:.2f} ms without, isolated all-reduce {ar_ms}")
-        # ---- the same meta-step as pretrain.py --tasks_per_gpu K runs it: the K tasks of a rank concurrently on their slots (host
-        # thread + stream each, slot 0 on the default stream), the meta update reading the K gradient buffers in one pass
-        # (one rank) or their local sum all-reduced first (several ranks); no host sync between meta-steps
-        if K > 1:
-            main = torch.cuda.current_stream(dev)
+          def time_meta(exchange):
+              meta_step(0, exchange)
+              barrier()
+              t1 = time.perf_counter()
+              for i in range(nmeta):
+                  meta_step(1 + i, exchange)
+              barrier()
+              d = time.perf_counter() - t1
+              if dist is not None:
+                  tt = torch.tensor([d], device=coll_dev, dtype=torch.float64)
+                  dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                  d = float(tt.item())
+              return d / nmeta * 1e3
+          ms_no = time_meta(False)
+          ms_ex = time_meta(True) if dist is not None else ms_no
+          ar_ms = None
+          if dist is not None:
+              barrier()
+              t1 = time.perf_counter()
+              for _ in range(5):
+                  all_reduce_(contribs[0])
+              torch.cuda.synchronize(dev)
+              ar_ms = (time.perf_counter() - t1) / 5 * 1e3
+          meta = {"rounds_per_rank": R, "inner_steps": 1, "tasks": R * world, "ms": ms_ex, "ms_without_exchange": ms_no,
+                  "exposed_exchange_ms": ms_ex - ms_no, "allreduce_ms_isolated": ar_ms, "allreduces_per_meta_step": R if dist is not None else 0,
+                  "payload_mb": orig.numel() * 4 / 1e6, "backend": ("rccl" if backend == "nccl" else backend) if dist is not None else None,
+                  "utt_per_s": world * R * 2 * B / (ms_ex * 1e-3)}
+          log(f"meta-step: {ms_ex:.2f} ms with exchange, {ms_no:.2f} ms without, isolated all-reduce {ar_ms}")
+          # ---- the same meta-step as pretrain.py --tasks_per_gpu K runs it: the K tasks of a rank concurrently on their slots (host
+          # thread + stream each, slot 0 on the default stream), the meta update reading the K gradient buffers in one pass
+          # (one rank) or their local sum all-reduced first (several ranks); no host sync between meta-steps
+          if K > 1:
+              main = torch.cuda.current_stream(dev)
 
-            def task_body(t):
-                with torch.cuda.stream(t.stream):
-                    e = t.eng
-                    e.copy(e.params, orig)
-                    e.mark_dirty()
-                    e.run_batch(t.xs, t.il, t.ys, t.ol, train=True)
-                    e.clip_sgd_step(t.mom, 5.0, lr, 0.9, True, first_step=True)
-                    e.run_batch(t.xs, t.il, t.ys, t.ol, train=True)
-                    e.clip_grads(5.0)
+              def task_body(t):
+                  with torch.cuda.stream(t.stream):
+                      e = t.eng
+                      e.copy(e.params, orig)
+                      e.mark_dirty()
+                      e.run_batch(t.xs, t.il, t.ys, t.ol, train=True)
+                      e.clip_sgd_step(t.mom, 5.0, lr, 0.9, True, first_step=True)
+                      e.run_batch(t.xs, t.il, t.ys, t.ol, train=True)
+                      e.clip_grads(5.0)
 
-            def meta_step_slots(i):
-                ths = []
-                for t in tasks:
-                    if t.stream != main:
-                        t.stream.wait_stream(main)
-                    th = threading.Thread(target=task_body, args=(t,))
-                    th.start(); ths.append(th)
-                for th in ths:
-                    th.join()
-                for t in tasks:
-                    if t.stream != main:
-                        main.wait_stream(t.stream)
-                if dist is None:
-                    eng.adam_sum_step(orig, [t.eng.grads for t in tasks], 1.0 / K, ea, eas, 1e-7, 0.9, 0.98, 1e-9, i + 1)
-                else:
-                    total.zero_()
-                    for t in tasks:
-                        eng.axpy(total, t.eng.grads, 1.0)
-                    if backend == "nccl":
-                        sharder.reduce_async(total)
-                        sharder.wait_all()
-                    else:
-                        all_reduce_(total)
-                    eng.scale(total, 1.0 / (K * world))
-                    eng.adam_step(orig, total, ea, eas, 1e-7, 0.9, 0.98, 1e-9, i + 1)
-            for i in range(2):
-                meta_step_slots(i)
-            barrier()
-            t1 = time.perf_counter()
-            for i in range(nmeta):
-                meta_step_slots(2 + i)
-            barrier()
-            d = time.perf_counter() - t1
-            if dist is not None:
-                tt = torch.tensor([d], device=coll_dev, dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                d = float(tt.item())
-            ms_k = d / nmeta * 1e3
-            meta["concurrent_slots"] = {"tasks_per_gpu": K, "tasks": K * world, "ms": ms_k, "utt_per_s": world * K * 2 * B / (ms_k * 1e-3),
-                                        "allreduces_per_meta_step": 1 if dist is not None else 0}
-            log(f"meta-step, {K} concurrent task slots: {ms_k:.2f} ms = {meta['concurrent_slots']['utt_per_s']:.0f} utt/s")
-            for t in tasks:
-                t.eng.copy(t.eng.params, orig)
-                t.eng.mark_dirty()
-        eng.copy(eng.params, orig)
-        eng.mark_dirty()
-        del contribs, total, ea, eas
+              def meta_step_slots(i):
+                  ths = []
+                  for t in tasks:
+                      if t.stream != main:
+                          t.stream.wait_stream(main)
+                      th = threading.Thread(target=task_body, args=(t,))
+                      th.start(); ths.append(th)
+                  for th in ths:
+                      th.join()
+                  for t in tasks:
+                      if t.stream != main:
+                          main.wait_stream(t.stream)
+                  if dist is None:
+                      eng.adam_sum_step(orig, [t.eng.grads for t in tasks], 1.0 / K, ea, eas, 1e-7, 0.9, 0.98, 1e-9, i + 1)
+                  else:
+                      total.zero_()
+                      for t in tasks:
+                          eng.axpy(total, t.eng.grads, 1.0)
+                      if backend == "nccl":
+                          sharder.reduce_async(total)
+                          sharder.wait_all()
+                      else:
+                          all_reduce_(total)
+                      eng.scale(total, 1.0 / (K * world))
+                      eng.adam_step(orig, total, ea, eas, 1e-7, 0.9, 0.98, 1e-9, i + 1)
+              for i in range(2):
+                  meta_step_slots(i)
+              barrier()
+              t1 = time.perf_counter()
+              for i in range(nmeta):
+                  meta_step_slots(2 + i)
+              barrier()
+              d = time.perf_counter() - t1
+              if dist is not None:
+                  tt = torch.tensor([d], device=coll_dev, dtype=torch.float64)
+                  dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                  d = float(tt.item())
+              ms_k = d / nmeta * 1e3
+              meta["concurrent_slots"] = {"tasks_per_gpu": K, "tasks": K * world, "ms": ms_k, "utt_per_s": world * K * 2 * B / (ms_k * 1e-3),
+                                          "allreduces_per_meta_step": 1 if dist is not None else 0}
+              log(f"meta-step, {K} concurrent task slots: {ms_k:.2f} ms = {meta['concurrent_slots']['utt_per_s']:.0f} utt/s")
+              for t in tasks:
+                  t.eng.copy(t.eng.params, orig)
+                  t.eng.mark_dirty()
+          eng.copy(eng.params, orig)
+          eng.mark_dirty()
+          del contribs, total, ea, eas
+      except Exception as ex:                                     # (the metric counts inner steps: an exchange leg that fails must not take the line down)
+        import traceback
+        log("meta-step leg FAILED: " + traceback.format_exc())
+        meta = {"error": f"{type(ex).__name__}: {ex}"}
 
     # ---- roofline: every conv launch of the step timed live with HIP events on the launch stream (one engine slot per
     # launch), the LONGEST launch is the "dominant kernel"; plus a per-class table (algorithmic GFLOP per step / measured ms)

@@ -110,6 +110,9 @@ int masr_clip_sgd_step(masr_model* m, float* momentum_buf, float max_norm, float
 int masr_clip_grads(masr_model* m, float max_norm, void* stream);
 /* _partial_meta_update after the val-batch clip (fo_meta_interface.py:148-154,180-198): updates += clip(grads) */
 int masr_clip_accumulate(masr_model* m, float* updates, float max_norm, void* stream);
+/* buf[0..n) *= min(1, max_norm / (*norm + 1e-6)) with the norm read from device memory (what masr_allreduce applies chunk by chunk, as one
+   pass: for transports that cannot pipeline it) */
+int masr_clip_scale_flat(float* buf, int64_t n, const float* norm, float max_norm, void* stream);
 
 /* flat helpers on arbitrary device buffers */
 int masr_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

@@ -43,6 +43,7 @@ _SIGS = {
     "masr_clip_sgd_step": (i32, [vp, vp, f32, f32, f32, i32, i32, vp]),
     "masr_clip_grads": (i32, [vp, f32, vp]),
     "masr_clip_accumulate": (i32, [vp, vp, f32, vp]),
+    "masr_clip_scale_flat": (i32, [vp, i64, vp, f32, vp]),
     "masr_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]),
     "masr_adam_step_guarded": (i32, [vp, vp, vp, vp, vp, i64, f32, i32, f32, i32, f32, f32, f32, f32, i32, i32, vp]),
     "masr_sum_n": (i32, [vp, vp, i32, f32, i64, vp]),

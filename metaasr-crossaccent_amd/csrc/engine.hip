@@ -1071,6 +1071,9 @@ int masr_clip_grads(masr_model* m, float max_norm, void* stream) {
     CK(masr_grad_norm(m, stream));
     return mk_clip_scale(m->G, m->nparams, m->stats + 3, max_norm, (hipStream_t)stream);
 }
+int masr_clip_scale_flat(float* buf, int64_t n, const float* norm, float max_norm, void* stream) {
+    return mk_clip_scale(buf, n, norm, max_norm, (hipStream_t)stream);
+}
 int masr_clip_accumulate(masr_model* m, float* updates, float max_norm, void* stream) {
     CK(masr_grad_norm(m, stream));
     return mk_clip_axpy(updates, m->G, m->nparams, m->stats + 3, max_norm, (hipStream_t)stream);

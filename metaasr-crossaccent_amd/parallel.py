@@ -100,9 +100,21 @@ class TaskSharder:
                 box[0] = raw.raw
             if self.world > 1:
                 dist.broadcast_object_list(box, src=0)
-            self._comm = L.masr_allreduce_init(self.rank, self.world, box[0])
-            if not self._comm:
-                raise _cabi.MasrError("masr_allreduce_init: " + L.masr_last_error().decode())
+            comm = L.masr_allreduce_init(self.rank, self.world, box[0]) if box[0] else None
+            # every rank must take the same transport: agree on the outcome (a rank whose init failed would otherwise wait for ever in
+            # the process group's collective while the others sit in ours)
+            ok = torch.tensor([1 if comm else 0], device=device, dtype=torch.int32)
+            if self.world > 1:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if not int(ok.item()):
+                err = L.masr_last_error().decode()
+                if comm:
+                    L.masr_allreduce_destroy(comm)
+                import warnings
+                warnings.warn(f"masr_allreduce_init failed on some rank ({err!r}): the meta-gradient goes through ProcessGroupNCCL instead")
+                self.native = False
+                return None
+            self._comm = comm
             self._L = L
         return self._comm
 
@@ -120,16 +132,22 @@ class TaskSharder:
         way out, chunk by chunk beside the collective (native path; elsewhere the scale pass runs first)."""
         if not self.collective:
             return
-        if self.native and buf.device.type == "cuda":
+        comm = self._native_comm(buf.device) if self.native and buf.device.type == "cuda" else None
+        if comm is not None:
             from . import _cabi
-            comm = self._native_comm(buf.device)
             norm, max_norm = clip if clip is not None else (None, 0.0)
             _cabi.check(self._L.masr_allreduce(comm, buf.data_ptr(), buf.numel(), norm, max_norm, self.nchunks,
                                                torch.cuda.current_stream(buf.device).cuda_stream), "masr_allreduce")
             self._native_issued = True
             return
         if clip is not None:
-            raise ValueError("clip= needs the native exchange (callers clip in place first on the other transports)")
+            # (the native exchange was asked for and is not available: the scale pass runs first, on the producer stream)
+            from . import _cabi
+            norm, max_norm = clip
+            L = _cabi.lib()
+            import ctypes as C
+            _cabi.check(L.masr_clip_scale_flat(buf.data_ptr(), buf.numel(), C.c_void_p(norm), max_norm,
+                                               torch.cuda.current_stream(buf.device).cuda_stream), "masr_clip_scale_flat")
         import torch.distributed as dist
         if buf.device.type == "cuda" and self.backend == "gloo":
             # rehearsal of the multi-rank path on a box with fewer GPUs than ranks (gloo has no device collectives worth the
