@@ -101,6 +101,9 @@ class TaskSharder:
             if self.world > 1:
                 dist.broadcast_object_list(box, src=0)
             comm = L.masr_allreduce_init(self.rank, self.world, box[0]) if box[0] else None
+            if comm and os.environ.get("MASR_TEST_FAIL_ALLREDUCE_INIT") == "1":      # (tests: the agreed fallback below)
+                L.masr_allreduce_destroy(comm)
+                comm = None
             # every rank must take the same transport: agree on the outcome (a rank whose init failed would otherwise wait for ever in
             # the process group's collective while the others sit in ours)
             ok = torch.tensor([1 if comm else 0], device=device, dtype=torch.int32)

@@ -59,6 +59,15 @@ def test_pretrain_cli_meta_steps_through_rccl_with_one_rank(golden_dir, tmp_path
     a, b = torch.load(tmp_path / "plain_r0.pt"), torch.load(tmp_path / "rccl_r0.pt")
     assert not a["collective"] and b["collective"] and b["backend"] == "nccl"
     assert b["native"] and not a["native"]                     # the exchange went through the C ABI (masr_allreduce), clip on the wire at K = 1
+    if tasks_per_gpu == 1:
+        # the communicator cannot be made (forced): every rank agrees to fall back to ProcessGroupNCCL, the clip that was to ride on
+        # the wire runs as one pass first -- same meta weights, bit for bit
+        fb = subprocess.run([sys.executable, worker, str(tmp_path), "fallback"] + extra, cwd=tmp_path,
+                            env=_env(MASR_FORCE_COLLECTIVE="1", MASR_TEST_FAIL_ALLREDUCE_INIT="1"), capture_output=True, text=True, timeout=420)
+        assert fb.returncode == 0, fb.stderr[-3000:]
+        c = torch.load(tmp_path / "fallback_r0.pt")
+        assert c["collective"] and not c["native"] and "ProcessGroupNCCL instead" in fb.stderr
+        assert torch.equal(c["meta"], a["meta"])
     assert a["step"] == b["step"] == 5
     # the same four task gradients; summed as (((0 + g0) + g1) + g2) + g3 either way at one task per GPU, as (g0 + g1) + (g2 + g3)
     # through the per-wave sums at two: fp32 rounding of the gradient only, Adam's step is <= lr = 3.2e-8 per element and meta-step
