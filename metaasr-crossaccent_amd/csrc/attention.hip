@@ -509,6 +509,9 @@ __device__ __forceinline__ void ring_issue(bf16* tile, const bf16* src, long ld,
         const int c = tid + i * NT, r = c >> 3;
         const int row = r0 + r < nrows ? r0 + r : nrows - 1;
         const bf16* g = src + (long)row * ld + (((c & 7) ^ (r & 7)) * 8);
+        // (behind this builtin the compiler drains the ring -- s_waitcnt vmcnt(0) -- in front of the first ds_read_b64_tr_b16 of a block,
+        // common.h glds16; with the asm form instead the encoder / decoder attention slots measured the same, 105 / 200 us: four key
+        // blocks per sequence, nothing left in flight to lose.  The encoder-row weight-gradient GEMM is where it mattered.)
         __builtin_amdgcn_global_load_lds((gptr_t*)g, (lptr_t*)(tile + (wave * 64 + i * NT) * 8), 16, 0, 0);
     }
 }

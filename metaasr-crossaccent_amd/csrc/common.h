@@ -32,6 +32,20 @@ __device__ __forceinline__ bf16x8 zero8() {
 __device__ __forceinline__ bf16x8 ld8(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
 __device__ __forceinline__ void st8(bf16* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
 
+// one LDS-DMA instruction (global_load_lds_dwordx4: lane l's 16 bytes land at lds_dst + 16 l; lds_dst = LDS byte address, wave-uniform),
+// written in asm so that the compiler does not know an LDS write is pending: behind a __builtin_amdgcn_global_load_lds it puts
+// `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 (not in front of plain ds_read_b128), which drains a DMA ring at the first
+// transposing fragment read of each step.  The kernel's own counted s_waitcnt vmcnt(N) + barrier must then order every LDS read behind
+// the DMA that feeds it; the compiler's counted waits for its own loads can only over-wait beside these (vmcnt retires in order).
+__device__ __forceinline__ void glds16(const void* g, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {            // LDS byte address of a pointer into __shared__ (wave-uniform p)
+    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) const void*)p);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -451,7 +451,6 @@ struct StagerRMT {
     }
 };
 constexpr int W8_LDS = 2 * (int)sizeof(TileRM<128>) + 2 * (int)sizeof(TileRM<256>);
-constexpr int W16_LDS = 4 * (int)sizeof(TileRM<256>);
 #ifndef MASR_W8_PARTS
 #define MASR_W8_PARTS 4
 #endif
@@ -577,10 +576,229 @@ __global__ __launch_bounds__(512) void gemm_wgrad_grouped8_kernel(WgradGroup grp
     else if (bx * 256 + part * PW < d.K) wgrad8_tile<PW>(d, by * 128, bx * 256 + part * PW, d.db != nullptr && bx == 0 && part == 0, smem);
 }
 
-// 256 x 256 tiles (2 x 4 waves of 128 x 64): taken when the whole group is at most ONE round of the CUs in such tiles (hkust: 148).
-// A third fewer operand bytes per FLOP than 128 x 256, no partial round, and fewer CUs drawing on the L2s at once.
+// ---- 256 x 256 tiles (2 x 4 waves of 128 x 64) with LDS-DMA staging: taken when the whole group is at most ONE round of the CUs in such
+// tiles (hkust: 148).  A third fewer operand bytes per FLOP than 128 x 256, no partial round, fewer CUs drawing on the L2s at once.
+// The register-staged form of this tile (wgrad8_tile<256, 256>, rounds 3-4) spent, per 64 reduction rows and thread, 8 global loads with
+// ~10 vector instructions of clamping each, 8 ds_write_b128 and 64 staging registers (251 VGPRs in all) beside its 64 MFMAs and ran at
+// 2.06 us per 64 rows against 0.86 of MFMA time (132 us in the engine).  Here the tiles go L2 -> LDS by global_load_lds_dwordx4 (no
+// VGPRs, no LDS stores) into a ring of four 32-row stages; a super-step multiplies two of them while the next two travel (114 us).
+// LDS image of an operand tile [32 k][256 cols]: 4 x 4 sub-tiles of [8 k][64 cols] = 1 KiB = ONE DMA instruction (lane l -> k row l >> 3,
+// 16-byte chunk l & 7); inside a sub-tile, chunk c of row r sits at chunk position c ^ r (applied to the SOURCE address: the image must be
+// lane-linear).  The transposing fragment read (ds_read_b64_tr_b16: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3)
+// then finds the 8 rows of a 32-lane half in 8 different chunk positions, odd and even rows in different bank halves: conflict-free
+// (SQ_LDS_BANK_CONFLICT 0).  Reduction rows past the end are zeroed in LDS after they land; rows / columns past the matrix edge are
+// clamped re-reads whose products are never stored.
+// What each piece bought, same box, engine launch / 128-tile probe (tools/wgrad_probe.py): DMA through the builtin, two 64-row stages,
+// __syncthreads: 180 us (the compiler drains the DMAs in front of the first fragment read, see glds16); asm DMA + four-stage ring, barrier per
+// 32 rows: 121 / 121; super-steps of 64 rows: - / 118; fragment reads three steps ahead + bias MFMAs spread over the waves: 122 / 110;
+// DMA issue spread over steps 0..7: 122 / 99; L2 prefetch three super-steps ahead: 114 / 104; 16-byte dW stores through LDS: 114 / 102.
+// The MFMA floor is 54 us; the loop alone (no DMA) runs at 87, the DMAs alone at 50.
+constexpr int W16_BK = 32, W16_NST = 4;                               // reduction rows per k tile, LDS stages (NST - 1 tiles in flight)
+constexpr int W16_OP = W16_BK * 256 * 2, W16_STAGE = 2 * W16_OP;    // one operand tile 16 KiB, one stage (dY | X) 32 KiB
+__device__ __forceinline__ int w16_off(int k, int col) {               // byte offset of element (k, col) inside an operand tile image
+    const int r = k & 7, c = (col & 63) >> 3;
+    return ((k >> 3) * 4 + (col >> 6)) * 1024 + r * 128 + ((c ^ r) << 4) + ((col & 7) << 1);
+}
+// fragment of 16 columns starting at r0 (a multiple of 16), k = 0 .. 31.  The lane-dependent part of the address is one of FOUR values
+// (`loff[(r0 >> 4) & 3]`: which 16 columns of a 64-column sub-tile) shared by both operands and both k halves -- everything else is a
+// constant added to it (kept explicit: left to the compiler the loop-invariant addresses were hoisted into registers and spilled)
+__device__ __forceinline__ bf16x8 w16_frag(const char* tile, int r0, const int (&loff)[4]) {
+    typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+    const char* a = tile + loff[(r0 >> 4) & 3] + (r0 >> 6) * 1024;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)a);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(a + 2 * 4 * 1024));       // 16 k rows = two sub-tile rows down
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+__device__ __forceinline__ void wgrad16_tile(const WgradDesc& d, const int m0, const int n0, const bool do_colsum, char* smem) {
+    constexpr int FM = 8, FN = 4;                                        // wave tile 128 x 64
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
+    const int M = d.N, N = d.K, K = d.rows;
+    const int nk = (K + W16_BK - 1) / W16_BK;
+    // this wave's DMA pieces of a k tile: waves 0-3 the dY tile, 4-7 the X tile; k rows 8 (w & 3) .. + 7, the four 64-column blocks;
+    // lane -> (row, chunk) of the sub-tile, source chunk = chunk ^ row
+    const int sop = wave >> 2, sr = lane >> 3, sc = (lane & 7) ^ sr;
+    const bf16* src[4];
+    const long sld = sop ? d.ldx : d.lddy;
+    {
+        const int last = ((sop ? N : M) + 7) / 8 * 8 - 8;                // last 16-byte chunk of a row (the padded row exists)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int c = (sop ? n0 : m0) + j * 64 + sc * 8;
+            c = c < last ? c : last;
+            src[j] = (sop ? d.x : d.dy) + c;
+        }
+    }
+    const int krow = (wave & 3) * 8 + sr;
+    const unsigned dst0 = lds_addr(smem) + sop * W16_OP + (wave & 3) * 4 * 1024;
+    auto stage = [&](int kt) {                                           // (rows past the end of the reduction are clamped re-reads: zeroed after landing)
+        const unsigned st = dst0 + (kt % W16_NST) * W16_STAGE;
+        long row = (long)kt * W16_BK + krow;
+        row = row < K ? row : K - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(src[j] + row * sld, st + j * 1024);
+    };
+    f32x4 acc[FM][FN];
+    // bias gradient = row sums of the dY tile: dY fragments x ones on the matrix cores, each of the four waves of a row half taking two
+    // of its eight fragments (2 wn, 2 wn + 1), re-read at the end of a super-step (one uniform branch there, none inside the pipeline)
+    f32x4 accs[2];
+    accs[0] = accs[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+    int loff[4], csoff[2];
+    {
+        const int g = lane >> 4, ii = lane & 15, q = ii >> 2, p = ii & 3, rowq = 4 * g + q, r = rowq & 7;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) loff[c4] = (rowq >> 3) * 4 * 1024 + r * 128 + (((c4 * 2 + (p >> 1)) ^ r) << 4) + (p & 1) * 8;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int fi = 2 * wn + e;                                   // fragment of the row half: columns wm * 128 + fi * 16 of the dY tile
+            csoff[e] = (rowq >> 3) * 4 * 1024 + r * 128 + ((((fi & 3) * 2 + (p >> 1)) ^ r) << 4) + (p & 1) * 8 + (wm * 2 + (fi >> 2)) * 1024;
+        }
+    }
+    // super-steps of two k tiles (64 reduction rows, 64 MFMAs per wave between barriers): tiles 2s and 2s + 1 are multiplied while
+    // 2s + 2 and 2s + 3 (issued right after the barrier, into the buffers of the super-step before) travel
+    const int ns = (nk + 1) / 2;
+    // L2 prefetch W16_PD super-steps ahead (operands that no cache holds take longer than one super-step to arrive): one dword load
+    // per thread and super-step, one 128-byte line each (2 operands x 64 rows x 4 lines), never read.  It is issued AFTER the
+    // super-step's DMAs and the loop waits with vmcnt(1): the youngest prefetch stays in flight across the barrier.
+    constexpr int W16_PD = 3;                                           // (2..4 alike, 6 slower, none: +8 % on the engine's launch)
+    const bf16* pf_src; long pf_ld; int pf_row;
+    {
+        const int op = tid >> 8, line = tid & 3;
+        pf_row = (tid >> 2) & 63;
+        const int last = ((op ? N : M) + 7) / 8 * 8 - 8;
+        int col = (op ? n0 : m0) + line * 64;
+        col = col < last ? col : last;
+        pf_src = (op ? d.x : d.dy) + col; pf_ld = op ? d.ldx : d.lddy;
+    }
+    int pf_sink = 0;
+    auto prefetch = [&](int s2) {
+        long row = (long)s2 * 2 * W16_BK + pf_row;
+        row = row < K ? row : K - 1;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(pf_src + row * pf_ld) : "memory");
+    };
+    stage(0); stage(1);
+    prefetch(W16_PD - 1);
+    for (int ss = 0; ss < ns; ++ss) {
+        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                 // this wave's pieces of tiles 2s, 2s + 1 (the prefetch behind them may still travel)
+        __builtin_amdgcn_s_barrier();                                    // everyone's; and everyone is done reading the other two buffers
+        // the next two tiles' DMAs go out one per step during steps 0..7 (as a burst in front of the first fragment reads they cost
+        // every wave ~800 cycles of issue before its first MFMA)
+        long roff[2]; unsigned sdst[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kt = 2 * ss + 2 + h;
+            long row = (long)kt * W16_BK + krow;
+            row = row < K ? row : K - 1;
+            roff[h] = row * sld;
+            sdst[h] = dst0 + (kt % W16_NST) * W16_STAGE;
+        }
+        char* t0 = smem + (ss & 1) * 2 * W16_STAGE;
+        if (ss == ns - 1 && K - 2 * ss * W16_BK < 2 * W16_BK) {
+            // the last super-step holds fewer than 64 valid rows: zero the others (clamped re-reads of the last row), once
+            const int valid = K - 2 * ss * W16_BK;
+            for (int c = tid; c < 2 * 2 * W16_BK * 32; c += 512) {
+                const int h = c / (2 * W16_BK * 32), op = (c / (W16_BK * 32)) & 1, k = (c >> 5) % W16_BK, ch = c & 31;
+                if (h * W16_BK + k >= valid) *reinterpret_cast<bf16x8*>(t0 + h * W16_STAGE + op * W16_OP + w16_off(k, ch * 8)) = zero8();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        // 16 steps of one dY fragment x four X fragments (two k tiles of eight); fragment reads run three steps ahead through a ring of
+        // four, the second tile's X fragments arrive during steps 4..7
+        const char* ab0 = t0; const char* bb0 = t0 + W16_OP;
+        const char* ab1 = t0 + W16_STAGE; const char* bb1 = ab1 + W16_OP;
+        bf16x8 b0[FN], b1[FN], ar[4];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) b0[j] = w16_frag(bb0, wn * 64 + j * 16, loff);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) ar[t] = w16_frag(ab0, wm * 128 + t * 16, loff);
+        // (the order is pinned: left alone, the scheduler folds the ring into one fragment that is read and used at once)
+#define W16_STEP(t)                                                                                                                    \
+        {                                                                                                                               \
+            if ((t) + 3 < 16) ar[((t) + 3) & 3] = w16_frag(((t) + 3) >> 3 ? ab1 : ab0, wm * 128 + (((t) + 3) & 7) * 16, loff);        \
+            if ((t) >= 4 && (t) < 8) b1[((t) - 4) & 3] = w16_frag(bb1, wn * 64 + (((t) - 4) & 3) * 16, loff);                           \
+            _Pragma("unroll") for (int j = 0; j < FN; ++j) acc[(t) & 7][j] = mma16(ar[(t) & 3], (t) >> 3 ? b1[j] : b0[j], acc[(t) & 7][j]); \
+            if ((t) < 8) glds16(src[(t) & 3] + roff[(t) >> 2], sdst[(t) >> 2] + ((t) & 3) * 1024);                                    \
+            if ((t) == 8) prefetch(ss + W16_PD);                                                                                       \
+            __builtin_amdgcn_sched_group_barrier(0x100, ((t) + 3 < 16 ? 2 : 0) + ((t) >= 4 && (t) < 8 ? 2 : 0), 0);                     \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                                          \
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
+        W16_STEP(0) W16_STEP(1) W16_STEP(2) W16_STEP(3) W16_STEP(4) W16_STEP(5) W16_STEP(6) W16_STEP(7)
+        W16_STEP(8) W16_STEP(9) W16_STEP(10) W16_STEP(11) W16_STEP(12) W16_STEP(13) W16_STEP(14) W16_STEP(15)
+#undef W16_STEP
+        if (do_colsum) {
+            typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const char* a = (kc ? ab1 : ab0) + csoff[e];
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)a);
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(a + 2 * 4 * 1024));
+                    bf16x8 f;
+                    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+                    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+                    accs[e] = mma16(f, ones, accs[e]);
+                }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink)::"memory");        // the read-ahead past the last tile lands before the LDS is released
+    const int fq = lane >> 4, fr = lane & 15;
+    if (do_colsum && fr == 0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int m = m0 + wm * 128 + (2 * wn + e) * 16 + fq * 4 + r; if (m < M) d.db[m] = accs[e][r]; }
+    }
+    if ((N & 3) == 0 && (reinterpret_cast<size_t>(d.dW) & 15) == 0) {
+        // dW rows in whole 256-byte runs: the wave's 128 x 64 block goes through LDS 32 rows at a time (row pitch 68 floats: the four row
+        // groups of a fragment land in different banks) and leaves as 16-byte stores, 16 lanes per row (as dword stores straight from
+        // the fragments the 148 tiles' 39 MB took ~7 us of store issue at the end of the launch)
+        __builtin_amdgcn_s_barrier();                                    // every wave's read-ahead has landed: the LDS is free
+        float* st = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+#pragma unroll
+        for (int c = 0; c < FM / 2; ++c) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) st[(ii * 16 + fq * 4 + r) * 68 + j * 16 + fr] = acc[2 * c + ii][j][r];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int row = k * 4 + fq, m = m0 + wm * 128 + c * 32 + row, n = n0 + wn * 64 + fr * 4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(st + row * 68 + fr * 4);
+                if (m < M && n < N) *reinterpret_cast<f32x4*>(d.dW + (long)m * N + n) = v;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * 128 + i * 16 + fq * 4 + r;
+            if (m >= M) continue;
+            float* row = d.dW + (long)m * N;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) { const int n = n0 + wn * 64 + j * 16 + fr; if (n < N) row[n] = acc[i][j][r]; }
+        }
+}
 __global__ __launch_bounds__(512) void gemm_wgrad_grouped16_kernel(WgradGroup grp) {
-    __shared__ __attribute__((aligned(16))) char smem[W16_LDS];
+    __shared__ __attribute__((aligned(1024))) char smem[W16_NST * W16_STAGE];
     // XCD-contiguous runs of the tile list (workgroup ids are dealt round-robin to the 8 XCDs; bijective for any tile count): the tiles
     // that share a dY / X panel meet in ONE L2 -- 507 MB of HBM traffic without this, 2.1 x the algorithmic bytes
     const int total = gridDim.x, l = blockIdx.x, xc = l & 7, q8 = total >> 3, r8 = total & 7;
@@ -590,7 +808,7 @@ __global__ __launch_bounds__(512) void gemm_wgrad_grouped16_kernel(WgradGroup gr
     const WgradDesc& d = grp.p[p];
     const int t = t_ - d.tile_start, tiles_x = (d.K + 255) / 256;
     const int bx = t % tiles_x, by = t / tiles_x;
-    wgrad8_tile<256, 256>(d, by * 256, bx * 256, d.db != nullptr && bx == 0, smem);
+    wgrad16_tile(d, by * 256, bx * 256, d.db != nullptr && bx == 0, smem);
 }
 
 #undef HAS
