@@ -2047,7 +2047,7 @@ constexpr int W2_TOTAL_WG = 256;    // one persistent workgroup per CU (see mk_c
 // POOLED: the dy tile comes from ConvWgradArgs::dy_pooled + pool_idx: a thread fetches ONE pooled cell x 8 channels (16 B + 8 B of codes) and
 // stages the four positions of its window (4 + 0 instead of 4 x 16-byte loads per thread and tile)
 template <int CIN, int COUT, int OCC, int W2_TW, bool POOLED = false>
-__global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs a, int nwg, int ntiles, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(OCC == 1 ? 512 : 256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs a, int nwg, int ntiles, int tiles_x, int tiles_y) {
     constexpr int W2_TH = 128 / W2_TW, W2_PH = W2_TH + 2, W2_PW = W2_TW + 2, RPS = 32 / W2_TW;      // RPS = pixel rows per 32-pixel slab
     constexpr int KTOT = 9 * CIN;
     constexpr int NPCH = (W2_PH * W2_PW * 8 + 255) / 256;   // patch chunks per thread (6)
@@ -2058,7 +2058,11 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs 
     __shared__ __attribute__((aligned(16))) bf16 patch_[NB * PATCH_EL];
     __shared__ __attribute__((aligned(16))) bf16 dyt_[NB * DYT_EL];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // OCC 1: 512 threads in two roles -- waves 0-3 multiply (wave w: input channels 16 w ..), waves 4-7 fetch and stage the next tile; each SIMD
+    // holds one wave of each role, so a tile's ~220 vector instructions of staging (pooled-dy expansion, zero fill, LDS stores, address
+    // arithmetic) and its load waits run BESIDE the MFMAs instead of in front of them in the same wave.  tid = index inside the role.
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const bool producer = OCC == 1 && threadIdx.x >= 256;
     const int cs = blockIdx.y % (CIN / 64), ch = blockIdx.y / (CIN / 64);
     const int H = a.H, W = a.W;
 
@@ -2157,115 +2161,140 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs 
     // wave w owns input channels 16w .. 16w+15 x all 64 output channels x 9 taps: the four dy fragments of a pixel slab are
     // tap-independent (read once per slab), only ONE x fragment is read per tap: 26 transposing reads per 36 MFMAs
     // (the 2 x 2 wave grid needed 40)
-    f32x4 acc[9][4];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     typedef __attribute__((address_space(3))) bf16x4 lds_b4;
     const int g = lane >> 4, q = (lane & 15) >> 2, p4 = (lane & 3) * 4;
-
-    int tile = blockIdx.x, it = 0;
     const float dbm1 = do_db ? 1.f : 0.f;
-    if (OCC == 1 && tile < ntiles) { load_tile(tile); store_tile(patch_, dyt_, dbm1); load_tile(tile + nwg); }
-    __syncthreads();
-    for (; tile < ntiles; tile += nwg, ++it) {
-        const bool has_next = tile + nwg < ntiles;
-        const bf16* patch = patch_ + (OCC == 1 ? (it & 1) * PATCH_EL : 0);
-        const bf16* dyt = dyt_ + (OCC == 1 ? (it & 1) * DYT_EL : 0);
-        if constexpr (OCC == 1) {
-            // the registers hold tile + nwg (requested a whole MFMA phase ago): into the OTHER buffer now (last read before the barrier that
-            // ended the previous tile), then request tile + 2 nwg; both run under this tile's MFMAs
-            // (behind the last tile the registers hold a clamped re-read: staged into the buffer nobody reads any more, not counted)
-            store_tile(patch_ + ((it + 1) & 1) * PATCH_EL, dyt_ + ((it + 1) & 1) * DYT_EL, has_next ? dbm1 : 0.f);
-            load_tile(tile + 2 * nwg);                           // (clamped when past the end)
+    float* red = reinterpret_cast<float*>(patch_);                        // bias-gradient partials [256][8] floats = 8 KB (after the last tile)
+
+    auto read_a = [&](const bf16* dyt, int kc, bf16x8 (&af)[4]) {
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm) {
+            const bf16* a0 = dyt + (kc * 32 + 4 * g + q) * W2_LDY + fm * 16 + p4;
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)a0);
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(a0 + 16 * W2_LDY));
+            af[fm][0] = lo[0]; af[fm][1] = lo[1]; af[fm][2] = lo[2]; af[fm][3] = lo[3];
+            af[fm][4] = hi[0]; af[fm][5] = hi[1]; af[fm][6] = hi[2]; af[fm][7] = hi[3];
+        }
+    };
+    auto read_b = [&](const bf16* patch, int kc, int tap) {
+        const int dyi = tap / 3, dxj = tap % 3;
+        const int pi = 4 * g + q;                               // pixel of the slab's first half this lane addresses
+        const bf16* b0 = patch + ((RPS * kc + pi / W2_TW + dyi) * W2_PW + pi % W2_TW + dxj) * W2_PS + wave * 16 + p4;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)b0);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(b0 + (16 / W2_TW) * W2_PW * W2_PS));
+        bf16x8 bfr;
+        bfr[0] = lo[0]; bfr[1] = lo[1]; bfr[2] = lo[2]; bfr[3] = lo[3];
+        bfr[4] = hi[0]; bfr[5] = hi[1]; bfr[6] = hi[2]; bfr[7] = hi[3];
+        return bfr;
+    };
+    // wave w owns input channels 16w .. 16w+15 x all 64 output channels x 9 taps: the four dy fragments of a pixel slab are
+    // tap-independent (read once per slab), only ONE x fragment is read per tap: 26 transposing reads per 36 MFMAs
+    // (the 2 x 2 wave grid needed 40)
+    auto write_slab = [&](f32x4 (&acc)[9][4]) {
+        float* out = a.slab + (long)blockIdx.x * COUT * KTOT;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = ch * 64 + fm * 16 + (lane >> 4) * 4 + r;
+                    const int ci = cs * 64 + wave * 16 + (lane & 15);
+                    out[(long)co * KTOT + tap * CIN + ci] = acc[tap][fm][r];
+                }
+    };
+    auto fold_db = [&]() {                                       // threads with equal tid % 8 own the same 8 output channels
+        const int rc = tid / 8, j = tid % 8;
+        float sum = 0.f;
+        for (int t = rc; t < 256; t += 8) sum += red[t * 8 + j];
+        a.slab[(long)nwg * COUT * KTOT + (long)blockIdx.x * COUT + ch * 64 + tid] = sum;
+    };
+
+    if constexpr (OCC == 1) {
+        // The two roles are two separate loops with the SAME sequence of barriers (one in front of the first tile, one behind every tile,
+        // one behind the bias partials): the accumulators live only in the consumers' branch and the staging registers only in the
+        // producers', so one register budget (256 per thread at two waves per SIMD) holds either.
+        const int first = blockIdx.x, niter = first < ntiles ? (ntiles - first + nwg - 1) / nwg : 0;
+        if (producer) {
+            if (niter) { load_tile(first); store_tile(patch_, dyt_, dbm1); load_tile(first + nwg); }
+            __syncthreads();
+            for (int it = 0; it < niter; ++it) {
+                // the registers hold tile it + 1 (requested a whole tile ago): into the buffer the consumers are NOT reading, then request
+                // tile it + 2 (behind the last tile: a clamped re-read into the buffer nobody reads any more, not counted)
+                const int tile = first + it * nwg;
+                store_tile(patch_ + ((it + 1) & 1) * PATCH_EL, dyt_ + ((it + 1) & 1) * DYT_EL, tile + nwg < ntiles ? dbm1 : 0.f);
+                load_tile(tile + 2 * nwg);
+                __syncthreads();
+            }
+            if (do_db) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) red[tid * 8 + j] = csum[j];
+            }
+            __syncthreads();
         } else {
-            // two workgroups per CU: no register prefetch (it would spill at 256 VGPRs); the co-resident workgroup's MFMA
-            // phase covers this one's load + staging
+            f32x4 acc[9][4];
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            __syncthreads();
+            for (int it = 0; it < niter; ++it) {
+                const bf16* patch = patch_ + (it & 1) * PATCH_EL;
+                const bf16* dyt = dyt_ + (it & 1) * DYT_EL;
+                // the x fragment of the NEXT tap (and the dy fragments of the next pixel slab) are requested before the current tap's MFMAs
+                bf16x8 af[2][4];
+                read_a(dyt, 0, af[0]);
+                bf16x8 bcur = read_b(patch, 0, 0);
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        bf16x8 bnext = bcur;
+                        if (tap < 8) bnext = read_b(patch, kc, tap + 1);
+                        else if (kc < 3) bnext = read_b(patch, kc + 1, 0);
+                        if (tap == 4 && kc < 3) read_a(dyt, kc + 1, af[(kc + 1) & 1]);
+#pragma unroll
+                        for (int fm = 0; fm < 4; ++fm) acc[tap][fm] = mma16(af[kc & 1][fm], bcur, acc[tap][fm]);
+                        bcur = bnext;
+                    }
+                }
+                __syncthreads();
+            }
+            write_slab(acc);
+            __syncthreads();
+            if (do_db && tid < 64) fold_db();
+        }
+    } else {
+        // two workgroups per CU (MASR_WGRAD_OCC=2): one tile buffer, no register prefetch (it would spill at 256 VGPRs); the co-resident
+        // workgroup's MFMA phase covers this one's load + staging
+        f32x4 acc[9][4];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        for (int tile = blockIdx.x; tile < ntiles; tile += nwg) {
             load_tile(tile); store_tile(patch_, dyt_, dbm1);
             __syncthreads();
-        }
-        auto read_a = [&](int kc, bf16x8 (&af)[4]) {
 #pragma unroll
-            for (int fm = 0; fm < 4; ++fm) {
-                const bf16* a0 = dyt + (kc * 32 + 4 * g + q) * W2_LDY + fm * 16 + p4;
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)a0);
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(a0 + 16 * W2_LDY));
-                af[fm][0] = lo[0]; af[fm][1] = lo[1]; af[fm][2] = lo[2]; af[fm][3] = lo[3];
-                af[fm][4] = hi[0]; af[fm][5] = hi[1]; af[fm][6] = hi[2]; af[fm][7] = hi[3];
-            }
-        };
-        auto read_b = [&](int kc, int tap) {
-            const int dyi = tap / 3, dxj = tap % 3;
-            const int pi = 4 * g + q;                           // pixel of the slab's first half this lane addresses
-            const bf16* b0 = patch + ((RPS * kc + pi / W2_TW + dyi) * W2_PW + pi % W2_TW + dxj) * W2_PS + wave * 16 + p4;
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)b0);
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(b0 + (16 / W2_TW) * W2_PW * W2_PS));
-            bf16x8 bfr;
-            bfr[0] = lo[0]; bfr[1] = lo[1]; bfr[2] = lo[2]; bfr[3] = lo[3];
-            bfr[4] = hi[0]; bfr[5] = hi[1]; bfr[6] = hi[2]; bfr[7] = hi[3];
-            return bfr;
-        };
-        if constexpr (OCC == 1) {
-            // one wave per SIMD: nobody else covers the LDS latency in front of each tap's four MFMAs, so the x fragment of the NEXT tap (and the
-            // dy fragments of the next pixel slab) are requested before the current tap's MFMAs issue
-            bf16x8 af[2][4];
-            read_a(0, af[0]);
-            bf16x8 bcur = read_b(0, 0);
-#pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {
+            for (int kc = 0; kc < 4; ++kc) {                         // slab of 32 pixels = RPS pixel rows
+                bf16x8 af[4];
+                read_a(dyt_, kc, af);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
-                    bf16x8 bnext = bcur;
-                    if (tap < 8) bnext = read_b(kc, tap + 1);
-                    else if (kc < 3) bnext = read_b(kc + 1, 0);
-                    if (tap == 4 && kc < 3) read_a(kc + 1, af[(kc + 1) & 1]);
+                    const bf16x8 bfr = read_b(patch_, kc, tap);
 #pragma unroll
-                    for (int fm = 0; fm < 4; ++fm) acc[tap][fm] = mma16(af[kc & 1][fm], bcur, acc[tap][fm]);
-                    bcur = bnext;
+                    for (int fm = 0; fm < 4; ++fm) acc[tap][fm] = mma16(af[fm], bfr, acc[tap][fm]);
                 }
             }
-            // (sched_group_barrier pipelines -- 36 groups of 4 MFMAs + 3 fragment reads + 8 vector instructions, the LDS writes and global loads
-            // spread over the first groups -- ran 10-20 % slower than hipcc's own order: 138-146 us against 121.)
-        } else {
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {                         // slab of 32 pixels = RPS pixel rows
-            bf16x8 af[4];
-            read_a(kc, af);
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const bf16x8 bfr = read_b(kc, tap);
-#pragma unroll
-                for (int fm = 0; fm < 4; ++fm) acc[tap][fm] = mma16(af[fm], bfr, acc[tap][fm]);
-            }
+            __syncthreads();
         }
-        }
-        __syncthreads();
-    }
-
-    float* out = a.slab + (long)blockIdx.x * COUT * KTOT;
+        write_slab(acc);
+        if (do_db) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int fm = 0; fm < 4; ++fm)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = ch * 64 + fm * 16 + (lane >> 4) * 4 + r;
-                const int ci = cs * 64 + wave * 16 + (lane & 15);
-                out[(long)co * KTOT + tap * CIN + ci] = acc[tap][fm][r];
-            }
-    if (do_db) {
-        // threads with equal tid % 8 own the same 8 output channels
-        float* red = reinterpret_cast<float*>(patch_);                // [256][8] floats = 8 KB
-#pragma unroll
-        for (int j = 0; j < 8; ++j) red[tid * 8 + j] = csum[j];
-        __syncthreads();
-        if (tid < 64) {
-            const int rc = tid / 8, j = tid % 8;
-            float sum = 0.f;
-            for (int t = rc; t < 256; t += 8) sum += red[t * 8 + j];
-            a.slab[(long)nwg * COUT * KTOT + (long)blockIdx.x * COUT + ch * 64 + tid] = sum;
+            for (int j = 0; j < 8; ++j) red[tid * 8 + j] = csum[j];
+            __syncthreads();
+            if (tid < 64) fold_db();
         }
     }
 }
@@ -2771,8 +2800,8 @@ int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s, int phase) {
         if (nwg > ntiles) nwg = ntiles;
         splits = nwg;
         dim3 grid(nwg, (a.CIN / 64) * (a.COUT / 64));
-#define W2T(CI, CO, OC, TWV) hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CI, CO, OC, TWV>), grid, dim3(256), 0, s, a, nwg, ntiles, tiles_x, tiles_y)
-#define W2P(CI, CO) { if (occ == 1) hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CI, CO, 1, 16, true>), grid, dim3(256), 0, s, a, nwg, ntiles, tiles_x, tiles_y); \
+#define W2T(CI, CO, OC, TWV) hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CI, CO, OC, TWV>), grid, dim3(OC == 1 ? 512 : 256), 0, s, a, nwg, ntiles, tiles_x, tiles_y)
+#define W2P(CI, CO) { if (occ == 1) hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CI, CO, 1, 16, true>), grid, dim3(512), 0, s, a, nwg, ntiles, tiles_x, tiles_y); \
                      else hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CI, CO, 2, 16, true>), grid, dim3(256), 0, s, a, nwg, ntiles, tiles_x, tiles_y); }
 #define W2(CI, CO) \
         if (occ == 1) { if (narrow) W2T(CI, CO, 1, 8); else W2T(CI, CO, 1, 16); } \
