@@ -2066,9 +2066,8 @@ __global__ __launch_bounds__(OCC == 1 ? 512 : 256, OCC) void conv3x3_wgrad2_kern
     const int cs = blockIdx.y % (CIN / 64), ch = blockIdx.y / (CIN / 64);
     const int H = a.H, W = a.W;
 
-    bf16x8 pr[NPCH], dr[NDCH];
-    uint2 pcode = {0u, 0u};
-    unsigned okp = 0, okd = 0;
+    // one tile's fetch, in registers between request and staging (OCC 1 keeps TWO of them in flight)
+    struct Stage { bf16x8 pr[NPCH], dr[NDCH]; uint2 pcode; unsigned okp, okd; };
     // Per-thread constants of the tile fetch: chunk i of the patch is pixel (ppi, ppj) relative to the tile origin (t0, d0) and sits prel
     // elements behind that pixel's address; per tile only the origin (wave-uniform: scalar ALU) and two range tests per chunk remain.  (With
     // the divisions, 64-bit multiplies and selects of the first version the fetch cost ~200 vector instructions per tile, which a lone
@@ -2090,36 +2089,36 @@ __global__ __launch_bounds__(OCC == 1 ? 512 : 256, OCC) void conv3x3_wgrad2_kern
     }
     const int pp_r = (tid >> 3) / (W2_TW / 2), pp_c = (tid >> 3) % (W2_TW / 2), H2 = H / 2, W2p = W / 2;
     const int pprel = (pp_r * W2p + pp_c) * COUT + (tid & 7) * 8;
-    auto load_tile = [&](int tile) {
+    auto load_tile = [&](Stage& S, int tile) {
         const int tc = tile < ntiles ? tile : ntiles - 1;
         const int tx = tc % tiles_x, ty = (tc / tiles_x) % tiles_y, b = tc / (tiles_x * tiles_y);
         const int t0 = ty * W2_TH, d0 = tx * W2_TW;
         const bf16* in_o = a.in + (((long)b * H + t0) * W + d0) * CIN + cs * 64;             // the tile's origin pixel (always inside the map)
-        okp = 0; okd = 0;
+        S.okp = 0; S.okd = 0;
 #pragma unroll
         for (int i = 0; i < NPCH; ++i) {
             const bool ok = (unsigned)(t0 + ppi[i]) < (unsigned)H && (unsigned)(d0 + ppj[i]) < (unsigned)W;
-            if (ok) okp |= 1u << i;
-            pr[i] = ld8(in_o + (ok ? prel[i] : (tid & 7) * 8));
+            if (ok) S.okp |= 1u << i;
+            S.pr[i] = ld8(in_o + (ok ? prel[i] : (tid & 7) * 8));
         }
         if constexpr (POOLED) {
             const int t2 = t0 / 2 + pp_r, d2 = d0 / 2 + pp_c;
             const bool ok = t2 < H2 && d2 < W2p;                            // (floor mode: the cropped last row / column gets no gradient)
-            if (ok) okd = 1u;
+            if (ok) S.okd = 1u;
             // (origin cell of the tile: inside the pooled map unless the map's last row / column is the cropped one -- then ok is false for
             // every cell of the tile and the clamped origin is read)
             const int t2o = t0 / 2 < H2 ? t0 / 2 : H2 - 1, d2o = d0 / 2 < W2p ? d0 / 2 : W2p - 1;
             const long po = (((long)b * H2 + t2o) * W2p + d2o) * COUT + ch * 64;
             const int rel = ok ? pprel : (tid & 7) * 8;
-            dr[0] = ld8(a.dy_pooled + po + rel);
-            pcode = *reinterpret_cast<const uint2*>(a.pool_idx + po + rel);
+            S.dr[0] = ld8(a.dy_pooled + po + rel);
+            S.pcode = *reinterpret_cast<const uint2*>(a.pool_idx + po + rel);
         } else {
             const bf16* dy_o = a.dy + (((long)b * H + t0) * W + d0) * COUT + ch * 64;
 #pragma unroll
             for (int i = 0; i < NDCH; ++i) {
                 const bool ok = t0 + dpi[i] < H && d0 + dpj[i] < W;
-                if (ok) okd |= 1u << i;
-                dr[i] = ld8(dy_o + (ok ? drel[i] : (tid & 7) * 8));
+                if (ok) S.okd |= 1u << i;
+                S.dr[i] = ld8(dy_o + (ok ? drel[i] : (tid & 7) * 8));
             }
         }
     };
@@ -2127,19 +2126,19 @@ __global__ __launch_bounds__(OCC == 1 ? 512 : 256, OCC) void conv3x3_wgrad2_kern
     const bool do_db = a.db != nullptr && cs == 0;
     // dbm: 1.0 when this tile's dy counts towards the bias gradient (branch-free: the fetch / staging / MFMA code of a tile is ONE basic block, so
     // that the scheduler can spread the vector work of the staging over the MFMA phase)
-    auto store_tile = [&](bf16* patch, bf16* dyt, float dbm) {
+    auto store_tile = [&](const Stage& S, bf16* patch, bf16* dyt, float dbm) {
 #pragma unroll
         for (int i = 0; i < NPCH; ++i) {
             const int c = tid + i * 256;
-            if (c < W2_PH * W2_PW * 8) st8(patch + (c >> 3) * W2_PS + (c & 7) * 8, (okp >> i) & 1 ? pr[i] : zero8());
+            if (c < W2_PH * W2_PW * 8) st8(patch + (c >> 3) * W2_PS + (c & 7) * 8, (S.okp >> i) & 1 ? S.pr[i] : zero8());
         }
         if constexpr (POOLED) {
             const int pp = tid >> 3, pr2 = pp / (W2_TW / 2), pc2 = pp % (W2_TW / 2);
             bf16x8 o[4];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const unsigned cj = ((j < 4 ? pcode.x : pcode.y) >> (8 * (j & 3))) & 0xffu;
-                const bf16 gj = okd ? dr[0][j] : (bf16)0.f;
+                const unsigned cj = ((j < 4 ? S.pcode.x : S.pcode.y) >> (8 * (j & 3))) & 0xffu;
+                const bf16 gj = S.okd ? S.dr[0][j] : (bf16)0.f;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k][j] = cj == (unsigned)k ? gj : (bf16)0.f;
                 csum[j] = fmaf(dbm, cj < 4u ? (float)gj : 0.f, csum[j]);
@@ -2150,7 +2149,7 @@ __global__ __launch_bounds__(OCC == 1 ? 512 : 256, OCC) void conv3x3_wgrad2_kern
 #pragma unroll
         for (int i = 0; i < NDCH; ++i) {
             const int c = tid + i * 256;
-            const bf16x8 v = (okd >> i) & 1 ? dr[i] : zero8();
+            const bf16x8 v = (S.okd >> i) & 1 ? S.dr[i] : zero8();
             st8(dyt + (c >> 3) * W2_LDY + (c & 7) * 8, v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) csum[j] = fmaf(dbm, (float)v[j], csum[j]);
@@ -2216,15 +2215,25 @@ __global__ __launch_bounds__(OCC == 1 ? 512 : 256, OCC) void conv3x3_wgrad2_kern
         // producers', so one register budget (256 per thread at two waves per SIMD) holds either.
         const int first = blockIdx.x, niter = first < ntiles ? (ntiles - first + nwg - 1) / nwg : 0;
         if (producer) {
-            if (niter) { load_tile(first); store_tile(patch_, dyt_, dbm1); load_tile(first + nwg); }
+            // TWO tiles in flight: a tile's loads are requested two tile periods before they are staged (with one, the producers alone ran
+            // at a memory round trip per tile, ~2 us, and set the pace of the launch).  Stage A carries the odd tiles of the walk, B the
+            // even ones; behind the last tile the registers hold clamped re-reads, staged into the buffer nobody reads any more, not counted.
+            Stage A, B;
+            A.pcode = B.pcode = uint2{0u, 0u};
+            if (niter) { load_tile(B, first); load_tile(A, first + nwg); store_tile(B, patch_, dyt_, dbm1); load_tile(B, first + 2 * nwg); }
             __syncthreads();
-            for (int it = 0; it < niter; ++it) {
-                // the registers hold tile it + 1 (requested a whole tile ago): into the buffer the consumers are NOT reading, then request
-                // tile it + 2 (behind the last tile: a clamped re-read into the buffer nobody reads any more, not counted)
+            for (int it = 0; it < niter; it += 2) {
+                // consumers read buffer it & 1 = 0: tile it + 1 (A) goes into buffer 1, then A requests tile it + 3
                 const int tile = first + it * nwg;
-                store_tile(patch_ + ((it + 1) & 1) * PATCH_EL, dyt_ + ((it + 1) & 1) * DYT_EL, tile + nwg < ntiles ? dbm1 : 0.f);
-                load_tile(tile + 2 * nwg);
+                store_tile(A, patch_ + PATCH_EL, dyt_ + DYT_EL, tile + nwg < ntiles ? dbm1 : 0.f);
+                load_tile(A, tile + 3 * nwg);
                 __syncthreads();
+                if (it + 1 < niter) {
+                    // consumers read buffer 1: tile it + 2 (B) goes into buffer 0, then B requests tile it + 4
+                    store_tile(B, patch_, dyt_, tile + 2 * nwg < ntiles ? dbm1 : 0.f);
+                    load_tile(B, tile + 4 * nwg);
+                    __syncthreads();
+                }
             }
             if (do_db) {
 #pragma unroll
@@ -2241,23 +2250,29 @@ __global__ __launch_bounds__(OCC == 1 ? 512 : 256, OCC) void conv3x3_wgrad2_kern
             for (int it = 0; it < niter; ++it) {
                 const bf16* patch = patch_ + (it & 1) * PATCH_EL;
                 const bf16* dyt = dyt_ + (it & 1) * DYT_EL;
-                // the x fragment of the NEXT tap (and the dy fragments of the next pixel slab) are requested before the current tap's MFMAs
-                bf16x8 af[2][4];
+                // 36 steps (4 pixel slabs x 9 taps) of one x fragment x four dy fragments.  One wave per SIMD multiplies, so nobody else
+                // covers the LDS latency: the x fragments run THREE steps ahead through a ring of four (one step = 4 MFMAs = 64 cycles; at
+                // one step ahead every tap waited ~a step for its fragment), the dy fragments of the next slab arrive during tap 4.
+                // The order is pinned (left alone the scheduler folds the ring into read-and-use-at-once).
+                bf16x8 af[2][4], br[4];
                 read_a(dyt, 0, af[0]);
-                bf16x8 bcur = read_b(patch, 0, 0);
 #pragma unroll
-                for (int kc = 0; kc < 4; ++kc) {
-#pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) {
-                        bf16x8 bnext = bcur;
-                        if (tap < 8) bnext = read_b(patch, kc, tap + 1);
-                        else if (kc < 3) bnext = read_b(patch, kc + 1, 0);
-                        if (tap == 4 && kc < 3) read_a(dyt, kc + 1, af[(kc + 1) & 1]);
-#pragma unroll
-                        for (int fm = 0; fm < 4; ++fm) acc[tap][fm] = mma16(af[kc & 1][fm], bcur, acc[tap][fm]);
-                        bcur = bnext;
-                    }
+                for (int t = 0; t < 3; ++t) br[t] = read_b(patch, 0, t);
+                __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
+#define CW_STEP(s_)                                                                                                                  \
+                {                                                                                                                    \
+                    constexpr int kc_ = (s_) / 9, tap_ = (s_) % 9;                                                                   \
+                    if ((s_) + 3 < 36) br[((s_) + 3) & 3] = read_b(patch, ((s_) + 3) / 9, ((s_) + 3) % 9);                              \
+                    if (tap_ == 4 && kc_ < 3) read_a(dyt, kc_ + 1, af[(kc_ + 1) & 1]);                                                \
+                    _Pragma("unroll") for (int fm = 0; fm < 4; ++fm) acc[tap_][fm] = mma16(af[kc_ & 1][fm], br[(s_) & 3], acc[tap_][fm]); \
+                    __builtin_amdgcn_sched_group_barrier(0x100, ((s_) + 3 < 36 ? 2 : 0) + (tap_ == 4 && kc_ < 3 ? 8 : 0), 0);         \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                               \
                 }
+                CW_STEP(0) CW_STEP(1) CW_STEP(2) CW_STEP(3) CW_STEP(4) CW_STEP(5) CW_STEP(6) CW_STEP(7) CW_STEP(8)
+                CW_STEP(9) CW_STEP(10) CW_STEP(11) CW_STEP(12) CW_STEP(13) CW_STEP(14) CW_STEP(15) CW_STEP(16) CW_STEP(17)
+                CW_STEP(18) CW_STEP(19) CW_STEP(20) CW_STEP(21) CW_STEP(22) CW_STEP(23) CW_STEP(24) CW_STEP(25) CW_STEP(26)
+                CW_STEP(27) CW_STEP(28) CW_STEP(29) CW_STEP(30) CW_STEP(31) CW_STEP(32) CW_STEP(33) CW_STEP(34) CW_STEP(35)
+#undef CW_STEP
                 __syncthreads();
             }
             write_slab(acc);
@@ -2272,9 +2287,11 @@ __global__ __launch_bounds__(OCC == 1 ? 512 : 256, OCC) void conv3x3_wgrad2_kern
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        Stage S;
+        S.pcode = uint2{0u, 0u};
         __syncthreads();
         for (int tile = blockIdx.x; tile < ntiles; tile += nwg) {
-            load_tile(tile); store_tile(patch_, dyt_, dbm1);
+            load_tile(S, tile); store_tile(S, patch_, dyt_, dbm1);
             __syncthreads();
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) {                         // slab of 32 pixels = RPS pixel rows
