@@ -701,6 +701,10 @@ def main():
             "pool": B * (H2 * W2 * 64 * 3 + T * D * 64 * 2 + (H2 // 2) * (W2 // 2) * 128 * 3 + H2 * W2 * 128 * 2),   # pooled gradient + codes in, dense map out
             "conv1_fwd": B * T * D * (4 + 64 * 2 + 8),   # fp32 input in, 64-channel bf16 map + one 64-bit word of ReLU sign bits per pixel out
         }
+        if prof_all["shadows"][0] == 0:
+            # the SGD step runs INSIDE the shadow launch (MASR_FUSED_SGD=1): p is read once; one pass, timed under `optim`
+            hbm_bytes["optim"] = NP * (4 + 20 + 4)
+            del hbm_bytes["shadows"]
         t_hbm = sum(prof_all[k][0] for k in hbm_bytes) / nprof * 1e-3
         b_hbm = float(sum(hbm_bytes.values()))
         per_class["other"].update({

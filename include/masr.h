@@ -79,6 +79,11 @@ void masr_set_step_graphs(masr_model* m, int on);
  * Default OFF -- it measured slower (every column-tile workgroup of a row block repeats the row work and they all hit the same L2
  * lines at once: DESIGN 6.0); MASR_LN_FUSION=1 in the environment or this switch turn it on for A/B runs and the parity test. */
 void masr_set_ln_fusion(masr_model* m, int on);
+/* masr_clip_sgd_step's update applied INSIDE the shadow-refresh launch (one pass over the parameters: p and g in, p and every bf16
+ * operand layout out) instead of an update pass followed by the refresh.  Same arithmetic, same bits.  Default OFF -- it measured slower
+ * (tile-shaped fp32 write-back against a flat stream: DESIGN 6.00); MASR_FUSED_SGD=1 in the environment or this switch turn it on for A/B
+ * runs and the parity test. */
+void masr_set_fused_sgd(masr_model* m, int on);
 void masr_step_counters(const masr_model* m, int64_t out[3]);
 /* out[0]=loss, out[1]=n_correct, out[2]=n_total, out[3]=last grad norm.  Synchronises the stream. */
 int masr_read_stats(masr_model* m, float out[4], void* stream);

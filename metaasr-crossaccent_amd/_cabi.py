@@ -33,6 +33,7 @@ _SIGS = {
     "masr_run_batch": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "masr_set_step_graphs": (None, [vp, i32]),
     "masr_set_ln_fusion": (None, [vp, i32]),
+    "masr_set_fused_sgd": (None, [vp, i32]),
     "masr_step_counters": (None, [vp, C.POINTER(i64)]),
     "masr_read_stats": (i32, [vp, C.POINTER(f32), vp]),
     "masr_stats_post": (i64, [vp, vp]),

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <algorithm>
 
 #include "../../include/masr.h"
 #include "kernels.h"
@@ -81,6 +82,7 @@ static const int WG_SPLIT_ENV = [] { const char* e = getenv("MASR_WG_SPLIT"); co
 
 }  // namespace
 
+constexpr int GAP_CHUNKS_MAX = 8192;        // (offset, length <= 2048) chunks of the parameters without a bf16 shadow (hkust: ~600)
 struct masr_model {
     masr_config cfg;
     int E, H, hd, Fi, NE, ND, C, Cp, D, Dp, F;
@@ -95,6 +97,14 @@ struct masr_model {
     bf16 *kv_k16 = nullptr, *kvT = nullptr; float* kv_bias = nullptr; int NK = 0;
     long* d_ranges = nullptr; int nranges = 0;            // split-K combine table: (offset, length) of every Linear weight / bias
     std::vector<ShadowJobs> shadows;                       // job list(s) of the operand-shadow refresh: one launch per <= SHADOW_JOBS_MAX jobs (hkust: one)
+    // masr_clip_sgd_step CAN apply its update inside that launch (mk_sgd_shadows: p and g in, p and every bf16 layout out, 28 instead
+    // of 32 bytes per parameter; the parameters no shadow job reads are these chunks).  Same bits (tests/test_hip_engine.py), but SLOWER:
+    // 165 us against 75 + 57 for the flat update pass and the refresh (hkust, momentum buffer read and written): the tiles' 256-byte
+    // row segments at arbitrary dword offsets make every fp32 write-back a partial-line store, where the flat pass streams whole lines
+    // (and neither the instruction count -- 17 lanes per row, one load per array and pass -- nor the 4 B/param matter beside that).
+    // Default OFF; MASR_FUSED_SGD=1 / masr_set_fused_sgd for A/B runs and the parity test.
+    long* d_gaps = nullptr; int ngaps = 0;
+    bool fuse_sgd = getenv("MASR_FUSED_SGD") != nullptr && atoi(getenv("MASR_FUSED_SGD")) != 0;
     float* stats = nullptr;                   // device [8]: loss, n_correct, n_total, grad_norm
     unsigned* conv_sched = nullptr;           // tile counters of the streaming conv kernel (this model's stream only)
     float* h_stats = nullptr;                 // pinned
@@ -202,6 +212,7 @@ void plan_persistent(masr_model* m, Arena& ar) {
     m->stats = ar.get<float>(64);
     m->conv_sched = ar.get<unsigned>(64);
     m->d_ranges = ar.get<long>((int64_t)split_chunks(m).size());
+    m->d_gaps = ar.get<long>(2 * GAP_CHUNKS_MAX);
 }
 
 // ------------------------------------------------------------------ activation plan
@@ -646,6 +657,30 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
         }
         m->nranges = (int)ranges.size() / 2;
         HIP_CHECK_RET(hipMemcpy(m->d_ranges, ranges.data(), sizeof(long) * ranges.size(), hipMemcpyHostToDevice));
+        // the complement of the jobs' source ranges in [0, nparams), cut into chunks of <= 2048 floats
+        std::vector<std::pair<long, long>> src;
+        for (const ShadowJobs& J : m->shadows)
+            for (int i = 0; i < J.n; ++i) {
+                const ShadowDesc& d = J.d[i];
+                const long len = d.type == SH_LINEAR ? (long)d.N * d.K : d.type == SH_CONV ? (long)d.N * d.K * 9
+                               : d.type == SH_VGG2ENC ? (long)d.N * d.a0 * d.a1 : (long)d.N;
+                src.emplace_back(d.src, len);
+            }
+        std::sort(src.begin(), src.end());
+        std::vector<long> gaps;
+        long at = 0;
+        auto gap = [&](long from, long to) { for (long o = from; o < to; o += 2048) { gaps.push_back(o); gaps.push_back(std::min<long>(2048, to - o)); } };
+        for (auto& r : src) {
+            if (r.first < at) { mk_set_error("masr_bind", "shadow jobs overlap in the parameter vector"); return -1; }
+            gap(at, r.first);
+            at = r.first + r.second;
+        }
+        gap(at, m->nparams);
+        if ((int)gaps.size() / 2 > GAP_CHUNKS_MAX) { m->fuse_sgd = false; m->ngaps = 0; }     // (a model with that many unshadowed parameters: two passes)
+        else {
+            m->ngaps = (int)gaps.size() / 2;
+            if (m->ngaps) HIP_CHECK_RET(hipMemcpy(m->d_gaps, gaps.data(), sizeof(long) * gaps.size(), hipMemcpyHostToDevice));
+        }
     }
     // pads of the char_trans shadows must be zero (rows/cols >= odim); the refresh kernels only write the odim part
     HIP_CHECK_RET(hipMemset(m->conv_sched, 0, sizeof(unsigned) * 64));   // tile counters of the streaming conv (re-armed by the kernel itself)
@@ -1010,6 +1045,7 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
 
 void masr_set_step_graphs(masr_model* m, int on) { m->step_graphs_on = on != 0; }
 void masr_set_ln_fusion(masr_model* m, int on) { m->ln_fusion = on != 0; }
+void masr_set_fused_sgd(masr_model* m, int on) { m->fuse_sgd = on != 0 && m->ngaps <= GAP_CHUNKS_MAX; }
 void masr_step_counters(const masr_model* m, int64_t out[3]) { out[0] = m->n_direct; out[1] = m->n_captured; out[2] = m->n_replayed; }
 
 int masr_read_stats(masr_model* m, float out[4], void* stream) {
@@ -1063,6 +1099,14 @@ int masr_grad_norm(masr_model* m, void* stream) {
 }
 int masr_clip_sgd_step(masr_model* m, float* mom, float max_norm, float lr, float momentum, int nesterov, int first_step, void* stream) {
     CK(masr_grad_norm(m, stream));
+    if (m->fuse_sgd && !m->shadows.empty()) {
+        // ONE pass: p and g in, p and every bf16 layout out (kernels.h mk_sgd_shadows)
+        Prof p(m, MASR_PROF_OPTIM, (hipStream_t)stream);
+        const SgdFuse sg{m->G, mom, m->stats + 3, max_norm, lr, momentum, nesterov, first_step};
+        bool first = true;
+        for (const ShadowJobs& J : m->shadows) { CK(mk_sgd_shadows(m->P, sg, J, m->d_gaps, first ? m->ngaps : 0, (hipStream_t)stream)); first = false; }
+        return 0;
+    }
     { Prof p(m, MASR_PROF_OPTIM, (hipStream_t)stream);
       CK(mk_clip_sgd(m->P, m->G, mom, m->nparams, m->stats + 3, max_norm, lr, momentum, nesterov, first_step, (hipStream_t)stream)); }
     return masr_refresh(m, stream);

@@ -219,6 +219,11 @@ constexpr int SHADOW_JOBS_MAX = 56;
 struct ShadowJobs { int n, blocks; ShadowDesc d[SHADOW_JOBS_MAX]; bf16* p[2 * SHADOW_JOBS_MAX]; };
 int mk_shadow_blocks(const ShadowDesc& d);                          // workgroups this job needs (tile_start bookkeeping on the host)
 int mk_all_shadows(const float* P, const ShadowJobs& jobs, hipStream_t s);
+// the same launch with masr_clip_sgd_step's update applied on the way (optim.hip all_shadows_kernel<true>): g / mom mirror P's layout, norm =
+// device float holding ||g|| (null: no clip), step_flags as mk_clip_sgd; gaps = device (offset, length <= 2048) chunks of the elements no job
+// covers.  With several job lists (deep models) the gaps go with ONE of the launches.
+struct SgdFuse { const float* g; float* mom; const float* norm; float max_norm, lr, momentum; int nesterov, step_flags; };
+int mk_sgd_shadows(float* P, const SgdFuse& sg, const ShadowJobs& jobs, const long* gaps, int ngaps, hipStream_t s);
 // inverse map for the weight gradient: g_nhwc [E][d*C+c] fp32 -> dw [E][c*Dp+d]
 int mk_vgg2enc_grad_unpermute(const float* g_nhwc, float* dw, int E, int C, int Dp, hipStream_t s);
 

@@ -4,6 +4,7 @@
 // (reference call sites: src/fo_meta_interface.py:148-149,180-221,223-250; optimizer.py:19-28).
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -50,6 +51,21 @@ __device__ __forceinline__ float clip_coef(float norm, float max_norm) {
 
 // inner step of run_task (fo_meta_interface.py:242-248): clip, then (unless the norm is NaN)
 // torch.optim.SGD(momentum, nesterov, dampening 0): buf = first ? g : m*buf + g; p -= lr*(nesterov ? g + m*buf : buf)
+struct SgdUpd {
+    float coef, lr, momentum; int nesterov, first_step;
+    // (explicit fused multiply-adds: left to -ffp-contract the scalar and the 16-byte forms of a pass were contracted differently, one
+    // ulp apart on ~1 element in 10 000)
+    __device__ __forceinline__ float operator()(float pi, float gr, float mi, float& mo) const {
+        const float gi = __fmul_rn(gr, coef);
+        float step = gi;
+        if (momentum != 0.f) {
+            const float b = first_step ? gi : __fmaf_rn(momentum, mi, gi);
+            mo = b;
+            step = nesterov ? __fmaf_rn(momentum, b, gi) : b;
+        }
+        return __fmaf_rn(-lr, step, pi);
+    }
+};
 __global__ void clip_sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom, long n,
                                 const float* __restrict__ norm, float max_norm, float lr, float momentum, int nesterov,
                                 int step_flags, int vec) {
@@ -62,16 +78,7 @@ __global__ void clip_sgd_kernel(float* __restrict__ p, const float* __restrict__
         if (nv != nv) return;                               // math.isnan(grad_norm) -> skip the step
         coef = clip_coef(nv, max_norm);
     }
-    auto upd = [&](float pi, float gr, float mi, float& mo) {
-        const float gi = gr * coef;
-        float step = gi;
-        if (momentum != 0.f) {
-            const float b = first_step ? gi : momentum * mi + gi;
-            mo = b;
-            step = nesterov ? gi + momentum * b : b;
-        }
-        return pi - lr * step;
-    };
+    const SgdUpd upd{coef, lr, momentum, nesterov, first_step};
     // 16 bytes per lane and stream (the flat buffers are 16-byte aligned allocations): a 4-byte-per-lane pass needs four times
     // the vector-memory instructions for the same bytes
     const long n4 = vec ? n >> 2 : 0, stride = (long)gridDim.x * blockDim.x;
@@ -244,8 +251,41 @@ __global__ __launch_bounds__(256) void split_reduce_kernel(float* __restrict__ G
     for (int e = 0; e < 8; ++e) { const int i = threadIdx.x + e * 256; if (i < len) G[off + i] = v[e]; }
 }
 // every operand shadow of the model, one job list, one launch (see kernels.h)
-constexpr int SH_TILE = 64;
-__global__ __launch_bounds__(256) void all_shadows_kernel(const float* __restrict__ P, const ShadowJobs jobs) {
+constexpr int SH_TILE = 64, SH_GAP = 2048;
+// SGD = true: the clipped SGD step of masr_clip_sgd_step is applied to every element ON ITS WAY into the shadows (read p and g, write p
+// and the bf16 layouts: the separate pass read p twice and the launch boundary drained the chip in between); elements that no shadow
+// job covers (biases, LayerNorm, embedding, conv1) are the `gaps` chunks, taken by the blocks behind the jobs'.  Same update expression
+// as clip_sgd_kernel (SgdUpd): same bits.
+template <bool SGD>
+__global__ __launch_bounds__(256) void all_shadows_kernel(typename std::conditional<SGD, float*, const float*>::type __restrict__ P, const ShadowJobs jobs,
+                                                          const SgdFuse sg, const long* __restrict__ gaps) {
+    SgdUpd upd{1.f, sg.lr, sg.momentum, sg.nesterov, sg.step_flags & 1};
+    const bool use_m = SGD && sg.momentum != 0.f, rd_m = use_m && !(sg.step_flags & 1), wr_m = use_m && !(sg.step_flags & 2);
+    if constexpr (SGD) {
+        if (sg.norm) {
+            const float nv = sg.norm[0];
+            if (nv != nv) return;                               // NaN norm: the step is skipped, the shadows are still right
+            upd.coef = clip_coef(nv, sg.max_norm);
+        }
+    }
+    // one element: new value (written back to P, and the momentum buffer) or, without SGD, the value itself
+    auto elem = [&](long i) -> float {
+        if constexpr (SGD) {
+            float mo = rd_m ? sg.mom[i] : 0.f;
+            const float v = upd(P[i], sg.g[i], mo, mo);
+            P[i] = v;
+            if (wr_m) sg.mom[i] = mo;
+            return v;
+        } else return P[i];
+    };
+    if constexpr (SGD) {
+        if ((int)blockIdx.x >= jobs.blocks) {                     // a gap chunk: (offset, length <= SH_GAP)
+            const int c = blockIdx.x - jobs.blocks;
+            const long off = gaps[2 * c]; const int len = (int)gaps[2 * c + 1];
+            for (int i = threadIdx.x; i < len; i += 256) elem(off + i);
+            return;
+        }
+    }
     int lo = 0, hi = jobs.n - 1;                                  // last job whose tile_start <= blockIdx.x (uniform: scalar ALU)
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -256,6 +296,11 @@ __global__ __launch_bounds__(256) void all_shadows_kernel(const float* __restric
     const int blk = blockIdx.x - d.tile_start;
     const float* x = P + d.src;
     bf16* p0 = jobs.p[2 * e]; bf16* p1 = jobs.p[2 * e + 1];
+    auto upd4 = [&](float4 pv, float4 gv, float4& mv) {
+        float4 o;
+        o.x = upd(pv.x, gv.x, mv.x, mv.x); o.y = upd(pv.y, gv.y, mv.y, mv.y); o.z = upd(pv.z, gv.z, mv.z, mv.z); o.w = upd(pv.w, gv.w, mv.w, mv.w);
+        return o;
+    };
     if (d.type == SH_LINEAR) {
         // 64 x 64 tile: fp32 rows in, through LDS, bf16 out as 16 bytes per lane in BOTH layouts -- the pass is bound by
         // vector-memory instructions: 4-byte loads and 2-byte stores made 48 of them per wave and tile where 9 suffice
@@ -263,36 +308,46 @@ __global__ __launch_bounds__(256) void all_shadows_kernel(const float* __restric
         const int r0 = (blk / tc) * SH_TILE, c0 = (blk % tc) * SH_TILE;
         __shared__ float t[SH_TILE][SH_TILE + 1];
         if ((d.K & 3) == 0 && c0 + SH_TILE <= d.K) {
-            // 16-byte loads although the tensor sits at an arbitrary dword offset of the flat buffer (P itself is 16-byte
-            // aligned): every row of the tile starts `mis` floats past a 16-byte boundary (K % 4 == 0: the same for all rows);
-            // 16 lanes fetch the row's 17 ALIGNED float4s (the last lane two of them) and each lane assembles its four
-            // elements from its own vector and its right neighbour's.  The bytes before / behind a row belong to neighbouring
-            // tensors of P (never to the first or the last one): readable, ignored.
+            // 16-byte accesses although the tensor sits at an arbitrary dword offset of the flat buffer (P itself is 16-byte aligned):
+            // every row of the tile starts `mis` floats past a 16-byte boundary (K % 4 == 0: the same for all rows) and spans 17
+            // ALIGNED float4s, the first owned from element `mis` on, the 17th up to it.  SEVENTEEN lanes per row take one vector
+            // each (15 rows per pass, five passes) and drop its owned elements into the LDS tile at their tile columns: one load per
+            // array and pass, no realignment in registers (16 lanes per row took two loads each -- the 17th vector -- and eight
+            // shuffles).  What lies outside the tile belongs to a neighbouring tile or tensor of P (never past its ends: the shadowed
+            // tensors are neither the first nor the last): read, in SGD mode updated in registers, never stored.
             const int mis = (int)((d.src + (long)r0 * d.K + c0) & 3);
-            const int j = threadIdx.x & 15, rr = threadIdx.x >> 4;          // 16 rows per pass
+            const int v = threadIdx.x % 17, rr = threadIdx.x / 17;
+            const int lo = v == 0 ? mis : 0, hi = v == 16 ? mis : 4;              // owned elements of the vector: [lo, hi)
 #pragma unroll
-            for (int pass = 0; pass < SH_TILE / 16; ++pass) {
-                const int k = rr + 16 * pass;
-                const bool ok = r0 + k < d.N;
-                const float* ab = x + (long)(ok ? r0 + k : r0) * d.K + c0 - mis;
-                const float4 q = *reinterpret_cast<const float4*>(ab + 4 * j);
-                const float4 qx = *reinterpret_cast<const float4*>(ab + 4 * (j == 15 ? 16 : j));      // (lane 15: the 17th vector)
-                float4 nb;
-                nb.x = __shfl_down(q.x, 1, 16); nb.y = __shfl_down(q.y, 1, 16); nb.z = __shfl_down(q.z, 1, 16); nb.w = __shfl_down(q.w, 1, 16);
-                if (j == 15) nb = qx;
-                const float w8[8] = {q.x, q.y, q.z, q.w, nb.x, nb.y, nb.z, nb.w};
+            for (int pass = 0; pass < 5; ++pass) {
+                const int k = rr + 15 * pass;
+                const bool in = rr < 15 && k < SH_TILE, ok = in && r0 + k < d.N;
+                const long aoff = d.src + (long)(ok ? r0 + k : r0) * d.K + c0 - mis + 4 * (hi > lo ? v : 15);
+                float4 q = *reinterpret_cast<const float4*>(P + aoff);
+                if constexpr (SGD) {
+                    const float4 gq = *reinterpret_cast<const float4*>(sg.g + aoff);
+                    float4 mq = rd_m ? *reinterpret_cast<const float4*>(sg.mom + aoff) : float4{0.f, 0.f, 0.f, 0.f};
+                    q = upd4(q, gq, mq);
+                    if (ok) {
+                        if (hi - lo == 4) {
+                            *reinterpret_cast<float4*>(P + aoff) = q;
+                            if (wr_m) *reinterpret_cast<float4*>(sg.mom + aoff) = mq;
+                        } else {
+                            const float qa[4] = {q.x, q.y, q.z, q.w}, ma[4] = {mq.x, mq.y, mq.z, mq.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = w8[e];                                                                       // mis == 0
-                    if (mis == 1) v = w8[e + 1]; else if (mis == 2) v = w8[e + 2]; else if (mis == 3) v = w8[e + 3];
-                    t[k][4 * j + e] = ok ? v : 0.f;
+                            for (int e = 0; e < 4; ++e) if (e >= lo && e < hi) { P[aoff + e] = qa[e]; if (wr_m) sg.mom[aoff + e] = ma[e]; }
+                        }
+                    }
                 }
+                const float qa[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (in && e >= lo && e < hi) t[k][4 * v - mis + e] = ok ? qa[e] : 0.f;
             }
         } else {
             const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 4 rows per pass, 64 consecutive columns per row
             for (int k = ty; k < SH_TILE; k += 4) {
                 const bool ok = r0 + k < d.N && c0 + tx < d.K;
-                t[k][tx] = ok ? x[(long)(r0 + k) * d.K + c0 + tx] : 0.f;
+                t[k][tx] = ok ? elem(d.src + (long)(r0 + k) * d.K + c0 + tx) : 0.f;
             }
         }
         __syncthreads();
@@ -326,7 +381,7 @@ __global__ __launch_bounds__(256) void all_shadows_kernel(const float* __restric
         const int i = blk * 256 + threadIdx.x;
         if (i >= n) return;
         const int tap = i % 9, ci = (i / 9) % CI, co = i / (9 * CI);
-        const bf16 v = (bf16)x[i];
+        const bf16 v = (bf16)elem(d.src + i);
         p0[(long)co * 9 * CI + tap * CI + ci] = v;                        // forward: out[co] += in[p+off(tap)][ci] * w
         p1[(long)ci * 9 * CO + (8 - tap) * CO + co] = v;                  // dgrad: din[ci] += dy[p-off(tap)][co] * w
     } else if (d.type == SH_VGG2ENC) {
@@ -336,13 +391,14 @@ __global__ __launch_bounds__(256) void all_shadows_kernel(const float* __restric
         const int f = (int)(i % F), en = (int)(i / F);
         const int c = f / Dp, dd = f % Dp;                                   // reference feature index c*Dp + d
         const int fn = dd * C + c;                                           // NHWC feature index
-        const bf16 v = (bf16)x[i];
+        const bf16 v = (bf16)elem(d.src + i);
         p0[(long)en * F + fn] = v;
         p1[(long)fn * E + en] = v;
     } else {
         const int i = blk * 256 + threadIdx.x;
-        if (i < d.N) reinterpret_cast<float*>(p0)[i] = x[i];
+        if (i < d.N) reinterpret_cast<float*>(p0)[i] = elem(d.src + i);
     }
+    (void)x;
 }
 
 inline int aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
@@ -464,7 +520,13 @@ int mk_shadow_blocks(const ShadowDesc& d) {
 }
 int mk_all_shadows(const float* P, const ShadowJobs& jobs, hipStream_t s) {
     if (jobs.n <= 0) return 0;
-    hipLaunchKernelGGL(all_shadows_kernel, dim3(jobs.blocks), dim3(256), 0, s, P, jobs);
+    hipLaunchKernelGGL(all_shadows_kernel<false>, dim3(jobs.blocks), dim3(256), 0, s, P, jobs, SgdFuse{}, (const long*)nullptr);
+    return LAUNCH_OK();
+}
+int mk_sgd_shadows(float* P, const SgdFuse& sg, const ShadowJobs& jobs, const long* gaps, int ngaps, hipStream_t s) {
+    if (jobs.n <= 0 && ngaps <= 0) return 0;
+    if (!aligned16(P, sg.g, sg.mom)) { mk_set_error("mk_sgd_shadows", "the flat buffers must be 16-byte aligned"); return -1; }
+    hipLaunchKernelGGL(all_shadows_kernel<true>, dim3(jobs.blocks + ngaps), dim3(256), 0, s, P, jobs, sg, gaps);
     return LAUNCH_OK();
 }
 int mk_conv_weight_shadows(const float* w, bf16* wk, bf16* wd, int CO, int CI, hipStream_t s) {

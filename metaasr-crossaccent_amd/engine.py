@@ -247,6 +247,10 @@ class MasrEngine:
         """decoder-row LayerNorms inside their consumer GEMMs (include/masr.h masr_set_ln_fusion); default off (measured slower)"""
         self._l.masr_set_ln_fusion(self.h, int(bool(on)))
 
+    def set_fused_sgd(self, on: bool):
+        """clip_sgd_step's update inside the shadow-refresh launch (include/masr.h masr_set_fused_sgd); default off (measured slower)"""
+        self._l.masr_set_fused_sgd(self.h, int(bool(on)))
+
     def step_counters(self):
         """{'direct', 'captured', 'replayed'}: how run_batch calls reached the GPU (kernel by kernel / graph capture / graph replay)"""
         out = (C.c_int64 * 3)()

@@ -427,3 +427,48 @@ def test_layernorm_in_the_gemm_prologue_gives_the_same_step(cfg_name):
             torch.testing.assert_close(a, b, rtol=2e-5, atol=1e-6 * float(b.abs().max() + 1e-30))
         else:
             assert torch.equal(a, b), f"{n}: gradient differs between the fused and the standalone LayerNorm path"
+
+
+@pytest.mark.parametrize("cfg_name,mom_steps", [("tiny", 1), ("hkust", 1), ("tiny", 3)])
+def test_sgd_step_inside_the_shadow_refresh_gives_the_same_bits(cfg_name, mom_steps):
+    """masr_clip_sgd_step applies its update inside the launch that rewrites the bf16 operand layouts (csrc/optim.hip
+    all_shadows_kernel<true>: one pass over the parameters).  Against the two-pass form (update, then refresh): parameters and
+    momentum buffer equal bit for bit after every step, and so does the loss of the forward pass that follows (it reads the
+    shadows).  mom_steps = 3: first step (buffer = g, nothing read), a middle one (buffer read and written), a last one (read only)."""
+    cfg = dict(TINY if cfg_name == "tiny" else HKUST)
+    sd = ref_cpu.deterministic_state_dict(cfg, ODIM, seed=8)
+    ilens, olens = ([64, 52, 40, 33], [9, 7, 5, 3]) if cfg_name == "tiny" else ([203, 160, 121, 96, 90], [12, 9, 7, 30, 2])
+    xs, il, ys, ol = synth_batch(22, ilens, olens)
+    outs = []
+    for fused in (True, False):
+        eng = MasrEngine(cfg, ODIM, label_smoothing=0.1)
+        eng.load_state_dict(sd)
+        eng.set_seed(7)
+        eng.set_fused_sgd(fused)
+        mom = torch.zeros_like(eng.params)
+        trace = []
+        for k in range(mom_steps):
+            eng.run_batch(xs, il, ys, ol.clone(), train=True)
+            flags = (1 if k == 0 else 0) | (2 if k == mom_steps - 1 else 0)
+            eng.clip_sgd_step(mom, 5.0, 0.05, 0.9, True, flags)
+            trace.append((eng.params.clone(), mom.clone()))
+        eng.run_batch(xs, il, ys, ol.clone(), train=False)
+        trace.append((torch.tensor(eng.read_stats()["loss"]), eng.last_logits()[0].clone()))
+        outs.append(trace)
+    for (a0, a1), (b0, b1) in zip(*outs):
+        assert torch.equal(a0, b0) and torch.equal(a1, b1)
+    assert not torch.equal(outs[0][0][0], torch.zeros_like(outs[0][0][0]))
+
+
+def test_sgd_step_with_nan_norm_is_skipped_in_the_fused_launch_too():
+    """math.isnan(grad_norm) -> the reference skips the step (fo_meta_interface.py:245); the fused launch returns before touching
+    anything, like the update pass did"""
+    cfg = dict(TINY)
+    eng = MasrEngine(cfg, ODIM, label_smoothing=0.1)
+    eng.load_state_dict(ref_cpu.deterministic_state_dict(cfg, ODIM, seed=8))
+    xs, il, ys, ol = synth_batch(22, [64, 52], [9, 7])
+    eng.run_batch(xs, il, ys, ol.clone(), train=True)
+    eng.grads[5] = float("nan")
+    before = eng.params.clone()
+    eng.clip_sgd_step(torch.zeros_like(eng.params), 5.0, 0.05, 0.9, True, 3)
+    assert torch.equal(eng.params, before)
