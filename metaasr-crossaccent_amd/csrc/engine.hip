@@ -396,7 +396,10 @@ int flush_wgrads(Ctx& c) {
     m->wg_defer = false;
     if (m->wg.n == 0) return 0;
     Prof p(m, MASR_PROF_WGRAD_DEC, c.s);
-    const int rc = mk_gemm_wgrad_grouped(m->wg, c.s);
+    // the decoder-row group on the encoder rows' 256 x 256 tiles too (hkust: 228 of them = one round): as 3 632 tiles of 64 x 64 the launch
+    // moved 0.6 GB of tile operands for 19 GFLOP and ran at the CUs' intake limit (63 us).  MASR_DEC_WGRAD_TILE=64: the small tiles (A/B).
+    static const int tile = getenv("MASR_DEC_WGRAD_TILE") ? atoi(getenv("MASR_DEC_WGRAD_TILE")) : 256;
+    const int rc = mk_gemm_wgrad_grouped(m->wg, c.s, tile);
     m->wg.n = 0;
     return rc;
 }
