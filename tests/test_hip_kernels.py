@@ -471,3 +471,27 @@ def test_dropout_keep_rate_and_scale_per_site():
     sd_expect = (p / (1 - p) / Tk) ** 0.5
     row = of.view(Bq * Tq, H, hd)[:, :, 0]
     assert abs(float(row.std()) - sd_expect) < 0.15 * sd_expect, (float(row.std()), sd_expect)
+
+
+@pytest.mark.parametrize("M,N,K,flavour", [(4000, 2048, 512, "bias_relu"), (2100, 1152, 192, "bias"), (4000, 1024, 512, "plain"),
+                                            (3000, 2048, 2048, "mask"), (4000, 4096, 512, "bias")])
+def test_gemm_wide_outputs(L, M, N, K, flavour):
+    """the encoder-row NT GEMMs at their full size through mk_gemm's epilogues: FFN first layer (bias + ReLU, bf16 out), K|V projection of the
+    memory (bias), the plain and the ReLU-masked dgrads; ragged row counts (2100, 3000), a width that is not a multiple of 256 (1152)."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = (torch.randn(M, K, device="cuda", generator=g) * 0.5).bfloat16()
+    B = (torch.randn(N, K, device="cuda", generator=g) * 0.5).bfloat16()
+    bias = torch.randn(N, device="cuda", generator=g) if flavour.startswith("bias") else None
+    mask = (torch.randn(M, N, device="cuda", generator=g) > 0).bfloat16() if flavour == "mask" else None
+    C16 = torch.full((M + 1, N), 3.0, device="cuda").bfloat16()
+    _cabi.check(L.masr_test_gemm_epi(P(A), K, P(B), K, M, N, K, P(bias) if bias is not None else None, 1 if flavour == "bias_relu" else 0, 0.0,
+                                     None, P(mask) if mask is not None else None, None, P(C16), S()))
+    ref = A.float() @ B.float().t()
+    if bias is not None:
+        ref = ref + bias
+    if flavour == "bias_relu":
+        ref = ref.clamp_min(0)
+    if mask is not None:
+        ref = ref * mask.float()
+    torch.testing.assert_close(C16[:M].float(), ref, rtol=1e-2, atol=2e-2 * (K ** 0.5) / 8)
+    assert torch.all(C16[M].float() == 3.0)
