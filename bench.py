@@ -656,7 +656,7 @@ def main():
             launches[name] = {"kernel": kern, "avg_launch_ms": per, "gflop_per_launch": flops / 1e9, "tflops": flops / (per * 1e-3) / 1e12,
                               "frac_of_bf16_peak": flops / (per * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "algorithmic_bytes": abytes,
                               "traffic_bytes": pmc.get(name)}
-        # the encoder-row Linear weight gradients are ONE launch since round 3 (round 4: gemm_wgrad_grouped16_kernel / grouped8): a candidate too
+        # the encoder-row Linear weight gradients are ONE launch since round 3 (round 4: gemm_wgrad_grouped16_kernel): a candidate too
         ms_w, n_w = prof_all["wgrad_enc"]
         if n_w == nprof:                                         # (one launch per step: the grouped path is on)
             E_, F_, Tp_ = cfg["d_model"], cfg["d_inner"], T // 4

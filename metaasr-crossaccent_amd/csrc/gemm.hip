@@ -399,186 +399,19 @@ __global__ __launch_bounds__(256) void gemm_wgrad_grouped_kernel(WgradGroup grp)
     gemm_body<BM, BN, true, E_C32>(g, t % tiles_x, t / tiles_x, 0);
 }
 
-// ---- the encoder-row weight gradients on EIGHT-wave tiles (round 4).  What bounds the 128 x 128 four-wave launch above is operand
-// intake: every tile streams a [rows x 128] panel of dY and one of X through its CU (1.21 GB of tile operands for 244 MB of distinct
-// bytes, ~28 GB/s per CU: L2-miss territory), MFMA pipes busy 0.21.  A 128 x 256 tile on eight waves (2 x 4, 64 x 64 per wave: the same
-// per-wave work) takes in (128 + 256) / (128 * 256) bytes per FLOP instead of (128 + 128) / (128 * 128): -25 %.  One workgroup per CU
-// (106 KB of LDS, two waves per SIMD as two four-wave workgroups had).  The tile list of the hkust geometry is 296 such tiles for 256
-// CUs: a second round at 16 % occupancy would cost what the intake saves, so only a whole number of rounds runs as big tiles
-// (n_big = the largest multiple of 256 <= the tile count) and the remaining big tiles are cut into W8_PARTS column pieces (128 x 64
-// quarters: 2 x 4 waves of 64 x 16) that the SAME eight waves take as the CUs come free.  Every output element is still reduced by ONE workgroup over the rows in
-// order, so dW is bit-identical to the four-wave kernel's; the bias gradient (column sums, folded over 512 threads) differs in fp32
+// ---- the encoder- and decoder-row weight gradients on EIGHT-wave tiles (round 4).  What bounds the 128 x 128 four-wave launch above is
+// operand intake: every tile streams a [rows x 128] panel of dY and one of X through its CU (1.21 GB of tile operands for 244 MB of
+// distinct bytes, ~28 GB/s per CU), MFMA pipes busy 0.21; the CUs together take in ~8.7 TB/s from the L2s at this access shape
+// (tools/wgrad_probe.py: a full round takes the same time over 8 MB of resident operands as over 49 MB), so the way to fewer microseconds
+// is fewer operand bytes per FLOP.  A register-staged 128 x 256 tile on eight waves (-25 % bytes per FLOP: 169 -> 134 us on the hkust
+// encoder group, whole rounds of big tiles + quarter tiles for the partial last round) was the first step and is gone; the 256 x 256
+// LDS-DMA tile below (-50 %) replaced it for every group size: against it, groups of 320 / 384 / 512 such tiles (two rounds, the last
+// one partial) take 225 / 219 / 252 us where the 128 x 256 form took 275 / 245 / 341.  Every output element is reduced by ONE workgroup
+// over the rows in order whatever the tile, so dW is bit-identical to the four-wave kernel's; the bias gradient differs in fp32
 // rounding only.  MASR_ENC_WGRAD_TILE=128 restores the four-wave launch.
-// What bounds a full round (tools/wgrad_probe.py: 256 big tiles, one per CU): 88-92 us whether the operands are 8 MB (resident in every
-// cache) or 49 MB, 40 us per tile when only 64 CUs have one -- i.e. not HBM, not the L2 hit rate, not latency (a four-deep register ring:
-// -1 %) and not sharers walking a panel in lock-step (a start skew of the XCD's tiles only added its own delay): the CUs together take in
-// ~8.7 TB/s from the L2s at this access shape, and the way to fewer microseconds is fewer operand bytes per FLOP (256 x 256 tiles: -33 %).
-template <int ROWS, int NT>
-struct StagerRMT {
-    static constexpr int LDT = ROWS + 16;
-    static constexpr int RC = ROWS / 8;
-    static constexpr int CHUNKS = BK * RC;
-    static constexpr int PT = CHUNKS / NT;
-    static_assert(CHUNKS % NT == 0 && NT % RC == 0, "tile must be a multiple of NT chunks; a thread must keep its rows");
-    bf16x8 regs[PT];
-    unsigned ok;
-    __device__ __forceinline__ void load(const bf16* __restrict__ src, long ld, int r0, int k0, int nrows, int nk, int tid) {
-        ok = 0;
-        const int rmax = (nrows + 7) / 8 * 8 - 8;
-#pragma unroll
-        for (int i = 0; i < PT; ++i) {
-            const int c = tid + i * NT;
-            const int k = k0 + c / RC, r = r0 + (c % RC) * 8;
-            if (k < nk && r < nrows) ok |= 1u << i;
-            const int kc = k < nk ? k : nk - 1, rc = r < nrows ? r : rmax;
-            regs[i] = ld8(src + (long)kc * ld + rc);
-        }
-    }
-    __device__ __forceinline__ void store(bf16* __restrict__ dst, int tid) {
-#pragma unroll
-        for (int i = 0; i < PT; ++i) {
-            const int c = tid + i * NT;
-            st8(dst + (c / RC) * LDT + (c % RC) * 8, (ok >> i) & 1 ? regs[i] : zero8());
-        }
-    }
-    __device__ __forceinline__ void accumulate(float (&acc)[8]) {
-#pragma unroll
-        for (int i = 0; i < PT; ++i) {
-            const float m = (ok >> i) & 1 ? 1.f : 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf(m, (float)regs[i][j], acc[j]);
-        }
-    }
-};
-constexpr int W8_LDS = 2 * (int)sizeof(TileRM<128>) + 2 * (int)sizeof(TileRM<256>);
-#ifndef MASR_W8_PARTS
-#define MASR_W8_PARTS 4
-#endif
-constexpr int W8_PARTS = MASR_W8_PARTS;            // pieces a big tile of the last, partial round is cut into (2: 128 x 128, 4: 128 x 64)
-
-// dW[m0 .. m0+128)[n0 .. n0+BN) of one group member; 512 threads = 8 waves as 2 (rows) x 4 (columns)
-template <int BN, int BM = 128>
-__device__ __forceinline__ void wgrad8_tile(const WgradDesc& d, const int m0, const int n0, const bool do_colsum, char* smem) {
-    constexpr int WM = BM / 2, WN = BN / 4, FM = WM / 16, FN = WN / 16, NT = 512;
-    using SA = StagerRMT<BM, NT>;
-    using SB = StagerRMT<BN, NT>;
-    TileRM<BM>* sa_ = reinterpret_cast<TileRM<BM>*>(smem);
-    TileRM<BN>* sb_ = reinterpret_cast<TileRM<BN>*>(smem + 2 * sizeof(TileRM<BM>));
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
-    const int M = d.N, N = d.K, K = d.rows;                        // dW is [M = out features][N = in features], reduced over the K rows
-#ifndef MASR_W8_DEPTH
-#define MASR_W8_DEPTH 2
-#endif
-    constexpr int DEPTH = MASR_W8_DEPTH;                          // k tiles of global loads in flight per thread (register ring)
-    static_assert(DEPTH % 2 == 0, "the LDS buffer parity of ring slot u must be static");
-    SA sa[DEPTH]; SB sb[DEPTH];
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int nk = (K + BK - 1) / BK;
-    // (tried: unclamped loads from per-thread base pointers for interior tiles -- the clamping arithmetic is ~10 vector instructions per
-    // 16-byte load; with both paths in the kernel it needed 8 more registers (the 256 x 256 form spilled) and ran 8 % SLOWER.  Tried: the
-    // second half of the waves writes tile kt + 1 BEFORE it multiplies tile kt, so that SIMD partners alternate between the matrix pipe and
-    // the LDS (MI355X_MICROARCH.md "two waves per SIMD", item 9): 132 -> 182 us on the 256 x 256 form (7 spilled registers), 133 -> 153 on
-    // the 128 x 256 one -- the register ring of the global loads is consumed a phase earlier and the compiler serialises on it)
-    auto fetch = [&](SA& a_, SB& b_, int kt) {
-        a_.load(d.dy, d.lddy, m0, kt * BK, M, K, tid); b_.load(d.x, d.ldx, n0, kt * BK, N, K, tid);
-    };
-#pragma unroll
-    for (int dd = 0; dd < DEPTH; ++dd) fetch(sa[dd], sb[dd], dd);
-    if (do_colsum) sa[0].accumulate(csum);
-    sa[0].store(sa_[0].d, tid);
-    sb[0].store(sb_[0].d, tid);
-    __syncthreads();
-    for (int kt0 = 0; kt0 < nk; kt0 += DEPTH) {
-#pragma unroll
-        for (int u = 0; u < DEPTH; ++u) {
-            const int kt = kt0 + u;
-            if (kt >= nk) break;
-            const int cur = u & 1;
-            fetch(sa[u], sb[u], kt + DEPTH);
-#pragma unroll
-            for (int kc = 0; kc < BK / 32; ++kc) {
-                bf16x8 bfr[FN];
-#pragma unroll
-                for (int j = 0; j < FN; ++j) bfr[j] = frag_rm<BN + 16>(sb_[cur].d, wn * WN + j * 16, lane, kc * 32);
-                // (the dY fragments four at a time: a 256-row tile has eight per wave, and all of them live at once would not fit beside
-                // its 128 accumulator registers)
-#pragma unroll
-                for (int i0 = 0; i0 < FM; i0 += 4) {
-                    bf16x8 af[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) af[i] = frag_rm<BM + 16>(sa_[cur].d, wm * WM + (i0 + i) * 16, lane, kc * 32);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < FN; ++j) acc[i0 + i][j] = mma16(af[i], bfr[j], acc[i0 + i][j]);
-                }
-            }
-            if (kt + 1 < nk) {
-                const int nx = (u + 1) % DEPTH;
-                if (do_colsum) sa[nx].accumulate(csum);
-                sa[nx].store(sa_[cur ^ 1].d, tid);
-                sb[nx].store(sb_[cur ^ 1].d, tid);
-            }
-            __syncthreads();
-        }
-    }
-    if (do_colsum) {                                             // threads tid, tid + BM / 8, ... own the same 8 rows of the dY tile
-        constexpr int RC = BM / 8;
-        float* red = reinterpret_cast<float*>(smem);              // [512][8] floats = 16 KB
-#pragma unroll
-        for (int j = 0; j < 8; ++j) red[tid * 8 + j] = csum[j];
-        __syncthreads();
-        if (tid < BM) {
-            const int rc = tid / 8, j = tid % 8;
-            float sum = 0.f;
-            for (int t = rc; t < NT; t += RC) sum += red[t * 8 + j];
-            if (m0 + tid < M) d.db[m0 + tid] = sum;
-        }
-        __syncthreads();
-    }
-    // accumulators straight to dW: lane (fq, fr) holds rows fq * 4 + r, column fr of every 16 x 16 block -- 16 lanes write 64 contiguous
-    // bytes of a row (the 39.5 MB of dW are written once per step: not what bounds this launch)
-    const int fq = lane >> 4, fr = lane & 15;
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm * WM + i * 16 + fq * 4 + r;
-            if (m >= M) continue;
-            float* row = d.dW + (long)m * N;
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int n = n0 + wn * WN + j * 16 + fr;
-                if (n < N) row[n] = acc[i][j][r];
-            }
-        }
-}
-__global__ __launch_bounds__(512) void gemm_wgrad_grouped8_kernel(WgradGroup grp, int n_big) {
-    __shared__ __attribute__((aligned(16))) char smem[W8_LDS];
-    // blocks [0, n_big): big tiles in XCD-contiguous runs (n_big is a multiple of 256, hence of 8); the rest: 128 x 128 halves of the
-    // big tiles n_big, n_big + 1, ... in list order
-    const int l = blockIdx.x;
-    int tbig, part = -1;
-    if (l < n_big) tbig = (l & 7) * (n_big >> 3) + (l >> 3);
-    else { tbig = n_big + (l - n_big) / W8_PARTS; part = (l - n_big) % W8_PARTS; }
-    int p = 0;
-    while (p + 1 < grp.n && tbig >= grp.p[p + 1].tile_start) ++p;
-    const WgradDesc& d = grp.p[p];
-    const int t = tbig - d.tile_start, tiles_x = (d.K + 255) / 256;
-    const int bx = t % tiles_x, by = t / tiles_x;
-    constexpr int PW = 256 / W8_PARTS;
-    if (part < 0) wgrad8_tile<256>(d, by * 128, bx * 256, d.db != nullptr && bx == 0, smem);
-    else if (bx * 256 + part * PW < d.K) wgrad8_tile<PW>(d, by * 128, bx * 256 + part * PW, d.db != nullptr && bx == 0 && part == 0, smem);
-}
-
-// ---- 256 x 256 tiles (2 x 4 waves of 128 x 64) with LDS-DMA staging: taken when the whole group is at most ONE round of the CUs in such
-// tiles (hkust: 148).  A third fewer operand bytes per FLOP than 128 x 256, no partial round, fewer CUs drawing on the L2s at once.
-// The register-staged form of this tile (wgrad8_tile<256, 256>, rounds 3-4) spent, per 64 reduction rows and thread, 8 global loads with
+// ---- 256 x 256 tiles (2 x 4 waves of 128 x 64) with LDS-DMA staging (hkust: 148 tiles for the encoder rows, 228 for the decoder rows: one
+// partial round each).
+// The register-staged form of this tile (rounds 3-4) spent, per 64 reduction rows and thread, 8 global loads with
 // ~10 vector instructions of clamping each, 8 ds_write_b128 and 64 staging registers (251 VGPRs in all) beside its 64 MFMAs and ran at
 // 2.06 us per 64 rows against 0.86 of MFMA time (132 us in the engine).  Here the tiles go L2 -> LDS by global_load_lds_dwordx4 (no
 // VGPRs, no LDS stores) into a ring of four 32-row stages; a super-step multiplies two of them while the next two travel (114 us).
@@ -1209,7 +1042,7 @@ int launch_tile(const GemmArgs& g_in, hipStream_t s) {
 
 int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s, int tile) {
     if (grp.n <= 0) return 0;
-    if (tile != 64 && tile != 128 && tile != 256) { mk_set_error("mk_gemm_wgrad_grouped", "tile 64, 128 or 256 (= 128 x 256 on eight waves)"); return -1; }
+    if (tile != 64 && tile != 128 && tile != 256) { mk_set_error("mk_gemm_wgrad_grouped", "tile 64, 128 or 256 (= 256 x 256 on eight waves)"); return -1; }
     int tiles = 0;
     for (int i = 0; i < grp.n; ++i) {
         WgradDesc& d = grp.p[i];
@@ -1217,23 +1050,12 @@ int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s, int tile) {
             mk_set_error("mk_gemm_wgrad_grouped", "operands must be 16-byte aligned with padded rows"); return -1;
         }
         d.tile_start = tiles;
-        tiles += tile == 256 ? ((d.N + 127) / 128) * ((d.K + 255) / 256) : ((d.N + tile - 1) / tile) * ((d.K + tile - 1) / tile);
+        tiles += ((d.N + tile - 1) / tile) * ((d.K + tile - 1) / tile);
     }
     if (tile == 256) {
-        // whole rounds of the 256 CUs as 128 x 256 tiles, the rest as their 128 x 128 halves (see gemm_wgrad_grouped8_kernel)
-        static const int ncu = [] { int dev = 0, n = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n / 8 * 8 : 256; }();
-        static const bool no16 = getenv("MASR_ENC_WGRAD_NO_256SQ") != nullptr;
         int t16 = 0;
-        for (int i = 0; i < grp.n; ++i) t16 += ((grp.p[i].N + 255) / 256) * ((grp.p[i].K + 255) / 256);
-        if (!no16 && t16 <= ncu) {                            // one round (or less) of 256 x 256 tiles
-            int acc_t = 0;
-            for (int i = 0; i < grp.n; ++i) { grp.p[i].tile_start = acc_t; acc_t += ((grp.p[i].N + 255) / 256) * ((grp.p[i].K + 255) / 256); }
-            hipLaunchKernelGGL(gemm_wgrad_grouped16_kernel, dim3(t16), dim3(512), 0, s, grp);
-            if (hipGetLastError() != hipSuccess) { mk_set_error("mk_gemm_wgrad_grouped", "launch failed"); return -1; }
-            return 0;
-        }
-        const int n_big = tiles / ncu * ncu;
-        hipLaunchKernelGGL(gemm_wgrad_grouped8_kernel, dim3(n_big + W8_PARTS * (tiles - n_big)), dim3(512), 0, s, grp, n_big);
+        for (int i = 0; i < grp.n; ++i) { grp.p[i].tile_start = t16; t16 += ((grp.p[i].N + 255) / 256) * ((grp.p[i].K + 255) / 256); }
+        hipLaunchKernelGGL(gemm_wgrad_grouped16_kernel, dim3(t16), dim3(512), 0, s, grp);
         if (hipGetLastError() != hipSuccess) { mk_set_error("mk_gemm_wgrad_grouped", "launch failed"); return -1; }
         return 0;
     }

@@ -61,11 +61,11 @@ def test_gemm_reduction_major(L, M, N, K):
 
 @pytest.mark.parametrize("rows,N,K,tile", [(4000, 512, 512, 128), (1000, 1536, 512, 128), (777, 256, 2048, 128), (63, 128, 128, 128), (592, 512, 2048, 64),
                                          (500, 200, 328, 128), (4000, 2560, 512, 128),
-                                         # tile 256 = the encoder-row launch since round 4: 256 x 256 tiles on eight waves while the group is at most one
-                                         # round of the CUs in such tiles (ragged edges included), 128 x 256 tiles beyond that
+                                         # tile 256 = the encoder- and decoder-row launches since round 4: 256 x 256 tiles on eight waves, LDS-DMA ring
+                                         # (ragged edges included)
                                          (4000, 512, 512, 256), (1000, 1536, 512, 256), (777, 256, 2048, 256), (63, 128, 128, 256), (500, 200, 328, 256),
                                          (4000, 2560, 512, 256), (1000, 2048, 2304, 256), (300, 2048, 2100, 256),
-                                         # more than one round of 256 x 256 tiles (2 x 17 x 16 = 544): the 128 x 256 launch with its partial last round
+                                         # more than one round of 256 x 256 tiles (2 x 17 x 16 = 544 on 256 CUs)
                                          (200, 4200, 4096, 256)])
 def test_wgrad_grouped(L, rows, N, K, tile):
     """mk_gemm_wgrad_grouped (the Linear weight gradients of a backward pass as one grid, lin_wgrad / flush_enc_wgrads): dW = dY^T X and
