@@ -664,8 +664,15 @@ def main():
             rows = B * Tp_
             fl = sum(2.0 * rows * n_ * k_ for n_, k_ in shapes)
             by = sum(rows * (n_ + k_) * 2 + n_ * k_ * 4 for n_, k_ in shapes)
+            merged = prof_all["wgrad_dec"][1] == 0               # the decoder-row weight gradients ride in the same launch (engine.hip flush_enc_wgrads)
+            if merged:
+                rows_dd = B * (int(max(tasks[0].ol)) + 1)
+                dshapes = [(3 * E_, E_), (E_, E_), (E_, E_), (E_, E_), (F_, E_), (E_, F_)] * cfg["decoder"]["nlayers"] + [(ODIM, E_)]
+                fl += sum(2.0 * rows_dd * n_ * k_ for n_, k_ in dshapes)
+                by += sum(rows_dd * (n_ + k_) * 2 + n_ * k_ * 4 for n_, k_ in dshapes)
             per = ms_w / n_w
-            launches["wgrad_enc"] = {"kernel": "gemm_wgrad_grouped16_kernel (ALL encoder-row Linear weight gradients of the step, %d GEMMs dW = dY^T X over %d rows, one grid of 256x256 tiles on eight waves; 128x256 tiles + quarters when the group exceeds one round of the CUs)" % (len(shapes), rows),
+            launches["wgrad_enc"] = {"kernel": ("gemm_wgrad_grouped16_kernel (ALL Linear weight gradients of the step: %d GEMMs dW = dY^T X over the %d encoder rows and %d over the %d decoder rows, one grid of 256x256 tiles on eight waves, LDS-DMA ring; the long tiles are dispatched first)" % (len(shapes), rows, len(dshapes), rows_dd)) if merged else
+                                               ("gemm_wgrad_grouped16_kernel (ALL encoder-row Linear weight gradients of the step, %d GEMMs dW = dY^T X over %d rows, one grid of 256x256 tiles on eight waves, LDS-DMA ring)" % (len(shapes), rows)),
                                      "avg_launch_ms": per, "gflop_per_launch": fl / 1e9, "tflops": fl / (per * 1e-3) / 1e12,
                                      "frac_of_bf16_peak": fl / (per * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "algorithmic_bytes": by, "traffic_bytes": pmc.get("wgrad_enc")}
         dom = max(launches, key=lambda k: launches[k]["avg_launch_ms"])
@@ -673,7 +680,7 @@ def main():
         roof = {"bound": "mfma", "kernel": d["kernel"], "slot": dom, "achieved": d["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": d["frac_of_bf16_peak"], "traffic": d["traffic_bytes"], "traffic_source": pmc_src if d["traffic_bytes"] else None,
                 "algorithmic_bytes": d["algorithmic_bytes"], "avg_launch_ms": d["avg_launch_ms"], "flops_per_launch": d["gflop_per_launch"] * 1e9,
-                "selection": "longest single launch of the step at this commit (every chip-filling launch that is timed alone is listed under \"launches\": the nine conv launches and the grouped encoder-row weight-gradient GEMM)",
+                "selection": "longest single launch of the step at this commit (every chip-filling launch that is timed alone is listed under \"launches\": the nine conv launches and the grouped weight-gradient GEMM)",
                 "launches": launches}
         # per-class table of ONE single-task step: algorithmic FLOPs (forward x 3; conv1 has no dgrad) vs measured kernel time
         Lmax = int(max(tasks[0].ol)) + 1

@@ -382,13 +382,32 @@ int lin_wgrad(Ctx& c, const bf16* dy, long lddy, const bf16* x, long ldx, int ro
     CK(gemm(c, g));
     return 0;
 }
+static int enc_wgrad_tile() {
+    static const int tile = getenv("MASR_ENC_WGRAD_TILE") ? atoi(getenv("MASR_ENC_WGRAD_TILE")) : 256;      // 256 = 256 x 256 on eight waves (A/B: 128, 64)
+    return tile;
+}
+// do the decoder-row weight gradients wait for the encoder rows' launch?  hkust: 148 tiles of 256 x 256 over 4000 rows + 228 over 640 rows;
+// as two launches the first leaves 108 CUs idle for ~110 us and the second takes ~40 us of its own, as one the short tiles run on those
+// CUs.  They feed nothing but the optimiser and their operands are per-layer buffers.  MASR_SPLIT_WGRAD_LAUNCHES=1: two launches (A/B).
+static bool merge_wgrad_launches(const masr_model* m) {
+    static const bool split = getenv("MASR_SPLIT_WGRAD_LAUNCHES") != nullptr && atoi(getenv("MASR_SPLIT_WGRAD_LAUNCHES")) != 0;
+    return !split && m->wge_defer && enc_wgrad_tile() == 256;
+}
+int flush_wgrads(Ctx& c);
 int flush_enc_wgrads(Ctx& c) {
     masr_model* m = c.m;
-    if (m->wge.n == 0) return 0;
-    Prof p(m, MASR_PROF_WGRAD_ENC, c.s);
-    static const int tile = getenv("MASR_ENC_WGRAD_TILE") ? atoi(getenv("MASR_ENC_WGRAD_TILE")) : 256;      // 256 = 128 x 256 on eight waves (A/B: 128, 64)
-    const int rc = mk_gemm_wgrad_grouped(m->wge, c.s, tile);
+    if (m->wge.n == 0) return flush_wgrads(c);
+    int first = 0;
+    if (m->wg.n > 0 && merge_wgrad_launches(m) && m->wge.n + m->wg.n <= WGRAD_GROUP_MAX) {
+        first = m->wge.n;                                                  // the encoder-row members go first (long reductions)
+        for (int i = 0; i < m->wg.n; ++i) m->wge.p[m->wge.n++] = m->wg.p[i];
+        m->wg.n = 0;
+    }
+    int rc;
+    { Prof p(m, MASR_PROF_WGRAD_ENC, c.s);
+      rc = mk_gemm_wgrad_grouped(m->wge, c.s, enc_wgrad_tile(), first); }
     m->wge.n = 0;
+    if (rc == 0 && m->wg.n > 0) rc = flush_wgrads(c);                      // (a decoder-row group that did not fit the merged list)
     return rc;
 }
 int flush_wgrads(Ctx& c) {
@@ -886,7 +905,8 @@ static int backward(Ctx& c, const float* xs) {
         CK(attn_block_bwd(c, w.sa, a.y16[l], nullptr, a.rows_d, 0, L, L, true, true, nullptr, d.qkv, nullptr, d.ao, d.lse_s, gs, dg.g1,
                           a.gao_d, dg.gqkv, nullptr, a.delta_d, gcur, nullptr, 0, d.site[0], false));
     }
-    CK(flush_wgrads(c));
+    if (merge_wgrad_launches(m) && group_wgrads) m->wg_defer = false;      // (the pending decoder-row group joins flush_enc_wgrads' launch)
+    else CK(flush_wgrads(c));
     CK(memory_kv_bwd(c));
     float* g_dec_in = gcur;                                  // d(decoder input): consumed by embed_bwd after the split-K combine
     // ---- encoder

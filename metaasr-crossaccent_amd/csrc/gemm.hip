@@ -630,12 +630,27 @@ __device__ __forceinline__ void wgrad16_tile(const WgradDesc& d, const int m0, c
             for (int j = 0; j < FN; ++j) { const int n = n0 + wn * 64 + j * 16 + fr; if (n < N) row[n] = acc[i][j][r]; }
         }
 }
-__global__ __launch_bounds__(512) void gemm_wgrad_grouped16_kernel(WgradGroup grp) {
+__global__ __launch_bounds__(512) void gemm_wgrad_grouped16_kernel(WgradGroup grp, int n_first) {
     __shared__ __attribute__((aligned(1024))) char smem[W16_NST * W16_STAGE];
     // XCD-contiguous runs of the tile list (workgroup ids are dealt round-robin to the 8 XCDs; bijective for any tile count): the tiles
-    // that share a dY / X panel meet in ONE L2 -- 507 MB of HBM traffic without this, 2.1 x the algorithmic bytes
-    const int total = gridDim.x, l = blockIdx.x, xc = l & 7, q8 = total >> 3, r8 = total & 7;
-    const int t_ = xc * q8 + (xc < r8 ? xc : r8) + (l >> 3);
+    // that share a dY / X panel meet in ONE L2 -- 507 MB of HBM traffic without this, 2.1 x the algorithmic bytes.
+    // n_first > 0: the list is two segments, the first n_first tiles (long reductions: the encoder rows) and the rest (short ones: the
+    // decoder rows).  Each XCD takes a contiguous run of EACH segment and starts with its long tiles (workgroups are dispatched in id
+    // order): the short tiles then fill the CUs the long ones leave idle instead of being a launch of their own.
+    const int total = gridDim.x, l = blockIdx.x, xc = l & 7, j = l >> 3;
+    auto cnt = [](int n, int x) { return (n >> 3) + (x < (n & 7) ? 1 : 0); };          // what XCD x gets of n items dealt round-robin
+    auto start = [](int n, int x) { const int r = n & 7; return x * (n >> 3) + (x < r ? x : r); };
+    int t_;
+    if (n_first <= 0 || total - n_first < 8) t_ = start(total, xc) + j;
+    else {
+        const int ca = cnt(n_first, xc);
+        if (j < ca) t_ = start(n_first, xc) + j;
+        else {
+            int sb = 0;                                                   // second-segment tiles of the XCDs before this one
+            for (int x = 0; x < xc; ++x) sb += cnt(total, x) - cnt(n_first, x);
+            t_ = n_first + sb + (j - ca);
+        }
+    }
     int p = 0;
     while (p + 1 < grp.n && t_ >= grp.p[p + 1].tile_start) ++p;
     const WgradDesc& d = grp.p[p];
@@ -1040,7 +1055,7 @@ int launch_tile(const GemmArgs& g_in, hipStream_t s) {
 
 }  // namespace
 
-int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s, int tile) {
+int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s, int tile, int first_members) {
     if (grp.n <= 0) return 0;
     if (tile != 64 && tile != 128 && tile != 256) { mk_set_error("mk_gemm_wgrad_grouped", "tile 64, 128 or 256 (= 256 x 256 on eight waves)"); return -1; }
     int tiles = 0;
@@ -1053,9 +1068,12 @@ int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s, int tile) {
         tiles += ((d.N + tile - 1) / tile) * ((d.K + tile - 1) / tile);
     }
     if (tile == 256) {
-        int t16 = 0;
-        for (int i = 0; i < grp.n; ++i) { grp.p[i].tile_start = t16; t16 += ((grp.p[i].N + 255) / 256) * ((grp.p[i].K + 255) / 256); }
-        hipLaunchKernelGGL(gemm_wgrad_grouped16_kernel, dim3(t16), dim3(512), 0, s, grp);
+        int t16 = 0, n_first = 0;
+        for (int i = 0; i < grp.n; ++i) {
+            if (i == first_members) n_first = t16;
+            grp.p[i].tile_start = t16; t16 += ((grp.p[i].N + 255) / 256) * ((grp.p[i].K + 255) / 256);
+        }
+        hipLaunchKernelGGL(gemm_wgrad_grouped16_kernel, dim3(t16), dim3(512), 0, s, grp, first_members > 0 && first_members < grp.n ? n_first : 0);
         if (hipGetLastError() != hipSuccess) { mk_set_error("mk_gemm_wgrad_grouped", "launch failed"); return -1; }
         return 0;
     }

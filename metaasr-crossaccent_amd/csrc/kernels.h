@@ -48,7 +48,7 @@ inline int mk_gemm_ln_blocks(int rows) { return (rows + 63) / 64; }      // dgam
 struct WgradDesc { const bf16* dy; const bf16* x; float* dW; float* db; int lddy, ldx, rows, N, K, tile_start; };
 constexpr int WGRAD_GROUP_MAX = 40;
 struct WgradGroup { int n; WgradDesc p[WGRAD_GROUP_MAX]; };
-int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s, int tile = 64);       // fills tile_start; tile = 64 / 128 (four waves) or 256 (256 x 256 on eight waves, LDS-DMA)
+int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s, int tile = 64, int first_members = 0);       // fills tile_start; tile = 64 / 128 (four waves) or 256 (256 x 256 on eight waves, LDS-DMA; first_members > 0: members [0, first_members) are dispatched first)
 inline GemmArgs gemm_args() { GemmArgs g{}; g.alpha = 1.f; g.mask_scale = 1.f; return g; }
 
 // ---------------------------------------------------------------- conv front-end (conv.hip)
