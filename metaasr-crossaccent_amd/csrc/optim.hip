@@ -301,13 +301,26 @@ __global__ __launch_bounds__(256) void all_shadows_kernel(typename std::conditio
         o.x = upd(pv.x, gv.x, mv.x, mv.x); o.y = upd(pv.y, gv.y, mv.y, mv.y); o.z = upd(pv.z, gv.z, mv.z, mv.z); o.w = upd(pv.w, gv.w, mv.w, mv.w);
         return o;
     };
-    if (d.type == SH_LINEAR) {
+    if (d.type == SH_LINEAR || d.type == SH_VGG2ENC) {
         // 64 x 64 tile: fp32 rows in, through LDS, bf16 out as 16 bytes per lane in BOTH layouts -- the pass is bound by
-        // vector-memory instructions: 4-byte loads and 2-byte stores made 48 of them per wave and tile where 9 suffice
-        const int tc = (d.K + SH_TILE - 1) / SH_TILE;
+        // vector-memory instructions: 4-byte loads and 2-byte stores made 48 of them per wave and tile where 9 suffice.
+        // SH_VGG2ENC is the same tile pass with a column gather on the way in: output column fn = dd * C + c comes from source column
+        // c * Dp + dd (one element per thread and 2-byte scattered stores made this 5 % of the bytes 16 % of the launch's time and 43 % of
+        // its workgroups)
+        const bool vgg = d.type == SH_VGG2ENC;
+        const int dK = vgg ? d.a0 * d.a1 : d.K, dldt = vgg ? d.N : d.ldt;
+        const int tc = (dK + SH_TILE - 1) / SH_TILE;
         const int r0 = (blk / tc) * SH_TILE, c0 = (blk % tc) * SH_TILE;
         __shared__ float t[SH_TILE][SH_TILE + 1];
-        if ((d.K & 3) == 0 && c0 + SH_TILE <= d.K) {
+        if (vgg) {
+            const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 4 rows per pass, 64 consecutive OUTPUT columns per row
+            const int fn = c0 + tx, C = d.a0, Dp = d.a1;
+            const int f = (fn % C) * Dp + fn / C;                        // source column
+            for (int k = ty; k < SH_TILE; k += 4) {
+                const bool ok = r0 + k < d.N && fn < dK;
+                t[k][tx] = ok ? elem(d.src + (long)(r0 + k) * dK + f) : 0.f;
+            }
+        } else if ((d.K & 3) == 0 && c0 + SH_TILE <= d.K) {
             // 16-byte accesses although the tensor sits at an arbitrary dword offset of the flat buffer (P itself is 16-byte aligned):
             // every row of the tile starts `mis` floats past a 16-byte boundary (K % 4 == 0: the same for all rows) and spans 17
             // ALIGNED float4s, the first owned from element `mis` on, the 17th up to it.  SEVENTEEN lanes per row take one vector
@@ -357,22 +370,22 @@ __global__ __launch_bounds__(256) void all_shadows_kernel(typename std::conditio
             const int l = line + 32 * pass;
             {   // k16 [N][K]: line = tile row
                 const int r = r0 + l, c = c0 + sub * 8;
-                if (r < d.N && c < d.K) {
+                if (r < d.N && c < dK) {
                     bf16x8 o;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (bf16)t[l][sub * 8 + e];
-                    if (c + 8 <= d.K) st8(p0 + (long)r * d.K + c, o);
-                    else for (int e = 0; c + e < d.K; ++e) p0[(long)r * d.K + c + e] = o[e];
+                    if (c + 8 <= dK) st8(p0 + (long)r * dK + c, o);
+                    else for (int e = 0; c + e < dK; ++e) p0[(long)r * dK + c + e] = o[e];
                 }
             }
             {   // t16 [K][ldt]: line = tile column, elements run over the tile's rows
                 const int c = c0 + l, r = r0 + sub * 8;
-                if (c < d.K && r < d.N) {
+                if (c < dK && r < d.N) {
                     bf16x8 o;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (bf16)t[sub * 8 + e][l];
-                    if (r + 8 <= d.N) st8(p1 + (long)c * d.ldt + r, o);
-                    else for (int e = 0; r + e < d.N; ++e) p1[(long)c * d.ldt + r + e] = o[e];       // (pads of a padded row stay untouched)
+                    if (r + 8 <= d.N) st8(p1 + (long)c * dldt + r, o);
+                    else for (int e = 0; r + e < d.N; ++e) p1[(long)c * dldt + r + e] = o[e];       // (pads of a padded row stay untouched)
                 }
             }
         }
@@ -384,16 +397,6 @@ __global__ __launch_bounds__(256) void all_shadows_kernel(typename std::conditio
         const bf16 v = (bf16)elem(d.src + i);
         p0[(long)co * 9 * CI + tap * CI + ci] = v;                        // forward: out[co] += in[p+off(tap)][ci] * w
         p1[(long)ci * 9 * CO + (8 - tap) * CO + co] = v;                  // dgrad: din[ci] += dy[p-off(tap)][co] * w
-    } else if (d.type == SH_VGG2ENC) {
-        const int E = d.N, C = d.a0, Dp = d.a1, F = C * Dp;
-        const long i = (long)blk * 256 + threadIdx.x;
-        if (i >= (long)E * F) return;
-        const int f = (int)(i % F), en = (int)(i / F);
-        const int c = f / Dp, dd = f % Dp;                                   // reference feature index c*Dp + d
-        const int fn = dd * C + c;                                           // NHWC feature index
-        const bf16 v = (bf16)elem(d.src + i);
-        p0[(long)en * F + fn] = v;
-        p1[(long)fn * E + en] = v;
     } else {
         const int i = blk * 256 + threadIdx.x;
         if (i < d.N) reinterpret_cast<float*>(p0)[i] = elem(d.src + i);
@@ -514,7 +517,7 @@ int mk_shadow_blocks(const ShadowDesc& d) {
     switch (d.type) {
         case SH_LINEAR: return ((d.N + SH_TILE - 1) / SH_TILE) * ((d.K + SH_TILE - 1) / SH_TILE);
         case SH_CONV: return (d.N * d.K * 9 + 255) / 256;
-        case SH_VGG2ENC: return (int)(((long)d.N * d.a0 * d.a1 + 255) / 256);
+        case SH_VGG2ENC: return ((d.N + SH_TILE - 1) / SH_TILE) * ((d.a0 * d.a1 + SH_TILE - 1) / SH_TILE);
         default: return (d.N + 255) / 256;
     }
 }
