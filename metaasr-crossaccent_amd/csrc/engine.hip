@@ -51,6 +51,7 @@ struct EncGrad { bf16 *g2, *g1, *gf, *gqkv; };          // per-layer gradient op
 struct Acts {
     int B, T, D, H2, W2, Tp, Dp, L, rows_e, rows_d;
     int *tok_in, *gold, *enc_lens, *step_dev;
+    int *tok_order, *tok_start;             // decoder-input token positions sorted by token id + the C + 1 segment starts (embedding backward)
     uint32_t* meta;                                        // [8] behind enc_lens, same upload: [0] dropout seed of the step, [1] 1/n_total (float bits)
     bf16* step_qkv;                                        // incremental decode: the newest position's q|k|v [B][3E]
     bf16 *a1, *a2, *p1, *a3, *a4, *p2;
@@ -221,8 +222,9 @@ void plan_acts(const masr_model* m, Arena& ar, Acts& a, int B, int T, int L, boo
     a.B = B; a.T = T; a.D = m->D; a.H2 = T / 2; a.W2 = m->D / 2; a.Tp = a.H2 / 2; a.Dp = a.W2 / 2; a.L = L;
     a.rows_e = B * a.Tp; a.rows_d = B * L;
     const int64_t re = a.rows_e, rd = a.rows_d;
-    a.tok_in = ar.get<int>(2 * rd + B + 8); a.gold = a.tok_in + rd; a.enc_lens = a.gold + rd;   // one block: one H2D copy per step
+    a.tok_in = ar.get<int>(3 * rd + B + 8 + m->C + 1); a.gold = a.tok_in + rd; a.enc_lens = a.gold + rd;   // one block: one H2D copy per step
     a.meta = reinterpret_cast<uint32_t*>(a.enc_lens + B);
+    a.tok_order = a.enc_lens + B + 8; a.tok_start = a.tok_order + rd;
     a.step_dev = ar.get<int>(4);
     a.step_qkv = ar.get<bf16>((int64_t)B * 3 * E);
     const int64_t P1 = (int64_t)B * T * m->D, P2 = (int64_t)B * a.H2 * a.W2;
@@ -970,7 +972,7 @@ static int backward(Ctx& c, const float* xs) {
     // ---- combine the split-K partials of all Linear gradients, then add the embedding rows into the (tied) table
     { Prof p(m, MASR_PROF_MISC, s);
       if (m->wg_split > 1 && !m->wge_defer) CK(mk_split_reduce(G, a.wg_slab, m->wg_split - 1, m->nparams, m->d_ranges, m->nranges, s));
-      CK(mk_embed_bwd(a.tok_in, g_dec_in, G + m->embed_w, a.rows_d, m->C, E, m->cfg.tie_weights ? 1 : 0, c.p_pos, c.seed, a.site_emb, s, c.seed_ptr)); }
+      CK(mk_embed_bwd(a.tok_order, a.tok_start, g_dec_in, G + m->embed_w, m->C, E, m->cfg.tie_weights ? 1 : 0, c.p_pos, c.seed, a.site_emb, s, c.seed_ptr)); }
     return 0;
 }
 
@@ -987,7 +989,8 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
     plan_acts(m, ar, m->acts, B, T, L, train);
     if (ar.off > m->ws_bytes) { mk_set_error("masr_run_batch", "workspace too small (see masr_workspace_bytes)"); return -2; }
     Acts& a = m->acts; m->have_acts = true;
-    if ((int64_t)2 * B * L + B + 8 > m->stage_ints) { mk_set_error("masr_run_batch", "token staging buffer too small"); return -1; }
+    const int64_t stage_n = (int64_t)3 * B * L + B + 8 + m->C + 1;        // tok_in | gold | enc_lens | meta | tok_order | tok_start
+    if (stage_n > m->stage_ints) { mk_set_error("masr_run_batch", "token staging buffer too small"); return -1; }
     // ---- MyTransformer.preprocess (:124-141): ys_in = [sos]+y padded with eos, ys_out = y+[eos] padded with -1
     const int slot = m->stage_slot; m->stage_slot = (slot + 1) & 3;
     HIP_CHECK_RET(hipEventSynchronize(m->stage_ev[slot]));
@@ -1016,7 +1019,18 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
     m->step++;
     const float inv_ntot = 1.0f / (float)ntot;
     std::memcpy(h_len + B, &c.seed, 4); std::memcpy(h_len + B + 1, &inv_ntot, 4);     // Acts::meta
-    HIP_CHECK_RET(hipMemcpyAsync(a.tok_in, h, sizeof(int) * ((size_t)2 * B * L + B + 8), hipMemcpyHostToDevice, s));   // tok_in | gold | enc_lens | meta
+    {   // the decoder-input positions grouped by token (counting sort, stable: ascending position inside a token) for the embedding backward
+        int* h_order = h_len + B + 8; int* h_start = h_order + (int64_t)B * L;
+        const int rd = B * L, V = m->C;
+        for (int v = 0; v <= V; ++v) h_start[v] = 0;
+        for (int r = 0; r < rd; ++r) h_start[h_in[r] + 1]++;
+        for (int v = 0; v < V; ++v) h_start[v + 1] += h_start[v];
+        // (fill with a running cursor kept in the start array itself, then shift it back)
+        for (int r = 0; r < rd; ++r) h_order[h_start[h_in[r]]++] = r;
+        for (int v = V; v > 0; --v) h_start[v] = h_start[v - 1];
+        h_start[0] = 0;
+    }
+    HIP_CHECK_RET(hipMemcpyAsync(a.tok_in, h, sizeof(int) * (size_t)stage_n, hipMemcpyHostToDevice, s));   // tok_in | gold | enc_lens | meta | tok_order | tok_start
     HIP_CHECK_RET(hipEventRecord(m->stage_ev[slot], s));
 
     auto run = [&](Ctx& cc) -> int {

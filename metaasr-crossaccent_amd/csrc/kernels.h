@@ -163,8 +163,9 @@ int mk_layernorm_bwd_reduce_grouped(const LnReduceGroup& grp, int E, hipStream_t
 int mk_embed_fwd(const int* tok, const float* table, const float* pe, float* y32, bf16* y16,
                    int B, int L, int E, float drop_p, uint32_t seed, uint32_t site, hipStream_t s, const uint32_t* seed_ptr = nullptr);
 // dtable[v] (+)= sum over rows with tok==v of dy[row]  (deterministic: one block per vocab row)
-int mk_embed_bwd(const int* tok, const float* dy, float* dtable, int rows, int V, int E, int accumulate,
-                   float drop_p, uint32_t seed, uint32_t site, hipStream_t s, const uint32_t* seed_ptr = nullptr);
+// order / start: the token positions sorted by token id (ascending position inside a token) and the V + 1 segment starts, from the host
+int mk_embed_bwd(const int* order, const int* start, const float* dy, float* dtable, int V, int E, int accumulate,
+                 float drop_p, uint32_t seed, uint32_t site, hipStream_t s, const uint32_t* seed_ptr = nullptr);
 // greedy decode: build the next decoder input from the previous step's tokens; arg-max of every logits row
 int mk_recog_build_tok(int* tok, const int* out, int B, int L, int sos, hipStream_t s);
 int mk_recog_argmax(const float* logits, long ld, int* out, int B, int L, int C, hipStream_t s);
