@@ -630,9 +630,9 @@ def main():
             "conv3_fwd": ("conv3x3_stream_kernel<64,128> (64->128 forward; + the ReLU mask of its output as 16 bytes of sign bits per pixel)", c3, B * H2 * W2 * ((64 + 128) * 2 + 16)),
             "conv4_fwd": ("conv3x3_stream_kernel<128,128> (128->128 forward + fused 2x2 max-pool, pooled map + codes out)", c4, B * H2 * W2 * 128 * 2 + B * (H2 // 2) * (W2 // 2) * 128 * 3),
             # (reads d(conv2 out), the ReLU mask of conv1's output as one 64-bit word per pixel, the fp32 network input; writes 640 sums per workgroup)
-            "conv2_dgrad": ("conv3x3_resw_w1x_kernel (64<-64 dgrad on 16x16 tiles + fused conv1 weight gradient)", c2, B * T * D * 64 * 2 + B * T * D * (8 + 4)),
+            "conv2_dgrad": ("conv3x3_resw_w1x_kernel<unpool> (64<-64 dgrad on 16x16 tiles, patches expanded from the pooled gradient + pool codes, + fused conv1 weight gradient)", c2, B * H2 * W2 * 64 * 3 + B * T * D * (8 + 4)),
             "conv3_dgrad": ("conv3x3_stream_kernel<128,64> (64<-128 dgrad)", c3, B * H2 * W2 * (128 + 64) * 2),
-            "conv4_dgrad": ("conv3x3_stream_kernel<128,128,32-row tiles,sign-bit mask> (128<-128 dgrad through the ReLU mask)", c4, B * H2 * W2 * (256 * 2 + 16)),
+            "conv4_dgrad": ("conv3x3_stream_kernel<128,128,32-row tiles,sign-bit mask,unpool> (128<-128 dgrad through the ReLU mask, patches expanded from the pooled gradient + pool codes)", c4, B * (H2 // 2) * (W2 // 2) * 128 * 3 + B * H2 * W2 * (128 * 2 + 16)),
             # (the wgrad slots time the partial-slab kernel alone; the slab reduces are under conv1_wgrad, "weight-gradient folds")
             # (the two in front of a max-pool read their dy as pooled gradient (2 B) + pool code (1 B) per pooled element; every launch
             # writes 256 partial slabs of 9*CIN*COUT fp32 per 64x64 channel block: 37.7 MB)
@@ -694,7 +694,7 @@ def main():
         for c_, g_ in gf.items():
             t_ = per_class[c_]["ms_per_step"] * 1e-3
             per_class[c_].update({"algorithmic_gflop_per_step": g_, "tflops": g_ / 1e3 / t_, "frac_of_bf16_peak": g_ / 1e3 / t_ / PEAK_BF16_TFLOPS})
-        per_class["other"]["note"] = "HBM-bound passes: LayerNorm, pools, loss/embedding, grad-norm + clip + SGD (24 B/param), operand shadows"
+        per_class["other"]["note"] = "HBM-bound passes: LayerNorm, loss/embedding, grad-norm + clip + SGD (24 B/param), operand shadows"
         # the HBM-bound class against the HBM roofline: ALGORITHMIC bytes of each pass (what it must read + write once) over its measured time
         NP = eng.numel
         E_, Tp_ = cfg["d_model"], T // 4
@@ -705,13 +705,14 @@ def main():
             "optim": NP * (4 + 20),              # grad-norm reads g; clip + SGD reads p, g, momentum and writes p, momentum
             "shadows": NP * (4 + 2 + 2),         # fp32 weights in, bf16 operand + its transpose out
             "layernorm": ln_elems * (10 + 14),   # fwd: x in, y fp32 + bf16 out; bwd: dy + x in, dx fp32 + bf16 out
-            "pool": B * (H2 * W2 * 64 * 3 + T * D * 64 * 2 + (H2 // 2) * (W2 // 2) * 128 * 3 + H2 * W2 * 128 * 2),   # pooled gradient + codes in, dense map out
             "conv1_fwd": B * T * D * (4 + 64 * 2 + 8),   # fp32 input in, 64-channel bf16 map + one 64-bit word of ReLU sign bits per pixel out
         }
+        # (no `pool` pass since round 5: the dgrad and weight-gradient kernels behind a max-pool expand pooled gradient + codes themselves)
+        hbm_bytes = {k: v for k, v in hbm_bytes.items() if prof_all[k][0] > 0}
         if prof_all["shadows"][0] == 0:
             # the SGD step runs INSIDE the shadow launch (MASR_FUSED_SGD=1): p is read once; one pass, timed under `optim`
             hbm_bytes["optim"] = NP * (4 + 20 + 4)
-            del hbm_bytes["shadows"]
+            hbm_bytes.pop("shadows", None)
         t_hbm = sum(prof_all[k][0] for k in hbm_bytes) / nprof * 1e-3
         b_hbm = float(sum(hbm_bytes.values()))
         per_class["other"].update({

@@ -187,6 +187,9 @@ masr_comm* masr_allreduce_init(int rank, int world, const char* id);
 void masr_allreduce_destroy(masr_comm* c);
 int masr_allreduce(masr_comm* c, float* buf, int64_t n, const float* norm, float max_norm, int nchunks, void* producer_stream);
 int masr_allreduce_wait(masr_comm* c, void* stream);
+/* host-side health check of the exchange: 0 = the last exchange completed (or none is pending), 1 = still running (timeout_ms == 0: one
+ * poll), -1 = RCCL reports an asynchronous error, or timeout_ms ran out -- the communicator is then aborted and the job must end. */
+int masr_allreduce_check(masr_comm* c, int timeout_ms);
 /* device view of the model's stats block: [0] loss, [1] n_correct, [2] n_total, [3] gradient norm (after masr_grad_norm / masr_clip_*) */
 const float* masr_stats_device(masr_model* m);
 
@@ -339,9 +342,17 @@ int masr_test_conv3x3_sign_bits(const uint16_t* in, const uint16_t* wk, const fl
 int masr_test_conv3x3_pool_idx(const uint16_t* in, const uint16_t* wk, const float* bias, uint16_t* out, uint16_t* pool_out,
                                uint8_t* pool_idx, int drop_out, int B, int H, int W, int CIN, int COUT, void* stream);
 int masr_test_maxpool_idx_bwd(const uint8_t* idx, const uint16_t* dout, uint16_t* din, int B, int H, int W, int C, void* stream);
-/* same launch with per-workgroup phase timing: prof receives 6 cycle counts per workgroup (tools/prof_conv_phases.py) */
-int masr_test_conv3x3_prof(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, uint16_t* out,
-                           int B, int H, int W, int CIN, int COUT, int64_t* prof, void* stream);
+/* The two dgrad launches that sit behind a max-pool (reference: the autograd of nn.MaxPool2d + nn.ReLU in front of nn.Conv2d,
+ * mono_transformer_torch.py:51-52,57-58).  Input either as the map dy [B][H][W][C] or -- dy == NULL -- as the pooled gradient dy_pooled
+ * [B][H/2][W/2][C] + the codes of masr_test_conv3x3_pool_idx, expanded while the patches are staged (no map in memory): same bits.
+ * masr_test_conv3x3_dgrad_pooled: 128 <- 128 channels through the ReLU mask given as sign words (masr_test_conv3x3_sign_bits).
+ * masr_test_conv1_wgrad_fused: 64 <- 64 channels whose output is contracted with the network input x1 [B][H][W] inside the launch:
+ * dw1 [64][9], db1 [64] = the weight / bias gradient of the FIRST conv; mask_bits = one 64-bit word of sign bits per pixel. */
+int masr_test_conv3x3_dgrad_pooled(const uint16_t* dy, const uint16_t* dy_pooled, const uint8_t* pool_idx, const uint16_t* wk, const uint32_t* mask_bits,
+                                   uint16_t* out, int B, int H, int W, void* stream);
+int64_t masr_test_conv1_wgrad_fused_slab_floats(int B, int H, int W);
+int masr_test_conv1_wgrad_fused(const uint16_t* dy, const uint16_t* dy_pooled, const uint8_t* pool_idx, const uint16_t* wk, const uint64_t* mask_bits,
+                                const float* x1, float* slab, int64_t slab_floats, float* dw1, float* db1, int B, int H, int W, void* stream);
 int masr_test_conv3x3_wgrad(const uint16_t* in, const uint16_t* dy, float* dw, float* slab, int64_t slab_floats,
                             int B, int H, int W, int CIN, int COUT, void* stream);
 int64_t masr_test_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT);

@@ -60,6 +60,7 @@ _SIGS = {
     "masr_allreduce_destroy": (None, [vp]),
     "masr_allreduce": (i32, [vp, vp, i64, vp, f32, i32, vp]),
     "masr_allreduce_wait": (i32, [vp, vp]),
+    "masr_allreduce_check": (i32, [vp, i32]),
     "masr_stats_device": (vp, [vp]),
     "masr_recog": (i32, [vp, vp, vp, i32, i32, vp, vp]),
     "masr_recog_full": (i32, [vp, vp, vp, i32, i32, vp, vp]),
@@ -97,7 +98,9 @@ _SIGS = {
     "masr_test_conv3x3_sign_bits": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "masr_test_conv3x3_pool_idx": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "masr_test_maxpool_idx_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
-    "masr_test_conv3x3_prof": (i32, [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "masr_test_conv3x3_dgrad_pooled": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "masr_test_conv1_wgrad_fused_slab_floats": (i64, [i32, i32, i32]),
+    "masr_test_conv1_wgrad_fused": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, vp]),
     "masr_test_conv3x3_wgrad": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     "masr_test_conv3x3_wgrad_slab_floats": (i64, [i32, i32, i32, i32, i32]),
     "masr_test_wgrad_grouped": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, vp]),

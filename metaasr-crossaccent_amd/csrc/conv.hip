@@ -217,108 +217,6 @@ static void launch_conv1_reduce(float* slab, int nb, float* dw, float* db, hipSt
     hipLaunchKernelGGL(conv1_wgrad_reduce, dim3(40, 1), dim3(256), 0, s, part, C1_RSPLIT, dw, db, nullptr);
 }
 
-// ------------------------------------------------------------------ implicit GEMM 3x3 (fwd and dgrad)
-template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
-    constexpr int BM = 128;
-    constexpr int WGN = COUT / 64, WGM = 4 / WGN;        // wave grid
-    constexpr int WM = BM / WGM, WN = 64;
-    constexpr int FM = WM / 16, FN = 4;
-    constexpr int KTOT = 9 * CIN, NK = KTOT / BK;
-    constexpr int BCH = COUT * BK / 8 / 256;              // B chunks per thread (1 or 2)
-    __shared__ __attribute__((aligned(16))) bf16 sA[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) bf16 sB[2][COUT * LDK];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
-    const long P = (long)a.B * a.H * a.W;
-    const long m0 = (long)blockIdx.x * BM;
-    const int H = a.H, W = a.W;
-
-    // the two A rows (pixels) this thread stages are fixed over the K loop
-    long pix[2]; int pt[2], pd[2]; bool pv[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = (tid + i * 256) >> 2;
-        pix[i] = m0 + r;
-        pv[i] = pix[i] < P;
-        pd[i] = (int)(pix[i] % W);
-        pt[i] = (int)((pix[i] / W) % H);
-    }
-    const int kc = (tid & 3) * 8;
-
-    bf16x8 ra[2], rb[BCH];
-    auto load = [&](int kt) {
-        const int tap = (kt * BK) / CIN, ci0 = (kt * BK) % CIN;
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int tt = pt[i] + dy, dd = pd[i] + dx;
-            bf16x8 v = zero8();
-            if (pv[i] && tt >= 0 && tt < H && dd >= 0 && dd < W)
-                v = ld8(a.in + (pix[i] + (long)dy * W + dx) * CIN + ci0 + kc);
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < BCH; ++i) {
-            const int c = tid + i * 256;
-            rb[i] = ld8(a.wk + (long)(c >> 2) * KTOT + kt * BK + (c & 3) * 8);
-        }
-    };
-    auto store = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) st8(&sA[buf][((tid + i * 256) >> 2) * LDK + kc], ra[i]);
-#pragma unroll
-        for (int i = 0; i < BCH; ++i) {
-            const int c = tid + i * 256;
-            st8(&sB[buf][(c >> 2) * LDK + (c & 3) * 8], rb[i]);
-        }
-    };
-
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    load(0);
-    store(0);
-    __syncthreads();
-    for (int kt = 0; kt < NK; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < NK) load(kt + 1);
-        bf16x8 af[FM], bfr[FN];
-        const int kq = (lane >> 4) * 8, rr = lane & 15;
-#pragma unroll
-        for (int i = 0; i < FM; ++i) af[i] = ld8(&sA[cur][(wm * WM + i * 16 + rr) * LDK + kq]);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) bfr[j] = ld8(&sB[cur][(wn * WN + j * 16 + rr) * LDK + kq]);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
-        if (kt + 1 < NK) store(cur ^ 1);
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long p = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
-            if (p >= P) continue;
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int co = wn * WN + j * 16 + (lane & 15);
-                float v = acc[i][j][r];
-                if (a.bias) v += a.bias[co];
-                if (a.relu) v = fmaxf(v, 0.f);
-                if (a.mask) v = ((float)a.mask[p * COUT + co] > 0.f) ? v : 0.f;
-                a.out[p * COUT + co] = (bf16)v;
-            }
-        }
-}
-
 // fragment of a reduction-major LDS tile [k][m] (row stride LDT): 32 k-rows x columns r0..r0+15 through two transposing reads
 template <int LDT>
 __device__ __forceinline__ bf16x8 frag_rm(const bf16* tile, int r0, int lane) {
@@ -340,14 +238,9 @@ __device__ __forceinline__ bf16x8 frag_rm(const bf16* tile, int r0, int lane) {
 // re-fetch: HBM/L2 traffic per output pixel drops from 9x to ~1.3x the input bytes); the per-tap weight slice
 // [COUT][64] is double-buffered through registers.  4 waves, wave w owns TH/4 pixel rows x all COUT.
 // LDS: patch pixel / weight row stride 80 elements (160 B), conflict-free for the four 16-lane groups of ds_read_b128.
-// W1 = true (dgrad of the second conv only): the tile of d(conv1 output) never goes to HBM.  Its only consumer is the
-// weight gradient of conv1 (the network input needs no gradient), so the epilogue contracts the masked tile in LDS with
-// the 3x3 neighbourhoods of the 1-channel input on the MFMA -- [64 channels] x [9 taps + a column of ones for the bias
-// gradient] over the 256 pixels of the tile -- and writes 640 partial sums per workgroup (folded by conv1_wgrad_reduce).
-// This removes the 164 MB store, the 164 MB re-read and the whole conv1_wgrad launch.
 // TW = 8 (tile 8 pixels wide, an MFMA pixel tile = 2 rows x 8 columns) exists for maps whose width is not a multiple
 // of 16: the 40-column maps behind the first pool would waste 8 of every 48 columns (17 % of the MFMAs) with TW = 16.
-template <int CIN, int COUT, int TH, bool W1 = false, int TW = 16, bool PROF = false>
+template <int CIN, int COUT, int TH, int TW = 16>
 __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
     constexpr int PW = TW + 2, PH = TH + 2, RPT = 16 / TW;     // RPT = pixel rows per 16-pixel MFMA tile
     constexpr int PS = 80;                                 // patch pixel stride (elements): 160 B is conflict-free for the
@@ -367,30 +260,11 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
     const int d0 = blockIdx.x * TW, t0 = blockIdx.y * TH, b = blockIdx.z;
     const bf16* in_b = a.in + (long)b * H * W * CIN;
 
-    // W1: the (TH+2) x 18 neighbourhood of the 1-channel network input, fetched now, used in the epilogue
-    float x1v[2] = {0.f, 0.f};
-    if constexpr (W1) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + i * 256;
-            const int pi = c / PW, pj = c % PW, t = t0 + pi - 1, d = d0 + pj - 1;
-            const int tc = t < 0 ? 0 : (t > H - 1 ? H - 1 : t), dc = d < 0 ? 0 : (d > W - 1 ? W - 1 : d);
-            const float v = a.x1[((long)b * H + tc) * W + dc];
-            x1v[i] = (c < PH * PW && t == tc && d == dc) ? v : 0.f;
-        }
-    }
-
     f32x4 acc[MF][NF];
 #pragma unroll
     for (int i = 0; i < MF; ++i)
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // PROF instances only (tools/prof_conv_phases.py): cycles wave 0 spends in
-    // [0] patch load+stage  [1] weight-prefetch issue  [2] fragment reads + MFMAs  [3] weight stage  [4] barrier  [5] epilogue
-    long pt[6] = {0, 0, 0, 0, 0, 0};
-    long tprev = PROF ? clock64() : 0;
-    auto stamp = [&](int k) { if constexpr (PROF) { const long now = clock64(); pt[k] += now - tprev; tprev = now; } };
 
     bf16x8 rw[WCH];
     auto load_w = [&](int slab, int tap) {
@@ -434,11 +308,9 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
         load_w(slab, 0);
         store_w(wbuf0 + (step & 1) * W_EL);
         __syncthreads();
-        stamp(0);
         for (int tap = 0; tap < 9; ++tap, ++step) {
             const bf16* wcur = wbuf0 + (step & 1) * W_EL;
             if (tap + 1 < 9) load_w(slab, tap + 1);
-            stamp(1);
             // keep the weight prefetch HERE: hipcc otherwise sinks the global loads to just before their LDS store,
             // exposing one L2 round trip per tap (9 per slab, longer than the tap's 32 MFMAs)
             __builtin_amdgcn_sched_barrier(0);
@@ -456,11 +328,8 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
 #pragma unroll
                     for (int j = 0; j < NF; ++j) acc[i][j] = mma16(bfr[j], af[i], acc[i][j]);   // weights as A: a lane ends up with 4 consecutive channels
             }
-            stamp(2);
             if (tap + 1 < 9) store_w(wbuf0 + ((step + 1) & 1) * W_EL);
-            stamp(3);
             __syncthreads();
-            stamp(4);
         }
     }
 
@@ -535,57 +404,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) if (!((float)mv[i][k] > 0.f)) v[k] = (bf16)0.f;
             }
-            if constexpr (!W1) st8(out_b + ((long)t * W + d) * COUT + ch, v);
-        } else {
-            v = zero8();
-        }
-        if constexpr (W1) st8(otile + pix * OS + ch, v);        // masked tile (zeros outside the image) stays in LDS
-    }
-    if constexpr (W1) {
-        static_assert(!W1 || (COUT == 64 && TH == 16), "fused conv1 wgrad: 64 channels, 16 x 16 pixel tile");
-        constexpr int XS = 256 + 8;                               // row stride of the tap-major input image
-        bf16* sxt = lds + OUT_EL;                                 // [16 taps][XS]: taps 0..8, 9 = ones (bias), 10..15 = 0
-        float* sxp = reinterpret_cast<float*>(sxt + 16 * XS);     // [(TH+2) * 18] input neighbourhood
-        static_assert(!W1 || (OUT_EL + 16 * XS) * 2 + PH * PW * 4 <= LDS_EL * 2, "LDS budget of the fused epilogue");
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { const int c = tid + i * 256; if (c < PH * PW) sxp[c] = x1v[i]; }
-        __syncthreads();
-        {   // thread = pixel: its 9 neighbours + 1 go to column kappa(pixel) of the tap-major image.  kappa undoes the
-            // k-permutation of frag_rm (MFMA k index 8g+j <-> tile row 4g+j for j < 4, 16+4g+(j-4) for j >= 4).
-            const int pr = tid >> 4, pc = tid & 15;
-            const int rho = tid & 31, slab = tid >> 5;
-            const int kap = rho < 16 ? 8 * (rho >> 2) + (rho & 3) : 8 * ((rho - 16) >> 2) + 4 + (rho & 3);
-            const bool in_img = t0 + pr < H && d0 + pc < W;
-#pragma unroll
-            for (int tap = 0; tap < 16; ++tap) {
-                float v = 0.f;
-                if (tap < 9) v = sxp[(pr + tap / 3) * PW + pc + tap % 3];
-                else if (tap == 9) v = 1.f;
-                sxt[tap * XS + slab * 32 + kap] = (bf16)(in_img ? v : 0.f);
-            }
-        }
-        __syncthreads();
-        // wave w: output channels 16w .. 16w+15 x 16 taps, contraction over the 256 pixels (8 slabs of 32)
-        f32x4 cw = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int sl = 0; sl < 8; ++sl) {
-            const bf16x8 af = frag_rm<OS>(otile + sl * 32 * OS, wave * 16, lane);
-            const bf16x8 bf = ld8(sxt + (lane & 15) * XS + sl * 32 + (lane >> 4) * 8);
-            cw = mma16(af, bf, cw);
-        }
-        const int tap = lane & 15;
-        if (tap < 10) {
-            const long wg = ((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a.w1_slab[wg * 640 + (wave * 16 + 4 * (lane >> 4) + r) * 10 + tap] = cw[r];
-        }
-    }
-    if constexpr (PROF) {
-        stamp(5);
-        if (tid == 0) {
-            const long wg = ((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) a.prof[wg * 6 + k] = pt[k];
+            st8(out_b + ((long)t * W + d) * COUT + ch, v);
         }
     }
 }
@@ -609,6 +428,27 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
 //     CONSECUTIVE output channels: the epilogue is bias/ReLU in registers and one 16-byte global store per (pixel
 //     tile, 32-channel group) -- no LDS round trip, no barrier; the 2x2 max-pool is taken across registers and lanes.
 __device__ __attribute__((aligned(128))) bf16 g_zero_line[64];
+
+// MaxPool2d(2,2) + ReLU backward of ONE pooled cell x 8 channels, as the patch producers of the UNPOOL dgrad flavours need it: g = the
+// cell's gradient (4 dwords of 2 bf16), code = its 8 pool codes (ConvArgs::pool_idx: window position 0..3 of the first maximum, 4 = nothing
+// passed the ReLU); o[k] = the 8 channels of window position k (row-major), the gradient where code == k, else 0.  0x80 - (code ^ k) has bit
+// 7 of a byte set exactly where the codes match (codes are 0..4: no borrow crosses a byte); v_perm moves the two bytes of a channel pair
+// into the high bytes of the 16-bit halves and an arithmetic shift makes them 0xffff / 0 masks: 16 vector instructions per position.
+__device__ __forceinline__ void unpool_expand(__attribute__((ext_vector_type(4))) unsigned g, uint2 code, __attribute__((ext_vector_type(4))) unsigned (&o)[4]) {
+    typedef __attribute__((ext_vector_type(2))) short sh2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned kx = 0x01010101u * (unsigned)k;
+        const unsigned e0 = 0x80808080u - (code.x ^ kx), e1 = 0x80808080u - (code.y ^ kx);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const unsigned e = kk < 2 ? e0 : e1;
+            const unsigned m = __builtin_amdgcn_perm(e, e, (kk & 1) ? 0x030C020Cu : 0x010C000Cu);
+            const sh2 mm = __builtin_bit_cast(sh2, m) >> 15;
+            o[k][kk] = g[kk] & __builtin_bit_cast(unsigned, mm);
+        }
+    }
+}
 __device__ unsigned g_conv_sched[2];                      // tile counter of launches that bring none (single-stream tools and tests)
 
 // MASK = 0: forward flavour (bias, ReLU flag, optional fused pool); MASK = 1: dgrad flavour (outputs zeroed where a.mask <= 0;
@@ -616,8 +456,11 @@ __device__ unsigned g_conv_sched[2];                      // tile counter of lau
 // bytes of channel groups 8q.., 32+8q.., 64+8q.., 96+8q.. -- exactly what lane (rr, q) masks, so ONE 4-byte load per pixel where the
 // bf16 map costs four 16-byte ones, and 4 mask registers instead of 64: room for the 32-row tiles of the unmasked kernels).
 // The forward flavour with 128 output channels writes those words for ITS output when a.out_sign_bits is set.
-template <int CIN, int COUT, int TH, int TW, int MASK, bool PROF = false>
-__global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int ntiles, int tiles_x, int tiles_y, int chunk) {
+// UNPOOL (dgrad behind a max-pool): the input map is never materialised -- three producer waves (5, 6, 7; one per SIMD beside an MFMA
+// wave, the fourth SIMD hosts the weight wave) build each stage's patch from the POOLED gradient a.in_pooled [B][H/2][W/2][CIN] and the
+// one-byte pool codes a.in_idx (ConvArgs::pool_idx of the forward launch), see unpool_expand.  512 threads.
+template <int CIN, int COUT, int TH, int TW, int MASK, bool UNPOOL = false>
+__global__ __launch_bounds__(UNPOOL ? 512 : 384) void conv3x3_stream_kernel(ConvArgs a, int ntiles, int tiles_x, int tiles_y) {
     constexpr int PW = TW + 2, PH = TH + 2, RPT = 16 / TW;
     constexpr int MF = TH * TW / 64, NF = COUT / 16, NH = NF / 2;
     constexpr int KTOT = 9 * CIN, NSLAB = CIN / 64;
@@ -648,14 +491,6 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
     // stage's patch -- have landed, and that every MFMA wave is done with tap u-1's slice (and, at the first tap of a
     // stage, with the previous stage's patch).  The MFMA waves read the fragments of the next half-tap before issuing the
     // MFMAs of the current one, so the barrier wait and the LDS latency sit under 16 MFMAs already in the pipe.
-    // PROF instances (tools/prof_conv_phases.py), cycles per workgroup: MFMA wave 0 [0] start-up [1] tap loops (reads, MFMAs,
-    // barriers) [2] epilogues; weight wave [3] waiting for slices; patch wave [4] issuing DMAs [5] waiting for the patch
-    // PROF instances also take ablation bits in a.relu >> 8: 1 = no patch DMA after the first, 2 = no weight DMA after the
-    // first ring fill, 4 = no epilogue (results are then garbage; timing only)
-    const int dbg = PROF ? a.relu >> 8 : 0;
-    long pt[3] = {0, 0, 0};
-    long tprev = PROF ? clock64() : 0;
-    auto stamp = [&](int k) { if constexpr (PROF) { const long now = clock64(); pt[k] += now - tprev; tprev = now; } };
     // (an LDS-qualified volatile read: through a generic `volatile int*` hipcc emits flat_load_dword sc0 sc1 + s_waitcnt vmcnt(0), i.e.
     // the read queues at the texture addresser behind the patch wave's DMA pieces and waits for all of this wave's stores)
     auto read_tileq = [&](int k) { return __builtin_amdgcn_readfirstlane(*(volatile __attribute__((address_space(3))) int*)&tileq[k & 3]); };
@@ -681,24 +516,127 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
             if (++it == 9) { it = 0; if (++is == NSLAB) is = 0; }
         };
         for (int k = 0; k < D - 1; ++k) issue_next();
-        stamp(1);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WPIECES) : "memory");
-        stamp(0);
         asm volatile("s_barrier" ::: "memory");           // opening barrier: slice 0 is in
         for (int k = 0; read_tileq(k) >= 0; ++k) {
             for (int u = 0; u < 9 * NSLAB; ++u) {
-                stamp(1);
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPIECES) : "memory");   // slice u+1 is in, u+2 may be in flight
-                stamp(0);
                 asm volatile("s_barrier" ::: "memory");
-                if (!(dbg & 2)) issue_next();              // slice u+3 -> the slot of tap u-1
+                issue_next();                              // slice u+3 -> the slot of tap u-1
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the read-ahead past the last tile lands before the LDS is released
-        if constexpr (PROF) { if (lane == 0) a.prof[blockIdx.x * 6 + 3] = pt[0]; }
         return;
     }
-    if (wave == 5) {
+    if constexpr (UNPOOL) {
+    if (wave >= 5) {
+        // ---------------- patch producers.  Item = (pooled cell, 16-byte channel chunk): 16 B of gradient + 8 B of codes in, the cell's
+        // (up to) four patch pixels out.  The patch origin (t0 - 1, d0 - 1) is odd, so the patch covers PH / 2 + 1 pooled rows and
+        // PW / 2 + 1 pooled columns, the first and the last of them with one row / column of their window.  Items are dealt to the
+        // producers round-robin in groups of 64; everything that does not depend on the tile is computed once.
+        constexpr int NPROD = 3, NPR = PH / 2 + 1, NPC = PW / 2 + 1, NITEM = NPR * NPC * 8, NIT = (NITEM + 64 * NPROD - 1) / (64 * NPROD);
+        static_assert(NIT <= 7, "the items of a patch are expanded during taps 1 .. 7");
+        const int pw = wave - 5, H2 = H / 2, W2 = W / 2;
+        int rel[NIT], offA[NIT], offB[NIT], rcf[NIT];      // rcf = R << 16 | Cc << 8 | flags (1 item, 2 upper row, 4 lower row, 8 left, 16 right column in the patch)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = (it * NPROD + pw) * 64 + lane, ee = e < NITEM ? e : 0;
+            const int c = ee & 7, pp = ee >> 3, R = pp / NPC, Cc = pp % NPC, pi0 = 2 * R - 1, pj0 = 2 * Cc - 1;
+            rel[it] = ((R - 1) * W2 + (Cc - 1)) * CIN + c * 8;
+            offA[it] = (pi0 * PW + pj0) * 128 + ((c ^ (pj0 & 7)) << 4);
+            offB[it] = (pi0 * PW + pj0 + 1) * 128 + ((c ^ ((pj0 + 1) & 7)) << 4);
+            rcf[it] = R << 16 | Cc << 8 | (e < NITEM ? 1 : 0) | (pi0 >= 0 ? 2 : 0) | (pi0 + 1 < PH ? 4 : 0) | (pj0 >= 0 ? 8 : 0) | (pj0 + 1 < PW ? 16 : 0);
+        }
+        u32x4 gr[NIT]; uint2 cd[NIT]; unsigned okm = 0;
+        auto issue_loads = [&](int tile, int slab) {
+            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+            const int t2o = ty * (TH / 2), d2o = tx * (TW / 2);
+            const long base = (((long)b * H2 + t2o) * W2 + d2o) * CIN + slab * 64;
+            okm = 0;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int t2 = t2o + (rcf[it] >> 16) - 1, d2 = d2o + ((rcf[it] >> 8) & 255) - 1;
+                const bool ok = (rcf[it] & 1) && (unsigned)t2 < (unsigned)H2 && (unsigned)d2 < (unsigned)W2;   // (floor mode: a cropped last row / column gets no gradient)
+                const long o = ok ? base + rel[it] : (long)(lane & 7) * 8;
+                gr[it] = *reinterpret_cast<const u32x4*>(a.in_pooled + o);
+                cd[it] = *reinterpret_cast<const uint2*>(a.in_idx + o);
+                okm |= (ok ? 1u : 0u) << it;
+            }
+        };
+        auto expand_store = [&](int it, char* dst) {
+            const int f = rcf[it];
+            if (!(f & 1)) return;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            u32x4 o[4];
+            unpool_expand((okm >> it) & 1 ? gr[it] : z, cd[it], o);
+            if (f & 2) {
+                if (f & 8) *reinterpret_cast<u32x4*>(dst + offA[it]) = o[0];
+                if (f & 16) *reinterpret_cast<u32x4*>(dst + offB[it]) = o[1];
+            }
+            if (f & 4) {
+                if (f & 8) *reinterpret_cast<u32x4*>(dst + offA[it] + PW * 128) = o[2];
+                if (f & 16) *reinterpret_cast<u32x4*>(dst + offB[it] + PW * 128) = o[3];
+            }
+        };
+        // Tiles: the FIRST tile of a workgroup is its index (every producer knows it without a hand-over), the later ones come from the
+        // counter as in the DMA flavour (wave 5 fetches, two tiles ahead, and publishes through tileq): tile = gridDim.x + counter value.
+        bool dry = false;
+        const unsigned lim = (unsigned)ntiles, G = gridDim.x;
+        auto issue_fetch = [&]() -> unsigned { unsigned t = 0; if (!dry && lane == 0) t = atomicAdd(&a.sched[0], 1u); return t; };
+        auto went_dry = [&]() {
+            dry = true;
+            if (lane == 0 && atomicAdd(&a.sched[1], 1u) == gridDim.x - 1) { atomicExch(&a.sched[0], 0u); atomicExch(&a.sched[1], 0u); }
+        };
+        auto resolve = [&](unsigned raw) -> int {
+            if (dry) return -1;
+            const unsigned t = G + __builtin_amdgcn_readfirstlane(raw);
+            if (t >= lim) { went_dry(); return -1; }
+            return (int)t;
+        };
+        int cur = (int)blockIdx.x, nxt = -1;
+        if (pw == 0) {
+            nxt = resolve(issue_fetch());
+            if (lane == 0) { tileq[0] = cur; tileq[1] = nxt; }
+        }
+        issue_loads(cur, 0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) expand_store(it, pbuf);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");           // opening barrier: patch 0 and tileq[0..1] are in
+        if (pw != 0) nxt = read_tileq(1);
+        int g = 0;
+        for (int k = 0; cur >= 0; ++k) {
+            int nn = -1;
+            unsigned raw = 0;
+#pragma unroll 1
+            for (int slab = 0; slab < NSLAB; ++slab, ++g) {
+                const bool last_slab = slab == NSLAB - 1;
+                const bool more = !last_slab || nxt >= 0;
+                char* const dst = pbuf + ((g + 1) & 1) * PBYTES;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    if (tap == 8) {
+                        if (pw == 0 && slab == 0) {
+                            nn = resolve(raw);
+                            if (lane == 0) tileq[(k + 2) & 3] = nn;
+                        }
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the next stage's patch (and tile id) is in
+                    }
+                    asm volatile("s_barrier" ::: "memory");
+                    if (pw == 0 && tap == 0 && slab == 0) raw = issue_fetch();         // the tile after next, two tiles ahead
+                    if (more) {
+                        if (tap == 0) issue_loads(last_slab ? nxt : cur, last_slab ? 0 : slab + 1);
+                        else if (tap - 1 < NIT) expand_store(tap - 1 < NIT ? tap - 1 : 0, dst);
+                    }
+                }
+            }
+            if (pw != 0) nn = read_tileq(k + 2);          // (published before the barrier of slab 0's last tap)
+            cur = nxt; nxt = nn;
+        }
+        return;
+    }
+    }
+    if (!UNPOOL && wave == 5) {
         // ---------------- patch stream.  Per-piece source offsets relative to the tile origin are fixed for the launch.
         const int sub = lane >> 3, sl = lane & 7;
         int rel[PPIECES], pij[PPIECES];
@@ -740,19 +678,15 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
         // tile fetch: the counter value comes back through vmcnt like any load, so a fetch is issued at the first tap of a
         // tile and only looked at (resolve) at its last one.  `dry`: a workgroup reports running dry exactly once.
         bool dry = false;
-        // chunk > 0: no counter, workgroup w owns tiles [w * chunk, (w + 1) * chunk) -- short-lived workgroups that give the CU
-        // back every few tiles, for runs where other streams' kernels should be able to slip in between
-        unsigned own = blockIdx.x * (unsigned)chunk;
-        const unsigned lim = chunk > 0 ? (own + chunk < (unsigned)ntiles ? own + chunk : (unsigned)ntiles) : (unsigned)ntiles;
+        const unsigned lim = (unsigned)ntiles;
         auto issue_fetch = [&](unsigned n) -> unsigned {
             unsigned t = 0;
-            if (chunk > 0) { t = own; own += n; }
-            else if (!dry && lane == 0) t = atomicAdd(&a.sched[0], n);
+            if (!dry && lane == 0) t = atomicAdd(&a.sched[0], n);
             return t;
         };
         auto went_dry = [&]() {
             dry = true;
-            if (chunk == 0 && lane == 0 && atomicAdd(&a.sched[1], 1u) == gridDim.x - 1) { atomicExch(&a.sched[0], 0u); atomicExch(&a.sched[1], 0u); }
+            if (lane == 0 && atomicAdd(&a.sched[1], 1u) == gridDim.x - 1) { atomicExch(&a.sched[0], 0u); atomicExch(&a.sched[1], 0u); }
         };
         auto resolve = [&](unsigned raw) -> int {
             if (dry) return -1;
@@ -769,9 +703,7 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
         }
         if (lane == 0) { tileq[0] = cur; tileq[1] = nxt; }
         if (cur >= 0) { begin_patch(cur, 0); issue_pieces(0, 0, PPIECES); }
-        stamp(0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        stamp(1);
         asm volatile("s_barrier" ::: "memory");           // opening barrier: patch 0 and tileq[0..1] are in
         int g = 0;
         for (int k = 0; cur >= 0; ++k) {
@@ -784,7 +716,6 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
                 if (more) begin_patch(last_slab ? nxt : cur, last_slab ? 0 : slab + 1);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
-                    stamp(2);
                     if (tap == 8) {
                         if (slab == 0) {
                             nn = resolve(raw);
@@ -792,17 +723,13 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
                         }
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the next stage's patch (and tile id) is in
                     }
-                    stamp(1);
                     asm volatile("s_barrier" ::: "memory");
-                    stamp(2);
                     if (tap == 0 && slab == 0) raw = issue_fetch(1u);                  // the tile after next, two tiles ahead
-                    if (tap < 6 && more && !(dbg & 1)) issue_pieces(g + 1, tap * PCHUNK, PCHUNK);
-                    stamp(0);
+                    if (tap < 6 && more) issue_pieces(g + 1, tap * PCHUNK, PCHUNK);
                 }
             }
             cur = nxt; nxt = nn;
         }
-        if constexpr (PROF) { if (lane == 0) { a.prof[blockIdx.x * 6 + 4] = pt[0]; a.prof[blockIdx.x * 6 + 5] = pt[1]; } }
         return;
     }
 
@@ -867,11 +794,9 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
     };
 
     AFrags f0, f1;
-    stamp(2);
     asm volatile("s_barrier" ::: "memory");               // opening barrier
     int tile = read_tileq(0);
     if (tile >= 0) load_frags(f0, pbuf, wbuf, 0, 0);
-    stamp(0);
     int g = 0;
     for (int k = 0; tile >= 0; ++k) {
         // this lane's output addressing for the tile
@@ -931,9 +856,7 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
             }
             if (slab == NSLAB - 1) next_tile = read_tileq(k + 1);
         }
-        stamp(1);
         tile = next_tile;
-        if (dbg & 4) continue;
 
         // epilogue of the tile, straight from the accumulators: bias in fp32, round to bf16, then ReLU / pool as
         // packed 16-bit integer ops (for bf16 bit patterns max(x, 0) is max_i16(x, 0), and non-negative values order like integers)
@@ -1029,10 +952,6 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
                 if (a.out_sign_bits && ok) reinterpret_cast<unsigned*>(a.out_sign_bits)[(((long)b * H + tl + i * RPT) * W + dl) * 4 + q] = sgn[i];
             }
         }
-        stamp(2);
-    }
-    if constexpr (PROF) {
-        if (wave == 0 && lane == 0) { a.prof[blockIdx.x * 6 + 0] = pt[0]; a.prof[blockIdx.x * 6 + 1] = pt[1]; a.prof[blockIdx.x * 6 + 2] = pt[2]; }
     }
 }
 
@@ -1043,8 +962,8 @@ __global__ __launch_bounds__(384) void conv3x3_stream_kernel(ConvArgs a, int nti
 // channels the whole filter bank is 72 KiB: a persistent workgroup loads it ONCE, which halves the instruction count per
 // tile, removes the weight wave and leaves one barrier per tile (patch hand-over) instead of nine.
 // LDS: 9 x [64 rows][128 B] weights (rows permuted, chunks XOR-swizzled as above) + two patches = 154 KiB.
-template <int TH, int TW, bool PROF = false>
-__global__ __launch_bounds__(320) void conv3x3_resw_kernel(ConvArgs a, int ntiles, int tiles_x, int tiles_y, int chunk) {
+template <int TH, int TW>
+__global__ __launch_bounds__(320) void conv3x3_resw_kernel(ConvArgs a, int ntiles, int tiles_x, int tiles_y) {
     constexpr int CIN = 64, COUT = 64;
     constexpr int PW = TW + 2, PH = TH + 2, RPT = 16 / TW;
     constexpr int MF = TH * TW / 64, NF = COUT / 16, NH = NF / 2;
@@ -1064,10 +983,6 @@ __global__ __launch_bounds__(320) void conv3x3_resw_kernel(ConvArgs a, int ntile
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int H = a.H, W = a.W;
-    const int dbg = PROF ? a.relu >> 8 : 0;                // ablation bits as in the streaming kernel (1, 4)
-    long pt[3] = {0, 0, 0};
-    long tprev = PROF ? clock64() : 0;
-    auto stamp = [&](int k) { if constexpr (PROF) { const long now = clock64(); pt[k] += now - tprev; tprev = now; } };
     // (an LDS-qualified volatile read: through a generic `volatile int*` hipcc emits flat_load_dword sc0 sc1 + s_waitcnt vmcnt(0), i.e.
     // the read queues at the texture addresser behind the patch wave's DMA pieces and waits for all of this wave's stores)
     auto read_tileq = [&](int k) { return __builtin_amdgcn_readfirstlane(*(volatile __attribute__((address_space(3))) int*)&tileq[k & 3]); };
@@ -1120,19 +1035,15 @@ __global__ __launch_bounds__(320) void conv3x3_resw_kernel(ConvArgs a, int ntile
             }
         };
         bool dry = false;
-        // chunk > 0: no counter, workgroup w owns tiles [w * chunk, (w + 1) * chunk) -- short-lived workgroups that give the CU
-        // back every few tiles, for runs where other streams' kernels should be able to slip in between
-        unsigned own = blockIdx.x * (unsigned)chunk;
-        const unsigned lim = chunk > 0 ? (own + chunk < (unsigned)ntiles ? own + chunk : (unsigned)ntiles) : (unsigned)ntiles;
+        const unsigned lim = (unsigned)ntiles;
         auto issue_fetch = [&](unsigned n) -> unsigned {
             unsigned t = 0;
-            if (chunk > 0) { t = own; own += n; }
-            else if (!dry && lane == 0) t = atomicAdd(&a.sched[0], n);
+            if (!dry && lane == 0) t = atomicAdd(&a.sched[0], n);
             return t;
         };
         auto went_dry = [&]() {
             dry = true;
-            if (chunk == 0 && lane == 0 && atomicAdd(&a.sched[1], 1u) == gridDim.x - 1) { atomicExch(&a.sched[0], 0u); atomicExch(&a.sched[1], 0u); }
+            if (lane == 0 && atomicAdd(&a.sched[1], 1u) == gridDim.x - 1) { atomicExch(&a.sched[0], 0u); atomicExch(&a.sched[1], 0u); }
         };
         int cur, nxt;
         {
@@ -1143,16 +1054,12 @@ __global__ __launch_bounds__(320) void conv3x3_resw_kernel(ConvArgs a, int ntile
         }
         if (lane == 0) { tileq[0] = cur; tileq[1] = nxt; }
         if (cur >= 0) issue_patch(cur, 0);
-        stamp(0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        stamp(1);
         asm volatile("s_barrier" ::: "memory");           // opening barrier: weights (every wave's share), patch 0, tileq[0..1]
         for (int k = 0; cur >= 0; ++k) {
             // tile k is being computed: fetch the id of tile k+2, stream tile k+1's patch, publish, hand over
             const unsigned raw = issue_fetch(1u);
-            stamp(2);
-            if (nxt >= 0 && !(dbg & 1)) issue_patch(nxt, k + 1);
-            stamp(0);
+            if (nxt >= 0) issue_patch(nxt, k + 1);
             int nn = -1;
             if (!dry) {
                 const unsigned t = __builtin_amdgcn_readfirstlane(raw);
@@ -1160,11 +1067,9 @@ __global__ __launch_bounds__(320) void conv3x3_resw_kernel(ConvArgs a, int ntile
             }
             if (lane == 0) tileq[(k + 2) & 3] = nn;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            stamp(1);
             asm volatile("s_barrier" ::: "memory");       // barrier k (middle of tile k's last tap)
             cur = nxt; nxt = nn;
         }
-        if constexpr (PROF) { if (lane == 0) { a.prof[blockIdx.x * 6 + 4] = pt[0]; a.prof[blockIdx.x * 6 + 5] = pt[1]; } }
         return;
     }
 
@@ -1209,7 +1114,6 @@ __global__ __launch_bounds__(320) void conv3x3_resw_kernel(ConvArgs a, int ntile
 
     Frags f0, f1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of the weights
-    stamp(2);
     asm volatile("s_barrier" ::: "memory");               // opening barrier
     int tile = read_tileq(0);
     {   // fragments of (tap 0, first k-half)
@@ -1220,7 +1124,6 @@ __global__ __launch_bounds__(320) void conv3x3_resw_kernel(ConvArgs a, int ntile
 #pragma unroll
         for (int j = 0; j < NF; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f0.b[j]) : "v"(wa), "n"(j * 2048));
     }
-    stamp(0);
     for (int k = 0; tile >= 0; ++k) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
         const int d0 = tx * TW, t0 = ty * TH;
@@ -1249,9 +1152,7 @@ __global__ __launch_bounds__(320) void conv3x3_resw_kernel(ConvArgs a, int ntile
             }
         }
         const int next_tile = read_tileq(k + 1);
-        stamp(1);
         tile = next_tile;
-        if (dbg & 4) continue;
 
         // epilogue as in the streaming kernel
         const int H2 = H / 2, W2 = W / 2;
@@ -1311,307 +1212,15 @@ __global__ __launch_bounds__(320) void conv3x3_resw_kernel(ConvArgs a, int ntile
                 }
             }
         }
-        stamp(2);
-    }
-    if constexpr (PROF) {
-        if (wave == 0 && lane == 0) { a.prof[blockIdx.x * 6 + 0] = pt[0]; a.prof[blockIdx.x * 6 + 1] = pt[1]; a.prof[blockIdx.x * 6 + 2] = pt[2]; }
     }
 }
 
 // ------------------------------------------------------------------ 64 -> 64 dgrad of the second conv with the conv1 weight gradient fused
-// Same skeleton as the resident-weight kernel (persistent workgroups, filter bank in LDS, patch stream by LDS-DMA), tiles of
-// 8 x 16 pixels so that the epilogue's staging fits next to the 72 KiB of weights: the accumulators are masked with the
-// ReLU mask of conv1's output (fetched three taps ahead), written to LDS as a bf16 tile and contracted on the MFMA with the
-// 3 x 3 neighbourhoods of the 1-channel network input (streamed in with the patch) -- d(conv1 output) is never stored.
-// Each wave keeps its 16 channels x 16 taps partial in registers over ALL tiles of the workgroup: one row of 640 sums
-// per workgroup instead of one per tile.  Two extra barriers per tile (tile staged / tap image built) include the patch wave.
-template <bool PROF = false>
-__global__ __launch_bounds__(320) void conv3x3_resw_w1_kernel(ConvArgs a, int ntiles, int tiles_x, int tiles_y, int chunk) {
-    constexpr int CIN = 64, COUT = 64, TH = 8, TW = 16;
-    constexpr int PW = TW + 2, PH = TH + 2, RPT = 16 / TW;
-    constexpr int MF = TH * TW / 64, NF = COUT / 16, NH = NF / 2;
-    constexpr int KTOT = 9 * CIN;
-    constexpr int PPIECES = (PH * PW + 7) / 8;             // 1 KiB DMA pieces per patch (8 pixels x 128 B)
-    constexpr int PBYTES = PPIECES * 1024, WBYTES = COUT * 128;
-    constexpr int OS = COUT + 8;                           // row stride of the masked bf16 tile [pixel][channel] (frag_rm reads)
-    constexpr int NPIX = TH * TW, XS = NPIX + 8;           // tap-major input image [16 taps][XS]
-    constexpr int OT_BYTES = NPIX * OS * 2, XT_BYTES = 16 * XS * 2, XP_BYTES = 192 * 4;
-    __shared__ __attribute__((aligned(1024))) char lds[2 * PBYTES + 9 * WBYTES + OT_BYTES + XT_BYTES + 2 * XP_BYTES];
-    __shared__ int tileq[4];
-    typedef __attribute__((address_space(1))) const void gptr_t;
-    typedef __attribute__((address_space(3))) void lptr_t;
-    typedef __attribute__((ext_vector_type(2))) short short2_t;
-    typedef __attribute__((ext_vector_type(2))) float f32x2;
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    char* const pbuf = lds;
-    char* const wres = lds + 2 * PBYTES;
-    bf16* const otile = reinterpret_cast<bf16*>(wres + 9 * WBYTES);
-    bf16* const sxt = reinterpret_cast<bf16*>(wres + 9 * WBYTES + OT_BYTES);
-    float* const sxp = reinterpret_cast<float*>(wres + 9 * WBYTES + OT_BYTES + XT_BYTES);   // two buffers of 192 floats
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int H = a.H, W = a.W;
-    const int dbg = PROF ? a.relu >> 8 : 0;                // ablation bits as in the streaming kernel (1, 4)
-    long pt[3] = {0, 0, 0};
-    long tprev = PROF ? clock64() : 0;
-    auto stamp = [&](int k) { if constexpr (PROF) { const long now = clock64(); pt[k] += now - tprev; tprev = now; } };
-    // (an LDS-qualified volatile read: through a generic `volatile int*` hipcc emits flat_load_dword sc0 sc1 + s_waitcnt vmcnt(0), i.e.
-    // the read queues at the texture addresser behind the patch wave's DMA pieces and waits for all of this wave's stores)
-    auto read_tileq = [&](int k) { return __builtin_amdgcn_readfirstlane(*(volatile __attribute__((address_space(3))) int*)&tileq[k & 3]); };
-
-    {   // the filter bank: 72 pieces of 8 rows, dealt round-robin to the 5 waves
-        const int sub = lane >> 3, sl = lane & 7;
-#pragma unroll
-        for (int n = 0; n < (72 + 4) / 5; ++n) {
-            const int pc = n * 5 + wave;
-            if (pc < 72) {
-                const int tap = pc >> 3, i = pc & 7;
-                const int r = i * 8 + sub, j = r >> 4, m = r & 15;
-                const int co = (j >> 1) * 32 + (m >> 2) * 8 + (j & 1) * 4 + (m & 3);
-                const bf16* src = a.wk + (long)co * KTOT + tap * CIN + ((sl ^ (r & 7)) * 8);
-                __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(wres + pc * 1024), 16, 0, 0);
-            }
-        }
-    }
-
-    if (wave == 4) {
-        // ---------------- patch stream (see the streaming kernel); barrier g hands patch g over and frees patch g-1's buffer
-        const int sub = lane >> 3, sl = lane & 7;
-        int rel[PPIECES], pij[PPIECES];
-#pragma unroll
-        for (int i = 0; i < PPIECES; ++i) {
-            int p = i * 8 + sub;
-            if (p >= PH * PW) p = PH * PW - 1;
-            const int pi = p / PW, pj = p % PW;
-            rel[i] = ((pi - 1) * W + (pj - 1)) * CIN + (sl ^ (pj & 7)) * 8;
-            pij[i] = pi << 8 | pj;
-        }
-        const bf16* zsrc = g_zero_line + sl * 8;
-        // the (TH+2) x 18 neighbourhood of the 1-channel network input travels with the patch (4-byte LDS-DMA, zeros outside)
-        const float* zx = reinterpret_cast<const float*>(g_zero_line);
-        auto issue_patch = [&](int tile, int g) {
-            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
-            const int d0 = tx * TW, t0 = ty * TH;
-            {
-                const float* x_b = a.x1 + (long)b * H * W;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const int e = i * 64 + lane, pi = e / PW, pj = e % PW;
-                    const int t = t0 + pi - 1, d = d0 + pj - 1;
-                    const float* src = (e < PH * PW && t >= 0 && t < H && d >= 0 && d < W) ? x_b + (long)t * W + d : zx;
-                    __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(sxp + (g & 1) * 192 + i * 64), 4, 0, 0);
-                }
-            }
-            const bf16* org = a.in + ((long)b * H * W + (long)t0 * W + d0) * CIN;
-            const bool interior = t0 >= 1 && t0 + TH + 1 <= H && d0 >= 1 && d0 + TW + 1 <= W;
-            char* dst = pbuf + (g & 1) * PBYTES;
-            if (interior) {
-#pragma unroll
-                for (int i = 0; i < PPIECES; ++i)
-                    __builtin_amdgcn_global_load_lds((gptr_t*)(org + rel[i]), (lptr_t*)(dst + i * 1024), 16, 0, 0);
-            } else {
-#pragma unroll
-                for (int i = 0; i < PPIECES; ++i) {
-                    const int t = t0 + (pij[i] >> 8) - 1, d = d0 + (pij[i] & 255) - 1;
-                    const bf16* src = (t >= 0 && t < H && d >= 0 && d < W) ? org + rel[i] : zsrc;
-                    __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(dst + i * 1024), 16, 0, 0);
-                }
-            }
-        };
-        bool dry = false;
-        // Tiles are dealt by a STATIC stride here (workgroup w: tiles w, w + G, ...), not by the tile counter: the wave-level
-        // partial sums run over all tiles of a workgroup, so the assignment fixes the summation order -- the gradient must
-        // be bit-reproducible from run to run.
-        unsigned own = blockIdx.x;
-        const unsigned lim = (unsigned)ntiles;
-        auto issue_fetch = [&](unsigned) -> unsigned { const unsigned t = own; own += gridDim.x; return t; };
-        auto went_dry = [&]() { dry = true; };
-        int cur, nxt;
-        {
-            const unsigned t0f = issue_fetch(1u), t1f = issue_fetch(1u);
-            cur = t0f < lim ? (int)t0f : -1;
-            nxt = t1f < lim ? (int)t1f : -1;
-            if (nxt < 0) went_dry();
-        }
-        if (lane == 0) { tileq[0] = cur; tileq[1] = nxt; }
-        if (cur >= 0) issue_patch(cur, 0);
-        stamp(0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        stamp(1);
-        asm volatile("s_barrier" ::: "memory");           // opening barrier: weights (every wave's share), patch 0, tileq[0..1]
-        for (int k = 0; cur >= 0; ++k) {
-            // tile k is being computed: fetch the id of tile k+2, stream tile k+1's patch, publish, hand over
-            const unsigned raw = issue_fetch(1u);
-            stamp(2);
-            if (nxt >= 0 && !(dbg & 1)) issue_patch(nxt, k + 1);
-            stamp(0);
-            int nn = -1;
-            if (!dry) {
-                const unsigned t = __builtin_amdgcn_readfirstlane(raw);
-                if (t >= lim) went_dry(); else nn = (int)t;
-            }
-            if (lane == 0) tileq[(k + 2) & 3] = nn;
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            stamp(1);
-            asm volatile("s_barrier" ::: "memory");       // barrier k (middle of tile k's last tap)
-            asm volatile("s_barrier" ::: "memory");       // E1, E2: the MFMA waves' epilogue barriers (masked tile staged; tap image built)
-            asm volatile("s_barrier" ::: "memory");
-            cur = nxt; nxt = nn;
-        }
-        if constexpr (PROF) { if (lane == 0) { a.prof[blockIdx.x * 6 + 4] = pt[0]; a.prof[blockIdx.x * 6 + 5] = pt[1]; } }
-        return;
-    }
-
-    // ---------------- MFMA waves
-    const int rr = lane & 15, q = lane >> 4;
-    const int pcol0 = rr % TW, prow0 = wave * MF * RPT + rr / TW;
-    int poff[3][2], woff[2];
-#pragma unroll
-    for (int kc = 0; kc < 2; ++kc) {
-        woff[kc] = rr * 128 + (((kc * 4 + q) ^ (rr & 7)) * 16);
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) poff[dx][kc] = (prow0 * PW + pcol0 + dx) * 128 + (((kc * 4 + q) ^ ((pcol0 + dx) & 7)) * 16);
-    }
-    struct Frags { bf16x8 a[MF], b[NF]; };
-    typedef __attribute__((address_space(3))) const char lds_cchar;
-    const unsigned wbase = (unsigned)(size_t)((lds_cchar*)wres);
-    f32x4 acc[MF][NF];
-    // half_tap: MF*NF MFMAs on `use`, the reads of `ld` issued in their shadow (see the streaming kernel)
-    auto half_tap = [&](const Frags& use, Frags& ld, const char* pl, int tap, int kc) {
-        const int dy = tap / 3, dx = tap % 3;
-        const unsigned pa = (unsigned)(size_t)((lds_cchar*)pl) + poff[dx][kc];
-        const unsigned wa = wbase + woff[kc] + tap * WBYTES;   // (the DS offset field is 16 bits: the tap's 8 KiB stride goes here)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < MF * NF; ++m) {
-            const int i = m / NF, j = m % NF;
-            acc[i][j] = mma16(use.b[j], use.a[i], acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (m < MF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ld.a[m < MF ? m : 0]) : "v"(pa), "n"(((m < MF ? m : 0) * RPT + dy) * PW * 128));
-            else if (m < MF + NF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ld.b[m < MF + NF ? m - MF : 0]) : "v"(wa), "n"((m < MF + NF ? m - MF : 0) * 2048));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    Frags f0, f1;
-    f32x4 cw = {0.f, 0.f, 0.f, 0.f};                    // conv1 weight-gradient partial of this wave over all its tiles
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of the weights
-    stamp(2);
-    asm volatile("s_barrier" ::: "memory");               // opening barrier
-    int tile = read_tileq(0);
-    {   // fragments of (tap 0, first k-half)
-        const unsigned pa = (unsigned)(size_t)((lds_cchar*)pbuf) + poff[0][0];
-        const unsigned wa = wbase + woff[0];
-#pragma unroll
-        for (int i = 0; i < MF; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f0.a[i]) : "v"(pa), "n"(i * RPT * PW * 128));
-#pragma unroll
-        for (int j = 0; j < NF; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f0.b[j]) : "v"(wa), "n"(j * 2048));
-    }
-    stamp(0);
-    for (int k = 0; tile >= 0; ++k) {
-        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
-        const int d0 = tx * TW, t0 = ty * TH;
-        const int tl = t0 + prow0, dl = d0 + pcol0;
-        const unsigned voff = (unsigned)((tl * W + dl) * COUT + q * 8) * 2u;
-        const char* mask_b = reinterpret_cast<const char*>(a.mask) + (long)b * H * W * COUT * 2;
-        auto row_ok = [&](int i) { return tl + i * RPT < H && dl < W; };
-        auto row_off = [&](int i) { return voff + (unsigned)(i * RPT) * (unsigned)(W * COUT * 2); };
-#pragma unroll
-        for (int i = 0; i < MF; ++i)
-#pragma unroll
-            for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const char* pcur = pbuf + (k & 1) * PBYTES;
-        const char* pnext = pbuf + ((k + 1) & 1) * PBYTES;
-        u32x4 mk[MF][NH];                                 // ReLU mask of this lane's outputs, requested three taps before use
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            if (tap == 6) {
-#pragma unroll
-                for (int i = 0; i < MF; ++i)
-#pragma unroll
-                    for (int h = 0; h < NH; ++h) {
-                        const u32x4 z = {0u, 0u, 0u, 0u};
-                        mk[i][h] = row_ok(i) ? *reinterpret_cast<const u32x4*>(mask_b + row_off(i) + h * 64) : z;
-                    }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            half_tap(f0, f1, pcur, tap, 1);
-            if (tap < 8) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                half_tap(f1, f0, pcur, tap + 1, 0);
-            } else {
-                // barrier k: the next tile's patch and tileq[k+1..k+2] are in; this wave will not read patch k again
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                half_tap(f1, f0, pnext, 0, 0);            // (after the last tile: stale LDS, never used)
-            }
-        }
-        const int next_tile = read_tileq(k + 1);
-        stamp(1);
-        tile = next_tile;
-
-        // epilogue: the masked bf16 tile (zeros outside the image) goes to LDS and is contracted there with the 3 x 3
-        // neighbourhoods of the network input: [64 channels] x [9 taps + ones] over the tile's pixels, on the MFMA
-        const short2_t zero2 = {0, 0}, one2 = {1, 1};
-#pragma unroll
-        for (int i = 0; i < MF; ++i) {
-            const bool ok = row_ok(i);
-#pragma unroll
-            for (int h = 0; h < NH; ++h) {
-                u32x4 ov;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const f32x4& c = acc[i][2 * h + (kk >> 1)];
-                    unsigned r;
-                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(c[2 * (kk & 1)]), "v"(c[2 * (kk & 1) + 1]));
-                    const unsigned mw = mk[i][h][kk];       // (bit_cast straight from a vector element reads element 0: clang 22)
-                    short2_t m = __builtin_bit_cast(short2_t, mw);
-                    m = __builtin_elementwise_min(__builtin_elementwise_max(m, zero2), one2);   // 1 where mask > 0
-                    const short2_t pk = __builtin_bit_cast(short2_t, r) & (zero2 - m);
-                    ov[kk] = ok ? __builtin_bit_cast(unsigned, pk) : 0u;
-                }
-                *reinterpret_cast<u32x4*>(otile + ((wave * MF + i) * 16 + rr) * OS + h * 32 + q * 8) = ov;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // E1
-        if (threadIdx.x < NPIX) {
-            // thread = pixel: its 9 neighbours + 1 go to column kappa(pixel) of the tap-major image.  kappa undoes the
-            // k-permutation of frag_rm (MFMA k index 8g+j <-> tile row 4g+j for j < 4, 16+4g+(j-4) for j >= 4).
-            const int tid = threadIdx.x, pr = tid >> 4, pc = tid & 15;
-            const int rho = tid & 31, sl = tid >> 5;
-            const int kap = rho < 16 ? 8 * (rho >> 2) + (rho & 3) : 8 * ((rho - 16) >> 2) + 4 + (rho & 3);
-            const bool in_img = t0 + pr < H && d0 + pc < W;
-            const float* xp = sxp + (k & 1) * 192;
-#pragma unroll
-            for (int tap = 0; tap < 16; ++tap) {
-                float v = 0.f;
-                if (tap < 9) v = xp[(pr + tap / 3) * PW + pc + tap % 3];
-                else if (tap == 9) v = 1.f;
-                sxt[tap * XS + sl * 32 + kap] = (bf16)(in_img ? v : 0.f);
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // E2
-        // wave w: output channels 16w .. 16w+15 x 16 taps, contraction over the tile's pixels (slabs of 32)
-#pragma unroll
-        for (int sl = 0; sl < NPIX / 32; ++sl) {
-            const bf16x8 af = frag_rm<OS>(otile + sl * 32 * OS, wave * 16, lane);
-            const bf16x8 bf = ld8(sxt + (lane & 15) * XS + sl * 32 + (lane >> 4) * 8);
-            cw = mma16(af, bf, cw);
-        }
-        stamp(2);
-    }
-    if ((lane & 15) < 10) {                                // one row of 640 partial sums per workgroup (mk_conv1_wgrad_fused_reduce)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a.w1_slab[(long)blockIdx.x * 640 + (wave * 16 + 4 * (lane >> 4) + r) * 10 + (lane & 15)] = cw[r];
-    }
-    if constexpr (PROF) {
-        if (wave == 0 && lane == 0) { a.prof[blockIdx.x * 6 + 0] = pt[0]; a.prof[blockIdx.x * 6 + 1] = pt[1]; a.prof[blockIdx.x * 6 + 2] = pt[2]; }
-    }
-}
-
-// 16 x 16-pixel tiles for the same launch (VERDICT r2 next #1a).  The 8 x 16 kernel above pays 0.75 LDS fragment reads per MFMA (two
-// pixel fragments against four weight fragments per half-tap); 16 x 16 pays 0.5, like the forward kernel -- but two 41 KiB patches and
-// the 72 KiB filter bank leave 6 KiB of the CU's 160 KiB, not the 45 KiB the epilogue's staging took.  So:
+// Same skeleton as the resident-weight kernel (persistent workgroups, filter bank in LDS, patch stream by LDS-DMA) on 16 x 16-pixel
+// tiles (0.5 LDS fragment reads per MFMA, like the forward kernel): the accumulators are masked with the ReLU mask of conv1's output,
+// written to LDS as a bf16 tile and contracted on the MFMA with the 3 x 3 neighbourhoods of the 1-channel network input (streamed in
+// with the patch) -- d(conv1 output) is never stored; each wave keeps its 16 channels x 16 taps partial in registers over ALL tiles of
+// the workgroup (one row of 640 sums per workgroup).  Two 41 KiB patches and the 72 KiB filter bank leave 6 KiB of the CU's 160 KiB, so:
 //   * the masked bf16 tile [256 pixels][64 + 8 channels] (36 KiB) is staged in the patch buffer the tile has just CONSUMED (no wave
 //     reads patch k after barrier k); a third barrier per tile (E3, in place of the old "tap image built" one) keeps the patch
 //     wave from refilling that buffer before the contraction has read it;
@@ -1620,11 +1229,12 @@ __global__ __launch_bounds__(320) void conv3x3_resw_w1_kernel(ConvArgs a, int nt
 //     (one 4-pixel group per lane: three 8-byte reads and three 8-byte writes per tap row), while the MFMA waves run the tap loop:
 //     the MFMA waves' epilogue, every instruction of which is on the critical path, loses the 16 + 16 LDS accesses per lane and one
 //     barrier; the row of ones (bias gradient) is a register constant.
-// ABL (ablation builds for timing only, MASR_W1_ABL): bit 0 = no epilogue arithmetic (staging + contraction skipped, barriers kept),
-// bit 1 = no mask loads, bits 2.. = tap at which the mask is requested (default 6)
-template <int ABL = 0>
-__global__ __launch_bounds__(320) void conv3x3_resw_w1x_kernel(ConvArgs a, int ntiles, int tiles_x, int tiles_y, int chunk) {
-    constexpr int MASK_TAP = (ABL >> 2) ? (ABL >> 2) - 1 : 0;
+// UNPOOL: the input map (the gradient behind the first max-pool) is never materialised -- FOUR producer waves (4 .. 7, one per SIMD;
+// wave 4 keeps the tap image and the neighbourhood DMA) build each patch from the pooled gradient a.in_pooled + the pool codes
+// a.in_idx (unpool_expand), 512 threads.
+template <bool UNPOOL = false>
+__global__ __launch_bounds__(UNPOOL ? 512 : 320) void conv3x3_resw_w1x_kernel(ConvArgs a, int ntiles, int tiles_x, int tiles_y) {
+    constexpr int MASK_TAP = 0;
     constexpr int CIN = 64, COUT = 64, TH = 16, TW = 16;
     constexpr int PW = TW + 2, PH = TH + 2, RPT = 16 / TW;
     constexpr int MF = TH * TW / 64, NF = COUT / 16, NH = NF / 2;
@@ -1655,11 +1265,12 @@ __global__ __launch_bounds__(320) void conv3x3_resw_w1x_kernel(ConvArgs a, int n
     // the read queues at the texture addresser behind the patch wave's DMA pieces and waits for all of this wave's stores)
     auto read_tileq = [&](int k) { return __builtin_amdgcn_readfirstlane(*(volatile __attribute__((address_space(3))) int*)&tileq[k & 3]); };
 
-    {   // the filter bank: 72 pieces of 8 rows, dealt round-robin to the 5 waves
+    {   // the filter bank: 72 pieces of 8 rows, dealt round-robin to the waves
+        constexpr int NWV = UNPOOL ? 8 : 5;
         const int sub = lane >> 3, sl = lane & 7;
 #pragma unroll
-        for (int n = 0; n < (72 + 4) / 5; ++n) {
-            const int pc = n * 5 + wave;
+        for (int n = 0; n < (72 + NWV - 1) / NWV; ++n) {
+            const int pc = n * NWV + wave;
             if (pc < 72) {
                 const int tap = pc >> 3, i = pc & 7;
                 const int r = i * 8 + sub, j = r >> 4, m = r & 15;
@@ -1670,7 +1281,118 @@ __global__ __launch_bounds__(320) void conv3x3_resw_w1x_kernel(ConvArgs a, int n
         }
     }
 
-    if (wave == 4) {
+    if constexpr (UNPOOL) {
+    if (wave >= 4) {
+        // ---------------- patch producers (see the streaming kernel's UNPOOL flavour: item = pooled cell x 16-byte channel chunk); wave 4
+        // also keeps the tap image, the neighbourhood DMA and tileq.  Tiles are dealt by a static stride, so every producer knows them.
+        constexpr int NPROD = 4, NPR = PH / 2 + 1, NPC = PW / 2 + 1, NITEM = NPR * NPC * 8, NIT = (NITEM + 64 * NPROD - 1) / (64 * NPROD);
+        const int pw = wave - 4, H2 = H / 2, W2 = W / 2;
+        int rel[NIT], offA[NIT], offB[NIT], rcf[NIT];      // rcf = R << 16 | Cc << 8 | flags (1 item, 2 upper row, 4 lower row, 8 left, 16 right column in the patch)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = (it * NPROD + pw) * 64 + lane, ee = e < NITEM ? e : 0;
+            const int c = ee & 7, pp = ee >> 3, R = pp / NPC, Cc = pp % NPC, pi0 = 2 * R - 1, pj0 = 2 * Cc - 1;
+            rel[it] = ((R - 1) * W2 + (Cc - 1)) * CIN + c * 8;
+            offA[it] = (pi0 * PW + pj0) * 128 + ((c ^ (pj0 & 7)) << 4);
+            offB[it] = (pi0 * PW + pj0 + 1) * 128 + ((c ^ ((pj0 + 1) & 7)) << 4);
+            rcf[it] = R << 16 | Cc << 8 | (e < NITEM ? 1 : 0) | (pi0 >= 0 ? 2 : 0) | (pi0 + 1 < PH ? 4 : 0) | (pj0 >= 0 ? 8 : 0) | (pj0 + 1 < PW ? 16 : 0);
+        }
+        u32x4 gr[NIT]; uint2 cd[NIT]; unsigned okm = 0;
+        auto issue_loads = [&](int tile) {
+            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+            const int t2o = ty * (TH / 2), d2o = tx * (TW / 2);
+            const long base = (((long)b * H2 + t2o) * W2 + d2o) * CIN;
+            okm = 0;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int t2 = t2o + (rcf[it] >> 16) - 1, d2 = d2o + ((rcf[it] >> 8) & 255) - 1;
+                const bool ok = (rcf[it] & 1) && (unsigned)t2 < (unsigned)H2 && (unsigned)d2 < (unsigned)W2;   // (floor mode: a cropped last row / column gets no gradient)
+                const long o = ok ? base + rel[it] : (long)(lane & 7) * 8;
+                gr[it] = *reinterpret_cast<const u32x4*>(a.in_pooled + o);
+                cd[it] = *reinterpret_cast<const uint2*>(a.in_idx + o);
+                okm |= (ok ? 1u : 0u) << it;
+            }
+        };
+        auto expand_store = [&](int it, char* dst) {
+            const int f = rcf[it];
+            if (!(f & 1)) return;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            u32x4 o[4];
+            unpool_expand((okm >> it) & 1 ? gr[it] : z, cd[it], o);
+            if (f & 2) {
+                if (f & 8) *reinterpret_cast<u32x4*>(dst + offA[it]) = o[0];
+                if (f & 16) *reinterpret_cast<u32x4*>(dst + offB[it]) = o[1];
+            }
+            if (f & 4) {
+                if (f & 8) *reinterpret_cast<u32x4*>(dst + offA[it] + PW * 128) = o[2];
+                if (f & 16) *reinterpret_cast<u32x4*>(dst + offB[it] + PW * 128) = o[3];
+            }
+        };
+        const float* zx = reinterpret_cast<const float*>(g_zero_line);
+        auto issue_x1 = [&](int tile) {                    // the (TH+2) x 18 neighbourhood of the 1-channel network input, ONE buffer (see below)
+            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+            const int d0 = tx * TW, t0 = ty * TH;
+            const float* x_b = a.x1 + (long)b * H * W;
+#pragma unroll
+            for (int i = 0; i < (PH * PW + 63) / 64; ++i) {
+                const int e = i * 64 + lane, pi = e / PW, pj = e % PW;
+                const int t = t0 + pi - 1, d = d0 + pj - 1;
+                const float* src = (t >= 0 && t < H && d >= 0 && d < W) ? x_b + (long)t * W + d : zx;
+                if (e < PH * PW) __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(sxp + i * 64), 4, 0, 0);
+            }
+        };
+        const int gpr = lane >> 2, gc = lane & 3;
+        const int xt_off = (gpr >> 1) * 32 + 8 * gc + 4 * (gpr & 1);
+        auto build_tap_image = [&]() {                     // (as the DMA flavour's, below)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const f32x2* row = reinterpret_cast<const f32x2*>(sxp + (gpr + dy) * PW + 4 * gc);
+                const f32x2 v0 = row[0], v1 = row[1], v2 = row[2];
+                const float w[6] = {v0[0], v0[1], v1[0], v1[1], v2[0], v2[1]};
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    bf16x4 o;
+                    o[0] = (bf16)w[dx]; o[1] = (bf16)w[dx + 1]; o[2] = (bf16)w[dx + 2]; o[3] = (bf16)w[dx + 3];
+                    *reinterpret_cast<bf16x4*>(sxt + (dy * 3 + dx) * XS + xt_off) = o;
+                }
+            }
+        };
+        const int G = (int)gridDim.x;
+        int cur = (int)blockIdx.x;                          // (the grid never exceeds the tile count)
+        issue_loads(cur);
+        if (pw == 0) {
+            issue_x1(cur);
+            if (lane == 0) { tileq[0] = cur; tileq[1] = cur + G < ntiles ? cur + G : -1; }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) expand_store(it, pbuf);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");           // opening barrier: weights (every wave's share), patch 0, tileq[0..1]
+        for (int k = 0; cur >= 0; ++k) {
+            const int nxt = cur + G < ntiles ? cur + G : -1;
+            if (nxt >= 0) issue_loads(nxt);
+            if (pw == 0) {
+                // tile k is being computed: its tap image first (frees sxp), then tile k+1's neighbourhood
+                build_tap_image();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (nxt >= 0) issue_x1(nxt);
+                if (lane == 0) tileq[(k + 2) & 3] = (nxt >= 0 && nxt + G < ntiles) ? nxt + G : -1;
+            }
+            if (nxt >= 0) {
+                char* const dst = pbuf + ((k + 1) & 1) * PBYTES;       // (patch k-1's buffer: free since E3 of tile k-1)
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) expand_store(it, dst);
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");       // barrier k (middle of tile k's last tap)
+            asm volatile("s_barrier" ::: "memory");       // E1: the masked tile is staged (in patch k's buffer)
+            asm volatile("s_barrier" ::: "memory");       // E3: contraction done -- patch k's buffer and the tap image are free again
+            cur = nxt;
+        }
+        return;
+    }
+    }
+    if (!UNPOOL && wave == 4) {
         // ---------------- patch stream + tap image; barrier k hands patch k+1 and tap image k over, E3 frees patch k's buffer
         const int sub = lane >> 3, sl = lane & 7;
         int rel[PPIECES], pij[PPIECES];
@@ -1840,7 +1562,7 @@ __global__ __launch_bounds__(320) void conv3x3_resw_w1x_kernel(ConvArgs a, int n
         for (int tap = 0; tap < 9; ++tap) {
             if (tap == MASK_TAP) {
 #pragma unroll
-                for (int i = 0; i < MF; ++i) mb[i] = (row_ok(i) && !(ABL & 2)) ? bits_b[(long)i * RPT * W] : uint2{0u, 0u};
+                for (int i = 0; i < MF; ++i) mb[i] = row_ok(i) ? bits_b[(long)i * RPT * W] : uint2{0u, 0u};
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             half_tap(f0, f1, pcur, tap, 1);
@@ -1858,7 +1580,7 @@ __global__ __launch_bounds__(320) void conv3x3_resw_w1x_kernel(ConvArgs a, int n
         // epilogue: the masked bf16 tile (zeros outside the image) goes into the consumed patch buffer and is contracted there with
         // the tap image: [64 channels] x [9 taps + ones] over the tile's 256 pixels, on the MFMA
         bf16* const otile = reinterpret_cast<bf16*>(pcur);
-        if constexpr (!(ABL & 1)) {
+        {
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
 #pragma unroll
@@ -1880,14 +1602,14 @@ __global__ __launch_bounds__(320) void conv3x3_resw_w1x_kernel(ConvArgs a, int n
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // E1
         // wave w: output channels 16w .. 16w+15 x 16 taps, contraction over the tile's pixels (slabs of 32)
-        if constexpr (!(ABL & 1)) {
+        {
 #pragma unroll
         for (int sl = 0; sl < NPIX / 32; ++sl) {
             const bf16x8 af = frag_rm<OS>(otile + sl * 32 * OS, wave * 16, lane);
             const bf16x8 xb = ld8(xt_row + sl * 32);
             cw = mma16(af, wtap < 9 ? xb : cfrag, cw);
         }
-        } else { cw[0] += acc[0][0][0] + acc[1][1][1] + acc[2][2][2] + acc[3][3][3] + __builtin_bit_cast(float, mb[0].x ^ mb[1].y ^ mb[2].x ^ mb[3].y); }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // E3
     }
     if ((lane & 15) < 10) {                                // one row of 640 partial sums per workgroup (mk_conv1_wgrad_fused_reduce)
@@ -1897,142 +1619,6 @@ __global__ __launch_bounds__(320) void conv3x3_resw_w1x_kernel(ConvArgs a, int n
 }
 
 // ------------------------------------------------------------------ wgrad (reduction over pixels)
-
-template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(ConvWgradArgs a, long pix_per_split) {
-    constexpr int WBK = 64;                               // pixels per k-tile
-    constexpr int BM = COUT, BN = 64;
-    constexpr int LDA = BM + 16, LDB = BN + 16;
-    constexpr int WM = BM / 2, WN = BN / 2;
-    constexpr int FM = WM / 16, FN = WN / 16;
-    constexpr int ACH = WBK * (BM / 8) / 256;             // A chunks per thread (2 or 4)
-    constexpr int BCH = WBK * (BN / 8) / 256;             // B chunks per thread (2)
-    constexpr int KTOT = 9 * CIN;
-    __shared__ __attribute__((aligned(16))) bf16 sA[2][WBK * LDA];
-    __shared__ __attribute__((aligned(16))) bf16 sB[2][WBK * LDB];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tap = blockIdx.x / (CIN / 64), ci0 = (blockIdx.x % (CIN / 64)) * 64;
-    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-    const long P = (long)a.B * a.H * a.W;
-    const long ps = (long)blockIdx.y * pix_per_split;
-    const long pe = ps + pix_per_split < P ? ps + pix_per_split : P;
-    const int H = a.H, W = a.W;
-
-    // register ring (depth 2) with UNCONDITIONAL loads: out-of-range pixels / taps read a clamped valid address and
-    // are zeroed when written to LDS (a branch around a global load costs an s_waitcnt vmcnt(0) per k-tile)
-    struct Stage { bf16x8 ra[ACH], rb[BCH]; unsigned oka, okb; };
-    Stage st[2];
-    auto load = [&](Stage& g, long p0) {
-        g.oka = 0; g.okb = 0;
-#pragma unroll
-        for (int i = 0; i < ACH; ++i) {
-            const int c = tid + i * 256;
-            const long p = p0 + c / (BM / 8);
-            if (p < pe) g.oka |= 1u << i;
-            g.ra[i] = ld8(a.dy + (p < P ? p : P - 1) * COUT + (c % (BM / 8)) * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < BCH; ++i) {
-            const int c = tid + i * 256;
-            const long p = p0 + (c >> 3);
-            const long pc = p < P ? p : P - 1;
-            const int d = (int)(pc % W), t = (int)((pc / W) % H);
-            const int tt = t + dy, dd = d + dx;
-            const bool ok = p < pe && tt >= 0 && tt < H && dd >= 0 && dd < W;
-            if (ok) g.okb |= 1u << i;
-            g.rb[i] = ld8(a.in + (ok ? pc + (long)dy * W + dx : pc) * CIN + ci0 + (c & 7) * 8);
-        }
-    };
-    auto store = [&](const Stage& g, int buf) {
-#pragma unroll
-        for (int i = 0; i < ACH; ++i) {
-            const int c = tid + i * 256;
-            st8(&sA[buf][(c / (BM / 8)) * LDA + (c % (BM / 8)) * 8], (g.oka >> i) & 1 ? g.ra[i] : zero8());
-        }
-#pragma unroll
-        for (int i = 0; i < BCH; ++i) {
-            const int c = tid + i * 256;
-            st8(&sB[buf][(c >> 3) * LDB + (c & 7) * 8], (g.okb >> i) & 1 ? g.rb[i] : zero8());
-        }
-    };
-    // fused bias gradient: db[co] = sum_p dy[p][co], accumulated by the column-tile-0 workgroup of each split
-    const bool do_db = a.db != nullptr && blockIdx.x == 0;
-    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto accumulate = [&](const Stage& g) {
-#pragma unroll
-        for (int i = 0; i < ACH; ++i)
-            if ((g.oka >> i) & 1) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) csum[j] += (float)g.ra[i][j];
-            }
-    };
-
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = pe > ps ? (int)((pe - ps + WBK - 1) / WBK) : 0;
-    load(st[0], ps);
-    load(st[1], ps + WBK);
-    if (do_db) accumulate(st[0]);
-    store(st[0], 0);
-    __syncthreads();
-    for (int kt0 = 0; kt0 < nk; kt0 += 2) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int kt = kt0 + u;
-            if (kt >= nk) break;
-            const int cur = kt & 1;
-            load(st[u], ps + (long)(kt + 2) * WBK);          // slot u is free: tile kt already sits in LDS
-#pragma unroll
-            for (int kc = 0; kc < WBK / 32; ++kc) {
-                bf16x8 af[FM], bfr[FN];
-#pragma unroll
-                for (int i = 0; i < FM; ++i) af[i] = frag_rm<LDA>(sA[cur] + kc * 32 * LDA, wm * WM + i * 16, lane);
-#pragma unroll
-                for (int j = 0; j < FN; ++j) bfr[j] = frag_rm<LDB>(sB[cur] + kc * 32 * LDB, wn * WN + j * 16, lane);
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
-            }
-            if (kt + 1 < nk) {
-                if (do_db) accumulate(st[u ^ 1]);
-                store(st[u ^ 1], cur ^ 1);
-            }
-            __syncthreads();
-        }
-    }
-    if (do_db) {
-        constexpr int RC = BM / 8;
-        float* red = reinterpret_cast<float*>(sA[0]);                 // [256][8] floats (tile buffers are free now)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) red[tid * 8 + j] = csum[j];
-        __syncthreads();
-        if (tid < BM) {
-            const int rc = tid / 8, j = tid % 8;
-            float sum = 0.f;
-            for (int t = rc; t < 256; t += RC) sum += red[t * 8 + j];
-            a.slab[(long)gridDim.y * COUT * KTOT + (long)blockIdx.y * COUT + tid] = sum;
-        }
-    }
-    float* out = a.slab + (long)blockIdx.y * COUT * KTOT;
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = wm * WM + i * 16 + (lane >> 4) * 4 + r;
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int ci = ci0 + wn * WN + j * 16 + (lane & 15);
-                out[(long)co * KTOT + tap * CIN + ci] = acc[i][j][r];
-            }
-        }
-}
 
 // ------------------------------------------------------------------ wgrad v2: patch-tiled, persistent, all 9 taps per workgroup
 // dW[co][tap][ci] = sum_pixels dy[pix][co] * x[pix + off(tap)][ci].  A workgroup owns one (64-ci slab, 64-co half) and walks
@@ -2046,27 +1632,27 @@ constexpr int W2_TOTAL_WG = 256;    // one persistent workgroup per CU (see mk_c
 // W2_TW: tile width in pixels (16, or 8 for maps whose width pads badly to 16 -- see conv3x3_patch_kernel); tile = 128 pixels
 // POOLED: the dy tile comes from ConvWgradArgs::dy_pooled + pool_idx: a thread fetches ONE pooled cell x 8 channels (16 B + 8 B of codes) and
 // stages the four positions of its window (4 + 0 instead of 4 x 16-byte loads per thread and tile)
-template <int CIN, int COUT, int OCC, int W2_TW, bool POOLED = false>
-__global__ __launch_bounds__(OCC == 1 ? 512 : 256, OCC) void conv3x3_wgrad2_kernel(ConvWgradArgs a, int nwg, int ntiles, int tiles_x, int tiles_y) {
+template <int CIN, int COUT, int W2_TW, bool POOLED = false>
+__global__ __launch_bounds__(512) void conv3x3_wgrad2_kernel(ConvWgradArgs a, int nwg, int ntiles, int tiles_x, int tiles_y) {
     constexpr int W2_TH = 128 / W2_TW, W2_PH = W2_TH + 2, W2_PW = W2_TW + 2, RPS = 32 / W2_TW;      // RPS = pixel rows per 32-pixel slab
     constexpr int KTOT = 9 * CIN;
     constexpr int NPCH = (W2_PH * W2_PW * 8 + 255) / 256;   // patch chunks per thread (6)
     constexpr int NDCH = W2_TH * W2_TW * 8 / 256;           // dy chunks per thread (4)
-    // one workgroup per CU (OCC 1): TWO tile buffers -- the next tile is written to LDS at the start of a tile's MFMA phase instead of behind
+    // one workgroup per CU: TWO tile buffers -- the next tile is written to LDS at the start of a tile's MFMA phase instead of behind
     // it (staging between two barriers with the MFMA pipes idle cost a third of the launch: 135 us against 90 for 128 -> 128 channels)
-    constexpr int NB = OCC == 1 ? 2 : 1, PATCH_EL = W2_PH * W2_PW * W2_PS, DYT_EL = W2_TH * W2_TW * W2_LDY;
+    constexpr int NB = 2, PATCH_EL = W2_PH * W2_PW * W2_PS, DYT_EL = W2_TH * W2_TW * W2_LDY;
     __shared__ __attribute__((aligned(16))) bf16 patch_[NB * PATCH_EL];
     __shared__ __attribute__((aligned(16))) bf16 dyt_[NB * DYT_EL];
 
-    // OCC 1: 512 threads in two roles -- waves 0-3 multiply (wave w: input channels 16 w ..), waves 4-7 fetch and stage the next tile; each SIMD
+    // 512 threads in two roles -- waves 0-3 multiply (wave w: input channels 16 w ..), waves 4-7 fetch and stage the next tile; each SIMD
     // holds one wave of each role, so a tile's ~220 vector instructions of staging (pooled-dy expansion, zero fill, LDS stores, address
     // arithmetic) and its load waits run BESIDE the MFMAs instead of in front of them in the same wave.  tid = index inside the role.
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-    const bool producer = OCC == 1 && threadIdx.x >= 256;
+    const bool producer = threadIdx.x >= 256;
     const int cs = blockIdx.y % (CIN / 64), ch = blockIdx.y / (CIN / 64);
     const int H = a.H, W = a.W;
 
-    // one tile's fetch, in registers between request and staging (OCC 1 keeps TWO of them in flight)
+    // one tile's fetch, in registers between request and staging (TWO of them are kept in flight)
     struct Stage { bf16x8 pr[NPCH], dr[NDCH]; uint2 pcode; unsigned okp, okd; };
     // Per-thread constants of the tile fetch: chunk i of the patch is pixel (ppi, ppj) relative to the tile origin (t0, d0) and sits prel
     // elements behind that pixel's address; per tile only the origin (wave-uniform: scalar ALU) and two range tests per chunk remain.  (With
@@ -2218,7 +1804,7 @@ __global__ __launch_bounds__(OCC == 1 ? 512 : 256, OCC) void conv3x3_wgrad2_kern
         a.slab[(long)nwg * COUT * KTOT + (long)blockIdx.x * COUT + ch * 64 + tid] = sum;
     };
 
-    if constexpr (OCC == 1) {
+    {
         // The two roles are two separate loops with the SAME sequence of barriers (one in front of the first tile, one behind every tile,
         // one behind the bias partials): the accumulators live only in the consumers' branch and the staging registers only in the
         // producers', so one register budget (256 per thread at two waves per SIMD) holds either.
@@ -2288,40 +1874,6 @@ __global__ __launch_bounds__(OCC == 1 ? 512 : 256, OCC) void conv3x3_wgrad2_kern
             __syncthreads();
             if (do_db && tid < 64) fold_db();
         }
-    } else {
-        // two workgroups per CU (MASR_WGRAD_OCC=2): one tile buffer, no register prefetch (it would spill at 256 VGPRs); the co-resident
-        // workgroup's MFMA phase covers this one's load + staging
-        f32x4 acc[9][4];
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        Stage S;
-        S.pcode = uint2{0u, 0u};
-        __syncthreads();
-        for (int tile = blockIdx.x; tile < ntiles; tile += nwg) {
-            load_tile(S, tile); store_tile(S, patch_, dyt_, dbm1);
-            __syncthreads();
-#pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {                         // slab of 32 pixels = RPS pixel rows
-                bf16x8 af[4];
-                read_a(dyt_, kc, af);
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const bf16x8 bfr = read_b(patch_, kc, tap);
-#pragma unroll
-                    for (int fm = 0; fm < 4; ++fm) acc[tap][fm] = mma16(af[fm], bfr, acc[tap][fm]);
-                }
-            }
-            __syncthreads();
-        }
-        write_slab(acc);
-        if (do_db) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) red[tid * 8 + j] = csum[j];
-            __syncthreads();
-            if (tid < 64) fold_db();
-        }
     }
 }
 
@@ -2354,15 +1906,6 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce(const float* __restr
             dw[((long)co * CIN + ci) * 9 + tap] = t;
         }
     }
-}
-
-int wgrad_splits(long P, int CIN) {
-    const int col_tiles = 9 * (CIN / 64);
-    int splits = (1536 + col_tiles - 1) / col_tiles;                 // ~1.5k workgroups
-    const long max_splits = (P + 255) / 256;                         // at least 256 pixels per split
-    if (splits > max_splits) splits = (int)max_splits;
-    if (splits < 1) splits = 1;
-    return splits;
 }
 
 // ------------------------------------------------------------------ max-pool 2x2 (floor) NHWC
@@ -2509,13 +2052,6 @@ int mk_conv1_fwd(const float* x, const float* w, const float* bias, bf16* out, i
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 long mk_conv1_wgrad_slab_floats(int B, int H, int W) { return (((long)B * H * W + C1_PIX - 1) / C1_PIX + C1_RSPLIT) * 640; }
-int mk_conv1_wgrad(const float* x, const bf16* dy, float* dw, float* db, float* slab, int B, int H, int W, hipStream_t s) {
-    const long P = (long)B * H * W;
-    const int nb = (int)((P + C1_PIX - 1) / C1_PIX);
-    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(nb), dim3(256), 0, s, x, dy, slab, B, H, W, 64);
-    launch_conv1_reduce(slab, nb, dw, db, s);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-}
 
 // CIN = 1 conv with COUT = 64 * n channels (the BLSTM front-end has 128): n launches of the 64-channel kernels
 int mk_conv1_fwd_n(const float* x, const float* w, const float* bias, bf16* out, int B, int H, int W, int COUT, hipStream_t s) {
@@ -2542,108 +2078,59 @@ static int conv_ncu() {
     if (!ncu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); if (ncu <= 0) ncu = 256; }
     return ncu;
 }
-// the fused conv1-wgrad dgrad: resident-weight kernel unless switched off (then the patch kernel, one slab row per tile)
-static bool use_resw_w1() {
-    static const bool on = !(getenv("MASR_CONV_STREAM") && atoi(getenv("MASR_CONV_STREAM")) == 0) &&
-                           !(getenv("MASR_CONV_RESW") && atoi(getenv("MASR_CONV_RESW")) == 0) &&
-                           !(getenv("MASR_CONV_RESW_W1") && atoi(getenv("MASR_CONV_RESW_W1")) == 0);
-    return on;
-}
-static bool w1_th8() { static const bool v = getenv("MASR_CONV_W1_TH8") != nullptr; return v; }     // the 8 x 16-tile kernel (reads the bf16 map as its mask), for A/B runs
+// workgroups (= rows of 640 partial sums) of the fused conv1-wgrad dgrad: one persistent workgroup per CU
 static int resw_w1_rows(int B, int H, int W) {
-    const int th = w1_th8() ? 8 : 16;
-    const long ntiles = (long)B * ((H + th - 1) / th) * ((W + 15) / 16);
+    const long ntiles = (long)B * ((H + 15) / 16) * ((W + 15) / 16);
     return (int)(ntiles < conv_ncu() ? ntiles : conv_ncu());
 }
-long mk_conv1_wgrad_fused_slab_floats(int B, int H, int W) {
-    const long per_tile = (long)B * ((H + 15) / 16) * ((W + 15) / 16), per_wg = resw_w1_rows(B, H, W);
-    return ((per_tile > per_wg ? per_tile : per_wg) + C1_RSPLIT) * 640;
-}
+long mk_conv1_wgrad_fused_slab_floats(int B, int H, int W) { return ((long)resw_w1_rows(B, H, W) + C1_RSPLIT) * 640; }
 int mk_conv1_wgrad_fused_reduce(float* slab, int B, int H, int W, float* dw, float* db, hipStream_t s) {
-    const int nb = use_resw_w1() ? resw_w1_rows(B, H, W) : B * ((H + 15) / 16) * ((W + 15) / 16);
-    launch_conv1_reduce(slab, nb, dw, db, s);
+    launch_conv1_reduce(slab, resw_w1_rows(B, H, W), dw, db, s);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// persistent grid of the streaming kernel: as many workgroups as fit on the chip at once (1 or 2 per CU)
-// tiles per workgroup of the streaming kernels: 0 = persistent workgroups fed by the tile counter
-static int stream_chunk() {
-    static const int c = getenv("MASR_CONV_CHUNK") ? atoi(getenv("MASR_CONV_CHUNK")) : 0;
-    return c;
+// tile counters of launches that bring none (single-stream tools and tests)
+static unsigned* sched_or_fallback(unsigned* sched) {
+    if (sched) return sched;
+    static unsigned* fallback = nullptr;
+    if (!fallback) hipGetSymbolAddress((void**)&fallback, HIP_SYMBOL(g_conv_sched));
+    return fallback;
 }
 static int launch_resw_w1(const ConvArgs& a, hipStream_t s) {
-    const int th = w1_th8() ? 8 : 16;
-    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + th - 1) / th, ntiles = tiles_x * tiles_y * a.B;
-    ConvArgs b = a;
-    if (!b.sched) {
-        static unsigned* fallback = nullptr;
-        if (!fallback) hipGetSymbolAddress((void**)&fallback, HIP_SYMBOL(g_conv_sched));
-        b.sched = fallback;
-    }
-    if (!w1_th8() && !a.mask_bits) { mk_set_error("mk_conv3x3", "fused conv1 wgrad (16 x 16 tiles) needs ConvArgs::mask_bits"); return -1; }
-    if (w1_th8()) hipLaunchKernelGGL((conv3x3_resw_w1_kernel<false>), dim3((unsigned)resw_w1_rows(a.B, a.H, a.W)), dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, 0);
-    else {
-        static const int abl = getenv("MASR_W1_ABL") ? atoi(getenv("MASR_W1_ABL")) : 0;
-        const dim3 g((unsigned)resw_w1_rows(a.B, a.H, a.W));
-        switch (abl) {
-            case 1: hipLaunchKernelGGL((conv3x3_resw_w1x_kernel<1>), g, dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, 0); break;
-            case 2: hipLaunchKernelGGL((conv3x3_resw_w1x_kernel<2>), g, dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, 0); break;
-            case 3: hipLaunchKernelGGL((conv3x3_resw_w1x_kernel<3>), g, dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, 0); break;
-            case 4: hipLaunchKernelGGL((conv3x3_resw_w1x_kernel<4>), g, dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, 0); break;      // mask at tap 0
-            case 12: hipLaunchKernelGGL((conv3x3_resw_w1x_kernel<12>), g, dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, 0); break;    // mask at tap 2
-            default: hipLaunchKernelGGL((conv3x3_resw_w1x_kernel<0>), g, dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, 0);
-        }
-    }
+    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 15) / 16, ntiles = tiles_x * tiles_y * a.B;
+    if (!a.mask_bits) { mk_set_error("mk_conv3x3", "fused conv1 wgrad needs ConvArgs::mask_bits"); return -1; }
+    const dim3 g((unsigned)resw_w1_rows(a.B, a.H, a.W));
+    if (a.in_pooled) hipLaunchKernelGGL((conv3x3_resw_w1x_kernel<true>), g, dim3(512), 0, s, a, ntiles, tiles_x, tiles_y);
+    else hipLaunchKernelGGL((conv3x3_resw_w1x_kernel<false>), g, dim3(320), 0, s, a, ntiles, tiles_x, tiles_y);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-template <bool PROF = false>
+// persistent grids: one workgroup per CU for the resident-weight kernel, as many as fit (1 or 2 per CU) for the streaming kernels
 static void launch_resw(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
-    static int resident = 0;
-    if (!resident) {
-        int dev = 0;
-        hipGetDevice(&dev);
-        hipDeviceGetAttribute(&resident, hipDeviceAttributeMultiprocessorCount, dev);
-        if (resident <= 0) resident = 256;
-    }
-    const int ntiles = tiles_x * tiles_y * a.B;
+    const int ntiles = tiles_x * tiles_y * a.B, resident = conv_ncu();
     ConvArgs b = a;
-    if (!b.sched) {
-        static unsigned* fallback = nullptr;
-        if (!fallback) hipGetSymbolAddress((void**)&fallback, HIP_SYMBOL(g_conv_sched));
-        b.sched = fallback;
-    }
-    const int chunk = stream_chunk();
-    const int grid = chunk > 0 ? (ntiles + chunk - 1) / chunk : (ntiles < resident ? ntiles : resident);
-    hipLaunchKernelGGL((conv3x3_resw_kernel<16, 16, PROF>), dim3((unsigned)grid), dim3(320), 0, s, b, ntiles, tiles_x, tiles_y, chunk);
+    b.sched = sched_or_fallback(a.sched);
+    hipLaunchKernelGGL((conv3x3_resw_kernel<16, 16>), dim3((unsigned)(ntiles < resident ? ntiles : resident)), dim3(320), 0, s, b, ntiles, tiles_x, tiles_y);
 }
-template <int CI, int CO, int TWV, int MASK, bool PROF = false, int THV = 16>
+template <int CI, int CO, int TWV, int MASK, int THV = 16, bool UNPOOL = false>
 static void launch_stream_t(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
+    constexpr int NT = UNPOOL ? 512 : 384;
     static int resident = 0;
     if (!resident) {
-        int dev = 0, ncu = 0, per_cu = 0;
-        hipGetDevice(&dev);
-        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3x3_stream_kernel<CI, CO, THV, TWV, MASK, PROF>, 384, 0);
-        if (ncu <= 0) ncu = 256;
+        int per_cu = 0;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3x3_stream_kernel<CI, CO, THV, TWV, MASK, UNPOOL>, NT, 0);
         if (per_cu <= 0) per_cu = 1;
-        static const int cap = getenv("MASR_CONV_STREAM_WGPC") ? atoi(getenv("MASR_CONV_STREAM_WGPC")) : 2;
-        resident = ncu * (per_cu < cap ? per_cu : cap);
+        resident = conv_ncu() * (per_cu < 2 ? per_cu : 2);
     }
     const int ntiles = tiles_x * tiles_y * a.B;
     ConvArgs b = a;
-    if (!b.sched) {
-        static unsigned* fallback = nullptr;
-        if (!fallback) hipGetSymbolAddress((void**)&fallback, HIP_SYMBOL(g_conv_sched));
-        b.sched = fallback;
-    }
-    const int chunk = stream_chunk();
-    const int grid = chunk > 0 ? (ntiles + chunk - 1) / chunk : (ntiles < resident ? ntiles : resident);
-    hipLaunchKernelGGL((conv3x3_stream_kernel<CI, CO, THV, TWV, MASK, PROF>), dim3((unsigned)grid), dim3(384), 0, s, b, ntiles, tiles_x, tiles_y, chunk);
+    b.sched = sched_or_fallback(a.sched);
+    hipLaunchKernelGGL((conv3x3_stream_kernel<CI, CO, THV, TWV, MASK, UNPOOL>), dim3((unsigned)(ntiles < resident ? ntiles : resident)), dim3(NT), 0, s, b, ntiles,
+                       tiles_x, tiles_y);
 }
-template <int CI, int CO, int TWV, bool PROF = false, int THV = 16>
+template <int CI, int CO, int TWV, int THV = 16>
 static void launch_stream(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
-    if (a.mask) launch_stream_t<CI, CO, TWV, 1, PROF, THV>(a, tiles_x, tiles_y, s);
-    else launch_stream_t<CI, CO, TWV, 0, PROF, THV>(a, tiles_x, tiles_y, s);
+    if (a.mask) launch_stream_t<CI, CO, TWV, 1, THV>(a, tiles_x, tiles_y, s);
+    else launch_stream_t<CI, CO, TWV, 0, THV>(a, tiles_x, tiles_y, s);
 }
 // ConvArgs::out_sign_bits for launches whose epilogue does not write them: from the stored 128-channel map, thread = (pixel, dword q)
 __global__ void sign_bits128_kernel(const bf16* __restrict__ map, unsigned* __restrict__ bits, long npix) {
@@ -2657,39 +2144,24 @@ __global__ void sign_bits128_kernel(const bf16* __restrict__ map, unsigned* __re
     }
     bits[i] = w;
 }
-// 8-wide tiles for every map width (CIN, COUT <= 128; 64 -> 64 keeps its resident-weight kernel on 16-wide tiles): the streaming
-// kernels of the 128-channel shapes exist on 8-wide tiles only, and they beat the 16-wide patch kernel also where both pad the
-// width alike -- W = 41, the pooled map of the SHIPPED idim 83: conv4 forward 143 -> 100 us, its masked dgrad 134 -> 90 us.
-// MASR_CONV_TW8_STRICT=1: only where 8-wide tiles pad less (W = 40: 40 vs 48 columns), the rule until round 3.
-static bool narrow_w(int W) {
-    static const bool strict = getenv("MASR_CONV_TW8_STRICT") != nullptr;
-    return strict ? (W + 7) / 8 * 8 < (W + 15) / 16 * 16 : true;
-}
-// will a masked 128 <- 128 dgrad on a map of this width read its mask as sign bits (ConvArgs::mask_bits / out_sign_bits)?  Only the
-// streaming kernel on 8-wide, 32-row tiles does; elsewhere the words would be written for nothing.
-bool mk_conv3x3_mask_bits_used(int W) {
-    static const bool allow_narrow = !getenv("MASR_CONV_NO_TW8");
-    static const bool stream = !(getenv("MASR_CONV_STREAM") && atoi(getenv("MASR_CONV_STREAM")) == 0);
-    static const bool th32 = !(getenv("MASR_CONV_TH32") && atoi(getenv("MASR_CONV_TH32")) == 0);
-    static const bool v1 = getenv("MASR_CONV_V1") != nullptr;
-    return allow_narrow && stream && th32 && !v1 && narrow_w(W);
-}
 static int conv3x3_dispatch(const ConvArgs& a, hipStream_t s);
 int mk_conv3x3(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     uint8_t* idx_after = nullptr;
     unsigned long long* sign_after = nullptr;
-    {   // pool_idx / out_optional are honoured by the epilogues of the streaming kernels only: everywhere else the launch
-        // stores the map and the codes are computed from it afterwards
-        static const bool allow_narrow = !getenv("MASR_CONV_NO_TW8");
-        static const bool stream = !(getenv("MASR_CONV_STREAM") && atoi(getenv("MASR_CONV_STREAM")) == 0);
-        const bool narrow = allow_narrow && narrow_w(a.W) && a.CIN <= 128 && a.COUT <= 128;
-        const bool in_epilogue = !getenv("MASR_CONV_V1") && !a.prof && stream && !a.x1 && !a.mask && a.CIN <= 128 && a.COUT <= 128 &&
-                                 (narrow || (a.CIN == 64 && a.COUT == 64));
+    const bool small = a.CIN <= 128 && a.COUT <= 128;        // the streaming / resident-weight kernels (8-wide tiles at every map width; 64 -> 64 forward: 16-wide)
+    if ((a.in != nullptr) == (a.in_pooled != nullptr)) { mk_set_error("mk_conv3x3", "exactly one of in / in_pooled"); return -1; }
+    if (a.in_pooled && (!a.in_idx || !(a.x1 || (a.CIN == 128 && a.COUT == 128 && a.mask_bits)))) {
+        mk_set_error("mk_conv3x3", "in_pooled: needs in_idx; only the two dgrads behind a max-pool read it (64 <- 64 with the fused conv1 weight gradient, 128 <- 128 with mask_bits)");
+        return -1;
+    }
+    {   // pool_idx / out_optional / out_sign_bits are honoured by the epilogues of the forward flavours of those kernels only: elsewhere
+        // the launch stores the map and the codes / sign words are computed from it afterwards
+        const bool in_epilogue = small && !a.x1 && !a.mask;
         if (!in_epilogue) { idx_after = a.pool_idx; a.pool_idx = nullptr; a.out_optional = 0; }
         if (a.out_sign_bits && (a.COUT != 128 || !a.out)) { mk_set_error("mk_conv3x3", "out_sign_bits: 128 output channels, stored map"); return -1; }
         if (a.out_sign_bits && !in_epilogue) { sign_after = a.out_sign_bits; a.out_sign_bits = nullptr; }
-        if ((a.pool_idx && !a.pool_out) || (!a.out && !(a.out_optional && a.pool_out))) { mk_set_error("mk_conv3x3", "pool_idx needs pool_out, and out may only be dropped when the launch pools"); return -1; }
+        if ((a.pool_idx && !a.pool_out) || (!a.out && !(a.out_optional && a.pool_out) && !a.x1)) { mk_set_error("mk_conv3x3", "pool_idx needs pool_out, and out may only be dropped when the launch pools"); return -1; }
     }
     const int rc = conv3x3_dispatch(a, s);
     if (rc == 0 && sign_after) {
@@ -2700,156 +2172,66 @@ int mk_conv3x3(const ConvArgs& a0, hipStream_t s) {
     return rc;
 }
 static int conv3x3_dispatch(const ConvArgs& a, hipStream_t s) {
-    if (getenv("MASR_CONV_V1")) {                          // first-generation im2col-on-the-fly kernel (kept for A/B runs)
-        const long P = (long)a.B * a.H * a.W;
-        dim3 grid((unsigned)((P + 127) / 128));
-        if (a.CIN == 64 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_kernel<64, 64>), grid, dim3(256), 0, s, a);
-        else if (a.CIN == 64 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_kernel<64, 128>), grid, dim3(256), 0, s, a);
-        else if (a.CIN == 128 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_kernel<128, 128>), grid, dim3(256), 0, s, a);
-        else if (a.CIN == 128 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_kernel<128, 64>), grid, dim3(256), 0, s, a);
-        else { mk_set_error("mk_conv3x3", "unsupported channel counts"); return -1; }
-        if (a.pool_out && mk_maxpool_fwd(a.out, a.pool_out, a.B, a.H, a.W, a.COUT, s)) return -1;     // (no fused pool in v1)
-        return hipGetLastError() == hipSuccess ? 0 : -1;
+    if (a.x1) {
+        if (!(a.CIN == 64 && a.COUT == 64) || !a.w1_slab) { mk_set_error("mk_conv3x3", "fused conv1 wgrad needs the 64->64 dgrad"); return -1; }
+        return launch_resw_w1(a, s);                         // (-1 without launching when mask_bits is missing: w1_slab stays unwritten)
     }
-    auto grid = [&](int TH) { return dim3((a.W + 15) / 16, (a.H + TH - 1) / TH, a.B); };
-    if (a.prof) {                                          // phase-timing instances of the four Transformer front-end shapes
-        const bool nar = a.W % 16 != 0;
-        const int TWv = nar ? 8 : 16;
-        const int tiles_x = (a.W + TWv - 1) / TWv, tiles_y = (a.H + 15) / 16;
-        if (getenv("MASR_CONV_STREAM") && atoi(getenv("MASR_CONV_STREAM")) == 0) {
-            auto grid8 = [&](int TH) { return dim3((a.W + 7) / 8, (a.H + TH - 1) / TH, a.B); };
-            if (a.CIN == 64 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<64, 64, 16, false, 16, true>), grid(16), dim3(256), 0, s, a);
-            else if (a.CIN == 64 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<64, 128, 16, false, 8, true>), grid8(16), dim3(256), 0, s, a);
-            else if (a.CIN == 128 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 128, 16, false, 8, true>), grid8(16), dim3(256), 0, s, a);
-            else if (a.CIN == 128 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 64, 16, false, 8, true>), grid8(16), dim3(256), 0, s, a);
-            else { mk_set_error("mk_conv3x3", "no phase-timing instance for this shape"); return -1; }
-        } else if (a.CIN == 64 && a.COUT == 64 && !nar && !(getenv("MASR_CONV_RESW") && atoi(getenv("MASR_CONV_RESW")) == 0)) launch_resw<true>(a, tiles_x, tiles_y, s);
-        else if (a.CIN == 64 && a.COUT == 64 && !nar) launch_stream<64, 64, 16, true>(a, tiles_x, tiles_y, s);
-        else if (a.CIN == 64 && a.COUT == 128 && nar) launch_stream<64, 128, 8, true>(a, tiles_x, tiles_y, s);
-        else if (a.CIN == 128 && a.COUT == 128 && nar) launch_stream<128, 128, 8, true>(a, tiles_x, tiles_y, s);
-        else if (a.CIN == 128 && a.COUT == 64 && nar) launch_stream<128, 64, 8, true>(a, tiles_x, tiles_y, s);
-        else { mk_set_error("mk_conv3x3", "no phase-timing instance for this shape"); return -1; }
-        return hipGetLastError() == hipSuccess ? 0 : -1;
-    }
-    // 8-wide tiles when they cover the width with fewer padded columns than 16-wide ones (e.g. W = 40: 40 vs 48)
-    static const bool allow_narrow = !getenv("MASR_CONV_NO_TW8");
-    const bool narrow = allow_narrow && narrow_w(a.W) && a.CIN <= 128 && a.COUT <= 128;
-    static const bool stream = !(getenv("MASR_CONV_STREAM") && atoi(getenv("MASR_CONV_STREAM")) == 0);
-    // (a forward flavour -- bias / ReLU / pool -- and a dgrad flavour -- mask only; anything else takes the patch kernel)
-    if (stream && !a.x1 && !(a.mask && (a.bias || a.relu || a.pool_out)) && a.CIN <= 128 && a.COUT <= 128 && (narrow || (a.CIN == 64 && a.COUT == 64))) {
-        const int TWv = narrow ? 8 : 16;
-        const int tiles_x = (a.W + TWv - 1) / TWv, tiles_y = (a.H + 15) / 16;
-        static const bool resw = !(getenv("MASR_CONV_RESW") && atoi(getenv("MASR_CONV_RESW")) == 0);
-        // 64 -> 64 always takes the resident-weight kernel with 16-wide tiles, also on widths that pad badly to 16
-        // (W = 83: 0.100 ms against 0.172 ms for the weight-ring kernel on 8-wide tiles)
-        if (a.CIN == 64 && a.COUT == 64 && resw && !a.mask) launch_resw<false>(a, (a.W + 15) / 16, tiles_y, s);
-        else if (!narrow) launch_stream<64, 64, 16>(a, tiles_x, tiles_y, s);
+    if (a.mask && (a.bias || a.relu || a.pool_out)) { mk_set_error("mk_conv3x3", "a launch is a forward flavour (bias / ReLU / pool) or a dgrad flavour (mask), not both"); return -1; }
+    if (a.CIN <= 128 && a.COUT <= 128) {
+        const int tiles_x = (a.W + 7) / 8, tiles_y = (a.H + 15) / 16, ty32 = (a.H + 31) / 32;
+        // 64 -> 64 forward takes the resident-weight kernel with 16-wide tiles, also on widths that pad badly to 16 (W = 83: 0.100 ms
+        // against 0.172 ms for the weight-ring kernel on 8-wide tiles).  32-row tiles where the registers allow: the per-tap weight slices
+        // (the bulk of these kernels' vector-memory instructions) are amortised over twice the pixels -- not for 64 -> 128 (spills), nor
+        // for a masked 128 <- 128 dgrad that reads the bf16 map as its mask (64 mask registers; with sign bits: 4)
+        if (a.CIN == 64 && a.COUT == 64 && !a.mask) launch_resw(a, (a.W + 15) / 16, tiles_y, s);
         else if (a.CIN == 64 && a.COUT == 64) launch_stream<64, 64, 8>(a, tiles_x, tiles_y, s);
         else if (a.CIN == 64 && a.COUT == 128) launch_stream<64, 128, 8>(a, tiles_x, tiles_y, s);
-        else {
-            // 32-row tiles where the registers allow: the per-tap weight slices (the bulk of these kernels' vector-memory
-            // instructions) are amortised over twice the pixels (128 -> 128 forward 103 -> 89 us, 128 -> 64 76 -> 61 us
-            // isolated).  Not for 64 -> 128 (spills, slower) nor for the masked 128 -> 128 dgrad (64 more mask registers).
-            static const bool th32 = !(getenv("MASR_CONV_TH32") && atoi(getenv("MASR_CONV_TH32")) == 0);
-            const int ty32 = (a.H + 31) / 32;
-            if (a.CIN == 128 && a.COUT == 128) {
-                // (the masked dgrad too once its mask comes as sign bits: 4 mask registers instead of 64)
-                if (th32 && !a.mask) launch_stream_t<128, 128, 8, 0, false, 32>(a, tiles_x, ty32, s);
-                else if (th32 && a.mask_bits) launch_stream_t<128, 128, 8, 2, false, 32>(a, tiles_x, ty32, s);
-                else launch_stream<128, 128, 8>(a, tiles_x, tiles_y, s);
-            } else if (th32) launch_stream<128, 64, 8, false, 32>(a, tiles_x, ty32, s);
-            else launch_stream<128, 64, 8>(a, tiles_x, tiles_y, s);
-        }
+        else if (a.CIN == 128 && a.COUT == 64) launch_stream<128, 64, 8, 32>(a, tiles_x, ty32, s);
+        else if (a.CIN == 128 && a.COUT == 128) {
+            if (!a.mask) launch_stream_t<128, 128, 8, 0, 32>(a, tiles_x, ty32, s);
+            else if (a.mask_bits && a.in_pooled) launch_stream_t<128, 128, 8, 2, 32, true>(a, tiles_x, ty32, s);
+            else if (a.mask_bits) launch_stream_t<128, 128, 8, 2, 32>(a, tiles_x, ty32, s);
+            else launch_stream<128, 128, 8>(a, tiles_x, tiles_y, s);
+        } else { mk_set_error("mk_conv3x3", "unsupported channel counts"); return -1; }
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
-    if (a.x1) {
-        if (!(a.CIN == 64 && a.COUT == 64) || !a.w1_slab || !a.mask) { mk_set_error("mk_conv3x3", "fused conv1 wgrad needs the 64->64 dgrad with a mask"); return -1; }
-        if (use_resw_w1()) return launch_resw_w1(a, s);          // (-1 without launching when mask_bits is missing: da1 / w1_slab stay unwritten)
-        hipLaunchKernelGGL((conv3x3_patch_kernel<64, 64, 16, true>), grid(16), dim3(256), 0, s, a);
-    } else if (a.CIN == 64 && a.COUT == 64) {
-        static const bool th8 = getenv("MASR_CONV_TH8") != nullptr;
-        if (th8) hipLaunchKernelGGL((conv3x3_patch_kernel<64, 64, 8>), grid(8), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((conv3x3_patch_kernel<64, 64, 16>), grid(16), dim3(256), 0, s, a);
-    } else if (narrow) {                                     // same pixels per workgroup, tile 8 columns wide and twice as tall
-        auto grid8 = [&](int TH) { return dim3((a.W + 7) / 8, (a.H + TH - 1) / TH, a.B); };
-        if (a.CIN == 64 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<64, 128, 16, false, 8>), grid8(16), dim3(256), 0, s, a);
-        else if (a.CIN == 128 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 128, 16, false, 8>), grid8(16), dim3(256), 0, s, a);
-        else if (a.CIN == 128 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 64, 16, false, 8>), grid8(16), dim3(256), 0, s, a);
-        else { mk_set_error("mk_conv3x3", "unsupported channel counts"); return -1; }
-    }
-    else if (a.CIN == 128 && a.COUT == 256) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 256, 8>), grid(8), dim3(256), 0, s, a);   // BLSTM front-end
+    auto grid = [&](int TH) { return dim3((a.W + 15) / 16, (a.H + TH - 1) / TH, a.B); };        // BLSTM front-end (256 channels): the patch kernel
+    if (a.CIN == 128 && a.COUT == 256) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 256, 8>), grid(8), dim3(256), 0, s, a);
     else if (a.CIN == 256 && a.COUT == 256) hipLaunchKernelGGL((conv3x3_patch_kernel<256, 256, 8>), grid(8), dim3(256), 0, s, a);
     else if (a.CIN == 256 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<256, 128, 8>), grid(8), dim3(256), 0, s, a);
-    else if (a.CIN == 64 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<64, 128, 8>), grid(8), dim3(256), 0, s, a);
-    else if (a.CIN == 128 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 128, 8>), grid(8), dim3(256), 0, s, a);
-    else if (a.CIN == 128 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 64, 16>), grid(16), dim3(256), 0, s, a);
     else { mk_set_error("mk_conv3x3", "unsupported channel counts"); return -1; }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-static int wgrad2_nwg(int CIN, int COUT) {
-    static const int total = getenv("MASR_WGRAD_WGS") ? atoi(getenv("MASR_WGRAD_WGS")) : W2_TOTAL_WG;
-    return total / ((CIN / 64) * (COUT / 64));
-}
+// ONE persistent workgroup per CU with the next tiles prefetched in registers (256 partial slabs: 37 MB written and read again per layer).
+// One configuration for every mode: the partition of the pixels into partial sums is part of the result's bits (slots = sequential run).
+static int wgrad2_nwg(int CIN, int COUT) { return W2_TOTAL_WG / ((CIN / 64) * (COUT / 64)); }
 long mk_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT) {
-    const long v1 = (long)wgrad_splits((long)B * H * W, CIN) * (COUT * 9 * CIN + COUT);
-    const long v2 = (long)wgrad2_nwg(CIN, COUT) * (COUT * 9 * CIN + COUT);
-    return v1 > v2 ? v1 : v2;
+    (void)B; (void)H; (void)W;
+    return (long)wgrad2_nwg(CIN, COUT) * (COUT * 9 * CIN + COUT);
 }
 int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s, int phase) {
     // phase 0: both launches; 1: the partial-slab kernel only; 2: the slab reduce only (the engine times them in separate slots)
-    const long P = (long)a.B * a.H * a.W;
-    int splits;
-    if (getenv("MASR_WGRAD_V1")) {                         // first-generation one-tap-per-workgroup kernel (kept for A/B runs)
-        splits = wgrad_splits(P, a.CIN);
-        long pps = (P + splits - 1) / splits;
-        pps = (pps + 63) / 64 * 64;
-        dim3 grid(9 * (a.CIN / 64), splits);
-        if (phase == 2) {}
-        else if (a.CIN == 64 && a.COUT == 64) hipLaunchKernelGGL((conv3x3_wgrad_kernel<64, 64>), grid, dim3(256), 0, s, a, pps);
-        else if (a.CIN == 64 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_wgrad_kernel<64, 128>), grid, dim3(256), 0, s, a, pps);
-        else if (a.CIN == 128 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_wgrad_kernel<128, 128>), grid, dim3(256), 0, s, a, pps);
-        else { mk_set_error("mk_conv3x3_wgrad", "unsupported channel counts"); return -1; }
-    } else {
-        static const bool allow_narrow = getenv("MASR_WGRAD_TW8") != nullptr;
-        const bool narrow = allow_narrow && (a.W + 7) / 8 * 8 < (a.W + 15) / 16 * 16;
-        const int tw = narrow ? 8 : 16, th = 128 / tw;
-        const int tiles_x = (a.W + tw - 1) / tw, tiles_y = (a.H + th - 1) / th;
-        const int ntiles = tiles_x * tiles_y * a.B;
-        // ONE persistent workgroup per CU with the next tile prefetched in registers (256 partial slabs: 37 MB written and read again per
-        // layer).  Two per CU (one multiplies while the other loads and stages; MASR_WGRAD_WGS=512 MASR_WGRAD_OCC=2) is 2 % faster for a
-        // model that has the chip to itself but doubles the slabs, and under concurrent task slots the other slots' launches fill the gaps
-        // anyway.  Measured, utt/s single task / four slots: 512 x 2: 6 107 / 8 926; 256 x 1: 5 980 / 9 155.  One configuration for both
-        // modes: the partition of the pixels into partial sums is part of the result's bits (slots = sequential run, bit for bit).
-        static const int occ = getenv("MASR_WGRAD_OCC") ? atoi(getenv("MASR_WGRAD_OCC")) : 1;
-        int nwg = wgrad2_nwg(a.CIN, a.COUT);
-        if (nwg > ntiles) nwg = ntiles;
-        splits = nwg;
-        dim3 grid(nwg, (a.CIN / 64) * (a.COUT / 64));
-#define W2T(CI, CO, OC, TWV) hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CI, CO, OC, TWV>), grid, dim3(OC == 1 ? 512 : 256), 0, s, a, nwg, ntiles, tiles_x, tiles_y)
-#define W2P(CI, CO) { if (occ == 1) hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CI, CO, 1, 16, true>), grid, dim3(512), 0, s, a, nwg, ntiles, tiles_x, tiles_y); \
-                     else hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CI, CO, 2, 16, true>), grid, dim3(256), 0, s, a, nwg, ntiles, tiles_x, tiles_y); }
-#define W2(CI, CO) \
-        if (occ == 1) { if (narrow) W2T(CI, CO, 1, 8); else W2T(CI, CO, 1, 16); } \
-        else { if (narrow) W2T(CI, CO, 2, 8); else W2T(CI, CO, 2, 16); }
-        const bool pooled = a.dy_pooled && a.pool_idx && !narrow;
-        if (!pooled && !a.dy) { mk_set_error("mk_conv3x3_wgrad", "dy missing (the pooled form needs 16-wide tiles)"); return -1; }
-        if (pooled && !((a.CIN == 64 && a.COUT == 64) || (a.CIN == 128 && a.COUT == 128))) { mk_set_error("mk_conv3x3_wgrad", "pooled dy: 64->64 and 128->128 only"); return -1; }
-        if (phase == 2) {}
-        else if (pooled && a.CIN == 64) W2P(64, 64)
-        else if (pooled) W2P(128, 128)
-        else if (a.CIN == 64 && a.COUT == 64) { W2(64, 64) }
-        else if (a.CIN == 64 && a.COUT == 128) { W2(64, 128) }
-        else if (a.CIN == 128 && a.COUT == 128) { W2(128, 128) }
-        else if (a.CIN == 128 && a.COUT == 256) { W2(128, 256) }
-        else if (a.CIN == 256 && a.COUT == 256) { W2(256, 256) }
-        else { mk_set_error("mk_conv3x3_wgrad", "unsupported channel counts"); return -1; }
-#undef W2T
-#undef W2P
+    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 7) / 8, ntiles = tiles_x * tiles_y * a.B;
+    int nwg = wgrad2_nwg(a.CIN, a.COUT);
+    if (nwg > ntiles) nwg = ntiles;
+    const dim3 grid(nwg, (a.CIN / 64) * (a.COUT / 64));
+#define W2(CI, CO, PL) hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CI, CO, 16, PL>), grid, dim3(512), 0, s, a, nwg, ntiles, tiles_x, tiles_y)
+    const bool pooled = a.dy_pooled && a.pool_idx;
+    if (!pooled && !a.dy) { mk_set_error("mk_conv3x3_wgrad", "dy missing"); return -1; }
+    if (pooled && !((a.CIN == 64 && a.COUT == 64) || (a.CIN == 128 && a.COUT == 128))) { mk_set_error("mk_conv3x3_wgrad", "pooled dy: 64->64 and 128->128 only"); return -1; }
+    if (phase == 2) {}
+    else if (pooled && a.CIN == 64) W2(64, 64, true);
+    else if (pooled) W2(128, 128, true);
+    else if (a.CIN == 64 && a.COUT == 64) W2(64, 64, false);
+    else if (a.CIN == 64 && a.COUT == 128) W2(64, 128, false);
+    else if (a.CIN == 128 && a.COUT == 128) W2(128, 128, false);
+    else if (a.CIN == 128 && a.COUT == 256) W2(128, 256, false);
+    else if (a.CIN == 256 && a.COUT == 256) W2(256, 256, false);
+    else { mk_set_error("mk_conv3x3_wgrad", "unsupported channel counts"); return -1; }
 #undef W2
-    }
     const int n = a.COUT * 9 * a.CIN + a.COUT;
-    if (phase != 1) hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((n + 63) / 64), dim3(256), 0, s, a.slab, splits, a.dw, a.db, a.CIN, a.COUT);
+    if (phase != 1) hipLaunchKernelGGL(conv3x3_wgrad_reduce, dim3((n + 63) / 64), dim3(256), 0, s, a.slab, nwg, a.dw, a.db, a.CIN, a.COUT);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -167,6 +167,8 @@ __global__ __launch_bounds__(256) void recog_argmax_step_kernel(int* step, const
 // fp32 logits of the greedy decode: z[r][c] = bias[c] + sum_k y[r][k] W[c][k] on the fp32 MASTER weights and the fp32 LayerNorm output
 // (the training forward's bf16 operands are fine for a loss, but an arg-max is an index: the last projection is where two near-tied
 // classes are told apart, and it is 0.4 MFLOP per row).  grid (rows, ceil(C / 64)), a wave = 16 classes, fixed summation order.
+// VEC: 16-byte loads (rows of y and W 16-byte aligned); otherwise the same products in the same order from 4-byte loads
+template <bool VEC>
 __global__ __launch_bounds__(256) void logits_f32_kernel(const float* __restrict__ y, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ z, long ldz, int C, int E) {
     const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -176,7 +178,9 @@ __global__ __launch_bounds__(256) void logits_f32_kernel(const float* __restrict
         const float* w = W + (long)c * E;
         float acc = 0.f;
         for (int k = lane * 4; k < E; k += 256) {
-            const float4 a = *reinterpret_cast<const float4*>(yr + k), b = *reinterpret_cast<const float4*>(w + k);
+            float4 a, b;
+            if constexpr (VEC) { a = *reinterpret_cast<const float4*>(yr + k); b = *reinterpret_cast<const float4*>(w + k); }
+            else { a = float4{yr[k], yr[k + 1], yr[k + 2], yr[k + 3]}; b = float4{w[k], w[k + 1], w[k + 2], w[k + 3]}; }
             acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
         }
         acc = wave_sum(acc);
@@ -219,7 +223,10 @@ int mk_recog_embed_step(const int* step, const int* out, const float* table, con
 }
 int mk_logits_f32(const float* y32, const float* W32, const float* bias, float* logits, long ld, int rows, int C, int E, hipStream_t s) {
     if (E % 4 != 0 || rows <= 0) { mk_set_error("mk_logits_f32", "E % 4 == 0 and rows >= 1 required"); return -1; }
-    hipLaunchKernelGGL(logits_f32_kernel, dim3(rows, (C + 63) / 64), dim3(256), 0, s, y32, W32, bias, logits, ld, C, E);
+    // (the projection sits at an arbitrary dword offset of the flat parameter buffer as far as this launcher knows: 16-byte loads only
+    // when both operands' rows are 16-byte aligned -- always the case for the engine's models, whose d_model is a multiple of 64)
+    if (!(((uintptr_t)y32 | (uintptr_t)W32) & 15)) hipLaunchKernelGGL(logits_f32_kernel<true>, dim3(rows, (C + 63) / 64), dim3(256), 0, s, y32, W32, bias, logits, ld, C, E);
+    else hipLaunchKernelGGL(logits_f32_kernel<false>, dim3(rows, (C + 63) / 64), dim3(256), 0, s, y32, W32, bias, logits, ld, C, E);
     return LAUNCH_OK();
 }
 int mk_recog_argmax_step(int* step, const float* logits, long ld, int* out, int B, int C, hipStream_t s) {

@@ -54,7 +54,7 @@ struct Acts {
     int *tok_order, *tok_start;             // decoder-input token positions sorted by token id + the C + 1 segment starts (embedding backward)
     uint32_t* meta;                                        // [8] behind enc_lens, same upload: [0] dropout seed of the step, [1] 1/n_total (float bits)
     bf16* step_qkv;                                        // incremental decode: the newest position's q|k|v [B][3E]
-    bf16 *a1, *a2, *p1, *a3, *a4, *p2;
+    bf16 *a1, *p1, *a3, *p2;
     unsigned long long *a1_bits, *a3_bits;                           // ReLU mask of a1, one word per pixel (written by conv1's forward, read by conv2's fused dgrad)
     uint8_t *i1, *i2;                                  // ConvArgs::pool_idx of the two pools (a2 / a4 are only written by conv kernels that cannot emit them)
     std::vector<float*> x32; std::vector<bf16*> x16;        // encoder layer inputs/outputs [NE+1]
@@ -67,7 +67,7 @@ struct Acts {
     uint32_t site_v2e, site_emb;
     // backward scratch
     float *ge_a, *ge_b, *gd_a, *gd_b, *dmem32, *v2e_g32;
-    bf16 *ge16, *gqkv_e, *gf_e, *gao_e, *gao_d, *gkv_all, *dp2, *da4, *da3, *dp1, *da2, *da1;
+    bf16 *ge16, *gqkv_e, *gf_e, *gao_e, *gao_d, *gkv_all, *dp2, *da3, *dp1;      // (d(a4), d(a2) exist only as pooled gradient + codes; d(a1) never)
     float *delta_e, *delta_d;
     std::vector<DecGrad> dgr;
     std::vector<EncGrad> egr;
@@ -104,7 +104,7 @@ struct masr_model {
     // row segments at arbitrary dword offsets make every fp32 write-back a partial-line store, where the flat pass streams whole lines
     // (and neither the instruction count -- 17 lanes per row, one load per array and pass -- nor the 4 B/param matter beside that).
     // Default OFF; MASR_FUSED_SGD=1 / masr_set_fused_sgd for A/B runs and the parity test.
-    long* d_gaps = nullptr; int ngaps = 0;
+    long* d_gaps = nullptr; int ngaps = 0; bool gaps_ok = false;     // gaps_ok: the gap list exists (masr_bind) -- without it the fused pass would skip the unshadowed parameters
     bool fuse_sgd = getenv("MASR_FUSED_SGD") != nullptr && atoi(getenv("MASR_FUSED_SGD")) != 0;
     float* stats = nullptr;                   // device [8]: loss, n_correct, n_total, grad_norm
     unsigned* conv_sched = nullptr;           // tile counters of the streaming conv kernel (this model's stream only)
@@ -228,9 +228,9 @@ void plan_acts(const masr_model* m, Arena& ar, Acts& a, int B, int T, int L, boo
     a.step_dev = ar.get<int>(4);
     a.step_qkv = ar.get<bf16>((int64_t)B * 3 * E);
     const int64_t P1 = (int64_t)B * T * m->D, P2 = (int64_t)B * a.H2 * a.W2;
-    a.a1 = ar.get<bf16>(P1 * 64); a.a2 = ar.get<bf16>(P1 * 64); a.p1 = ar.get<bf16>(P2 * 64);
+    a.a1 = ar.get<bf16>(P1 * 64); a.p1 = ar.get<bf16>(P2 * 64);      // (the maps in front of the pools, a2 and a4, are never stored: pooled map + codes)
     a.a1_bits = ar.get<unsigned long long>(P1); a.a3_bits = ar.get<unsigned long long>(P2 * 2);      // (64 / 128 sign bits per pixel)
-    a.a3 = ar.get<bf16>(P2 * 128); a.a4 = ar.get<bf16>(P2 * 128); a.p2 = ar.get<bf16>(re * m->F);
+    a.a3 = ar.get<bf16>(P2 * 128); a.p2 = ar.get<bf16>(re * m->F);
     a.i1 = ar.get<uint8_t>(P2 * 64); a.i2 = ar.get<uint8_t>(re * m->F);
     a.x32.resize(m->NE + 1); a.x16.resize(m->NE + 1); a.enc.resize(m->NE);
     for (int l = 0; l <= m->NE; ++l) { a.x32[l] = ar.get<float>(re * E); a.x16[l] = ar.get<bf16>(re * E); }
@@ -263,7 +263,7 @@ void plan_acts(const masr_model* m, Arena& ar, Acts& a, int B, int T, int L, boo
     mx(mk_layernorm_bwd_slab_floats((int)(re > rd ? re : rd), E));
     mx(mk_colsum_slab_floats((int)P1, 64)); mx(mk_colsum_slab_floats((int)P2, 128));
     mx(mk_colsum_slab_floats((int)(re > rd ? re : rd), 3 * E > Fi ? 3 * E : Fi));
-    mx(mk_conv1_wgrad_slab_floats(B, T, m->D)); mx(mk_conv1_wgrad_fused_slab_floats(B, T, m->D));
+    mx(mk_conv1_wgrad_fused_slab_floats(B, T, m->D));
     mx(mk_conv3x3_wgrad_slab_floats(B, T, m->D, 64, 64));
     mx(mk_conv3x3_wgrad_slab_floats(B, a.H2, a.W2, 64, 128));
     mx(mk_conv3x3_wgrad_slab_floats(B, a.H2, a.W2, 128, 128));
@@ -289,8 +289,7 @@ void plan_acts(const masr_model* m, Arena& ar, Acts& a, int B, int T, int L, boo
             g.g3 = ar.get<bf16>(rd * E); g.g2 = ar.get<bf16>(rd * E); g.g1 = ar.get<bf16>(rd * E);
             g.gf = ar.get<bf16>(rd * Fi); g.gq = ar.get<bf16>(rd * E); g.gqkv = ar.get<bf16>(rd * 3 * E);
         }
-        a.dp2 = ar.get<bf16>(re * m->F); a.da4 = ar.get<bf16>(P2 * 128); a.da3 = ar.get<bf16>(P2 * 128);
-        a.dp1 = ar.get<bf16>(P2 * 64); a.da2 = ar.get<bf16>(P1 * 64); a.da1 = ar.get<bf16>(P1 * 64);
+        a.dp2 = ar.get<bf16>(re * m->F); a.da3 = ar.get<bf16>(P2 * 128); a.dp1 = ar.get<bf16>(P2 * 64);
     }
 }
 
@@ -700,8 +699,9 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
             at = r.first + r.second;
         }
         gap(at, m->nparams);
-        if ((int)gaps.size() / 2 > GAP_CHUNKS_MAX) { m->fuse_sgd = false; m->ngaps = 0; }     // (a model with that many unshadowed parameters: two passes)
+        if ((int)gaps.size() / 2 > GAP_CHUNKS_MAX) { m->fuse_sgd = false; m->ngaps = 0; m->gaps_ok = false; }     // (a model with that many unshadowed parameters: two passes)
         else {
+            m->gaps_ok = true;
             m->ngaps = (int)gaps.size() / 2;
             if (m->ngaps) HIP_CHECK_RET(hipMemcpy(m->d_gaps, gaps.data(), sizeof(long) * gaps.size(), hipMemcpyHostToDevice));
         }
@@ -741,22 +741,19 @@ static int forward_encoder(Ctx& c, const float* xs) {
         Prof p(m, MASR_PROF_CONV1_FWD, s);
         CK(mk_conv1_fwd(xs, P + m->conv[0].w, P + m->conv[0].b, a.a1, B, T, D, s, c.train ? a.a1_bits : nullptr));
     }
-    static const bool fuse_pool = !getenv("MASR_NO_FUSED_POOL");      // MaxPool2d written by the producing conv's epilogue
     // the maps in front of the two pools are needed by nothing but the pool + ReLU backward, and that needs one byte per POOLED
     // element (which window position won, or that none passed the ReLU): the pooling convs store those and drop the map
     auto conv = [&](const bf16* in, const Conv& cv, bf16* out, int H, int W, bf16* pooled, uint8_t* idx) -> int {
         Prof p(m, MASR_PROF_CONV2_FWD + (int)(&cv - &m->conv[1]), s);
         ConvArgs ca{}; ca.sched = m->conv_sched; ca.in = in; ca.wk = cv.k16; ca.bias = P + cv.b; ca.relu = 1; ca.mask = nullptr; ca.out = out;
-        ca.B = B; ca.H = H; ca.W = W; ca.CIN = cv.CI; ca.COUT = cv.CO; ca.pool_out = fuse_pool ? pooled : nullptr;
+        ca.B = B; ca.H = H; ca.W = W; ca.CIN = cv.CI; ca.COUT = cv.CO; ca.pool_out = pooled;      // MaxPool2d written by the producing conv's epilogue
         if (ca.pool_out) { ca.pool_idx = c.train ? idx : nullptr; ca.out_optional = 1; }
-        if (&cv == &m->conv[2] && c.train && mk_conv3x3_mask_bits_used(W)) ca.out_sign_bits = a.a3_bits;      // conv3's ReLU mask as sign bits for conv4's masked dgrad
+        if (&cv == &m->conv[2] && c.train) ca.out_sign_bits = a.a3_bits;      // conv3's ReLU mask as sign bits for conv4's masked dgrad
         return mk_conv3x3(ca, s);
     };
-    CK(conv(a.a1, m->conv[1], a.a2, T, D, a.p1, a.i1));
-    if (!fuse_pool) { Prof p(m, MASR_PROF_POOL, s); CK(mk_maxpool_fwd(a.a2, a.p1, B, T, D, 64, s)); if (c.train) CK(mk_maxpool_idx(a.a2, a.i1, B, T, D, 64, s)); }
+    CK(conv(a.a1, m->conv[1], nullptr, T, D, a.p1, a.i1));
     CK(conv(a.p1, m->conv[2], a.a3, a.H2, a.W2, nullptr, nullptr));
-    CK(conv(a.a3, m->conv[3], a.a4, a.H2, a.W2, a.p2, a.i2));
-    if (!fuse_pool) { Prof p(m, MASR_PROF_POOL, s); CK(mk_maxpool_fwd(a.a4, a.p2, B, a.H2, a.W2, 128, s)); if (c.train) CK(mk_maxpool_idx(a.a4, a.i2, B, a.H2, a.W2, 128, s)); }
+    CK(conv(a.a3, m->conv[3], nullptr, a.H2, a.W2, a.p2, a.i2));
     // vgg2enc + positional encoding + pos dropout
     {
         GemmArgs g = lin_fwd_args(a.p2, m->F, m->v2e_k, a.rows_e, E, m->F, P + m->v2e.b);
@@ -932,42 +929,34 @@ static int backward(Ctx& c, const float* xs) {
     { Prof p(m, MASR_PROF_MISC, s); CK(mk_vgg2enc_grad_unpermute(a.v2e_g32, G + m->v2e.w, E, 128, m->Dp, s)); }
     { GemmArgs g = lin_dgrad_args(a.ge16, E, m->v2e.t16, E, a.rows_e, E, m->F); g.C16 = a.dp2; g.ldc16 = m->F; CK(gemm(c, g)); }
     // ---- VGG
-    const int64_t P1 = (int64_t)B * a.T * a.D, P2 = (int64_t)B * a.H2 * a.W2;
-    static const bool wgrad_pooled = !getenv("MASR_WGRAD_NO_POOLED");
-    auto wgrad = [&](const bf16* in, const bf16* dy, const Conv& cv, int H, int W, int64_t P, const bf16* dy_pooled = nullptr, const uint8_t* idx = nullptr) -> int {
+    // The two maps behind a max-pool, d(a4) and d(a2), are never materialised: their consumers -- the weight-gradient kernels and the
+    // dgrad kernels -- take the POOLED gradient + the one-byte pool codes of the forward launch and expand the 2 x 2 windows while staging
+    // (a quarter of the gradient bytes; the maxpool backward launches and their 338 MB per step are gone)
+    auto wgrad = [&](const bf16* in, const bf16* dy, const Conv& cv, int H, int W, const bf16* dy_pooled = nullptr, const uint8_t* idx = nullptr) -> int {
         ConvWgradArgs wa{}; wa.in = in; wa.dy = dy; wa.dw = G + cv.w; wa.db = G + cv.b; wa.slab = a.slab; wa.B = B; wa.H = H; wa.W = W; wa.CIN = cv.CI; wa.COUT = cv.CO;
-        if (wgrad_pooled) { wa.dy_pooled = dy_pooled; wa.pool_idx = idx; }      // (the pooled gradient + codes: a quarter of the bytes of dy)
+        wa.dy_pooled = dy_pooled; wa.pool_idx = idx;
         { Prof p(m, MASR_PROF_CONV2_WGRAD + (int)(&cv - &m->conv[1]), s); CK(mk_conv3x3_wgrad(wa, s, 1)); }     // ONE launch per slot:
         { Prof p(m, MASR_PROF_CONV1_WGRAD, s); CK(mk_conv3x3_wgrad(wa, s, 2)); }                                 // the slab reduce is timed with the other folds
-        (void)P;
         return 0;
     };
-    auto dgrad = [&](const bf16* dy, const Conv& cv, const bf16* mask, bf16* out, int H, int W) -> int {
+    auto dgrad = [&](const bf16* dy, const Conv& cv, bf16* out, int H, int W, const bf16* dy_pooled = nullptr, const uint8_t* idx = nullptr) -> int {
         Prof p(m, MASR_PROF_CONV2_DGRAD + (int)(&cv - &m->conv[1]), s);
-        ConvArgs ca{}; ca.sched = m->conv_sched; ca.in = dy; ca.wk = cv.d16; ca.bias = nullptr; ca.relu = 0; ca.mask = mask; ca.out = out; ca.B = B; ca.H = H; ca.W = W;
+        ConvArgs ca{}; ca.sched = m->conv_sched; ca.in = dy; ca.in_pooled = dy_pooled; ca.in_idx = idx; ca.wk = cv.d16; ca.out = out; ca.B = B; ca.H = H; ca.W = W;
         ca.CIN = cv.CO; ca.COUT = cv.CI;
-        if (mask == a.a3 && mk_conv3x3_mask_bits_used(W)) ca.mask_bits = a.a3_bits;                           // written by conv3's forward launch (128-channel sign words)
+        if (&cv == &m->conv[3]) { ca.mask = a.a3; ca.mask_bits = a.a3_bits; }      // conv3's ReLU mask: the sign words its forward launch wrote
+        if (&cv == &m->conv[1]) {
+            // d(conv1 output) is consumed only by conv1's weight gradient: contracted inside the dgrad epilogue, never stored
+            ca.mask = a.a1; ca.mask_bits = a.a1_bits; ca.out = nullptr; ca.x1 = xs; ca.w1_slab = a.slab;
+        }
         return mk_conv3x3(ca, s);
     };
-    { Prof p(m, MASR_PROF_POOL, s); CK(mk_maxpool_idx_bwd(a.i2, a.dp2, a.da4, B, a.H2, a.W2, 128, s)); }
-    CK(wgrad(a.a3, a.da4, m->conv[3], a.H2, a.W2, P2, a.dp2, a.i2));
-    CK(dgrad(a.da4, m->conv[3], a.a3, a.da3, a.H2, a.W2));
-    CK(wgrad(a.p1, a.da3, m->conv[2], a.H2, a.W2, P2));
-    CK(dgrad(a.da3, m->conv[2], nullptr, a.dp1, a.H2, a.W2));
-    { Prof p(m, MASR_PROF_POOL, s); CK(mk_maxpool_idx_bwd(a.i1, a.dp1, a.da2, B, a.T, a.D, 64, s)); }
-    CK(wgrad(a.a1, a.da2, m->conv[1], a.T, a.D, P1, a.dp1, a.i1));
-    static const bool fuse_w1 = !getenv("MASR_NO_FUSED_CONV1_WGRAD");
-    if (fuse_w1) {
-        // d(conv1 output) is consumed only by conv1's weight gradient: contract it inside the dgrad epilogue, never store it
-        { Prof p(m, MASR_PROF_CONV2_DGRAD, s);
-          ConvArgs ca{}; ca.sched = m->conv_sched; ca.in = a.da2; ca.wk = m->conv[1].d16; ca.mask = a.a1; ca.mask_bits = a.a1_bits; ca.out = a.da1; ca.B = B; ca.H = a.T; ca.W = a.D;
-          ca.CIN = 64; ca.COUT = 64; ca.x1 = xs; ca.w1_slab = a.slab;
-          CK(mk_conv3x3(ca, s)); }
-        { Prof p(m, MASR_PROF_CONV1_WGRAD, s); CK(mk_conv1_wgrad_fused_reduce(a.slab, B, a.T, a.D, G + m->conv[0].w, G + m->conv[0].b, s)); }
-    } else {
-        CK(dgrad(a.da2, m->conv[1], a.a1, a.da1, a.T, a.D));
-        { Prof p(m, MASR_PROF_CONV1_WGRAD, s); CK(mk_conv1_wgrad(xs, a.da1, G + m->conv[0].w, G + m->conv[0].b, a.slab, B, a.T, a.D, s)); }
-    }
+    CK(wgrad(a.a3, nullptr, m->conv[3], a.H2, a.W2, a.dp2, a.i2));
+    CK(dgrad(nullptr, m->conv[3], a.da3, a.H2, a.W2, a.dp2, a.i2));
+    CK(wgrad(a.p1, a.da3, m->conv[2], a.H2, a.W2));
+    CK(dgrad(a.da3, m->conv[2], a.dp1, a.H2, a.W2));
+    CK(wgrad(a.a1, nullptr, m->conv[1], a.T, a.D, a.dp1, a.i1));
+    CK(dgrad(nullptr, m->conv[1], nullptr, a.T, a.D, a.dp1, a.i1));
+    { Prof p(m, MASR_PROF_CONV1_WGRAD, s); CK(mk_conv1_wgrad_fused_reduce(a.slab, B, a.T, a.D, G + m->conv[0].w, G + m->conv[0].b, s)); }
     CK(flush_ln_reduce(c));
     // ---- combine the split-K partials of all Linear gradients, then add the embedding rows into the (tied) table
     { Prof p(m, MASR_PROF_MISC, s);
@@ -990,7 +979,15 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
     if (ar.off > m->ws_bytes) { mk_set_error("masr_run_batch", "workspace too small (see masr_workspace_bytes)"); return -2; }
     Acts& a = m->acts; m->have_acts = true;
     const int64_t stage_n = (int64_t)3 * B * L + B + 8 + m->C + 1;        // tok_in | gold | enc_lens | meta | tok_order | tok_start
-    if (stage_n > m->stage_ints) { mk_set_error("masr_run_batch", "token staging buffer too small"); return -1; }
+    if (stage_n > m->stage_ints) {
+        // the pinned staging ring grows with the batch (B * L) and the vocabulary (C): drain the copies in flight, then re-allocate
+        for (auto& ev : m->stage_ev) HIP_CHECK_RET(hipEventSynchronize(ev));
+        int* grown = nullptr;
+        const int64_t want = stage_n + stage_n / 2;
+        HIP_CHECK_RET(hipHostMalloc((void**)&grown, sizeof(int) * want * 4, hipHostMallocDefault));
+        hipHostFree(m->h_stage);
+        m->h_stage = grown; m->stage_ints = want;
+    }
     // ---- MyTransformer.preprocess (:124-141): ys_in = [sos]+y padded with eos, ys_out = y+[eos] padded with -1
     const int slot = m->stage_slot; m->stage_slot = (slot + 1) & 3;
     HIP_CHECK_RET(hipEventSynchronize(m->stage_ev[slot]));
@@ -1082,7 +1079,7 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
 
 void masr_set_step_graphs(masr_model* m, int on) { m->step_graphs_on = on != 0; }
 void masr_set_ln_fusion(masr_model* m, int on) { m->ln_fusion = on != 0; }
-void masr_set_fused_sgd(masr_model* m, int on) { m->fuse_sgd = on != 0 && m->ngaps <= GAP_CHUNKS_MAX; }
+void masr_set_fused_sgd(masr_model* m, int on) { m->fuse_sgd = on != 0 && m->gaps_ok; }
 void masr_step_counters(const masr_model* m, int64_t out[3]) { out[0] = m->n_direct; out[1] = m->n_captured; out[2] = m->n_replayed; }
 
 int masr_read_stats(masr_model* m, float out[4], void* stream) {
@@ -1136,7 +1133,7 @@ int masr_grad_norm(masr_model* m, void* stream) {
 }
 int masr_clip_sgd_step(masr_model* m, float* mom, float max_norm, float lr, float momentum, int nesterov, int first_step, void* stream) {
     CK(masr_grad_norm(m, stream));
-    if (m->fuse_sgd && !m->shadows.empty()) {
+    if (m->fuse_sgd && m->gaps_ok && !m->shadows.empty()) {
         // ONE pass: p and g in, p and every bf16 layout out (kernels.h mk_sgd_shadows)
         Prof p(m, MASR_PROF_OPTIM, (hipStream_t)stream);
         const SgdFuse sg{m->G, mom, m->stats + 3, max_norm, lr, momentum, nesterov, first_step};
@@ -1443,11 +1440,22 @@ int masr_test_conv3x3_pool_idx(const uint16_t* in, const uint16_t* wk, const flo
 int masr_test_maxpool_idx_bwd(const uint8_t* idx, const uint16_t* dout, uint16_t* din, int B, int H, int W, int C, void* stream) {
     return mk_maxpool_idx_bwd(idx, (const bf16*)dout, (bf16*)din, B, H, W, C, (hipStream_t)stream);
 }
-int masr_test_conv3x3_prof(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, uint16_t* out, int B, int H, int W, int CIN,
-                           int COUT, int64_t* prof, void* stream) {
-    ConvArgs a{}; a.in = (const bf16*)in; a.wk = (const bf16*)wk; a.bias = bias; a.relu = relu; a.out = (bf16*)out;
-    a.B = B; a.H = H; a.W = W; a.CIN = CIN; a.COUT = COUT; a.prof = (long*)prof;
+int masr_test_conv3x3_dgrad_pooled(const uint16_t* dy, const uint16_t* dy_pooled, const uint8_t* pool_idx, const uint16_t* wk, const uint32_t* mask_bits,
+                                   uint16_t* out, int B, int H, int W, void* stream) {
+    ConvArgs a{}; a.in = (const bf16*)dy; a.in_pooled = (const bf16*)dy_pooled; a.in_idx = pool_idx; a.wk = (const bf16*)wk;
+    a.mask = (const bf16*)out; a.mask_bits = (const unsigned long long*)mask_bits; a.out = (bf16*)out;      // (mask: any non-null pointer -- the sign words are what is read)
+    a.B = B; a.H = H; a.W = W; a.CIN = 128; a.COUT = 128;
     return mk_conv3x3(a, (hipStream_t)stream);
+}
+int64_t masr_test_conv1_wgrad_fused_slab_floats(int B, int H, int W) { return mk_conv1_wgrad_fused_slab_floats(B, H, W); }
+int masr_test_conv1_wgrad_fused(const uint16_t* dy, const uint16_t* dy_pooled, const uint8_t* pool_idx, const uint16_t* wk, const uint64_t* mask_bits,
+                                const float* x1, float* slab, int64_t slab_floats, float* dw1, float* db1, int B, int H, int W, void* stream) {
+    if (slab_floats < mk_conv1_wgrad_fused_slab_floats(B, H, W)) { mk_set_error("masr_test_conv1_wgrad_fused", "slab too small"); return -1; }
+    ConvArgs a{}; a.in = (const bf16*)dy; a.in_pooled = (const bf16*)dy_pooled; a.in_idx = pool_idx; a.wk = (const bf16*)wk;
+    a.mask = (const bf16*)wk; a.mask_bits = (const unsigned long long*)mask_bits; a.x1 = x1; a.w1_slab = slab;
+    a.B = B; a.H = H; a.W = W; a.CIN = 64; a.COUT = 64;
+    CK(mk_conv3x3(a, (hipStream_t)stream));
+    return mk_conv1_wgrad_fused_reduce(slab, B, H, W, dw1, db1, (hipStream_t)stream);
 }
 int64_t masr_test_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT) { return mk_conv3x3_wgrad_slab_floats(B, H, W, CIN, COUT); }
 int masr_test_conv3x3_wgrad(const uint16_t* in, const uint16_t* dy, float* dw, float* slab, int64_t slab_floats, int B, int H, int W, int CIN,

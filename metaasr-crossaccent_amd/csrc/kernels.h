@@ -55,11 +55,15 @@ inline GemmArgs gemm_args() { GemmArgs g{}; g.alpha = 1.f; g.mask_scale = 1.f; r
 // activations NHWC bf16: [B][H][W][C]; x input fp32 [B][H][W] (C=1)
 // relu_bits (optional): [B][H][W] 64-bit words, bit c = (out[..][c] > 0) -- ConvArgs::mask_bits of the next conv's fused dgrad
 int mk_conv1_fwd(const float* x, const float* w /*[64][9]*/, const float* bias, bf16* out, int B, int H, int W, hipStream_t s, unsigned long long* relu_bits = nullptr);
-int mk_conv1_wgrad(const float* x, const bf16* dy, float* dw /*[64][9]*/, float* db, float* slab, int B, int H, int W, hipStream_t s);
 long mk_conv1_wgrad_slab_floats(int B, int H, int W);
 // implicit-GEMM 3x3 pad 1: out[p][co] = epi( sum_{tap,ci} in[p+off(tap)][ci] * wk[co][tap*CIN+ci] )
 struct ConvArgs {
     const bf16* in; const bf16* wk; const float* bias; int relu;
+    // the input map given as a 2x2 max-pool (+ ReLU) backward that is never materialised: in_pooled [B][H/2][W/2][CIN] (the pooled gradient)
+    // under the codes in_idx (ConvArgs::pool_idx of the forward launch that pooled).  `in` is then null.  Honoured by the two dgrad launches
+    // that sit behind a pool: 64 <- 64 with the fused conv1 weight gradient (x1) and 128 <- 128 with mask_bits; their patch producers expand
+    // the 2 x 2 windows while staging (a quarter of the gradient bytes + one code byte per pooled element instead of the map)
+    const bf16* in_pooled; const uint8_t* in_idx;
     const bf16* mask;             // optional ReLU mask source (same shape as out): out = mask>0 ? v : 0
     // the same mask as one 64-bit word per pixel [B][H][W] (bit c = mask[..][c] > 0, written by mk_conv1_fwd): what the
     // fused-conv1-wgrad dgrad reads instead of the map (16 x 16 tiles)
@@ -73,7 +77,6 @@ struct ConvArgs {
     // epilogue; `out` is then never written, w1_slab receives 640 partial sums per workgroup (mk_conv1_wgrad_fused_reduce)
     const float* x1; float* w1_slab;
     unsigned* sched;              // streaming kernel: 2 zero-initialised counters owned by the calling stream (null: a process-wide pair)
-    long* prof;                   // optional phase-timing output, 6 cycle counts per workgroup (see conv3x3_patch_kernel)
     bf16* pool_out;               // optional: MaxPool2d(2,2) (floor) of the ReLU'd output, [B][H/2][W/2][COUT], written by the same launch
     // optional, with pool_out: one byte per pooled element = window position (0..3, row-major scan) of its FIRST maximum, 4 where
     // that maximum is <= 0 (nothing passes the ReLU): all the pool + ReLU backward needs of the full-resolution map
@@ -81,7 +84,6 @@ struct ConvArgs {
     int out_optional;             // the caller does not need `out`: a launch that pools in its epilogue may skip storing it
 };
 int mk_conv3x3(const ConvArgs& a, hipStream_t s);
-bool mk_conv3x3_mask_bits_used(int W);      // does the masked 128 <- 128 dgrad at this map width take mask_bits (else: do not ask for out_sign_bits)
 long mk_conv1_wgrad_fused_slab_floats(int B, int H, int W);
 int mk_conv1_wgrad_fused_reduce(float* slab, int B, int H, int W, float* dw, float* db, hipStream_t s);
 // wgrad: dw[co][ci][3][3] (+ db[co]) from in (NHWC, CIN) and dy (NHWC, COUT)

@@ -401,10 +401,12 @@ class FOMetaASRInterface(PretrainInterface):
             self._drain_stats()
             self.save_per_steps(gather=False)
             self.dashboard.set_status('pretrained(SIGINT)')
+            self.sharder.close()
         else:
             self._drain_stats()
             logger.notice("Pretraining completed")
             self.dashboard.set_status('pretrained')
+            self.sharder.close()
 
     def _partial_meta_update(self, engine=None):
         """_updates[n] += p.grad for every parameter (:180-198) == one flat axpy.  With several ranks the freshly

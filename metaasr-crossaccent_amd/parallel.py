@@ -26,12 +26,15 @@ class TaskSharder:
         self.collective = (world > 1) if collective is None else bool(collective)
         self._side = None
         self._pending = []
-        # the exchange itself goes through the C ABI (include/masr.h masr_allreduce: librccl bound directly, our own side stream and
-        # event ordering, clip-scale pipelined with the collective) whenever the ranks sit on GPUs with the RCCL backend;
-        # torch.distributed then only carries the control plane (the communicator id, barriers, gathered eval numbers) and stays
-        # the transport of the gloo rehearsals.  MASR_NO_NATIVE_ALLREDUCE=1: ProcessGroupNCCL's all_reduce instead (A/B).
-        self.native = self.collective and backend == "nccl" and os.environ.get("MASR_NO_NATIVE_ALLREDUCE") != "1"
+        # Transport of the exchange.  Default: ProcessGroupNCCL's all_reduce (= RCCL) on a side stream.  OPT-IN (MASR_NATIVE_ALLREDUCE=1):
+        # the C ABI's own exchange (include/masr.h masr_allreduce: librccl bound directly, our own side stream and event ordering,
+        # clip-scale pipelined with the collective); torch.distributed then only carries the control plane (the communicator id,
+        # barriers, gathered eval numbers).  It stays opt-in until a run on two or more physical GPUs has shown its meta weights
+        # bit-equal to the default transport's: so far it has only ever run with one rank (tests/test_hip_rccl_world1.py).
+        self.native = self.collective and backend == "nccl" and os.environ.get("MASR_NATIVE_ALLREDUCE") == "1"
+        self.transport_note = ""                                 # why the transport is what it is (bench line: meta_step.transport)
         self.nchunks = int(os.environ.get("MASR_ALLREDUCE_CHUNKS", "4"))
+        self.timeout_s = float(os.environ.get("MASR_ALLREDUCE_TIMEOUT_S", "300"))
         self._comm = None
         self._native_issued = False
 
@@ -116,15 +119,34 @@ class TaskSharder:
                 import warnings
                 warnings.warn(f"masr_allreduce_init failed on some rank ({err!r}): the meta-gradient goes through ProcessGroupNCCL instead")
                 self.native = False
+                self.transport_note = f"native init failed ({err})"
                 return None
             self._comm = comm
             self._L = L
         return self._comm
 
+    @property
+    def transport(self):
+        """what carries the meta-gradient: 'none' (one rank, no collective), 'native' (masr_allreduce), 'pg_nccl', 'pg_gloo'"""
+        if not self.collective:
+            return "none"
+        return "native" if self.native else f"pg_{self.backend}"
+
+    def watchdog(self):
+        """host-side health check of the native exchange, called where a new exchange is about to be issued: RCCL's asynchronous error
+        state, and a bounded wait for the PREVIOUS exchange (long complete in a healthy run, so this costs nothing; a collective that
+        never completes would otherwise hang the job silently -- the waits of wait_all are device-side).  Raises: the caller lets the
+        exception end the process, so the launcher tears the other ranks down."""
+        if self._comm is not None:
+            from . import _cabi
+            _cabi.check(self._L.masr_allreduce_check(self._comm, int(self.timeout_s * 1000)), "masr_allreduce_check")
+
     def close(self):
+        """end of train() (normal or SIGINT): drain and destroy the native communicator"""
         if self._comm is not None:
             self._L.masr_allreduce_destroy(self._comm)
             self._comm = None
+            self._native_issued = False
 
     def reduce_async(self, buf, side_stream=True, clip=None):
         """all-reduce(sum) `buf` in place, overlapped with whatever the caller enqueues next on the main stream.
@@ -138,6 +160,8 @@ class TaskSharder:
         comm = self._native_comm(buf.device) if self.native and buf.device.type == "cuda" else None
         if comm is not None:
             from . import _cabi
+            if not self._native_issued:                          # first exchange of a meta-step: the previous step's must be done by now
+                self.watchdog()
             norm, max_norm = clip if clip is not None else (None, 0.0)
             _cabi.check(self._L.masr_allreduce(comm, buf.data_ptr(), buf.numel(), norm, max_norm, self.nchunks,
                                                torch.cuda.current_stream(buf.device).cuda_stream), "masr_allreduce")

@@ -19,7 +19,7 @@ def main():
     os.environ["MASR_FORCE_COLLECTIVE"] = "1"
     TaskSharder.init_process_group()
     assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
-    native = os.environ.get("MASR_NO_NATIVE_ALLREDUCE") != "1"
+    native = os.environ.get("MASR_NATIVE_ALLREDUCE") == "1"
     sh = TaskSharder.from_env()
     assert sh.collective and sh.world == 1 and sh.backend == "nccl" and sh.native == native
     dev = torch.device("cuda:0")
@@ -72,6 +72,13 @@ def main():
         # bad arguments are refused with a message, nothing is launched
         assert L.masr_allreduce(sh._comm, None, 10, None, 0.0, 1, None) != 0 and b"masr_allreduce" in L.masr_last_error()
         assert not L.masr_allreduce_init(3, 2, b"x" * 128) and b"masr_allreduce_init" in L.masr_last_error()
+        # the host-side health check: nothing pending -> 0 at once; an exchange in flight -> 1 (one poll) and 0 within the time limit
+        assert sh.transport == "native" and L.masr_allreduce_check(sh._comm, 0) == 0
+        big = torch.ones(n, device=dev)
+        sh.reduce_async(big); sh.wait_all()
+        assert L.masr_allreduce_check(sh._comm, 0) in (0, 1) and L.masr_allreduce_check(sh._comm, 60000) == 0
+        sh.watchdog()
+        assert L.masr_allreduce_check(None, 0) != 0
         sh.close()
         assert sh._comm is None
     t = sh.all_reduce_scalar_sum(3.5)

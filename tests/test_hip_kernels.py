@@ -276,6 +276,68 @@ def test_conv3x3_wgrad_from_pooled_gradient(L, B_, H, W, C):
     assert float(dw1.abs().max()) > 0
 
 
+@pytest.mark.parametrize("B_,H,W", [(2, 40, 20), (1, 33, 41), (3, 250, 40), (2, 70, 24), (1, 21, 7), (2, 64, 8)])
+def test_conv3x3_dgrad_from_pooled_gradient(L, B_, H, W):
+    """ConvArgs::in_pooled: the masked 128 <- 128 dgrad behind the second MaxPool2d (mono_transformer_torch.py:57-58) builds its patches from
+    the pooled gradient + pool codes (three producer waves expand the 2 x 2 windows while staging).  Same bits as the launch that reads the
+    map masr_test_maxpool_idx_bwd writes; odd H / W: the cropped last row / column carries no gradient."""
+    g = torch.Generator(device="cuda").manual_seed(7 * H + W)
+    H2, W2 = H // 2, W // 2
+    dyp = torch.randn(B_, H2, W2, 128, device="cuda", generator=g).bfloat16()
+    codes = torch.randint(0, 5, (B_, H2, W2, 128), device="cuda", generator=g).to(torch.uint8)
+    dy = torch.full((B_, H, W, 128), 9.0, device="cuda").bfloat16()
+    _cabi.check(L.masr_test_maxpool_idx_bwd(P(codes), P(dyp), P(dy), B_, H, W, 128, S()))
+    mask = torch.randn(B_, H, W, 128, device="cuda", generator=g).bfloat16()
+    words = _sign_words(mask).to(torch.int32)
+    wd = (torch.randn(128, 128, 3, 3, device="cuda", generator=g) * 0.05).bfloat16()
+    wdk = wd.permute(0, 2, 3, 1).reshape(128, 9 * 128).contiguous()
+    o1 = torch.full((B_, H, W, 128), 7.0, device="cuda").bfloat16()
+    o2 = torch.full((B_, H, W, 128), 5.0, device="cuda").bfloat16()
+    _cabi.check(L.masr_test_conv3x3_dgrad_pooled(P(dy), None, None, P(wdk), P(words), P(o1), B_, H, W, S()))
+    _cabi.check(L.masr_test_conv3x3_dgrad_pooled(None, P(dyp), P(codes), P(wdk), P(words), P(o2), B_, H, W, S()))
+    assert torch.equal(o1, o2)
+    conv = torch.nn.functional.conv2d(dy.float().permute(0, 3, 1, 2), wd.float(), None, padding=1).permute(0, 2, 3, 1)
+    torch.testing.assert_close(o2.float(), torch.where(mask.float() > 0, conv, torch.zeros_like(conv)), rtol=1e-2, atol=2e-2)
+    assert float(o2.float().abs().max()) > 0
+    # a second launch on the same stream re-arms the tile counter correctly (the producers' first tile is static, the rest counted)
+    o3 = torch.full_like(o2, 3.0)
+    _cabi.check(L.masr_test_conv3x3_dgrad_pooled(None, P(dyp), P(codes), P(wdk), P(words), P(o3), B_, H, W, S()))
+    assert torch.equal(o3, o2)
+
+
+@pytest.mark.parametrize("B_,H,W", [(2, 38, 80), (1, 45, 83), (2, 301, 80), (1, 16, 16), (3, 17, 35), (16, 100, 80)])
+def test_conv1_wgrad_fused_from_pooled_gradient(L, B_, H, W):
+    """The 64 <- 64 dgrad behind the first MaxPool2d with conv1's weight gradient fused into its epilogue (mono_transformer_torch.py:49-52): fed
+    the pooled gradient + codes (four producer waves) it returns the bits of the launch fed the expanded map; both agree with the plain
+    formula dW1[c][tap] = sum_p mask(p, c) (dy * W2)(p, c) x(p + tap)."""
+    g = torch.Generator(device="cuda").manual_seed(3 * H + W)
+    H2, W2 = H // 2, W // 2
+    dyp = torch.randn(B_, H2, W2, 64, device="cuda", generator=g).bfloat16()
+    codes = torch.randint(0, 5, (B_, H2, W2, 64), device="cuda", generator=g).to(torch.uint8)
+    dy = torch.full((B_, H, W, 64), 9.0, device="cuda").bfloat16()
+    _cabi.check(L.masr_test_maxpool_idx_bwd(P(codes), P(dyp), P(dy), B_, H, W, 64, S()))
+    x1 = torch.randn(B_, H, W, device="cuda", generator=g)
+    keep = torch.rand(B_, H, W, 64, device="cuda", generator=g) > 0.4
+    words = (keep.to(torch.int64) << torch.arange(64, device="cuda").view(1, 1, 1, 64)).sum(-1)          # bit c = channel c passed conv1's ReLU
+    wd = (torch.randn(64, 64, 3, 3, device="cuda", generator=g) * 0.05).bfloat16()
+    wdk = wd.permute(0, 2, 3, 1).reshape(64, 9 * 64).contiguous()
+    n = int(L.masr_test_conv1_wgrad_fused_slab_floats(B_, H, W))
+    slab = torch.zeros(n, device="cuda")
+    dwa = torch.zeros(64, 9, device="cuda"); dba = torch.zeros(64, device="cuda")
+    dwb = torch.full((64, 9), 3.0, device="cuda"); dbb = torch.full((64,), 3.0, device="cuda")
+    _cabi.check(L.masr_test_conv1_wgrad_fused(P(dy), None, None, P(wdk), P(words), P(x1), P(slab), n, P(dwa), P(dba), B_, H, W, S()))
+    slab.zero_()
+    _cabi.check(L.masr_test_conv1_wgrad_fused(None, P(dyp), P(codes), P(wdk), P(words), P(x1), P(slab), n, P(dwb), P(dbb), B_, H, W, S()))
+    assert torch.equal(dwa, dwb) and torch.equal(dba, dbb)
+    da1 = torch.nn.functional.conv2d(dy.float().permute(0, 3, 1, 2), wd.float(), None, padding=1) * keep.permute(0, 3, 1, 2)      # [B,64,H,W]
+    da1 = da1.bfloat16().float()
+    xp = torch.nn.functional.pad(x1.bfloat16().float(), (1, 1, 1, 1))
+    ref = torch.stack([(da1 * xp[:, None, ky:ky + H, kx:kx + W]).sum((0, 2, 3)) for ky in range(3) for kx in range(3)], dim=1)
+    scale = float(ref.abs().max())
+    assert float((dwb - ref).abs().max()) < 2e-2 * scale + 1e-2
+    torch.testing.assert_close(dbb, da1.sum((0, 2, 3)), rtol=2e-2, atol=2e-2 * float(da1.sum((0, 2, 3)).abs().max()) + 1e-2)
+
+
 def _attn_ref(q, k, v, klens, causal, dout):
     B_, Tq, H, hd = q.shape
     Tk = k.shape[1]

@@ -38,8 +38,8 @@ def _env(**kw):
 @pytest.mark.parametrize("native", [True, False])
 def test_tasksharder_exchange_through_rccl_with_one_rank(tmp_path, native):
     """native: the exchange through the C ABI (masr_allreduce: librccl bound directly, own side stream, clip pipelined with the
-    collective); otherwise ProcessGroupNCCL's all_reduce (MASR_NO_NATIVE_ALLREDUCE=1, the A/B transport)"""
-    env = _env() if native else _env(MASR_NO_NATIVE_ALLREDUCE="1")
+    collective; opt-in: MASR_NATIVE_ALLREDUCE=1); otherwise ProcessGroupNCCL's all_reduce, the default transport"""
+    env = _env(MASR_NATIVE_ALLREDUCE="1") if native else _env()
     r = subprocess.run([sys.executable, str(ROOT / "tests" / "_rccl_world1_worker.py")], cwd=tmp_path, env=env, capture_output=True, text=True,
                        timeout=420)
     assert r.returncode == 0 and "rccl-world1-ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
@@ -53,7 +53,7 @@ def test_pretrain_cli_meta_steps_through_rccl_with_one_rank(golden_dir, tmp_path
     extra = ["--tasks_per_gpu", str(tasks_per_gpu)]
     plain = subprocess.run([sys.executable, worker, str(tmp_path), "plain"] + extra, cwd=tmp_path, env=_env(), capture_output=True, text=True, timeout=420)
     assert plain.returncode == 0, plain.stderr[-3000:]
-    rccl = subprocess.run([sys.executable, worker, str(tmp_path), "rccl"] + extra, cwd=tmp_path, env=_env(MASR_FORCE_COLLECTIVE="1"),
+    rccl = subprocess.run([sys.executable, worker, str(tmp_path), "rccl"] + extra, cwd=tmp_path, env=_env(MASR_FORCE_COLLECTIVE="1", MASR_NATIVE_ALLREDUCE="1"),
                           capture_output=True, text=True, timeout=420)
     assert rccl.returncode == 0, rccl.stderr[-3000:]
     a, b = torch.load(tmp_path / "plain_r0.pt"), torch.load(tmp_path / "rccl_r0.pt")
@@ -63,7 +63,7 @@ def test_pretrain_cli_meta_steps_through_rccl_with_one_rank(golden_dir, tmp_path
         # the communicator cannot be made (forced): every rank agrees to fall back to ProcessGroupNCCL, the clip that was to ride on
         # the wire runs as one pass first -- same meta weights, bit for bit
         fb = subprocess.run([sys.executable, worker, str(tmp_path), "fallback"] + extra, cwd=tmp_path,
-                            env=_env(MASR_FORCE_COLLECTIVE="1", MASR_TEST_FAIL_ALLREDUCE_INIT="1"), capture_output=True, text=True, timeout=420)
+                            env=_env(MASR_FORCE_COLLECTIVE="1", MASR_NATIVE_ALLREDUCE="1", MASR_TEST_FAIL_ALLREDUCE_INIT="1"), capture_output=True, text=True, timeout=420)
         assert fb.returncode == 0, fb.stderr[-3000:]
         c = torch.load(tmp_path / "fallback_r0.pt")
         assert c["collective"] and not c["native"] and "ProcessGroupNCCL instead" in fb.stderr

@@ -14,12 +14,12 @@ from collections import defaultdict
 from pathlib import Path
 
 SLOTS = {   # bench.py roofline slot -> substring of the kernel name
-    "conv2_fwd": "conv3x3_resw_kernel<16, 16, false>",
+    "conv2_fwd": "conv3x3_resw_kernel<16, 16",
     "conv3_fwd": "conv3x3_stream_kernel<64, 128, 16, 8, 0, false>",
     "conv4_fwd": "conv3x3_stream_kernel<128, 128, 32, 8, 0, false>",
     "conv2_dgrad": "conv3x3_resw_w1x_kernel",
     "conv3_dgrad": "conv3x3_stream_kernel<128, 64, 32, 8, 0, false>",
-    "conv4_dgrad": "conv3x3_stream_kernel<128, 128, 32, 8, 2, false>",
+    "conv4_dgrad": "conv3x3_stream_kernel<128, 128, 32, 8, 2, true>",
     "conv2_wgrad": "conv3x3_wgrad2_kernel<64, 64,",
     "conv3_wgrad": "conv3x3_wgrad2_kernel<64, 128,",
     "conv4_wgrad": "conv3x3_wgrad2_kernel<128, 128,",
