@@ -67,7 +67,7 @@ void masr_dropout_state(masr_model* m, uint64_t state[2], int set);
  * are left in `grads`.  olens is NOT mutated (quirk Q6 is reproduced by the Python mirror). */
 int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const int64_t* ys_flat,
                    const int64_t* olens, int B, int T, int flags, void* stream);
-/* Opt-in (or MASR_STEP_GRAPH=1): a batch shape (B, T, L, flags, xs pointer) that repeats on a non-null stream is captured into
+/* Opt-in: a batch shape (B, T, L, flags, xs pointer) that repeats on a non-null stream is captured into
  * a hipGraph on its second consecutive occurrence and replayed afterwards (one launch instead of ~150; tokens, lengths, dropout
  * seed and 1/n_total reach the kernels through the per-step upload, so replays are bit-identical to direct launches).  It cuts
  * the host's enqueue time 6x and leaves the step time unchanged -- the step is GPU-bound -- hence off by default.
@@ -77,13 +77,15 @@ void masr_set_step_graphs(masr_model* m, int on);
  * that consumes their bf16 output (forward: the next projection; backward: the next dgrad) normalises the rows in its prologue.  Same
  * arithmetic, hence the same results (the LayerNorm weight gradients are folded over 64-row instead of 4-row partials: fp32 rounding).
  * Default OFF -- it measured slower (every column-tile workgroup of a row block repeats the row work and they all hit the same L2
- * lines at once: DESIGN 6.0); MASR_LN_FUSION=1 in the environment or this switch turn it on for A/B runs and the parity test. */
+ * lines at once: DESIGN); this switch turns it on for A/B runs and the parity test. */
 void masr_set_ln_fusion(masr_model* m, int on);
 /* masr_clip_sgd_step's update applied INSIDE the shadow-refresh launch (one pass over the parameters: p and g in, p and every bf16
  * operand layout out) instead of an update pass followed by the refresh.  Same arithmetic, same bits.  Default OFF -- it measured slower
- * (tile-shaped fp32 write-back against a flat stream: DESIGN 6.00); MASR_FUSED_SGD=1 in the environment or this switch turn it on for A/B
- * runs and the parity test. */
+ * (tile-shaped fp32 write-back against a flat stream: DESIGN); this switch turns it on for A/B runs and the parity test. */
 void masr_set_fused_sgd(masr_model* m, int on);
+/* The Linear weight gradients of a step are ONE launch (the decoder-row tiles fill the CUs the encoder-row tiles leave idle); on: two
+ * launches, encoder rows then decoder rows (A/B; identical bits -- each element of dW is reduced by one workgroup either way). */
+void masr_set_split_wgrad_launches(masr_model* m, int on);
 void masr_step_counters(const masr_model* m, int64_t out[3]);
 /* out[0]=loss, out[1]=n_correct, out[2]=n_total, out[3]=last grad norm.  Synchronises the stream. */
 int masr_read_stats(masr_model* m, float out[4], void* stream);
@@ -356,12 +358,14 @@ int masr_test_conv1_wgrad_fused(const uint16_t* dy, const uint16_t* dy_pooled, c
 int masr_test_conv3x3_wgrad(const uint16_t* in, const uint16_t* dy, float* dw, float* slab, int64_t slab_floats,
                             int B, int H, int W, int CIN, int COUT, void* stream);
 int64_t masr_test_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT);
-/* Linear weight gradients as a grouped launch (mk_gemm_wgrad_grouped): dW[N][K] = dy[rows][N]^T x[rows][K], db[N] = column sums of dy (or null); a second
- * member with the same operands when dW2 is given; tile = 64 or 128 */
+/* Linear weight gradients as a grouped launch (mk_gemm_wgrad_grouped: one grid of 256 x 256 tiles): dW[N][K] = dy[rows][N]^T x[rows][K], db[N] =
+ * column sums of dy (or null); a second member with the same operands when dW2 is given.
+ * _n: `members` members over the same operands (member i writes dW + i * member_stride); first_members > 0: the two-segment tile list of the
+ * engine's merged launch -- members [0, first_members) reduce over `rows` rows and are dispatched first, the others over the first rows_rest. */
 int masr_test_wgrad_grouped(const uint16_t* dy, int64_t lddy, const uint16_t* x, int64_t ldx, float* dW, float* db, float* dW2, float* db2,
-                            int rows, int N, int K, int tile, void* stream);
+                            int rows, int N, int K, void* stream);
 int masr_test_wgrad_grouped_n(const uint16_t* dy, int64_t lddy, const uint16_t* x, int64_t ldx, float* dW, int64_t member_stride, int members,
-                              int rows, int N, int K, int tile, void* stream);
+                              int first_members, int rows, int rows_rest, int N, int K, void* stream);
 /* the same with dy given as the pooled gradient [B][H/2][W/2][COUT] + the pool codes of masr_test_conv3x3_pool_idx (the weight-gradient kernel
  * expands the 2x2 max-pool + ReLU backward while staging; 64->64 and 128->128 channels); db may be null */
 int masr_test_conv3x3_wgrad_pooled(const uint16_t* in, const uint16_t* dy_pooled, const uint8_t* pool_idx, float* dw, float* db, float* slab,

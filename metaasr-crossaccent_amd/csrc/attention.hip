@@ -905,12 +905,9 @@ __global__ __launch_bounds__(64 * NW, (NW > 4 || RQ > 1 || RK > 1) ? 2 : 3) void
 
 template <int HD>
 int launch_fwd(const AttnArgs& a, hipStream_t s) {
-    static const bool ring = !getenv("MASR_ATTN_NO_RING");
-    static const int long_min = getenv("MASR_ATTN_LONG_MIN") ? atoi(getenv("MASR_ATTN_LONG_MIN")) : 65;   // sequences from this length on: 128-row workgroups
-    static const int long_rt = getenv("MASR_ATTN_LONG_RT2") ? 2 : 1;                                       // (A/B: 4 waves x 2 row tiles instead of 8 x 1)
-    if (HD == 64 && ring) {
+    constexpr int long_min = 65;                             // sequences from this length on: 128-row workgroups (8 waves x 1 row tile)
+    if (HD == 64) {
         if (a.Tq < long_min) hipLaunchKernelGGL((attn_fwd_ring_kernel<4, 1>), dim3((a.Tq + 63) / 64, a.H, a.B), dim3(256), 0, s, a);
-        else if (long_rt == 2) hipLaunchKernelGGL((attn_fwd_ring_kernel<4, 2>), dim3((a.Tq + 127) / 128, a.H, a.B), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((attn_fwd_ring_kernel<8, 1>), dim3((a.Tq + 127) / 128, a.H, a.B), dim3(512), 0, s, a);
     } else {
         hipLaunchKernelGGL(attn_fwd_kernel<HD>, dim3((a.Tq + BLK - 1) / BLK, a.H, a.B), dim3(256), 0, s, a);
@@ -919,18 +916,13 @@ int launch_fwd(const AttnArgs& a, hipStream_t s) {
 }
 template <int HD>
 int launch_bwd(const AttnArgs& a, hipStream_t s) {
-    static const bool ring = !getenv("MASR_ATTN_NO_RING");
-    static const int long_min = getenv("MASR_ATTN_LONG_MIN") ? atoi(getenv("MASR_ATTN_LONG_MIN")) : 65;
-    static const bool w8 = getenv("MASR_ATTN_BWD_W8") != nullptr;                                          // (A/B: 8 waves x 1 row tile on both sides)
-    if (HD == 64 && ring) {
+    constexpr int long_min = 65;
+    if (HD == 64) {
         // the dQ and the dK/dV workgroups share one grid, hence one workgroup size.  Measured (16 x 8 heads, fwd + bwd, us): 250 x 250:
         // 4 waves x 1 tile 52.9, 8 x 1 45.5, 4 x 2 44.3; 37 x 250: 24.7, 29.0 (a 128-row dQ workgroup holds 37 rows), 23.5 with
         // two tiles on the key side only
         const bool lq = a.Tq >= long_min, lk = a.Tk >= long_min;
-        if (w8 && (lq || lk)) {
-            const int nqb = (a.Tq + 127) / 128, nkb = (a.Tk + 127) / 128;
-            hipLaunchKernelGGL((attn_bwd_ring_kernel<8, 1, 1>), dim3(nqb + nkb, a.H, a.B), dim3(512), 0, s, a, nqb);
-        } else {
+        {
             const int rq = lq ? 2 : 1, rk = lk ? 2 : 1;
             const int nqb = (a.Tq + 64 * rq - 1) / (64 * rq), nkb = (a.Tk + 64 * rk - 1) / (64 * rk);
             const dim3 grid(nqb + nkb, a.H, a.B);

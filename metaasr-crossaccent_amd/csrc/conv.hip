@@ -12,6 +12,7 @@
 // (transposing LDS reads), split over pixel ranges with a deterministic slab reduce.
 #include "common.h"
 #include "kernels.h"
+#include "folds.h"
 #include <cstdlib>
 
 namespace {
@@ -186,29 +187,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
 constexpr int C1_RSPLIT = 16;
 __global__ __launch_bounds__(256) void conv1_wgrad_reduce(const float* __restrict__ slab, int nblocks, float* __restrict__ dw,
                                                           float* __restrict__ db, float* __restrict__ part_out) {
-    __shared__ float part[16][17];
-    const int o = threadIdx.x & 15, l = threadIdx.x >> 4, i = blockIdx.x * 16 + o;
-    const int rows = (nblocks + gridDim.y - 1) / gridDim.y;
-    const int b0 = blockIdx.y * rows, b1 = b0 + rows < nblocks ? b0 + rows : nblocks;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = b0 + l;
-    for (; b + 48 < b1; b += 64) {                          // four independent chains keep 4 loads in flight per thread
-        s0 += slab[(long)b * 640 + i]; s1 += slab[(long)(b + 16) * 640 + i];
-        s2 += slab[(long)(b + 32) * 640 + i]; s3 += slab[(long)(b + 48) * 640 + i];
-    }
-    for (; b < b1; b += 16) s0 += slab[(long)b * 640 + i];
-    part[l][o] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (threadIdx.x < 16) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s += part[k][threadIdx.x];
-        if (part_out) part_out[blockIdx.y * 640 + i] = s;
-        else {
-            const int co = i / 10, k = i % 10;
-            if (k < 9) dw[co * 9 + k] = s; else db[co] = s;
-        }
-    }
+    conv1_wgrad_reduce_body(slab, nblocks, dw, db, part_out, blockIdx.x, blockIdx.y, gridDim.y);
 }
 // slab rows [nblocks, nblocks + C1_RSPLIT) hold the first pass's partials
 static void launch_conv1_reduce(float* slab, int nb, float* dw, float* db, hipStream_t s) {
@@ -1881,31 +1860,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad2_kernel(ConvWgradArgs a, in
 // partial sums per thread (fixed order -> deterministic); the trailing COUT entries are the bias gradient
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce(const float* __restrict__ slab, int nsplit, float* __restrict__ dw,
                                                             float* __restrict__ db, int CIN, int COUT) {
-    const int KTOT = 9 * CIN, NW = COUT * KTOT;
-    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + cl;                       // co*KTOT + tap*CIN + ci, then NW + co for the bias
-    __shared__ float red[4][64];
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (i < NW + COUT) {
-        const bool is_b = i >= NW;
-        const float* p = is_b ? slab + (long)nsplit * NW + (i - NW) : slab + i;
-        const long stride = is_b ? COUT : NW;
-        int k = part;
-        for (; k + 12 < nsplit; k += 16) {
-            s0 += p[(long)k * stride]; s1 += p[(long)(k + 4) * stride]; s2 += p[(long)(k + 8) * stride]; s3 += p[(long)(k + 12) * stride];
-        }
-        for (; k < nsplit; k += 4) s0 += p[(long)k * stride];
-    }
-    red[part][cl] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (part == 0 && i < NW + COUT) {
-        const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
-        if (i >= NW) { if (db) db[i - NW] = t; }
-        else {
-            const int co = i / KTOT, rem = i % KTOT, tap = rem / CIN, ci = rem % CIN;
-            dw[((long)co * CIN + ci) * 9 + tap] = t;
-        }
-    }
+    conv3x3_wgrad_reduce_body(slab, nsplit, dw, db, CIN, COUT, blockIdx.x);
 }
 
 // ------------------------------------------------------------------ max-pool 2x2 (floor) NHWC
@@ -2210,6 +2165,11 @@ long mk_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT) {
     (void)B; (void)H; (void)W;
     return (long)wgrad2_nwg(CIN, COUT) * (COUT * 9 * CIN + COUT);
 }
+int mk_conv3x3_wgrad_nsplit(int B, int H, int W, int CIN, int COUT) {
+    const int ntiles = ((W + 15) / 16) * ((H + 7) / 8) * B, nwg = wgrad2_nwg(CIN, COUT);
+    return nwg < ntiles ? nwg : ntiles;
+}
+int mk_conv1_wgrad_fused_rows(int B, int H, int W) { return resw_w1_rows(B, H, W); }
 int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s, int phase) {
     // phase 0: both launches; 1: the partial-slab kernel only; 2: the slab reduce only (the engine times them in separate slots)
     const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 7) / 8, ntiles = tiles_x * tiles_y * a.B;

@@ -67,19 +67,14 @@ struct Acts {
     uint32_t site_v2e, site_emb;
     // backward scratch
     float *ge_a, *ge_b, *gd_a, *gd_b, *dmem32, *v2e_g32;
-    bf16 *ge16, *gqkv_e, *gf_e, *gao_e, *gao_d, *gkv_all, *dp2, *da3, *dp1;      // (d(a4), d(a2) exist only as pooled gradient + codes; d(a1) never)
+    bf16 *ge16, *gao_e, *gao_d, *gkv_all, *dp2, *da3, *dp1;      // (d(a4), d(a2) exist only as pooled gradient + codes; d(a1) never)
     float *delta_e, *delta_d;
     std::vector<DecGrad> dgr;
     std::vector<EncGrad> egr;
     float* slab; int64_t slab_floats;
+    float *cw_slab[3], *c1_slab;                           // partial slabs of the conv weight gradients: each its own, all folded by ONE launch at the end of the pass
     float* ln_slab; int64_t ln_slab_floats;                // one region per LayerNorm backward (grouped reduce)
-    float* wg_slab;                                        // split-K partials: (WG_SPLIT-1) x nparams
 };
-constexpr int WG_SPLIT_MAX = 4;
-// split-K factor of the encoder-row weight gradients on the ungrouped path (MASR_NO_GROUPED_ENC_WGRAD=1; the default grouped launch is
-// unsplit): 4 for every model, whatever the number of task slots (see masr_set_concurrency).  Measured when it followed the slot count,
-// 4 tasks / single task utt/s: split 4: 8 440 / 5 485, split 2: 8 530 / 5 435, none: 8 475 / 5 380.  MASR_WG_SPLIT = 1..4 overrides it.
-static const int WG_SPLIT_ENV = [] { const char* e = getenv("MASR_WG_SPLIT"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > WG_SPLIT_MAX ? WG_SPLIT_MAX : v); }();
 
 }  // namespace
 
@@ -96,16 +91,15 @@ struct masr_model {
     // with N = ND*2E (forward), its gradient comes back through one GEMM with K = ND*2E and the ND weight gradients are one
     // reduction-major GEMM with M = ND*2E (segmented output rows).  kv_k16 [ND*2E][E], kvT [E][ND*2E], kv_bias [ND*2E].
     bf16 *kv_k16 = nullptr, *kvT = nullptr; float* kv_bias = nullptr; int NK = 0;
-    long* d_ranges = nullptr; int nranges = 0;            // split-K combine table: (offset, length) of every Linear weight / bias
     std::vector<ShadowJobs> shadows;                       // job list(s) of the operand-shadow refresh: one launch per <= SHADOW_JOBS_MAX jobs (hkust: one)
     // masr_clip_sgd_step CAN apply its update inside that launch (mk_sgd_shadows: p and g in, p and every bf16 layout out, 28 instead
     // of 32 bytes per parameter; the parameters no shadow job reads are these chunks).  Same bits (tests/test_hip_engine.py), but SLOWER:
     // 165 us against 75 + 57 for the flat update pass and the refresh (hkust, momentum buffer read and written): the tiles' 256-byte
     // row segments at arbitrary dword offsets make every fp32 write-back a partial-line store, where the flat pass streams whole lines
     // (and neither the instruction count -- 17 lanes per row, one load per array and pass -- nor the 4 B/param matter beside that).
-    // Default OFF; MASR_FUSED_SGD=1 / masr_set_fused_sgd for A/B runs and the parity test.
+    // Default OFF; masr_set_fused_sgd for A/B runs and the parity test.
     long* d_gaps = nullptr; int ngaps = 0; bool gaps_ok = false;     // gaps_ok: the gap list exists (masr_bind) -- without it the fused pass would skip the unshadowed parameters
-    bool fuse_sgd = getenv("MASR_FUSED_SGD") != nullptr && atoi(getenv("MASR_FUSED_SGD")) != 0;
+    bool fuse_sgd = false;
     float* stats = nullptr;                   // device [8]: loss, n_correct, n_total, grad_norm
     unsigned* conv_sched = nullptr;           // tile counters of the streaming conv kernel (this model's stream only)
     float* h_stats = nullptr;                 // pinned
@@ -115,20 +109,17 @@ struct masr_model {
     float* h_ring = nullptr; hipEvent_t ring_ev[RING]; bool ring_used[RING]; int64_t ring_next = 0;
     int* h_stage = nullptr; int64_t stage_ints = 0; int stage_slot = 0; hipEvent_t stage_ev[4];
     uint64_t seed = 0x1234; uint64_t step = 0;
-    int wg_split = WG_SPLIT_ENV ? WG_SPLIT_ENV : 4;       // split-K of the encoder-row weight gradients (masr_set_concurrency)
     Acts acts; bool have_acts = false;
     LnReduceGroup lng; int64_t ln_slab_used = 0;           // LayerNorm dgamma/dbeta partials, folded by one grouped launch
-    WgradGroup wg; bool wg_defer = false;                  // decoder-row weight gradients collected for one grouped launch
-    // ... and the encoder-row ones (reduction over B*T' rows): ONE grid of 128 x 128 tiles over all of them at the end of the backward
-    // pass instead of ten split-K launches of 64-192 workgroups each + a combine pass over the partial slabs
-    WgradGroup wge; bool wge_defer = false;
+    bool split_wgrad = false;                              // masr_set_split_wgrad_launches
+    WgradGroup wg, wge;                                    // decoder-row / encoder-row weight gradients collected for the grouped launch (lin_wgrad)
     // a LayerNorm (forward) / LayerNorm backward on few rows that has been ASKED for but not launched: the next GEMM that takes its bf16
     // output as the A operand computes it in its own prologue (kernels.h mk_gemm_lnfwd / mk_gemm_lnbwd); anything else flushes it first
     // OFF by default: measured SLOWER (round 4, rocprofv3, hkust decoder rows): the fused q-projection 17.9 us against 6.6 (GEMM) + 5.2
     // (LayerNorm), the fused FFN-1 34.5 us against 8 + 5 -- every one of the 8 .. 32 column-tile workgroups of a row block re-reads the
     // same 128 KB of fp32 rows at the same moment (the same L2 channels) and only then starts its k loop; single task 6 160 -> 5 420
-    // utt/s, four slots 9 160 -> 8 510.  Kept as an A/B switch with its parity test (MASR_LN_FUSION=1 / masr_set_ln_fusion).
-    bool ln_fusion = getenv("MASR_LN_FUSION") != nullptr && atoi(getenv("MASR_LN_FUSION")) != 0;
+    // utt/s, four slots 9 160 -> 8 510.  Kept as an A/B switch with its parity test (masr_set_ln_fusion).
+    bool ln_fusion = false;
     struct PendF { bool on = false; Norm n; const float* x; float* y32; bf16* y16; float* mean; float* rstd; int rows; } pend_f;
     struct PendB { bool on = false; Norm n; const float* dy; const float* x; const float* mean; const float* rstd; float* dx32; bf16* dx16;
                    uint32_t site; int rows; float* slab; int desc; } pend_b;
@@ -173,20 +164,6 @@ Attn add_attn(masr_model* m, const std::string& pre) {
     return a;
 }
 
-// split-K combine table: the Linear weight / bias ranges whose gradients have partial sums in the slab (encoder-row
-// reductions: encoder layers, cross-attention K/V projections), cut into chunks of <= SPLIT_CHUNK floats = one workgroup each
-constexpr long SPLIT_CHUNK = 2048;
-std::vector<long> split_chunks(const masr_model* m) {
-    std::vector<long> c;
-    auto add = [&](long off, long len) {
-        for (long o = 0; o < len; o += SPLIT_CHUNK) { c.push_back(off + o); c.push_back(len - o < SPLIT_CHUNK ? len - o : SPLIT_CHUNK); }
-    };
-    auto lin = [&](const Lin& l) { add(l.w, (long)l.N * l.K); add(l.b, l.N); };
-    for (auto& e : m->enc) { lin(e.sa.in); lin(e.sa.out); lin(e.l1); lin(e.l2); }
-    for (auto& d : m->dec) { add(d.ca.in.w + (long)m->E * m->E, 2L * m->E * m->E); add(d.ca.in.b + m->E, 2L * m->E); }
-    return c;
-}
-
 // ------------------------------------------------------------------ persistent region (shadows, stats)
 void plan_persistent(masr_model* m, Arena& ar) {
     for (int i = 1; i < 4; ++i) {
@@ -212,7 +189,6 @@ void plan_persistent(masr_model* m, Arena& ar) {
     m->kv_k16 = ar.get<bf16>((int64_t)m->NK * m->E); m->kvT = ar.get<bf16>((int64_t)m->E * m->NK); m->kv_bias = ar.get<float>(m->NK);
     m->stats = ar.get<float>(64);
     m->conv_sched = ar.get<unsigned>(64);
-    m->d_ranges = ar.get<long>((int64_t)split_chunks(m).size());
     m->d_gaps = ar.get<long>(2 * GAP_CHUNKS_MAX);
 }
 
@@ -263,22 +239,19 @@ void plan_acts(const masr_model* m, Arena& ar, Acts& a, int B, int T, int L, boo
     mx(mk_layernorm_bwd_slab_floats((int)(re > rd ? re : rd), E));
     mx(mk_colsum_slab_floats((int)P1, 64)); mx(mk_colsum_slab_floats((int)P2, 128));
     mx(mk_colsum_slab_floats((int)(re > rd ? re : rd), 3 * E > Fi ? 3 * E : Fi));
-    mx(mk_conv1_wgrad_fused_slab_floats(B, T, m->D));
-    mx(mk_conv3x3_wgrad_slab_floats(B, T, m->D, 64, 64));
-    mx(mk_conv3x3_wgrad_slab_floats(B, a.H2, a.W2, 64, 128));
-    mx(mk_conv3x3_wgrad_slab_floats(B, a.H2, a.W2, 128, 128));
     a.slab_floats = sl; a.slab = ar.get<float>(sl);
     if (train) {
         const int nln = 2 * m->NE + 1 + 3 * m->ND + 1;
         a.ln_slab_floats = 0;
         for (int i = 0; i < nln; ++i) a.ln_slab_floats += mk_layernorm_bwd_slab_floats((int)(i < 2 * m->NE + 1 ? re : rd), E);
         a.ln_slab = ar.get<float>(a.ln_slab_floats);
-        a.wg_slab = ar.get<float>((int64_t)(WG_SPLIT_MAX - 1) * m->nparams);
+        a.cw_slab[0] = ar.get<float>(mk_conv3x3_wgrad_slab_floats(B, T, m->D, 64, 64));
+        a.cw_slab[1] = ar.get<float>(mk_conv3x3_wgrad_slab_floats(B, a.H2, a.W2, 64, 128));
+        a.cw_slab[2] = ar.get<float>(mk_conv3x3_wgrad_slab_floats(B, a.H2, a.W2, 128, 128));
+        a.c1_slab = ar.get<float>(mk_conv1_wgrad_fused_slab_floats(B, T, m->D));
         a.ge_a = ar.get<float>(re * E); a.ge_b = ar.get<float>(re * E); a.gd_a = ar.get<float>(rd * E); a.gd_b = ar.get<float>(rd * E);
         a.dmem32 = ar.get<float>(re * E); a.v2e_g32 = ar.get<float>((int64_t)E * m->F);
         a.ge16 = ar.get<bf16>(re * E);
-        a.gqkv_e = ar.get<bf16>(re * 3 * E);
-        a.gf_e = ar.get<bf16>(re * Fi);
         a.gao_e = ar.get<bf16>(re * E); a.gao_d = ar.get<bf16>(rd * E);
         a.gkv_all = ar.get<bf16>(re * m->NK);
         a.delta_e = ar.get<float>((int64_t)B * H * a.Tp); a.delta_d = ar.get<float>((int64_t)B * H * L);
@@ -358,69 +331,39 @@ int gemm(Ctx& c, const GemmArgs& g) {
     return mk_gemm(h, c.s);
 }
 
-// weight/bias gradients of a Linear: dW[N][K] = dy^T x, db = colsum(dy)
-int lin_wgrad(Ctx& c, const bf16* dy, long lddy, const bf16* x, long ldx, int rows, int N, int K, float* dW, float* db, bool split = false,
-              int accumulate = 0) {
+// weight/bias gradients of a Linear: dW[N][K] = dy^T x, db = colsum(dy).  They feed nothing but the optimiser, so they are not launched one by
+// one: every layer keeps its own dY operand and ONE grid of 256 x 256 tiles (gemm.hip gemm_wgrad_grouped16_kernel) computes them all at the end
+// of the backward pass -- the encoder-row members (reduction over B*T' rows: `enc`) first, the decoder-row ones (B*L rows) filling the CUs
+// those leave idle.  A member that does not fit the descriptor list (very deep models) runs as a plain reduction-major GEMM at once.
+int lin_wgrad(Ctx& c, const bf16* dy, long lddy, const bf16* x, long ldx, int rows, int N, int K, float* dW, float* db, bool enc = false) {
     masr_model* m = c.m;
-    if (split && m->wge_defer && !accumulate && m->wge.n < WGRAD_GROUP_MAX) {      // encoder rows: joins the grouped launch of flush_enc_wgrads
-        WgradDesc& d = m->wge.p[m->wge.n++];
-        d.dy = dy; d.x = x; d.dW = dW; d.db = db; d.lddy = (int)lddy; d.ldx = (int)ldx; d.rows = rows; d.N = N; d.K = K; d.tile_start = 0;
-        return 0;
-    }
-    if (m->wg_defer && !split && !accumulate && m->wg.n < WGRAD_GROUP_MAX) {      // joins the grouped launch (flush_wgrads)
-        WgradDesc& d = m->wg.p[m->wg.n++];
+    WgradGroup& grp = enc ? m->wge : m->wg;
+    if (m->wge.n + m->wg.n < WGRAD_GROUP_MAX) {
+        WgradDesc& d = grp.p[grp.n++];
         d.dy = dy; d.x = x; d.dW = dW; d.db = db; d.lddy = (int)lddy; d.ldx = (int)ldx; d.rows = rows; d.N = N; d.K = K; d.tile_start = 0;
         return 0;
     }
     GemmArgs g = gemm_args();
     g.reduction_major = 1; g.A = dy; g.lda = lddy; g.B = x; g.ldb = ldx; g.M = N; g.N = K; g.K = rows;
-    g.C32 = dW; g.ldc = K; g.accumulate = accumulate; g.colsum = db;
-    // long reductions (encoder rows B*T') are split over WG_SPLIT workgroups with slab partials that
-    // mk_split_reduce combines in fixed order; decoder-row reductions (B*L) are short and stay whole
-    if (split && !m->wge_defer && dW >= m->G && dW < m->G + m->nparams) {      // (with the grouped launch on, an overflowing group member runs whole)
-        g.split_k = m->wg_split; g.split_delta = m->acts.wg_slab - m->G; g.split_stride = m->nparams;
-    }
-    CK(gemm(c, g));
-    return 0;
+    g.C32 = dW; g.ldc = K; g.colsum = db;
+    return gemm(c, g);
 }
-static int enc_wgrad_tile() {
-    static const int tile = getenv("MASR_ENC_WGRAD_TILE") ? atoi(getenv("MASR_ENC_WGRAD_TILE")) : 256;      // 256 = 256 x 256 on eight waves (A/B: 128, 64)
-    return tile;
-}
-// do the decoder-row weight gradients wait for the encoder rows' launch?  hkust: 148 tiles of 256 x 256 over 4000 rows + 228 over 640 rows;
-// as two launches the first leaves 108 CUs idle for ~110 us and the second takes ~40 us of its own, as one the short tiles run on those
-// CUs.  They feed nothing but the optimiser and their operands are per-layer buffers.  MASR_SPLIT_WGRAD_LAUNCHES=1: two launches (A/B).
-static bool merge_wgrad_launches(const masr_model* m) {
-    static const bool split = getenv("MASR_SPLIT_WGRAD_LAUNCHES") != nullptr && atoi(getenv("MASR_SPLIT_WGRAD_LAUNCHES")) != 0;
-    return !split && m->wge_defer && enc_wgrad_tile() == 256;
-}
-int flush_wgrads(Ctx& c);
-int flush_enc_wgrads(Ctx& c) {
-    masr_model* m = c.m;
-    if (m->wge.n == 0) return flush_wgrads(c);
-    int first = 0;
-    if (m->wg.n > 0 && merge_wgrad_launches(m) && m->wge.n + m->wg.n <= WGRAD_GROUP_MAX) {
-        first = m->wge.n;                                                  // the encoder-row members go first (long reductions)
-        for (int i = 0; i < m->wg.n; ++i) m->wge.p[m->wge.n++] = m->wg.p[i];
-        m->wg.n = 0;
-    }
-    int rc;
-    { Prof p(m, MASR_PROF_WGRAD_ENC, c.s);
-      rc = mk_gemm_wgrad_grouped(m->wge, c.s, enc_wgrad_tile(), first); }
-    m->wge.n = 0;
-    if (rc == 0 && m->wg.n > 0) rc = flush_wgrads(c);                      // (a decoder-row group that did not fit the merged list)
-    return rc;
-}
+// hkust: 148 tiles over 4000 rows + 228 over 592 rows.  As two launches the first leaves 108 CUs idle for ~110 us and the second takes ~40 us
+// of its own; as one the short tiles run on those CUs (125 us).  masr_set_split_wgrad_launches: two launches (A/B; same bits -- every element
+// of dW is reduced by one workgroup over its rows in order either way: tests/test_hip_engine.py).
 int flush_wgrads(Ctx& c) {
     masr_model* m = c.m;
-    m->wg_defer = false;
-    if (m->wg.n == 0) return 0;
-    Prof p(m, MASR_PROF_WGRAD_DEC, c.s);
-    // the decoder-row group on the encoder rows' 256 x 256 tiles too (hkust: 228 of them = one round): as 3 632 tiles of 64 x 64 the launch
-    // moved 0.6 GB of tile operands for 19 GFLOP and ran at the CUs' intake limit (63 us).  MASR_DEC_WGRAD_TILE=64: the small tiles (A/B).
-    static const int tile = getenv("MASR_DEC_WGRAD_TILE") ? atoi(getenv("MASR_DEC_WGRAD_TILE")) : 256;
-    const int rc = mk_gemm_wgrad_grouped(m->wg, c.s, tile);
-    m->wg.n = 0;
+    int rc = 0;
+    if (!m->split_wgrad) {
+        const int first = m->wge.n;                                        // the encoder-row members go first (long reductions)
+        for (int i = 0; i < m->wg.n; ++i) m->wge.p[m->wge.n++] = m->wg.p[i];
+        m->wg.n = 0;
+        if (m->wge.n) { Prof p(m, MASR_PROF_WGRAD_ENC, c.s); rc = mk_gemm_wgrad_grouped(m->wge, c.s, first); }
+    } else {
+        if (m->wge.n) { Prof p(m, MASR_PROF_WGRAD_ENC, c.s); rc = mk_gemm_wgrad_grouped(m->wge, c.s); }
+        if (rc == 0 && m->wg.n) { Prof p(m, MASR_PROF_WGRAD_DEC, c.s); rc = mk_gemm_wgrad_grouped(m->wg, c.s); }
+    }
+    m->wge.n = 0; m->wg.n = 0;
     return rc;
 }
 // dX = dy W via the transposed shadow t16 [K][ldt]
@@ -653,8 +596,7 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
         HIP_CHECK_RET(hipHostMalloc((void**)&m->h_ring, sizeof(float) * 4 * masr_model::RING, hipHostMallocDefault));
         for (auto& e : m->ring_ev) HIP_CHECK_RET(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    {   // device tables: split-K combine ranges and the job list of the one-launch shadow refresh
-        std::vector<long> ranges = split_chunks(m);
+    {   // device tables: the job list of the one-launch shadow refresh
         // the list travels BY VALUE in the kernel arguments (kernels.h), which caps one launch at SHADOW_JOBS_MAX jobs: deeper
         // models (8e4d = 69 jobs) simply take a second launch
         m->shadows.clear();
@@ -678,8 +620,6 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
             job(SH_LINEAR, d.ca.in.w + (long)E * E, 2 * E, E, m->NK, 0, 0, m->kv_k16 + (long)l * 2 * E * E, m->kvT + (long)l * 2 * E);   // key|value thirds
             job(SH_COPY32, d.ca.in.b + E, 2 * E, 0, 0, 0, 0, m->kv_bias + (long)l * 2 * E, nullptr);
         }
-        m->nranges = (int)ranges.size() / 2;
-        HIP_CHECK_RET(hipMemcpy(m->d_ranges, ranges.data(), sizeof(long) * ranges.size(), hipMemcpyHostToDevice));
         // the complement of the jobs' source ranges in [0, nparams), cut into chunks of <= 2048 floats
         std::vector<std::pair<long, long>> src;
         for (const ShadowJobs& J : m->shadows)
@@ -715,9 +655,8 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
 }
 
 void masr_set_seed(masr_model* m, uint64_t seed) { m->seed = seed; m->step = 0; }
-// The split factor is part of the weight gradients' fp32 summation order, i.e. of the result's BITS, and "K task slots == the sequential
-// run, bit for bit" is a guarantee of --tasks_per_gpu: so it no longer follows the slot count (it did: 2 for a shared chip, 4 alone --
-// only visible with MASR_NO_GROUPED_ENC_WGRAD=1, the grouped launch being unsplit).  MASR_WG_SPLIT still sets it for A/B runs.
+// (kept for callers: nothing in a step depends on the number of task slots any more -- "K task slots == the sequential run, bit for bit" is a
+// guarantee of --tasks_per_gpu, and every partition into partial sums is fixed per shape)
 void masr_set_concurrency(masr_model* m, int slots) { (void)m; (void)slots; }
 void masr_dropout_state(masr_model* m, uint64_t state[2], int set) {
     if (set) { m->seed = state[0]; m->step = state[1]; } else { state[0] = m->seed; state[1] = m->step; }
@@ -860,7 +799,7 @@ static int memory_kv_bwd(Ctx& c) {
     masr_model* m = c.m; Acts& a = m->acts; float* G = m->G;
     const int E = m->E;
     const DecL& d0 = m->dec[0];
-    if (m->wge_defer && m->wge.n + m->ND <= WGRAD_GROUP_MAX) {
+    if (m->wge.n + m->wg.n + m->ND <= WGRAD_GROUP_MAX) {
         // one descriptor per decoder layer in the grouped encoder-row launch (gkv_all stays untouched until the end of the pass)
         for (int l = 0; l < m->ND; ++l)
             CK(lin_wgrad(c, a.gkv_all + (int64_t)l * 2 * E, m->NK, a.mem16, E, a.rows_e, 2 * E, E, G + m->dec[l].ca.in.w + (long)E * E, G + m->dec[l].ca.in.b + E, true));
@@ -869,7 +808,6 @@ static int memory_kv_bwd(Ctx& c) {
         g.reduction_major = 1; g.A = a.gkv_all; g.lda = m->NK; g.B = a.mem16; g.ldb = E; g.M = m->NK; g.N = E; g.K = a.rows_e;
         g.C32 = G + d0.ca.in.w + (long)E * E; g.ldc = E; g.colsum = G + d0.ca.in.b + E;
         g.cseg_rows = 2 * E; g.cseg_stride = m->ND > 1 ? m->dec[1].ca.in.w - d0.ca.in.w : 0;
-        if (!m->wge_defer) { g.split_k = m->wg_split; g.split_delta = a.wg_slab - G; g.split_stride = m->nparams; }
         CK(gemm(c, g));
     }
     GemmArgs h = lin_dgrad_args(a.gkv_all, m->NK, m->kvT, m->NK, a.rows_e, m->NK, E);
@@ -883,10 +821,7 @@ static int backward(Ctx& c, const float* xs) {
     const int E = m->E, L = a.L, B = a.B;
     // ---- output projection.  The weight gradients of the decoder-row Linears (reduction over only B*L rows) are not
     // launched one by one: their operands are kept per layer and ONE grouped launch computes them after the layer loop
-    static const bool group_wgrads = !getenv("MASR_NO_GROUPED_WGRAD");
-    m->wg.n = 0; m->wg_defer = group_wgrads;
-    static const bool group_enc = !getenv("MASR_NO_GROUPED_ENC_WGRAD");
-    m->wge.n = 0; m->wge_defer = group_enc;
+    m->wg.n = 0; m->wge.n = 0;
     m->lng.n = 0; m->ln_slab_used = 0;
     CK(lin_wgrad(c, a.dlogits, m->Cp, a.yf16, E, a.rows_d, m->C, E, G + m->ct.w, G + m->ct.b));
     { GemmArgs g = lin_dgrad_args(a.dlogits, m->Cp, m->ct.t16, m->Cp, a.rows_d, m->Cp, E); g.C32 = a.gd_a; g.ldc = E; CK(gemm(c, g)); }
@@ -904,8 +839,6 @@ static int backward(Ctx& c, const float* xs) {
         CK(attn_block_bwd(c, w.sa, a.y16[l], nullptr, a.rows_d, 0, L, L, true, true, nullptr, d.qkv, nullptr, d.ao, d.lse_s, gs, dg.g1,
                           a.gao_d, dg.gqkv, nullptr, a.delta_d, gcur, nullptr, 0, d.site[0], false));
     }
-    if (merge_wgrad_launches(m) && group_wgrads) m->wg_defer = false;      // (the pending decoder-row group joins flush_enc_wgrads' launch)
-    else CK(flush_wgrads(c));
     CK(memory_kv_bwd(c));
     float* g_dec_in = gcur;                                  // d(decoder input): consumed by embed_bwd after the split-K combine
     // ---- encoder
@@ -914,7 +847,7 @@ static int backward(Ctx& c, const float* xs) {
     for (int l = m->NE - 1; l >= 0; --l) {
         EncAct& e = a.enc[l]; const EncL& w = m->enc[l];
         // (grouped weight gradients read their dY operands at the END of the pass: every layer keeps its own)
-        const EncGrad eg = m->wge_defer ? a.egr[l] : EncGrad{a.ge16, a.ge16, a.gf_e, a.gqkv_e};
+        const EncGrad eg = a.egr[l];
         CK(ln_bwd(c, w.n2, gcur, e.s2, e.m2, e.r2, gs, eg.g2, e.site[3], a.rows_e));
         CK(ffn_bwd(c, w.l1, w.l2, e.x1_16, e.f, gs, eg.g2, a.rows_e, eg.gf, gcur, true));
         CK(ln_bwd(c, w.n1, gcur, e.s1, e.m1, e.r1, gs, eg.g1, e.site[1], a.rows_e));
@@ -923,20 +856,20 @@ static int backward(Ctx& c, const float* xs) {
     }
     // ---- vgg2enc (through the positional dropout)
     { Prof p(m, MASR_PROF_MISC, s); CK(mk_cast_dropout(gcur, a.ge16, (long)a.rows_e * E, c.p_pos, c.seed, a.site_v2e, s, c.seed_ptr)); }
-    static const bool v2e_sep = getenv("MASR_V2E_SEPARATE") != nullptr;                // (A/B: keep vgg2enc's 80 tiles out of the 512-slot grid)
-    CK(lin_wgrad(c, a.ge16, E, a.p2, m->F, a.rows_e, E, m->F, a.v2e_g32, G + m->v2e.b, m->wge_defer && !v2e_sep));
-    CK(flush_enc_wgrads(c));                                 // every encoder-row weight gradient of the step, one grid
-    { Prof p(m, MASR_PROF_MISC, s); CK(mk_vgg2enc_grad_unpermute(a.v2e_g32, G + m->v2e.w, E, 128, m->Dp, s)); }
+    CK(lin_wgrad(c, a.ge16, E, a.p2, m->F, a.rows_e, E, m->F, a.v2e_g32, G + m->v2e.b, true));
+    CK(flush_wgrads(c));                                     // every Linear weight gradient of the step, one grid
     { GemmArgs g = lin_dgrad_args(a.ge16, E, m->v2e.t16, E, a.rows_e, E, m->F); g.C16 = a.dp2; g.ldc16 = m->F; CK(gemm(c, g)); }
     // ---- VGG
+    FoldJobs folds{};
     // The two maps behind a max-pool, d(a4) and d(a2), are never materialised: their consumers -- the weight-gradient kernels and the
     // dgrad kernels -- take the POOLED gradient + the one-byte pool codes of the forward launch and expand the 2 x 2 windows while staging
     // (a quarter of the gradient bytes; the maxpool backward launches and their 338 MB per step are gone)
     auto wgrad = [&](const bf16* in, const bf16* dy, const Conv& cv, int H, int W, const bf16* dy_pooled = nullptr, const uint8_t* idx = nullptr) -> int {
-        ConvWgradArgs wa{}; wa.in = in; wa.dy = dy; wa.dw = G + cv.w; wa.db = G + cv.b; wa.slab = a.slab; wa.B = B; wa.H = H; wa.W = W; wa.CIN = cv.CI; wa.COUT = cv.CO;
+        const int k = (int)(&cv - &m->conv[1]);
+        ConvWgradArgs wa{}; wa.in = in; wa.dy = dy; wa.dw = G + cv.w; wa.db = G + cv.b; wa.slab = a.cw_slab[k]; wa.B = B; wa.H = H; wa.W = W; wa.CIN = cv.CI; wa.COUT = cv.CO;
         wa.dy_pooled = dy_pooled; wa.pool_idx = idx;
-        { Prof p(m, MASR_PROF_CONV2_WGRAD + (int)(&cv - &m->conv[1]), s); CK(mk_conv3x3_wgrad(wa, s, 1)); }     // ONE launch per slot:
-        { Prof p(m, MASR_PROF_CONV1_WGRAD, s); CK(mk_conv3x3_wgrad(wa, s, 2)); }                                 // the slab reduce is timed with the other folds
+        { Prof p(m, MASR_PROF_CONV2_WGRAD + k, s); CK(mk_conv3x3_wgrad(wa, s, 1)); }     // the partial slabs; their reduce rides in the fold launch below
+        folds.conv[folds.nconv++] = {a.cw_slab[k], mk_conv3x3_wgrad_nsplit(B, H, W, cv.CI, cv.CO), G + cv.w, G + cv.b, cv.CI, cv.CO};
         return 0;
     };
     auto dgrad = [&](const bf16* dy, const Conv& cv, bf16* out, int H, int W, const bf16* dy_pooled = nullptr, const uint8_t* idx = nullptr) -> int {
@@ -946,7 +879,7 @@ static int backward(Ctx& c, const float* xs) {
         if (&cv == &m->conv[3]) { ca.mask = a.a3; ca.mask_bits = a.a3_bits; }      // conv3's ReLU mask: the sign words its forward launch wrote
         if (&cv == &m->conv[1]) {
             // d(conv1 output) is consumed only by conv1's weight gradient: contracted inside the dgrad epilogue, never stored
-            ca.mask = a.a1; ca.mask_bits = a.a1_bits; ca.out = nullptr; ca.x1 = xs; ca.w1_slab = a.slab;
+            ca.mask = a.a1; ca.mask_bits = a.a1_bits; ca.out = nullptr; ca.x1 = xs; ca.w1_slab = a.c1_slab;
         }
         return mk_conv3x3(ca, s);
     };
@@ -956,12 +889,16 @@ static int backward(Ctx& c, const float* xs) {
     CK(dgrad(a.da3, m->conv[2], a.dp1, a.H2, a.W2));
     CK(wgrad(a.a1, nullptr, m->conv[1], a.T, a.D, a.dp1, a.i1));
     CK(dgrad(nullptr, m->conv[1], nullptr, a.T, a.D, a.dp1, a.i1));
-    { Prof p(m, MASR_PROF_CONV1_WGRAD, s); CK(mk_conv1_wgrad_fused_reduce(a.slab, B, a.T, a.D, G + m->conv[0].w, G + m->conv[0].b, s)); }
-    CK(flush_ln_reduce(c));
-    // ---- combine the split-K partials of all Linear gradients, then add the embedding rows into the (tied) table
-    { Prof p(m, MASR_PROF_MISC, s);
-      if (m->wg_split > 1 && !m->wge_defer) CK(mk_split_reduce(G, a.wg_slab, m->wg_split - 1, m->nparams, m->d_ranges, m->nranges, s));
-      CK(mk_embed_bwd(a.tok_order, a.tok_start, g_dec_in, G + m->embed_w, m->C, E, m->cfg.tie_weights ? 1 : 0, c.p_pos, c.seed, a.site_emb, s, c.seed_ptr)); }
+    // ---- every fold of the pass as ONE launch (fold.hip): the conv / conv1 slab reduces, the LayerNorm dgamma / dbeta partials, vgg2enc's weight
+    // gradient back in the reference's feature order, and the embedding rows added into the (tied) table -- after the grouped launch wrote it
+    CK(flush_ln_pending(c));
+    folds.E = E;
+    folds.conv1 = {a.c1_slab, mk_conv1_wgrad_fused_rows(B, a.T, a.D), G + m->conv[0].w, G + m->conv[0].b};
+    folds.unperm = {a.v2e_g32, G + m->v2e.w, E, 128, m->Dp};
+    folds.embed = {a.tok_order, a.tok_start, g_dec_in, G + m->embed_w, m->C, E, m->cfg.tie_weights ? 1 : 0, c.p_pos, c.seed, a.site_emb, c.seed_ptr};
+    folds.ln = m->lng;
+    { Prof p(m, MASR_PROF_CONV1_WGRAD, s); CK(mk_backward_folds(folds, s)); }
+    m->lng.n = 0; m->ln_slab_used = 0;
     return 0;
 }
 
@@ -1043,8 +980,7 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
     };
     // ---- a batch shape seen twice in a row is captured once and replayed from then on (everything that changes from step to
     // step -- tokens, lengths, dropout seed, 1/n_total -- reaches the kernels through the upload above)
-    static const bool graphs_env = getenv("MASR_STEP_GRAPH") && atoi(getenv("MASR_STEP_GRAPH")) != 0;
-    const bool graphs_on = m->step_graphs_on || graphs_env;
+    const bool graphs_on = m->step_graphs_on;
     const int key[4] = {B, T, L, train ? 1 : 0};
     const bool repeat = !memcmp(key, m->last_key, sizeof key) && m->last_xs == (const void*)xs;
     memcpy(m->last_key, key, sizeof key); m->last_xs = xs;
@@ -1079,6 +1015,7 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
 
 void masr_set_step_graphs(masr_model* m, int on) { m->step_graphs_on = on != 0; }
 void masr_set_ln_fusion(masr_model* m, int on) { m->ln_fusion = on != 0; }
+void masr_set_split_wgrad_launches(masr_model* m, int on) { m->split_wgrad = on != 0; }
 void masr_set_fused_sgd(masr_model* m, int on) { m->fuse_sgd = on != 0 && m->gaps_ok; }
 void masr_step_counters(const masr_model* m, int64_t out[3]) { out[0] = m->n_direct; out[1] = m->n_captured; out[2] = m->n_replayed; }
 
@@ -1472,7 +1409,7 @@ int masr_test_layernorm(const float* x, const float* gamma, const float* beta, c
     return mk_layernorm_bwd(dy, x, gamma, mean, rstd, dx, (bf16*)dx16, drop_p, seed, site, dgamma, dbeta, slab, rows, E, (hipStream_t)stream, nullptr);
 }
 int masr_test_wgrad_grouped(const uint16_t* dy, int64_t lddy, const uint16_t* x, int64_t ldx, float* dW, float* db, float* dW2, float* db2,
-                            int rows, int N, int K, int tile, void* stream) {
+                            int rows, int N, int K, void* stream) {
     // two members over the same operands (the second one optional): exercises the descriptor walk of the grouped grid
     WgradGroup grp{};
     grp.n = dW2 ? 2 : 1;
@@ -1480,19 +1417,22 @@ int masr_test_wgrad_grouped(const uint16_t* dy, int64_t lddy, const uint16_t* x,
         WgradDesc& d = grp.p[i];
         d.dy = (const bf16*)dy; d.x = (const bf16*)x; d.dW = i ? dW2 : dW; d.db = i ? db2 : db; d.lddy = (int)lddy; d.ldx = (int)ldx; d.rows = rows; d.N = N; d.K = K;
     }
-    return mk_gemm_wgrad_grouped(grp, (hipStream_t)stream, tile);
+    return mk_gemm_wgrad_grouped(grp, (hipStream_t)stream);
 }
 int masr_test_wgrad_grouped_n(const uint16_t* dy, int64_t lddy, const uint16_t* x, int64_t ldx, float* dW, int64_t member_stride, int members,
-                              int rows, int N, int K, int tile, void* stream) {
+                              int first_members, int rows, int rows_rest, int N, int K, void* stream) {
     // `members` group members over the SAME operands (member i writes dW + i * member_stride; 0 = all into one buffer): what the grouped
-    // launch costs when every panel is resident in L2 / the Infinity Cache (tools/wgrad_probe.py)
+    // launch costs when every panel is resident in L2 / the Infinity Cache (tools/wgrad_probe.py).  first_members > 0: the two-segment
+    // tile list of the engine's merged launch -- members [0, first_members) reduce over `rows` rows and are dispatched first, the rest
+    // over the first `rows_rest` rows
     WgradGroup grp{};
     grp.n = members < WGRAD_GROUP_MAX ? members : WGRAD_GROUP_MAX;
     for (int i = 0; i < grp.n; ++i) {
         WgradDesc& d = grp.p[i];
-        d.dy = (const bf16*)dy; d.x = (const bf16*)x; d.dW = dW + (int64_t)i * member_stride; d.db = nullptr; d.lddy = (int)lddy; d.ldx = (int)ldx; d.rows = rows; d.N = N; d.K = K;
+        d.dy = (const bf16*)dy; d.x = (const bf16*)x; d.dW = dW + (int64_t)i * member_stride; d.db = nullptr; d.lddy = (int)lddy; d.ldx = (int)ldx;
+        d.rows = (first_members > 0 && i >= first_members) ? rows_rest : rows; d.N = N; d.K = K;
     }
-    return mk_gemm_wgrad_grouped(grp, (hipStream_t)stream, tile);
+    return mk_gemm_wgrad_grouped(grp, (hipStream_t)stream, first_members);
 }
 int masr_test_conv3x3_wgrad_pooled(const uint16_t* in, const uint16_t* dy_pooled, const uint8_t* pool_idx, float* dw, float* db, float* slab,
                                    int64_t slab_floats, int B, int H, int W, int CIN, int COUT, void* stream) {

@@ -379,26 +379,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     gemm_body<BM, BN, RM, EPI>(g, bx, by, bz);
 }
 
-// ---- grouped weight-gradient launch: many small reduction-major GEMMs (dW = dY^T X of the decoder Linears, reduction
-// over only B*L rows) as ONE grid.  Each of them alone is 16-256 workgroups and ~12 us of mostly launch latency; together
-// they fill the chip.  The descriptors travel in the kernel-argument segment (uniform scalar loads, no table upload).
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_wgrad_grouped_kernel(WgradGroup grp) {
-    // XCD-aware order (workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2): every XCD takes a CONTIGUOUS run of
-    // the tile list, so the tiles that share a dY column block / an X column block meet in one L2 instead of eight (the long
-    // encoder-row reductions: 670 MB of HBM traffic for 243 MB of operands before)
-    const int total = gridDim.x, l = blockIdx.x, xc = l & 7, q = total >> 3, r = total & 7;
-    const int tlin = BM >= 128 ? xc * q + (xc < r ? xc : r) + (l >> 3) : l;
-    int p = 0;
-    while (p + 1 < grp.n && tlin >= grp.p[p + 1].tile_start) ++p;
-    const WgradDesc& d = grp.p[p];
-    GemmArgs g{};
-    g.A = d.dy; g.lda = d.lddy; g.B = d.x; g.ldb = d.ldx; g.M = d.N; g.N = d.K; g.K = d.rows; g.reduction_major = 1;
-    g.alpha = 1.f; g.mask_scale = 1.f; g.C32 = d.dW; g.ldc = d.K; g.colsum = d.db;
-    const int t = tlin - d.tile_start, tiles_x = (d.K + BN - 1) / BN;
-    gemm_body<BM, BN, true, E_C32>(g, t % tiles_x, t / tiles_x, 0);
-}
-
 // ---- the encoder- and decoder-row weight gradients on EIGHT-wave tiles (round 4).  What bounds the 128 x 128 four-wave launch above is
 // operand intake: every tile streams a [rows x 128] panel of dY and one of X through its CU (1.21 GB of tile operands for 244 MB of
 // distinct bytes, ~28 GB/s per CU), MFMA pipes busy 0.21; the CUs together take in ~8.7 TB/s from the L2s at this access shape
@@ -1020,10 +1000,9 @@ void launch_epi(const GemmArgs& g, dim3 grid, hipStream_t s) {
 
 template <int BM, int BN>
 int launch_tile(const GemmArgs& g_in, hipStream_t s) {
-    static const bool xcd = !getenv("MASR_GEMM_NO_XCD");
     GemmArgs g = g_in;
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, (g.reduction_major && g.split_k > 1) ? g.split_k : 1);
-    g.xcd_order = xcd && (long)grid.x * grid.y * grid.z >= 64;
+    g.xcd_order = (long)grid.x * grid.y * grid.z >= 64;
     const int epi = (g.bias ? E_BIAS : 0) | (g.pe ? E_PE : 0) | (g.relu ? E_RELU : 0) | (g.mask ? E_MASK : 0) |
                     (g.drop_p > 0.f ? E_DROP : 0) | (g.residual ? E_RES : 0) | (g.accumulate ? E_ACC : 0) |
                     (g.C32 ? E_C32 : 0) | (g.C16 ? E_C16 : 0);
@@ -1031,8 +1010,7 @@ int launch_tile(const GemmArgs& g_in, hipStream_t s) {
         if (epi == E_C32) launch_epi<BM, BN, true, E_C32>(g, grid, s);
         else launch_epi<BM, BN, true, -1>(g, grid, s);
     } else {
-        static const bool use_glds = !getenv("MASR_GEMM_NO_GLDS");
-        const bool glds = use_glds && (g.K % 64 == 0);
+        const bool glds = g.K % 64 == 0;
         switch (epi & ~E_DROP) {                       // dropout stays a run-time test inside the specialised kernels
 #define CASE(mask) case (mask): if (glds) launch_glds<BM, BN, (mask) | E_DROP>(g, grid, s); else launch_epi<BM, BN, false, (mask) | E_DROP>(g, grid, s); break;
             CASE(E_BIAS | E_C16)                       // q/k/v projections
@@ -1055,19 +1033,17 @@ int launch_tile(const GemmArgs& g_in, hipStream_t s) {
 
 }  // namespace
 
-int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s, int tile, int first_members) {
+int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s, int first_members) {
     if (grp.n <= 0) return 0;
-    if (tile != 64 && tile != 128 && tile != 256) { mk_set_error("mk_gemm_wgrad_grouped", "tile 64, 128 or 256 (= 256 x 256 on eight waves)"); return -1; }
-    int tiles = 0;
     for (int i = 0; i < grp.n; ++i) {
-        WgradDesc& d = grp.p[i];
+        const WgradDesc& d = grp.p[i];
         if ((d.lddy & 7) || (d.ldx & 7) || ((uintptr_t)d.dy & 15) || ((uintptr_t)d.x & 15) || d.lddy < (d.N + 7) / 8 * 8 || d.ldx < (d.K + 7) / 8 * 8) {
             mk_set_error("mk_gemm_wgrad_grouped", "operands must be 16-byte aligned with padded rows"); return -1;
         }
-        d.tile_start = tiles;
-        tiles += ((d.N + tile - 1) / tile) * ((d.K + tile - 1) / tile);
+        // (the tile loop clamps its reduction rows to rows - 1: an empty reduction would read row -1)
+        if (d.rows < 1 || d.N < 1 || d.K < 1) { mk_set_error("mk_gemm_wgrad_grouped", "rows, N and K must be >= 1"); return -1; }
     }
-    if (tile == 256) {
+    {
         int t16 = 0, n_first = 0;
         for (int i = 0; i < grp.n; ++i) {
             if (i == first_members) n_first = t16;
@@ -1079,11 +1055,7 @@ int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s, int tile, int first_me
     }
     // (Tried: the 128 x 128 form with LDS-DMA staging -- reduction-major tiles are lane-linear per DMA piece as they are, chunk c of row k
     // at c ^ (k & 15) for the transposing reads, zero line behind the last row, bias gradient as one more MFMA column against ones: 202 us
-    // against this kernel's 160 on the encoder-row launch.  Eight DMA pieces per wave and k tile cost more issue time than the 32 MFMAs
-    // they feed (100-185 cycles each beside fragment reads), and the register path spreads its loads and LDS writes over the whole gap.)
-    if (tile == 64) hipLaunchKernelGGL((gemm_wgrad_grouped_kernel<64, 64>), dim3(tiles), dim3(256), 0, s, grp);
-    else hipLaunchKernelGGL((gemm_wgrad_grouped_kernel<128, 128>), dim3(tiles), dim3(256), 0, s, grp);
-    if (hipGetLastError() != hipSuccess) { mk_set_error("mk_gemm_wgrad_grouped", "launch failed"); return -1; }
+    // against 160 for the register-staged kernel of that size on the encoder-row launch; both are gone: the 256 x 256 tiles above run it in 111.)
     return 0;
 }
 
@@ -1155,10 +1127,7 @@ int mk_gemm(const GemmArgs& g, hipStream_t s) {
     // largest tile that still yields roughly one workgroup per CU (256 CUs)
     const long z = (g.reduction_major && g.split_k > 1) ? g.split_k : 1;
     auto wgs = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * z; };
-    static const int rm_tile = getenv("MASR_GEMM_RM_TILE") ? atoi(getenv("MASR_GEMM_RM_TILE")) : 0;     // A/B switch: 1 = 64x64, 2 = 128x64
-    if (g.reduction_major && rm_tile == 1) return launch_tile<64, 64>(g, s);
-    if (g.reduction_major && rm_tile == 2) return launch_tile<128, 64>(g, s);
-    static const long min_wgs = getenv("MASR_GEMM_MIN_WGS") ? atol(getenv("MASR_GEMM_MIN_WGS")) : 192;   // A/B switch for the tile choice
+    constexpr long min_wgs = 192;
     if (wgs(128, 128) >= min_wgs) return launch_tile<128, 128>(g, s);
     if (wgs(128, 64) >= min_wgs) return launch_tile<128, 64>(g, s);
     return launch_tile<64, 64>(g, s);

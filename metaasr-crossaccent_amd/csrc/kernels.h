@@ -20,7 +20,7 @@ struct GemmArgs {
     const float* residual; long ldres;                 // + residual[m*ldres + n]
     float* colsum;                // reduction-major only: colsum[m] = sum_k A(m,k) (fused bias gradient) or null
     int split_k;                  // reduction-major only: >1 splits the reduction over gridDim.z workgroups; split 0 writes
-    long split_delta, split_stride;   // C32/colsum, split z>0 writes the same addresses + split_delta + (z-1)*split_stride
+    long split_delta, split_stride;   // C32/colsum, split z>0 writes the same addresses + split_delta + (z-1)*split_stride (mk_split_reduce combines)
     int accumulate;               // C32 += v
     int xcd_order;                // set by mk_gemm: XCD-contiguous tile order
     float* C32; long ldc;         // fp32 output or null
@@ -48,7 +48,9 @@ inline int mk_gemm_ln_blocks(int rows) { return (rows + 63) / 64; }      // dgam
 struct WgradDesc { const bf16* dy; const bf16* x; float* dW; float* db; int lddy, ldx, rows, N, K, tile_start; };
 constexpr int WGRAD_GROUP_MAX = 40;
 struct WgradGroup { int n; WgradDesc p[WGRAD_GROUP_MAX]; };
-int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s, int tile = 64, int first_members = 0);       // fills tile_start; tile = 64 / 128 (four waves) or 256 (256 x 256 on eight waves, LDS-DMA; first_members > 0: members [0, first_members) are dispatched first)
+// ONE grid of 256 x 256 tiles on eight waves (LDS-DMA ring) over all members; fills tile_start.  first_members > 0: members [0, first_members)
+// are dispatched first (the engine's merged launch: long encoder-row reductions, then the short decoder-row ones)
+int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s, int first_members = 0);
 inline GemmArgs gemm_args() { GemmArgs g{}; g.alpha = 1.f; g.mask_scale = 1.f; return g; }
 
 // ---------------------------------------------------------------- conv front-end (conv.hip)
@@ -162,6 +164,21 @@ struct LnReduceDesc { const float* slab; float* dgamma; float* dbeta; int nblock
 constexpr int LN_GROUP_MAX = 64;
 struct LnReduceGroup { int n; LnReduceDesc p[LN_GROUP_MAX]; };
 int mk_layernorm_bwd_reduce_grouped(const LnReduceGroup& grp, int E, hipStream_t s);
+// every fold pass that closes a transformer step's backward as ONE launch (fold.hip): conv[k] = slab reduce of a 3x3-conv weight gradient
+// (mk_conv3x3_wgrad phase 2; nsplit = the partial slabs its phase 1 wrote), conv1 = the 640-sum rows of the fused conv1 weight gradient
+// (nblocks rows: one per workgroup of that launch), ln = mk_layernorm_bwd_reduce_grouped's list, unperm = mk_vgg2enc_grad_unpermute,
+// embed = mk_embed_bwd.  A null output pointer (dw / dtable) leaves the job out.
+struct FoldJobs {
+    int nconv, E;
+    struct { const float* slab; int nsplit; float* dw; float* db; int CIN, COUT; } conv[3];
+    struct { const float* slab; int nblocks; float* dw; float* db; } conv1;
+    struct { const float* g; float* dw; int E, C, Dp; } unperm;
+    struct { const int* order; const int* start; const float* dy; float* dtable; int V, E, accumulate; float drop_p; uint32_t seed, site; const uint32_t* seed_ptr; } embed;
+    LnReduceGroup ln;
+};
+int mk_backward_folds(const FoldJobs& j, hipStream_t s);
+int mk_conv3x3_wgrad_nsplit(int B, int H, int W, int CIN, int COUT);      // the partial slabs mk_conv3x3_wgrad's phase 1 writes for this shape
+int mk_conv1_wgrad_fused_rows(int B, int H, int W);                      // the 640-sum rows the fused conv1 weight gradient writes
 int mk_embed_fwd(const int* tok, const float* table, const float* pe, float* y32, bf16* y16,
                    int B, int L, int E, float drop_p, uint32_t seed, uint32_t site, hipStream_t s, const uint32_t* seed_ptr = nullptr);
 // dtable[v] (+)= sum over rows with tok==v of dy[row]  (deterministic: one block per vocab row)
@@ -207,8 +224,6 @@ int mk_cast_bf16(const float* x, bf16* y, long n, hipStream_t s);
 int mk_transpose_cast_bf16(const float* x /*[R][C]*/, bf16* y /*[C][ldy]*/, int R, int C, long ldy, hipStream_t s);
 // conv weight shadows: w [CO][CI][3][3] fp32 -> wk [CO][tap*CI+ci] (fwd) and wd [CI][tap'*CO+co] = w[co][ci][8-tap'] (dgrad)
 int mk_conv_weight_shadows(const float* w, bf16* wk, bf16* wd, int CO, int CI, hipStream_t s);       // (BLSTM engine; the transformer uses mk_all_shadows)
-// G[i] += sum_{s<nslab} slab[s*stride + i] over the listed (offset, length <= 2048) chunks (deterministic split-K combine)
-int mk_split_reduce(float* G, const float* slab, int nslab, long stride, const long* ranges, int nranges, hipStream_t s);
 // EVERY bf16 operand shadow of the model in ONE launch (masr_refresh after each parameter update), descriptor driven:
 //   SH_LINEAR   weight [N][K] at P+src -> k16 [N][K] and its transpose t16 [K][ldt] (32x32 tiles); ptrs[2i] = k16, ptrs[2i+1] = t16
 //   SH_CONV     w [CO=N][CI=K][3][3] -> wk [CO][tap*CI+ci] (forward) and wd [CI][tap'*CO+co] = w[co][ci][8-tap'] (dgrad)

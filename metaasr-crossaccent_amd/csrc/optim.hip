@@ -4,6 +4,7 @@
 // (reference call sites: src/fo_meta_interface.py:148-149,180-221,223-250; optimizer.py:19-28).
 #include "common.h"
 #include "kernels.h"
+#include "folds.h"
 #include <type_traits>
 
 namespace {
@@ -225,31 +226,10 @@ __global__ void conv_shadow_kernel(const float* __restrict__ w, bf16* __restrict
     wk[(long)co * 9 * CI + tap * CI + ci] = v;                        // forward: out[co] += in[p+off(tap)][ci] * w
     if (wd) wd[(long)ci * 9 * CO + (8 - tap) * CO + co] = v;          // dgrad: din[ci] += dy[p-off(tap)][co] * w
 }
-__global__ void vgg2enc_unpermute_kernel(const float* __restrict__ g, float* __restrict__ dw, int E, int C, int Dp) {
-    const int F = C * Dp;
-    const long n = (long)E * F;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int f = (int)(i % F), e = (int)(i / F);
-    const int c = f / Dp, d = f % Dp;
-    dw[i] = g[(long)e * F + d * C + c];
+__global__ __launch_bounds__(256) void vgg2enc_unpermute_kernel(const float* __restrict__ g, float* __restrict__ dw, int E, int C, int Dp) {
+    vgg2enc_unpermute_body(g, dw, E, C, Dp, blockIdx.x);
 }
 
-// one workgroup per (offset, length <= 2048) chunk; 8 independent elements per thread in flight
-__global__ __launch_bounds__(256) void split_reduce_kernel(float* __restrict__ G, const float* __restrict__ slab, int nslab, long stride,
-                                                           const long* __restrict__ chunks) {
-    const long off = chunks[2 * blockIdx.x]; const int len = (int)chunks[2 * blockIdx.x + 1];
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { const int i = threadIdx.x + e * 256; v[e] = i < len ? G[off + i] : 0.f; }
-    for (int s = 0; s < nslab; ++s) {
-        const float* sp = slab + (long)s * stride + off;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const int i = threadIdx.x + e * 256; if (i < len) v[e] += sp[i]; }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { const int i = threadIdx.x + e * 256; if (i < len) G[off + i] = v[e]; }
-}
 // every operand shadow of the model, one job list, one launch (see kernels.h)
 constexpr int SH_TILE = 64, SH_GAP = 2048;
 // SGD = true: the clipped SGD step of masr_clip_sgd_step is applied to every element ON ITS WAY into the shadows (read p and g, write p
@@ -506,11 +486,6 @@ int mk_cast_bf16(const float* x, bf16* y, long n, hipStream_t s) {
 }
 int mk_transpose_cast_bf16(const float* x, bf16* y, int R, int C, long ldy, hipStream_t s) {
     hipLaunchKernelGGL(transpose_cast_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, s, x, y, R, C, ldy);
-    return LAUNCH_OK();
-}
-int mk_split_reduce(float* G, const float* slab, int nslab, long stride, const long* ranges, int nranges, hipStream_t s) {
-    if (nslab <= 0 || nranges <= 0) return 0;
-    hipLaunchKernelGGL(split_reduce_kernel, dim3(nranges), dim3(256), 0, s, G, slab, nslab, stride, ranges);
     return LAUNCH_OK();
 }
 int mk_shadow_blocks(const ShadowDesc& d) {

@@ -2,6 +2,7 @@
 // the fused label-smoothed cross entropy of run_batch.  fp32 statistics throughout.
 #include "common.h"
 #include "kernels.h"
+#include "folds.h"
 
 namespace {
 
@@ -136,29 +137,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 // 32 columns x 8 block-lanes per workgroup, 4 independent partial sums per thread; fixed order -> deterministic
-__device__ __forceinline__ void ln_bwd_reduce_body(const float* __restrict__ slab, int nblocks, float* __restrict__ dgamma,
-                                                   float* __restrict__ dbeta, int E, int bx) {
-    const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
-    const int c = bx * 32 + cl;
-    __shared__ float red[8][32];
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (c < 2 * E) {
-        const float* p = slab + (long)(c / E) * E + c % E;
-        int b = part;
-        for (; b + 24 < nblocks; b += 32) {
-            s0 += p[(long)b * 2 * E]; s1 += p[(long)(b + 8) * 2 * E]; s2 += p[(long)(b + 16) * 2 * E]; s3 += p[(long)(b + 24) * 2 * E];
-        }
-        for (; b < nblocks; b += 8) s0 += p[(long)b * 2 * E];
-    }
-    red[part][cl] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (part == 0 && c < 2 * E) {
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][cl];
-        (c / E == 0 ? dgamma : dbeta)[c % E] = t;
-    }
-}
 __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ slab, int nblocks, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int E) {
     ln_bwd_reduce_body(slab, nblocks, dgamma, dbeta, E, blockIdx.x);
@@ -193,40 +171,7 @@ __global__ void embed_fwd_kernel(const int* __restrict__ tok, const float* __res
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ order, const int* __restrict__ start, const float* __restrict__ dy,
                                                         float* __restrict__ dtable, int E, int accumulate,
                                                         float drop_p, uint32_t seed, uint32_t site, const uint32_t* __restrict__ seed_ptr) {
-    if (seed_ptr) seed = *seed_ptr;
-    const int v = blockIdx.x, col = blockIdx.y * 64 + (threadIdx.x & 63);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    __shared__ float part[4][64];
-    __shared__ int hit[1024];
-    const int s0 = start[v], ntot = start[v + 1] - s0;
-    if (ntot == 0) { if (!accumulate && wave == 0) dtable[(long)v * E + col] = 0.f; return; }
-    float s = 0.f;
-    for (int c0 = 0; c0 < ntot; c0 += 1024) {                          // (the hit list through LDS: the row loads must not wait for it one by one)
-        const int n = ntot - c0 < 1024 ? ntot - c0 : 1024;
-        if (c0) __syncthreads();
-        for (int i = threadIdx.x; i < n; i += 256) hit[i] = order[s0 + c0 + i];
-        __syncthreads();
-        for (int h0 = wave; h0 < n; h0 += 32) {                         // 8 independent row loads in flight per wave
-            float gv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int h = h0 + 4 * u;
-                const int r = hit[h < n ? h : n - 1];
-                float g = dy[(long)r * E + col];
-                if (drop_p > 0.f) g *= dropout_scale(seed, site, (uint32_t)((long)r * E + col), drop_p, inv_keep);
-                gv[u] = h < n ? g : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += gv[u];
-        }
-    }
-    part[wave][lane] = s;
-    __syncthreads();
-    if (wave == 0) {
-        const float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-        if (accumulate) dtable[(long)v * E + col] += t; else dtable[(long)v * E + col] = t;
-    }
+    embed_bwd_body(order, start, dy, dtable, E, accumulate, drop_p, seed, site, seed_ptr, blockIdx.x, blockIdx.y);
 }
 
 __global__ void cast_dropout_kernel(const float* __restrict__ x, bf16* __restrict__ y, long n, float drop_p,

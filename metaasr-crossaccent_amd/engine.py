@@ -247,6 +247,10 @@ class MasrEngine:
         """decoder-row LayerNorms inside their consumer GEMMs (include/masr.h masr_set_ln_fusion); default off (measured slower)"""
         self._l.masr_set_ln_fusion(self.h, int(bool(on)))
 
+    def set_split_wgrad_launches(self, on: bool):
+        """the step's Linear weight gradients as two launches instead of one (include/masr.h masr_set_split_wgrad_launches; A/B, same bits)"""
+        self._l.masr_set_split_wgrad_launches(self.h, int(bool(on)))
+
     def set_fused_sgd(self, on: bool):
         """clip_sgd_step's update inside the shadow-refresh launch (include/masr.h masr_set_fused_sgd); default off (measured slower)"""
         self._l.masr_set_fused_sgd(self.h, int(bool(on)))

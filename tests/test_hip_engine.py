@@ -429,6 +429,26 @@ def test_layernorm_in_the_gemm_prologue_gives_the_same_step(cfg_name):
             assert torch.equal(a, b), f"{n}: gradient differs between the fused and the standalone LayerNorm path"
 
 
+@pytest.mark.parametrize("cfg_name", ["tiny", "hkust"])
+def test_merged_weight_gradient_launch_equals_two_launches(cfg_name):
+    """engine.hip flush_wgrads: the decoder-row weight gradients ride in the encoder rows' launch (two-segment tile list, long tiles
+    dispatched first).  Against the two separate launches (masr_set_split_wgrad_launches): every gradient of a training step bit for bit."""
+    cfg = dict(TINY if cfg_name == "tiny" else HKUST)
+    sd = ref_cpu.deterministic_state_dict(cfg, ODIM, seed=6)
+    ilens, olens = ([64, 52, 40, 33], [9, 7, 5, 3]) if cfg_name == "tiny" else ([203, 160, 121, 96, 90], [12, 9, 7, 30, 2])
+    xs, il, ys, ol = synth_batch(22, ilens, olens)
+    grads = []
+    for split in (False, True):
+        eng = MasrEngine(cfg, ODIM, label_smoothing=0.2)
+        eng.load_state_dict(sd)
+        eng.set_seed(3)
+        eng.set_split_wgrad_launches(split)
+        eng.run_batch(xs, il, ys, ol.clone(), train=True)
+        grads.append(eng.grads.clone())
+        assert np.isfinite(eng.read_stats()["loss"])
+    assert torch.equal(grads[0], grads[1]) and float(grads[0].abs().max()) > 0
+
+
 @pytest.mark.parametrize("cfg_name,mom_steps", [("tiny", 1), ("hkust", 1), ("tiny", 3)])
 def test_sgd_step_inside_the_shadow_refresh_gives_the_same_bits(cfg_name, mom_steps):
     """masr_clip_sgd_step applies its update inside the launch that rewrites the bf16 operand layouts (csrc/optim.hip

@@ -59,37 +59,52 @@ def test_gemm_reduction_major(L, M, N, K):
     torch.testing.assert_close(Cc, ref, rtol=2e-4, atol=2e-3 * (K ** 0.5) / 8)
 
 
-@pytest.mark.parametrize("rows,N,K,tile", [(4000, 512, 512, 128), (1000, 1536, 512, 128), (777, 256, 2048, 128), (63, 128, 128, 128), (592, 512, 2048, 64),
-                                         (500, 200, 328, 128), (4000, 2560, 512, 128),
-                                         # tile 256 = the encoder- and decoder-row launches since round 4: 256 x 256 tiles on eight waves, LDS-DMA ring
-                                         # (ragged edges included)
-                                         (4000, 512, 512, 256), (1000, 1536, 512, 256), (777, 256, 2048, 256), (63, 128, 128, 256), (500, 200, 328, 256),
-                                         (4000, 2560, 512, 256), (1000, 2048, 2304, 256), (300, 2048, 2100, 256),
-                                         # more than one round of 256 x 256 tiles (2 x 17 x 16 = 544 on 256 CUs)
-                                         (200, 4200, 4096, 256)])
-def test_wgrad_grouped(L, rows, N, K, tile):
-    """mk_gemm_wgrad_grouped (the Linear weight gradients of a backward pass as one grid, lin_wgrad / flush_enc_wgrads): dW = dY^T X and
-    the fused bias gradient, two members per launch; reductions that are not multiples of the 64-row k tile (4000, 777, 63), output dims
-    that are not multiples of the tile (200 x 328)."""
+@pytest.mark.parametrize("rows,N,K", [(4000, 512, 512), (1000, 1536, 512), (777, 256, 2048), (63, 128, 128), (500, 200, 328), (592, 512, 2048),
+                                      (4000, 2560, 512), (1000, 2048, 2304), (300, 2048, 2100), (1, 64, 64),
+                                      # more than one round of 256 x 256 tiles (2 x 17 x 16 = 544 on 256 CUs)
+                                      (200, 4200, 4096)])
+def test_wgrad_grouped(L, rows, N, K):
+    """mk_gemm_wgrad_grouped (the Linear weight gradients of a backward pass as one grid of 256 x 256 tiles on eight waves, LDS-DMA ring:
+    lin_wgrad / flush_wgrads): dW = dY^T X and the fused bias gradient, two members per launch; reductions that are not multiples of the
+    32-row k tile (4000, 777, 63, 1), output dims that are not multiples of the tile (200 x 328)."""
     g = torch.Generator(device="cuda").manual_seed(rows + N + K)
     lddy, ldx = (N + 7) // 8 * 8 + 8, (K + 7) // 8 * 8
     dy = torch.zeros(rows, lddy, device="cuda").bfloat16(); dy[:, :N] = torch.randn(rows, N, device="cuda", generator=g).bfloat16()
     x = torch.zeros(rows, ldx, device="cuda").bfloat16(); x[:, :K] = torch.randn(rows, K, device="cuda", generator=g).bfloat16()
     dW = torch.full((N + 1, K), 7.0, device="cuda"); db = torch.zeros(N, device="cuda")
     dW2 = torch.zeros(N, K, device="cuda"); db2 = torch.zeros(N, device="cuda")
-    _cabi.check(L.masr_test_wgrad_grouped(P(dy), lddy, P(x), ldx, P(dW), P(db), P(dW2), P(db2), rows, N, K, tile, S()))
+    _cabi.check(L.masr_test_wgrad_grouped(P(dy), lddy, P(x), ldx, P(dW), P(db), P(dW2), P(db2), rows, N, K, S()))
     ref = dy[:, :N].float().t() @ x[:, :K].float()
     torch.testing.assert_close(dW[:N], ref, rtol=2e-4, atol=2e-3 * (rows ** 0.5) / 8)
     assert torch.all(dW[N] == 7.0) and torch.equal(dW[:N], dW2)
     torch.testing.assert_close(db, dy[:, :N].float().sum(0), rtol=1e-4, atol=1e-3 * rows ** 0.5)
     assert torch.equal(db, db2)
-    if tile == 256:
-        # every element of dW is reduced by one workgroup over the rows in order whatever the tile: the eight-wave launch equals the
-        # four-wave one bit for bit (the bias gradient is folded over 512 instead of 256 threads: fp32 rounding only)
-        dW3 = torch.zeros(N, K, device="cuda"); db3 = torch.zeros(N, device="cuda")
-        _cabi.check(L.masr_test_wgrad_grouped(P(dy), lddy, P(x), ldx, P(dW3), P(db3), None, None, rows, N, K, 128, S()))
-        assert torch.equal(dW3, dW2)
-        torch.testing.assert_close(db3, db, rtol=1e-5, atol=1e-5 * rows ** 0.5)
+    # an empty reduction is refused (the tile loop clamps its rows to rows - 1)
+    assert L.masr_test_wgrad_grouped(P(dy), lddy, P(x), ldx, P(dW), P(db), None, None, 0, N, K, S()) != 0
+    assert b"rows, N and K must be >= 1" in L.masr_last_error()
+
+
+@pytest.mark.parametrize("members,first,rows,rows_rest,N,K", [(7, 3, 1000, 148, 512, 512), (5, 2, 4000, 592, 1536, 512), (11, 4, 333, 37, 200, 328),
+                                                              (9, 8, 700, 64, 256, 256), (6, 0, 500, 500, 300, 512), (13, 5, 250, 31, 512, 2048)])
+def test_wgrad_grouped_two_segment_tile_list(L, members, first, rows, rows_rest, N, K):
+    """the engine's merged launch: the encoder-row members (long reductions) are dispatched first, every XCD takes a contiguous run of
+    each segment; mixed reduction lengths, tile totals that are no multiple of the 8 XCDs.  Every member must equal its own product."""
+    g = torch.Generator(device="cuda").manual_seed(members * 100 + first)
+    lddy, ldx = (N + 7) // 8 * 8, (K + 7) // 8 * 8
+    dy = torch.zeros(rows, lddy, device="cuda").bfloat16(); dy[:, :N] = torch.randn(rows, N, device="cuda", generator=g).bfloat16()
+    x = torch.zeros(rows, ldx, device="cuda").bfloat16(); x[:, :K] = torch.randn(rows, K, device="cuda", generator=g).bfloat16()
+    dW = torch.full((members, N, K), 7.0, device="cuda")
+    _cabi.check(L.masr_test_wgrad_grouped_n(P(dy), lddy, P(x), ldx, P(dW), N * K, members, first, rows, rows_rest, N, K, S()))
+    ref_long = dy[:, :N].float().t() @ x[:, :K].float()
+    ref_short = dy[:rows_rest, :N].float().t() @ x[:rows_rest, :K].float()
+    for i in range(members):
+        r, n = (ref_long, rows) if (first == 0 or i < first) else (ref_short, rows_rest)
+        torch.testing.assert_close(dW[i], r, rtol=2e-4, atol=2e-3 * (n ** 0.5) / 8)
+    # the same members as one plain list: identical bits (each element is reduced by one workgroup over its rows in order)
+    if first:
+        dW2 = torch.zeros(first, N, K, device="cuda")
+        _cabi.check(L.masr_test_wgrad_grouped_n(P(dy), lddy, P(x), ldx, P(dW2), N * K, first, 0, rows, rows, N, K, S()))
+        assert torch.equal(dW2, dW[:first])
 
 
 def test_gemm_exact_integers(L):
