@@ -540,7 +540,34 @@ def main():
                   "exposed_exchange_ms": ms_ex - ms_no, "allreduce_ms_isolated": ar_ms, "allreduces_per_meta_step": R if dist is not None else 0,
                   "payload_mb": orig.numel() * 4 / 1e6, "backend": ("rccl" if backend == "nccl" else backend) if dist is not None else None,
                   "utt_per_s": world * R * 2 * B / (ms_ex * 1e-3)}
-          log(f"meta-step: {ms_ex:.2f} ms with exchange, {ms_no:.2f} ms without, isolated all-reduce {ar_ms}")
+          # ---- what a first run on several GPUs must say about itself: which transport carried the meta-gradient and why,
+          # the task-slot cap the CLI would apply, and what the (quirk-kept) evaluate() costs the ranks that do not evaluate
+          from masr_amd.fo_meta_interface import slot_cap
+          meta["transport"] = sharder.transport if dist is not None and backend == "nccl" else (f"pg_{backend}" if dist is not None else "none")
+          meta["transport_note"] = (sharder.transport_note or ("native exchange (masr_allreduce) is opt-in: MASR_NATIVE_ALLREDUCE=1"
+                                                                 if not sharder.native else "MASR_NATIVE_ALLREDUCE=1")) if dist is not None else "one rank, no collective"
+          meta["slot_cap"] = {"tasks_per_gpu_asked": K, "tasks_per_gpu_run_by_pretrain_cli": slot_cap(K, 8, world, dist is not None), "meta_batch_size": 8,
+                              "rule": "collective and tasks_per_gpu > 3 and ceil(meta_batch_size / world) > tasks_per_gpu -> 3 (--no_slot_cap keeps the setting)"}
+          n_dev = 8
+          barrier()
+          t_e = time.perf_counter()
+          if rank == 0:                                           # evaluate() as shipped (reference quirk Q2): rank 0 alone, on ITS last task's adapted weights
+              for _ in range(n_dev):
+                  eng.run_batch(t0_.xs, t0_.il, t0_.ys, t0_.ol, train=False)
+              torch.cuda.synchronize(dev)
+          eval_ms = (time.perf_counter() - t_e) * 1e3
+          barrier()
+          wait_ms = (time.perf_counter() - t_e) * 1e3
+          idle = wait_ms if rank != 0 else 0.0
+          if dist is not None:
+              tt = torch.tensor([idle, eval_ms if rank == 0 else 0.0], device=coll_dev, dtype=torch.float64)
+              dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+              idle, eval_ms = float(tt[0].item()), float(tt[1].item())
+          meta["evaluate"] = {"dev_batches": n_dev, "eval_ms_rank0": eval_ms, "idle_ms_other_ranks": idle if world > 1 else 0.0,
+                              "mode": "rank 0 alone while the other ranks wait at a barrier (reference quirk Q2: evaluate() runs on the last task's adapted "
+                                      "weights, which differ per rank); pretrain.py --fix_snapshot_meta_weights evaluates the META weights and splits the dev "
+                                      "accents over the ranks"}
+          log(f"meta-step: {ms_ex:.2f} ms with exchange, {ms_no:.2f} ms without, isolated all-reduce {ar_ms}; transport {meta['transport']}")
           # ---- the same meta-step as pretrain.py --tasks_per_gpu K runs it: the K tasks of a rank concurrently on their slots (host
           # thread + stream each, slot 0 on the default stream), the meta update reading the K gradient buffers in one pass
           # (one rank) or their local sum all-reduced first (several ranks); no host sync between meta-steps

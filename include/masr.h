@@ -220,7 +220,9 @@ typedef struct masr_blstm_config {
     int32_t idim, odim;          /* feature width (83), vocabulary incl. <blank> and <eos> (367) */
     int32_t enc_dim, proj_dim;   /* LSTM hidden size per direction, projection width between layers */
     int32_t enc_odim;            /* projection width of the last layer (encoder.odim) */
-    int32_t nlayers;
+    int32_t nlayers;             /* <= 8 */
+    int32_t sample_rate[8];      /* time sub-sampling behind BLSTM layer i (encoder.sample_rate, e.g. 1_2_2): the layer's output keeps every
+                                  * sample_rate[i]-th frame, enc_lens -> (enc_lens + 1) / sample_rate[i] (src/modules/encoder.py:118-121); 0 = 1 */
 } masr_blstm_config;
 masr_blstm* masr_blstm_create(const masr_blstm_config* cfg);
 void masr_blstm_destroy(masr_blstm* m);

@@ -16,7 +16,7 @@ MASR_TRAIN, MASR_EVAL = 1, 0
 
 
 class BlstmConfig(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("idim", "odim", "enc_dim", "proj_dim", "enc_odim", "nlayers")]
+    _fields_ = [(n, C.c_int32) for n in ("idim", "odim", "enc_dim", "proj_dim", "enc_odim", "nlayers")] + [("sample_rate", C.c_int32 * 8)]
 
 
 def _ptr(t):
@@ -32,14 +32,15 @@ class BlstmEngine:
         drops = [float(v) for v in e["dropout"].split("_")]
         # `dropout` goes to nn.LSTM(dropout=..., num_layers=1) in the reference (src/modules/encoder.py:86-90), where torch applies
         # it only BETWEEN stacked layers: with one layer per module it is a no-op (torch warns), so any value gives the same
-        # results and is accepted here.  Sub-sampling between layers is not built (the shipped config uses 1_1_1).
+        # results and is accepted here.  sample_rate[i] > 1: layer i's output keeps every sample_rate[i]-th frame (encoder.py:118-121).
         if len(drops) != len(rates):
             raise ValueError("encoder.sample_rate and encoder.dropout must list one value per BLSTM layer")
-        if any(r != 1 for r in rates):
-            raise NotImplementedError("BLSTM encoder: sample_rate 1 per layer (the shipped config/blstm setting)")
+        if not 1 <= len(rates) <= 8 or any(not 1 <= r <= 8 for r in rates):
+            raise ValueError("BLSTM encoder: 1 .. 8 layers, sample_rate 1 .. 8 per layer")
         self.device = torch.device(device)
         self.odim = odim
-        self.cfg = BlstmConfig(idim=e["idim"], odim=odim, enc_dim=e["enc_dim"], proj_dim=e["proj_dim"], enc_odim=e["odim"], nlayers=len(rates))
+        self.cfg = BlstmConfig(idim=e["idim"], odim=odim, enc_dim=e["enc_dim"], proj_dim=e["proj_dim"], enc_odim=e["odim"], nlayers=len(rates),
+                               sample_rate=(C.c_int32 * 8)(*(rates + [0] * (8 - len(rates)))))
         self._l = lib()
         self.h = self._l.masr_blstm_create(C.byref(self.cfg))
         if not self.h:

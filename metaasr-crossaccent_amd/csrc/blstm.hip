@@ -4,8 +4,10 @@
 //   pad frames zeroed) + Linear head, and BLSTMTrainer.run_batch (src/blstm_trainer.py:55-85): targets [sos]+y+[eos] with
 //   sos = eos = odim-1, log_softmax + nn.CTCLoss(blank 0, mean, zero_infinity), backward.
 // Same memory model as engine.hip: one flat fp32 parameter / gradient buffer in the reference's state_dict order, bf16
-// operand shadows, a bump-allocated activation arena, every kernel on the caller's stream.  sample_rate 1 and dropout 0
-// per layer (what the shipped config/blstm files use) are the supported settings.
+// operand shadows, a bump-allocated activation arena, every kernel on the caller's stream.  Time sub-sampling between layers
+// (encoder.sample_rate, RNNP.forward encoder.py:118-121): layer i's LSTM runs on Ts[i] frames per utterance, its output keeps
+// every sub[i]-th frame before the projection, enc_lens -> (enc_lens + 1) / sub[i].  Dropout 0 per layer (a no-op in the
+// reference too: nn.LSTM(dropout=..., num_layers=1)).
 #include <cstring>
 #include <string>
 #include <vector>
@@ -30,6 +32,7 @@ struct LstmDir { int64_t wih, whh, bih, bhh; bf16 *wih16, *wihT16, *whh16, *whhT
 struct Layer { LstmDir d[2]; int64_t btw, btb; int K, N; bf16 *bt16, *btT16; };       // K = LSTM input width, N = projection width
 struct LayerAct {
     float *gx[2], *act[2], *c[2]; bf16* y16; float* z32; float* x32; bf16* x16;      // x = tanh(projection) = next layer's input
+    bf16* ys16;                                                                       // y16 sub-sampled in time (== y16 where sub == 1)
     bf16 *dzg[2], *hp[2];
 };
 
@@ -45,11 +48,13 @@ struct masr_blstm {
     float* stats = nullptr; float* h_stats = nullptr; int* h_stage = nullptr; hipEvent_t stage_ev = nullptr;
     // activations of the last batch
     int B = 0, T = 0, H2 = 0, W2 = 0, Tp = 0, Dp = 0, F = 0; int64_t rows = 0;
+    int sub[8] = {1, 1, 1, 1, 1, 1, 1, 1}; int Ts[9] = {0};                         // Ts[i] = frames per utterance entering layer i, Ts[L] = leaving the encoder
+    int* lens_l[9] = {nullptr};                                                      // enc_lens entering layer i (device [B]); lens_l[L]: the encoder's output lengths
     bf16 *c1, *c2, *p1, *c3, *c4, *p2;
     std::vector<LayerAct> act;
     float* logits; float* dlogits; bf16* dl16; int *lens, *tgt, *tgt_off, *tgt_len; float *nll, *ctc_work; int maxS = 0;
     bf16 *h16[2][2]; float* cstate[2];
-    float *dx32, *dy32, *wtmp, *slab; int64_t slab_floats = 0;
+    float *dx32, *dy32, *dys32, *wtmp, *slab; int64_t slab_floats = 0;
     bf16 *dp2, *dc4, *dc3, *dp1, *dc2, *dc1;
     bool have = false;
 };
@@ -92,6 +97,8 @@ void plan_persistent(masr_blstm* m, Arena& ar) {
 void plan_acts(masr_blstm* m, Arena& ar, int B, int T, int maxS) {
     m->B = B; m->T = T; m->H2 = (T + 1) / 2; m->W2 = (m->D + 1) / 2; m->Tp = (m->H2 + 1) / 2; m->Dp = (m->W2 + 1) / 2;
     m->F = 256 * m->Dp; m->rows = (int64_t)B * m->Tp; m->maxS = maxS;
+    m->Ts[0] = m->Tp;
+    for (int i = 0; i < m->L; ++i) m->Ts[i + 1] = (m->Ts[i] + m->sub[i] - 1) / m->sub[i];
     const int64_t P1 = (int64_t)B * T * m->D, P2 = (int64_t)B * m->H2 * m->W2, R = m->rows;
     const int H = m->H, G = 4 * H;
     m->c1 = ar.get<bf16>(P1 * 128); m->c2 = ar.get<bf16>(P1 * 128); m->p1 = ar.get<bf16>(P2 * 128);
@@ -103,14 +110,15 @@ void plan_acts(masr_blstm* m, Arena& ar, int B, int T, int maxS) {
             a.gx[d] = ar.get<float>(R * G); a.act[d] = ar.get<float>(R * G); a.c[d] = ar.get<float>(R * H);
             a.dzg[d] = ar.get<bf16>(R * G); a.hp[d] = ar.get<bf16>(R * m->KP);
         }
-        a.y16 = ar.get<bf16>(R * 2 * H); a.z32 = ar.get<float>(R * l.N); a.x32 = ar.get<float>(R * l.N); a.x16 = ar.get<bf16>(R * l.N);
+        a.y16 = ar.get<bf16>(R * 2 * H); a.ys16 = m->sub[i] > 1 ? ar.get<bf16>(R * 2 * H) : a.y16; a.z32 = ar.get<float>(R * l.N); a.x32 = ar.get<float>(R * l.N); a.x16 = ar.get<bf16>(R * l.N);
     }
     m->logits = ar.get<float>(R * m->C); m->dlogits = ar.get<float>(R * m->C); m->dl16 = ar.get<bf16>(R * m->Cp8);
-    m->lens = ar.get<int>(B); m->tgt_off = ar.get<int>(B); m->tgt_len = ar.get<int>(B); m->tgt = ar.get<int>((int64_t)B * (maxS / 2 + 2));
+    m->lens = ar.get<int>((int64_t)B * (m->L + 1)); m->tgt_off = ar.get<int>(B); m->tgt_len = ar.get<int>(B); m->tgt = ar.get<int>((int64_t)B * (maxS / 2 + 2));
+    for (int i = 0; i <= m->L; ++i) m->lens_l[i] = m->lens ? m->lens + (int64_t)i * B : nullptr;
     m->nll = ar.get<float>(B); m->ctc_work = ar.get<float>(mk_ctc_work_floats(m->Tp, B, maxS));
     for (int d = 0; d < 2; ++d) { m->h16[d][0] = ar.get<bf16>((int64_t)B * m->KP); m->h16[d][1] = ar.get<bf16>((int64_t)B * m->KP); m->cstate[d] = ar.get<float>((int64_t)B * H); }
     int64_t maxK = m->F > 2 * H ? m->F : 2 * H;
-    m->dx32 = ar.get<float>(R * maxK); m->dy32 = ar.get<float>(R * 2 * H); m->wtmp = ar.get<float>((int64_t)G * maxK + G);
+    m->dx32 = ar.get<float>(R * maxK); m->dy32 = ar.get<float>(R * 2 * H); m->dys32 = ar.get<float>(R * 2 * H); m->wtmp = ar.get<float>((int64_t)G * maxK + G);
     m->dp2 = ar.get<bf16>(R * m->F); m->dc4 = ar.get<bf16>(P2 * 256); m->dc3 = ar.get<bf16>(P2 * 256); m->dp1 = ar.get<bf16>(P2 * 128);
     m->dc2 = ar.get<bf16>(P1 * 128); m->dc1 = ar.get<bf16>(P1 * 128);
     int64_t sl = mk_sumsq_slab_floats(m->nparams);
@@ -134,7 +142,7 @@ GemmArgs rm(const bf16* dy, long lddy, const bf16* x, long ldx, int rows, int N,
 }
 
 int forward(masr_blstm* m, const float* xs, hipStream_t s) {
-    const float* P = m->P; const int B = m->B, T = m->T, D = m->D, H = m->H, G = 4 * H; const int R = (int)m->rows;
+    const float* P = m->P; const int B = m->B, T = m->T, D = m->D, H = m->H, G = 4 * H;
     CK(mk_conv1_fwd_n(xs, P + m->conv[0].w, P + m->conv[0].b, m->c1, B, T, D, 128, s));
     auto conv = [&](const bf16* in, const ConvP& cv, bf16* out, int Hh, int Ww) -> int {
         ConvArgs ca{}; ca.sched = m->conv_sched; ca.in = in; ca.wk = cv.k16; ca.bias = P + cv.b; ca.relu = 1; ca.out = out; ca.B = B; ca.H = Hh; ca.W = Ww; ca.CIN = cv.CI; ca.COUT = cv.CO;
@@ -148,49 +156,56 @@ int forward(masr_blstm* m, const float* xs, hipStream_t s) {
     const bf16* x16 = m->p2; int K = m->F;
     for (int i = 0; i < m->L; ++i) {
         LayerAct& a = m->act[i]; const Layer& l = m->layers[i];
+        const int Tin = m->Ts[i], Tout = m->Ts[i + 1], R = B * Tin, Ro = B * Tout;
         for (int d = 0; d < 2; ++d) {
             GemmArgs g = nt(x16, K, l.d[d].wih16, K, R, G, K, l.d[d].bias); g.C32 = a.gx[d]; g.ldc = G;
             CK(mk_gemm(g, s));
         }
-        LstmStepArgs st{}; st.B = B; st.T = m->Tp; st.H = H; st.KP = m->KP; st.lens = m->lens; st.y16 = a.y16;
+        LstmStepArgs st{}; st.B = B; st.T = Tin; st.H = H; st.KP = m->KP; st.lens = m->lens_l[i]; st.y16 = a.y16;
         for (int d = 0; d < 2; ++d) {
             st.h16[d][0] = m->h16[d][0]; st.h16[d][1] = m->h16[d][1]; st.whh16[d] = l.d[d].whh16; st.whhT16[d] = l.d[d].whhT16;
             st.gx[d] = a.gx[d]; st.act[d] = a.act[d]; st.c[d] = a.c[d]; st.cstate[d] = m->cstate[d]; st.dz16[d] = a.dzg[d];
         }
         CK(mk_lstm_fwd_steps(st, s));
-        GemmArgs g = nt(a.y16, 2 * H, l.bt16, 2 * H, R, l.N, 2 * H, P + l.btb); g.C32 = a.z32; g.ldc = l.N;
+        if (m->sub[i] > 1) CK(mk_subsample_rows(a.y16, a.ys16, B, Tin, Tout, m->sub[i], 2 * H, s));      // ys_pad[:, ::sub] (encoder.py:118-121)
+        GemmArgs g = nt(a.ys16, 2 * H, l.bt16, 2 * H, Ro, l.N, 2 * H, P + l.btb); g.C32 = a.z32; g.ldc = l.N;
         CK(mk_gemm(g, s));
-        CK(mk_tanh_fwd(a.z32, a.x32, a.x16, (long)R * l.N, s));
+        CK(mk_tanh_fwd(a.z32, a.x32, a.x16, (long)Ro * l.N, s));
         x16 = a.x16; K = l.N;
     }
     LayerAct& la = m->act[m->L - 1];
-    CK(mk_mask_rows(la.x32, la.x16, m->lens, B, m->Tp, K, s));                 // out.masked_fill(pad, 0) (encoder.py:297-298)
+    const int Tl = m->Ts[m->L], R = B * Tl;
+    CK(mk_mask_rows(la.x32, la.x16, m->lens_l[m->L], B, Tl, K, s));            // out.masked_fill(pad, 0) (encoder.py:297-298)
     GemmArgs g = nt(la.x16, K, m->head16, K, R, m->C, K, P + m->headb); g.C32 = m->logits; g.ldc = m->C;
     CK(mk_gemm(g, s));
     return 0;
 }
 
 int backward(masr_blstm* m, const float* xs, hipStream_t s) {
-    float* Gr = m->G; const int B = m->B, T = m->T, D = m->D, H = m->H, G = 4 * H; const int R = (int)m->rows;
-    const int Tp = m->Tp;
+    float* Gr = m->G; const int B = m->B, T = m->T, D = m->D, H = m->H, G = 4 * H;
     int K = m->layers.back().N;
     LayerAct& la = m->act[m->L - 1];
     // head
-    CK(mk_cast_rows_pad(m->dlogits, m->dl16, R, m->C, m->Cp8, s));
-    CK(mk_gemm(rm(m->dl16, m->Cp8, la.x16, K, R, m->C, K, Gr + m->headw, K, Gr + m->headb), s));
-    { GemmArgs g = nt(m->dl16, m->Cp8, m->headT16, m->Cp8, R, K, m->Cp8, nullptr); g.C32 = m->dx32; g.ldc = K; CK(mk_gemm(g, s)); }
-    CK(mk_mask_rows(m->dx32, nullptr, m->lens, B, Tp, K, s));
+    {
+        const int Tl = m->Ts[m->L], R = B * Tl;
+        CK(mk_cast_rows_pad(m->dlogits, m->dl16, R, m->C, m->Cp8, s));
+        CK(mk_gemm(rm(m->dl16, m->Cp8, la.x16, K, R, m->C, K, Gr + m->headw, K, Gr + m->headb), s));
+        { GemmArgs g = nt(m->dl16, m->Cp8, m->headT16, m->Cp8, R, K, m->Cp8, nullptr); g.C32 = m->dx32; g.ldc = K; CK(mk_gemm(g, s)); }
+        CK(mk_mask_rows(m->dx32, nullptr, m->lens_l[m->L], B, Tl, K, s));
+    }
     for (int i = m->L - 1; i >= 0; --i) {
         LayerAct& a = m->act[i]; const Layer& l = m->layers[i];
         const bf16* xin = i > 0 ? m->act[i - 1].x16 : m->p2;
         const int Kin = l.K;
+        const int Tp = m->Ts[i], To = m->Ts[i + 1], R = B * Tp, Ro = B * To;       // frames entering / leaving this layer
         // tanh + projection
         bf16* dz16 = a.x16;                                   // the bf16 copy of this layer's output is dead now: reuse it for d(projection)
-        CK(mk_tanh_bwd(m->dx32, a.x32, dz16, (long)R * l.N, s));
-        CK(mk_gemm(rm(dz16, l.N, a.y16, 2 * H, R, l.N, 2 * H, Gr + l.btw, 2 * H, Gr + l.btb), s));
-        { GemmArgs g = nt(dz16, l.N, l.btT16, (l.N + 7) / 8 * 8, R, 2 * H, l.N, nullptr); g.C32 = m->dy32; g.ldc = 2 * H; CK(mk_gemm(g, s)); }
+        CK(mk_tanh_bwd(m->dx32, a.x32, dz16, (long)Ro * l.N, s));
+        CK(mk_gemm(rm(dz16, l.N, a.ys16, 2 * H, Ro, l.N, 2 * H, Gr + l.btw, 2 * H, Gr + l.btb), s));
+        { GemmArgs g = nt(dz16, l.N, l.btT16, (l.N + 7) / 8 * 8, Ro, 2 * H, l.N, nullptr); g.C32 = m->sub[i] > 1 ? m->dys32 : m->dy32; g.ldc = 2 * H; CK(mk_gemm(g, s)); }
+        if (m->sub[i] > 1) CK(mk_subsample_rows_bwd(m->dys32, m->dy32, B, Tp, To, m->sub[i], 2 * H, s));     // the dropped frames carry no gradient
         // recurrence
-        LstmStepArgs st{}; st.B = B; st.T = Tp; st.H = H; st.KP = m->KP; st.lens = m->lens; st.y16 = a.y16; st.dy = m->dy32;
+        LstmStepArgs st{}; st.B = B; st.T = Tp; st.H = H; st.KP = m->KP; st.lens = m->lens_l[i]; st.y16 = a.y16; st.dy = m->dy32;
         for (int d = 0; d < 2; ++d) {
             st.h16[d][0] = m->h16[d][0]; st.h16[d][1] = m->h16[d][1]; st.whh16[d] = l.d[d].whh16; st.whhT16[d] = l.d[d].whhT16;
             st.gx[d] = a.gx[d]; st.act[d] = a.act[d]; st.c[d] = a.c[d]; st.cstate[d] = m->cstate[d]; st.dz16[d] = a.dzg[d];
@@ -211,7 +226,7 @@ int backward(masr_blstm* m, const float* xs, hipStream_t s) {
         }
     }
     // VGG front-end
-    CK(mk_cast_bf16(m->dx32, m->dp2, (long)R * m->F, s));
+    CK(mk_cast_bf16(m->dx32, m->dp2, (long)m->rows * m->F, s));
     auto wgrad = [&](const bf16* in, const bf16* dy, const ConvP& cv, int Hh, int Ww) -> int {
         ConvWgradArgs wa{}; wa.in = in; wa.dy = dy; wa.dw = Gr + cv.w; wa.db = Gr + cv.b; wa.slab = m->slab; wa.B = B; wa.H = Hh; wa.W = Ww; wa.CIN = cv.CI; wa.COUT = cv.CO;
         return mk_conv3x3_wgrad(wa, s);
@@ -237,12 +252,16 @@ int backward(masr_blstm* m, const float* xs, hipStream_t s) {
 extern "C" {
 
 masr_blstm* masr_blstm_create(const masr_blstm_config* cfg) {
-    if (!cfg || cfg->nlayers < 1 || cfg->enc_dim < 8 || cfg->enc_dim % 8 || cfg->proj_dim % 8 || cfg->enc_odim % 8 || cfg->idim < 4 || cfg->odim < 2) {
+    if (!cfg || cfg->nlayers < 1 || cfg->nlayers > 8 || cfg->enc_dim < 8 || cfg->enc_dim % 8 || cfg->proj_dim % 8 || cfg->enc_odim % 8 || cfg->idim < 4 || cfg->odim < 2) {
         mk_set_error("masr_blstm_create", "bad config (enc_dim / proj_dim / odim of the encoder must be multiples of 8)"); return nullptr;
     }
     masr_blstm* m = new masr_blstm();
     m->cfg = *cfg; m->D = cfg->idim; m->C = cfg->odim; m->H = cfg->enc_dim; m->KP = (cfg->enc_dim + 31) / 32 * 32; m->L = cfg->nlayers;
     m->Cp8 = (cfg->odim + 7) / 8 * 8;
+    for (int i = 0; i < m->L; ++i) {
+        m->sub[i] = cfg->sample_rate[i] > 0 ? cfg->sample_rate[i] : 1;
+        if (m->sub[i] > 8) { mk_set_error("masr_blstm_create", "sample_rate: 1 .. 8 per layer"); delete m; return nullptr; }
+    }
     const int idx[4] = {0, 2, 5, 7}; const int co[4] = {128, 128, 256, 256}, ci[4] = {1, 128, 128, 256};
     for (int i = 0; i < 4; ++i) {
         ConvP& c = m->conv[i]; c.CO = co[i]; c.CI = ci[i]; c.k16 = c.d16 = nullptr;
@@ -343,7 +362,7 @@ int masr_blstm_run_batch(masr_blstm* m, const float* xs, const int64_t* ilens, c
     Arena ar{m->ws, m->ws_bytes, m->persist_bytes};
     plan_acts(m, ar, B, T, maxS);
     if (ar.off > m->ws_bytes) { mk_set_error("masr_blstm_run_batch", "workspace too small (masr_blstm_workspace_bytes)"); return -2; }
-    if ((int64_t)B * (maxL + 5) + 3 * B > (1 << 16)) { mk_set_error("masr_blstm_run_batch", "staging buffer too small"); return -1; }
+    if ((int64_t)B * (maxL + 5) + 3 * B + (int64_t)B * (m->L + 1) > (1 << 16)) { mk_set_error("masr_blstm_run_batch", "staging buffer too small"); return -1; }
     HIP_CHECK_RET(hipEventSynchronize(m->stage_ev));
     // targets [sos] + y + [eos] with sos = eos = odim - 1 (blstm_trainer.py:56-59); enc_lens = ceil(ceil(ilens/2)/2)
     int* h = m->h_stage; int* h_len = h; int* h_off = h + B; int* h_tl = h + 2 * B; int* h_t = h + 3 * B;
@@ -362,13 +381,16 @@ int masr_blstm_run_batch(masr_blstm* m, const float* xs, const int64_t* ilens, c
         h_t[dst++] = eos;
         src += olens[b];
     }
-    HIP_CHECK_RET(hipMemcpyAsync(m->lens, h_len, sizeof(int) * B, hipMemcpyHostToDevice, s));
+    int* h_ll = h_t + dst;                                      // enc_lens entering every layer + leaving the last: (len + 1) / sub (encoder.py:121)
+    for (int b = 0; b < B; ++b) h_ll[b] = h_len[b];
+    for (int i = 0; i < m->L; ++i) for (int b = 0; b < B; ++b) h_ll[(i + 1) * B + b] = m->sub[i] > 1 ? (h_ll[i * B + b] + 1) / m->sub[i] : h_ll[i * B + b];
+    HIP_CHECK_RET(hipMemcpyAsync(m->lens, h_ll, sizeof(int) * B * (m->L + 1), hipMemcpyHostToDevice, s));
     HIP_CHECK_RET(hipMemcpyAsync(m->tgt_off, h_off, sizeof(int) * B, hipMemcpyHostToDevice, s));
     HIP_CHECK_RET(hipMemcpyAsync(m->tgt_len, h_tl, sizeof(int) * B, hipMemcpyHostToDevice, s));
     HIP_CHECK_RET(hipMemcpyAsync(m->tgt, h_t, sizeof(int) * dst, hipMemcpyHostToDevice, s));
     HIP_CHECK_RET(hipEventRecord(m->stage_ev, s));
     CK(forward(m, xs, s));
-    CK(mk_ctc_loss(m->logits, m->tgt, m->tgt_off, m->lens, m->tgt_len, m->Tp, B, m->C, 0, m->nll, m->stats, m->dlogits, m->ctc_work, maxS, s, 1));
+    CK(mk_ctc_loss(m->logits, m->tgt, m->tgt_off, m->lens_l[m->L], m->tgt_len, m->Ts[m->L], B, m->C, 0, m->nll, m->stats, m->dlogits, m->ctc_work, maxS, s, 1));
     m->have = true;
     if (flags & MASR_TRAIN) CK(backward(m, xs, s));
     return 0;
@@ -385,7 +407,8 @@ int masr_blstm_forward(masr_blstm* m, const float* xs, const int64_t* ilens, int
         if (ilens[b] < 1 || ilens[b] > T) { mk_set_error("masr_blstm_forward", "ilens must be in [1, T]"); return -1; }
         m->h_stage[b] = (int)(((ilens[b] + 1) / 2 + 1) / 2);
     }
-    HIP_CHECK_RET(hipMemcpyAsync(m->lens, m->h_stage, sizeof(int) * B, hipMemcpyHostToDevice, s));
+    for (int i = 0; i < m->L; ++i) for (int b = 0; b < B; ++b) m->h_stage[(i + 1) * B + b] = m->sub[i] > 1 ? (m->h_stage[i * B + b] + 1) / m->sub[i] : m->h_stage[i * B + b];
+    HIP_CHECK_RET(hipMemcpyAsync(m->lens, m->h_stage, sizeof(int) * B * (m->L + 1), hipMemcpyHostToDevice, s));
     HIP_CHECK_RET(hipEventRecord(m->stage_ev, s));
     CK(forward(m, xs, s));
     m->have = true;
@@ -400,7 +423,7 @@ int masr_blstm_read_stats(masr_blstm* m, float out[4], void* stream) {
 }
 int masr_blstm_last_logits(masr_blstm* m, float** logits, int32_t** enc_lens, int* B, int* Tp, int* C) {
     if (!m->have) { mk_set_error("masr_blstm_last_logits", "run a batch first"); return -1; }
-    *logits = m->logits; *enc_lens = m->lens; *B = m->B; *Tp = m->Tp; *C = m->C;
+    *logits = m->logits; *enc_lens = m->lens_l[m->L]; *B = m->B; *Tp = m->Ts[m->L]; *C = m->C;      // (frames / lengths LEAVING the encoder)
     return 0;
 }
 int masr_blstm_clip_grads(masr_blstm* m, float max_norm, void* stream) {

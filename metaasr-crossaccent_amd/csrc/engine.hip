@@ -953,14 +953,17 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
     m->step++;
     const float inv_ntot = 1.0f / (float)ntot;
     std::memcpy(h_len + B, &c.seed, 4); std::memcpy(h_len + B + 1, &inv_ntot, 4);     // Acts::meta
-    {   // the decoder-input positions grouped by token (counting sort, stable: ascending position inside a token) for the embedding backward
+    {   // the decoder-input positions grouped by token (counting sort, stable: ascending position inside a token) for the embedding backward.
+        // Only the positions 0 .. olens[b] of an utterance: behind them the inputs are eos padding whose gradient is exactly zero (their
+        // outputs carry no loss, and the causal mask keeps every valid output from reading them) -- hundreds of hits on ONE table row
+        // that a single workgroup column would sum for nothing.
         int* h_order = h_len + B + 8; int* h_start = h_order + (int64_t)B * L;
-        const int rd = B * L, V = m->C;
+        const int V = m->C;
         for (int v = 0; v <= V; ++v) h_start[v] = 0;
-        for (int r = 0; r < rd; ++r) h_start[h_in[r] + 1]++;
+        for (int b = 0; b < B; ++b) for (int l = 0; l <= (int)olens[b]; ++l) h_start[h_in[b * L + l] + 1]++;
         for (int v = 0; v < V; ++v) h_start[v + 1] += h_start[v];
         // (fill with a running cursor kept in the start array itself, then shift it back)
-        for (int r = 0; r < rd; ++r) h_order[h_start[h_in[r]]++] = r;
+        for (int b = 0; b < B; ++b) for (int l = 0; l <= (int)olens[b]; ++l) h_order[h_start[h_in[b * L + l]]++] = b * L + l;
         for (int v = V; v > 0; --v) h_start[v] = h_start[v - 1];
         h_start[0] = 0;
     }

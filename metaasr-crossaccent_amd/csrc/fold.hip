@@ -30,12 +30,13 @@ __global__ __launch_bounds__(256) void backward_folds_kernel(const FoldJobs j) {
     const int ln_x = (2 * j.E + 31) / 32, n_ln = ln_x * j.ln.n;
     if (b < n_ln) { const LnReduceDesc& d = j.ln.p[b / ln_x]; ln_bwd_reduce_body(d.slab, d.nblocks, d.dgamma, d.dbeta, j.E, b % ln_x); return; }
     b -= n_ln;
-    if (j.conv1.dw && b < 40) conv1_wgrad_reduce_body(j.conv1.slab, j.conv1.nblocks, j.conv1.dw, j.conv1.db, nullptr, b, 0, 1);
+    if (j.conv1.dw && b < 40) conv1_wgrad_reduce256_body(j.conv1.slab, j.conv1.nblocks, j.conv1.dw, j.conv1.db, b);
 }
 
 }  // namespace
 
 int mk_backward_folds(const FoldJobs& j, hipStream_t s) {
+    if (j.conv1.dw && j.conv1.nblocks > 256) { mk_set_error("mk_backward_folds", "conv1 slab: at most 256 rows"); return -1; }
     if (j.nconv < 0 || j.nconv > 3 || j.ln.n < 0 || j.ln.n > LN_GROUP_MAX || (j.embed.dtable && j.embed.E % 64)) { mk_set_error("mk_backward_folds", "bad job list"); return -1; }
     long blocks = j.embed.dtable ? (long)j.embed.V * (j.embed.E / 64) : 0;
     for (int k = 0; k < j.nconv; ++k) blocks += (j.conv[k].COUT * 9 * j.conv[k].CIN + j.conv[k].COUT + 63) / 64;

@@ -65,6 +65,31 @@ __device__ __forceinline__ void conv1_wgrad_reduce_body(const float* __restrict_
     }
 }
 
+// the two passes above (C1_RSPLIT = 16 row chunks, then their 16 partials) in ONE block per 16 columns, for slabs of at most 256 rows (the
+// fused conv1 weight gradient writes one row per persistent workgroup): with <= 16 rows per chunk the first pass's thread l of chunk c holds
+// exactly one row, so a chunk's partial is the sequential sum of its rows and the result the sequential sum of the chunks -- thread l sums
+// chunk l here, thread 0..15 the sixteen partials: the same additions in the same order, bit for bit.
+__device__ __forceinline__ void conv1_wgrad_reduce256_body(const float* __restrict__ slab, int nblocks, float* __restrict__ dw, float* __restrict__ db, int bx) {
+    __shared__ float part[16][17];
+    const int o = threadIdx.x & 15, l = threadIdx.x >> 4, i = bx * 16 + o;
+    const int rows = (nblocks + 15) / 16;
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int b = l * rows + r; v[r] = (r < rows && b < nblocks) ? slab[(long)b * 640 + i] : 0.f; }
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += v[r];
+    part[l][o] = s;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += part[k][threadIdx.x];
+        const int co = i / 10, k = i % 10;
+        if (k < 9) dw[co * 9 + k] = t; else db[co] = t;
+    }
+}
+
 __device__ __forceinline__ void ln_bwd_reduce_body(const float* __restrict__ slab, int nblocks, float* __restrict__ dgamma,
                                                    float* __restrict__ dbeta, int E, int bx) {
     const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;

@@ -277,6 +277,10 @@ int mk_cast_rows_pad(const float* x, bf16* y, long rows, int C, int Cp, hipStrea
 int mk_tanh_fwd(const float* x, float* y32, bf16* y16, long n, hipStream_t s);
 int mk_tanh_bwd(const float* dy, const float* y, bf16* dx16, long n, hipStream_t s);
 int mk_mask_rows(float* x32, bf16* x16, const int* lens, int B, int T, int C, hipStream_t s);
+// time sub-sampling between BLSTM-P layers (ys_pad[:, ::sub], src/modules/encoder.py:118-121): ys[b][t'] = y[b][t' * sub], C % 8 == 0;
+// backward: dy[b][t] = t % sub == 0 ? dys[b][t / sub] : 0 (fp32, C % 4 == 0)
+int mk_subsample_rows(const bf16* y, bf16* ys, int B, int Tin, int Tout, int sub, int C, hipStream_t s);
+int mk_subsample_rows_bwd(const float* dys, float* dy, int B, int Tin, int Tout, int sub, int C, hipStream_t s);
 
 // ---------------------------------------------------------------- features (fbank.hip)
 // Kaldi-style log-mel filterbank: wav fp32 (PCM scale, utterances concatenated), wav_off [B+1], row_off [B] (first output

@@ -245,6 +245,36 @@ int mk_tanh_bwd(const float* dy, const float* y, bf16* dx16, long n, hipStream_t
     hipLaunchKernelGGL(tanh_bwd_kernel, dim3(nblk(n)), dim3(256), 0, s, dy, y, dx16, n);
     return LAUNCH_OK();
 }
+namespace {
+__global__ void subsample_rows_kernel(const bf16* __restrict__ y, bf16* __restrict__ ys, int B, int Tin, int Tout, int sub, int C8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * Tout * C8) return;
+    const int c = (int)(i % C8); const long row = i / C8; const int t = (int)(row % Tout); const long b = row / Tout;
+    st8(ys + i * 8, ld8(y + ((b * Tin + (long)t * sub) * C8 + c) * 8));
+}
+__global__ void subsample_rows_bwd_kernel(const float* __restrict__ dys, float* __restrict__ dy, int B, int Tin, int Tout, int sub, int C4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * Tin * C4) return;
+    const int c = (int)(i % C4); const long row = i / C4; const int t = (int)(row % Tin); const long b = row / Tin;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (t % sub == 0 && t / sub < Tout) v = *reinterpret_cast<const f32x4*>(dys + ((b * Tout + t / sub) * C4 + c) * 4);
+    *reinterpret_cast<f32x4*>(dy + i * 4) = v;
+}
+}  // namespace
+int mk_subsample_rows(const bf16* y, bf16* ys, int B, int Tin, int Tout, int sub, int C, hipStream_t s) {
+    if (C % 8 || sub < 1 || Tout != (Tin + sub - 1) / sub) { mk_set_error("mk_subsample_rows", "C % 8 == 0, Tout == ceil(Tin / sub)"); return -1; }
+    const long n = (long)B * Tout * (C / 8);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(subsample_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, ys, B, Tin, Tout, sub, C / 8);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int mk_subsample_rows_bwd(const float* dys, float* dy, int B, int Tin, int Tout, int sub, int C, hipStream_t s) {
+    if (C % 4 || sub < 1 || Tout != (Tin + sub - 1) / sub) { mk_set_error("mk_subsample_rows_bwd", "C % 4 == 0, Tout == ceil(Tin / sub)"); return -1; }
+    const long n = (long)B * Tin * (C / 4);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(subsample_rows_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dys, dy, B, Tin, Tout, sub, C / 4);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 int mk_mask_rows(float* x32, bf16* x16, const int* lens, int B, int T, int C, hipStream_t s) {
     hipLaunchKernelGGL(mask_rows_kernel, dim3(nblk((long)B * T * C)), dim3(256), 0, s, x32, x16, lens, B, T, C);
     return LAUNCH_OK();

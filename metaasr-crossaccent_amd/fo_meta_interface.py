@@ -44,6 +44,16 @@ class _Resolved:
         return self.info, self.grad_norm
 
 
+def slot_cap(tasks_per_gpu, meta_batch_size, world, collective, no_slot_cap=False):
+    """task slots a rank actually runs: several ranks AND several waves per meta-step means the all-reduce of wave w (RCCL's own stream)
+    runs beside the tasks of wave w+1, i.e. a fifth stream with work queued -- three task slots keep the total at the four that run side
+    by side on the hardware queues (DESIGN: concurrent task slots).  Also reported by bench.py (meta_step.slot_cap)."""
+    rounds = -(-meta_batch_size // world)
+    if collective and tasks_per_gpu > 3 and rounds > tasks_per_gpu and not no_slot_cap:
+        return 3
+    return tasks_per_gpu
+
+
 class FOMetaASRInterface(PretrainInterface):
     def __init__(self, config, paras, id2accent):
         super().__init__(config, paras, id2accent)
@@ -74,12 +84,11 @@ class FOMetaASRInterface(PretrainInterface):
             # and more than four streams with work queued take turns on the hardware queues anyway
             raise ValueError(f"--tasks_per_gpu {self.tasks_per_gpu}: at most 8 task slots per GPU (4 is the most that pays)")
         rounds = -(-self.meta_batch_size // self.sharder.world)
-        if self.sharder.collective and self.tasks_per_gpu > 3 and rounds > self.tasks_per_gpu and not getattr(paras, 'no_slot_cap', False):
-            # several ranks AND several waves per meta-step: the all-reduce of wave w (RCCL's own stream) runs beside the tasks of
-            # wave w+1, i.e. a fifth stream with work queued -- three task slots keep the total at the four that run side by side
-            logger.notice(f"tasks_per_gpu {self.tasks_per_gpu} -> 3: {rounds} tasks per rank and meta-step run as several waves whose "
+        capped = slot_cap(self.tasks_per_gpu, self.meta_batch_size, self.sharder.world, self.sharder.collective, getattr(paras, 'no_slot_cap', False))
+        if capped != self.tasks_per_gpu:
+            logger.notice(f"tasks_per_gpu {self.tasks_per_gpu} -> {capped}: {rounds} tasks per rank and meta-step run as several waves whose "
                           f"all-reduce overlaps the next wave (four-queue rule, DESIGN 6.2; --no_slot_cap keeps the setting)")
-            self.tasks_per_gpu = 3
+            self.tasks_per_gpu = capped
         self._slots = None
         self._n_reduces = 0                                          # all-reduces this rank has issued in the current meta-step
         # task order: the reference's global `random` stream (:136).  Every rank consumes that stream identically (data

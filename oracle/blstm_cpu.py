@@ -81,8 +81,9 @@ def _lstm_dir(x, lens, wih, whh, bih, bhh, reverse):
 def forward(p, cfg, xs_pad, ilens):
     """-> (logits [B, T', odim], enc_lens [B])"""
     e = cfg["encoder"]
-    nl = len(e["sample_rate"].split("_"))
-    assert all(int(v) == 1 for v in e["sample_rate"].split("_")) and all(float(v) == 0 for v in e["dropout"].split("_"))
+    rates = [int(v) for v in e["sample_rate"].split("_")]
+    nl = len(rates)
+    assert all(float(v) == 0 for v in e["dropout"].split("_"))
     x = xs_pad.unsqueeze(1)                                                        # [B,1,T,D]
     x = F.relu(F.conv2d(x, p["encoder.vgg.0.weight"], p["encoder.vgg.0.bias"], padding=1))
     x = F.relu(F.conv2d(x, p["encoder.vgg.2.weight"], p["encoder.vgg.2.bias"], padding=1))
@@ -98,6 +99,9 @@ def forward(p, cfg, xs_pad, ilens):
         yb = _lstm_dir(x, lens, p[pre + "weight_ih_l0_reverse"], p[pre + "weight_hh_l0_reverse"], p[pre + "bias_ih_l0_reverse"],
                        p[pre + "bias_hh_l0_reverse"], True)
         y = torch.cat([yf, yb], dim=2)
+        if rates[i] > 1:                                                           # RNNP.forward, encoder.py:118-121 (:149-152)
+            y = y[:, ::rates[i]]
+            lens = (lens + 1) // rates[i]
         x = torch.tanh(y @ p[f"encoder.blstm.bt{i}.weight"].t() + p[f"encoder.blstm.bt{i}.bias"])
     mask = (torch.arange(x.size(1)).unsqueeze(0) >= lens.unsqueeze(1)).unsqueeze(-1)
     x = x.masked_fill(mask, 0.0)

@@ -960,6 +960,45 @@ def gen_blstm_goldens():
     print("blstm_tiny.npz loss", out["ragged/loss"], "grad norm", out["ragged/grad_norm"])
 
 
+BLSTM_SUB = {"optimizer": {"type": "SGD"}, "optimizer_opt": {"lr": 0.01, "momentum": 0.9, "nesterov": True},
+             "encoder": {"idim": 83, "enc_dim": 40, "proj_dim": 40, "odim": 40, "sample_rate": "1_2_2", "dropout": "0_0_0"}}
+
+
+def gen_blstm_subsample_goldens():
+    """The reference's RNNP with time sub-sampling between the BLSTM layers (sample_rate 1_2_2: ys_pad[:, ::sub], enc_lens -> (len + 1) // sub,
+    src/modules/encoder.py:118-121) + the loss of BLSTMTrainer.run_batch; lengths chosen so that odd and even frame counts both occur."""
+    from oracle import blstm_cpu
+    from src.model.blstm.mono_blstm import MonoBLSTM
+    id2char = ["<blank>"] + [f"u{i}" for i in range(1, 366)] + ["</s>"]
+    model = MonoBLSTM(id2char, BLSTM_SUB)
+    sd = blstm_cpu.deterministic_state_dict(BLSTM_SUB, ODIM, seed=12)
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    model.load_state_dict(sd)
+    model.train()
+    out = {"state_dict_keys": np.array(list(sd.keys()))}
+    for tag, (ilens, olens) in {"ragged": ([118, 101, 77, 60], [4, 3, 2, 2]), "single": ([90], [3])}.items():
+        xs, il, ys, ol = synth_batch(23, ilens, olens)
+        sos = ys[0].new([model.sos_id]); eos = ys[0].new([model.eos_id])
+        y_true = torch.cat([torch.cat([sos, y, eos], dim=0) for y in ys])
+        pred, enc_lens = model(xs, il)
+        logp = torch.nn.functional.log_softmax(pred, dim=-1)
+        loss = torch.nn.CTCLoss(blank=0, reduction='mean', zero_infinity=True)(logp.transpose(0, 1).contiguous(), y_true, enc_lens.cpu().long(), (ol + 2).long())
+        model.zero_grad()
+        loss.backward()
+        out[f"{tag}/loss"] = np.float64(loss.item())
+        out[f"{tag}/logits"] = pred.detach().numpy().copy()
+        out[f"{tag}/enc_lens"] = enc_lens.numpy().copy()
+        for n, prm in model.named_parameters():
+            out[f"{tag}/grad/{n}"] = flat_checks(prm.grad)
+        out[f"{tag}/gradfull/head.bias"] = model.head.bias.grad.numpy().copy()
+        out[f"{tag}/gradfull/encoder.blstm.bt1.bias"] = model.encoder.blstm.bt1.bias.grad.numpy().copy()
+        out[f"{tag}/gradfull/encoder.blstm.rnn2.weight_hh_l0_reverse"] = model.encoder.blstm.rnn2.weight_hh_l0_reverse.grad.numpy().copy()
+        gn = torch.sqrt(sum((prm.grad ** 2).sum() for prm in model.parameters()))
+        out[f"{tag}/grad_norm"] = np.float64(gn.item())
+    np.savez_compressed(OUT / "blstm_sub.npz", **out)
+    print("blstm_sub.npz loss", out["ragged/loss"], "enc_lens", out["ragged/enc_lens"], "logits", out["ragged/logits"].shape)
+
+
 def gen_blstm_mono_goldens():
     """BASELINE configs[0]: train.py mono-accent, config/blstm CTC on a toy memmap shard -- the reference's
     get_trainer(MonoASRInterface...) from src/blstm_trainer.py, two epochs of clip-5 + SGD(nesterov) steps."""
@@ -1185,7 +1224,7 @@ def main():
     sys.path.insert(0, str(REF))
     torch.set_num_threads(4)
     gens = [gen_masks_noam, gen_sampler_goldens, gen_ctc_goldens, gen_init_goldens, gen_metric_goldens, gen_model_goldens,
-            gen_fomaml_goldens, gen_fomaml_cfg3_goldens, gen_fomaml_8acc_goldens, gen_chain_goldens, gen_multi_goldens, gen_mono_goldens, gen_tester_goldens, gen_blstm_goldens,
+            gen_fomaml_goldens, gen_fomaml_cfg3_goldens, gen_fomaml_8acc_goldens, gen_chain_goldens, gen_multi_goldens, gen_mono_goldens, gen_tester_goldens, gen_blstm_goldens, gen_blstm_subsample_goldens,
             gen_blstm_mono_goldens, gen_blstm_tester_goldens, gen_hkust_fullsize_goldens]
     only = set(sys.argv[1:])                       # e.g.  python oracle/make_goldens.py gen_fomaml_cfg3_goldens
     for g in gens:

@@ -63,6 +63,47 @@ def test_run_batch_vs_reference_golden(sd, golden_dir, tag, ilens, olens):
     assert abs(gn / float(g[f"{tag}/grad_norm"]) - 1) < 3e-2
 
 
+@pytest.mark.parametrize("tag,ilens,olens", [("ragged", [118, 101, 77, 60], [4, 3, 2, 2]), ("single", [90], [3])])
+def test_time_subsampling_vs_reference_golden(golden_dir, tag, ilens, olens):
+    """encoder.sample_rate 1_2_2: every second frame behind BLSTM layers 1 and 2 (RNNP.forward, src/modules/encoder.py:118-121), against the
+    reference's own MonoBLSTM (tests/golden/blstm_sub.npz): output lengths exactly, logits, CTC loss, gradients; and every gradient
+    tensor against the oracle with autograd."""
+    from oracle.make_goldens import BLSTM_SUB
+    g = np.load(golden_dir / "blstm_sub.npz")
+    sds = blstm_cpu.deterministic_state_dict(BLSTM_SUB, ODIM, seed=12)
+    xs, il, ys, ol = synth_batch(23, ilens, olens)
+    eng = BlstmEngine(BLSTM_SUB, ODIM)
+    eng.load_state_dict(sds)
+    eng.run_batch(xs, il, ys, ol, train=True)
+    st = eng.read_stats()
+    logits, lens = eng.last_logits()
+    ref_logits = torch.from_numpy(g[f"{tag}/logits"])
+    assert lens.cpu().tolist() == g[f"{tag}/enc_lens"].tolist()
+    assert logits.shape[1] >= ref_logits.shape[1]
+    got_l = logits.cpu()[:, :ref_logits.shape[1]]
+    rel_logits = float((got_l - ref_logits).norm() / ref_logits.norm())
+    rel_loss = abs(st["loss"] - float(g[f"{tag}/loss"])) / float(g[f"{tag}/loss"])
+    print(f"{tag}: loss {st['loss']:.5f} vs reference {float(g[f'{tag}/loss']):.5f} (rel {rel_loss:.1e}); logits rel-L2 {rel_logits:.1e}")
+    assert rel_loss < 1e-3 and rel_logits < 2e-2
+    got = eng.state_dict(flat=eng.grads)
+    for n in ("head.bias", "encoder.blstm.bt1.bias", "encoder.blstm.rnn2.weight_hh_l0_reverse"):
+        ref = torch.from_numpy(g[f"{tag}/gradfull/{n}"])
+        rel = float((got[n].cpu() - ref).norm() / ref.norm())
+        print(f"   grad {n}: rel-L2 {rel:.2e}")
+        assert rel < 0.15
+    # oracle autograd on the same batch: every tensor
+    p = {k: v.clone().requires_grad_(True) for k, v in sds.items()}
+    loss, _, _ = blstm_cpu.run_batch(p, BLSTM_SUB, (xs, il, ys, ol.clone()), ODIM)
+    loss.backward()
+    for n in sds:
+        ref = p[n].grad
+        if float(ref.norm()) > 1e-6:
+            rel = float((got[n].cpu() - ref).norm() / ref.norm())
+            assert rel < 0.15, (n, rel)
+    gn = float(torch.cat([got[n].reshape(-1) for n in sds]).double().norm())
+    assert abs(gn / float(g[f"{tag}/grad_norm"]) - 1) < 3e-2
+
+
 def test_gradients_vs_oracle_per_tensor(sd):
     """every parameter gradient against the CPU oracle (fp32): cosine and norm per tensor"""
     xs, il, ys, ol = synth_batch(21, [61, 50, 38, 30], [7, 5, 4, 3])

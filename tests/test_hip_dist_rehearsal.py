@@ -71,6 +71,8 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert ms["tasks"] == 4 and ms["allreduces_per_meta_step"] == 2 and ms["ms"] >= ms["ms_without_exchange"] > 0 and ms["allreduce_ms_isolated"] > 0
     cs = ms["concurrent_slots"]                                                       # 2 ranks x 2 task slots, one all-reduce of the local sum
     assert cs["tasks_per_gpu"] == 2 and cs["tasks"] == 4 and cs["allreduces_per_meta_step"] == 1 and cs["ms"] > 0
+    assert ms["transport"] == "pg_gloo" and ms["slot_cap"]["tasks_per_gpu_run_by_pretrain_cli"] == 2
+    assert ms["evaluate"]["eval_ms_rank0"] > 0 and ms["evaluate"]["idle_ms_other_ranks"] >= ms["evaluate"]["eval_ms_rank0"] * 0.5     # rank 1 waited while rank 0 evaluated
     assert "roofline" in d and d["roofline"]["slot"] in d["roofline"]["launches"]
     bad = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1"], cwd=tmp_path, env=dict(env, WORLD_SIZE="1"),
                          capture_output=True, text=True, timeout=120)

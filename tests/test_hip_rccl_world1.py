@@ -93,3 +93,9 @@ def test_bench_collective_legs_through_rccl_with_one_rank(tmp_path):
     ms = d["meta_step"]
     assert ms["backend"] == "rccl" and ms["allreduces_per_meta_step"] == 2 and ms["allreduce_ms_isolated"] > 0 and ms["ms"] > 0
     assert ms["concurrent_slots"]["allreduces_per_meta_step"] == 1 and ms["concurrent_slots"]["ms"] > 0
+    # a first multi-GPU run describes itself: the transport (default: ProcessGroupNCCL; the C-ABI exchange is opt-in), the slot cap the CLI
+    # would apply, and what the quirk-kept evaluate() costs
+    assert ms["transport"] == "pg_nccl" and "MASR_NATIVE_ALLREDUCE" in ms["transport_note"]
+    assert ms["slot_cap"]["tasks_per_gpu_asked"] == 2 and ms["slot_cap"]["tasks_per_gpu_run_by_pretrain_cli"] == 2
+    ev = ms["evaluate"]
+    assert ev["dev_batches"] == 8 and ev["eval_ms_rank0"] > 0 and ev["idle_ms_other_ranks"] == 0.0 and "fix_snapshot_meta_weights" in ev["mode"]

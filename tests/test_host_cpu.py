@@ -235,3 +235,21 @@ def test_data_stream_state_round_trip(tmp_path, is_bucket):
     dc2.load_state_dict(saved["data"])
     restore_rng(saved["rng"])
     assert draw(dc2, 12) == after
+
+
+def test_slot_cap_rule_and_transport_names():
+    """what bench.py reports as meta_step.slot_cap / meta_step.transport (fo_meta_interface.slot_cap, parallel.TaskSharder.transport)"""
+    from masr_amd.fo_meta_interface import slot_cap
+    from masr_amd.parallel import TaskSharder
+    assert slot_cap(4, 8, 1, False) == 4                       # one rank, no collective: nothing to make room for
+    assert slot_cap(4, 8, 8, True) == 4                        # one task per rank and meta-step: a single wave
+    assert slot_cap(4, 8, 1, True) == 3 and slot_cap(4, 16, 2, True) == 3          # several waves whose all-reduce overlaps the next wave
+    assert slot_cap(4, 8, 1, True, no_slot_cap=True) == 4 and slot_cap(3, 8, 1, True) == 3 and slot_cap(2, 8, 2, True) == 2
+    assert TaskSharder().transport == "none"
+    assert TaskSharder(0, 2, "gloo").transport == "pg_gloo" and TaskSharder(0, 8, "nccl").transport == "pg_nccl"
+    import os
+    os.environ["MASR_NATIVE_ALLREDUCE"] = "1"
+    try:
+        assert TaskSharder(0, 8, "nccl").transport == "native" and TaskSharder(0, 8, "gloo").transport == "pg_gloo"
+    finally:
+        del os.environ["MASR_NATIVE_ALLREDUCE"]

@@ -309,6 +309,29 @@ def test_blstm_oracle_matches_reference(golden_dir, tag, ilens, olens):
                                g[f"{tag}/gradfull/encoder.blstm.rnn0.weight_hh_l0_reverse"], rtol=1e-3, atol=1e-7)
 
 
+@pytest.mark.parametrize("tag,ilens,olens", [("ragged", [118, 101, 77, 60], [4, 3, 2, 2]), ("single", [90], [3])])
+def test_blstm_oracle_with_time_subsampling_matches_reference(golden_dir, tag, ilens, olens):
+    """sample_rate 1_2_2 (RNNP.forward, src/modules/encoder.py:118-121: ys_pad[:, ::sub], enc_lens -> (len + 1) // sub): the oracle against
+    the real MonoBLSTM -- output lengths, logits, CTC loss, every parameter gradient."""
+    from oracle import blstm_cpu
+    from oracle.make_goldens import BLSTM_SUB, ODIM, flat_checks, synth_batch
+    g = np.load(golden_dir / "blstm_sub.npz")
+    sd = blstm_cpu.deterministic_state_dict(BLSTM_SUB, ODIM, seed=12)
+    assert list(sd.keys()) == g["state_dict_keys"].tolist()
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xs, il, ys, ol = synth_batch(23, ilens, olens)
+    loss, logits, lens = blstm_cpu.run_batch(p, BLSTM_SUB, (xs, il, ys, ol), ODIM)
+    loss.backward()
+    assert lens.tolist() == g[f"{tag}/enc_lens"].tolist()
+    ref = g[f"{tag}/logits"]                                            # (the reference's time axis ends at the longest utterance's length)
+    np.testing.assert_allclose(logits.detach().numpy()[:, :ref.shape[1]], ref, rtol=1e-4, atol=2e-5)
+    assert abs(float(loss) - float(g[f"{tag}/loss"])) < 1e-5 * float(g[f"{tag}/loss"])
+    for n in sd:
+        np.testing.assert_allclose(flat_checks(p[n].grad), g[f"{tag}/grad/{n}"], rtol=2e-3, atol=1e-6, err_msg=n)
+    for n in ("head.bias", "encoder.blstm.bt1.bias", "encoder.blstm.rnn2.weight_hh_l0_reverse"):
+        np.testing.assert_allclose(p[n].grad.numpy(), g[f"{tag}/gradfull/{n}"], rtol=1e-3, atol=1e-7)
+
+
 def test_fomaml_8acc_oracle_matches_reference(golden_dir, tmp_path, monkeypatch):
     """BASELINE configs[3] in one process (pretrain.py --algo fomaml, EIGHT accents, meta_batch_size 8, meta_k 1), run by the
     reference from its own seed-531 initialisation (tests/golden/fomaml_8acc.npz): the oracle's meta loop over the product's
