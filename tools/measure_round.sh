@@ -18,3 +18,9 @@ find $O/prof_k4 $O/prof_single -name "*kernel_trace.csv" -delete      # (the per
 rm -rf $O/prof_blstm
 rocprofv3 --kernel-trace --stats -d $O/prof_blstm -o b --output-format csv -- python3 tools/bench_blstm.py --steps 20 --warm 3 --out gpurun_out/blstm.json > $O/prof_blstm.log 2>&1 && echo "blstm profile done"
 find $O/prof_blstm -name "*kernel_trace.csv" -delete
+# effective shader clock per conv launch: GRBM_GUI_ACTIVE / 8 / wall on back-to-back dispatches of >= 1 ms (B = 256: the quotient reads high on short ones)
+rm -rf $O/pmc_grbm_conv $O/pmc_grbm
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_grbm_conv -o p --output-format csv -- python3 tools/bench_conv.py 256 150 > $O/pmc_grbm_conv.log 2>&1 && echo "pmc grbm conv done"
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_grbm -o p --output-format csv -- python3 bench.py --steps 40 --warmup 10 $Q --tasks-per-gpu 1 > $O/pmc_grbm.log 2>&1 && echo "pmc grbm step done"
+find $O/pmc_grbm_conv $O/pmc_grbm -name "*kernel_trace.csv" -delete
+python3 tools/grbm_clock.py $O/pmc_grbm_conv > $O/grbm_clock_conv.txt && python3 tools/grbm_clock.py $O/pmc_grbm > $O/grbm_clock_step.txt && head -8 $O/grbm_clock_conv.txt
