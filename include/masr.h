@@ -86,6 +86,10 @@ void masr_set_fused_sgd(masr_model* m, int on);
 /* The Linear weight gradients of a step are ONE launch (the decoder-row tiles fill the CUs the encoder-row tiles leave idle); on: two
  * launches, encoder rows then decoder rows (A/B; identical bits -- each element of dW is reduced by one workgroup either way). */
 void masr_set_split_wgrad_launches(masr_model* m, int on);
+/* The decoder's few-row GEMMs with a long reduction (FFN second layer, its first layer's dgrad, the packed q/k/v dgrad: <= 1024 rows, K >= 1024)
+ * run k-split over K / 512 x as many workgroups; the LayerNorm (backward) that follows sums the fp32 partial products and applies the GEMM's
+ * epilogue (bias, dropout, residual) on its way in.  Default ON; off = whole reductions (same results up to fp32 summation order; A/B + test). */
+void masr_set_ksplit(masr_model* m, int on);
 void masr_step_counters(const masr_model* m, int64_t out[3]);
 /* out[0]=loss, out[1]=n_correct, out[2]=n_total, out[3]=last grad norm.  Synchronises the stream. */
 int masr_read_stats(masr_model* m, float out[4], void* stream);
@@ -366,6 +370,10 @@ int64_t masr_test_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int CO
  * engine's merged launch -- members [0, first_members) reduce over `rows` rows and are dispatched first, the others over the first rows_rest. */
 int masr_test_wgrad_grouped(const uint16_t* dy, int64_t lddy, const uint16_t* x, int64_t ldx, float* dW, float* db, float* dW2, float* db2,
                             int rows, int N, int K, void* stream);
+/* the k-split GEMM + summing LayerNorm pair of the decoder (engine.hip ffn_fwd / ln_fwd, ffn_bwd / ln_bwd): forward when x == NULL, backward otherwise */
+int masr_test_ksplit_ln(const uint16_t* A, const uint16_t* B, int rows, int E, int K, int split, const float* bias, const float* residual, float drop_p,
+                        uint32_t seed, uint32_t site, float* part, const float* gamma, const float* beta, float* sum_out, float* y32, uint16_t* y16,
+                        float* mean, float* rstd, const float* x, float* dx32, uint16_t* dx16, float* slab, void* stream);
 int masr_test_wgrad_grouped_n(const uint16_t* dy, int64_t lddy, const uint16_t* x, int64_t ldx, float* dW, int64_t member_stride, int members,
                               int first_members, int rows, int rows_rest, int N, int K, void* stream);
 /* the same with dy given as the pooled gradient [B][H/2][W/2][COUT] + the pool codes of masr_test_conv3x3_pool_idx (the weight-gradient kernel

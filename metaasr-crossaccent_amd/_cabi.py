@@ -35,6 +35,7 @@ _SIGS = {
     "masr_set_ln_fusion": (None, [vp, i32]),
     "masr_set_fused_sgd": (None, [vp, i32]),
     "masr_set_split_wgrad_launches": (None, [vp, i32]),
+    "masr_set_ksplit": (None, [vp, i32]),
     "masr_step_counters": (None, [vp, C.POINTER(i64)]),
     "masr_read_stats": (i32, [vp, C.POINTER(f32), vp]),
     "masr_stats_post": (i64, [vp, vp]),
@@ -105,6 +106,7 @@ _SIGS = {
     "masr_test_conv3x3_wgrad": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     "masr_test_conv3x3_wgrad_slab_floats": (i64, [i32, i32, i32, i32, i32]),
     "masr_test_wgrad_grouped": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "masr_test_ksplit_ln": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, f32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "masr_test_wgrad_grouped_n": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
     "masr_test_conv3x3_wgrad_pooled": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     "masr_test_layernorm_slab_floats": (i64, [i32, i32]),

@@ -71,6 +71,7 @@ struct Acts {
     float *delta_e, *delta_d;
     std::vector<DecGrad> dgr;
     std::vector<EncGrad> egr;
+    float* part;                                           // fp32 partial products of a k-split few-row GEMM, summed by the LayerNorm that follows ([<= 8][rows_d][E])
     float* slab; int64_t slab_floats;
     float *cw_slab[3], *c1_slab;                           // partial slabs of the conv weight gradients: each its own, all folded by ONE launch at the end of the pass
     float* ln_slab; int64_t ln_slab_floats;                // one region per LayerNorm backward (grouped reduce)
@@ -78,6 +79,7 @@ struct Acts {
 
 }  // namespace
 
+constexpr int KSPLIT_MAX = 8;
 constexpr int GAP_CHUNKS_MAX = 8192;        // (offset, length <= 2048) chunks of the parameters without a bf16 shadow (hkust: ~600)
 struct masr_model {
     masr_config cfg;
@@ -112,6 +114,7 @@ struct masr_model {
     Acts acts; bool have_acts = false;
     LnReduceGroup lng; int64_t ln_slab_used = 0;           // LayerNorm dgamma/dbeta partials, folded by one grouped launch
     bool split_wgrad = false;                              // masr_set_split_wgrad_launches
+    bool ksplit = true;                                    // masr_set_ksplit: few-row long-reduction GEMMs k-split, partials summed by the LayerNorm behind them
     WgradGroup wg, wge;                                    // decoder-row / encoder-row weight gradients collected for the grouped launch (lin_wgrad)
     // a LayerNorm (forward) / LayerNorm backward on few rows that has been ASKED for but not launched: the next GEMM that takes its bf16
     // output as the A operand computes it in its own prologue (kernels.h mk_gemm_lnfwd / mk_gemm_lnbwd); anything else flushes it first
@@ -240,6 +243,7 @@ void plan_acts(const masr_model* m, Arena& ar, Acts& a, int B, int T, int L, boo
     mx(mk_colsum_slab_floats((int)P1, 64)); mx(mk_colsum_slab_floats((int)P2, 128));
     mx(mk_colsum_slab_floats((int)(re > rd ? re : rd), 3 * E > Fi ? 3 * E : Fi));
     a.slab_floats = sl; a.slab = ar.get<float>(sl);
+    a.part = ar.get<float>((int64_t)KSPLIT_MAX * rd * E);
     if (train) {
         const int nln = 2 * m->NE + 1 + 3 * m->ND + 1;
         a.ln_slab_floats = 0;
@@ -398,13 +402,30 @@ int attn_block_fwd(Ctx& c, const Attn& at, const bf16* xq, const bf16* xkv, int 
     return 0;
 }
 
-int ffn_fwd(Ctx& c, const Lin& l1, const Lin& l2, const bf16* x16, const float* x32, int rows, bf16* f, float* s_out, uint32_t site_i, uint32_t site_o) {
+// The few-row GEMMs with a long reduction (decoder rows: FFN second layer and the first layer's dgrad, K = d_inner; packed q/k/v dgrad, K = 3E) are
+// 80 workgroups with a chain of 24-32 k steps each -- 16 us where their K = 512 siblings take 8.  They run k-split over K / 512 x as many
+// workgroups; each writes its fp32 partial product and the LayerNorm that always follows sums them (and applies what the GEMM's epilogue would
+// have: bias, dropout, residual) on its way in: no combine pass, no extra launch (rowops.hip LnSumArgs).  0: not this shape.
+static int ksplit_of(const masr_model* m, int rows, int K) { return (m->ksplit && rows <= 1024 && K >= 1024 && K % 512 == 0 && K / 512 <= KSPLIT_MAX) ? K / 512 : 0; }
+static GemmArgs ksplit_args(const masr_model* m, GemmArgs g, int S, int rows, int N) {
+    g.bias = nullptr; g.drop_p = 0.f; g.residual = nullptr; g.C16 = nullptr;
+    g.C32 = m->acts.part; g.ldc = N; g.split_k = S; g.split_stride = (long)rows * N;
+    return g;
+}
+int ffn_fwd(Ctx& c, const Lin& l1, const Lin& l2, const bf16* x16, const float* x32, int rows, bf16* f, float* s_out, uint32_t site_i, uint32_t site_o,
+            LnSumArgs* defer = nullptr) {
     masr_model* m = c.m; const int E = m->E, Fi = m->Fi; const float* P = m->P;
     GemmArgs g = lin_fwd_args(x16, E, l1.k16, rows, Fi, E, P + l1.b); g.relu = 1; g.drop_p = c.p_drop; g.seed = c.seed; g.site = site_i;
     g.C16 = f; g.ldc16 = Fi;
     CK(gemm(c, g));
     GemmArgs h = lin_fwd_args(f, Fi, l2.k16, rows, E, Fi, P + l2.b); h.drop_p = c.p_drop; h.seed = c.seed; h.site = site_o;
     h.residual = x32; h.ldres = E; h.C32 = s_out; h.ldc = E;
+    const int S = defer ? ksplit_of(m, rows, Fi) : 0;
+    if (S) {                                                   // (the caller's LayerNorm takes `defer`: ln_fwd below)
+        *defer = LnSumArgs{m->acts.part, (long)rows * E, S, P + l2.b, x32, c.p_drop, c.seed, site_o, c.seed_ptr, s_out};
+        return gemm(c, ksplit_args(m, h, S, rows, E));
+    }
+    if (defer) defer->n = 0;
     CK(gemm(c, h));
     return 0;
 }
@@ -412,19 +433,32 @@ static bool ln_fusable(const Ctx& c, int rows) {
     const int E = c.m->E;
     return c.fuse_ln && rows <= 1024 && (E == 64 || E == 128 || E == 256 || E == 512);
 }
-int ln_fwd(Ctx& c, const Norm& n, const float* x, float* y32, bf16* y16, float* mean, float* rstd, int rows) {
+int ln_fwd(Ctx& c, const Norm& n, const float* x, float* y32, bf16* y16, float* mean, float* rstd, int rows, const LnSumArgs* sum = nullptr) {
     masr_model* m = c.m;
     CK(flush_ln_pending(c));                                   // (a LayerNorm of a LayerNorm output: the inner one runs now)
+    if (sum && sum->n > 0) {                                   // x = the partial products of a k-split GEMM (ffn_fwd): summed on the way in
+        Prof p(c.m, MASR_PROF_LAYERNORM, c.s);
+        return mk_layernorm_fwd_sum(*sum, m->P + n.w, m->P + n.b, y32, y16, mean, rstd, rows, m->E, c.s);
+    }
     if (y16 && mean && rstd && ln_fusable(c, rows)) { m->pend_f = {true, n, x, y32, y16, mean, rstd, rows}; return 0; }
     Prof p(c.m, MASR_PROF_LAYERNORM, c.s);
     return mk_layernorm_fwd(x, c.m->P + n.w, c.m->P + n.b, y32, y16, mean, rstd, rows, c.m->E, c.s);
 }
 int ln_bwd(Ctx& c, const Norm& n, const float* dy, const float* x, const float* mean, const float* rstd, float* dx32, bf16* dx16,
-           uint32_t site, int rows) {
+           uint32_t site, int rows, const LnSumArgs* sum = nullptr) {
     masr_model* m = c.m;
     CK(flush_ln_pending(c));
-    // the dgamma/dbeta partials of every LayerNorm go to their own slab region; flush_ln_reduce folds them all at once
+    // the dgamma/dbeta partials of every LayerNorm go to their own slab region; the fold launch at the end of the pass folds them all at once
     const int64_t need = (int64_t)mk_layernorm_bwd_blocks(rows) * 2 * m->E;
+    if (sum && sum->n > 0) {                                   // dy = the partial products of a k-split dgrad GEMM + its residual gradient
+        if (m->lng.n >= LN_GROUP_MAX || m->ln_slab_used + need > m->acts.ln_slab_floats) { mk_set_error("ln_bwd", "no room for the LayerNorm partials"); return -1; }
+        float* slab = m->acts.ln_slab + m->ln_slab_used;
+        m->ln_slab_used += need;
+        LnReduceDesc& d = m->lng.p[m->lng.n++];
+        d.slab = slab; d.dgamma = m->G + n.w; d.dbeta = m->G + n.b; d.nblocks = (rows + 3) / 4;
+        Prof p(c.m, MASR_PROF_LAYERNORM, c.s);
+        return mk_layernorm_bwd_sum(*sum, x, m->P + n.w, mean, rstd, dx32, dx16, dx16 ? c.p_drop : 0.f, c.seed, site, slab, rows, m->E, c.s, c.seed_ptr);
+    }
     if (dx16 && ln_fusable(c, rows) && m->lng.n < LN_GROUP_MAX && m->ln_slab_used + need <= m->acts.ln_slab_floats) {
         // deferred: the dgrad GEMM that takes dx16 as its A operand computes this backward in its prologue (gemm() above); the slab
         // region is sized for the standalone kernel (4 rows per partial), the fused form uses the first rows / 64 blocks of it
@@ -476,7 +510,7 @@ int flush_ln_reduce(Ctx& c) {
 // backward of  s_out = x + drop(ffn(x16))  given d s_out (gs32 fp32, gs16 bf16 already dropout-masked for the ffn output site)
 // writes d x (fp32) = gs32 + ffn-branch gradient into gout
 int ffn_bwd(Ctx& c, const Lin& l1, const Lin& l2, const bf16* x16, const bf16* f, const float* gs32, const bf16* gs16, int rows,
-            bf16* gf, float* gout, bool split) {
+            bf16* gf, float* gout, bool split, LnSumArgs* defer = nullptr) {
     masr_model* m = c.m; const int E = m->E, Fi = m->Fi;
     CK(lin_wgrad(c, gs16, E, f, Fi, rows, E, Fi, m->G + l2.w, m->G + l2.b, split));
     GemmArgs g = lin_dgrad_args(gs16, E, l2.t16, E, rows, E, Fi);
@@ -485,6 +519,12 @@ int ffn_bwd(Ctx& c, const Lin& l1, const Lin& l2, const bf16* x16, const bf16* f
     CK(lin_wgrad(c, gf, Fi, x16, E, rows, Fi, E, m->G + l1.w, m->G + l1.b, split));
     GemmArgs h = lin_dgrad_args(gf, Fi, l1.t16, Fi, rows, Fi, E);
     h.residual = gs32; h.ldres = E; h.C32 = gout; h.ldc = E;
+    const int S = defer ? ksplit_of(m, rows, Fi) : 0;
+    if (S) {                                                   // (gout is not written: the LayerNorm backward that follows takes `defer`)
+        *defer = LnSumArgs{m->acts.part, (long)rows * E, S, nullptr, gs32, 0.f, 0u, 0u, nullptr, nullptr};
+        return gemm(c, ksplit_args(m, h, S, rows, E));
+    }
+    if (defer) defer->n = 0;
     CK(gemm(c, h));
     return 0;
 }
@@ -737,8 +777,9 @@ static int forward_decoder(Ctx& c, bool project_kv = true, bool logits_f32 = fal
         CK(attn_block_fwd(c, w.ca, d.y1_16, a.mem16, a.rows_d, a.rows_e, L, a.Tp, false, false, a.enc_lens, d.q, d.kv, d.co, d.lse_c, d.y1_32,
                           d.s2, d.site[2], d.site[3]));
         CK(ln_fwd(c, w.n2, d.s2, d.y2_32, d.y2_16, d.m2, d.r2, a.rows_d));
-        CK(ffn_fwd(c, w.l1, w.l2, d.y2_16, d.y2_32, a.rows_d, d.f, d.s3, d.site[4], d.site[5]));
-        CK(ln_fwd(c, w.n3, d.s3, a.y32[l + 1], a.y16[l + 1], d.m3, d.r3, a.rows_d));
+        LnSumArgs ks{};                                        // (FFN second layer k-split: its partial products are summed by norm3)
+        CK(ffn_fwd(c, w.l1, w.l2, d.y2_16, d.y2_32, a.rows_d, d.f, d.s3, d.site[4], d.site[5], &ks));
+        CK(ln_fwd(c, w.n3, d.s3, a.y32[l + 1], a.y16[l + 1], d.m3, d.r3, a.rows_d, &ks));
     }
     if (logits_f32) {
         // greedy decode: the last projection in fp32 on the master weights (see mk_logits_f32); layer 0's pre-LayerNorm sum is free by now
@@ -760,7 +801,7 @@ static int forward_decoder(Ctx& c, bool project_kv = true, bool logits_f32 = fal
 static int attn_block_bwd(Ctx& c, const Attn& at, const bf16* xq16, const bf16* xkv16, int rows_q, int rows_kv, int Tq, int Tk, bool self,
                           bool causal, const int* klens, const bf16* qkv_or_q, const bf16* kv, const bf16* ao, const float* lse,
                           const float* gs32, const bf16* gs16, bf16* gao, bf16* gqkv_or_q, bf16* gkv, float* delta, float* gout,
-                          float* dmem, int dmem_accumulate, uint32_t site_p, bool split) {
+                          float* dmem, int dmem_accumulate, uint32_t site_p, bool split, LnSumArgs* defer = nullptr) {
     masr_model* m = c.m; const int E = m->E; float* G = m->G;
     CK(lin_wgrad(c, gs16, E, ao, E, rows_q, E, E, G + at.out.w, G + at.out.b, split));
     { GemmArgs g = lin_dgrad_args(gs16, E, at.out.t16, E, rows_q, E, E); g.C16 = gao; g.ldc16 = E; CK(gemm(c, g)); }
@@ -779,6 +820,12 @@ static int attn_block_bwd(Ctx& c, const Attn& at, const bf16* xq16, const bf16* 
         CK(lin_wgrad(c, gqkv_or_q, 3 * E, xq16, E, rows_q, 3 * E, E, G + at.in.w, G + at.in.b, split));
         GemmArgs g = lin_dgrad_args(gqkv_or_q, 3 * E, at.in.t16, 3 * E, rows_q, 3 * E, E);
         g.residual = gs32; g.ldres = E; g.C32 = gout; g.ldc = E;
+        const int S = defer ? ksplit_of(m, rows_q, 3 * E) : 0;
+        if (S) {                                               // (gout is not written: the next LayerNorm backward takes `defer`)
+            *defer = LnSumArgs{m->acts.part, (long)rows_q * E, S, nullptr, gs32, 0.f, 0u, 0u, nullptr, nullptr};
+            return gemm(c, ksplit_args(m, g, S, rows_q, E));
+        }
+        if (defer) defer->n = 0;
         CK(gemm(c, g));
     } else {
         CK(lin_wgrad(c, gqkv_or_q, E, xq16, E, rows_q, E, E, G + at.in.w, G + at.in.b));
@@ -828,16 +875,19 @@ static int backward(Ctx& c, const float* xs) {
     float *gcur = a.gd_b, *gs = a.gd_a;
     CK(ln_bwd(c, m->dec_norm, a.gd_a, a.y32[m->ND], a.mdf, a.rdf, gcur, nullptr, 0, a.rows_d));
     // ---- decoder layers
+    LnSumArgs ks{};                                            // pending partial products of a k-split dgrad (the LayerNorm backward behind it sums them)
     for (int l = m->ND - 1; l >= 0; --l) {
         DecAct& d = a.dec[l]; const DecL& w = m->dec[l]; const DecGrad& dg = a.dgr[l];
-        CK(ln_bwd(c, w.n3, gcur, d.s3, d.m3, d.r3, gs, dg.g3, d.site[5], a.rows_d));
-        CK(ffn_bwd(c, w.l1, w.l2, d.y2_16, d.f, gs, dg.g3, a.rows_d, dg.gf, gcur, false));
-        CK(ln_bwd(c, w.n2, gcur, d.s2, d.m2, d.r2, gs, dg.g2, d.site[3], a.rows_d));
+        CK(ln_bwd(c, w.n3, gcur, d.s3, d.m3, d.r3, gs, dg.g3, d.site[5], a.rows_d, &ks));
+        CK(ffn_bwd(c, w.l1, w.l2, d.y2_16, d.f, gs, dg.g3, a.rows_d, dg.gf, gcur, false, &ks));
+        CK(ln_bwd(c, w.n2, gcur, d.s2, d.m2, d.r2, gs, dg.g2, d.site[3], a.rows_d, &ks));
+        ks.n = 0;
         CK(attn_block_bwd(c, w.ca, d.y1_16, a.mem16, a.rows_d, a.rows_e, L, a.Tp, false, false, a.enc_lens, d.q, d.kv, d.co, d.lse_c, gs,
                           dg.g2, a.gao_d, dg.gq, a.gkv_all + (int64_t)l * 2 * E, a.delta_d, gcur, a.dmem32, 0, d.site[2], false));
         CK(ln_bwd(c, w.n1, gcur, d.s1, d.m1, d.r1, gs, dg.g1, d.site[1], a.rows_d));
+        // (layer 0's input gradient goes to the embedding backward, not to a LayerNorm: its q/k/v dgrad runs whole)
         CK(attn_block_bwd(c, w.sa, a.y16[l], nullptr, a.rows_d, 0, L, L, true, true, nullptr, d.qkv, nullptr, d.ao, d.lse_s, gs, dg.g1,
-                          a.gao_d, dg.gqkv, nullptr, a.delta_d, gcur, nullptr, 0, d.site[0], false));
+                          a.gao_d, dg.gqkv, nullptr, a.delta_d, gcur, nullptr, 0, d.site[0], false, l > 0 ? &ks : nullptr));
     }
     CK(memory_kv_bwd(c));
     float* g_dec_in = gcur;                                  // d(decoder input): consumed by embed_bwd after the split-K combine
@@ -1019,6 +1069,7 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
 void masr_set_step_graphs(masr_model* m, int on) { m->step_graphs_on = on != 0; }
 void masr_set_ln_fusion(masr_model* m, int on) { m->ln_fusion = on != 0; }
 void masr_set_split_wgrad_launches(masr_model* m, int on) { m->split_wgrad = on != 0; }
+void masr_set_ksplit(masr_model* m, int on) { m->ksplit = on != 0; }
 void masr_set_fused_sgd(masr_model* m, int on) { m->fuse_sgd = on != 0 && m->gaps_ok; }
 void masr_step_counters(const masr_model* m, int64_t out[3]) { out[0] = m->n_direct; out[1] = m->n_captured; out[2] = m->n_replayed; }
 
@@ -1410,6 +1461,23 @@ int masr_test_layernorm(const float* x, const float* gamma, const float* beta, c
                         uint32_t seed, uint32_t site, void* stream) {
     if (mk_layernorm_fwd(x, gamma, beta, y, (bf16*)y16, mean, rstd, rows, E, (hipStream_t)stream)) return -1;
     return mk_layernorm_bwd(dy, x, gamma, mean, rstd, dx, (bf16*)dx16, drop_p, seed, site, dgamma, dbeta, slab, rows, E, (hipStream_t)stream, nullptr);
+}
+int masr_test_ksplit_ln(const uint16_t* A, const uint16_t* B, int rows, int E, int K, int split, const float* bias, const float* residual, float drop_p,
+                        uint32_t seed, uint32_t site, float* part, const float* gamma, const float* beta, float* sum_out, float* y32, uint16_t* y16,
+                        float* mean, float* rstd, const float* x, float* dx32, uint16_t* dx16, float* slab, void* stream) {
+    // the engine's k-split pair (ffn_fwd + ln_fwd / ffn_bwd + ln_bwd): C = A [rows, K] . B [E, K]^T as `split` fp32 partial products in `part`,
+    // then the LayerNorm that sums them.  x == null: forward (row = sum + bias, dropout, + residual -> sum_out, y32 / y16, mean, rstd);
+    // x given: backward (dy = sum + residual; mean / rstd are inputs; dx32 / dx16 and the [ceil(rows / 4)][2][E] partials of dgamma / dbeta in slab)
+    GemmArgs g = gemm_args();
+    g.A = (const bf16*)A; g.lda = K; g.B = (const bf16*)B; g.ldb = K; g.M = rows; g.N = E; g.K = K;
+    g.C32 = part; g.ldc = E; g.split_k = split; g.split_stride = (long)rows * E;
+    CK(mk_gemm(g, (hipStream_t)stream));
+    if (!x) {
+        const LnSumArgs sm{part, (long)rows * E, split, bias, residual, drop_p, seed, site, nullptr, sum_out};
+        return mk_layernorm_fwd_sum(sm, gamma, beta, y32, (bf16*)y16, mean, rstd, rows, E, (hipStream_t)stream);
+    }
+    const LnSumArgs sm{part, (long)rows * E, split, nullptr, residual, 0.f, 0u, 0u, nullptr, nullptr};
+    return mk_layernorm_bwd_sum(sm, x, gamma, mean, rstd, dx32, (bf16*)dx16, drop_p, seed, site, slab, rows, E, (hipStream_t)stream, nullptr);
 }
 int masr_test_wgrad_grouped(const uint16_t* dy, int64_t lddy, const uint16_t* x, int64_t ldx, float* dW, float* db, float* dW2, float* db2,
                             int rows, int N, int K, void* stream) {

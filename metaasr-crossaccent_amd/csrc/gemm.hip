@@ -667,9 +667,12 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    int bx_ = blockIdx.x, by_ = blockIdx.y, bz_ = 0;
+    int bx_ = blockIdx.x, by_ = blockIdx.y, bz_ = blockIdx.z;
     if (g.xcd_order) xcd_tile(bx_, by_, bz_);
     const int m0 = by_ * BM, n0 = bx_ * BN;
+    // split_k > 1 (gridDim.z workgroups per tile): workgroup z multiplies the z-th part of the reduction and writes its fp32 partial product to
+    // C32 + z * split_stride -- no combine pass: the LayerNorm that follows sums the partials (rowops.hip LnSumArgs)
+    const int nk = g.K / 64 / (int)gridDim.z, kt0 = bz_ * nk;
 
     // per-thread source rows are fixed over the k loop
     constexpr int ACH = BM * 8 / 256, BCH = BN * 8 / 256;
@@ -691,10 +694,10 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
         char* bb = ab + A_BYTES;
 #pragma unroll
         for (int i = 0; i < ACH; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(asrc[i] + kt * 64), (lptr_t*)(ab + (wave * 64 + i * 256) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t*)(asrc[i] + (kt0 + kt) * 64), (lptr_t*)(ab + (wave * 64 + i * 256) * 16), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < BCH; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(bsrc[i] + kt * 64), (lptr_t*)(bb + (wave * 64 + i * 256) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t*)(bsrc[i] + (kt0 + kt) * 64), (lptr_t*)(bb + (wave * 64 + i * 256) * 16), 16, 0, 0);
     };
 
     f32x4 acc[FM][FN];
@@ -703,7 +706,6 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = g.K / 64;
     const int rr = lane & 15, q = lane >> 4;
     auto compute = [&](int buf) {
         const bf16* ab = reinterpret_cast<const bf16*>(smem + buf * BUF);
@@ -759,7 +761,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // all fragment reads done before the epilogue reuses the LDS
     }
-    gemm_epilogue<BM, BN, EPI>(g, acc, smem, m0, n0, 0);
+    gemm_epilogue<BM, BN, EPI>(g, acc, smem, m0, n0, (long)bz_ * g.split_stride);
 }
 
 // ---- LayerNorm in the prologue of its consumer GEMM (round 4).  64-row tiles, K == E <= 512: the workgroup normalises its 64 rows
@@ -1001,7 +1003,7 @@ void launch_epi(const GemmArgs& g, dim3 grid, hipStream_t s) {
 template <int BM, int BN>
 int launch_tile(const GemmArgs& g_in, hipStream_t s) {
     GemmArgs g = g_in;
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, (g.reduction_major && g.split_k > 1) ? g.split_k : 1);
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.split_k > 1 ? g.split_k : 1);
     g.xcd_order = (long)grid.x * grid.y * grid.z >= 64;
     const int epi = (g.bias ? E_BIAS : 0) | (g.pe ? E_PE : 0) | (g.relu ? E_RELU : 0) | (g.mask ? E_MASK : 0) |
                     (g.drop_p > 0.f ? E_DROP : 0) | (g.residual ? E_RES : 0) | (g.accumulate ? E_ACC : 0) |
@@ -1125,7 +1127,12 @@ int mk_gemm(const GemmArgs& g, hipStream_t s) {
         return -1;
     }
     // largest tile that still yields roughly one workgroup per CU (256 CUs)
-    const long z = (g.reduction_major && g.split_k > 1) ? g.split_k : 1;
+    const long z = g.split_k > 1 ? g.split_k : 1;
+    if (!g.reduction_major && g.split_k > 1 &&
+        (g.K % (64 * g.split_k) || g.bias || g.pe || g.relu || g.mask || g.drop_p > 0.f || g.residual || g.accumulate || !g.C32 || g.C16 || g.cseg_rows)) {
+        mk_set_error("mk_gemm", "k-split NT form: K a multiple of 64 * split_k, plain fp32 partial products only (the consumer applies the epilogue)");
+        return -1;
+    }
     auto wgs = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * z; };
     constexpr long min_wgs = 192;
     if (wgs(128, 128) >= min_wgs) return launch_tile<128, 128>(g, s);

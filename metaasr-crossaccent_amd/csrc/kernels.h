@@ -156,6 +156,14 @@ int mk_layernorm_fwd(const float* x, const float* gamma, const float* beta, floa
 int mk_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        float* dx32, bf16* dx16, float drop_p, uint32_t seed, uint32_t site,
                        float* dgamma, float* dbeta, float* slab, int rows, int E, hipStream_t s, const uint32_t* seed_ptr = nullptr);
+// LayerNorm whose input row (forward) / incoming gradient (backward) is NOT in memory: it is what the epilogue of a k-split GEMM would have
+// written -- the sum of n fp32 partial products part[z][row][E] (z-th at part + z * stride) (+ bias) (x dropout at element index row * E + column,
+// the GEMM's) + residual.  Forward: the sum is stored to sum_out (the backward pass normalises it again).  Few rows only (< 2048).
+struct LnSumArgs { const float* part; long stride; int n; const float* bias; const float* residual; float drop_p; uint32_t seed, site; const uint32_t* seed_ptr; float* sum_out; };
+int mk_layernorm_fwd_sum(const LnSumArgs& sm, const float* gamma, const float* beta, float* y32, bf16* y16, float* mean, float* rstd, int rows, int E,
+                         hipStream_t s);
+int mk_layernorm_bwd_sum(const LnSumArgs& sm, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx32, bf16* dx16,
+                         float drop_p, uint32_t seed, uint32_t site, float* slab, int rows, int E, hipStream_t s, const uint32_t* seed_ptr = nullptr);
 long mk_layernorm_bwd_slab_floats(int rows, int E);     // capacity for any row count <= rows
 int mk_layernorm_bwd_blocks(int rows);                    // partial-sum blocks a launch over `rows` rows writes
 // dgamma == null: only the per-block partials are written to `slab` (each LayerNorm its own region) and

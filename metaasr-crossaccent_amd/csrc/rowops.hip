@@ -24,11 +24,14 @@ template <> struct LnVec<1> {
     static __device__ __forceinline__ void st16(bf16* p, const float (&o)[1]) { p[0] = (bf16)o[0]; }
 };
 // lane's columns: group i (of NV) holds columns (i * 64 + lane) * VW .. + VW - 1
-template <int PT>
+// SUM (kernels.h LnSumArgs): the row is not in memory -- it is what the epilogue of a k-split GEMM would have written: the sum of sm.n fp32
+// partial products (+ bias) (x dropout) + residual, formed here in the epilogue's order of operations and stored to sm.sum_out (the backward
+// pass normalises it again).  The few-row GEMMs with a long reduction run as n x more workgroups with a short k chain each, and no combine pass.
+template <int PT, bool SUM = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ y32,
                                                      bf16* __restrict__ y16, float* __restrict__ mean,
-                                                     float* __restrict__ rstd, int rows) {
+                                                     float* __restrict__ rstd, int rows, const LnSumArgs sm) {
     constexpr int E = 64 * PT, VW = PT % 4 == 0 ? 4 : 1, NV = PT / VW;
     using V = LnVec<VW>;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -36,8 +39,40 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const float* xr = x + (long)row * E;
     float v[NV][VW], gm[NV][VW], bt[NV][VW];
     float s = 0.f;
+    if constexpr (SUM) {
+        const uint32_t seed = sm.seed_ptr ? *sm.seed_ptr : sm.seed;
+        const float inv_keep = sm.drop_p > 0.f ? 1.f / (1.f - sm.drop_p) : 1.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * VW;
+            const long idx = (long)row * E + c;
+            float acc[VW], t[VW], rsd[VW], bs[VW];
+            V::ld(sm.part + idx, acc);
+            for (int z = 1; z < sm.n; ++z) {
+                V::ld(sm.part + z * sm.stride + idx, t);
+#pragma unroll
+                for (int e = 0; e < VW; ++e) acc[e] += t[e];
+            }
+            V::ld(sm.residual + idx, rsd);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) bs[e] = 0.f;
+            if (sm.bias) {                                    // (parameters sit unpadded in the flat buffer: a bias need not be 16-byte aligned)
+#pragma unroll
+                for (int e = 0; e < VW; ++e) bs[e] = sm.bias[c + e];
+            }
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+                float xx = acc[e] + bs[e];
+                if (sm.drop_p > 0.f) xx *= dropout_scale(seed, sm.site, (uint32_t)(idx + e), sm.drop_p, inv_keep);
+                v[i][e] = xx + rsd[e];
+            }
+            if (sm.sum_out) V::st(sm.sum_out + idx, v[i]);
+            V::ld(gamma + c, gm[i]); V::ld(beta + c, bt[i]);
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < NV; ++i) { const int c = (i * 64 + lane) * VW; V::ld(xr + c, v[i]); V::ld(gamma + c, gm[i]); V::ld(beta + c, bt[i]); }
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i)
 #pragma unroll
@@ -65,12 +100,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // partials per thread-column, written to slab[block][2][E]; reduced by ln_bwd_reduce.  R = 4 for the encoder's rows (250 workgroups for
 // 4000 rows), 1 for the decoder's few hundred (148 workgroups instead of 37).
 __host__ __device__ inline int ln_rows_per_wave(int rows) { return rows >= 2048 ? 4 : 1; }
-template <int PT, int R>
+// SUM: dy is the sum of sm.n partial products of a k-split dgrad GEMM + its residual gradient (see ln_fwd_kernel)
+template <int PT, int R, bool SUM = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx32,
                                                      bf16* __restrict__ dx16, float drop_p, uint32_t seed, uint32_t site,
-                                                     float* __restrict__ slab, int rows, const uint32_t* __restrict__ seed_ptr) {
+                                                     float* __restrict__ slab, int rows, const uint32_t* __restrict__ seed_ptr, const LnSumArgs sm) {
     constexpr int E = 64 * PT, VW = PT % 4 == 0 ? 4 : 1, NV = PT / VW;
     using V = LnVec<VW>;
     if (seed_ptr) seed = *seed_ptr;                           // replayed (graph-captured) step: the seed of THIS step lives on the device
@@ -90,7 +126,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         const int row = row0 + r < rows ? row0 + r : rows - 1;               // (clamped: loads stay unconditional)
         mu[r] = mean[row]; rs[r] = rstd[row];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) { const long idx = (long)row * E + (i * 64 + lane) * VW; V::ld(dy + idx, d[r][i]); V::ld(x + idx, xv[r][i]); }
+        for (int i = 0; i < NV; ++i) {
+            const long idx = (long)row * E + (i * 64 + lane) * VW;
+            if constexpr (SUM) {
+                float t[VW];
+                V::ld(sm.part + idx, d[r][i]);
+                for (int z = 1; z < sm.n; ++z) {
+                    V::ld(sm.part + z * sm.stride + idx, t);
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) d[r][i][e] += t[e];
+                }
+                V::ld(sm.residual + idx, t);
+#pragma unroll
+                for (int e = 0; e < VW; ++e) d[r][i][e] += t[e];
+            } else {
+                V::ld(dy + idx, d[r][i]);
+            }
+            V::ld(x + idx, xv[r][i]);
+        }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -315,16 +368,21 @@ __global__ __launch_bounds__(256) void ls_ce_reduce(const float* __restrict__ ro
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : (mk_set_error(__func__, "launch failed"), -1))
 
 template <int PT>
-static void ln_fwd_launch(const float* x, const float* gamma, const float* beta, float* y32, bf16* y16, float* mean, float* rstd, int rows, hipStream_t s) {
-    hipLaunchKernelGGL(ln_fwd_kernel<PT>, dim3((rows + 3) / 4), dim3(256), 0, s, x, gamma, beta, y32, y16, mean, rstd, rows);
+static void ln_fwd_launch(const float* x, const float* gamma, const float* beta, float* y32, bf16* y16, float* mean, float* rstd, int rows, hipStream_t s,
+                          const LnSumArgs* sm = nullptr) {
+    if (sm) hipLaunchKernelGGL((ln_fwd_kernel<PT, true>), dim3((rows + 3) / 4), dim3(256), 0, s, x, gamma, beta, y32, y16, mean, rstd, rows, *sm);
+    else hipLaunchKernelGGL((ln_fwd_kernel<PT, false>), dim3((rows + 3) / 4), dim3(256), 0, s, x, gamma, beta, y32, y16, mean, rstd, rows, LnSumArgs{});
 }
 template <int PT>
 static void ln_bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx32, bf16* dx16,
-                          float drop_p, uint32_t seed, uint32_t site, float* slab, int rows, int nb, hipStream_t s, const uint32_t* seed_ptr) {
-    if (ln_rows_per_wave(rows) == 4)
-        hipLaunchKernelGGL((ln_bwd_kernel<PT, 4>), dim3(nb), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx32, dx16, drop_p, seed, site, slab, rows, seed_ptr);
+                          float drop_p, uint32_t seed, uint32_t site, float* slab, int rows, int nb, hipStream_t s, const uint32_t* seed_ptr,
+                          const LnSumArgs* sm = nullptr) {
+    if (sm)            // (few rows only: one row per wave)
+        hipLaunchKernelGGL((ln_bwd_kernel<PT, 1, true>), dim3(nb), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx32, dx16, drop_p, seed, site, slab, rows, seed_ptr, *sm);
+    else if (ln_rows_per_wave(rows) == 4)
+        hipLaunchKernelGGL((ln_bwd_kernel<PT, 4>), dim3(nb), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx32, dx16, drop_p, seed, site, slab, rows, seed_ptr, LnSumArgs{});
     else
-        hipLaunchKernelGGL((ln_bwd_kernel<PT, 1>), dim3(nb), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx32, dx16, drop_p, seed, site, slab, rows, seed_ptr);
+        hipLaunchKernelGGL((ln_bwd_kernel<PT, 1>), dim3(nb), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx32, dx16, drop_p, seed, site, slab, rows, seed_ptr, LnSumArgs{});
 }
 #define LN_DISPATCH(E, CALL)                                                                      \
     switch ((E) / 64) {                                                                           \
@@ -336,6 +394,22 @@ int mk_layernorm_fwd(const float* x, const float* gamma, const float* beta, floa
                        float* rstd, int rows, int E, hipStream_t s) {
     if (E % 64) { mk_set_error("mk_layernorm_fwd", "d_model must be a multiple of 64"); return -1; }
 #define CALL(P) ln_fwd_launch<P>(x, gamma, beta, y32, y16, mean, rstd, rows, s)
+    LN_DISPATCH(E, CALL)
+#undef CALL
+    return LAUNCH_OK();
+}
+static bool ln_sum_ok(const LnSumArgs& sm, int rows, int E, const char* who) {
+    if (!sm.part || !sm.residual || sm.n < 1 || sm.n > 8 || rows >= 2048 || (sm.stride & 3) || ((uintptr_t)sm.part & 15) || ((uintptr_t)sm.residual & 15) ||
+        (sm.sum_out && ((uintptr_t)sm.sum_out & 15)) || E % 64) {
+        mk_set_error(who, "k-split partial sums: 1..8 aligned partials + a residual, fewer than 2048 rows"); return false;
+    }
+    return true;
+}
+int mk_layernorm_fwd_sum(const LnSumArgs& sm, const float* gamma, const float* beta, float* y32, bf16* y16, float* mean, float* rstd, int rows, int E,
+                         hipStream_t s) {
+    if (!ln_sum_ok(sm, rows, E, "mk_layernorm_fwd_sum")) return -1;
+    const float* x = nullptr;
+#define CALL(P) ln_fwd_launch<P>(x, gamma, beta, y32, y16, mean, rstd, rows, s, &sm)
     LN_DISPATCH(E, CALL)
 #undef CALL
     return LAUNCH_OK();
@@ -356,6 +430,17 @@ int mk_layernorm_bwd(const float* dy, const float* x, const float* gamma, const 
     LN_DISPATCH(E, CALL)
 #undef CALL
     if (dgamma) hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * E + 31) / 32), dim3(256), 0, s, slab, nb, dgamma, dbeta, E);
+    return LAUNCH_OK();
+}
+// the same with dy = sum of the partial products of a k-split dgrad GEMM + its residual gradient; partials of dgamma / dbeta to `slab` only
+int mk_layernorm_bwd_sum(const LnSumArgs& sm, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx32, bf16* dx16,
+                         float drop_p, uint32_t seed, uint32_t site, float* slab, int rows, int E, hipStream_t s, const uint32_t* seed_ptr) {
+    if (!ln_sum_ok(sm, rows, E, "mk_layernorm_bwd_sum")) return -1;
+    const int nb = (rows + 3) / 4;
+    const float* dy = nullptr;
+#define CALL(P) ln_bwd_launch<P>(dy, x, gamma, mean, rstd, dx32, dx16, drop_p, seed, site, slab, rows, nb, s, seed_ptr, &sm)
+    LN_DISPATCH(E, CALL)
+#undef CALL
     return LAUNCH_OK();
 }
 int mk_layernorm_bwd_reduce_grouped(const LnReduceGroup& grp, int E, hipStream_t s) {

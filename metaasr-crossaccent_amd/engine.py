@@ -251,6 +251,10 @@ class MasrEngine:
         """the step's Linear weight gradients as two launches instead of one (include/masr.h masr_set_split_wgrad_launches; A/B, same bits)"""
         self._l.masr_set_split_wgrad_launches(self.h, int(bool(on)))
 
+    def set_ksplit(self, on: bool):
+        """k-split of the decoder's long-reduction few-row GEMMs with the combine inside the next LayerNorm (include/masr.h masr_set_ksplit); default on"""
+        self._l.masr_set_ksplit(self.h, int(bool(on)))
+
     def set_fused_sgd(self, on: bool):
         """clip_sgd_step's update inside the shadow-refresh launch (include/masr.h masr_set_fused_sgd); default off (measured slower)"""
         self._l.masr_set_fused_sgd(self.h, int(bool(on)))

@@ -429,6 +429,46 @@ def test_layernorm_in_the_gemm_prologue_gives_the_same_step(cfg_name):
             assert torch.equal(a, b), f"{n}: gradient differs between the fused and the standalone LayerNorm path"
 
 
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_ksplit_gemms_with_the_combine_inside_the_layernorm(dropout):
+    """engine.hip ksplit_of: at the hkust geometry the decoder's FFN second layer (K = 2048), its first layer's dgrad and the packed q/k/v dgrad
+    (K = 1536) run k-split, and the LayerNorm (backward) behind each sums the fp32 partial products and applies the GEMM's epilogue (bias, dropout
+    with the GEMM's element index, residual).  The pair itself is checked number by number in test_hip_kernels.py
+    (test_ksplit_gemm_summed_by_the_layernorm); here the whole step against whole reductions (masr_set_ksplit(0)).  The two differ in fp32
+    summation order only, but not bit for bit downstream: a last-bit difference moves some bf16 operand roundings of the following layers, so
+    the step agrees to the engine's bf16 noise floor -- the same distance either schedule keeps from the bf16-emulated oracle (logits ~5e-3 of
+    their range, loss ~1e-4): loss to 3e-4, logits to 1 % of their range, every gradient tensor's direction to cos > 0.998, the flat gradient to
+    cos > 0.9995 and 0.5 % in norm (the engine against the bf16-emulated oracle: cos > 0.995).  Decoder rows in front of the first such rounding are bit-identical (causal attention), which a wrong
+    element index in the dropout or a missing bias would not leave."""
+    cfg = dict(HKUST)
+    cfg["dropout"] = cfg["pos_dropout"] = dropout
+    sd = ref_cpu.deterministic_state_dict(cfg, ODIM, seed=4)
+    xs, il, ys, ol = synth_batch(23, [203, 160, 121, 96, 90], [12, 9, 7, 30, 2])
+    outs = []
+    for on in (True, False):
+        eng = MasrEngine(cfg, ODIM, label_smoothing=0.2)
+        eng.load_state_dict(sd)
+        eng.set_seed(17)
+        eng.set_ksplit(on)
+        eng.run_batch(xs, il, ys, ol.clone(), train=True)
+        outs.append((dict(eng.read_stats()), eng.last_logits()[0].clone(), eng.grads.clone(), eng))
+    (sa, la, ga, eng), (sb, lb, gb, _) = outs
+    assert abs(sa["loss"] - sb["loss"]) <= 3e-4 * abs(sb["loss"]), (sa["loss"], sb["loss"])
+    assert float((la - lb).abs().max()) <= 1e-2 * float(lb.abs().max())
+    assert not torch.equal(ga, gb)                            # (the two schedules do differ: this is not the same code path twice)
+    assert torch.equal(la[0, 0], lb[0, 0])                    # first decoder row of the batch: nothing upstream of it has been re-rounded yet
+    worst = 1.0
+    for n, (off, shape) in eng.table.items():
+        k = int(np.prod(shape))
+        a, b = ga[off:off + k].double(), gb[off:off + k].double()
+        if float(b.norm()) > 0:
+            worst = min(worst, float((a * b).sum() / (a.norm() * b.norm())))
+    a, b = ga.double(), gb.double()
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    print(f"dropout {dropout}: k-split vs whole reductions: loss {sa['loss']:.6f} / {sb['loss']:.6f}, flat gradient cos {cos:.6f}, worst tensor cos {worst:.5f}")
+    assert worst > 0.998 and cos > 0.9995 and abs(float(a.norm() / b.norm()) - 1) < 5e-3
+
+
 @pytest.mark.parametrize("cfg_name", ["tiny", "hkust"])
 def test_merged_weight_gradient_launch_equals_two_launches(cfg_name):
     """engine.hip flush_wgrads: the decoder-row weight gradients ride in the encoder rows' launch (two-segment tile list, long tiles

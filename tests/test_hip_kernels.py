@@ -432,6 +432,63 @@ def test_layernorm_fwd_bwd(L, rows, E):
     assert torch.equal(dxd[:rows], dx[:rows]) and torch.equal(dx16d, (dx[:rows] * keep.view(rows, E)).bfloat16())
 
 
+@pytest.mark.parametrize("rows,E,K,split,drop", [(155, 512, 2048, 4, 0.0), (656, 512, 2048, 4, 0.1), (61, 512, 1536, 3, 0.0), (1024, 512, 1024, 2, 0.25),
+                                                  (3, 256, 4096, 8, 0.1)])
+def test_ksplit_gemm_summed_by_the_layernorm(L, rows, E, K, split, drop):
+    """The decoder's few-row GEMMs with a long reduction run k-split, and the LayerNorm behind them sums the fp32 partial products
+    (engine.hip ffn_fwd / ln_fwd, ffn_bwd / ln_bwd, attn_block_bwd; rowops.hip LnSumArgs).  Forward: sum + bias, dropout at the GEMM's element
+    index, + residual, LayerNorm -- against mk_gemm's own epilogue followed by the plain LayerNorm (same numbers up to fp32 summation order)
+    and against torch.  Backward: dy = sum + residual gradient."""
+    g = torch.Generator(device="cuda").manual_seed(rows + K)
+    A = (torch.randn(rows, K, device="cuda", generator=g) * 0.5).bfloat16()
+    B = (torch.randn(E, K, device="cuda", generator=g) * 0.05).bfloat16()
+    bias = torch.randn(E + 1, device="cuda", generator=g)[1:]                # (4-byte aligned only, like a bias inside the flat parameter buffer)
+    res = torch.randn(rows, E, device="cuda", generator=g)
+    gamma = 1 + 0.2 * torch.randn(E, device="cuda", generator=g); beta = 0.1 * torch.randn(E, device="cuda", generator=g)
+    part = torch.zeros(split, rows, E, device="cuda")
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    ssum, y, y16, mean, rstd = z(rows + 1, E), z(rows + 1, E), z(rows, E).bfloat16(), z(rows), z(rows)
+    ssum[rows] = 7.0; y[rows] = 7.0
+    _cabi.check(L.masr_test_ksplit_ln(P(A), P(B), rows, E, K, split, P(bias), P(res), drop, 1, 2, P(part), P(gamma), P(beta), P(ssum), P(y), P(y16),
+                                      P(mean), P(rstd), None, None, None, None, S()))
+    # the partial products are what they say
+    ref_part = torch.stack([A[:, i * K // split:(i + 1) * K // split].float() @ B[:, i * K // split:(i + 1) * K // split].float().t() for i in range(split)])
+    torch.testing.assert_close(part, ref_part, rtol=1e-4, atol=1e-4)
+    # whole-reduction GEMM with the epilogue, then the plain LayerNorm
+    C = z(rows, E)
+    _cabi.check(L.masr_test_gemm_epi(P(A), K, P(B), K, rows, E, K, P(bias), 0, drop, P(res), None, P(C), None, S()))
+    torch.testing.assert_close(ssum[:rows], C, rtol=2e-6, atol=2e-5)
+    assert torch.all(ssum[rows] == 7.0) and torch.all(y[rows] == 7.0)
+    keep = torch.ones(rows * E, device="cuda")
+    if drop:
+        _cabi.check(L.masr_test_dropout_mask(1, 2, rows * E, drop, P(keep), S()))
+    ref_sum = (A.float() @ B.float().t() + bias) * keep.view(rows, E) + res
+    torch.testing.assert_close(ssum[:rows], ref_sum, rtol=1e-5, atol=1e-4)
+    ref_y = torch.nn.functional.layer_norm(ssum[:rows], (E,), gamma, beta, 1e-5)
+    torch.testing.assert_close(y[:rows], ref_y, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(y16.float(), ref_y.bfloat16().float(), rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(mean, ssum[:rows].mean(1), rtol=1e-5, atol=1e-5)
+    # backward: dy = A.B^T + res (no bias, no dropout on the sum), x = an arbitrary matrix with its own statistics
+    x = torch.randn(rows, E, device="cuda", generator=g) * 1.3 + 0.2
+    y2, y2_16, mean2, rstd2 = z(rows, E), z(rows, E).bfloat16(), z(rows), z(rows)
+    dgm, dbt, dx_ref, dx16_ref = z(E), z(E), z(rows, E), z(rows, E).bfloat16()
+    slab0 = z(int(L.masr_test_layernorm_slab_floats(rows, E)))
+    _cabi.check(L.masr_test_gemm_epi(P(A), K, P(B), K, rows, E, K, None, 0, 0.0, P(res), None, P(C), None, S()))
+    _cabi.check(L.masr_test_layernorm(P(x), P(gamma), P(beta), P(C), P(y2), P(y2_16), P(mean2), P(rstd2), P(dx_ref), P(dx16_ref), P(dgm), P(dbt), P(slab0),
+                                      rows, E, drop, 1, 2, S()))
+    nb = (rows + 3) // 4
+    dx, dx16, slab = z(rows + 1, E), z(rows, E).bfloat16(), z(nb, 2, E)
+    dx[rows] = 7.0
+    _cabi.check(L.masr_test_ksplit_ln(P(A), P(B), rows, E, K, split, None, P(res), drop, 1, 2, P(part), P(gamma), None, None, None, None,
+                                      P(mean2), P(rstd2), P(x), P(dx), P(dx16), P(slab), S()))
+    scale = float(dx_ref.abs().max())
+    torch.testing.assert_close(dx[:rows], dx_ref, rtol=1e-5, atol=2e-6 * scale)
+    assert torch.all(dx[rows] == 7.0)
+    assert float((dx16.float() - dx16_ref.float()).abs().max()) <= 2 ** -7 * scale          # (one bf16 step where the fp32 value sits on a tie)
+    torch.testing.assert_close(slab[:, 0].sum(0), dgm, rtol=1e-4, atol=1e-5 * scale * rows ** 0.5)
+    torch.testing.assert_close(slab[:, 1].sum(0), dbt, rtol=1e-4, atol=1e-5 * scale * rows ** 0.5)
+
+
 @pytest.mark.parametrize("B_,H,T,hd,mag", [(4, 4, 3, 16, 3e4), (2, 8, 250, 64, 3e3), (2, 4, 37, 64, 1e4), (1, 2, 130, 32, 1e3)])
 def test_attention_huge_scores(L, B_, H, T, hd, mag):
     """A diverging run (train.py with an aggressive Noam schedule: |q|, |k| ~ 3e4, scores ~ 1e9) must still get torch's one-hot softmax
