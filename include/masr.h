@@ -243,6 +243,11 @@ int masr_blstm_run_batch(masr_blstm* m, const float* xs, const int64_t* ilens, c
 /* forward only (MonoBLSTM.forward / greedy_decode, mono_blstm.py:63-92): head output readable through masr_blstm_last_logits */
 int masr_blstm_forward(masr_blstm* m, const float* xs, const int64_t* ilens, int B, int T, void* stream);
 int masr_blstm_read_stats(masr_blstm* m, float out[4], void* stream);            /* out[0] = CTC loss, out[3] = grad norm */
+/* The LSTM recurrence of a layer as ONE launch per pass (workgroups resident for the whole sequence, W_hh slices in registers, h_t / dz_t
+ * exchanged as self-flagging granules: csrc/lstm_rec.hip) instead of one launch per timestep.  Default ON for the shapes it covers (B <= 32,
+ * enc_dim <= 384); off = per-timestep launches (A/B + test; same results to fp32 rounding).  A timed-out exchange is reported by
+ * masr_blstm_read_stats. */
+void masr_blstm_set_resident_recurrence(masr_blstm* m, int on);
 /* head output (pre-softmax) [B][Tp][odim] fp32 and enc_lens int32 [B] on the device, Tp = ceil(ceil(T/2)/2) */
 int masr_blstm_last_logits(masr_blstm* m, float** logits, int32_t** enc_lens, int* B, int* Tp, int* C);
 /* nn.utils.clip_grad_norm_(parameters, max_norm) on the flat gradient; the norm is read with masr_blstm_read_stats */

@@ -130,6 +130,10 @@ class BlstmEngine:
         self._last_x = xs
         return self.last_logits()
 
+    def set_resident_recurrence(self, on: bool):
+        """the LSTM recurrence as one launch per layer and pass (include/masr.h masr_blstm_set_resident_recurrence); default on"""
+        self._l.masr_blstm_set_resident_recurrence(self.h, int(bool(on)))
+
     def read_stats(self):
         out = (C.c_float * 4)()
         check(self._l.masr_blstm_read_stats(self.h, out, self.stream()), "masr_blstm_read_stats")

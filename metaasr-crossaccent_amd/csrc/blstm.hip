@@ -54,6 +54,8 @@ struct masr_blstm {
     std::vector<LayerAct> act;
     float* logits; float* dlogits; bf16* dl16; int *lens, *tgt, *tgt_off, *tgt_len; float *nll, *ctc_work; int maxS = 0;
     bf16 *h16[2][2]; float* cstate[2];
+    unsigned long long* rec_words = nullptr;                                         // granule exchange of the resident recurrence (lstm_rec.hip)
+    bool resident = true;                                                            // masr_blstm_set_resident_recurrence
     float *dx32, *dy32, *dys32, *wtmp, *slab; int64_t slab_floats = 0;
     bf16 *dp2, *dc4, *dc3, *dp1, *dc2, *dc1;
     bool have = false;
@@ -117,6 +119,7 @@ void plan_acts(masr_blstm* m, Arena& ar, int B, int T, int maxS) {
     for (int i = 0; i <= m->L; ++i) m->lens_l[i] = m->lens ? m->lens + (int64_t)i * B : nullptr;
     m->nll = ar.get<float>(B); m->ctc_work = ar.get<float>(mk_ctc_work_floats(m->Tp, B, maxS));
     for (int d = 0; d < 2; ++d) { m->h16[d][0] = ar.get<bf16>((int64_t)B * m->KP); m->h16[d][1] = ar.get<bf16>((int64_t)B * m->KP); m->cstate[d] = ar.get<float>((int64_t)B * H); }
+    m->rec_words = ar.get<unsigned long long>(mk_lstm_rec_words(B > 32 ? 32 : B, H));
     int64_t maxK = m->F > 2 * H ? m->F : 2 * H;
     m->dx32 = ar.get<float>(R * maxK); m->dy32 = ar.get<float>(R * 2 * H); m->dys32 = ar.get<float>(R * 2 * H); m->wtmp = ar.get<float>((int64_t)G * maxK + G);
     m->dp2 = ar.get<bf16>(R * m->F); m->dc4 = ar.get<bf16>(P2 * 256); m->dc3 = ar.get<bf16>(P2 * 256); m->dp1 = ar.get<bf16>(P2 * 128);
@@ -166,7 +169,9 @@ int forward(masr_blstm* m, const float* xs, hipStream_t s) {
             st.h16[d][0] = m->h16[d][0]; st.h16[d][1] = m->h16[d][1]; st.whh16[d] = l.d[d].whh16; st.whhT16[d] = l.d[d].whhT16;
             st.gx[d] = a.gx[d]; st.act[d] = a.act[d]; st.c[d] = a.c[d]; st.cstate[d] = m->cstate[d]; st.dz16[d] = a.dzg[d];
         }
-        CK(mk_lstm_fwd_steps(st, s));
+        // one launch for the whole sequence where the shape allows (lstm_rec.hip), else one per timestep
+        if (m->resident && mk_lstm_rec_ok(B, H, m->KP)) CK(mk_lstm_fwd_rec(st, m->rec_words, reinterpret_cast<int*>(m->stats + 8), s));
+        else CK(mk_lstm_fwd_steps(st, s));
         if (m->sub[i] > 1) CK(mk_subsample_rows(a.y16, a.ys16, B, Tin, Tout, m->sub[i], 2 * H, s));      // ys_pad[:, ::sub] (encoder.py:118-121)
         GemmArgs g = nt(a.ys16, 2 * H, l.bt16, 2 * H, Ro, l.N, 2 * H, P + l.btb); g.C32 = a.z32; g.ldc = l.N;
         CK(mk_gemm(g, s));
@@ -210,7 +215,8 @@ int backward(masr_blstm* m, const float* xs, hipStream_t s) {
             st.h16[d][0] = m->h16[d][0]; st.h16[d][1] = m->h16[d][1]; st.whh16[d] = l.d[d].whh16; st.whhT16[d] = l.d[d].whhT16;
             st.gx[d] = a.gx[d]; st.act[d] = a.act[d]; st.c[d] = a.c[d]; st.cstate[d] = m->cstate[d]; st.dz16[d] = a.dzg[d];
         }
-        CK(mk_lstm_bwd_steps(st, s));
+        if (m->resident && mk_lstm_rec_ok(B, H, m->KP)) CK(mk_lstm_bwd_rec(st, m->rec_words, reinterpret_cast<int*>(m->stats + 8), s));
+        else CK(mk_lstm_bwd_steps(st, s));
         CK(mk_lstm_hprev(a.y16, a.hp[0], a.hp[1], B, Tp, H, m->KP, s));
         const int pc = i == 0 ? 256 : 0, pd = i == 0 ? m->Dp : 0;
         for (int d = 0; d < 2; ++d) {
@@ -327,6 +333,7 @@ int masr_blstm_bind(masr_blstm* m, float* params, float* grads, void* workspace,
         HIP_CHECK_RET(hipEventCreateWithFlags(&m->stage_ev, hipEventDisableTiming));
     }
     HIP_CHECK_RET(hipMemset(m->conv_sched, 0, sizeof(unsigned) * 64));
+    HIP_CHECK_RET(hipMemset(m->stats, 0, sizeof(float) * 64));
     HIP_CHECK_RET(hipMemset(m->head16, 0, sizeof(bf16) * (size_t)m->Cp8 * m->layers.back().N));
     HIP_CHECK_RET(hipMemset(m->headT16, 0, sizeof(bf16) * (size_t)m->layers.back().N * m->Cp8));
     m->have = false;
@@ -416,11 +423,17 @@ int masr_blstm_forward(masr_blstm* m, const float* xs, const int64_t* ilens, int
 }
 int masr_blstm_read_stats(masr_blstm* m, float out[4], void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    HIP_CHECK_RET(hipMemcpyAsync(m->h_stats, m->stats, sizeof(float) * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK_RET(hipMemcpyAsync(m->h_stats, m->stats, sizeof(float) * 12, hipMemcpyDeviceToHost, s));
     HIP_CHECK_RET(hipStreamSynchronize(s));
     for (int i = 0; i < 4; ++i) out[i] = m->h_stats[i];
+    if (reinterpret_cast<const int*>(m->h_stats)[8] != 0) {       // a workgroup of the resident recurrence gave up waiting for its peers (lstm_rec.hip)
+        HIP_CHECK_RET(hipMemsetAsync(m->stats + 8, 0, sizeof(int), s));
+        mk_set_error("masr_blstm_read_stats", "the resident LSTM recurrence timed out waiting for a peer workgroup: the step's results are invalid");
+        return -1;
+    }
     return 0;
 }
+void masr_blstm_set_resident_recurrence(masr_blstm* m, int on) { m->resident = on != 0; }
 int masr_blstm_last_logits(masr_blstm* m, float** logits, int32_t** enc_lens, int* B, int* Tp, int* C) {
     if (!m->have) { mk_set_error("masr_blstm_last_logits", "run a batch first"); return -1; }
     *logits = m->logits; *enc_lens = m->lens_l[m->L]; *B = m->B; *Tp = m->Ts[m->L]; *C = m->C;      // (frames / lengths LEAVING the encoder)

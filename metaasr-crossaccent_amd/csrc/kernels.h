@@ -275,6 +275,13 @@ struct LstmStepArgs {
 };
 int mk_lstm_fwd_steps(const LstmStepArgs& a, hipStream_t s);
 int mk_lstm_bwd_steps(const LstmStepArgs& a, hipStream_t s);
+// The same recurrences as ONE launch per layer and pass: workgroups that stay for the whole sequence, W_hh slices in registers, h_t / dz_t
+// exchanged between them as self-flagging 8-byte granules (lstm_rec.hip).  `words`: mk_lstm_rec_words() 64-bit words of scratch (start of an
+// allocation-aligned block); *err is set to 1 when a workgroup gave up waiting for its peers (never cleared by the kernels).
+bool mk_lstm_rec_ok(int B, int H, int KP);
+int64_t mk_lstm_rec_words(int B, int H);
+int mk_lstm_fwd_rec(const LstmStepArgs& a, unsigned long long* words, int* err, hipStream_t s);
+int mk_lstm_bwd_rec(const LstmStepArgs& a, unsigned long long* words, int* err, hipStream_t s);
 // W_ih [4H][K], W_hh [4H][H], biases in torch order -> unit-major bf16 shadows (+ transposes for the dgrad GEMMs)
 int mk_lstm_shadows(const float* wih, const float* whh, const float* bih, const float* bhh, int H, int K, int KP_in, int KP_h,
                     bf16* wih16, bf16* wihT16, bf16* whh16, bf16* whhT16, float* bias, int pc, int pd, hipStream_t s);

@@ -237,6 +237,52 @@ def test_shipped_geometry_runs_deterministically():
     assert losses[-1] < losses[0]
 
 
+@pytest.mark.parametrize("B,T,ilens", [(8, 160, [160, 160, 148, 131, 110, 93, 60, 17]), (20, 96, None), (3, 40, [40, 9, 33])])
+def test_resident_recurrence_equals_per_step_launches(B, T, ilens):
+    """csrc/lstm_rec.hip: the recurrence of a layer as one launch per pass (workgroups resident over the sequence, W_hh in registers, h_t / dz_t
+    exchanged as self-flagging granules) against lstm.hip's launch per timestep (masr_blstm_set_resident_recurrence(0)), at the shipped widths
+    (enc_dim 360 -> 12 workgroups per direction, the last one with 8 units): ragged lengths incl. a sequence shorter than one pooled frame
+    pair, a batch over 16 rows (two MFMA row tiles), a tiny one.  Same fp32 formulas; the recurrent product is one MFMA chain per tile instead
+    of four partial chains, and h_t travels as bf16 either way (a last-bit difference in fp32 can move that rounding), so: logits to 1e-2 of
+    their range (0.2 at these initial weights), loss to 2e-4, every gradient tensor cos > 0.9995 and 1 % in norm.  Repeating the
+    resident step gives the same bits (nothing in it depends on which workgroup arrives first)."""
+    from masr_amd.blstm_engine import reference_init_state_dict
+    cfg = {"encoder": {"idim": 83, "enc_dim": 360, "proj_dim": 360, "odim": 360, "sample_rate": "1_1_1", "dropout": "0_0_0"}}
+    torch.manual_seed(531)
+    sd = reference_init_state_dict(cfg, ODIM)
+    g = torch.Generator().manual_seed(B + T)
+    il = torch.tensor(ilens) if ilens is not None else torch.tensor(sorted([int(x) for x in torch.randint(T // 3, T + 1, (B,), generator=g)], reverse=True))
+    il[0] = T
+    xs = torch.randn(B, T, 83, generator=g)
+    for b in range(B):
+        xs[b, il[b]:] = 0
+    olens = torch.tensor([max(1, min(int(n) // 8 - 1, 12)) for n in il])
+    ys = [torch.randint(1, 366, (int(n),), generator=g) for n in olens]
+    outs = []
+    for resident in (True, True, False):
+        eng = BlstmEngine(cfg, ODIM)
+        eng.load_state_dict(sd)
+        eng.set_resident_recurrence(resident)
+        eng.run_batch(xs, il, ys, olens, train=True)
+        st = eng.read_stats()
+        lg, el = eng.last_logits()
+        outs.append((st["loss"], lg.clone(), el.clone(), eng.grads.clone(), eng))
+    (l0, lg0, el0, g0, eng), (l1, lg1, _, g1, _), (l2, lg2, el2, g2, _) = outs
+    assert l0 == l1 and torch.equal(lg0, lg1) and torch.equal(g0, g1)
+    assert torch.equal(el0, el2) and np.isfinite(l0)
+    assert abs(l0 - l2) <= 2e-4 * abs(l2), (l0, l2)
+    assert float((lg0 - lg2).abs().max()) <= 1e-2 * float(lg2.abs().max())
+    worst = 1.0
+    for n, (off, shape) in eng.table.items():
+        k = int(np.prod(shape))
+        a, b = g0[off:off + k].double(), g2[off:off + k].double()
+        if float(b.norm()) > 0:
+            worst = min(worst, float((a * b).sum() / (a.norm() * b.norm())))
+            assert abs(float(a.norm() / b.norm()) - 1) < 1e-2, n
+    print(f"B={B} T={T}: resident vs per-step: loss {l0:.6f} / {l2:.6f}, max logit difference {float((lg0 - lg2).abs().max()):.2e}, worst gradient cos {worst:.6f}")
+    assert worst > 0.9995
+
+
 def test_tester_best_hyp_matches_reference(golden_dir, tmp_path, monkeypatch):
     """train.py --test --model_name blstm: the best-hyp file of the reference's Tester (arg-max over all frames, trim,
     collapse repeats, drop blanks) for the deterministic tiny model, line by line."""
