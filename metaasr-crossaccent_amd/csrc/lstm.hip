@@ -120,19 +120,35 @@ __global__ void lstm_perm_rows_kernel(const float* __restrict__ w, bf16* __restr
     const int k = (int)(i % KP), pr = (int)(i / KP), u = pr >> 2, g = pr & 3;
     out[i] = k < K ? (bf16)w[(long)(g * H + u) * K + src_col(k, pc, pd)] : (bf16)0.f;
 }
-// transposed recurrent shadow: out[n][pk] = W_hh[(g*H+u)][n] with pk = u*4+g  ([H][4H] bf16)
-__global__ void lstm_whhT_kernel(const float* __restrict__ w, bf16* __restrict__ out, int H) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)H * 4 * H) return;
-    const int pk = (int)(i % (4 * H)), n = (int)(i / (4 * H)), u = pk >> 2, g = pk & 3;
-    out[i] = (bf16)w[(long)(g * H + u) * H + n];
+// the same with permuted columns (pc > 0: layer 0 reads an NHWC conv map), one workgroup per output row: the torch row goes through LDS so
+// that both the read (torch column order) and the write (our column order) are contiguous -- the element-per-thread form above reads
+// with a stride of pd floats here and took 37 us per direction for the 1440 x 5376 matrix of config/blstm
+__global__ __launch_bounds__(256) void lstm_perm_rows_cperm_kernel(const float* __restrict__ w, bf16* __restrict__ out, int H, int K, int KP, int pc, int pd) {
+    extern __shared__ float rowbuf[];
+    const int pr = blockIdx.x, u = pr >> 2, g = pr & 3;
+    const float* src = w + (long)(g * H + u) * K;
+    for (int k = threadIdx.x; k < K; k += 256) rowbuf[k] = src[k];
+    __syncthreads();
+    for (int k = threadIdx.x; k < KP; k += 256) out[(long)pr * KP + k] = k < K ? (bf16)rowbuf[src_col(k, pc, pd)] : (bf16)0.f;
 }
-// transposed input shadow for dX = dz W_ih: out[k][pk] = W_ih[(g*H+u)][k]   ([K][4H] bf16)
-__global__ void lstm_wihT_kernel(const float* __restrict__ w, bf16* __restrict__ out, int H, int K, int pc, int pd) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)K * 4 * H) return;
-    const int pk = (int)(i % (4 * H)), k = (int)(i / (4 * H)), u = pk >> 2, g = pk & 3;
-    out[i] = (bf16)w[(long)(g * H + u) * K + src_col(k, pc, pd)];
+// transposed shadows for the dgrad GEMMs, from the row-major ones: out[k][pk] = in[pk][k] for k < K ([K][R] bf16 from [R][ld]); 64 x 64 tiles
+// through LDS (the element-per-thread form read the fp32 master with a stride of a whole row: 127 us per direction for layer 0's W_ih)
+__global__ __launch_bounds__(256) void transpose16_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int R, int K, int ld) {
+    __shared__ unsigned short tile[64][66];
+    const int r0 = blockIdx.y * 64, k0 = blockIdx.x * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const unsigned short* src = reinterpret_cast<const unsigned short*>(in);
+    unsigned short* dst = reinterpret_cast<unsigned short*>(out);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty * 16 + i, k = k0 + tx;
+        tile[ty * 16 + i][tx] = (r < R && k < K) ? src[(long)r * ld + k] : (unsigned short)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int k = k0 + ty * 16 + i, r = r0 + tx;
+        if (k < K && r < R) dst[(long)k * R + r] = tile[tx][ty * 16 + i];
+    }
 }
 // bias[pk] = b_ih[g*H+u] + b_hh[g*H+u]
 __global__ void lstm_bias_kernel(const float* __restrict__ bih, const float* __restrict__ bhh, float* __restrict__ out, int H) {
@@ -150,6 +166,15 @@ __global__ void lstm_unperm_rows_kernel(const float* __restrict__ src, float* __
     const float v = src[i];
     dst[(long)(g * H + u) * K + src_col(k, pc, pd)] = v;
     if (dst2) dst2[(long)(g * H + u) * K + src_col(k, pc, pd)] = v;
+}
+// the same with permuted columns (pc > 0), one workgroup per row through LDS: dst[(g*H+u)][c*pd + d] = src[(u*4+g)][d*pc + c]
+__global__ __launch_bounds__(256) void lstm_unperm_rows_cperm_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int K, int pc, int pd) {
+    extern __shared__ float rowbuf[];
+    const int pr = blockIdx.x, u = pr >> 2, g = pr & 3;
+    for (int k = threadIdx.x; k < K; k += 256) rowbuf[k] = src[(long)pr * K + k];
+    __syncthreads();
+    float* drow = dst + (long)(g * H + u) * K;
+    for (int kc = threadIdx.x; kc < K; kc += 256) drow[kc] = rowbuf[(kc % pd) * pc + kc / pd];
 }
 // h_{t-1} as the forward pass saw it, for dW_hh = dz^T h_prev: direction 0 takes y[b][t-1][0:H], direction 1 y[b][t+1][H:2H]
 // (rows outside the sequence are zero in y, so the sequence ends need no special case); columns >= H zero
@@ -199,15 +224,21 @@ static inline unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
 
 int mk_lstm_shadows(const float* wih, const float* whh, const float* bih, const float* bhh, int H, int K, int KP_in, int KP_h,
                     bf16* wih16, bf16* wihT16, bf16* whh16, bf16* whhT16, float* bias, int pc, int pd, hipStream_t s) {
-    hipLaunchKernelGGL(lstm_perm_rows_kernel, dim3(nblk((long)4 * H * KP_in)), dim3(256), 0, s, wih, wih16, H, K, KP_in, pc, pd);
-    hipLaunchKernelGGL(lstm_wihT_kernel, dim3(nblk((long)K * 4 * H)), dim3(256), 0, s, wih, wihT16, H, K, pc, pd);
+    if (pc && (size_t)K * sizeof(float) <= 64 * 1024)
+        hipLaunchKernelGGL(lstm_perm_rows_cperm_kernel, dim3(4 * H), dim3(256), (size_t)K * sizeof(float), s, wih, wih16, H, K, KP_in, pc, pd);
+    else
+        hipLaunchKernelGGL(lstm_perm_rows_kernel, dim3(nblk((long)4 * H * KP_in)), dim3(256), 0, s, wih, wih16, H, K, KP_in, pc, pd);
+    hipLaunchKernelGGL(transpose16_kernel, dim3((K + 63) / 64, (4 * H + 63) / 64), dim3(256), 0, s, wih16, wihT16, 4 * H, K, KP_in);
     hipLaunchKernelGGL(lstm_perm_rows_kernel, dim3(nblk((long)4 * H * KP_h)), dim3(256), 0, s, whh, whh16, H, H, KP_h, 0, 0);
-    hipLaunchKernelGGL(lstm_whhT_kernel, dim3(nblk((long)H * 4 * H)), dim3(256), 0, s, whh, whhT16, H);
+    hipLaunchKernelGGL(transpose16_kernel, dim3((H + 63) / 64, (4 * H + 63) / 64), dim3(256), 0, s, whh16, whhT16, 4 * H, H, KP_h);
     hipLaunchKernelGGL(lstm_bias_kernel, dim3(nblk(4 * H)), dim3(256), 0, s, bih, bhh, bias, H);
     return LAUNCH_OK();
 }
 int mk_lstm_unperm(const float* src, float* dst, float* dst2, int H, int K, int pc, int pd, hipStream_t s) {
-    hipLaunchKernelGGL(lstm_unperm_rows_kernel, dim3(nblk((long)4 * H * K)), dim3(256), 0, s, src, dst, dst2, H, K, pc, pd);
+    if (pc && !dst2 && (size_t)K * sizeof(float) <= 64 * 1024)
+        hipLaunchKernelGGL(lstm_unperm_rows_cperm_kernel, dim3(4 * H), dim3(256), (size_t)K * sizeof(float), s, src, dst, H, K, pc, pd);
+    else
+        hipLaunchKernelGGL(lstm_unperm_rows_kernel, dim3(nblk((long)4 * H * K)), dim3(256), 0, s, src, dst, dst2, H, K, pc, pd);
     return LAUNCH_OK();
 }
 int mk_lstm_hprev(const bf16* y16, bf16* hp0, bf16* hp1, int B, int T, int H, int KP, hipStream_t s) {

@@ -91,6 +91,8 @@ __global__ __launch_bounds__(REC_THREADS) void lstm_fwd_rec_kernel(LstmStepArgs 
     constexpr int HS = KS * 32 + 8;                              // LDS row of h in bf16 (+16 bytes: rows fall on different banks)
     __shared__ __attribute__((aligned(16))) bf16 hs[MT * 16 * HS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (Tried: all workgroups of a direction on ONE XCD -- a grid of 8 NW under round-robin placement, the others leaving at once -- so that a
+    // direction's exchange stays behind one L2: forward 290 -> 273 us per layer, backward 394 -> 415.  Not kept.)
     const int dir = blockIdx.x / ra.NW, slice = blockIdx.x % ra.NW;
     const int H = a.H, G = 4 * H, KP = a.KP, T = a.T, B = a.B;
     const int u0 = slice * ra.UPW, uend = u0 + ra.UPW < H ? u0 + ra.UPW : H;
