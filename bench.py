@@ -823,4 +823,17 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:
+        # a rank that fails must END: with several ranks the others sit in a collective or a barrier, and worker threads or a half-issued
+        # exchange can keep this interpreter alive for ever -- the launcher then never learns that the job is dead (seen: a 2-rank run silent
+        # for its whole time limit after an error on rank 0 only)
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush(); sys.stdout.flush()
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            os._exit(1)
+        raise

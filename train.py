@@ -88,4 +88,18 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:
+        # with several ranks a failed rank must end at once (the others wait for it in a collective; worker threads or a half-issued exchange
+        # could otherwise keep this interpreter alive and the launcher would never tear the job down)
+        import os
+        import sys
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush(); sys.stdout.flush()
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            os._exit(1)
+        raise
