@@ -377,9 +377,19 @@ GemmArgs lin_dgrad_args(const bf16* dy, long lddy, const bf16* t16, long ldt, in
     return g;
 }
 
+// The few-row GEMMs with a long reduction (decoder rows: FFN second layer and the first layer's dgrad, K = d_inner; packed q/k/v dgrad, K = 3E) are
+// 80 workgroups with a chain of 24-32 k steps each -- 16 us where their K = 512 siblings take 8.  They run k-split over K / 512 x as many
+// workgroups; each writes its fp32 partial product and the LayerNorm that always follows sums them (and applies what the GEMM's epilogue would
+// have: bias, dropout, residual) on its way in: no combine pass, no extra launch (rowops.hip LnSumArgs).  0: not this shape.
+static int ksplit_of(const masr_model* m, int rows, int K) { return (m->ksplit && rows <= 1024 && K >= 1024 && K % 512 == 0 && K / 512 <= KSPLIT_MAX) ? K / 512 : 0; }
+static GemmArgs ksplit_args(const masr_model* m, GemmArgs g, int S, int rows, int N) {
+    g.bias = nullptr; g.drop_p = 0.f; g.residual = nullptr; g.C16 = nullptr;
+    g.C32 = m->acts.part; g.ldc = N; g.split_k = S; g.split_stride = (long)rows * N;
+    return g;
+}
 int attn_block_fwd(Ctx& c, const Attn& at, const bf16* xq, const bf16* xkv, int rows_q, int rows_kv, int Tq, int Tk, bool self,
                    bool causal, const int* klens, bf16* qkv_or_q, bf16* kv, bf16* ao, float* lse, const float* resid, float* s_out,
-                   uint32_t site_p, uint32_t site_o) {
+                   uint32_t site_p, uint32_t site_o, LnSumArgs* defer = nullptr) {
     masr_model* m = c.m; const int E = m->E; const float* P = m->P;
     AttnArgs a{};
     if (self) {
@@ -398,20 +408,18 @@ int attn_block_fwd(Ctx& c, const Attn& at, const bf16* xq, const bf16* xkv, int 
     { Prof p(m, Tk == m->acts.Tp && Tq == Tk ? MASR_PROF_ATTN_ENC : MASR_PROF_ATTN_DEC, c.s); CK(mk_attn_fwd(a, c.s)); }
     GemmArgs o = lin_fwd_args(ao, E, at.out.k16, rows_q, E, E, P + at.out.b);
     o.drop_p = c.p_drop; o.seed = c.seed; o.site = site_o; o.residual = resid; o.ldres = E; o.C32 = s_out; o.ldc = E;
+    // few rows: the reduction over E runs as two halves on twice the workgroups, the LayerNorm behind the block sums them (see ksplit_of):
+    // out-projection 8.6 -> 5.9 us, the LayerNorm 4.8 -> 5.6 with the second partial to read
+    const int S = (defer && m->ksplit && rows_q <= 1024 && E >= 512 && E % 128 == 0) ? 2 : 0;
+    if (S) {
+        *defer = LnSumArgs{m->acts.part, (long)rows_q * E, S, P + at.out.b, resid, c.p_drop, c.seed, site_o, c.seed_ptr, s_out};
+        return gemm(c, ksplit_args(m, o, S, rows_q, E));
+    }
+    if (defer) defer->n = 0;
     CK(gemm(c, o));
     return 0;
 }
 
-// The few-row GEMMs with a long reduction (decoder rows: FFN second layer and the first layer's dgrad, K = d_inner; packed q/k/v dgrad, K = 3E) are
-// 80 workgroups with a chain of 24-32 k steps each -- 16 us where their K = 512 siblings take 8.  They run k-split over K / 512 x as many
-// workgroups; each writes its fp32 partial product and the LayerNorm that always follows sums them (and applies what the GEMM's epilogue would
-// have: bias, dropout, residual) on its way in: no combine pass, no extra launch (rowops.hip LnSumArgs).  0: not this shape.
-static int ksplit_of(const masr_model* m, int rows, int K) { return (m->ksplit && rows <= 1024 && K >= 1024 && K % 512 == 0 && K / 512 <= KSPLIT_MAX) ? K / 512 : 0; }
-static GemmArgs ksplit_args(const masr_model* m, GemmArgs g, int S, int rows, int N) {
-    g.bias = nullptr; g.drop_p = 0.f; g.residual = nullptr; g.C16 = nullptr;
-    g.C32 = m->acts.part; g.ldc = N; g.split_k = S; g.split_stride = (long)rows * N;
-    return g;
-}
 int ffn_fwd(Ctx& c, const Lin& l1, const Lin& l2, const bf16* x16, const float* x32, int rows, bf16* f, float* s_out, uint32_t site_i, uint32_t site_o,
             LnSumArgs* defer = nullptr) {
     masr_model* m = c.m; const int E = m->E, Fi = m->Fi; const float* P = m->P;
@@ -771,13 +779,13 @@ static int forward_decoder(Ctx& c, bool project_kv = true, bool logits_f32 = fal
     for (int l = 0; l < m->ND; ++l) {
         DecAct& d = a.dec[l]; const DecL& w = m->dec[l];
         for (int i = 0; i < 6; ++i) d.site[i] = site++;
+        LnSumArgs ks{};                                        // (k-split GEMMs: their partial products are summed by the LayerNorm behind them)
         CK(attn_block_fwd(c, w.sa, a.y16[l], nullptr, a.rows_d, 0, L, L, true, true, nullptr, d.qkv, nullptr, d.ao, d.lse_s, a.y32[l], d.s1,
-                          d.site[0], d.site[1]));
-        CK(ln_fwd(c, w.n1, d.s1, d.y1_32, d.y1_16, d.m1, d.r1, a.rows_d));
+                          d.site[0], d.site[1], &ks));
+        CK(ln_fwd(c, w.n1, d.s1, d.y1_32, d.y1_16, d.m1, d.r1, a.rows_d, &ks));
         CK(attn_block_fwd(c, w.ca, d.y1_16, a.mem16, a.rows_d, a.rows_e, L, a.Tp, false, false, a.enc_lens, d.q, d.kv, d.co, d.lse_c, d.y1_32,
-                          d.s2, d.site[2], d.site[3]));
-        CK(ln_fwd(c, w.n2, d.s2, d.y2_32, d.y2_16, d.m2, d.r2, a.rows_d));
-        LnSumArgs ks{};                                        // (FFN second layer k-split: its partial products are summed by norm3)
+                          d.s2, d.site[2], d.site[3], &ks));
+        CK(ln_fwd(c, w.n2, d.s2, d.y2_32, d.y2_16, d.m2, d.r2, a.rows_d, &ks));
         CK(ffn_fwd(c, w.l1, w.l2, d.y2_16, d.y2_32, a.rows_d, d.f, d.s3, d.site[4], d.site[5], &ks));
         CK(ln_fwd(c, w.n3, d.s3, a.y32[l + 1], a.y16[l + 1], d.m3, d.r3, a.rows_d, &ks));
     }

@@ -438,8 +438,9 @@ def test_ksplit_gemms_with_the_combine_inside_the_layernorm(dropout):
     summation order only, but not bit for bit downstream: a last-bit difference moves some bf16 operand roundings of the following layers, so
     the step agrees to the engine's bf16 noise floor -- the same distance either schedule keeps from the bf16-emulated oracle (logits ~5e-3 of
     their range, loss ~1e-4): loss to 3e-4, logits to 1 % of their range, every gradient tensor's direction to cos > 0.998, the flat gradient to
-    cos > 0.9995 and 0.5 % in norm (the engine against the bf16-emulated oracle: cos > 0.995).  Decoder rows in front of the first such rounding are bit-identical (causal attention), which a wrong
-    element index in the dropout or a missing bias would not leave."""
+    cos > 0.9995 and 0.5 % in norm (the engine against the bf16-emulated oracle: cos > 0.995).  The first decoder row of the batch (causal attention:
+    the fewest such roundings upstream) agrees to 2e-3 of the logits' range, which a wrong element index in the dropout or a missing bias would
+    not leave.  Since round 5 the attention out-projections (K = 512, two halves) take the same route."""
     cfg = dict(HKUST)
     cfg["dropout"] = cfg["pos_dropout"] = dropout
     sd = ref_cpu.deterministic_state_dict(cfg, ODIM, seed=4)
@@ -456,7 +457,7 @@ def test_ksplit_gemms_with_the_combine_inside_the_layernorm(dropout):
     assert abs(sa["loss"] - sb["loss"]) <= 3e-4 * abs(sb["loss"]), (sa["loss"], sb["loss"])
     assert float((la - lb).abs().max()) <= 1e-2 * float(lb.abs().max())
     assert not torch.equal(ga, gb)                            # (the two schedules do differ: this is not the same code path twice)
-    assert torch.equal(la[0, 0], lb[0, 0])                    # first decoder row of the batch: nothing upstream of it has been re-rounded yet
+    assert float((la[0, 0] - lb[0, 0]).abs().max()) <= 2e-3 * float(lb.abs().max())      # first decoder row of the batch: the fewest re-roundings upstream
     worst = 1.0
     for n, (off, shape) in eng.table.items():
         k = int(np.prod(shape))
