@@ -103,8 +103,13 @@ class BlstmEngine:
 
     def run_batch(self, xs, ilens, ys, olens, train: bool):
         """forward + CTC loss (+ backward).  ys: list of int64 label tensors WITHOUT sos/eos; olens: their lengths."""
+        ready = getattr(xs, "_masr_ready", None)               # uploaded ahead on the loader's copy stream (io/dataset.py Loader._materialize_ahead)
+        if ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(ready)
         if xs.device != self.device:
             xs = xs.to(self.device, non_blocking=True)
+        elif xs.is_cuda:
+            xs.record_stream(torch.cuda.current_stream(self.device))      # (made on another stream: see MasrEngine.run_batch)
         xs = xs.contiguous().float()
         B, T, D = xs.shape
         assert D == self.cfg.idim

@@ -179,6 +179,9 @@ class MasrEngine:
     def run_batch(self, xs: torch.Tensor, ilens, ys, olens, train: bool):
         """forward + loss (+ backward).  xs: device fp32 [B,T,idim] (host tensors are uploaded);
         ilens/olens: int64 host tensors; ys: list of int64 host tensors."""
+        ready = getattr(xs, "_masr_ready", None)               # uploaded ahead on the loader's copy stream (io/dataset.py Loader._materialize_ahead)
+        if ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(ready)
         if xs.device != self.device:
             xs = xs.to(self.device, non_blocking=True)
         elif xs.is_cuda:
