@@ -345,6 +345,9 @@ __global__ __launch_bounds__(256) void all_shadows_kernel(typename std::conditio
         }
         __syncthreads();
         const int sub = threadIdx.x & 7, line = threadIdx.x >> 3;        // 8 lanes x 8 elements = one 64-element line
+        // LDS bank of element (line l, column 8 sub + e) is (l + 8 sub + e) mod 32: lanes sub and sub + 4 of a line would meet in every read
+        // (2-way conflict, SQ_LDS_BANK_CONFLICT 0.49 of the LDS cycles).  Lanes with sub >= 4 take their eight elements rotated by four.
+        const int rot = (sub >> 2) * 4;
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             const int l = line + 32 * pass;
@@ -352,8 +355,11 @@ __global__ __launch_bounds__(256) void all_shadows_kernel(typename std::conditio
                 const int r = r0 + l, c = c0 + sub * 8;
                 if (r < d.N && c < dK) {
                     bf16x8 o;
+                    float tv[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (bf16)t[l][sub * 8 + e];
+                    for (int e = 0; e < 8; ++e) tv[e] = t[l][sub * 8 + ((e + rot) & 7)];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16)(rot ? tv[(e + 4) & 7] : tv[e]);
                     if (c + 8 <= dK) st8(p0 + (long)r * dK + c, o);
                     else for (int e = 0; c + e < dK; ++e) p0[(long)r * dK + c + e] = o[e];
                 }
@@ -362,8 +368,11 @@ __global__ __launch_bounds__(256) void all_shadows_kernel(typename std::conditio
                 const int c = c0 + l, r = r0 + sub * 8;
                 if (c < dK && r < d.N) {
                     bf16x8 o;
+                    float tv[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (bf16)t[sub * 8 + e][l];
+                    for (int e = 0; e < 8; ++e) tv[e] = t[sub * 8 + ((e + rot) & 7)][l];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16)(rot ? tv[(e + 4) & 7] : tv[e]);
                     if (r + 8 <= d.N) st8(p1 + (long)c * dldt + r, o);
                     else for (int e = 0; r + e < d.N; ++e) p1[(long)c * dldt + r + e] = o[e];       // (pads of a padded row stay untouched)
                 }
