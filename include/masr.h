@@ -248,6 +248,9 @@ int masr_blstm_read_stats(masr_blstm* m, float out[4], void* stream);           
  * enc_dim <= 384); off = per-timestep launches (A/B + test; same results to fp32 rounding).  A timed-out exchange is reported by
  * masr_blstm_read_stats. */
 void masr_blstm_set_resident_recurrence(masr_blstm* m, int on);
+/* test only: the next resident forward launches lose one workgroup at start, so that its peers run into the bound of their wait and the step
+ * is reported as failed by masr_blstm_read_stats instead of hanging (tests/test_hip_blstm.py) */
+void masr_test_blstm_stall(int on);
 /* head output (pre-softmax) [B][Tp][odim] fp32 and enc_lens int32 [B] on the device, Tp = ceil(ceil(T/2)/2) */
 int masr_blstm_last_logits(masr_blstm* m, float** logits, int32_t** enc_lens, int* B, int* Tp, int* C);
 /* nn.utils.clip_grad_norm_(parameters, max_norm) on the flat gradient; the norm is read with masr_blstm_read_stats */

@@ -79,6 +79,7 @@ _SIGS = {
     "masr_blstm_forward": (i32, [vp, vp, vp, i32, i32, vp]),
     "masr_blstm_read_stats": (i32, [vp, C.POINTER(f32), vp]),
     "masr_blstm_set_resident_recurrence": (None, [vp, i32]),
+    "masr_test_blstm_stall": (None, [i32]),
     "masr_blstm_last_logits": (i32, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "masr_blstm_clip_grads": (i32, [vp, f32, vp]),
     "masr_blstm_clip_sgd_step": (i32, [vp, vp, f32, f32, f32, i32, i32, vp]),

@@ -434,6 +434,7 @@ int masr_blstm_read_stats(masr_blstm* m, float out[4], void* stream) {
     return 0;
 }
 void masr_blstm_set_resident_recurrence(masr_blstm* m, int on) { m->resident = on != 0; }
+void masr_test_blstm_stall(int on) { mk_lstm_rec_test_stall(on); }
 int masr_blstm_last_logits(masr_blstm* m, float** logits, int32_t** enc_lens, int* B, int* Tp, int* C) {
     if (!m->have) { mk_set_error("masr_blstm_last_logits", "run a batch first"); return -1; }
     *logits = m->logits; *enc_lens = m->lens_l[m->L]; *B = m->B; *Tp = m->Ts[m->L]; *C = m->C;      // (frames / lengths LEAVING the encoder)

@@ -282,6 +282,7 @@ bool mk_lstm_rec_ok(int B, int H, int KP);
 int64_t mk_lstm_rec_words(int B, int H);
 int mk_lstm_fwd_rec(const LstmStepArgs& a, unsigned long long* words, int* err, hipStream_t s);
 int mk_lstm_bwd_rec(const LstmStepArgs& a, unsigned long long* words, int* err, hipStream_t s);
+void mk_lstm_rec_test_stall(int on);      // fault injection for the time-out test: workgroup 0 of the forward launch leaves without publishing
 // W_ih [4H][K], W_hh [4H][H], biases in torch order -> unit-major bf16 shadows (+ transposes for the dgrad GEMMs)
 int mk_lstm_shadows(const float* wih, const float* whh, const float* bih, const float* bhh, int H, int K, int KP_in, int KP_h,
                     bf16* wih16, bf16* wihT16, bf16* whh16, bf16* whhT16, float* bias, int pc, int pd, hipStream_t s);

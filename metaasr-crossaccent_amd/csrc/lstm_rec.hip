@@ -81,7 +81,7 @@ __device__ __forceinline__ bool gather_granules(__amdgpu_buffer_rsrc_t rsrc, uns
     return true;
 }
 
-struct RecArgs { unsigned long long* gr; int* err; int NW, UPW; unsigned gr_bytes; };
+struct RecArgs { unsigned long long* gr; int* err; int NW, UPW; unsigned gr_bytes; int stall; };
 
 // ---- forward through time.  grid = 2 * NW workgroups of 512 threads: direction = blockIdx / NW, slice = blockIdx % NW.
 // Wave w multiplies the gate columns of units [u0 + 4w, u0 + 4w + 4) (one 16-column tile of the unit-major gate axis).
@@ -94,6 +94,7 @@ __global__ __launch_bounds__(REC_THREADS) void lstm_fwd_rec_kernel(LstmStepArgs 
     // (Tried: all workgroups of a direction on ONE XCD -- a grid of 8 NW under round-robin placement, the others leaving at once -- so that a
     // direction's exchange stays behind one L2: forward 290 -> 273 us per layer, backward 394 -> 415.  Not kept.)
     const int dir = blockIdx.x / ra.NW, slice = blockIdx.x % ra.NW;
+    if (ra.stall && blockIdx.x == 0) return;                    // fault injection (masr_test_blstm_stall): a workgroup that never publishes
     const int H = a.H, G = 4 * H, KP = a.KP, T = a.T, B = a.B;
     const int u0 = slice * ra.UPW, uend = u0 + ra.UPW < H ? u0 + ra.UPW : H;
     const int GRR = (H + 1) / 2, GR = (GRR + 1) / 2 * 2;         // granules per batch row: real ones / with the pad that makes the row even
@@ -309,11 +310,13 @@ static void fwd_rec_launch(const LstmStepArgs& a, const RecArgs& ra, hipStream_t
     else if (ks <= 8) hipLaunchKernelGGL((lstm_fwd_rec_kernel<8, MT>), grid, dim3(REC_THREADS), 0, s, a, ra);
     else hipLaunchKernelGGL((lstm_fwd_rec_kernel<12, MT>), grid, dim3(REC_THREADS), 0, s, a, ra);
 }
+static int g_rec_stall = 0;
+void mk_lstm_rec_test_stall(int on) { g_rec_stall = on; }
 int mk_lstm_fwd_rec(const LstmStepArgs& a, unsigned long long* words, int* err, hipStream_t s) {
     if (!mk_lstm_rec_ok(a.B, a.H, a.KP)) { mk_set_error("mk_lstm_fwd_rec", "shape not covered by the resident recurrence"); return -1; }
     // tags of the forward exchange: [2 dirs][2 parities][B][granules per row] (the block starts its allocation; zeroed in whole 16 bytes)
     const size_t bytes = sizeof(unsigned long long) * (size_t)2 * 2 * a.B * fwd_row_granules(a.H);
-    RecArgs ra{words, err, rec_slices(a.H), rec_units(a.H), (unsigned)bytes};
+    RecArgs ra{words, err, rec_slices(a.H), rec_units(a.H), (unsigned)bytes, g_rec_stall};
     if (hipMemsetAsync(words, 0, bytes, s) != hipSuccess) { mk_set_error("mk_lstm_fwd_rec", "memset failed"); return -1; }
     if (a.B <= 16) fwd_rec_launch<1>(a, ra, s); else fwd_rec_launch<2>(a, ra, s);
     return LAUNCH_OK();
@@ -332,7 +335,7 @@ static int bwd_rec_launch1(const LstmStepArgs& a, const RecArgs& ra, hipStream_t
 int mk_lstm_bwd_rec(const LstmStepArgs& a, unsigned long long* words, int* err, hipStream_t s) {
     if (!mk_lstm_rec_ok(a.B, a.H, a.KP)) { mk_set_error("mk_lstm_bwd_rec", "shape not covered by the resident recurrence"); return -1; }
     const size_t bytes = sizeof(unsigned long long) * (size_t)2 * 2 * a.B * 2 * a.H;
-    RecArgs ra{words, err, rec_slices(a.H), rec_units(a.H), (unsigned)bytes};
+    RecArgs ra{words, err, rec_slices(a.H), rec_units(a.H), (unsigned)bytes, 0};
     if (hipMemsetAsync(words, 0, bytes, s) != hipSuccess) { mk_set_error("mk_lstm_bwd_rec", "memset failed"); return -1; }
     const int kq = (4 * a.H / 32 + 3) / 4;
     int rc;

@@ -283,6 +283,37 @@ def test_resident_recurrence_equals_per_step_launches(B, T, ilens):
     assert worst > 0.9995
 
 
+def test_resident_recurrence_times_out_loudly():
+    """A workgroup of the resident recurrence that never publishes its part of h_t (fault injection: it leaves at start) must not hang the
+    step: its peers give up after a bounded number of polls, the launch ends, and masr_blstm_read_stats reports the step as failed.  The
+    next step (all workgroups present) runs and gives the numbers of an undisturbed engine."""
+    import time
+    from masr_amd import _cabi
+    sd = blstm_cpu.deterministic_state_dict(BLSTM_TINY, ODIM, seed=11)
+    xs, il, ys, ol = synth_batch(5, [64, 52, 40], [6, 4, 3])
+    ref = BlstmEngine(BLSTM_TINY, ODIM)
+    ref.load_state_dict(sd)
+    ref.run_batch(xs, il, ys, ol, train=True)
+    want = ref.read_stats()
+    eng = BlstmEngine(BLSTM_TINY, ODIM)
+    eng.load_state_dict(sd)
+    L = _cabi.lib()
+    L.masr_test_blstm_stall(1)
+    try:
+        t0 = time.perf_counter()
+        eng.run_batch(xs, il, ys, ol, train=True)
+        with pytest.raises(_cabi.MasrError, match="timed out"):
+            eng.read_stats()
+        dt = time.perf_counter() - t0
+    finally:
+        L.masr_test_blstm_stall(0)
+    print(f"stalled step reported after {dt:.1f} s")
+    assert dt < 120
+    eng.run_batch(xs, il, ys, ol, train=True)
+    got = eng.read_stats()
+    assert got["loss"] == want["loss"] and got["grad_norm"] == want["grad_norm"]
+
+
 def test_tester_best_hyp_matches_reference(golden_dir, tmp_path, monkeypatch):
     """train.py --test --model_name blstm: the best-hyp file of the reference's Tester (arg-max over all frames, trim,
     collapse repeats, drop blanks) for the deterministic tiny model, line by line."""
