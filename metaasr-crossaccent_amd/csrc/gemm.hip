@@ -764,6 +764,128 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
     gemm_epilogue<BM, BN, EPI>(g, acc, smem, m0, n0, (long)bz_ * g.split_stride);
 }
 
+// ---- The same NT tile with the two jobs on different waves (round 5): waves 4-7 only stream (LDS-DMA into a ring of NS stages, counted
+// vmcnt), waves 0-3 only read fragments and multiply (software-pipelined by half k-steps: the next half's ds_reads fly under the current
+// MFMAs); ONE barrier per k-step is the only synchronisation, and the multiplying waves never execute a vector-memory instruction or wait for
+// one.  Why: taken apart, gemm_glds_kernel<128, 64> spends 0.32 us per 64-deep k-step in the DMA alone (24 KB = 75 GB/s per CU, the L2-hit
+// ceiling) and 0.30 in reads + MFMAs alone, but 0.43 with both in the same four waves (issue, counted wait and barrier of the stream sit in
+// every multiplying wave's k-step); ring depth and read pipelining inside those waves changed nothing.  Split: 0.31 per k-step -- FFN2
+// (4000 x 512 x 2048, plain epilogue) 19.4 -> 14.9 us, q/k/v dgrad 16.2 -> 12.3, vgg2enc 24.4 -> 22.4 (vendor library, graph-replayed:
+// 15.8 / - / 19.6).  One workgroup per CU (96 KB of ring): for grids of at most one tile per CU, i.e. the 128 x 64 launches of the
+// encoder rows; the 128 x 128 launches (K = 512: eight k-steps per tile, prologue and epilogue are half the tile's life) need their second
+// workgroup per CU more than the split (q/k/v 17.3 -> 21.8 as one ring workgroup per CU).
+template <int BM, int BN, int EPI, int NS>
+__global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs g) {
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int LDC = BN + 4;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
+    constexpr size_t OUT_BYTES = sizeof(float) * BM * LDC;
+    __shared__ __attribute__((aligned(16))) char smem[NS * BUF > OUT_BYTES ? NS * BUF : OUT_BYTES];
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx_ = blockIdx.x, by_ = blockIdx.y, bz_ = blockIdx.z;
+    if (g.xcd_order) xcd_tile(bx_, by_, bz_);
+    const int m0 = by_ * BM, n0 = bx_ * BN;
+    const int nk = g.K / 64 / (int)gridDim.z, kt0 = bz_ * nk;
+    constexpr int ACH = BM * 8 / 256, BCH = BN * 8 / 256, LT = ACH + BCH;
+    static_assert(LT * (NS - 1) < 64, "vmcnt range");
+    if (wave >= 4) {
+        // ---- loader waves
+        const int lt = tid - 256, lw = wave - 4;
+        const bf16* asrc[ACH]; const bf16* bsrc[BCH];
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const int c = lt + i * 256, r = c >> 3, ch = (c & 7) ^ (r & 7);
+            const int row = m0 + r < g.M ? m0 + r : g.M - 1;
+            asrc[i] = g.A + (long)row * g.lda + ch * 8 + (long)kt0 * 64;
+        }
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            const int c = lt + i * 256, r = c >> 3, ch = (c & 7) ^ (r & 7);
+            const int row = n0 + r < g.N ? n0 + r : g.N - 1;
+            bsrc[i] = g.B + (long)row * g.ldb + ch * 8 + (long)kt0 * 64;
+        }
+        auto stage = [&](int buf, int kt) {
+            char* ab = smem + buf * BUF;
+            char* bb = ab + A_BYTES;
+#pragma unroll
+            for (int i = 0; i < ACH; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t*)(asrc[i] + kt * 64), (lptr_t*)(ab + (lw * 64 + i * 256) * 16), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < BCH; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t*)(bsrc[i] + kt * 64), (lptr_t*)(bb + (lw * 64 + i * 256) * 16), 16, 0, 0);
+        };
+        auto wait_stages = [&](int rem) {                  // at most `rem` stages' DMAs of this wave still outstanding
+            if (rem >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LT * 3 < 64 ? LT * 3 : 63) : "memory");
+            else if (rem == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LT * 2) : "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LT * 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        // barrier j (j = 0 .. nk - 1) tells the multiplying waves that stage j has landed; passing it also means they are done with stage j - 1
+#pragma unroll
+        for (int s0 = 0; s0 < NS - 1; ++s0) if (s0 < nk) stage(s0, s0);
+        int issued = nk < NS - 1 ? nk : NS - 1;
+        for (int j = 0; j < nk; ++j) {
+            const int rem = issued - (j + 1);
+            wait_stages(rem > NS - 2 ? NS - 2 : rem);
+            __builtin_amdgcn_s_barrier();
+            if (issued < nk) { stage(issued % NS, issued); ++issued; }      // into the buffer of stage j - 1
+        }
+        return;
+    }
+    // ---- multiplying waves
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int rr = lane & 15, q = lane >> 4;
+    auto load_frags = [&](int buf, int kc, bf16x8 (&af)[FM], bf16x8 (&bfr)[FN]) {
+        const bf16* ab = reinterpret_cast<const bf16*>(smem + buf * BUF);
+        const bf16* bb = reinterpret_cast<const bf16*>(smem + buf * BUF + A_BYTES);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int row = wm * WM + i * 16 + rr;
+            af[i] = ld8(ab + row * 64 + (((kc * 4 + q) ^ (row & 7)) * 8));
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int row = wn * WN + j * 16 + rr;
+            bfr[j] = ld8(bb + row * 64 + (((kc * 4 + q) ^ (row & 7)) * 8));
+        }
+    };
+    auto mma_all = [&](const bf16x8 (&af)[FM], const bf16x8 (&bfr)[FN]) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
+    };
+    bf16x8 a0[FM], b0[FN], a1[FM], b1[FN];
+    __builtin_amdgcn_s_barrier();                          // barrier 0: stage 0 has landed
+    load_frags(0, 0, a0, b0);
+    int cur = 0;
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        load_frags(cur, 1, a1, b1);
+        mma_all(a0, b0);
+        const int nxt = cur == NS - 1 ? 0 : cur + 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave has finished reading stage kt
+        __builtin_amdgcn_s_barrier();                      // barrier kt + 1: stage kt + 1 has landed
+        load_frags(nxt, 0, a0, b0);
+        mma_all(a1, b1);
+        cur = nxt;
+    }
+    load_frags(cur, 1, a1, b1);
+    mma_all(a0, b0);
+    mma_all(a1, b1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // (the loader waves are gone: the four of us) before the epilogue reuses the LDS
+    gemm_epilogue<BM, BN, EPI>(g, acc, smem, m0, n0, (long)bz_ * g.split_stride);
+}
+
 // ---- LayerNorm in the prologue of its consumer GEMM (round 4).  64-row tiles, K == E <= 512: the workgroup normalises its 64 rows
 // (one wave per row, four rows per pass: the arithmetic and the lane -> column map of rowops.hip's ln_fwd_kernel / ln_bwd_kernel, so the
 // fused path gives the same bits) into an LDS-resident bf16 A tile [64][E + 8], then runs the k loop with the B tiles streamed by LDS-DMA
@@ -990,8 +1112,17 @@ __global__ __launch_bounds__(256) void gemm_lnbwd_kernel(GemmArgs g, LnBwdA ln) 
     lnA_mainloop<BN, EPI>(g, sa, LDA, ring, smem, m0, n0);
 }
 
+static int gemm_ncu() {
+    static int ncu = 0;
+    if (!ncu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); if (ncu <= 0) ncu = 256; }
+    return ncu;
+}
 template <int BM, int BN, int EPI>
 void launch_glds(const GemmArgs& g, dim3 grid, hipStream_t s) {
+    if constexpr (BM == 128 && BN == 64) {
+        // at most one tile per CU: the loader-wave form (one workgroup per CU)
+        if ((long)grid.x * grid.y * grid.z <= gemm_ncu()) { hipLaunchKernelGGL((gemm_ring_kernel<BM, BN, EPI, 4>), grid, dim3(512), 0, s, g); return; }
+    }
     hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, EPI>), grid, dim3(256), 0, s, g);
 }
 
