@@ -125,8 +125,10 @@ enum { E_BIAS = 1, E_PE = 2, E_RELU = 4, E_MASK = 8, E_DROP = 16, E_RES = 32, E_
 #define HAS(flag, runtime) (EPI >= 0 ? bool(EPI & (flag)) : bool(runtime))
 
 // ---- shared epilogue (see the comment inside): consumes the accumulators of one BM x BN tile
-template <int BM, int BN, int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM / 32][BN / 32], char* smem, int m0, int n0, long out_delta) {
+// NT = threads that take part (512: the loader waves of gemm_ring_kernel store strips too; they hold no accumulators: has_acc false)
+template <int BM, int BN, int EPI, int NT = 256>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM / 32][BN / 32], char* smem, int m0, int n0, long out_delta,
+                                              bool has_acc = true) {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int FM = WM / 16, FN = WN / 16;
     constexpr int LDC = BN + 4;
@@ -137,13 +139,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
     // 8-byte (bf16) row segment, and each optional input is fetched with ONE batched load per 4 outputs (per-element
     // branches around loads serialise on s_waitcnt vmcnt(0) and used to dominate the small decoder GEMMs).
     float* ct = reinterpret_cast<float*>(smem);
+    if (has_acc) {
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
+            for (int j = 0; j < FN; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                ct[(wm * WM + i * 16 + (lane >> 4) * 4 + r) * LDC + wn * WN + j * 16 + (lane & 15)] = acc[i][j][r] * g.alpha;
+                for (int r = 0; r < 4; ++r)
+                    ct[(wm * WM + i * 16 + (lane >> 4) * 4 + r) * LDC + wn * WN + j * 16 + (lane & 15)] = acc[i][j][r] * g.alpha;
+    }
     __syncthreads();
     // A thread owns strips of SW columns.  The epilogue is bound by the NUMBER of vector-memory wave-instructions (one
     // texture addresser per CU, ~70 cycles each whatever their width), so epilogues with 16-bit streams (bf16 output, ReLU
@@ -153,7 +157,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
     // round trip per strip (8 to 16 per tile; the masked dgrad GEMMs ran 3x longer than their unmasked twins).  Strips are
     // therefore handled in batches of four: loads of the batch, then its arithmetic and stores.
     constexpr int SW = (EPI >= 0 && (EPI & (E_C16 | E_MASK))) ? 8 : 4;
-    constexpr int CS = BN / SW, NCH = BM * CS / 256;
+    constexpr int CS = BN / SW, NCH = BM * CS / NT;
+    static_assert(NCH >= 1, "tile too small for this many threads");
     const int cs = (tid % CS) * SW, n = n0 + cs;
     if (n >= g.N) return;
     const bool f_bias = HAS(E_BIAS, g.bias), f_pe = HAS(E_PE, g.pe), f_relu = HAS(E_RELU, g.relu), f_mask = HAS(E_MASK, g.mask);
@@ -187,7 +192,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
     float rs[NB][SW], old[NB][SW], pev[NB][SW], mk[NB][SW];
 #pragma unroll
     for (int ii = 0; ii < NB; ++ii) {
-        const int i = ii, row = (tid + (i0 + ii) * 256) / CS, m = m0 + row;
+        const int i = ii, row = (tid + (i0 + ii) * NT) / CS, m = m0 + row;
 #pragma unroll
         for (int e = 0; e < SW; ++e) { rs[i][e] = 0.f; old[i][e] = 0.f; pev[i][e] = 0.f; mk[i][e] = 1.f; }
         if (m >= g.M) continue;
@@ -217,7 +222,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
     // ---- phase 2: arithmetic and stores
 #pragma unroll
     for (int ii = 0; ii < NB; ++ii) {
-        const int i = ii, row = (tid + (i0 + ii) * 256) / CS, m = m0 + row;
+        const int i = ii, row = (tid + (i0 + ii) * NT) / CS, m = m0 + row;
         if (m >= g.M) continue;
         float v[SW];
         ldf(ct + row * LDC + cs, v);
@@ -792,6 +797,11 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs g) {
     const int nk = g.K / 64 / (int)gridDim.z, kt0 = bz_ * nk;
     constexpr int ACH = BM * 8 / 256, BCH = BN * 8 / 256, LT = ACH + BCH;
     static_assert(LT * (NS - 1) < 64, "vmcnt range");
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (wave >= 4) {
         // ---- loader waves
         const int lt = tid - 256, lw = wave - 4;
@@ -834,15 +844,14 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs g) {
             __builtin_amdgcn_s_barrier();
             if (issued < nk) { stage(issued % NS, issued); ++issued; }      // into the buffer of stage j - 1
         }
+        // the tile's epilogue is shared with the multiplying waves: twice the loads and stores in flight per CU (FFN2 + bias + residual in
+        // the step: 22.4 us with the four multiplying waves alone storing)
+        __builtin_amdgcn_s_barrier();
+        gemm_epilogue<BM, BN, EPI, 512>(g, acc, smem, m0, n0, (long)bz_ * g.split_stride, false);
         return;
     }
     // ---- multiplying waves
     const int wm = wave >> 1, wn = wave & 1;
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int rr = lane & 15, q = lane >> 4;
     auto load_frags = [&](int buf, int kc, bf16x8 (&af)[FM], bf16x8 (&bfr)[FN]) {
         const bf16* ab = reinterpret_cast<const bf16*>(smem + buf * BUF);
@@ -882,8 +891,8 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs g) {
     mma_all(a0, b0);
     mma_all(a1, b1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                          // (the loader waves are gone: the four of us) before the epilogue reuses the LDS
-    gemm_epilogue<BM, BN, EPI>(g, acc, smem, m0, n0, (long)bz_ * g.split_stride);
+    __builtin_amdgcn_s_barrier();                          // everybody is done with the ring: the epilogue stages the tile in it
+    gemm_epilogue<BM, BN, EPI, 512>(g, acc, smem, m0, n0, (long)bz_ * g.split_stride, true);
 }
 
 // ---- LayerNorm in the prologue of its consumer GEMM (round 4).  64-row tiles, K == E <= 512: the workgroup normalises its 64 rows
