@@ -1,6 +1,6 @@
 """Encoder-row NT GEMM shapes of the hkust step through masr_test_gemm (plain fp32 epilogue), operands rotated over 8 sets; beside
 tools/gemm_lib_probe.py (the vendor library on the same shapes).  GPU box only."""
-import ctypes as C, os, sys
+import ctypes as C, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
@@ -27,4 +27,4 @@ for tag, M, N, K in (("vgg2enc", 4000, 512, 2688), ("qkv", 4000, 1536, 512), ("o
                      ("kv_mem", 4000, 4096, 512), ("dqkv", 4000, 512, 1536), ("dkv", 4000, 512, 4096), ("dvgg", 4000, 2688, 512)):
     us, err = run(M, N, K)
     out.append(f"{tag} {us:.1f}" + ("" if err < 1e-3 else f" ERR {err:.1e}"))
-print("GEMM", os.environ.get("MASR_GEMM_RING", "-"), " | ".join(out))
+print("GEMM", " | ".join(out))
