@@ -114,6 +114,7 @@ struct masr_model {
     Acts acts; bool have_acts = false;
     LnReduceGroup lng; int64_t ln_slab_used = 0;           // LayerNorm dgamma/dbeta partials, folded by one grouped launch
     bool split_wgrad = false;                              // masr_set_split_wgrad_launches
+    int slots = 1;                                         // masr_set_concurrency: task slots sharing the GPU
     bool ksplit = true;                                    // masr_set_ksplit: few-row long-reduction GEMMs k-split, partials summed by the LayerNorm behind them
     WgradGroup wg, wge;                                    // decoder-row / encoder-row weight gradients collected for the grouped launch (lin_wgrad)
     // a LayerNorm (forward) / LayerNorm backward on few rows that has been ASKED for but not launched: the next GEMM that takes its bf16
@@ -330,8 +331,7 @@ int gemm(Ctx& c, const GemmArgs& g) {
         CK(flush_ln_pending(c));                               // not the consumer we hoped for (or a shape the fused form does not cover)
     }
     Prof p(c.m, cat, c.s);
-    if (!c.seed_ptr) return mk_gemm(g, c.s);
-    GemmArgs h = g; h.seed_ptr = c.seed_ptr;
+    GemmArgs h = g; h.seed_ptr = c.seed_ptr; h.lean = m->slots > 1;
     return mk_gemm(h, c.s);
 }
 
@@ -703,9 +703,9 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
 }
 
 void masr_set_seed(masr_model* m, uint64_t seed) { m->seed = seed; m->step = 0; }
-// (kept for callers: nothing in a step depends on the number of task slots any more -- "K task slots == the sequential run, bit for bit" is a
-// guarantee of --tasks_per_gpu, and every partition into partial sums is fixed per shape)
-void masr_set_concurrency(masr_model* m, int slots) { (void)m; (void)slots; }
+// (no RESULT depends on the number of task slots -- "K task slots == the sequential run, bit for bit" is a guarantee of --tasks_per_gpu, and
+// every partition into partial sums is fixed per shape; what follows the hint is the LDS footprint of a few launches: GemmArgs::lean)
+void masr_set_concurrency(masr_model* m, int slots) { m->slots = slots < 1 ? 1 : slots; }
 void masr_dropout_state(masr_model* m, uint64_t state[2], int set) {
     if (set) { m->seed = state[0]; m->step = state[1]; } else { state[0] = m->seed; state[1] = m->step; }
 }

@@ -1128,9 +1128,17 @@ static int gemm_ncu() {
 }
 template <int BM, int BN, int EPI>
 void launch_glds(const GemmArgs& g, dim3 grid, hipStream_t s) {
-    if constexpr (BM == 128 && BN == 64) {
-        // at most one tile per CU: the loader-wave form (one workgroup per CU)
-        if ((long)grid.x * grid.y * grid.z <= gemm_ncu()) { hipLaunchKernelGGL((gemm_ring_kernel<BM, BN, EPI, 4>), grid, dim3(512), 0, s, g); return; }
+    if constexpr (BN == 64) {
+        // at most one tile per CU: the loader-wave form (one workgroup per CU).  128 x 64: the encoder-row launches with N = 512; 64 x 64: the
+        // decoder-row launches of 80-240 workgroups (6.8 -> 6.2 us; with 320 workgroups the plain form's second workgroup per CU wins: 8.8 vs 10.1)
+        // Ring depth of the 128 x 64 form: four stages (96 KB) with the GPU to itself (FFN2 14.9 us; single task +2 %), three (72 KB, 15.6 us)
+        // when other task streams share the GPU (GemmArgs::lean): with four, the four-slot throughput FELL by 1.5 % -- a 96 KB workgroup on
+        // every CU keeps the other slots' GEMM workgroups (48-72 KB) off it -- with three it is unchanged and the lone task keeps +1 %.
+        if ((long)grid.x * grid.y * grid.z <= gemm_ncu()) {
+            if (BM == 128 && g.lean) hipLaunchKernelGGL((gemm_ring_kernel<BM, BN, EPI, 3>), grid, dim3(512), 0, s, g);
+            else hipLaunchKernelGGL((gemm_ring_kernel<BM, BN, EPI, 4>), grid, dim3(512), 0, s, g);
+            return;
+        }
     }
     hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, EPI>), grid, dim3(256), 0, s, g);
 }

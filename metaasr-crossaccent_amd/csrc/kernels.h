@@ -23,6 +23,7 @@ struct GemmArgs {
     long split_delta, split_stride;   // C32/colsum, split z>0 writes the same addresses + split_delta + (z-1)*split_stride (mk_split_reduce combines)
     int accumulate;               // C32 += v
     int xcd_order;                // set by mk_gemm: XCD-contiguous tile order
+    int lean;                     // the GPU is shared with other task streams (masr_set_concurrency > 1): forms with the smaller LDS footprint
     float* C32; long ldc;         // fp32 output or null
     bf16* C16; long ldc16;        // bf16 output or null
     // segmented fp32 output rows (grouped weight gradients: one GEMM whose M axis spans several Linear layers that sit at a
