@@ -168,11 +168,12 @@ def test_cfg4_fomaml_eight_accents_two_waves_of_four_slots(golden_dir, tmp_path,
         print(f"  meta-step {si}: meta-gradient cosine vs the fp32 oracle {cos:.5f}, norm ratio {ratio:.4f}; worst tensors "
               f"(fp32 oracle) {[(n, round(e, 4)) for e, n in r32[:3]]}; (bf16-emulating oracle) {[(n, round(e, 4)) for e, n in r16[:3]]}")
         assert cos > 0.995 and abs(ratio - 1) < 0.02
-        # per-tensor bounds of tests/test_hip_cfg3.py (inherited backward roundings; in_proj_bias: zero-gradient key third)
+        # per-tensor bounds from THIS run's own measurement (worst tensor 0.041 vs the fp32 oracle, 0.025 vs the bf16-emulating one: decoder
+        # linear1 and the first conv), with half again as margin; in_proj_bias: its key third has a zero gradient
         for e, n in r32:
-            assert n.endswith("in_proj_bias") or e < 0.15, f"meta-gradient step {si} {n}: rel-L2 {e:.3f} vs the fp32 oracle"
+            assert n.endswith("in_proj_bias") or e < 0.06, f"meta-gradient step {si} {n}: rel-L2 {e:.3f} vs the fp32 oracle"
         for e, n in r16:
-            assert n.endswith("in_proj_bias") or e < 0.08, f"meta-gradient step {si} {n}: rel-L2 {e:.3f} vs the bf16-emulating oracle"
+            assert n.endswith("in_proj_bias") or e < 0.04, f"meta-gradient step {si} {n}: rel-L2 {e:.3f} vs the bf16-emulating oracle"
         for n, w_ref in o32["steps"][si][1].items():
             if n not in eng.table or n == "pos_encoder.pe":
                 continue
@@ -221,7 +222,7 @@ def test_cfg5_reptile_five_inner_steps_eight_accents_chain(golden_dir, tmp_path,
         print(f"  meta-step {si}: pseudo-gradient cosine {cos:.5f}, norm ratio {ratio:.4f}, worst tensors {[(n, round(e, 4)) for e, n in rows[:4]]}")
         assert cos > 0.999 and abs(ratio - 1) < 0.02
         for e, n in rows:                                                  # bound of test_reptile_behind_fix_flag_matches_oracle
-            assert e < 0.10, f"pseudo-gradient step {si} {n}: rel-L2 {e:.3f}"
+            assert e < 0.03, f"pseudo-gradient step {si} {n}: rel-L2 {e:.3f}"        # (measured: worst tensor 0.015)
         for n, w_ref in o["steps"][si][1].items():
             if n not in eng.table or n == "pos_encoder.pe":
                 continue
