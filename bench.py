@@ -370,9 +370,13 @@ def main():
 
     def time_single(task_list, Bs, flops_per_utt, seconds):
         """one task per GPU over a region of at least `seconds` (a first short region sizes it): value, ms per step, model FLOPs / peak"""
+        # (one task per GPU = the engine has the GPU to itself: the launch-geometry hint of a lone task for this leg -- what train.py and a
+        # one-task-per-GPU rank run with -- and the slots' own setting back afterwards)
+        task_list[0].eng.set_concurrency(1)
         dtp = timed(task_list[:1], 8, args.warmup)
         n1 = max(8, int(seconds / (dtp / 8)) + 1)
         dt1 = timed(task_list[:1], n1, 2)
+        task_list[0].eng.set_concurrency(K)
         v = world * Bs * n1 / dt1
         return {"value": v, "unit": "utt/s", "ms_per_step": dt1 / n1 * 1e3, "steps": n1, "seconds": dt1,
                 "model_frac_of_bf16_peak": v * flops_per_utt / 1e12 / (PEAK_BF16_TFLOPS * world)}
@@ -380,7 +384,9 @@ def main():
     if K > 1 and args.single_seconds <= 0:
         # (profiling runs: a short one-task leg only, for the stagger -- 10 + warm-up steps in the trace, as tools/save_profiles.py assumes)
         n1 = max(5, args.steps // 3)
+        tasks[0].eng.set_concurrency(1)
         dt1 = timed(tasks[:1], n1, args.warmup)
+        tasks[0].eng.set_concurrency(K)
         single_first = {"value": world * B * n1 / dt1, "unit": "utt/s", "ms_per_step": dt1 / n1 * 1e3, "steps": n1, "seconds": dt1,
                         "model_frac_of_bf16_peak": world * B * n1 / dt1 * F_step / 1e12 / (PEAK_BF16_TFLOPS * world)}
         single = single_first

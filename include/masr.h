@@ -56,8 +56,9 @@ int masr_refresh(masr_model* m, void* stream);
 void masr_set_seed(masr_model* m, uint64_t seed);      /* dropout stream */
 /* hint: this model is one of `slots` task slots running concurrently on the GPU (pretrain.py --tasks_per_gpu).  Results do NOT depend
  * on it, bit for bit (no launch partition that enters a summation order follows the slot count).  What follows it is the LDS footprint of
- * some launches: with slots > 1 the encoder-row GEMMs keep a three-stage operand ring (72 KB) instead of four (96 KB), so that the other
- * slots' workgroups still fit beside them on a CU. */
+ * some launches and a latency-for-occupancy trade: with slots > 1 the encoder-row GEMMs keep a three-stage operand ring (72 KB) instead
+ * of four (96 KB), so that the other slots' workgroups still fit beside them on a CU, and the decoder's few-row GEMMs run whole reductions
+ * (masr_set_ksplit's split is for a lone task: it shortens the launch chain with four times the workgroups). */
 void masr_set_concurrency(masr_model* m, int slots);
 /* the dropout stream's position: state[0] = seed, state[1] = batches run since masr_set_seed (every run_batch derives its masks
  * from both); set != 0 writes it.  For checkpoints: a resumed run continues the mask stream where the saved one stopped. */

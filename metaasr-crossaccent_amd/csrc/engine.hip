@@ -381,7 +381,10 @@ GemmArgs lin_dgrad_args(const bf16* dy, long lddy, const bf16* t16, long ldt, in
 // 80 workgroups with a chain of 24-32 k steps each -- 16 us where their K = 512 siblings take 8.  They run k-split over K / 512 x as many
 // workgroups; each writes its fp32 partial product and the LayerNorm that always follows sums them (and applies what the GEMM's epilogue would
 // have: bias, dropout, residual) on its way in: no combine pass, no extra launch (rowops.hip LnSumArgs).  0: not this shape.
-static int ksplit_of(const masr_model* m, int rows, int K) { return (m->ksplit && rows <= 1024 && K >= 1024 && K % 512 == 0 && K / 512 <= KSPLIT_MAX) ? K / 512 : 0; }
+// Only with the GPU to itself (masr_set_concurrency 1): the split buys latency with occupancy -- 320 workgroups x 7.4 us instead of 80 x 16 -- and beside
+// other task slots it is occupancy that counts: four-slot throughput 9 920 -> 10 000 utt/s with whole reductions.
+static bool ksplit_on(const masr_model* m) { return m->ksplit && m->slots <= 1; }
+static int ksplit_of(const masr_model* m, int rows, int K) { return (ksplit_on(m) && rows <= 1024 && K >= 1024 && K % 512 == 0 && K / 512 <= KSPLIT_MAX) ? K / 512 : 0; }
 static GemmArgs ksplit_args(const masr_model* m, GemmArgs g, int S, int rows, int N) {
     g.bias = nullptr; g.drop_p = 0.f; g.residual = nullptr; g.C16 = nullptr;
     g.C32 = m->acts.part; g.ldc = N; g.split_k = S; g.split_stride = (long)rows * N;
@@ -410,7 +413,7 @@ int attn_block_fwd(Ctx& c, const Attn& at, const bf16* xq, const bf16* xkv, int 
     o.drop_p = c.p_drop; o.seed = c.seed; o.site = site_o; o.residual = resid; o.ldres = E; o.C32 = s_out; o.ldc = E;
     // few rows: the reduction over E runs as two halves on twice the workgroups, the LayerNorm behind the block sums them (see ksplit_of):
     // out-projection 8.6 -> 5.9 us, the LayerNorm 4.8 -> 5.6 with the second partial to read
-    const int S = (defer && m->ksplit && rows_q <= 1024 && E >= 512 && E % 128 == 0) ? 2 : 0;
+    const int S = (defer && ksplit_on(m) && rows_q <= 1024 && E >= 512 && E % 128 == 0) ? 2 : 0;
     if (S) {
         *defer = LnSumArgs{m->acts.part, (long)rows_q * E, S, P + at.out.b, resid, c.p_drop, c.seed, site_o, c.seed_ptr, s_out};
         return gemm(c, ksplit_args(m, o, S, rows_q, E));

@@ -1282,7 +1282,7 @@ int mk_gemm(const GemmArgs& g, hipStream_t s) {
         return -1;
     }
     auto wgs = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * z; };
-    constexpr long min_wgs = 192;
+    constexpr long min_wgs = 192;               // (larger tiles on fewer workgroups for the task-slot mode: 96 / 40 measured 0.5 / 1.7 % slower)
     if (wgs(128, 128) >= min_wgs) return launch_tile<128, 128>(g, s);
     if (wgs(128, 64) >= min_wgs) return launch_tile<128, 64>(g, s);
     return launch_tile<64, 64>(g, s);

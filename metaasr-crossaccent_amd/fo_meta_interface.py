@@ -196,6 +196,10 @@ class FOMetaASRInterface(PretrainInterface):
             sl['engine'].set_seed(getattr(self.paras, 'seed', 531) + 7919 * (self.sharder.rank * self.tasks_per_gpu + i))
             if hasattr(sl['engine'], 'set_concurrency'):
                 sl['engine'].set_concurrency(self.tasks_per_gpu)
+            # "K task slots == the sequential run, bit for bit" must hold for every K: the k-split of the decoder's few-row GEMMs (a different
+            # fp32 summation order; the engine keeps it for a lone task only) is therefore off in this interface whatever K is
+            if hasattr(sl['engine'], 'set_ksplit'):
+                sl['engine'].set_ksplit(False)
 
     def write_tr_logs(self):
         for k, v in self.train_info.items():
