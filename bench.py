@@ -203,8 +203,8 @@ def cpu_baseline(cfg, B, T, D, steps=6):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=120, help="timed steps per task slot (120 x 6.5 ms = 0.8 s: a 30-step region read 3 % below the 6 s long_run leg of the same process)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=16, help="utterances per inner step per GPU (16 = what the shipped half_batch_ilen rule yields at 1000 frames)")
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--idim", type=int, default=80)
