@@ -68,9 +68,10 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t seed, uint32_t site, uint3
 }
 // keep-scale: 0 (dropped) or 1/(1-p)
 __device__ __forceinline__ float dropout_scale(uint32_t seed, uint32_t site, uint32_t idx, float p, float inv_keep) {
-    // 24-bit uniform in [0,1)
-    float u = (float)(hash_u32(seed, site, idx) >> 8) * (1.0f / 16777216.0f);
-    return u < p ? 0.0f : inv_keep;
+    // 24-bit uniform u = (h >> 8) / 2^24 in [0,1); dropped where u < p.  Compared as integers: u and p 2^24 are exact in fp32, so
+    // u < p  <=>  (h >> 8) < ceil(p 2^24) -- the threshold is loop-invariant, which leaves a shift and a compare per element
+    const uint32_t thr = (uint32_t)ceilf(p * 16777216.0f);
+    return (hash_u32(seed, site, idx) >> 8) < thr ? 0.0f : inv_keep;
 }
 
 #define HIP_CHECK_RET(expr)                                                        \
