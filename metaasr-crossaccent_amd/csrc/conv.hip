@@ -2028,9 +2028,12 @@ int mk_conv1_wgrad_n(const float* x, const bf16* dy, float* dw, float* db, float
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-static int conv_ncu() {
-    static int ncu = 0;
-    if (!ncu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); if (ncu <= 0) ncu = 256; }
+static int conv_ncu() {                                         // (task-slot threads call this concurrently: a thread-safe one-time initialisation)
+    static const int ncu = [] {
+        int dev = 0, n = 0;
+        hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
     return ncu;
 }
 // workgroups (= rows of 640 partial sums) of the fused conv1-wgrad dgrad: one persistent workgroup per CU

@@ -1121,9 +1121,12 @@ __global__ __launch_bounds__(256) void gemm_lnbwd_kernel(GemmArgs g, LnBwdA ln) 
     lnA_mainloop<BN, EPI>(g, sa, LDA, ring, smem, m0, n0);
 }
 
-static int gemm_ncu() {
-    static int ncu = 0;
-    if (!ncu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); if (ncu <= 0) ncu = 256; }
+static int gemm_ncu() {                                         // (task-slot threads call this concurrently: a thread-safe one-time initialisation)
+    static const int ncu = [] {
+        int dev = 0, n = 0;
+        hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
     return ncu;
 }
 template <int BM, int BN, int EPI>
