@@ -15,7 +15,8 @@ the OUTER step is measured separately (field "meta_step") because the metric cou
 
 --tasks-per-gpu (default 4): tasks of one meta-step are independent, so each GPU runs several of them concurrently
 (one model replica + HIP stream + host thread per task; `--tasks_per_gpu` of pretrain.py).  Every task still performs
-full B-utterance inner steps; "single_task" in the output is the same measurement with one task per GPU.
+full B-utterance inner steps; "single_task_fomaml" / "single_task_train" in the output are the same measurement with one task per GPU under
+the launch schedule of pretrain.py --algo fomaml / of train.py (masr_set_ksplit off / on).
 GPU_MAX_HW_QUEUES=8 (ROCm runtime setting, set below unless the caller chose a value): four task streams plus the
 copy/side streams need more than the default four hardware queues, otherwise two tasks serialise on one queue
 (measured: 4 tasks 5490 utt/s with 4 queues, 6790 with 8; 3 tasks 6440 either way).
@@ -218,7 +219,7 @@ def main():
     ap.add_argument("--no-matrix", action="store_true", help="skip the SURVEY 8(d) matrix legs (idim 83, B 32, the 4e2d / E256 geometry), reported as \"matrix\"")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (\"e2e_pretrain\": the pretrain.py --algo fomaml loop WITH its data path, "
                     "shards on disk -> BucketSampler -> pinned collate -> upload -> tasks -> meta update; tools/bench_pretrain.py in a child process)")
-    ap.add_argument("--single-seconds", type=float, default=1.0, help="length of the one-task-per-GPU regions (\"single_task\")")
+    ap.add_argument("--single-seconds", type=float, default=1.0, help="length of the one-task-per-GPU regions (\"single_task_fomaml\", \"single_task_train\")")
     ap.add_argument("--no-stagger", action="store_true", help="start all concurrent tasks at the same instant (lock-step)")
     ap.add_argument("--no-meta-step", action="store_true", help="skip the whole-meta-step leg (\"meta_step\" in the output)")
     ap.add_argument("--meta-rounds", type=int, default=2, help="task rounds per rank in the meta-step leg (>= 2 shows the all-reduce overlap)")
@@ -368,19 +369,28 @@ def main():
 
     F_step = 3 * fwd_flops_per_utt(T, D)
 
-    def time_single(task_list, Bs, flops_per_utt, seconds):
-        """one task per GPU over a region of at least `seconds` (a first short region sizes it): value, ms per step, model FLOPs / peak"""
-        # (one task per GPU = the engine has the GPU to itself: the launch-geometry hint of a lone task for this leg -- what train.py and a
-        # one-task-per-GPU rank run with -- and the slots' own setting back afterwards)
-        task_list[0].eng.set_concurrency(1)
+    SINGLE_STANDS_FOR = {
+        False: "pretrain.py --algo fomaml with one task per GPU (BASELINE configs[3] per rank): FOMetaASRInterface keeps the decoder's k-split GEMM "
+               "schedule OFF for every --tasks_per_gpu (K slots == the sequential run == N ranks, bit for bit)",
+        True: "train.py mono-accent / multi-task (BASELINE configs[1]): the trainer turns the decoder's k-split GEMM schedule ON (masr_set_ksplit)"}
+
+    def time_single(task_list, Bs, flops_per_utt, seconds, ksplit=False):
+        """one task per GPU over a region of at least `seconds` (a first short region sizes it): value, ms per step, model FLOPs / peak.
+        ksplit: the schedule of the CLI the figure stands for (SINGLE_STANDS_FOR); the slots' own settings are put back afterwards."""
+        e0 = task_list[0].eng
+        e0.set_concurrency(1)                                    # (the engine has the GPU to itself: the launch-geometry hint of a lone task)
+        e0.set_ksplit(ksplit)
         dtp = timed(task_list[:1], 8, args.warmup)
         n1 = max(8, int(seconds / (dtp / 8)) + 1)
         dt1 = timed(task_list[:1], n1, 2)
-        task_list[0].eng.set_concurrency(K)
+        assert (e0.step_counters()["ksplit_gemms"] > 0) == bool(ksplit)
+        e0.set_concurrency(K)
+        e0.set_ksplit(False)
         v = world * Bs * n1 / dt1
-        return {"value": v, "unit": "utt/s", "ms_per_step": dt1 / n1 * 1e3, "steps": n1, "seconds": dt1,
+        return {"value": v, "unit": "utt/s", "ms_per_step": dt1 / n1 * 1e3, "steps": n1, "seconds": dt1, "ksplit": bool(ksplit),
+                "stands_for": SINGLE_STANDS_FOR[bool(ksplit)],
                 "model_frac_of_bf16_peak": v * flops_per_utt / 1e12 / (PEAK_BF16_TFLOPS * world)}
-    single = single_first = None
+    single = single_first = single_train = None
     if K > 1 and args.single_seconds <= 0:
         # (profiling runs: a short one-task leg only, for the stagger -- 10 + warm-up steps in the trace, as tools/save_profiles.py assumes)
         n1 = max(5, args.steps // 3)
@@ -417,7 +427,9 @@ def main():
             single = time_single(tasks, B, F_step, args.single_seconds)      # warm clocks: right behind the long run
         single["clocks_under_load"] = clk1.summary()
         single["first_measurement"] = single_first
-        log(f"single task per GPU (after the long run, {single['seconds']:.2f} s): {single['value']:.1f} utt/s = {single['model_frac_of_bf16_peak']:.3f} of the bf16 peak")
+        log(f"single task per GPU, pretrain.py schedule (after the long run, {single['seconds']:.2f} s): {single['value']:.1f} utt/s = {single['model_frac_of_bf16_peak']:.3f} of the bf16 peak")
+        single_train = time_single(tasks, B, F_step, args.single_seconds, ksplit=True)
+        log(f"single task per GPU, train.py schedule (k-split on, {single_train['seconds']:.2f} s): {single_train['value']:.1f} utt/s = {single_train['model_frac_of_bf16_peak']:.3f} of the bf16 peak")
 
     # ---- mixed-length leg (ilens ~ U{200..1500}): every task cycles through 8 batches of its own; all
     # utterances of a batch share one length (what the reference's BucketSampler yields) and the half-batch rule applies
@@ -472,8 +484,8 @@ def main():
                             "idim": Dm, "tasks_per_gpu": K, **({"model": over} if over else {})}
             log(f"matrix {name}: {matrix[name]['value']:.1f} utt/s")
             if name == "idim83" and K > 1:                       # the shipped feature width with one task per GPU (what configs[3] runs per GPU)
-                matrix[name]["single_task"] = time_single(tm, Bm, 3 * fwd_flops_per_utt(T, Dm), 0.5 * args.single_seconds)
-                log(f"matrix {name}, one task per GPU: {matrix[name]['single_task']['value']:.1f} utt/s")
+                matrix[name]["single_task_fomaml"] = time_single(tm, Bm, 3 * fwd_flops_per_utt(T, Dm), 0.5 * args.single_seconds)
+                log(f"matrix {name}, one task per GPU: {matrix[name]['single_task_fomaml']['value']:.1f} utt/s")
             del tm
             torch.cuda.empty_cache()
 
@@ -774,7 +786,10 @@ def main():
                        "tasks": world * K, "parallelism": f"{K} concurrent task(s) per GPU x {world} GPU(s)"},
             "algorithmic_gflop_per_utt_fwd_bwd": 3 * F / 1e9,
             "model_tflops": value * 3 * F / 1e12, "model_frac_of_bf16_peak": value * 3 * F / 1e12 / (PEAK_BF16_TFLOPS * world),
-            "single_task": single,
+            # one task per GPU, each figure under the schedule of the CLI it stands for ("stands_for"): the FOMAML interface runs whole
+            # reductions in the decoder's few-row GEMMs, the mono / multi trainers the k-split (+3 % alone on the GPU, a different fp32 order)
+            "single_task_fomaml": single,
+            "single_task_train": single_train,
             "long_run": long_run,
             "rccl_ranks": world if (dist is not None and backend == "nccl") else 0,
             "mixed_lengths": mixed,

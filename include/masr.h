@@ -76,16 +76,6 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
  * the host's enqueue time 6x and leaves the step time unchanged -- the step is GPU-bound -- hence off by default.
  * counters: out[0] = steps launched kernel by kernel, out[1] = graphs captured, out[2] = steps replayed from a graph. */
 void masr_set_step_graphs(masr_model* m, int on);
-/* LayerNorms on few rows (the decoder's B x L: <= 1024 rows, d_model in {64, 128, 256, 512}) are not launched on their own: the GEMM
- * that consumes their bf16 output (forward: the next projection; backward: the next dgrad) normalises the rows in its prologue.  Same
- * arithmetic, hence the same results (the LayerNorm weight gradients are folded over 64-row instead of 4-row partials: fp32 rounding).
- * Default OFF -- it measured slower (every column-tile workgroup of a row block repeats the row work and they all hit the same L2
- * lines at once: DESIGN); this switch turns it on for A/B runs and the parity test. */
-void masr_set_ln_fusion(masr_model* m, int on);
-/* masr_clip_sgd_step's update applied INSIDE the shadow-refresh launch (one pass over the parameters: p and g in, p and every bf16
- * operand layout out) instead of an update pass followed by the refresh.  Same arithmetic, same bits.  Default OFF -- it measured slower
- * (tile-shaped fp32 write-back against a flat stream: DESIGN); this switch turns it on for A/B runs and the parity test. */
-void masr_set_fused_sgd(masr_model* m, int on);
 /* The Linear weight gradients of a step are ONE launch (the decoder-row tiles fill the CUs the encoder-row tiles leave idle); on: two
  * launches, encoder rows then decoder rows (A/B; identical bits -- each element of dW is reduced by one workgroup either way). */
 void masr_set_split_wgrad_launches(masr_model* m, int on);
@@ -251,9 +241,11 @@ int masr_blstm_read_stats(masr_blstm* m, float out[4], void* stream);           
  * enc_dim <= 384); off = per-timestep launches (A/B + test; same results to fp32 rounding).  A timed-out exchange is reported by
  * masr_blstm_read_stats. */
 void masr_blstm_set_resident_recurrence(masr_blstm* m, int on);
-/* test only: the next resident forward launches lose one workgroup at start, so that its peers run into the bound of their wait and the step
- * is reported as failed by masr_blstm_read_stats instead of hanging (tests/test_hip_blstm.py) */
-void masr_test_blstm_stall(int on);
+/* forward-only callers (masr_blstm_forward + masr_blstm_last_logits, i.e. the Tester's greedy CTC decode) never read the stats block:
+ * this is their check.  Synchronises the stream; -1 (text in masr_last_error(), mark cleared) when the resident recurrence of a launch
+ * since the last check timed out -- the logits are then invalid.  After a time-out the remaining resident launches of the step return
+ * at once (one bounded wait per step, not one per layer and pass). */
+int masr_blstm_check(masr_blstm* m, void* stream);
 /* head output (pre-softmax) [B][Tp][odim] fp32 and enc_lens int32 [B] on the device, Tp = ceil(ceil(T/2)/2) */
 int masr_blstm_last_logits(masr_blstm* m, float** logits, int32_t** enc_lens, int* B, int* Tp, int* C);
 /* nn.utils.clip_grad_norm_(parameters, max_norm) on the flat gradient; the norm is read with masr_blstm_read_stats */
@@ -293,9 +285,10 @@ int masr_gather_pad(const float* feat, const int64_t* row_start, const int32_t* 
 int64_t masr_ctc_work_floats(int T, int B, int maxS);
 /* The lengths are DEVICE arrays, so they are vetted by the kernel: an utterance with in_len < 0 or > T, tgt_len < 0 or
  * 2 tgt_len + 1 > maxS is not run -- its nll (hence the mean loss) is NaN, its gradient rows are zero.  in_len == 0 is torch's
- * "no path" case: nll 0, zero gradient (zero_infinity).  masr_ctc_status(stream) synchronises and returns 0, or (index + 1) of
- * the last refused utterance with the text in masr_last_error(), and clears the mark. */
-int masr_ctc_status(void* stream);
+ * "no path" case: nll 0, zero gradient (zero_infinity).  masr_ctc_status synchronises and returns 0, or (index + 1) of the last
+ * utterance the most recent masr_ctc_loss call ON THIS work buffer (same T, B, maxS) refused, with the text in masr_last_error().  The mark
+ * lives in the call's own work buffer (re-armed by every masr_ctc_loss on it): calls on different buffers / streams do not mix. */
+int masr_ctc_status(const float* work, int T, int B, int maxS, void* stream);
 int masr_ctc_loss(const float* logits, const int32_t* targets, const int32_t* tgt_off, const int32_t* in_len,
                   const int32_t* tgt_len, int T, int B, int C, int blank, float* nll, float* loss, float* grad,
                   float* work, int maxS, void* stream);
@@ -329,82 +322,6 @@ int masr_ctc_loss(const float* logits, const int32_t* targets, const int32_t* tg
 int masr_profile_enable(masr_model* m, int on);
 /* sums since the last call: ms[MASR_PROF_N], launches[MASR_PROF_N]; synchronises */
 int masr_profile_read(masr_model* m, float* ms, int* launches);
-
-/* standalone kernel entry points used by the parity tests (bf16 passed as uint16_t bit patterns) */
-int masr_test_gemm(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int K, int reduction_major,
-                   const float* bias, int relu, float* C32, int64_t ldc, void* stream);
-/* dropout (torch nn.Dropout inside nn.Transformer*Layer / PositionalEncoding, mono_transformer_torch.py:30-32,74-98): the keep-scale
- * (0 or 1/(1-p)) of element i at a site; the GEMM epilogue and the attention-probability sites with their dropout switched on */
-int masr_test_dropout_mask(uint32_t seed, uint32_t site, int64_t n, float p, float* out, void* stream);
-int masr_test_gemm_dropout(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int K, float drop_p,
-                           uint32_t seed, uint32_t site, float* C32, int64_t ldc, void* stream);
-int masr_test_attention_dropout(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* lse, int B, int H,
-                                int Tq, int Tk, int hd, float drop_p, uint32_t seed, uint32_t site, void* stream);
-/* the NT GEMM with any combination of its fused epilogue stages (tools/bench_gemm_epi.py: what each stage costs per launch) */
-int masr_test_gemm_epi(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int K, const float* bias, int relu,
-                       float drop_p, const float* residual, const uint16_t* mask, float* C32, uint16_t* C16, void* stream);
-int masr_test_conv3x3(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, uint16_t* out,
-                      int B, int H, int W, int CIN, int COUT, void* stream);
-/* dgrad/fused-pool flavours of the same kernel: mask (optional, same shape as out) zeroes outputs where mask <= 0;
-   pool_out (optional, [B][H/2][W/2][COUT]) receives MaxPool2d(2,2) of the ReLU'd output */
-int masr_test_conv3x3_ex(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, const uint16_t* mask, uint16_t* out,
-                         uint16_t* pool_out, int B, int H, int W, int CIN, int COUT, void* stream);
-/* 128-channel ReLU masks as sign bits (four dwords per pixel, dword q = the sign bytes of channel groups 8q.., 32+8q.., 64+8q.., 96+8q..):
-   a forward launch with 128 output channels writes them for its output (out_sign_bits), a masked 128 <- 128 dgrad reads them
-   (mask_bits, next to the bf16 mask it replaces on the streaming path) */
-int masr_test_conv3x3_sign_bits(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, const uint16_t* mask, const uint32_t* mask_bits,
-                                uint16_t* out, uint32_t* out_sign_bits, int B, int H, int W, int CIN, int COUT, void* stream);
-/* the pooling forward conv as the engine launches it: pool_idx ([B][H/2][W/2][COUT] bytes) receives, per pooled element, the
-   window position 0..3 (row-major) of its first maximum, or 4 where nothing passed the ReLU; drop_out != 0 allows the launch to
-   leave `out` unwritten (the streaming kernels then never store the full-resolution map; the others still do).
-   masr_test_maxpool_idx_bwd is the pool + ReLU backward from those bytes: din [B][H][W][C] from dout [B][H/2][W/2][C]. */
-int masr_test_conv3x3_pool_idx(const uint16_t* in, const uint16_t* wk, const float* bias, uint16_t* out, uint16_t* pool_out,
-                               uint8_t* pool_idx, int drop_out, int B, int H, int W, int CIN, int COUT, void* stream);
-int masr_test_maxpool_idx_bwd(const uint8_t* idx, const uint16_t* dout, uint16_t* din, int B, int H, int W, int C, void* stream);
-/* The two dgrad launches that sit behind a max-pool (reference: the autograd of nn.MaxPool2d + nn.ReLU in front of nn.Conv2d,
- * mono_transformer_torch.py:51-52,57-58).  Input either as the map dy [B][H][W][C] or -- dy == NULL -- as the pooled gradient dy_pooled
- * [B][H/2][W/2][C] + the codes of masr_test_conv3x3_pool_idx, expanded while the patches are staged (no map in memory): same bits.
- * masr_test_conv3x3_dgrad_pooled: 128 <- 128 channels through the ReLU mask given as sign words (masr_test_conv3x3_sign_bits).
- * masr_test_conv1_wgrad_fused: 64 <- 64 channels whose output is contracted with the network input x1 [B][H][W] inside the launch:
- * dw1 [64][9], db1 [64] = the weight / bias gradient of the FIRST conv; mask_bits = one 64-bit word of sign bits per pixel. */
-int masr_test_conv3x3_dgrad_pooled(const uint16_t* dy, const uint16_t* dy_pooled, const uint8_t* pool_idx, const uint16_t* wk, const uint32_t* mask_bits,
-                                   uint16_t* out, int B, int H, int W, void* stream);
-int64_t masr_test_conv1_wgrad_fused_slab_floats(int B, int H, int W);
-int masr_test_conv1_wgrad_fused(const uint16_t* dy, const uint16_t* dy_pooled, const uint8_t* pool_idx, const uint16_t* wk, const uint64_t* mask_bits,
-                                const float* x1, float* slab, int64_t slab_floats, float* dw1, float* db1, int B, int H, int W, void* stream);
-int masr_test_conv3x3_wgrad(const uint16_t* in, const uint16_t* dy, float* dw, float* slab, int64_t slab_floats,
-                            int B, int H, int W, int CIN, int COUT, void* stream);
-int64_t masr_test_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT);
-/* Linear weight gradients as a grouped launch (mk_gemm_wgrad_grouped: one grid of 256 x 256 tiles): dW[N][K] = dy[rows][N]^T x[rows][K], db[N] =
- * column sums of dy (or null); a second member with the same operands when dW2 is given.
- * _n: `members` members over the same operands (member i writes dW + i * member_stride); first_members > 0: the two-segment tile list of the
- * engine's merged launch -- members [0, first_members) reduce over `rows` rows and are dispatched first, the others over the first rows_rest. */
-int masr_test_wgrad_grouped(const uint16_t* dy, int64_t lddy, const uint16_t* x, int64_t ldx, float* dW, float* db, float* dW2, float* db2,
-                            int rows, int N, int K, void* stream);
-/* the k-split GEMM + summing LayerNorm pair of the decoder (engine.hip ffn_fwd / ln_fwd, ffn_bwd / ln_bwd): forward when x == NULL, backward otherwise */
-int masr_test_ksplit_ln(const uint16_t* A, const uint16_t* B, int rows, int E, int K, int split, const float* bias, const float* residual, float drop_p,
-                        uint32_t seed, uint32_t site, float* part, const float* gamma, const float* beta, float* sum_out, float* y32, uint16_t* y16,
-                        float* mean, float* rstd, const float* x, float* dx32, uint16_t* dx16, float* slab, void* stream);
-int masr_test_wgrad_grouped_n(const uint16_t* dy, int64_t lddy, const uint16_t* x, int64_t ldx, float* dW, int64_t member_stride, int members,
-                              int first_members, int rows, int rows_rest, int N, int K, void* stream);
-/* the same with dy given as the pooled gradient [B][H/2][W/2][COUT] + the pool codes of masr_test_conv3x3_pool_idx (the weight-gradient kernel
- * expands the 2x2 max-pool + ReLU backward while staging; 64->64 and 128->128 channels); db may be null */
-int masr_test_conv3x3_wgrad_pooled(const uint16_t* in, const uint16_t* dy_pooled, const uint8_t* pool_idx, float* dw, float* db, float* slab,
-                                   int64_t slab_floats, int B, int H, int W, int CIN, int COUT, void* stream);
-/* LayerNorm forward + backward of one [rows][E] fp32 matrix (nn.LayerNorm inside nn.Transformer*Layer, mono_transformer_torch.py:74-98):
- * y, y16 (bf16), mean / rstd per row; dx, dgamma, dbeta from dy.  slab: masr_test_layernorm_slab_floats(rows, E) floats of scratch. */
-int64_t masr_test_layernorm_slab_floats(int rows, int E);
-int masr_test_layernorm(const float* x, const float* gamma, const float* beta, const float* dy, float* y, uint16_t* y16, float* mean,
-                        float* rstd, float* dx, uint16_t* dx16, float* dgamma, float* dbeta, float* slab, int rows, int E, float drop_p,
-                        uint32_t seed, uint32_t site, void* stream);   /* dx16 = bf16(dx * keep-scale of element row * E + col at `site`) */
-/* forward + backward of one attention with dropout on the probabilities (keep-scale of element ((b H + h) Tq + i) Tk + j at `site`,
- * masr_test_dropout_mask): the backward regenerates the masks of the forward from (seed, site, index) */
-int masr_test_attention_dropout_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* dout, uint16_t* o, uint16_t* dq, uint16_t* dk,
-                                    uint16_t* dv, float* lse, const int32_t* klens, int B, int H, int Tq, int Tk, int hd, int causal, float drop_p,
-                                    uint32_t seed, uint32_t site, void* stream);
-int masr_test_attention(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* dout, uint16_t* o,
-                        uint16_t* dq, uint16_t* dk, uint16_t* dv, float* lse, float* delta, const int32_t* klens,
-                        int B, int H, int Tq, int Tk, int hd, int causal, void* stream);
 
 #ifdef __cplusplus
 }

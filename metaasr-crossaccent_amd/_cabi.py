@@ -1,4 +1,4 @@
-"""ctypes binding of libmasr.so (include/masr.h).  No fallback: if the HIP library is missing the
+"""ctypes binding of libmasr.so (include/masr.h; the masr_test_* entries are include/masr_test.h).  No fallback: if the HIP library is missing the
 import raises -- the product path never runs on the CPU oracle."""
 import ctypes as C
 import os
@@ -32,8 +32,6 @@ _SIGS = {
     "masr_dropout_state": (None, [vp, C.POINTER(C.c_uint64), i32]),
     "masr_run_batch": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "masr_set_step_graphs": (None, [vp, i32]),
-    "masr_set_ln_fusion": (None, [vp, i32]),
-    "masr_set_fused_sgd": (None, [vp, i32]),
     "masr_set_split_wgrad_launches": (None, [vp, i32]),
     "masr_set_ksplit": (None, [vp, i32]),
     "masr_step_counters": (None, [vp, C.POINTER(i64)]),
@@ -79,7 +77,7 @@ _SIGS = {
     "masr_blstm_forward": (i32, [vp, vp, vp, i32, i32, vp]),
     "masr_blstm_read_stats": (i32, [vp, C.POINTER(f32), vp]),
     "masr_blstm_set_resident_recurrence": (None, [vp, i32]),
-    "masr_test_blstm_stall": (None, [i32]),
+    "masr_blstm_check": (i32, [vp, vp]),
     "masr_blstm_last_logits": (i32, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "masr_blstm_clip_grads": (i32, [vp, f32, vp]),
     "masr_blstm_clip_sgd_step": (i32, [vp, vp, f32, f32, f32, i32, i32, vp]),
@@ -88,10 +86,11 @@ _SIGS = {
     "masr_fbank_pitch": (i32, [vp, vp, vp, i64, i64, i32, i32, i32, vp, vp, i64, vp]),
     "masr_gather_pad": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "masr_ctc_work_floats": (i64, [i32, i32, i32]),
-    "masr_ctc_status": (i32, [vp]),
+    "masr_ctc_status": (i32, [vp, i32, i32, i32, vp]),
     "masr_ctc_loss": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]),
     "masr_profile_enable": (i32, [vp, i32]),
     "masr_profile_read": (i32, [vp, C.POINTER(f32), C.POINTER(i32)]),
+    "masr_test_blstm_stall": (None, [vp, i32]),          # include/masr_test.h from here on
     "masr_test_gemm": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, vp, i32, vp, i64, vp]),
     "masr_test_dropout_mask": (i32, [C.c_uint32, C.c_uint32, i64, f32, vp, vp]),
     "masr_test_gemm_dropout": (i32, [vp, i64, vp, i64, i32, i32, i32, f32, C.c_uint32, C.c_uint32, vp, i64, vp]),
@@ -101,7 +100,6 @@ _SIGS = {
     "masr_test_conv3x3_ex": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "masr_test_conv3x3_sign_bits": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "masr_test_conv3x3_pool_idx": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
-    "masr_test_maxpool_idx_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "masr_test_conv3x3_dgrad_pooled": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "masr_test_conv1_wgrad_fused_slab_floats": (i64, [i32, i32, i32]),
     "masr_test_conv1_wgrad_fused": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, vp]),

@@ -133,6 +133,9 @@ class BlstmEngine:
         self.refresh()
         check(self._l.masr_blstm_forward(self.h, _ptr(xs), C.c_void_p(il.data_ptr()), B, T, self.stream()), "masr_blstm_forward")
         self._last_x = xs
+        # the forward-only path reads no stats block: a timed-out resident recurrence must not hand out garbage logits silently
+        # (its callers copy the logits to the host next, so this stream sync costs them nothing)
+        check(self._l.masr_blstm_check(self.h, self.stream()), "masr_blstm_check")
         return self.last_logits()
 
     def set_resident_recurrence(self, on: bool):

@@ -205,15 +205,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         m = mn;
         float rs = 0.f;
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
+        for (int jt = 0; jt < 4; ++jt) {
+            float k4[4] = {1.f, 1.f, 1.f, 1.f};                   // keep-scales of this lane's four consecutive keys (one hash word per pair)
+            if (a.drop_p > 0.f) dropout_scale4(dseed, a.site, dbase + (uint32_t)(kb * BLK + jt * 16 + g4), a.drop_p, inv_keep, k4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float p = __builtin_amdgcn_exp2f((s[jt][r] - m) * sc2);
                 if (!full && s[jt][r] <= NEG) p = 0.f;
                 rs += p;
-                if (a.drop_p > 0.f) p *= dropout_scale(dseed, a.site, dbase + (uint32_t)(kb * BLK + jt * 16 + g4 + r), a.drop_p, inv_keep);
-                s[jt][r] = p;
+                s[jt][r] = p * k4[r];
             }
+        }
         l = l * alpha + fold_groups_sum(rs);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
@@ -311,6 +313,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
                     s = mma16(frag_row<LD>(cK, jt * 16, ks, lane), qf[ks], s);
                     dp = mma16(frag_row<LD>(cV, jt * 16, ks, lane), dof[ks], dp);
                 }
+                float k4[4] = {1.f, 1.f, 1.f, 1.f};
+                if (a.drop_p > 0.f) dropout_scale4(dseed, a.site, dbase + (uint32_t)(kb * BLK + jt * 16 + g4), a.drop_p, inv_keep, k4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float p = __builtin_amdgcn_exp2f((__fmul_rn(s[r], scale) - lse) * LOG2E);
@@ -318,9 +322,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bx
                         const int kj = kb * BLK + jt * 16 + g4 + r;
                         if (kj >= klen || (a.causal && kj > qi) || qi >= Tq) p = 0.f;
                     }
-                    float dpv = dp[r];
-                    if (a.drop_p > 0.f) dpv *= dropout_scale(dseed, a.site, dbase + (uint32_t)(kb * BLK + jt * 16 + g4 + r), a.drop_p, inv_keep);
-                    ds[j2][r] = p * (dpv - dl) * scale;
+                    ds[j2][r] = p * (dp[r] * k4[r] - dl) * scale;
                 }
             }
             const bf16x8 df = frag_acc(ds[0], ds[1]);
@@ -615,15 +617,17 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_ring_kernel(AttnArgs a) {
             m[rt] = mn;
                 float rs = 0.f;
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
+            for (int jt = 0; jt < 4; ++jt) {
+                float k4[4] = {1.f, 1.f, 1.f, 1.f};               // keep-scales of this lane's four consecutive keys (one hash word per pair)
+                if (a.drop_p > 0.f) dropout_scale4(dseed, a.site, dbase[rt] + (uint32_t)(kb * BLK + jt * 16 + g4), a.drop_p, inv_keep, k4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float p = __builtin_amdgcn_exp2f((s[rt][jt][r] - mn) * sc2);
                     if (!full && s[rt][jt][r] <= NEG) p = 0.f;
                     rs += p;
-                    if (a.drop_p > 0.f) p *= dropout_scale(dseed, a.site, dbase[rt] + (uint32_t)(kb * BLK + jt * 16 + g4 + r), a.drop_p, inv_keep);
-                    s[rt][jt][r] = p;
+                    s[rt][jt][r] = p * k4[r];
                 }
+            }
             l[rt] = l[rt] * alpha + fold_groups_sum(rs);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
@@ -720,6 +724,8 @@ __device__ __forceinline__ void attn_bwd_ring_dq(const AttnArgs& a, const int bx
                         s = mma16(kfr[ks], qf[rt][ks], s);
                         dp = mma16(vfr[ks], dof[rt][ks], dp);
                     }
+                    float k4[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (a.drop_p > 0.f) dropout_scale4(dseed, a.site, dbase[rt] + (uint32_t)(kb * BLK + jt * 16 + g4), a.drop_p, inv_keep, k4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float p = __builtin_amdgcn_exp2f((__fmul_rn(s[r], scale) - lse[rt]) * LOG2E);
@@ -727,9 +733,7 @@ __device__ __forceinline__ void attn_bwd_ring_dq(const AttnArgs& a, const int bx
                             const int kj = kb * BLK + jt * 16 + g4 + r;
                             if (kj >= klen || (a.causal && kj > qi) || qi >= Tq) p = 0.f;
                         }
-                        float dpv = dp[r];
-                        if (a.drop_p > 0.f) dpv *= dropout_scale(dseed, a.site, dbase[rt] + (uint32_t)(kb * BLK + jt * 16 + g4 + r), a.drop_p, inv_keep);
-                        ds[rt][j2][r] = p * (dpv - dl[rt]) * scale;
+                        ds[rt][j2][r] = p * (dp[r] * k4[r] - dl[rt]) * scale;
                     }
                 }
             }

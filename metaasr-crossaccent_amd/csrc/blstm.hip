@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/masr.h"
+#include "../../include/masr_test.h"
 #include "kernels.h"
 
 namespace {
@@ -56,6 +57,7 @@ struct masr_blstm {
     bf16 *h16[2][2]; float* cstate[2];
     unsigned long long* rec_words = nullptr;                                         // granule exchange of the resident recurrence (lstm_rec.hip)
     bool resident = true;                                                            // masr_blstm_set_resident_recurrence
+    int test_stall = 0;                                                              // masr_test_blstm_stall (include/masr_test.h)
     float *dx32, *dy32, *dys32, *wtmp, *slab; int64_t slab_floats = 0;
     bf16 *dp2, *dc4, *dc3, *dp1, *dc2, *dc1;
     bool have = false;
@@ -170,7 +172,7 @@ int forward(masr_blstm* m, const float* xs, hipStream_t s) {
             st.gx[d] = a.gx[d]; st.act[d] = a.act[d]; st.c[d] = a.c[d]; st.cstate[d] = m->cstate[d]; st.dz16[d] = a.dzg[d];
         }
         // one launch for the whole sequence where the shape allows (lstm_rec.hip), else one per timestep
-        if (m->resident && mk_lstm_rec_ok(B, H, m->KP)) CK(mk_lstm_fwd_rec(st, m->rec_words, reinterpret_cast<int*>(m->stats + 8), s));
+        if (m->resident && mk_lstm_rec_ok(B, H, m->KP)) CK(mk_lstm_fwd_rec(st, m->rec_words, reinterpret_cast<int*>(m->stats + 8), s, m->test_stall));
         else CK(mk_lstm_fwd_steps(st, s));
         if (m->sub[i] > 1) CK(mk_subsample_rows(a.y16, a.ys16, B, Tin, Tout, m->sub[i], 2 * H, s));      // ys_pad[:, ::sub] (encoder.py:118-121)
         GemmArgs g = nt(a.ys16, 2 * H, l.bt16, 2 * H, Ro, l.N, 2 * H, P + l.btb); g.C32 = a.z32; g.ldc = l.N;
@@ -434,7 +436,20 @@ int masr_blstm_read_stats(masr_blstm* m, float out[4], void* stream) {
     return 0;
 }
 void masr_blstm_set_resident_recurrence(masr_blstm* m, int on) { m->resident = on != 0; }
-void masr_test_blstm_stall(int on) { mk_lstm_rec_test_stall(on); }
+void masr_test_blstm_stall(masr_blstm* m, int on) { m->test_stall = on; }
+// forward-only callers (masr_blstm_forward + masr_blstm_last_logits: the Tester) never read the stats block: this is their check.  Synchronises
+// the stream; -1 (and the mark cleared) when the resident recurrence of a launch since the last check timed out -- the logits are then invalid.
+int masr_blstm_check(masr_blstm* m, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HIP_CHECK_RET(hipMemcpyAsync(m->h_stats + 8, m->stats + 8, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK_RET(hipStreamSynchronize(s));
+    if (reinterpret_cast<const int*>(m->h_stats)[8] != 0) {
+        HIP_CHECK_RET(hipMemsetAsync(m->stats + 8, 0, sizeof(int), s));
+        mk_set_error("masr_blstm_check", "the resident LSTM recurrence timed out waiting for a peer workgroup: the forward's results are invalid");
+        return -1;
+    }
+    return 0;
+}
 int masr_blstm_last_logits(masr_blstm* m, float** logits, int32_t** enc_lens, int* B, int* Tp, int* C) {
     if (!m->have) { mk_set_error("masr_blstm_last_logits", "run a batch first"); return -1; }
     *logits = m->logits; *enc_lens = m->lens_l[m->L]; *B = m->B; *Tp = m->Ts[m->L]; *C = m->C;      // (frames / lengths LEAVING the encoder)

@@ -7,7 +7,7 @@ mkdir -p $OUT build
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value"
 pids=()
 for f in gemm conv attention rowops optim fold data ctc decode fbank pitch lstm lstm_rec blstm comm engine; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ kernels.h -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ folds.h -nt build/$f.o ] || [ ../../include/masr.h -nt build/$f.o ]; then
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ kernels.h -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ folds.h -nt build/$f.o ] || [ ../../include/masr.h -nt build/$f.o ] || [ ../../include/masr_test.h -nt build/$f.o ]; then
     hipcc $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)
   fi

@@ -57,21 +57,38 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// Stateless counter-based RNG for dropout: the same (seed, site, index) gives the same
-// bit in forward and backward, so no mask is ever stored.
-__device__ __forceinline__ uint32_t hash_u32(uint32_t seed, uint32_t site, uint32_t idx) {
-    uint32_t x = idx * 0x9E3779B1u ^ (seed + site * 0x85EBCA77u);
+// Stateless counter-based RNG for dropout: the same (seed, site, index) gives the same bit in forward and backward, so no mask is ever
+// stored (and a resumed run regenerates the masks of the step it continues from).  Round 6: ONE 32-bit hash word decides the element PAIR
+// (2k, 2k + 1) -- its low / high 16 bits against a 16-bit threshold -- and the (seed, site) part is mixed once per kernel into a key that
+// is XORed into the pair index: two 32-bit multiplies per pair where round 5 paid three per element (v_mul_lo_u32 is a quarter-rate
+// instruction; the decision was a third of the encoder attention forward and ~6 us of FFN1's epilogue).
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {                  // "lowbias32" integer finaliser (a bijection of 32-bit words)
     x ^= x >> 16; x *= 0x7FEB352Du;
     x ^= x >> 15; x *= 0x846CA68Bu;
     x ^= x >> 16;
     return x;
 }
-// keep-scale: 0 (dropped) or 1/(1-p)
+__device__ __forceinline__ uint32_t dropout_key(uint32_t seed, uint32_t site) { return mix32(seed * 0x9E3779B1u + site * 0x85EBCA77u + 0x632BE5ABu); }   // loop-invariant
+// dropped where u16 < ceil(p 2^16): the drop probability is p rounded UP to a multiple of 2^-16 (p = 0.1: 0.100006)
+__device__ __forceinline__ uint32_t dropout_thr(float p) { return (uint32_t)ceilf(p * 65536.0f); }
+__device__ __forceinline__ uint32_t dropout_word(uint32_t key, uint32_t pair) { return mix32(pair ^ key); }
+// keep-scale of ONE element: 0 (dropped) or 1/(1-p)
 __device__ __forceinline__ float dropout_scale(uint32_t seed, uint32_t site, uint32_t idx, float p, float inv_keep) {
-    // 24-bit uniform u = (h >> 8) / 2^24 in [0,1); dropped where u < p.  Compared as integers: u and p 2^24 are exact in fp32, so
-    // u < p  <=>  (h >> 8) < ceil(p 2^24) -- the threshold is loop-invariant, which leaves a shift and a compare per element
-    const uint32_t thr = (uint32_t)ceilf(p * 16777216.0f);
-    return (hash_u32(seed, site, idx) >> 8) < thr ? 0.0f : inv_keep;
+    const uint32_t w = dropout_word(dropout_key(seed, site), idx >> 1);
+    return ((idx & 1u) ? (w >> 16) : (w & 0xFFFFu)) < dropout_thr(p) ? 0.0f : inv_keep;
+}
+// ... of the FOUR consecutive elements idx0 .. idx0 + 3: two hash words when idx0 is even, a third one when it is odd (the elements then
+// straddle three pairs; the halves are lined up with two funnel shifts)
+__device__ __forceinline__ void dropout_scale4(uint32_t seed, uint32_t site, uint32_t idx0, float p, float inv_keep, float (&s)[4]) {
+    const uint32_t key = dropout_key(seed, site), thr = dropout_thr(p), p0 = idx0 >> 1;
+    uint32_t a = dropout_word(key, p0), b = dropout_word(key, p0 + 1);
+    if (idx0 & 1u) {
+        const uint32_t c = dropout_word(key, p0 + 2);
+        a = __builtin_amdgcn_alignbit(b, a, 16);                         // [a.hi, b.lo]
+        b = __builtin_amdgcn_alignbit(c, b, 16);                         // [b.hi, c.lo]
+    }
+    s[0] = (a & 0xFFFFu) < thr ? 0.0f : inv_keep; s[1] = (a >> 16) < thr ? 0.0f : inv_keep;
+    s[2] = (b & 0xFFFFu) < thr ? 0.0f : inv_keep; s[3] = (b >> 16) < thr ? 0.0f : inv_keep;
 }
 
 #define HIP_CHECK_RET(expr)                                                        \

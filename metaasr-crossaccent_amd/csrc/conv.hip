@@ -1935,41 +1935,6 @@ __global__ void maxpool_relu_bwd_kernel(const bf16* __restrict__ in, const bf16*
     }
 }
 
-// pool + ReLU backward from the ConvArgs::pool_idx bytes (floor mode): thread = pooled cell x 8 channels; 8 B of codes + 16 B
-// of gradient in, the four full-resolution positions out (zeros at the three that lost, and in the cropped last row / column)
-__global__ void maxpool_idx_bwd_kernel(const uint8_t* __restrict__ idx, const bf16* __restrict__ dout, bf16* __restrict__ din,
-                                       int B, int H, int W, int C) {
-    const int H2 = H / 2, W2 = W / 2, C8 = C / 8;
-    const int H2c = (H + 1) / 2, W2c = (W + 1) / 2;           // cells incl. the cropped edge
-    const long n = (long)B * H2c * W2c * C8;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c8 = (int)(i % C8);
-    const int d2 = (int)((i / C8) % W2c);
-    const int t2 = (int)((i / ((long)C8 * W2c)) % H2c);
-    const int b = (int)(i / ((long)C8 * W2c * H2c));
-    const long base = (((long)b * H + 2 * t2) * W + 2 * d2) * C + c8 * 8;
-    if (t2 < H2 && d2 < W2) {
-        const long pe = (((long)b * H2 + t2) * W2 + d2) * C + c8 * 8;
-        const uint2 code = *reinterpret_cast<const uint2*>(idx + pe);
-        const bf16x8 g = ld8(dout + pe);
-        bf16x8 o[4];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const unsigned cj = ((j < 4 ? code.x : code.y) >> (8 * (j & 3))) & 0xffu;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k][j] = cj == (unsigned)k ? g[j] : (bf16)0.f;
-        }
-        st8(din + base, o[0]);
-        st8(din + base + C, o[1]);
-        st8(din + base + (long)W * C, o[2]);
-        st8(din + base + (long)W * C + C, o[3]);
-    } else {
-        for (int dt = 0; dt < 2; ++dt)
-            for (int dd = 0; dd < 2; ++dd)
-                if (2 * t2 + dt < H && 2 * d2 + dd < W) st8(din + base + ((long)dt * W + dd) * C, zero8());
-    }
-}
 // the codes from a stored (ReLU'd) map: for the conv kernels that do not emit them in their epilogue
 __global__ void maxpool_idx_kernel(const bf16* __restrict__ in, uint8_t* __restrict__ idx, int B, int H, int W, int C) {
     const int H2 = H / 2, W2 = W / 2, C8 = C / 8;
@@ -2050,8 +2015,7 @@ int mk_conv1_wgrad_fused_reduce(float* slab, int B, int H, int W, float* dw, flo
 // tile counters of launches that bring none (single-stream tools and tests)
 static unsigned* sched_or_fallback(unsigned* sched) {
     if (sched) return sched;
-    static unsigned* fallback = nullptr;
-    if (!fallback) hipGetSymbolAddress((void**)&fallback, HIP_SYMBOL(g_conv_sched));
+    static unsigned* const fallback = [] { unsigned* p = nullptr; hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_conv_sched)); return p; }();
     return fallback;
 }
 static int launch_resw_w1(const ConvArgs& a, hipStream_t s) {
@@ -2072,13 +2036,12 @@ static void launch_resw(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t
 template <int CI, int CO, int TWV, int MASK, int THV = 16, bool UNPOOL = false>
 static void launch_stream_t(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
     constexpr int NT = UNPOOL ? 512 : 384;
-    static int resident = 0;
-    if (!resident) {
+    static const int resident = [] {                             // (task-slot threads launch concurrently: thread-safe one-time initialisation)
         int per_cu = 0;
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3x3_stream_kernel<CI, CO, THV, TWV, MASK, UNPOOL>, NT, 0);
         if (per_cu <= 0) per_cu = 1;
-        resident = conv_ncu() * (per_cu < 2 ? per_cu : 2);
-    }
+        return conv_ncu() * (per_cu < 2 ? per_cu : 2);
+    }();
     const int ntiles = tiles_x * tiles_y * a.B;
     ConvArgs b = a;
     b.sched = sched_or_fallback(a.sched);
@@ -2207,12 +2170,6 @@ int mk_maxpool_fwd(const bf16* in, bf16* out, int B, int H, int W, int C, hipStr
 int mk_maxpool_relu_bwd(const bf16* in, const bf16* dout, bf16* din, int B, int H, int W, int C, hipStream_t s, int ceil_mode) {
     const long n = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
     hipLaunchKernelGGL(maxpool_relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, dout, din, B, H, W, C, ceil_mode);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-int mk_maxpool_idx_bwd(const uint8_t* idx, const bf16* dout, bf16* din, int B, int H, int W, int C, hipStream_t s) {
-    const long n = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
-    if (n == 0) return 0;
-    hipLaunchKernelGGL(maxpool_idx_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, idx, dout, din, B, H, W, C);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int mk_maxpool_idx(const bf16* in, uint8_t* idx, int B, int H, int W, int C, hipStream_t s) {

@@ -11,8 +11,9 @@ constexpr int MAXS = 2048;
 constexpr float NINF = -INFINITY;
 // lengths arrive in DEVICE arrays, so the launch cannot vet them on the host: an utterance whose lengths do not fit the call
 // (in_len < 0 or > T, tgt_len < 0, 2 tgt_len + 1 > the lattice width the work buffer was sized for) is not run -- its nll becomes
-// NaN (so does the mean: loud), its gradient rows stay zero, and its index + 1 is left here for mk_ctc_status
-__device__ int g_ctc_bad = 0;
+// NaN (so does the mean: loud), its gradient rows stay zero, and its index + 1 is left in the CALL's own work buffer (ctc_mark: the last
+// word of mk_ctc_work_floats, zeroed by the launch itself) for mk_ctc_status -- no process-wide state, concurrent calls do not mix
+__device__ __forceinline__ int* ctc_mark(float* work, int T, int B, int Spad) { return reinterpret_cast<int*>(work + 2L * B * T * Spad + 2L * B * T + B + 3); }
 
 __device__ __forceinline__ float lae(float a, float b) {          // log(exp a + exp b)
     if (a == NINF) return b;
@@ -32,7 +33,7 @@ __device__ __forceinline__ float lae(float a, float b) {          // log(exp a +
 //   ctc_grad_kernel    grid (T, B): posteriors and d loss / d logits of ONE frame per workgroup from the parked rows -- embarrassingly
 //                      parallel, so this part fills the chip; class posteriors summed by owner threads in a fixed order as before
 //                      (bit-reproducible), the blank states by wave sums folded in wave order
-// Lengths are vetted by both (see g_ctc_bad).
+// Lengths are vetted by both (see ctc_mark).
 struct CtcGeo { int T, B, C, blank, Spad; long st_t, st_b; };
 __device__ __forceinline__ long ctc_at(const CtcGeo& g, int t, int b) { return ((long)t * g.st_t + (long)b * g.st_b) * g.C; }
 
@@ -40,6 +41,7 @@ __device__ __forceinline__ long ctc_at(const CtcGeo& g, int t, int b) { return (
 __global__ __launch_bounds__(256) void ctc_lse_kernel(const float* __restrict__ logits, const int* __restrict__ in_len, CtcGeo g, float* __restrict__ work) {
     const int b = blockIdx.y, lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int Tb = in_len[b];
+    if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) *ctc_mark(work, g.T, g.B, g.Spad) = 0;      // (the sweeps run behind this launch)
     if (t >= g.T || t >= Tb) return;                       // (also bad lengths: Tb < 0 or > T are handled by the sweeps; rows past T do not exist)
     const float* z = logits + ctc_at(g, t, b);
     float v[8];                                            // C <= 512 in registers (larger vocabularies re-read)
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void ctc_sweep_kernel(const float* __restrict_
     if (bad || Tb == 0) {
         // no frames: torch's lattice has no path unless the target is empty too (nll 0); with a target the likelihood is 0, i.e. nll =
         // inf, which zero_infinity turns into 0 with a zero gradient -- 0 either way.  Bad lengths: NaN, marked.
-        if (!beta && tid == 0) { nll[b] = bad ? __int_as_float(0x7fc00000) : 0.f; ll_out[b] = NINF; if (bad) atomicMax(&g_ctc_bad, b + 1); }
+        if (!beta && tid == 0) { nll[b] = bad ? __int_as_float(0x7fc00000) : 0.f; ll_out[b] = NINF; if (bad) atomicMax(ctc_mark(work, T, B, Spad), b + 1); }
         return;
     }
     const int* tg = targets + tgt_off[b];
@@ -225,15 +227,14 @@ __global__ void ctc_mean_kernel(const float* __restrict__ nll, const int* __rest
 }
 }  // namespace
 
-int mk_ctc_status(hipStream_t s) {
-    // > 0: (index + 1) of the last utterance a CTC launch on this stream refused (see g_ctc_bad); reads and clears, synchronises `s`
+int mk_ctc_status(const float* work, int T, int B, int maxS, hipStream_t s) {
+    // > 0: (index + 1) of the last utterance the CTC launch that used `work` refused (see ctc_mark); synchronises `s`
+    if (!work || T <= 0 || B <= 0 || maxS < 1) { mk_set_error("mk_ctc_status", "bad arguments"); return -1; }
     int h = 0;
-    const int zero = 0;
-    if (hipMemcpyFromSymbolAsync(&h, HIP_SYMBOL(g_ctc_bad), sizeof(int), 0, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    const float* mark = work + 2L * B * T * ((maxS + 3) / 4 * 4) + 2L * B * T + B + 3;
+    if (hipMemcpyAsync(&h, mark, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     if (h > 0) {
-        hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ctc_bad), &zero, sizeof(int), 0, hipMemcpyHostToDevice, s);
-        hipStreamSynchronize(s);
         char msg[160];
         snprintf(msg, sizeof msg, "utterance %d: in_len outside [0, T] or target longer than the lattice the work buffer holds (its nll is NaN)", h - 1);
         mk_set_error("mk_ctc_loss", msg);

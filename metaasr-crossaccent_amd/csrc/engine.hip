@@ -15,6 +15,7 @@
 #include <algorithm>
 
 #include "../../include/masr.h"
+#include "../../include/masr_test.h"
 #include "kernels.h"
 
 static thread_local std::string g_err;
@@ -80,7 +81,6 @@ struct Acts {
 }  // namespace
 
 constexpr int KSPLIT_MAX = 8;
-constexpr int GAP_CHUNKS_MAX = 8192;        // (offset, length <= 2048) chunks of the parameters without a bf16 shadow (hkust: ~600)
 struct masr_model {
     masr_config cfg;
     int E, H, hd, Fi, NE, ND, C, Cp, D, Dp, F;
@@ -94,14 +94,6 @@ struct masr_model {
     // reduction-major GEMM with M = ND*2E (segmented output rows).  kv_k16 [ND*2E][E], kvT [E][ND*2E], kv_bias [ND*2E].
     bf16 *kv_k16 = nullptr, *kvT = nullptr; float* kv_bias = nullptr; int NK = 0;
     std::vector<ShadowJobs> shadows;                       // job list(s) of the operand-shadow refresh: one launch per <= SHADOW_JOBS_MAX jobs (hkust: one)
-    // masr_clip_sgd_step CAN apply its update inside that launch (mk_sgd_shadows: p and g in, p and every bf16 layout out, 28 instead
-    // of 32 bytes per parameter; the parameters no shadow job reads are these chunks).  Same bits (tests/test_hip_engine.py), but SLOWER:
-    // 165 us against 75 + 57 for the flat update pass and the refresh (hkust, momentum buffer read and written): the tiles' 256-byte
-    // row segments at arbitrary dword offsets make every fp32 write-back a partial-line store, where the flat pass streams whole lines
-    // (and neither the instruction count -- 17 lanes per row, one load per array and pass -- nor the 4 B/param matter beside that).
-    // Default OFF; masr_set_fused_sgd for A/B runs and the parity test.
-    long* d_gaps = nullptr; int ngaps = 0; bool gaps_ok = false;     // gaps_ok: the gap list exists (masr_bind) -- without it the fused pass would skip the unshadowed parameters
-    bool fuse_sgd = false;
     float* stats = nullptr;                   // device [8]: loss, n_correct, n_total, grad_norm
     unsigned* conv_sched = nullptr;           // tile counters of the streaming conv kernel (this model's stream only)
     float* h_stats = nullptr;                 // pinned
@@ -115,18 +107,9 @@ struct masr_model {
     LnReduceGroup lng; int64_t ln_slab_used = 0;           // LayerNorm dgamma/dbeta partials, folded by one grouped launch
     bool split_wgrad = false;                              // masr_set_split_wgrad_launches
     int slots = 1;                                         // masr_set_concurrency: task slots sharing the GPU
-    bool ksplit = true;                                    // masr_set_ksplit: few-row long-reduction GEMMs k-split, partials summed by the LayerNorm behind them
+    bool ksplit = false;                                   // masr_set_ksplit: few-row long-reduction GEMMs k-split, partials summed by the LayerNorm behind them
+    int64_t n_ksplit = 0;                                  // k-split GEMM launches of the last masr_run_batch (masr_step_counters out[3])
     WgradGroup wg, wge;                                    // decoder-row / encoder-row weight gradients collected for the grouped launch (lin_wgrad)
-    // a LayerNorm (forward) / LayerNorm backward on few rows that has been ASKED for but not launched: the next GEMM that takes its bf16
-    // output as the A operand computes it in its own prologue (kernels.h mk_gemm_lnfwd / mk_gemm_lnbwd); anything else flushes it first
-    // OFF by default: measured SLOWER (round 4, rocprofv3, hkust decoder rows): the fused q-projection 17.9 us against 6.6 (GEMM) + 5.2
-    // (LayerNorm), the fused FFN-1 34.5 us against 8 + 5 -- every one of the 8 .. 32 column-tile workgroups of a row block re-reads the
-    // same 128 KB of fp32 rows at the same moment (the same L2 channels) and only then starts its k loop; single task 6 160 -> 5 420
-    // utt/s, four slots 9 160 -> 8 510.  Kept as an A/B switch with its parity test (masr_set_ln_fusion).
-    bool ln_fusion = false;
-    struct PendF { bool on = false; Norm n; const float* x; float* y32; bf16* y16; float* mean; float* rstd; int rows; } pend_f;
-    struct PendB { bool on = false; Norm n; const float* dy; const float* x; const float* mean; const float* rstd; float* dx32; bf16* dx16;
-                   uint32_t site; int rows; float* slab; int desc; } pend_b;
     // captured training / evaluation steps (masr_run_batch, opt-in): a batch shape that repeats is replayed as ONE graph launch
     // instead of ~150 kernel launches.  Measured: host enqueue 0.61 -> 0.11 ms per step, step time unchanged (the GPU, not the
     // launch path, bounds both the single-task and the 4-task mode: tools/host_launch_cost.py) -- hence off by default
@@ -193,7 +176,6 @@ void plan_persistent(masr_model* m, Arena& ar) {
     m->kv_k16 = ar.get<bf16>((int64_t)m->NK * m->E); m->kvT = ar.get<bf16>((int64_t)m->E * m->NK); m->kv_bias = ar.get<float>(m->NK);
     m->stats = ar.get<float>(64);
     m->conv_sched = ar.get<unsigned>(64);
-    m->d_gaps = ar.get<long>(2 * GAP_CHUNKS_MAX);
 }
 
 // ------------------------------------------------------------------ activation plan
@@ -300,36 +282,12 @@ GemmArgs lin_fwd_args(const bf16* x, long ldx, const bf16* wk, int M, int N, int
 
 // seed_ptr / inv_ptr: non-null while a step is being captured into a graph -- the dropout seed and 1/n_total of the step
 // then live in device memory (Acts::meta, uploaded with the tokens), so one captured launch sequence serves every step
-struct Ctx { masr_model* m; hipStream_t s; uint32_t seed; bool train; float p_drop, p_pos; const uint32_t* seed_ptr = nullptr; const float* inv_ptr = nullptr;
-             bool fuse_ln = false; };      // masr_run_batch only: LayerNorms on few rows ride in the prologue of their consumer GEMM
-int flush_ln_pending(Ctx& c);
+struct Ctx { masr_model* m; hipStream_t s; uint32_t seed; bool train; float p_drop, p_pos; const uint32_t* seed_ptr = nullptr; const float* inv_ptr = nullptr; };
 
 int gemm(Ctx& c, const GemmArgs& g) {
     const int re = c.m->acts.rows_e;
     const int cat = g.reduction_major ? (g.K == re ? MASR_PROF_WGRAD_ENC : MASR_PROF_WGRAD_DEC) : (g.M == re ? MASR_PROF_GEMM_ENC : MASR_PROF_GEMM_DEC);
     masr_model* m = c.m;
-    if (m->pend_f.on || m->pend_b.on) {
-        const bool shape = !g.reduction_major && g.K == m->E && g.lda == m->E;
-        if (m->pend_f.on && shape && g.A == m->pend_f.y16 && g.M == m->pend_f.rows) {
-            const masr_model::PendF& q = m->pend_f;
-            LnFwdA ln{q.x, m->P + q.n.w, m->P + q.n.b, q.y32, q.y16, q.mean, q.rstd};
-            GemmArgs h = g; h.seed_ptr = c.seed_ptr;
-            int rc;
-            { Prof p(m, cat, c.s); rc = mk_gemm_lnfwd(h, ln, c.s); }
-            if (rc <= 0) { m->pend_f.on = false; return rc; }
-        } else if (m->pend_b.on && shape && g.A == m->pend_b.dx16 && g.M == m->pend_b.rows) {
-            const masr_model::PendB& q = m->pend_b;
-            LnBwdA ln{q.dy, q.x, m->P + q.n.w, q.mean, q.rstd, q.dx32, q.dx16, c.p_drop, c.seed, q.site, c.seed_ptr, q.slab};
-            GemmArgs h = g; h.seed_ptr = c.seed_ptr;
-            int rc;
-            { Prof p(m, cat, c.s); rc = mk_gemm_lnbwd(h, ln, c.s); }
-            if (rc <= 0) {
-                if (rc == 0 && q.desc >= 0) m->lng.p[q.desc].nblocks = mk_gemm_ln_blocks(q.rows);     // one partial per 64-row block
-                m->pend_b.on = false; return rc;
-            }
-        }
-        CK(flush_ln_pending(c));                               // not the consumer we hoped for (or a shape the fused form does not cover)
-    }
     Prof p(c.m, cat, c.s);
     GemmArgs h = g; h.seed_ptr = c.seed_ptr; h.lean = m->slots > 1;
     return mk_gemm(h, c.s);
@@ -381,11 +339,14 @@ GemmArgs lin_dgrad_args(const bf16* dy, long lddy, const bf16* t16, long ldt, in
 // 80 workgroups with a chain of 24-32 k steps each -- 16 us where their K = 512 siblings take 8.  They run k-split over K / 512 x as many
 // workgroups; each writes its fp32 partial product and the LayerNorm that always follows sums them (and applies what the GEMM's epilogue would
 // have: bias, dropout, residual) on its way in: no combine pass, no extra launch (rowops.hip LnSumArgs).  0: not this shape.
-// Only with the GPU to itself (masr_set_concurrency 1): the split buys latency with occupancy -- 320 workgroups x 7.4 us instead of 80 x 16 -- and beside
-// other task slots it is occupancy that counts: four-slot throughput 9 920 -> 10 000 utt/s with whole reductions.
-static bool ksplit_on(const masr_model* m) { return m->ksplit && m->slots <= 1; }
+// It buys latency with occupancy -- 320 workgroups x 7.4 us instead of 80 x 16 -- so it pays with the GPU to the task alone (train.py: +3 %) and costs
+// beside other task slots, where occupancy counts (four-slot throughput 9 920 -> 10 000 utt/s with whole reductions).  It changes the fp32 summation
+// order, so it follows ONLY masr_set_ksplit (default off), never the slot count: the caller that runs one task per GPU turns it on (mono / multi
+// interface), the FOMAML interface leaves it off for every --tasks_per_gpu (K slots == the sequential run == N ranks, bit for bit).
+static bool ksplit_on(const masr_model* m) { return m->ksplit; }
 static int ksplit_of(const masr_model* m, int rows, int K) { return (ksplit_on(m) && rows <= 1024 && K >= 1024 && K % 512 == 0 && K / 512 <= KSPLIT_MAX) ? K / 512 : 0; }
-static GemmArgs ksplit_args(const masr_model* m, GemmArgs g, int S, int rows, int N) {
+static GemmArgs ksplit_args(masr_model* m, GemmArgs g, int S, int rows, int N) {
+    ++m->n_ksplit;
     g.bias = nullptr; g.drop_p = 0.f; g.residual = nullptr; g.C16 = nullptr;
     g.C32 = m->acts.part; g.ldc = N; g.split_k = S; g.split_stride = (long)rows * N;
     return g;
@@ -440,25 +401,18 @@ int ffn_fwd(Ctx& c, const Lin& l1, const Lin& l2, const bf16* x16, const float* 
     CK(gemm(c, h));
     return 0;
 }
-static bool ln_fusable(const Ctx& c, int rows) {
-    const int E = c.m->E;
-    return c.fuse_ln && rows <= 1024 && (E == 64 || E == 128 || E == 256 || E == 512);
-}
 int ln_fwd(Ctx& c, const Norm& n, const float* x, float* y32, bf16* y16, float* mean, float* rstd, int rows, const LnSumArgs* sum = nullptr) {
     masr_model* m = c.m;
-    CK(flush_ln_pending(c));                                   // (a LayerNorm of a LayerNorm output: the inner one runs now)
     if (sum && sum->n > 0) {                                   // x = the partial products of a k-split GEMM (ffn_fwd): summed on the way in
         Prof p(c.m, MASR_PROF_LAYERNORM, c.s);
         return mk_layernorm_fwd_sum(*sum, m->P + n.w, m->P + n.b, y32, y16, mean, rstd, rows, m->E, c.s);
     }
-    if (y16 && mean && rstd && ln_fusable(c, rows)) { m->pend_f = {true, n, x, y32, y16, mean, rstd, rows}; return 0; }
     Prof p(c.m, MASR_PROF_LAYERNORM, c.s);
     return mk_layernorm_fwd(x, c.m->P + n.w, c.m->P + n.b, y32, y16, mean, rstd, rows, c.m->E, c.s);
 }
 int ln_bwd(Ctx& c, const Norm& n, const float* dy, const float* x, const float* mean, const float* rstd, float* dx32, bf16* dx16,
            uint32_t site, int rows, const LnSumArgs* sum = nullptr) {
     masr_model* m = c.m;
-    CK(flush_ln_pending(c));
     // the dgamma/dbeta partials of every LayerNorm go to their own slab region; the fold launch at the end of the pass folds them all at once
     const int64_t need = (int64_t)mk_layernorm_bwd_blocks(rows) * 2 * m->E;
     if (sum && sum->n > 0) {                                   // dy = the partial products of a k-split dgrad GEMM + its residual gradient
@@ -469,17 +423,6 @@ int ln_bwd(Ctx& c, const Norm& n, const float* dy, const float* x, const float* 
         d.slab = slab; d.dgamma = m->G + n.w; d.dbeta = m->G + n.b; d.nblocks = (rows + 3) / 4;
         Prof p(c.m, MASR_PROF_LAYERNORM, c.s);
         return mk_layernorm_bwd_sum(*sum, x, m->P + n.w, mean, rstd, dx32, dx16, dx16 ? c.p_drop : 0.f, c.seed, site, slab, rows, m->E, c.s, c.seed_ptr);
-    }
-    if (dx16 && ln_fusable(c, rows) && m->lng.n < LN_GROUP_MAX && m->ln_slab_used + need <= m->acts.ln_slab_floats) {
-        // deferred: the dgrad GEMM that takes dx16 as its A operand computes this backward in its prologue (gemm() above); the slab
-        // region is sized for the standalone kernel (4 rows per partial), the fused form uses the first rows / 64 blocks of it
-        float* slab = m->acts.ln_slab + m->ln_slab_used;
-        m->ln_slab_used += need;
-        const int di = m->lng.n++;
-        LnReduceDesc& d = m->lng.p[di];
-        d.slab = slab; d.dgamma = m->G + n.w; d.dbeta = m->G + n.b; d.nblocks = (int)(need / (2 * m->E));
-        m->pend_b = {true, n, dy, x, mean, rstd, dx32, dx16, site, rows, slab, di};
-        return 0;
     }
     Prof p(c.m, MASR_PROF_LAYERNORM, c.s);
     if (m->lng.n < LN_GROUP_MAX && m->ln_slab_used + need <= m->acts.ln_slab_floats) {
@@ -493,25 +436,8 @@ int ln_bwd(Ctx& c, const Norm& n, const float* dy, const float* x, const float* 
     return mk_layernorm_bwd(dy, x, m->P + n.w, mean, rstd, dx32, dx16, dx16 ? c.p_drop : 0.f, c.seed, site, m->G + n.w, m->G + n.b,
                             m->acts.slab, rows, m->E, c.s, c.seed_ptr);
 }
-// launch whatever LayerNorm is still pending as the standalone kernel (its consumer turned out not to be a GEMM on its bf16 output)
-int flush_ln_pending(Ctx& c) {
-    masr_model* m = c.m;
-    if (m->pend_f.on) {
-        const masr_model::PendF q = m->pend_f; m->pend_f.on = false;
-        Prof p(m, MASR_PROF_LAYERNORM, c.s);
-        CK(mk_layernorm_fwd(q.x, m->P + q.n.w, m->P + q.n.b, q.y32, q.y16, q.mean, q.rstd, q.rows, m->E, c.s));
-    }
-    if (m->pend_b.on) {
-        const masr_model::PendB q = m->pend_b; m->pend_b.on = false;
-        Prof p(m, MASR_PROF_LAYERNORM, c.s);
-        CK(mk_layernorm_bwd(q.dy, q.x, m->P + q.n.w, q.mean, q.rstd, q.dx32, q.dx16, c.p_drop, c.seed, q.site, nullptr, nullptr, q.slab, q.rows,
-                            m->E, c.s, c.seed_ptr));
-    }
-    return 0;
-}
 int flush_ln_reduce(Ctx& c) {
     masr_model* m = c.m;
-    CK(flush_ln_pending(c));
     Prof p(m, MASR_PROF_LAYERNORM, c.s);
     const int rc = mk_layernorm_bwd_reduce_grouped(m->lng, m->E, c.s);
     m->lng.n = 0; m->ln_slab_used = 0;
@@ -671,31 +597,6 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
             job(SH_LINEAR, d.ca.in.w + (long)E * E, 2 * E, E, m->NK, 0, 0, m->kv_k16 + (long)l * 2 * E * E, m->kvT + (long)l * 2 * E);   // key|value thirds
             job(SH_COPY32, d.ca.in.b + E, 2 * E, 0, 0, 0, 0, m->kv_bias + (long)l * 2 * E, nullptr);
         }
-        // the complement of the jobs' source ranges in [0, nparams), cut into chunks of <= 2048 floats
-        std::vector<std::pair<long, long>> src;
-        for (const ShadowJobs& J : m->shadows)
-            for (int i = 0; i < J.n; ++i) {
-                const ShadowDesc& d = J.d[i];
-                const long len = d.type == SH_LINEAR ? (long)d.N * d.K : d.type == SH_CONV ? (long)d.N * d.K * 9
-                               : d.type == SH_VGG2ENC ? (long)d.N * d.a0 * d.a1 : (long)d.N;
-                src.emplace_back(d.src, len);
-            }
-        std::sort(src.begin(), src.end());
-        std::vector<long> gaps;
-        long at = 0;
-        auto gap = [&](long from, long to) { for (long o = from; o < to; o += 2048) { gaps.push_back(o); gaps.push_back(std::min<long>(2048, to - o)); } };
-        for (auto& r : src) {
-            if (r.first < at) { mk_set_error("masr_bind", "shadow jobs overlap in the parameter vector"); return -1; }
-            gap(at, r.first);
-            at = r.first + r.second;
-        }
-        gap(at, m->nparams);
-        if ((int)gaps.size() / 2 > GAP_CHUNKS_MAX) { m->fuse_sgd = false; m->ngaps = 0; m->gaps_ok = false; }     // (a model with that many unshadowed parameters: two passes)
-        else {
-            m->gaps_ok = true;
-            m->ngaps = (int)gaps.size() / 2;
-            if (m->ngaps) HIP_CHECK_RET(hipMemcpy(m->d_gaps, gaps.data(), sizeof(long) * gaps.size(), hipMemcpyHostToDevice));
-        }
     }
     // pads of the char_trans shadows must be zero (rows/cols >= odim); the refresh kernels only write the odim part
     HIP_CHECK_RET(hipMemset(m->conv_sched, 0, sizeof(unsigned) * 64));   // tile counters of the streaming conv (re-armed by the kernel itself)
@@ -706,9 +607,19 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
 }
 
 void masr_set_seed(masr_model* m, uint64_t seed) { m->seed = seed; m->step = 0; }
+// captured steps hold the launch geometry of the settings they were captured under: every setter that changes it drops them (after the
+// device has drained: nothing of a graph may be in flight when it is destroyed)
+static void drop_step_graphs(masr_model* m) {
+    if (m->step_graphs.empty()) return;
+    hipDeviceSynchronize();
+    for (auto& sg : m->step_graphs) { hipGraphExecDestroy(sg.e); hipGraphDestroy(sg.g); }
+    m->step_graphs.clear();
+    m->last_key[3] = -1; m->last_xs = nullptr;
+}
 // (no RESULT depends on the number of task slots -- "K task slots == the sequential run, bit for bit" is a guarantee of --tasks_per_gpu, and
-// every partition into partial sums is fixed per shape; what follows the hint is the LDS footprint of a few launches: GemmArgs::lean)
-void masr_set_concurrency(masr_model* m, int slots) { m->slots = slots < 1 ? 1 : slots; }
+// every partition into partial sums is fixed per shape and per masr_set_ksplit; what follows the hint is the LDS footprint of a few launches:
+// GemmArgs::lean)
+void masr_set_concurrency(masr_model* m, int slots) { slots = slots < 1 ? 1 : slots; if (slots != m->slots) drop_step_graphs(m); m->slots = slots; }
 void masr_dropout_state(masr_model* m, uint64_t state[2], int set) {
     if (set) { m->seed = state[0]; m->step = state[1]; } else { state[0] = m->seed; state[1] = m->step; }
 }
@@ -952,7 +863,6 @@ static int backward(Ctx& c, const float* xs) {
     CK(dgrad(nullptr, m->conv[1], nullptr, a.T, a.D, a.dp1, a.i1));
     // ---- every fold of the pass as ONE launch (fold.hip): the conv / conv1 slab reduces, the LayerNorm dgamma / dbeta partials, vgg2enc's weight
     // gradient back in the reference's feature order, and the embedding rows added into the (tied) table -- after the grouped launch wrote it
-    CK(flush_ln_pending(c));
     folds.E = E;
     folds.conv1 = {a.c1_slab, mk_conv1_wgrad_fused_rows(B, a.T, a.D), G + m->conv[0].w, G + m->conv[0].b};
     folds.unperm = {a.v2e_g32, G + m->v2e.w, E, 128, m->Dp};
@@ -1009,8 +919,6 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
     }
     Ctx c{m, s, (uint32_t)(m->seed * 0x9E3779B97F4A7C15ull >> 32) + (uint32_t)m->step * 7919u, train,
           train ? m->cfg.dropout : 0.f, train ? m->cfg.pos_dropout : 0.f};
-    c.fuse_ln = m->ln_fusion;
-    m->pend_f.on = m->pend_b.on = false;
     m->step++;
     const float inv_ntot = 1.0f / (float)ntot;
     std::memcpy(h_len + B, &c.seed, 4); std::memcpy(h_len + B + 1, &inv_ntot, 4);     // Acts::meta
@@ -1032,10 +940,9 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
     HIP_CHECK_RET(hipEventRecord(m->stage_ev[slot], s));
 
     auto run = [&](Ctx& cc) -> int {
+        m->n_ksplit = 0;
         CK(forward_encoder(cc, xs));
-        CK(flush_ln_pending(cc));                              // (encoder memory: read by more than the K|V projection)
         CK(forward_decoder(cc));
-        CK(flush_ln_pending(cc));
         { Prof p(m, MASR_PROF_MISC, s);
           CK(mk_ls_ce(a.logits, m->Cp, a.gold, a.rows_d, m->C, m->cfg.label_smoothing, inv_ntot, a.dlogits, a.row_loss, a.row_correct,
                       m->stats, s, cc.inv_ptr)); }
@@ -1078,11 +985,9 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
 }
 
 void masr_set_step_graphs(masr_model* m, int on) { m->step_graphs_on = on != 0; }
-void masr_set_ln_fusion(masr_model* m, int on) { m->ln_fusion = on != 0; }
-void masr_set_split_wgrad_launches(masr_model* m, int on) { m->split_wgrad = on != 0; }
-void masr_set_ksplit(masr_model* m, int on) { m->ksplit = on != 0; }
-void masr_set_fused_sgd(masr_model* m, int on) { m->fuse_sgd = on != 0 && m->gaps_ok; }
-void masr_step_counters(const masr_model* m, int64_t out[3]) { out[0] = m->n_direct; out[1] = m->n_captured; out[2] = m->n_replayed; }
+void masr_set_split_wgrad_launches(masr_model* m, int on) { if ((on != 0) != m->split_wgrad) drop_step_graphs(m); m->split_wgrad = on != 0; }
+void masr_set_ksplit(masr_model* m, int on) { if ((on != 0) != m->ksplit) drop_step_graphs(m); m->ksplit = on != 0; }
+void masr_step_counters(const masr_model* m, int64_t out[4]) { out[0] = m->n_direct; out[1] = m->n_captured; out[2] = m->n_replayed; out[3] = m->n_ksplit; }
 
 int masr_read_stats(masr_model* m, float out[4], void* stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -1135,14 +1040,6 @@ int masr_grad_norm(masr_model* m, void* stream) {
 }
 int masr_clip_sgd_step(masr_model* m, float* mom, float max_norm, float lr, float momentum, int nesterov, int first_step, void* stream) {
     CK(masr_grad_norm(m, stream));
-    if (m->fuse_sgd && m->gaps_ok && !m->shadows.empty()) {
-        // ONE pass: p and g in, p and every bf16 layout out (kernels.h mk_sgd_shadows)
-        Prof p(m, MASR_PROF_OPTIM, (hipStream_t)stream);
-        const SgdFuse sg{m->G, mom, m->stats + 3, max_norm, lr, momentum, nesterov, first_step};
-        bool first = true;
-        for (const ShadowJobs& J : m->shadows) { CK(mk_sgd_shadows(m->P, sg, J, m->d_gaps, first ? m->ngaps : 0, (hipStream_t)stream)); first = false; }
-        return 0;
-    }
     { Prof p(m, MASR_PROF_OPTIM, (hipStream_t)stream);
       CK(mk_clip_sgd(m->P, m->G, mom, m->nparams, m->stats + 3, max_norm, lr, momentum, nesterov, first_step, (hipStream_t)stream)); }
     return masr_refresh(m, stream);
@@ -1355,7 +1252,7 @@ int masr_fbank_pitch(const float* wav, const int64_t* wav_off, const int64_t* ro
     return mk_pitch(wav, (const long*)wav_off, (const long*)row_off, total_samples, max_samples, B, max_frames, n_mel, feat, work, work_bytes, (hipStream_t)stream);
 }
 int64_t masr_ctc_work_floats(int T, int B, int maxS) { return mk_ctc_work_floats(T, B, maxS); }
-int masr_ctc_status(void* stream) { return mk_ctc_status((hipStream_t)stream); }
+int masr_ctc_status(const float* work, int T, int B, int maxS, void* stream) { return mk_ctc_status(work, T, B, maxS, (hipStream_t)stream); }
 int masr_ctc_loss(const float* logits, const int32_t* targets, const int32_t* tgt_off, const int32_t* in_len, const int32_t* tgt_len, int T,
                   int B, int C, int blank, float* nll, float* loss, float* grad, float* work, int maxS, void* stream) {
     return mk_ctc_loss(logits, targets, tgt_off, in_len, tgt_len, T, B, C, blank, nll, loss, grad, work, maxS, (hipStream_t)stream);
@@ -1438,9 +1335,6 @@ int masr_test_conv3x3_pool_idx(const uint16_t* in, const uint16_t* wk, const flo
     ConvArgs a{}; a.in = (const bf16*)in; a.wk = (const bf16*)wk; a.bias = bias; a.relu = 1; a.out = (bf16*)out;
     a.pool_out = (bf16*)pool_out; a.pool_idx = pool_idx; a.out_optional = drop_out; a.B = B; a.H = H; a.W = W; a.CIN = CIN; a.COUT = COUT;
     return mk_conv3x3(a, (hipStream_t)stream);
-}
-int masr_test_maxpool_idx_bwd(const uint8_t* idx, const uint16_t* dout, uint16_t* din, int B, int H, int W, int C, void* stream) {
-    return mk_maxpool_idx_bwd(idx, (const bf16*)dout, (bf16*)din, B, H, W, C, (hipStream_t)stream);
 }
 int masr_test_conv3x3_dgrad_pooled(const uint16_t* dy, const uint16_t* dy_pooled, const uint8_t* pool_idx, const uint16_t* wk, const uint32_t* mask_bits,
                                    uint16_t* out, int B, int H, int W, void* stream) {

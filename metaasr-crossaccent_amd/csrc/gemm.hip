@@ -226,12 +226,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
         if (m >= g.M) continue;
         float v[SW];
         ldf(ct + row * LDC + cs, v);
+        float ks[SW];                                             // dropout keep-scales of the SW consecutive elements: one hash word per pair
+#pragma unroll
+        for (int h = 0; h < SW / 4; ++h) {
+            float k4[4] = {1.f, 1.f, 1.f, 1.f};
+            if (f_drop) dropout_scale4(seed, g.site, (uint32_t)((long)m * g.N + n + 4 * h), g.drop_p, inv_keep, k4);
+            ks[4 * h] = k4[0]; ks[4 * h + 1] = k4[1]; ks[4 * h + 2] = k4[2]; ks[4 * h + 3] = k4[3];
+        }
 #pragma unroll
         for (int e = 0; e < SW; ++e) {
             float x = v[e] + bv[e] + pev[i][e];
             if (f_relu) x = fmaxf(x, 0.f);
             if (f_mask) x = mk[i][e] > 0.f ? x * g.mask_scale : 0.f;
-            if (f_drop) x *= dropout_scale(seed, g.site, (uint32_t)((long)m * g.N + n + e), g.drop_p, inv_keep);
+            if (f_drop) x *= ks[e];
             v[e] = x + rs[i][e] + old[i][e];
         }
         if (f_c32) {
@@ -895,232 +902,6 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs g) {
     gemm_epilogue<BM, BN, EPI, 512>(g, acc, smem, m0, n0, (long)bz_ * g.split_stride, true);
 }
 
-// ---- LayerNorm in the prologue of its consumer GEMM (round 4).  64-row tiles, K == E <= 512: the workgroup normalises its 64 rows
-// (one wave per row, four rows per pass: the arithmetic and the lane -> column map of rowops.hip's ln_fwd_kernel / ln_bwd_kernel, so the
-// fused path gives the same bits) into an LDS-resident bf16 A tile [64][E + 8], then runs the k loop with the B tiles streamed by LDS-DMA
-// through a ring of three (as gemm_glds_kernel).  Every column tile repeats the row work (8 .. 32 times 128 KB of L2 reads: ~2 us) -- the
-// standalone LayerNorm launch it replaces cost ~5 us + a kernel boundary on the decoder's few hundred rows.
-template <int VW> struct LnV;
-template <> struct LnV<4> {
-    static __device__ __forceinline__ void ld(const float* p, float (&o)[4]) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3]; }
-    static __device__ __forceinline__ void st(float* p, const float (&o)[4]) { *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]}; }
-    static __device__ __forceinline__ void st16(bf16* p, const float (&o)[4]) { bf16x4 t; t[0] = (bf16)o[0]; t[1] = (bf16)o[1]; t[2] = (bf16)o[2]; t[3] = (bf16)o[3]; *reinterpret_cast<bf16x4*>(p) = t; }
-};
-template <> struct LnV<1> {
-    static __device__ __forceinline__ void ld(const float* p, float (&o)[1]) { o[0] = p[0]; }
-    static __device__ __forceinline__ void st(float* p, const float (&o)[1]) { p[0] = o[0]; }
-    static __device__ __forceinline__ void st16(bf16* p, const float (&o)[1]) { p[0] = (bf16)o[0]; }
-};
-constexpr int LNA_PAD = 8;
-// the k loop both kernels share: A fragments from the resident tile `sa` (row stride LDA elements), B tiles by LDS-DMA into `ring`
-template <int BN, int EPI>
-__device__ __forceinline__ void lnA_mainloop(const GemmArgs& g, const bf16* sa, const int LDA, char* ring, char* smem, const int m0, const int n0) {
-    constexpr int BM = 64, WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
-    constexpr int B_BYTES = BN * 128, BCH = BN * 8 / 256;
-    typedef __attribute__((address_space(1))) const void gptr_t;
-    typedef __attribute__((address_space(3))) void lptr_t;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const bf16* bsrc[BCH];
-#pragma unroll
-    for (int i = 0; i < BCH; ++i) {
-        const int c = tid + i * 256, r = c >> 3, ch = (c & 7) ^ (r & 7);
-        const int row = n0 + r < g.N ? n0 + r : g.N - 1;
-        bsrc[i] = g.B + (long)row * g.ldb + ch * 8;
-    }
-    auto stage = [&](int buf, int kt) {
-        char* bb = ring + buf * B_BYTES;
-#pragma unroll
-        for (int i = 0; i < BCH; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(bsrc[i] + kt * 64), (lptr_t*)(bb + (wave * 64 + i * 256) * 16), 16, 0, 0);
-    };
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nk = g.K / 64, rr = lane & 15, q = lane >> 4;
-    static_assert(BCH == 2 || BCH == 4, "unexpected tile geometry");
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) {
-            if constexpr (BCH == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (first pass: this wave's rows of the A tile are written)
-        __builtin_amdgcn_s_barrier();                                 // tile kt landed for every wave; buffer (kt-1)%3 is no longer read
-        if (kt + 2 < nk) stage(cur == 0 ? 2 : cur - 1, kt + 2);
-        const bf16* bb = reinterpret_cast<const bf16*>(ring + cur * B_BYTES);
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
-            bf16x8 af[FM], bfr[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) af[i] = ld8(sa + (wm * WM + i * 16 + rr) * LDA + kt * 64 + kc * 32 + q * 8);
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int row = wn * WN + j * 16 + rr;
-                bfr[j] = ld8(bb + row * 64 + (((kc * 4 + q) ^ (row & 7)) * 8));
-            }
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
-        }
-        cur = cur == 2 ? 0 : cur + 1;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                     // all fragment reads done before the epilogue reuses the LDS
-    gemm_epilogue<BM, BN, EPI>(g, acc, smem, m0, n0, 0);
-}
-template <int PT> struct LnGeo { static constexpr int E = 64 * PT, VW = PT % 4 == 0 ? 4 : 1, NV = PT / VW, LDA = E + LNA_PAD; };
-template <int BN, int PT> struct LnSmem {
-    static constexpr int A_BYTES = 64 * LnGeo<PT>::LDA * 2, RING = 3 * BN * 128, OUT = 4 * 64 * (BN + 4), RED = 4 * 2 * LnGeo<PT>::E * 4;
-    static constexpr int HEAD = A_BYTES > OUT ? A_BYTES : OUT;          // the epilogue's fp32 tile reuses the A tile's place
-    static constexpr int BYTES = HEAD + (RING > RED ? RING : RED);
-};
-
-template <int BN, int EPI, int PT>
-__global__ __launch_bounds__(256) void gemm_lnfwd_kernel(GemmArgs g, LnFwdA ln) {
-    using G = LnGeo<PT>; using V = LnV<G::VW>;
-    constexpr int E = G::E, VW = G::VW, NV = G::NV, LDA = G::LDA;
-    __shared__ __attribute__((aligned(16))) char smem[LnSmem<BN, PT>::BYTES];
-    bf16* sa = reinterpret_cast<bf16*>(smem);
-    char* ring = smem + LnSmem<BN, PT>::HEAD;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * BN;
-    const bool writer = blockIdx.x == 0;
-    float gm[NV][VW], bt[NV][VW];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) { const int c = (i * 64 + lane) * VW; V::ld(ln.gamma + c, gm[i]); V::ld(ln.beta + c, bt[i]); }
-    // rows m0 + 4 it + wave; four passes in flight (their loads are issued up front, unconditionally: rows past M are clamped re-reads)
-#pragma unroll 1
-    for (int it0 = 0; it0 < 16; it0 += 4) {
-        float v[4][NV][VW];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = m0 + 4 * (it0 + u) + wave, rc = row < g.M ? row : g.M - 1;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) V::ld(ln.x + (long)rc * E + (i * 64 + lane) * VW, v[u][i]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int lr = 4 * (it0 + u) + wave, row = m0 + lr;
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < NV; ++i)
-#pragma unroll
-                for (int e = 0; e < VW; ++e) s += v[u][i][e];
-            const float mu = wave_sum(s) / E;
-            float qq = 0.f;
-#pragma unroll
-            for (int i = 0; i < NV; ++i)
-#pragma unroll
-                for (int e = 0; e < VW; ++e) { const float d = v[u][i][e] - mu; qq += d * d; }
-            const float rs = rsqrtf(wave_sum(qq) / E + 1e-5f);
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                float o[VW];
-#pragma unroll
-                for (int e = 0; e < VW; ++e) o[e] = (v[u][i][e] - mu) * rs * gm[i][e] + bt[i][e];
-                const int c = (i * 64 + lane) * VW;
-                V::st16(sa + lr * LDA + c, o);                               // (rows past M hold a copy of the last row: never stored by the epilogue)
-                if (writer && row < g.M) {
-                    const long idx = (long)row * E + c;
-                    if (ln.y32) V::st(ln.y32 + idx, o);
-                    if (ln.y16) V::st16(ln.y16 + idx, o);
-                }
-            }
-            if (writer && row < g.M && lane == 0) { ln.mean[row] = mu; ln.rstd[row] = rs; }
-        }
-    }
-    lnA_mainloop<BN, EPI>(g, sa, LDA, ring, smem, m0, n0);
-}
-
-template <int BN, int EPI, int PT>
-__global__ __launch_bounds__(256) void gemm_lnbwd_kernel(GemmArgs g, LnBwdA ln) {
-    using G = LnGeo<PT>; using V = LnV<G::VW>;
-    constexpr int E = G::E, VW = G::VW, NV = G::NV, LDA = G::LDA;
-    __shared__ __attribute__((aligned(16))) char smem[LnSmem<BN, PT>::BYTES];
-    bf16* sa = reinterpret_cast<bf16*>(smem);
-    char* ring = smem + LnSmem<BN, PT>::HEAD;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * BN;
-    const bool writer = blockIdx.x == 0;
-    const uint32_t seed = ln.seed_ptr ? *ln.seed_ptr : ln.seed;
-    const float inv_keep = ln.drop_p > 0.f ? 1.f / (1.f - ln.drop_p) : 1.f;
-    float gm[NV][VW], dg[NV][VW], db[NV][VW];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        V::ld(ln.gamma + (i * 64 + lane) * VW, gm[i]);
-#pragma unroll
-        for (int e = 0; e < VW; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
-    }
-#pragma unroll 1
-    for (int it0 = 0; it0 < 16; it0 += 2) {
-        float d[2][NV][VW], xv[2][NV][VW], mu[2], rs[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int row = m0 + 4 * (it0 + u) + wave, rc = row < g.M ? row : g.M - 1;
-            mu[u] = ln.mean[rc]; rs[u] = ln.rstd[rc];
-#pragma unroll
-            for (int i = 0; i < NV; ++i) { const long idx = (long)rc * E + (i * 64 + lane) * VW; V::ld(ln.dy + idx, d[u][i]); V::ld(ln.x + idx, xv[u][i]); }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int lr = 4 * (it0 + u) + wave, row = m0 + lr;
-            const float live = row < g.M ? 1.f : 0.f;                          // (clamped rows must not count towards dgamma / dbeta)
-            float gg[NV][VW], xh[NV][VW];
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < NV; ++i)
-#pragma unroll
-                for (int e = 0; e < VW; ++e) {
-                    xh[i][e] = (xv[u][i][e] - mu[u]) * rs[u];
-                    gg[i][e] = d[u][i][e] * gm[i][e];
-                    dg[i][e] += live * (d[u][i][e] * xh[i][e]);
-                    db[i][e] += live * d[u][i][e];
-                    s1 += gg[i][e];
-                    s2 += gg[i][e] * xh[i][e];
-                }
-            s1 = wave_sum(s1) / E;
-            s2 = wave_sum(s2) / E;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                float o[VW];
-#pragma unroll
-                for (int e = 0; e < VW; ++e) o[e] = (gg[i][e] - s1 - xh[i][e] * s2) * rs[u];
-                const int c = (i * 64 + lane) * VW;
-                const long idx = (long)row * E + c;
-                if (writer && row < g.M && ln.dx32) V::st(ln.dx32 + idx, o);
-                if (ln.drop_p > 0.f) {
-#pragma unroll
-                    for (int e = 0; e < VW; ++e) o[e] *= dropout_scale(seed, ln.site, (uint32_t)(idx + e), ln.drop_p, inv_keep);
-                }
-                V::st16(sa + lr * LDA + c, o);
-                if (writer && row < g.M && ln.dx16) V::st16(ln.dx16 + idx, o);
-            }
-        }
-    }
-    if (writer) {
-        // one dgamma | dbeta partial per 64-row block: the four waves' sums in wave order (fixed -> deterministic), in the ring's place
-        float* red = reinterpret_cast<float*>(ring);                        // [4][2][E]
-#pragma unroll
-        for (int i = 0; i < NV; ++i) { V::st(red + (wave * 2 + 0) * E + (i * 64 + lane) * VW, dg[i]); V::st(red + (wave * 2 + 1) * E + (i * 64 + lane) * VW, db[i]); }
-        __syncthreads();
-        for (int c = tid; c < E; c += 256) {
-            ln.slab[((long)blockIdx.y * 2 + 0) * E + c] = red[(0 * 2 + 0) * E + c] + red[(1 * 2 + 0) * E + c] + red[(2 * 2 + 0) * E + c] + red[(3 * 2 + 0) * E + c];
-            ln.slab[((long)blockIdx.y * 2 + 1) * E + c] = red[(0 * 2 + 1) * E + c] + red[(1 * 2 + 1) * E + c] + red[(2 * 2 + 1) * E + c] + red[(3 * 2 + 1) * E + c];
-        }
-        __syncthreads();                                                    // (the ring is about to receive the first B tiles)
-    }
-    lnA_mainloop<BN, EPI>(g, sa, LDA, ring, smem, m0, n0);
-}
-
 static int gemm_ncu() {                                         // (task-slot threads call this concurrently: a thread-safe one-time initialisation)
     static const int ncu = [] {
         int dev = 0, n = 0;
@@ -1209,57 +990,6 @@ int mk_gemm_wgrad_grouped(WgradGroup& grp, hipStream_t s, int first_members) {
     // (Tried: the 128 x 128 form with LDS-DMA staging -- reduction-major tiles are lane-linear per DMA piece as they are, chunk c of row k
     // at c ^ (k & 15) for the transposing reads, zero line behind the last row, bias gradient as one more MFMA column against ones: 202 us
     // against 160 for the register-staged kernel of that size on the encoder-row launch; both are gone: the 256 x 256 tiles above run it in 111.)
-    return 0;
-}
-
-namespace {
-int epi_of(const GemmArgs& g) {
-    return (g.bias ? E_BIAS : 0) | (g.pe ? E_PE : 0) | (g.relu ? E_RELU : 0) | (g.mask ? E_MASK : 0) | (g.drop_p > 0.f ? E_DROP : 0) |
-           (g.residual ? E_RES : 0) | (g.accumulate ? E_ACC : 0) | (g.C32 ? E_C32 : 0) | (g.C16 ? E_C16 : 0);
-}
-bool lnA_shape_ok(const GemmArgs& g) {
-    // complete rows of the LayerNorm in one tile (K == E in {64, 128, 256, 512}), the decoder's few hundred rows (a 64 x 64 tiling that
-    // mk_gemm would pick as well), operands of the LDS-DMA form
-    return !g.reduction_major && (g.K == 64 || g.K == 128 || g.K == 256 || g.K == 512) && g.M > 0 && g.M <= 1024 && g.N > 0 &&
-           !(g.ldb & 7) && !((uintptr_t)g.B & 15) && g.ldb >= g.K;
-}
-}  // namespace
-#define LN_PT_DISPATCH(K, CALL) switch ((K) / 64) { case 1: CALL(1); break; case 2: CALL(2); break; case 4: CALL(4); break; default: CALL(8); }
-int mk_gemm_lnfwd(const GemmArgs& g, const LnFwdA& ln, hipStream_t s) {
-    if (!lnA_shape_ok(g) || !ln.mean || !ln.rstd) return 1;
-    const dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
-    switch (epi_of(g) & ~E_DROP) {
-#define CALL(P) hipLaunchKernelGGL((gemm_lnfwd_kernel<64, EPIV | E_DROP, P>), grid, dim3(256), 0, s, g, ln)
-#define EPIV (E_BIAS | E_C16)
-        case EPIV: LN_PT_DISPATCH(g.K, CALL) break;                         // q / k / v projections
-#undef EPIV
-#define EPIV (E_BIAS | E_RELU | E_C16)
-        case EPIV: LN_PT_DISPATCH(g.K, CALL) break;                         // FFN first layer
-#undef EPIV
-#define EPIV (E_BIAS | E_C32)
-        case EPIV: LN_PT_DISPATCH(g.K, CALL) break;                         // output projection
-#undef EPIV
-#undef CALL
-        default: return 1;
-    }
-    if (hipGetLastError() != hipSuccess) { mk_set_error("mk_gemm_lnfwd", "launch failed"); return -1; }
-    return 0;
-}
-int mk_gemm_lnbwd(const GemmArgs& g, const LnBwdA& ln, hipStream_t s) {
-    if (!lnA_shape_ok(g) || !ln.slab) return 1;
-    const dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
-    switch (epi_of(g) & ~E_DROP) {
-#define CALL(P) hipLaunchKernelGGL((gemm_lnbwd_kernel<64, EPIV | E_DROP, P>), grid, dim3(256), 0, s, g, ln)
-#define EPIV (E_C16)
-        case EPIV: LN_PT_DISPATCH(g.K, CALL) break;                         // plain dgrad (attention out-proj)
-#undef EPIV
-#define EPIV (E_MASK | E_C16)
-        case EPIV: LN_PT_DISPATCH(g.K, CALL) break;                         // dgrad through the ReLU (+ dropout) mask (FFN second layer)
-#undef EPIV
-#undef CALL
-        default: return 1;
-    }
-    if (hipGetLastError() != hipSuccess) { mk_set_error("mk_gemm_lnbwd", "launch failed"); return -1; }
     return 0;
 }
 

@@ -33,18 +33,6 @@ struct GemmArgs {
     int cseg_rows; long cseg_stride;
 };
 int mk_gemm(const GemmArgs& g, hipStream_t s);
-// NT GEMMs whose A operand is a LayerNorm OUTPUT (forward) or a LayerNorm input-GRADIENT (backward) that the GEMM computes itself
-// from the fp32 rows, K == the LayerNorm width E: the few-hundred-row decoder LayerNorms are 5 us launches for 1 us of work, and every
-// consumer GEMM workgroup holds complete rows of its A tile anyway (gemm.hip gemm_lnfwd_kernel / gemm_lnbwd_kernel).  g.A is ignored.
-// The workgroups of the first column tile also write what the standalone LayerNorm kernels write (y32 / y16 / mean / rstd; dx32 /
-// dx16 / one dgamma|dbeta partial per 64-row block in `slab`).  Return 1 when the shape is not covered (the caller launches the
-// LayerNorm and the plain GEMM instead), 0 when launched, -1 on error.
-struct LnFwdA { const float* x; const float* gamma; const float* beta; float* y32; bf16* y16; float* mean; float* rstd; };
-struct LnBwdA { const float* dy; const float* x; const float* gamma; const float* mean; const float* rstd; float* dx32; bf16* dx16;
-                float drop_p; uint32_t seed, site; const uint32_t* seed_ptr; float* slab; };
-int mk_gemm_lnfwd(const GemmArgs& g, const LnFwdA& ln, hipStream_t s);
-int mk_gemm_lnbwd(const GemmArgs& g, const LnBwdA& ln, hipStream_t s);
-inline int mk_gemm_ln_blocks(int rows) { return (rows + 63) / 64; }      // dgamma|dbeta partial blocks mk_gemm_lnbwd writes
 // Linear weight gradients as one grouped launch: dW[N][K] = dy[rows][N]^T x[rows][K], db[N] = column sums of dy (or null)
 struct WgradDesc { const bf16* dy; const bf16* x; float* dW; float* db; int lddy, ldx, rows, N, K, tile_start; };
 constexpr int WGRAD_GROUP_MAX = 40;
@@ -101,8 +89,7 @@ long mk_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT);
 int mk_maxpool_fwd(const bf16* in, bf16* out, int B, int H, int W, int C, hipStream_t s, int ceil_mode = 0);
 // din = (in is the first max of its window && in > 0) ? dout : 0   (ReLU backward fused)
 int mk_maxpool_relu_bwd(const bf16* in, const bf16* dout, bf16* din, int B, int H, int W, int C, hipStream_t s, int ceil_mode = 0);
-// the same from ConvArgs::pool_idx instead of the full-resolution map (floor mode); mk_maxpool_idx computes the bytes from a stored map
-int mk_maxpool_idx_bwd(const uint8_t* idx, const bf16* dout, bf16* din, int B, int H, int W, int C, hipStream_t s);
+// ConvArgs::pool_idx computed from a stored map (for the conv kernels that cannot emit the codes in their epilogue)
 int mk_maxpool_idx(const bf16* in, uint8_t* idx, int B, int H, int W, int C, hipStream_t s);
 // CIN = 1 convs with COUT = 64 n channels
 int mk_conv1_fwd_n(const float* x, const float* w, const float* bias, bf16* out, int B, int H, int W, int COUT, hipStream_t s);
@@ -246,11 +233,6 @@ constexpr int SHADOW_JOBS_MAX = 56;
 struct ShadowJobs { int n, blocks; ShadowDesc d[SHADOW_JOBS_MAX]; bf16* p[2 * SHADOW_JOBS_MAX]; };
 int mk_shadow_blocks(const ShadowDesc& d);                          // workgroups this job needs (tile_start bookkeeping on the host)
 int mk_all_shadows(const float* P, const ShadowJobs& jobs, hipStream_t s);
-// the same launch with masr_clip_sgd_step's update applied on the way (optim.hip all_shadows_kernel<true>): g / mom mirror P's layout, norm =
-// device float holding ||g|| (null: no clip), step_flags as mk_clip_sgd; gaps = device (offset, length <= 2048) chunks of the elements no job
-// covers.  With several job lists (deep models) the gaps go with ONE of the launches.
-struct SgdFuse { const float* g; float* mom; const float* norm; float max_norm, lr, momentum; int nesterov, step_flags; };
-int mk_sgd_shadows(float* P, const SgdFuse& sg, const ShadowJobs& jobs, const long* gaps, int ngaps, hipStream_t s);
 // inverse map for the weight gradient: g_nhwc [E][d*C+c] fp32 -> dw [E][c*Dp+d]
 int mk_vgg2enc_grad_unpermute(const float* g_nhwc, float* dw, int E, int C, int Dp, hipStream_t s);
 
@@ -281,9 +263,8 @@ int mk_lstm_bwd_steps(const LstmStepArgs& a, hipStream_t s);
 // allocation-aligned block); *err is set to 1 when a workgroup gave up waiting for its peers (never cleared by the kernels).
 bool mk_lstm_rec_ok(int B, int H, int KP);
 int64_t mk_lstm_rec_words(int B, int H);
-int mk_lstm_fwd_rec(const LstmStepArgs& a, unsigned long long* words, int* err, hipStream_t s);
+int mk_lstm_fwd_rec(const LstmStepArgs& a, unsigned long long* words, int* err, hipStream_t s, int test_stall = 0);   // test_stall: fault injection of the time-out test -- workgroup 0 leaves without publishing
 int mk_lstm_bwd_rec(const LstmStepArgs& a, unsigned long long* words, int* err, hipStream_t s);
-void mk_lstm_rec_test_stall(int on);      // fault injection for the time-out test: workgroup 0 of the forward launch leaves without publishing
 // W_ih [4H][K], W_hh [4H][H], biases in torch order -> unit-major bf16 shadows (+ transposes for the dgrad GEMMs)
 int mk_lstm_shadows(const float* wih, const float* whh, const float* bih, const float* bhh, int H, int K, int KP_in, int KP_h,
                     bf16* wih16, bf16* wihT16, bf16* whh16, bf16* whhT16, float* bias, int pc, int pd, hipStream_t s);
@@ -315,5 +296,5 @@ int mk_pitch(const float* wav, const long* wav_off, const long* row_off, long to
 int mk_ctc_loss(const float* logits, const int* targets, const int* tgt_off, const int* in_len, const int* tgt_len,
                   int T, int B, int C, int blank, float* nll /*[B]*/, float* loss_out, float* grad, float* work,
                   int maxS, hipStream_t s, int batch_first = 0);      // batch_first: logits / grad are [B][T][C]
-int mk_ctc_status(hipStream_t s);                              // > 0: (index + 1) of an utterance a CTC launch refused (bad lengths); clears
+int mk_ctc_status(const float* work, int T, int B, int maxS, hipStream_t s);     // > 0: (index + 1) of an utterance the CTC launch on `work` refused (bad lengths)
 long mk_ctc_work_floats(int T, int B, int maxS);

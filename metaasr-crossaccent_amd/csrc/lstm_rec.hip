@@ -21,6 +21,7 @@
 // on a 256-CU chip; under other streams' load a late one starts when a CU frees up, the early ones only spin meanwhile.
 // Arithmetic: the same fp32 formulas as lstm.hip's step kernels; the recurrent product is accumulated in ONE MFMA chain per
 // output tile where the step kernels add four partial chains, so results agree to fp32 rounding, not bit for bit.
+#include <atomic>
 #include "kernels.h"
 
 namespace {
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(REC_THREADS) void lstm_fwd_rec_kernel(LstmStepArgs 
     // (Tried: all workgroups of a direction on ONE XCD -- a grid of 8 NW under round-robin placement, the others leaving at once -- so that a
     // direction's exchange stays behind one L2: forward 290 -> 273 us per layer, backward 394 -> 415.  Not kept.)
     const int dir = blockIdx.x / ra.NW, slice = blockIdx.x % ra.NW;
+    if (*ra.err != 0) return;                                   // an earlier launch of this step timed out: the step is lost already, do not spin again
     if (ra.stall && blockIdx.x == 0) return;                    // fault injection (masr_test_blstm_stall): a workgroup that never publishes
     const int H = a.H, G = 4 * H, KP = a.KP, T = a.T, B = a.B;
     const int u0 = slice * ra.UPW, uend = u0 + ra.UPW < H ? u0 + ra.UPW : H;
@@ -191,6 +193,7 @@ __global__ __launch_bounds__(REC_THREADS) void lstm_bwd_rec_kernel(LstmStepArgs 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dir = blockIdx.x / ra.NW, slice = blockIdx.x % ra.NW;
+    if (*ra.err != 0) return;                                   // (see lstm_fwd_rec_kernel)
     const int H = a.H, G = 4 * H, T = a.T, B = a.B;
     const int DS = G + 8;                                        // LDS row of dz in bf16 (+16 bytes)
     bf16* dzs = reinterpret_cast<bf16*>(smem_raw);               // [MT * 16][DS]
@@ -310,13 +313,11 @@ static void fwd_rec_launch(const LstmStepArgs& a, const RecArgs& ra, hipStream_t
     else if (ks <= 8) hipLaunchKernelGGL((lstm_fwd_rec_kernel<8, MT>), grid, dim3(REC_THREADS), 0, s, a, ra);
     else hipLaunchKernelGGL((lstm_fwd_rec_kernel<12, MT>), grid, dim3(REC_THREADS), 0, s, a, ra);
 }
-static int g_rec_stall = 0;
-void mk_lstm_rec_test_stall(int on) { g_rec_stall = on; }
-int mk_lstm_fwd_rec(const LstmStepArgs& a, unsigned long long* words, int* err, hipStream_t s) {
+int mk_lstm_fwd_rec(const LstmStepArgs& a, unsigned long long* words, int* err, hipStream_t s, int test_stall) {
     if (!mk_lstm_rec_ok(a.B, a.H, a.KP)) { mk_set_error("mk_lstm_fwd_rec", "shape not covered by the resident recurrence"); return -1; }
     // tags of the forward exchange: [2 dirs][2 parities][B][granules per row] (the block starts its allocation; zeroed in whole 16 bytes)
     const size_t bytes = sizeof(unsigned long long) * (size_t)2 * 2 * a.B * fwd_row_granules(a.H);
-    RecArgs ra{words, err, rec_slices(a.H), rec_units(a.H), (unsigned)bytes, g_rec_stall};
+    RecArgs ra{words, err, rec_slices(a.H), rec_units(a.H), (unsigned)bytes, test_stall};
     if (hipMemsetAsync(words, 0, bytes, s) != hipSuccess) { mk_set_error("mk_lstm_fwd_rec", "memset failed"); return -1; }
     if (a.B <= 16) fwd_rec_launch<1>(a, ra, s); else fwd_rec_launch<2>(a, ra, s);
     return LAUNCH_OK();
@@ -324,10 +325,13 @@ int mk_lstm_fwd_rec(const LstmStepArgs& a, unsigned long long* words, int* err, 
 template <int KQ, int MT>
 static int bwd_rec_launch1(const LstmStepArgs& a, const RecArgs& ra, hipStream_t s) {
     const size_t lds = (size_t)MT * 16 * (4 * a.H + 8) * sizeof(bf16) + sizeof(float) * 4 * 2 * MT * 16 * 16;
-    static bool raised = false;
-    if (!raised) {
+    // once per instantiation AND device (a set bit = raised on that device; two threads racing here both raise it: harmless)
+    static std::atomic<unsigned long long> raised{0};
+    int dev = 0; hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(raised.load(std::memory_order_acquire) & bit)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_rec_kernel<KQ, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return -1;
-        raised = true;
+        raised.fetch_or(bit, std::memory_order_release);
     }
     hipLaunchKernelGGL((lstm_bwd_rec_kernel<KQ, MT>), dim3(2 * ra.NW), dim3(REC_THREADS), lds, s, a, ra);
     return 0;

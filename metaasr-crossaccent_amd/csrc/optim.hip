@@ -231,41 +231,9 @@ __global__ __launch_bounds__(256) void vgg2enc_unpermute_kernel(const float* __r
 }
 
 // every operand shadow of the model, one job list, one launch (see kernels.h)
-constexpr int SH_TILE = 64, SH_GAP = 2048;
-// SGD = true: the clipped SGD step of masr_clip_sgd_step is applied to every element ON ITS WAY into the shadows (read p and g, write p
-// and the bf16 layouts: the separate pass read p twice and the launch boundary drained the chip in between); elements that no shadow
-// job covers (biases, LayerNorm, embedding, conv1) are the `gaps` chunks, taken by the blocks behind the jobs'.  Same update expression
-// as clip_sgd_kernel (SgdUpd): same bits.
-template <bool SGD>
-__global__ __launch_bounds__(256) void all_shadows_kernel(typename std::conditional<SGD, float*, const float*>::type __restrict__ P, const ShadowJobs jobs,
-                                                          const SgdFuse sg, const long* __restrict__ gaps) {
-    SgdUpd upd{1.f, sg.lr, sg.momentum, sg.nesterov, sg.step_flags & 1};
-    const bool use_m = SGD && sg.momentum != 0.f, rd_m = use_m && !(sg.step_flags & 1), wr_m = use_m && !(sg.step_flags & 2);
-    if constexpr (SGD) {
-        if (sg.norm) {
-            const float nv = sg.norm[0];
-            if (nv != nv) return;                               // NaN norm: the step is skipped, the shadows are still right
-            upd.coef = clip_coef(nv, sg.max_norm);
-        }
-    }
-    // one element: new value (written back to P, and the momentum buffer) or, without SGD, the value itself
-    auto elem = [&](long i) -> float {
-        if constexpr (SGD) {
-            float mo = rd_m ? sg.mom[i] : 0.f;
-            const float v = upd(P[i], sg.g[i], mo, mo);
-            P[i] = v;
-            if (wr_m) sg.mom[i] = mo;
-            return v;
-        } else return P[i];
-    };
-    if constexpr (SGD) {
-        if ((int)blockIdx.x >= jobs.blocks) {                     // a gap chunk: (offset, length <= SH_GAP)
-            const int c = blockIdx.x - jobs.blocks;
-            const long off = gaps[2 * c]; const int len = (int)gaps[2 * c + 1];
-            for (int i = threadIdx.x; i < len; i += 256) elem(off + i);
-            return;
-        }
-    }
+constexpr int SH_TILE = 64;
+__global__ __launch_bounds__(256) void all_shadows_kernel(const float* __restrict__ P, const ShadowJobs jobs) {
+    auto elem = [&](long i) -> float { return P[i]; };
     int lo = 0, hi = jobs.n - 1;                                  // last job whose tile_start <= blockIdx.x (uniform: scalar ALU)
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -276,11 +244,6 @@ __global__ __launch_bounds__(256) void all_shadows_kernel(typename std::conditio
     const int blk = blockIdx.x - d.tile_start;
     const float* x = P + d.src;
     bf16* p0 = jobs.p[2 * e]; bf16* p1 = jobs.p[2 * e + 1];
-    auto upd4 = [&](float4 pv, float4 gv, float4& mv) {
-        float4 o;
-        o.x = upd(pv.x, gv.x, mv.x, mv.x); o.y = upd(pv.y, gv.y, mv.y, mv.y); o.z = upd(pv.z, gv.z, mv.z, mv.z); o.w = upd(pv.w, gv.w, mv.w, mv.w);
-        return o;
-    };
     if (d.type == SH_LINEAR || d.type == SH_VGG2ENC) {
         // 64 x 64 tile: fp32 rows in, through LDS, bf16 out as 16 bytes per lane in BOTH layouts -- the pass is bound by
         // vector-memory instructions: 4-byte loads and 2-byte stores made 48 of them per wave and tile where 9 suffice.
@@ -307,7 +270,7 @@ __global__ __launch_bounds__(256) void all_shadows_kernel(typename std::conditio
             // each (15 rows per pass, five passes) and drop its owned elements into the LDS tile at their tile columns: one load per
             // array and pass, no realignment in registers (16 lanes per row took two loads each -- the 17th vector -- and eight
             // shuffles).  What lies outside the tile belongs to a neighbouring tile or tensor of P (never past its ends: the shadowed
-            // tensors are neither the first nor the last): read, in SGD mode updated in registers, never stored.
+            // tensors are neither the first nor the last): read and dropped.
             const int mis = (int)((d.src + (long)r0 * d.K + c0) & 3);
             const int v = threadIdx.x % 17, rr = threadIdx.x / 17;
             const int lo = v == 0 ? mis : 0, hi = v == 16 ? mis : 4;              // owned elements of the vector: [lo, hi)
@@ -316,22 +279,7 @@ __global__ __launch_bounds__(256) void all_shadows_kernel(typename std::conditio
                 const int k = rr + 15 * pass;
                 const bool in = rr < 15 && k < SH_TILE, ok = in && r0 + k < d.N;
                 const long aoff = d.src + (long)(ok ? r0 + k : r0) * d.K + c0 - mis + 4 * (hi > lo ? v : 15);
-                float4 q = *reinterpret_cast<const float4*>(P + aoff);
-                if constexpr (SGD) {
-                    const float4 gq = *reinterpret_cast<const float4*>(sg.g + aoff);
-                    float4 mq = rd_m ? *reinterpret_cast<const float4*>(sg.mom + aoff) : float4{0.f, 0.f, 0.f, 0.f};
-                    q = upd4(q, gq, mq);
-                    if (ok) {
-                        if (hi - lo == 4) {
-                            *reinterpret_cast<float4*>(P + aoff) = q;
-                            if (wr_m) *reinterpret_cast<float4*>(sg.mom + aoff) = mq;
-                        } else {
-                            const float qa[4] = {q.x, q.y, q.z, q.w}, ma[4] = {mq.x, mq.y, mq.z, mq.w};
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) if (e >= lo && e < hi) { P[aoff + e] = qa[e]; if (wr_m) sg.mom[aoff + e] = ma[e]; }
-                        }
-                    }
-                }
+                const float4 q = *reinterpret_cast<const float4*>(P + aoff);
                 const float qa[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (in && e >= lo && e < hi) t[k][4 * v - mis + e] = ok ? qa[e] : 0.f;
@@ -507,13 +455,7 @@ int mk_shadow_blocks(const ShadowDesc& d) {
 }
 int mk_all_shadows(const float* P, const ShadowJobs& jobs, hipStream_t s) {
     if (jobs.n <= 0) return 0;
-    hipLaunchKernelGGL(all_shadows_kernel<false>, dim3(jobs.blocks), dim3(256), 0, s, P, jobs, SgdFuse{}, (const long*)nullptr);
-    return LAUNCH_OK();
-}
-int mk_sgd_shadows(float* P, const SgdFuse& sg, const ShadowJobs& jobs, const long* gaps, int ngaps, hipStream_t s) {
-    if (jobs.n <= 0 && ngaps <= 0) return 0;
-    if (!aligned16(P, sg.g, sg.mom)) { mk_set_error("mk_sgd_shadows", "the flat buffers must be 16-byte aligned"); return -1; }
-    hipLaunchKernelGGL(all_shadows_kernel<true>, dim3(jobs.blocks + ngaps), dim3(256), 0, s, P, jobs, sg, gaps);
+    hipLaunchKernelGGL(all_shadows_kernel, dim3(jobs.blocks), dim3(256), 0, s, P, jobs);
     return LAUNCH_OK();
 }
 int mk_conv_weight_shadows(const float* w, bf16* wk, bf16* wd, int CO, int CI, hipStream_t s) {

@@ -23,6 +23,17 @@ template <> struct LnVec<1> {
     static __device__ __forceinline__ void st(float* p, const float (&o)[1]) { p[0] = o[0]; }
     static __device__ __forceinline__ void st16(bf16* p, const float (&o)[1]) { p[0] = (bf16)o[0]; }
 };
+// dropout keep-scales of a lane's VW consecutive elements (one hash word per element pair: common.h)
+template <int VW>
+__device__ __forceinline__ void ln_keep_scales(uint32_t seed, uint32_t site, uint32_t idx0, float p, float inv_keep, float (&ks)[VW]) {
+    if constexpr (VW == 4) {
+        ks[0] = ks[1] = ks[2] = ks[3] = 1.f;
+        if (p > 0.f) dropout_scale4(seed, site, idx0, p, inv_keep, ks);
+    } else {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) ks[e] = p > 0.f ? dropout_scale(seed, site, idx0 + e, p, inv_keep) : 1.f;
+    }
+}
 // lane's columns: group i (of NV) holds columns (i * 64 + lane) * VW .. + VW - 1
 // SUM (kernels.h LnSumArgs): the row is not in memory -- it is what the epilogue of a k-split GEMM would have written: the sum of sm.n fp32
 // partial products (+ bias) (x dropout) + residual, formed here in the epilogue's order of operations and stored to sm.sum_out (the backward
@@ -60,12 +71,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
                 for (int e = 0; e < VW; ++e) bs[e] = sm.bias[c + e];
             }
+            float ks[VW];
+            ln_keep_scales<VW>(seed, sm.site, (uint32_t)idx, sm.drop_p, inv_keep, ks);
 #pragma unroll
-            for (int e = 0; e < VW; ++e) {
-                float xx = acc[e] + bs[e];
-                if (sm.drop_p > 0.f) xx *= dropout_scale(seed, sm.site, (uint32_t)(idx + e), sm.drop_p, inv_keep);
-                v[i][e] = xx + rsd[e];
-            }
+            for (int e = 0; e < VW; ++e) v[i][e] = (acc[e] + bs[e]) * ks[e] + rsd[e];
             if (sm.sum_out) V::st(sm.sum_out + idx, v[i]);
             V::ld(gamma + c, gm[i]); V::ld(beta + c, bt[i]);
         }
@@ -104,7 +113,7 @@ __host__ __device__ inline int ln_rows_per_wave(int rows) { return rows >= 2048 
 template <int PT, int R, bool SUM = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, float* __restrict__ dx32,
+                                                     const float* __restrict__ rstd, float* dx32 /* SUM: may be sm.residual (in place) */,
                                                      bf16* __restrict__ dx16, float drop_p, uint32_t seed, uint32_t site,
                                                      float* __restrict__ slab, int rows, const uint32_t* __restrict__ seed_ptr, const LnSumArgs sm) {
     constexpr int E = 64 * PT, VW = PT % 4 == 0 ? 4 : 1, NV = PT / VW;
@@ -173,8 +182,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             if (dx32) V::st(dx32 + idx, o);
             if (dx16) {
                 if (drop_p > 0.f) {
+                    float ks[VW];
+                    ln_keep_scales<VW>(seed, site, (uint32_t)idx, drop_p, inv_keep, ks);
 #pragma unroll
-                    for (int e = 0; e < VW; ++e) o[e] *= dropout_scale(seed, site, (uint32_t)(idx + e), drop_p, inv_keep);
+                    for (int e = 0; e < VW; ++e) o[e] *= ks[e];
                 }
                 V::st16(dx16 + idx, o);
             }
@@ -233,13 +244,11 @@ __global__ void cast_dropout_kernel(const float* __restrict__ x, bf16* __restric
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
     const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    float ks[4] = {1.f, 1.f, 1.f, 1.f};
+    if (drop_p > 0.f) dropout_scale4(seed, site, (uint32_t)i, drop_p, inv_keep, ks);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if (i + j < n) {
-            float v = x[i + j];
-            if (drop_p > 0.f) v *= dropout_scale(seed, site, (uint32_t)(i + j), drop_p, inv_keep);
-            y[i + j] = (bf16)v;
-        }
+        if (i + j < n) y[i + j] = (bf16)(x[i + j] * ks[j]);
 }
 
 // ---------------------------------------------------------------- column sums (bias gradients)

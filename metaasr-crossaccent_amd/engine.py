@@ -246,27 +246,22 @@ class MasrEngine:
         """opt-in graph replay of repeated batch shapes (include/masr.h masr_set_step_graphs)"""
         self._l.masr_set_step_graphs(self.h, int(bool(on)))
 
-    def set_ln_fusion(self, on: bool):
-        """decoder-row LayerNorms inside their consumer GEMMs (include/masr.h masr_set_ln_fusion); default off (measured slower)"""
-        self._l.masr_set_ln_fusion(self.h, int(bool(on)))
-
     def set_split_wgrad_launches(self, on: bool):
         """the step's Linear weight gradients as two launches instead of one (include/masr.h masr_set_split_wgrad_launches; A/B, same bits)"""
         self._l.masr_set_split_wgrad_launches(self.h, int(bool(on)))
 
     def set_ksplit(self, on: bool):
-        """k-split of the decoder's long-reduction few-row GEMMs with the combine inside the next LayerNorm (include/masr.h masr_set_ksplit); default on"""
+        """k-split of the decoder's long-reduction few-row GEMMs with the combine inside the next LayerNorm (include/masr.h masr_set_ksplit).
+        Default OFF: it changes the fp32 summation order of those GEMMs, so it follows only this call, never the slot count.  The one-task-per-stream
+        loops (train.py: mono / multi interface) turn it on (+3 %); the FOMAML interface leaves it off for every --tasks_per_gpu."""
         self._l.masr_set_ksplit(self.h, int(bool(on)))
 
-    def set_fused_sgd(self, on: bool):
-        """clip_sgd_step's update inside the shadow-refresh launch (include/masr.h masr_set_fused_sgd); default off (measured slower)"""
-        self._l.masr_set_fused_sgd(self.h, int(bool(on)))
-
     def step_counters(self):
-        """{'direct', 'captured', 'replayed'}: how run_batch calls reached the GPU (kernel by kernel / graph capture / graph replay)"""
-        out = (C.c_int64 * 3)()
+        """{'direct', 'captured', 'replayed'}: how run_batch calls reached the GPU (kernel by kernel / graph capture / graph replay);
+        'ksplit_gemms': k-split GEMM launches of the last step launched or captured (0 = whole reductions: masr_set_ksplit off)"""
+        out = (C.c_int64 * 4)()
         self._l.masr_step_counters(self.h, out)
-        return {"direct": int(out[0]), "captured": int(out[1]), "replayed": int(out[2])}
+        return {"direct": int(out[0]), "captured": int(out[1]), "replayed": int(out[2]), "ksplit_gemms": int(out[3])}
 
     def last_logits(self):
         """[B, L, odim] fp32 view of the last forward's logits and gold [B, L] (int32, -1 = pad)."""

@@ -197,7 +197,7 @@ class FOMetaASRInterface(PretrainInterface):
             if hasattr(sl['engine'], 'set_concurrency'):
                 sl['engine'].set_concurrency(self.tasks_per_gpu)
             # "K task slots == the sequential run, bit for bit" must hold for every K: the k-split of the decoder's few-row GEMMs (a different
-            # fp32 summation order; the engine keeps it for a lone task only) is therefore off in this interface whatever K is
+            # fp32 summation order that pays for a lone task only; the engine's default is off) stays off in this interface whatever K is
             if hasattr(sl['engine'], 'set_ksplit'):
                 sl['engine'].set_ksplit(False)
 

@@ -24,6 +24,9 @@ def get_trainer(cls, config, paras, id2accent):
             eng = self.asr_model.engine
             eng.set_seed(getattr(self.paras, 'seed', 531) + 7919 * 64 * self.sharder.rank)      # dropout stream: one per rank
             if 'inner_optimizer_cls' not in mp:                              # multi-task or mono (:27)
+                # one task per stream: the decoder's few-row long-reduction GEMMs run k-split (masr_set_ksplit: +3 % alone on the GPU).  The
+                # FOMAML interface leaves it off for every --tasks_per_gpu so that K slots == the sequential run == N ranks, bit for bit.
+                eng.set_ksplit(True)
                 cls_name = mp['optimizer_cls']
                 if cls_name == 'noam':
                     self.asr_opt = TransformerOptimizer(FlatAdam(eng, eng.params, betas=(0.9, 0.98), eps=1e-09),

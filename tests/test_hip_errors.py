@@ -102,11 +102,11 @@ def test_ctc_lengths_outside_the_call_are_refused_by_the_kernel():
         nll, loss, grad = torch.zeros(B, device="cuda"), torch.zeros(1, device="cuda"), torch.full_like(lg, 3.0)
         tg, of, ild, tld = d(tgt), d(off), d(il), d(tl_)
         _cabi.check(L.masr_ctc_loss(P(lg), P(tg), P(of), P(ild), P(tld), T, B, Cc, 0, P(nll), P(loss), P(grad), P(work), maxS, S()))
-        return L.masr_ctc_status(S()), nll.cpu(), float(loss), grad.cpu()
+        return L.masr_ctc_status(P(work), T, B, maxS, S()), nll.cpu(), float(loss), grad.cpu(), work
 
     # ---- in_len == 0 on utterance 1: torch says inf -> 0 (zero_infinity), zero gradient; the others as torch computes them
     il = torch.tensor([24, 0, 20, 18])
-    st, nll, loss, grad = run(il)
+    st, nll, loss, grad, _ = run(il)
     lr = logits.clone().requires_grad_(True)
     ref = torch.nn.CTCLoss(blank=0, reduction="mean", zero_infinity=True)(torch.log_softmax(lr, -1), tgt, il, tl)
     ref.backward()
@@ -116,12 +116,13 @@ def test_ctc_lengths_outside_the_call_are_refused_by_the_kernel():
     # ---- in_len > T on utterance 2, negative on 0, a target wider than maxS on 3: refused, named, NaN; utterance 1 is still right
     for il_bad, tl_bad, who in ((torch.tensor([24, 22, 25, 18]), tl, 2), (torch.tensor([-1, 22, 20, 18]), tl, 0),
                                 (torch.tensor([24, 22, 20, 18]), torch.tensor([5, 3, 4, 9]), 3)):
-        st, nll, loss, grad = run(il_bad, tl_bad)
+        st, nll, loss, grad, work_bad = run(il_bad, tl_bad)
         assert st == who + 1 and b"mk_ctc_loss" in L.masr_last_error() and str(who).encode() in L.masr_last_error()
         assert np.isnan(float(nll[who])) and np.isnan(loss) and float(grad[:, who].abs().max()) == 0.0
         ok = [b for b in range(B) if b != who]
         assert all(np.isfinite(float(nll[b])) and float(nll[b]) > 0 for b in ok) and bool(torch.isfinite(grad).all())
-        assert L.masr_ctc_status(S()) == 0                                       # the mark was cleared by the read
+        # the mark lives in the call's own work buffer: a healthy call on another buffer reads 0 while this one still names its utterance
+        assert run(il)[0] == 0 and L.masr_ctc_status(P(work_bad), T, B, maxS, S()) == who + 1
     # ---- arguments the host CAN see are refused before anything is launched
     work = torch.zeros(int(L.masr_ctc_work_floats(T, B, maxS)), device="cuda")
     z = torch.zeros(B, device="cuda")

@@ -108,14 +108,16 @@ def test_edge_shapes_run_and_are_finite(B, T, ilens, olens):
     assert hyp.shape == (max(ilens) // 4, B) and int(hyp.min()) >= 0 and int(hyp.max()) < ODIM
 
 
-@pytest.mark.parametrize("idim", [80, 83])
-def test_headline_shape_against_the_reference(golden_dir, idim):
+@pytest.mark.parametrize("idim,ksplit", [(80, False), (83, False), (80, True)])
+def test_headline_shape_against_the_reference(golden_dir, idim, ksplit):
     """Element-wise pin of the BENCH shape (VERDICT r2 missing #2): fometa-hkust geometry, the reference's seed-531 initialisation,
     one B = 16 x T = 1000 batch at idim 80 / 83, dropout 0, against what the imported reference computed for it
     (tests/golden/hkust_fullsize.npz, oracle/make_goldens.py::gen_hkust_fullsize_goldens): loss within the north-star's 1e-3
     relative (measured ~1e-5), accuracy within one token, global and per-tensor gradient norms, small gradients element-wise,
     and the loss after clip 5 + the shipped inner SGD step.  The oracle run beside it (pinned to the same golden on the CPU) gives
-    the per-tensor comparison against EVERY gradient, in fp32 and with the engine's bf16 rounding points emulated."""
+    the per-tensor comparison against EVERY gradient, in fp32 and with the engine's bf16 rounding points emulated.
+    ksplit: the decoder's k-split GEMM schedule (masr_set_ksplit: what train.py runs; off = what pretrain.py --algo fomaml and the bench
+    headline run) -- BOTH schedules are pinned to the reference here, at unchanged tolerances, and the engine must report which one ran."""
     from oracle import ref_cpu
     from oracle.make_goldens import fullsize_batch
     g = np.load(golden_dir / "hkust_fullsize.npz")
@@ -125,8 +127,10 @@ def test_headline_shape_against_the_reference(golden_dir, idim):
     sd = reference_init_state_dict(cfg, ODIM)
     e = MasrEngine(cfg, ODIM, label_smoothing=0.2)
     e.load_state_dict(sd)
+    e.set_ksplit(ksplit)
     xs, il, ys, ol = fullsize_batch(idim)
     e.run_batch(xs, il, ys, ol.clone(), train=True)
+    assert (e.step_counters()["ksplit_gemms"] > 0) == ksplit, e.step_counters()      # the schedule under test is the one that ran
     e.grad_norm()
     st = e.read_stats()
     grads = {k: v.cpu() for k, v in e.state_dict(flat=e.grads).items()}

@@ -232,25 +232,30 @@ def test_conv3x3_pool_codes_and_their_backward(L, B_, H, W, CIN, COUT):
     _cabi.check(L.masr_test_conv3x3_pool_idx(P(x), P(wk), P(bias), P(out2), P(pool2), P(idx2), 1, B_, H, W, CIN, COUT, S()))
     assert torch.equal(pool2, pool) and torch.equal(idx2, idx)
     assert bool((out2.float() == 7.0).all()) or torch.equal(out2, out)  # dropped (streaming kernels) or stored (fallback), never half
-    # backward from the codes
+    # the pool + ReLU backward those codes stand for (what the dgrad / weight-gradient kernels expand while staging: _unpool) against autograd
     gp = torch.randn(B_, H2, W2, COUT, device="cuda", generator=g).bfloat16()
-    din = torch.full((B_, H, W, COUT), 5.0, device="cuda").bfloat16()
-    _cabi.check(L.masr_test_maxpool_idx_bwd(P(idx), P(gp), P(din), B_, H, W, COUT, S()))
+    din = _unpool(idx, gp, H, W)
     pre = out.float().permute(0, 3, 1, 2).clone().requires_grad_(True)  # (the map is already ReLU'd: relu'(x) = [x > 0])
     y = torch.nn.functional.max_pool2d(torch.relu(pre), 2, 2)
     y.backward(gp.float().permute(0, 3, 1, 2))
     ref = pre.grad.permute(0, 2, 3, 1)
     if torch.equal(din.float(), ref):
         return
-    # torch's CUDA max_pool2d backward breaks exact ties its own way: compare where the window has a unique maximum, and totals
+    # torch's CUDA max_pool2d backward breaks exact ties its own way: compare where the window has a unique maximum
     uniq = (win == mx.unsqueeze(-1)).sum(-1) == 1
     u = uniq.unsqueeze(-1).expand(-1, -1, -1, -1, 4).reshape(B_, H2, W2, COUT, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(B_, 2 * H2, 2 * W2, COUT)
     assert torch.equal(din.float()[:, :2 * H2, :2 * W2][u], ref[:, :2 * H2, :2 * W2][u])
-    assert bool((din.float()[:, 2 * H2:] == 0).all()) and bool((din.float()[:, :, 2 * W2:] == 0).all())
-    exp = torch.zeros(B_, H2, W2, COUT, 4, device="cuda")
-    exp.scatter_(-1, code.long().clamp(max=3).unsqueeze(-1), (gp.float() * (code < 4)).unsqueeze(-1))
-    exp = exp.reshape(B_, H2, W2, COUT, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(B_, 2 * H2, 2 * W2, COUT)
-    assert torch.equal(din.float()[:, :2 * H2, :2 * W2], exp)
+
+
+def _unpool(codes, gp, H, W):
+    """MaxPool2d(2, 2) + ReLU backward from the pool codes (window position 0..3 of the first maximum, 4 = nothing passed the ReLU): the map
+    [B][H][W][C] the dgrad / weight-gradient kernels expand in their staging -- pure indexing, exact."""
+    B_, H2, W2, C = gp.shape
+    exp = torch.zeros(B_, H2, W2, C, 4, device=gp.device, dtype=gp.dtype)
+    exp.scatter_(-1, codes.long().clamp(max=3).unsqueeze(-1), torch.where(codes < 4, gp, torch.zeros_like(gp)).unsqueeze(-1))
+    full = torch.zeros(B_, H, W, C, device=gp.device, dtype=gp.dtype)
+    full[:, :2 * H2, :2 * W2] = exp.reshape(B_, H2, W2, C, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(B_, 2 * H2, 2 * W2, C)
+    return full.contiguous()
 
 
 @pytest.mark.parametrize("B_,H,W,CIN,COUT", [(2, 10, 9, 64, 64), (1, 33, 21, 64, 128), (2, 40, 20, 128, 128), (1, 21, 48, 128, 128), (1, 17, 80, 64, 64)])
@@ -272,15 +277,14 @@ def test_conv3x3_wgrad(L, B_, H, W, CIN, COUT):
 @pytest.mark.parametrize("B_,H,W,C", [(2, 10, 9, 64), (2, 40, 20, 128), (1, 21, 47, 128), (1, 33, 80, 64), (3, 16, 32, 64)])
 def test_conv3x3_wgrad_from_pooled_gradient(L, B_, H, W, C):
     """ConvWgradArgs::dy_pooled: the weight-gradient kernel of the conv in FRONT of a MaxPool2d(2, 2) (mono_transformer_torch.py:49-60) expands
-    pooled gradient + pool codes itself.  Same bits as staging the map that masr_test_maxpool_idx_bwd writes (the LDS tile is identical);
+    pooled gradient + pool codes itself.  Same bits as staging the expanded map (_unpool; the LDS tile is identical);
     odd H / W: the cropped last row / column gets no gradient; the bias gradient (summed in another order) within rounding."""
     g = torch.Generator(device="cuda").manual_seed(C + H + W)
     x = torch.randn(B_, H, W, C, device="cuda", generator=g).bfloat16()
     H2, W2 = H // 2, W // 2
     dyp = torch.randn(B_, H2, W2, C, device="cuda", generator=g).bfloat16()
     codes = torch.randint(0, 5, (B_, H2, W2, C), device="cuda", generator=g).to(torch.uint8)           # 4 = nothing passed the ReLU
-    dy = torch.full((B_, H, W, C), 9.0, device="cuda").bfloat16()
-    _cabi.check(L.masr_test_maxpool_idx_bwd(P(codes), P(dyp), P(dy), B_, H, W, C, S()))
+    dy = _unpool(codes, dyp, H, W)
     n = int(L.masr_test_conv3x3_wgrad_slab_floats(B_, H, W, C, C))
     slab = torch.zeros(n, device="cuda")
     dw0 = torch.zeros(C, C, 3, 3, device="cuda"); dw1 = torch.zeros_like(dw0); db = torch.zeros(C, device="cuda")
@@ -295,13 +299,12 @@ def test_conv3x3_wgrad_from_pooled_gradient(L, B_, H, W, C):
 def test_conv3x3_dgrad_from_pooled_gradient(L, B_, H, W):
     """ConvArgs::in_pooled: the masked 128 <- 128 dgrad behind the second MaxPool2d (mono_transformer_torch.py:57-58) builds its patches from
     the pooled gradient + pool codes (three producer waves expand the 2 x 2 windows while staging).  Same bits as the launch that reads the
-    map masr_test_maxpool_idx_bwd writes; odd H / W: the cropped last row / column carries no gradient."""
+    expanded map (_unpool); odd H / W: the cropped last row / column carries no gradient."""
     g = torch.Generator(device="cuda").manual_seed(7 * H + W)
     H2, W2 = H // 2, W // 2
     dyp = torch.randn(B_, H2, W2, 128, device="cuda", generator=g).bfloat16()
     codes = torch.randint(0, 5, (B_, H2, W2, 128), device="cuda", generator=g).to(torch.uint8)
-    dy = torch.full((B_, H, W, 128), 9.0, device="cuda").bfloat16()
-    _cabi.check(L.masr_test_maxpool_idx_bwd(P(codes), P(dyp), P(dy), B_, H, W, 128, S()))
+    dy = _unpool(codes, dyp, H, W)
     mask = torch.randn(B_, H, W, 128, device="cuda", generator=g).bfloat16()
     words = _sign_words(mask).to(torch.int32)
     wd = (torch.randn(128, 128, 3, 3, device="cuda", generator=g) * 0.05).bfloat16()
@@ -329,8 +332,7 @@ def test_conv1_wgrad_fused_from_pooled_gradient(L, B_, H, W):
     H2, W2 = H // 2, W // 2
     dyp = torch.randn(B_, H2, W2, 64, device="cuda", generator=g).bfloat16()
     codes = torch.randint(0, 5, (B_, H2, W2, 64), device="cuda", generator=g).to(torch.uint8)
-    dy = torch.full((B_, H, W, 64), 9.0, device="cuda").bfloat16()
-    _cabi.check(L.masr_test_maxpool_idx_bwd(P(codes), P(dyp), P(dy), B_, H, W, 64, S()))
+    dy = _unpool(codes, dyp, H, W)
     x1 = torch.randn(B_, H, W, device="cuda", generator=g)
     keep = torch.rand(B_, H, W, 64, device="cuda", generator=g) > 0.4
     words = (keep.to(torch.int64) << torch.arange(64, device="cuda").view(1, 1, 1, 64)).sum(-1)          # bit c = channel c passed conv1's ReLU
@@ -576,6 +578,11 @@ def test_dropout_keep_rate_and_scale_per_site():
     a, b = masks[(0.2, 1)].float(), masks[(0.2, 2)].float()
     corr = float(((a - a.mean()) * (b - b.mean())).mean() / (a.std() * b.std()))
     assert abs(corr) < 5e-3, "masks of two sites are correlated"
+    # one hash word decides an element PAIR (low / high 16 bits, csrc/common.h): neighbours inside a pair and across pairs stay independent
+    for lag in (1, 2):
+        x, y = a[:-lag:2] if lag == 1 else a[:-lag], a[lag::2] if lag == 1 else a[lag:]
+        x, y = x[:min(len(x), len(y))], y[:min(len(x), len(y))]
+        assert abs(float(((x - x.mean()) * (y - y.mean())).mean() / (x.std() * y.std()))) < 5e-3, f"neighbouring elements (lag {lag}) are correlated"
     o2 = torch.empty(n, device="cuda")
     _cabi.check(L.masr_test_dropout_mask(1235, 1, n, 0.2, P(o2), S()))
     c = (o2 > 0).float()

@@ -1,5 +1,5 @@
 """CPU tests of the host mirror (no GPU): data path vs goldens captured from the reference, Noam schedule,
-init replay, masks, metric, parameter table, and that libmasr.so exports every symbol of include/masr.h."""
+init replay, masks, metric, parameter table, and that libmasr.so exports every symbol of include/masr.h and include/masr_test.h."""
 import ctypes
 import random
 import re
@@ -23,12 +23,16 @@ HK = dict(idim=83, nheads=8, d_model=512, d_inner=2048, dropout=0.1, pos_dropout
 
 
 def test_cabi_exports_every_declared_symbol():
-    """include/masr.h <-> libmasr.so <-> ctypes table (load + symbol lookup only, no compute)."""
-    hdr = (REPO / "include" / "masr.h").read_text()
-    declared = set(re.findall(r"\b(masr_[a-z0-9_]+)\s*\(", hdr))
+    """include/masr.h (operator API) + include/masr_test.h (test-only entry points) <-> libmasr.so <-> ctypes table (load + symbol
+    lookup only, no compute); the operator header holds no test entry point and the test header nothing else."""
+    api = set(re.findall(r"\b(masr_[a-z0-9_]+)\s*\(", (REPO / "include" / "masr.h").read_text()))
+    tst = set(re.findall(r"\b(masr_[a-z0-9_]+)\s*\(", (REPO / "include" / "masr_test.h").read_text()))
+    assert not any(n.startswith("masr_test_") for n in api), sorted(n for n in api if n.startswith("masr_test_"))
+    assert all(n.startswith("masr_test_") for n in tst), sorted(n for n in tst if not n.startswith("masr_test_"))
+    declared = api | tst
     lib = ctypes.CDLL(str(_cabi.LIB_PATH))
     for name in sorted(declared):
-        assert hasattr(lib, name), f"{name} declared in masr.h but not exported"
+        assert hasattr(lib, name), f"{name} declared in include/*.h but not exported"
     assert declared == set(_cabi.EXPORTS), declared ^ set(_cabi.EXPORTS)
     assert _cabi.lib().masr_version() >= 1
 

@@ -40,7 +40,7 @@ bl = glob.glob(str(g / "prof_blstm/**/*kernel_stats.csv"), recursive=True)
 if bl:
     shutil.copy(bl[0], out / f"{tag}_blstm_kernel_stats.csv")
     summary(bl[0], 23, "rocprofv3 --kernel-trace --stats -- python3 tools/bench_blstm.py --steps 20 --warm 3  (MI355X; BASELINE configs[0]: BLSTM-CTC training "
-                       "step, B = 8 x 400 frames, 3 x BLSTM-P(360); the CTC lattice = ctc_kernel, the recurrence = lstm_fwd_step / lstm_bwd_step)",
+                       "step, B = 8 x 400 frames, 3 x BLSTM-P(360); the CTC lattice = ctc_lse / ctc_sweep / ctc_grad, the recurrence = lstm_fwd_rec / lstm_bwd_rec: one resident launch per layer and pass)",
             out / f"{tag}_blstm_kernel_stats.txt")
     if (g / "blstm.json").exists():
         shutil.copy(g / "blstm.json", out / f"{tag}_blstm.json")

@@ -5,4 +5,4 @@ out = subprocess.run([sys.executable, "bench.py", "--steps", "10", "--warmup", "
 d = json.loads(out.strip().splitlines()[-1])
 k = d["kernel_ms_per_step"]
 want = sys.argv[1:] or list(k)
-print({s: round(k[s] * 1e3, 1) for s in want}, "us;", "single", round(d["single_task"]["value"]), "4-slot", round(d["value"]))
+print({s: round(k[s] * 1e3, 1) for s in want}, "us;", "single", round(d["single_task_fomaml"]["value"]), "4-slot", round(d["value"]))
