@@ -13,7 +13,6 @@
 #include "common.h"
 #include "kernels.h"
 #include "folds.h"
-#include <cstdlib>
 
 namespace {
 
@@ -57,79 +56,110 @@ __device__ __forceinline__ s16x2 lane_xor8(s16x2 v) { return __builtin_bit_cast(
 // OR-ed together by two DPP moves; the lanes with (cg & 3) < 2 then store the segment's 32 dwords (128 contiguous bytes).
 // (Tried instead: the patch wave of conv2's forward launch derives the words from the patches it streams -- 32 LDS reads + ~500
 // VALU per tile on a wave that shares its SIMD with an MFMA wave: conv2 forward 93 -> 133 us.)
-__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, bf16* __restrict__ out,
-                                                        int B, int H, int W, int cstride, unsigned* __restrict__ bits) {
-    // one launch = 64 output channels of a map with `cstride` channels (w, bias, out pre-offset by the caller).
-    // The launch is bound by vector-memory wave-instructions (~70 cycles each at the CU's one texture addresser; measured:
-    // loads + arithmetic 45 us, arithmetic + stores 32 us, everything 66 us with 2 loads + 1 store per 8 pixels), so a wave
-    // takes a 16-pixel row segment per step with ONE load -- its 3 x 18 input window, one float per lane -- and hands the
-    // taps round by lane permutes; thread = (pixel pair, group of 8 channels), the 72 weights + 8 biases stay in registers.
+// Round 6: the CIN = 1 layer on the fp32-input MFMA (v_mfma_f32_16x16x4_f32: exact fp32, a k-ordered fmaf chain -- the precision policy keeps
+// this layer in fp32).  A 16-pixel row segment is ONE product  D^T[cout][pixel] = W[cout][tap] X^T[tap][pixel]  per 16 output channels: four
+// channel blocks x three tap groups (taps 0-3, 4-7, 8 + zeros) = 12 MFMAs, the bias as the C operand of the first -- the summation order
+// (bias, tap 0 .. 8) is that of the vector-ALU kernel this replaces, so the bits are too.  The rows of block j are ASSIGNED to channels
+// 16 (i >> 2) + 4 j + (i & 3): a lane (pixel p = lane & 15, q = lane >> 4) then ends with the 16 consecutive channels 16 q .. 16 q + 15 of its
+// pixel = two 16-byte stores and one 16-bit piece of the pixel's ReLU sign word.  The window (3 x 18 floats) is one load per segment, the taps
+// come by lane permutes.
+// What bounded the launch (55-60 us for 164 MB of output, with the vector ALU or the MFMA alike) was not arithmetic: vector-memory operations
+// retire in order, so a segment's window load waited for the write acknowledgements of the previous segment's stores -- one store round trip +
+// one load round trip per segment and wave.  Here every access is a BUFFER access whose out-of-image lanes carry an offset past the
+// descriptor's end (loads return 0 = the zero padding, stores are dropped): no branch around a memory instruction, so the compiler counts its
+// waits, and the window of the NEXT segment is requested before the current one's stores.
+__global__ __launch_bounds__(256) void conv1_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, bf16* __restrict__ out,
+                                                             int B, int H, int W, int cstride, unsigned short* __restrict__ bits) {
     const int lane = threadIdx.x & 63;
-    const int pg = lane >> 3, cg = lane & 7;
-    typedef __attribute__((ext_vector_type(2))) float f32x2;
-    f32x2 wr[4][9], br[4];                                 // channel pairs: the 72 FMAs per pixel issue as 36 v_pk_fma_f32
+    const int p = lane & 15, q = lane >> 4;
+    const unsigned npix = (unsigned)B * H * W, OOB = 0xFFFFFFF0u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, npix * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out, 0, npix * (unsigned)cstride * 2u, 0x00020000);     // (< 4 GB: checked by the launcher)
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(bits, 0, bits ? npix * 8u : 0u, 0x00020000);
+    float wa[4][3];
+    f32x4 bi[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        br[j] = f32x2{bias[cg * 8 + 2 * j], bias[cg * 8 + 2 * j + 1]};
+        const int co = 16 * (p >> 2) + 4 * j + (p & 3);           // A operand: row i = lane & 15, k = lane >> 4
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) wr[j][tap] = f32x2{w[(cg * 8 + 2 * j) * 9 + tap], w[(cg * 8 + 2 * j + 1) * 9 + tap]};
+        for (int g = 0; g < 3; ++g) { const int tap = 4 * g + q; wa[j][g] = tap < 9 ? w[co * 9 + tap] : 0.f; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bi[j][r] = bias[16 * q + 4 * j + r];      // C / D: rows 4 q + r of block j
     }
-    const int nseg = (W + 15) / 16, total = B * H * nseg;  // 16-pixel segments (a segment never crosses a row)
-    const int gstride = gridDim.x * 4;
-    const int wrow = lane / 18, wcol = lane % 18;          // window element this lane loads (lanes 0..53)
-    for (int sg = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); sg < total; sg += gstride) {
-        const int row = sg / nseg, d0 = (sg - row * nseg) * 16, t = row % H;
-        int part[2] = {0, 0};                              // this thread's sign byte of its two pixels, at its place in the half-word
-        float wv = 0.f;
-        {
-            const int tt = t + wrow - 1, dd = d0 + wcol - 1;
-            if (lane < 54 && tt >= 0 && tt < H && dd >= 0 && dd < W) wv = x[(long)(row + wrow - 1) * W + dd];
-        }
+    int src[3];                                                   // window element of tap 4 g + q for pixel p (tap >= 9: the centre, times a zero weight)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int px = pg * 2 + k;
-            float xv[9];
+    for (int g = 0; g < 3; ++g) { const int tap = 4 * g + q < 9 ? 4 * g + q : 4; src[g] = (tap / 3) * 18 + p + tap % 3; }
+    const int nseg = (W + 15) / 16, total = B * H * nseg;
+    const int wrow = lane / 18, wcol = lane % 18;
+    // every wave takes ONE contiguous run of segments and steps (row of the [B * H] row list, frame t, segment sx of the row) by addition:
+    // a strided walk paid two integer divisions per segment on the scalar unit the CU's four SIMDs share
+    const int nwaves = gridDim.x * 4, per = (total + nwaves - 1) / nwaves;
+    const int first = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * per);
+    const int last = first + per < total ? first + per : total;
+    struct Seg { int sg, row, t, sx; };
+    auto advance = [&](Seg& g) {
+        ++g.sg;
+        if (++g.sx == nseg) { g.sx = 0; ++g.row; if (++g.t == H) g.t = 0; }
+    };
+    const int woff = (wrow - 1) * W + wcol - 1;                   // this lane's window element relative to (row, d0)
+    const unsigned lane_oo = ((unsigned)p * cstride + 16u * q) * 2u, lane_bo = (unsigned)p * 8u + 2u * q;
+    auto window = [&](const Seg& g) -> float {                    // 0 outside the image / the run (buffer load past the descriptor's end)
+        const int tt = g.t + wrow - 1, dd = g.sx * 16 + wcol - 1;
+        const bool ok = g.sg < last && lane < 54 && (unsigned)tt < (unsigned)H && (unsigned)dd < (unsigned)W;
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ok ? (unsigned)(g.row * W + g.sx * 16 + woff) * 4u : OOB, 0, 0));
+    };
+    Seg cur;
+    cur.sg = first; cur.row = first / nseg; cur.sx = first - cur.row * nseg; cur.t = cur.row % H;
+    float wv = window(cur);
+    // (the first window is waited for HERE: merged with the loop's back edge -- window complete, three stores pending -- a pending load at
+    // the loop's entry makes the compiler wait vmcnt(0) at the top of every iteration)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0)
+    while (cur.sg < last) {
+        Seg nxt = cur;
+        advance(nxt);
+        const float wnext = window(nxt);                          // in flight under this segment's MFMAs and in FRONT of its stores
+        float xb[3];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) xv[tap] = __shfl(wv, (tap / 3) * 18 + px + tap % 3);
-            bf16x8 o;
+        for (int g = 0; g < 3; ++g) xb[g] = __shfl(wv, src[g]);
+        f32x4 acc[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x2 a = br[j];
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][0], xb[0], bi[j], 0, 0, 0);
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) a = __builtin_elementwise_fma(wr[j][tap], f32x2{xv[tap], xv[tap]}, a);
-                o[2 * j] = (bf16)fmaxf(a[0], 0.f);
-                o[2 * j + 1] = (bf16)fmaxf(a[1], 0.f);
+        for (int g = 1; g < 3; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][g], xb[g], acc[j], 0, 0, 0);
+        // bf16 first (v_cvt_pk_bf16_f32), ReLU on the packed halves (a negative bf16 is a negative 16-bit integer: v_pk_max_i16 with 0), sign
+        // flags as v_pk_min_u16(half, 1): 8 + 8 + 8 + 8 instructions (asm: hipcc scalarises the packed forms of this chain)
+        typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
+        u4_t o[2];
+        unsigned e = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                unsigned dw, fl;
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(dw) : "v"(acc[j][2 * h]), "v"(acc[j][2 * h + 1]));
+                asm("v_pk_max_i16 %0, %1, %2" : "=v"(dw) : "v"(dw), "s"(0u));
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(fl) : "v"(dw), "s"(0x00010001u));
+                o[j >> 1][2 * (j & 1) + h] = dw;                  // channels 16 q + 4 j + 2 h, + 1
+                e |= fl << (4 * j + 2 * h);                       // flags at bits 4 j + 2 h and 16 + 4 j + 2 h
             }
-            const int d = d0 + px;
-            if (d < W) st8(out + ((long)row * W + d) * cstride + cg * 8, o);
-            if (bits) {                                    // (uniform) per 16-bit half min(max(v, 0), 1) = 1 for a positive, non-zero bf16
-                typedef __attribute__((ext_vector_type(2))) short s2_t;
-                typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
-                const u4_t ov = __builtin_bit_cast(u4_t, o);
-                unsigned e = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned dw = ov[j];             // (copy: bit_cast straight from a vector element reads element 0, clang 22)
-                    const s2_t f = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(s2_t, dw), s2_t{0, 0}), s2_t{1, 1});
-                    e |= __builtin_bit_cast(unsigned, f) << (2 * j);       // flags at bits 2j and 16 + 2j
-                }
-                part[k] = (int)(((e | e >> 15) & 0xFFu) << (8 * (cg & 3)));
-            }
-        }
-        if (bits) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                part[k] |= __builtin_amdgcn_mov_dpp(part[k], 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
-                part[k] |= __builtin_amdgcn_mov_dpp(part[k], 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]: the quad's four bytes in every lane
-            }
-            const int kk = cg & 1, px = pg * 2 + kk;        // lanes cg = 0, 1 (channels 0..31) and 4, 5 (32..63) of a pixel pair store
-            if ((cg & 3) < 2 && d0 + px < W) bits[((long)row * W + d0 + px) * 2 + (cg >> 2)] = (unsigned)(kk ? part[1] : part[0]);
-        }
+        e = (e | e >> 15) & 0xFFFFu;                              // bit c = channel 16 q + c passed the ReLU
+        // addresses without a vector multiply (the compiler branches around one): segment base on the scalar unit + this lane's fixed offset
+        const unsigned segpix = (unsigned)(cur.row * W + cur.sx * 16);
+        const bool in = cur.sx * 16 + p < W;
+        const unsigned oo = in ? segpix * (unsigned)cstride * 2u + lane_oo : OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(o[0], ro, oo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o[1], ro, oo, 16, 0);
+        // (a null `bits` has an empty descriptor: the store is dropped)
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)e, rb, in ? segpix * 8u + lane_bo : OOB, 0, 0);
+        wv = wnext;
+        cur = nxt;
     }
 }
 
-constexpr int C1_PIX = 2048;   // pixels per block in conv1 wgrad
+constexpr int C1_PIX = 512;    // pixels per block in conv1 wgrad (2048 until round 5: the BLSTM bench shape then ran on 130 workgroups, half the CUs with one each -- 77 us per launch)
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const bf16* __restrict__ dy,
                                                           float* __restrict__ slab, int B, int H, int W, int cstride) {
     const long P = (long)B * H * W;
@@ -211,188 +241,11 @@ __device__ __forceinline__ bf16x8 frag_rm(const bf16* tile, int r0, int lane) {
     return f;
 }
 
-// ------------------------------------------------------------------ patch-tiled 3x3 (fwd and dgrad), v2
-// One workgroup = a TH x 16 tile of output pixels of one image, all COUT channels.  The (TH+2) x 18 input patch
-// (64-channel slab) is brought into LDS ONCE and all 9 taps read their A fragments straight out of it (no im2col
-// re-fetch: HBM/L2 traffic per output pixel drops from 9x to ~1.3x the input bytes); the per-tap weight slice
-// [COUT][64] is double-buffered through registers.  4 waves, wave w owns TH/4 pixel rows x all COUT.
-// LDS: patch pixel / weight row stride 80 elements (160 B), conflict-free for the four 16-lane groups of ds_read_b128.
-// TW = 8 (tile 8 pixels wide, an MFMA pixel tile = 2 rows x 8 columns) exists for maps whose width is not a multiple
-// of 16: the 40-column maps behind the first pool would waste 8 of every 48 columns (17 % of the MFMAs) with TW = 16.
-template <int CIN, int COUT, int TH, int TW = 16>
-__global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a) {
-    constexpr int PW = TW + 2, PH = TH + 2, RPT = 16 / TW;     // RPT = pixel rows per 16-pixel MFMA tile
-    constexpr int PS = 80;                                 // patch pixel stride (elements): 160 B is conflict-free for the
-    constexpr int WS = 80;                                 // ds_read_b128 lane groups (144 B measured 39 % conflict cycles)
-    constexpr int MF = TH * TW / 64, NF = COUT / 16;
-    constexpr int KTOT = 9 * CIN, NSLAB = CIN / 64;
-    constexpr int PATCH_EL = PH * PW * PS, W_EL = COUT * WS;
-    constexpr int OUT_EL = TH * TW * (COUT + 8);
-    constexpr int LDS_EL = (PATCH_EL + 2 * W_EL) > OUT_EL ? (PATCH_EL + 2 * W_EL) : OUT_EL;
-    constexpr int WCH = COUT * 8 / 256;                    // weight chunks per thread per step
-    __shared__ __attribute__((aligned(16))) bf16 lds[LDS_EL];
-    bf16* patch = lds;
-    bf16* wbuf0 = lds + PATCH_EL;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int H = a.H, W = a.W;
-    const int d0 = blockIdx.x * TW, t0 = blockIdx.y * TH, b = blockIdx.z;
-    const bf16* in_b = a.in + (long)b * H * W * CIN;
-
-    f32x4 acc[MF][NF];
-#pragma unroll
-    for (int i = 0; i < MF; ++i)
-#pragma unroll
-        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    bf16x8 rw[WCH];
-    auto load_w = [&](int slab, int tap) {
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) {
-            const int c = tid + i * 256;
-            rw[i] = ld8(a.wk + (long)(c >> 3) * KTOT + tap * CIN + slab * 64 + (c & 7) * 8);
-        }
-    };
-    auto store_w = [&](bf16* dst) {
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) {
-            const int c = tid + i * 256;
-            st8(dst + (c >> 3) * WS + (c & 7) * 8, rw[i]);
-        }
-    };
-
-    const int kq = (lane >> 4) * 8, rr = lane & 15;
-    int step = 0;
-    for (int slab = 0; slab < NSLAB; ++slab) {
-        __syncthreads();                                   // previous slab's readers are done with patch / weights
-        {   // all patch loads are issued before the first LDS store (one round trip instead of NPCH dependent ones)
-            constexpr int NPCH = (PH * PW * 8 + 255) / 256;
-            bf16x8 pv[NPCH];
-#pragma unroll
-            for (int i = 0; i < NPCH; ++i) {
-                const int c = tid + i * 256;
-                const int pix = c >> 3, ch = (c & 7) * 8;
-                const int pi = pix / PW, pj = pix % PW;
-                const int t = t0 + pi - 1, d = d0 + pj - 1;
-                bf16x8 v = zero8();
-                if (c < PH * PW * 8 && t >= 0 && t < H && d >= 0 && d < W) v = ld8(in_b + ((long)t * W + d) * CIN + slab * 64 + ch);
-                pv[i] = v;
-            }
-#pragma unroll
-            for (int i = 0; i < NPCH; ++i) {
-                const int c = tid + i * 256;
-                if (c < PH * PW * 8) st8(patch + (c >> 3) * PS + (c & 7) * 8, pv[i]);
-            }
-        }
-        load_w(slab, 0);
-        store_w(wbuf0 + (step & 1) * W_EL);
-        __syncthreads();
-        for (int tap = 0; tap < 9; ++tap, ++step) {
-            const bf16* wcur = wbuf0 + (step & 1) * W_EL;
-            if (tap + 1 < 9) load_w(slab, tap + 1);
-            // keep the weight prefetch HERE: hipcc otherwise sinks the global loads to just before their LDS store,
-            // exposing one L2 round trip per tap (9 per slab, longer than the tap's 32 MFMAs)
-            __builtin_amdgcn_sched_barrier(0);
-            const int dy = tap / 3, dx = tap % 3;
-#pragma unroll
-            for (int kc = 0; kc < 2; ++kc) {
-                bf16x8 af[MF], bfr[NF];
-#pragma unroll
-                for (int i = 0; i < MF; ++i)
-                    af[i] = ld8(patch + (((wave * MF + i) * RPT + rr / TW + dy) * PW + rr % TW + dx) * PS + kc * 32 + kq);
-#pragma unroll
-                for (int j = 0; j < NF; ++j) bfr[j] = ld8(wcur + (j * 16 + rr) * WS + kc * 32 + kq);
-#pragma unroll
-                for (int i = 0; i < MF; ++i)
-#pragma unroll
-                    for (int j = 0; j < NF; ++j) acc[i][j] = mma16(bfr[j], af[i], acc[i][j]);   // weights as A: a lane ends up with 4 consecutive channels
-            }
-            if (tap + 1 < 9) store_w(wbuf0 + ((step + 1) & 1) * W_EL);
-            __syncthreads();
-        }
-    }
-
-    // epilogue: bias / ReLU in registers -> bf16 tile in LDS [pixel][COUT+8] -> coalesced 16-byte stores (+ ReLU mask)
-    constexpr int OS = COUT + 8;
-    bf16* otile = lds;
-    // (operands are swapped in the MFMA -- weights are the A operand -- so acc[i][j][r] is pixel lane&15 of pixel tile i,
-    // channel j*16 + 4*(lane>>4) + r: four consecutive channels per lane = one 8-byte LDS store instead of four 2-byte ones)
-    const int cq = 4 * (lane >> 4);
-#pragma unroll
-    for (int j = 0; j < NF; ++j) {
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bv[r] = a.bias[j * 16 + cq + r];
-        }
-#pragma unroll
-        for (int i = 0; i < MF; ++i) {
-            bf16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc[i][j][r] + bv[r];
-                if (a.relu) v = fmaxf(v, 0.f);
-                o[r] = (bf16)v;
-            }
-            *reinterpret_cast<bf16x4*>(otile + ((wave * MF + i) * 16 + rr) * OS + j * 16 + cq) = o;
-        }
-    }
-    __syncthreads();
-    if (a.pool_out) {
-        // fused MaxPool2d(2, 2) (floor): the ReLU'd tile is in LDS, tile origin and size are even -> each pooled pixel's
-        // 2 x 2 window lies inside this tile; saves the separate pool launch and its re-read of the full-resolution map
-        const int H2 = H / 2, W2 = W / 2;
-        constexpr int NPOOL = (TH / 2) * (TW / 2) * (COUT / 8);
-#pragma unroll
-        for (int i = 0; i < (NPOOL + 255) / 256; ++i) {
-            const int c = tid + i * 256;
-            const int pp = c / (COUT / 8), ch = (c % (COUT / 8)) * 8;
-            const int pr = pp / (TW / 2), pc = pp % (TW / 2);
-            const int t2 = t0 / 2 + pr, d2 = d0 / 2 + pc;
-            if (c < NPOOL && t2 < H2 && d2 < W2) {
-                const bf16* o00 = otile + ((2 * pr) * TW + 2 * pc) * OS + ch;
-                const bf16x8 v00 = ld8(o00), v01 = ld8(o00 + OS), v10 = ld8(o00 + TW * OS), v11 = ld8(o00 + TW * OS + OS);
-                bf16x8 o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    o[j] = (bf16)fmaxf(fmaxf((float)v00[j], (float)v01[j]), fmaxf((float)v10[j], (float)v11[j]));
-                st8(a.pool_out + (((long)b * H2 + t2) * W2 + d2) * COUT + ch, o);
-            }
-        }
-    }
-    bf16* out_b = a.out + (long)b * H * W * COUT;
-    const bf16* mask_b = a.mask ? a.mask + (long)b * H * W * COUT : nullptr;
-    constexpr int NOCH = TH * TW * (COUT / 8) / 256;
-    bf16x8 ov[NOCH], mv[NOCH];
-#pragma unroll
-    for (int i = 0; i < NOCH; ++i) {
-        const int c = tid + i * 256;
-        const int pix = c / (COUT / 8), ch = (c % (COUT / 8)) * 8;
-        const int t = t0 + pix / TW, d = d0 + pix % TW;
-        ov[i] = ld8(otile + pix * OS + ch);
-        if (mask_b && t < H && d < W) mv[i] = ld8(mask_b + ((long)t * W + d) * COUT + ch);
-    }
-#pragma unroll
-    for (int i = 0; i < NOCH; ++i) {
-        const int c = tid + i * 256;
-        const int pix = c / (COUT / 8), ch = (c % (COUT / 8)) * 8;
-        const int t = t0 + pix / TW, d = d0 + pix % TW;
-        bf16x8 v = ov[i];
-        if (t < H && d < W) {
-            if (mask_b) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) if (!((float)mv[i][k] > 0.f)) v[k] = (bf16)0.f;
-            }
-            st8(out_b + ((long)t * W + d) * COUT + ch, v);
-        }
-    }
-}
-
 // ------------------------------------------------------------------ streaming 3x3 (fwd and dgrad), v3
-// Phase timing of the patch kernel above (tools/prof_conv_phases.py) shows a workgroup spends a quarter of its life
-// waiting for its input patch, a quarter pushing its output tile out and a third in the MFMA loop, and the one other
-// workgroup on the CU is rarely in the complementary phase.  This kernel keeps the tile geometry and the MFMA loop
-// and takes the memory phases off the MFMA waves' timeline:
+// Phase timing of the patch-per-workgroup kernel this replaced (one TH x 16 tile per workgroup, patch in LDS once, weights through registers;
+// deleted in round 6 with its last caller) showed a workgroup spending a quarter of its life waiting for its input patch, a quarter pushing
+// its output tile out and a third in the MFMA loop, with the one other workgroup on the CU rarely in the complementary phase.  This kernel
+// keeps that tile geometry and MFMA loop and takes the memory phases off the MFMA waves' timeline:
 //   * persistent workgroups (one per CU) walk the tiles; a stage = (tile, 64-channel input slab)
 //   * 6 waves: waves 0-3 only read LDS, issue MFMAs and store their accumulators; wave 4 streams the per-tap weight slices
 //     and wave 5 the input patches, both by LDS-DMA (global_load_lds, no VGPR staging).  vmcnt is per wave and counts
@@ -782,11 +635,12 @@ __global__ __launch_bounds__(UNPOOL ? 512 : 384) void conv3x3_stream_kernel(Conv
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
         const int d0 = tx * TW, t0 = ty * TH;
         const int tl = t0 + prow0, dl = d0 + pcol0;        // this lane's pixel of pixel tile 0
-        const unsigned voff = (unsigned)((tl * W + dl) * COUT + q * 8) * 2u;
-        char* out_b = reinterpret_cast<char*>(a.out) + (long)b * H * W * COUT * 2;
+        const int CS = a.out_cstride ? a.out_cstride : COUT;      // channels per pixel of the output map (this launch: out_coff .. + COUT)
+        const unsigned voff = (unsigned)((tl * W + dl) * CS + a.out_coff + q * 8) * 2u;
+        char* out_b = reinterpret_cast<char*>(a.out) + (long)b * H * W * CS * 2;
         auto row_ok = [&](int i) { return tl + i * RPT < H && dl < W; };
-        auto row_off = [&](int i) { return voff + (unsigned)(i * RPT) * (unsigned)(W * COUT * 2); };
-        const char* mask_b = MASK == 1 ? reinterpret_cast<const char*>(a.mask) + (long)b * H * W * COUT * 2 : nullptr;
+        auto row_off = [&](int i) { return voff + (unsigned)(i * RPT) * (unsigned)(W * CS * 2); };
+        const char* mask_b = MASK == 1 ? reinterpret_cast<const char*>(a.mask) + (long)b * H * W * CS * 2 : nullptr;
         u32x4 mk[MASK == 1 ? MF : 1][MASK == 1 ? NH : 1]; // ReLU mask of this lane's outputs, requested three taps before the epilogue
         unsigned mb[MASK == 2 ? MF : 1];                  // ... as sign bits: this lane's dword of its pixel's four
         const unsigned* bits_b = MASK == 2 ? reinterpret_cast<const unsigned*>(a.mask_bits) + (((long)b * H + tl) * W + dl) * 4 + q : nullptr;
@@ -1608,7 +1462,7 @@ __global__ __launch_bounds__(UNPOOL ? 512 : 320) void conv3x3_resw_w1x_kernel(Co
 constexpr int W2_PS = 80, W2_LDY = 80;   // 160-B rows: tr-reads conflict-free
 constexpr int W2_TOTAL_WG = 256;    // one persistent workgroup per CU (see mk_conv3x3_wgrad)
 
-// W2_TW: tile width in pixels (16, or 8 for maps whose width pads badly to 16 -- see conv3x3_patch_kernel); tile = 128 pixels
+// W2_TW: tile width in pixels (16, or 8 for maps whose width pads badly to 16); tile = 128 pixels
 // POOLED: the dy tile comes from ConvWgradArgs::dy_pooled + pool_idx: a thread fetches ONE pooled cell x 8 channels (16 B + 8 B of codes) and
 // stages the four positions of its window (4 + 0 instead of 4 x 16-byte loads per thread and tile)
 template <int CIN, int COUT, int W2_TW, bool POOLED = false>
@@ -1960,15 +1814,21 @@ __global__ void maxpool_idx_kernel(const bf16* __restrict__ in, uint8_t* __restr
 
 }  // namespace
 
-// workgroups of 4 waves stride over the 16-pixel row segments
-static long conv1_grid(int B, int H, int W) {
+static int conv_ncu();
+// conv1 forward: exactly the workgroups that are resident together, every wave taking one contiguous run of the 16-pixel row segments
+static long conv1_mfma_grid(int B, int H, int W) {
+    static const int resident = [] {
+        int per_cu = 0;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1_fwd_mfma_kernel, 256, 0);
+        return conv_ncu() * (per_cu > 0 ? per_cu : 4);
+    }();
     const long blocks = ((long)B * H * ((W + 15) / 16) + 3) / 4;
-    return blocks < 2048 ? blocks : 2048;
+    return blocks < resident ? blocks : resident;
 }
 int mk_conv1_fwd(const float* x, const float* w, const float* bias, bf16* out, int B, int H, int W, hipStream_t s, unsigned long long* relu_bits) {
     const long P = (long)B * H * W;
-    if (P >= (1L << 31) - 65536) { mk_set_error("mk_conv1_fwd", "map too large"); return -1; }
-    hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)conv1_grid(B, H, W)), dim3(256), 0, s, x, w, bias, out, B, H, W, 64, reinterpret_cast<unsigned*>(relu_bits));
+    if (P * 64 * 2 >= (1L << 32) - 65536) { mk_set_error("mk_conv1_fwd", "map too large (the output is addressed through one 4 GB buffer descriptor)"); return -1; }
+    hipLaunchKernelGGL(conv1_fwd_mfma_kernel, dim3((unsigned)conv1_mfma_grid(B, H, W)), dim3(256), 0, s, x, w, bias, out, B, H, W, 64, reinterpret_cast<unsigned short*>(relu_bits));
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 long mk_conv1_wgrad_slab_floats(int B, int H, int W) { return (((long)B * H * W + C1_PIX - 1) / C1_PIX + C1_RSPLIT) * 640; }
@@ -1977,9 +1837,9 @@ long mk_conv1_wgrad_slab_floats(int B, int H, int W) { return (((long)B * H * W 
 int mk_conv1_fwd_n(const float* x, const float* w, const float* bias, bf16* out, int B, int H, int W, int COUT, hipStream_t s) {
     if (COUT % 64) { mk_set_error("mk_conv1_fwd_n", "COUT must be a multiple of 64"); return -1; }
     const long P = (long)B * H * W;
-    if (P >= (1L << 31) - 65536) { mk_set_error("mk_conv1_fwd_n", "map too large"); return -1; }
+    if (P * COUT * 2 >= (1L << 32) - 65536) { mk_set_error("mk_conv1_fwd_n", "map too large (the output is addressed through one 4 GB buffer descriptor)"); return -1; }
     for (int c0 = 0; c0 < COUT; c0 += 64)
-        hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)conv1_grid(B, H, W)), dim3(256), 0, s, x, w + c0 * 9, bias + c0, out + c0, B, H, W, COUT, (unsigned*)nullptr);
+        hipLaunchKernelGGL(conv1_fwd_mfma_kernel, dim3((unsigned)conv1_mfma_grid(B, H, W)), dim3(256), 0, s, x, w + c0 * 9, bias + c0, out + c0, B, H, W, COUT, (unsigned short*)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int mk_conv1_wgrad_n(const float* x, const bf16* dy, float* dw, float* db, float* slab, int B, int H, int W, int COUT, hipStream_t s) {
@@ -2027,10 +1887,14 @@ static int launch_resw_w1(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 // persistent grids: one workgroup per CU for the resident-weight kernel, as many as fit (1 or 2 per CU) for the streaming kernels
-static void launch_resw(const ConvArgs& a, int tiles_x, int tiles_y, hipStream_t s) {
-    const int ntiles = tiles_x * tiles_y * a.B, resident = conv_ncu();
+static void launch_resw(const ConvArgs& a, hipStream_t s) {
+    const int resident = conv_ncu();
     ConvArgs b = a;
     b.sched = sched_or_fallback(a.sched);
+    // 16 x 16 tiles at every width.  (Round 6: 32 x 8 tiles where the width pads better to 8 -- the shipped idim 83: 88 columns instead of
+    // 96 -- instantiate and pass every test, but run the W = 83 forward in 121 us against 100: two patch rows per MFMA row block and a 34 x 10
+    // patch per 256 pixels cost more than the 8 % of padded pixels return.)
+    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 15) / 16, ntiles = tiles_x * tiles_y * a.B;
     hipLaunchKernelGGL((conv3x3_resw_kernel<16, 16>), dim3((unsigned)(ntiles < resident ? ntiles : resident)), dim3(320), 0, s, b, ntiles, tiles_x, tiles_y);
 }
 template <int CI, int CO, int TWV, int MASK, int THV = 16, bool UNPOOL = false>
@@ -2104,7 +1968,7 @@ static int conv3x3_dispatch(const ConvArgs& a, hipStream_t s) {
         // against 0.172 ms for the weight-ring kernel on 8-wide tiles).  32-row tiles where the registers allow: the per-tap weight slices
         // (the bulk of these kernels' vector-memory instructions) are amortised over twice the pixels -- not for 64 -> 128 (spills), nor
         // for a masked 128 <- 128 dgrad that reads the bf16 map as its mask (64 mask registers; with sign bits: 4)
-        if (a.CIN == 64 && a.COUT == 64 && !a.mask) launch_resw(a, (a.W + 15) / 16, tiles_y, s);
+        if (a.CIN == 64 && a.COUT == 64 && !a.mask) launch_resw(a, s);
         else if (a.CIN == 64 && a.COUT == 64) launch_stream<64, 64, 8>(a, tiles_x, tiles_y, s);
         else if (a.CIN == 64 && a.COUT == 128) launch_stream<64, 128, 8>(a, tiles_x, tiles_y, s);
         else if (a.CIN == 128 && a.COUT == 64) launch_stream<128, 64, 8, 32>(a, tiles_x, ty32, s);
@@ -2116,11 +1980,20 @@ static int conv3x3_dispatch(const ConvArgs& a, hipStream_t s) {
         } else { mk_set_error("mk_conv3x3", "unsupported channel counts"); return -1; }
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
-    auto grid = [&](int TH) { return dim3((a.W + 15) / 16, (a.H + TH - 1) / TH, a.B); };        // BLSTM front-end (256 channels): the patch kernel
-    if (a.CIN == 128 && a.COUT == 256) hipLaunchKernelGGL((conv3x3_patch_kernel<128, 256, 8>), grid(8), dim3(256), 0, s, a);
-    else if (a.CIN == 256 && a.COUT == 256) hipLaunchKernelGGL((conv3x3_patch_kernel<256, 256, 8>), grid(8), dim3(256), 0, s, a);
-    else if (a.CIN == 256 && a.COUT == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<256, 128, 8>), grid(8), dim3(256), 0, s, a);
-    else { mk_set_error("mk_conv3x3", "unsupported channel counts"); return -1; }
+    // BLSTM front-end (256 channels), round 6: the streaming kernel in passes of 128 output channels over the same patches (its weight ring
+    // holds four [COUT][64] slices: 256 output channels at once would need 128 KB of it).  The patch kernel these launches ran on until
+    // round 5 took 163 us for 256 -> 256 on the 8 x 200 x 42 map of tools/bench_blstm.py.
+    if (a.pool_out || a.pool_idx || a.out_sign_bits || a.mask_bits || a.in_pooled) { mk_set_error("mk_conv3x3", "256-channel launches: plain forward / masked dgrad only"); return -1; }
+    if (!((a.CIN == 128 && a.COUT == 256) || (a.CIN == 256 && a.COUT == 256) || (a.CIN == 256 && a.COUT == 128))) { mk_set_error("mk_conv3x3", "unsupported channel counts"); return -1; }
+    const int tiles_x = (a.W + 7) / 8, tiles_y = (a.H + 15) / 16, ty32 = (a.H + 31) / 32;
+    for (int c0 = 0; c0 < a.COUT; c0 += 128) {
+        ConvArgs b = a;
+        b.COUT = 128; b.out_cstride = a.COUT; b.out_coff = c0;
+        b.wk = a.wk + (long)c0 * 9 * a.CIN;
+        if (a.bias) b.bias = a.bias + c0;
+        if (a.CIN == 128) { if (b.mask) launch_stream_t<128, 128, 8, 1, 16>(b, tiles_x, tiles_y, s); else launch_stream_t<128, 128, 8, 0, 32>(b, tiles_x, ty32, s); }
+        else { if (b.mask) launch_stream_t<256, 128, 8, 1, 16>(b, tiles_x, tiles_y, s); else launch_stream_t<256, 128, 8, 0, 32>(b, tiles_x, ty32, s); }
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

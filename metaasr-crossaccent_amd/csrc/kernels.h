@@ -73,6 +73,10 @@ struct ConvArgs {
     // that maximum is <= 0 (nothing passes the ReLU): all the pool + ReLU backward needs of the full-resolution map
     uint8_t* pool_idx;
     int out_optional;             // the caller does not need `out`: a launch that pools in its epilogue may skip storing it
+    // streaming kernels only: `out` (and `mask`, same shape) has out_cstride channels per pixel and this launch computes channels
+    // out_coff .. out_coff + COUT of it (wk / bias already offset by the caller); 0 = a plain [..][COUT] map.  How mk_conv3x3 runs the
+    // 256-channel convs of the BLSTM front-end: two passes of 128 output channels over the same patches.
+    int out_cstride, out_coff;
 };
 int mk_conv3x3(const ConvArgs& a, hipStream_t s);
 long mk_conv1_wgrad_fused_slab_floats(int B, int H, int W);
