@@ -54,11 +54,11 @@ int masr_bind(masr_model* m, float* params, float* grads, const float* pe, void*
 /* rebuild the bf16 operand shadows after ANY change of params (load_state_dict, optimizer step) */
 int masr_refresh(masr_model* m, void* stream);
 void masr_set_seed(masr_model* m, uint64_t seed);      /* dropout stream */
-/* hint: this model is one of `slots` task slots running concurrently on the GPU (pretrain.py --tasks_per_gpu).  Results do NOT depend
- * on it, bit for bit (no launch partition that enters a summation order follows the slot count).  What follows it is the LDS footprint of
- * some launches and a latency-for-occupancy trade: with slots > 1 the encoder-row GEMMs keep a three-stage operand ring (72 KB) instead
- * of four (96 KB), so that the other slots' workgroups still fit beside them on a CU, and the decoder's few-row GEMMs run whole reductions
- * (masr_set_ksplit's split is for a lone task: it shortens the launch chain with four times the workgroups). */
+/* hint: this model is one of `slots` task slots running concurrently on the GPU (pretrain.py --tasks_per_gpu).  NO result depends on it,
+ * bit for bit: no launch partition that enters a summation order follows the slot count (the k-split below follows masr_set_ksplit only;
+ * tests/test_hip_engine.py::test_task_slot_hint_never_changes_bits).  What follows it is the LDS footprint of some launches: with slots > 1
+ * the encoder-row GEMMs keep a three-stage operand ring (72 KB) instead of four (96 KB), so that the other slots' workgroups still fit
+ * beside them on a CU.  Changing it drops captured step graphs (masr_set_step_graphs). */
 void masr_set_concurrency(masr_model* m, int slots);
 /* the dropout stream's position: state[0] = seed, state[1] = batches run since masr_set_seed (every run_batch derives its masks
  * from both); set != 0 writes it.  For checkpoints: a resumed run continues the mask stream where the saved one stopped. */
@@ -74,16 +74,22 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
  * a hipGraph on its second consecutive occurrence and replayed afterwards (one launch instead of ~150; tokens, lengths, dropout
  * seed and 1/n_total reach the kernels through the per-step upload, so replays are bit-identical to direct launches).  It cuts
  * the host's enqueue time 6x and leaves the step time unchanged -- the step is GPU-bound -- hence off by default.
- * counters: out[0] = steps launched kernel by kernel, out[1] = graphs captured, out[2] = steps replayed from a graph. */
+ * counters: out[0] = steps launched kernel by kernel, out[1] = graphs captured, out[2] = steps replayed from a graph, out[3] = k-split GEMM
+ * launches of the last step launched or captured (0 = whole reductions).  Captured graphs hold the launch geometry of the settings they were
+ * captured under: masr_set_concurrency / masr_set_ksplit / masr_set_split_wgrad_launches drop them (after a device synchronisation). */
 void masr_set_step_graphs(masr_model* m, int on);
 /* The Linear weight gradients of a step are ONE launch (the decoder-row tiles fill the CUs the encoder-row tiles leave idle); on: two
  * launches, encoder rows then decoder rows (A/B; identical bits -- each element of dW is reduced by one workgroup either way). */
 void masr_set_split_wgrad_launches(masr_model* m, int on);
-/* The decoder's few-row GEMMs with a long reduction (FFN second layer, its first layer's dgrad, the packed q/k/v dgrad: <= 1024 rows, K >= 1024)
- * run k-split over K / 512 x as many workgroups; the LayerNorm (backward) that follows sums the fp32 partial products and applies the GEMM's
- * epilogue (bias, dropout, residual) on its way in.  Default ON; off = whole reductions (same results up to fp32 summation order; A/B + test). */
+/* The decoder's few-row GEMMs with a long reduction (FFN second layer, its first layer's dgrad, the packed q/k/v dgrad: <= 1024 rows, K >= 1024;
+ * and the attention out-projections in two halves) run k-split over K / 512 x as many workgroups; the LayerNorm (backward) that follows sums the
+ * fp32 partial products and applies the GEMM's epilogue (bias, dropout, residual) on its way in.  It shortens a lone task's launch chain (+1..3 %)
+ * and costs throughput beside other task slots, and it changes the fp32 summation order of those GEMMs -- so it follows THIS call only, never
+ * masr_set_concurrency.  Default OFF (whole reductions).  The one-task-per-stream loops turn it on (train.py: the mono / multi trainers); the
+ * FOMAML interface leaves it off for every --tasks_per_gpu, so that K slots == the sequential run == N ranks, bit for bit.  Both schedules are
+ * pinned to the reference at the headline shape (tests/test_hip_fullsize.py).  masr_step_counters out[3] reports which one ran. */
 void masr_set_ksplit(masr_model* m, int on);
-void masr_step_counters(const masr_model* m, int64_t out[3]);
+void masr_step_counters(const masr_model* m, int64_t out[4]);
 /* out[0]=loss, out[1]=n_correct, out[2]=n_total, out[3]=last grad norm.  Synchronises the stream. */
 int masr_read_stats(masr_model* m, float out[4], void* stream);
 /* the same four floats WITHOUT waiting: masr_stats_post queues their copy into a page-locked block owned by the handle (a ring of

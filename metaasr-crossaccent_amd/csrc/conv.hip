@@ -1891,9 +1891,11 @@ static void launch_resw(const ConvArgs& a, hipStream_t s) {
     const int resident = conv_ncu();
     ConvArgs b = a;
     b.sched = sched_or_fallback(a.sched);
-    // 16 x 16 tiles at every width.  (Round 6: 32 x 8 tiles where the width pads better to 8 -- the shipped idim 83: 88 columns instead of
-    // 96 -- instantiate and pass every test, but run the W = 83 forward in 121 us against 100: two patch rows per MFMA row block and a 34 x 10
-    // patch per 256 pixels cost more than the 8 % of padded pixels return.)
+    // 16 x 16 tiles at every width.  Round 6, measured and not kept: (i) 32 x 8 tiles where the width pads better to 8 -- the shipped idim 83:
+    // 88 columns instead of 96 -- instantiate and pass every test, but run the W = 83 forward in 121 us against 112: two patch rows per MFMA
+    // row block and a 34 x 10 patch per 256 pixels cost more than the 8 % of padded pixels return; (ii) the 64 -> 128 forward (conv3) as two
+    // 64-channel passes of this kernel (output channel stride / offset, the 128-channel sign words written a half-word per pass): 72 us
+    // against 61 for the weight-ring kernel -- the 40-column map pads to 48 under 16-wide tiles and each pass reloads its 72 KB bank.
     const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 15) / 16, ntiles = tiles_x * tiles_y * a.B;
     hipLaunchKernelGGL((conv3x3_resw_kernel<16, 16>), dim3((unsigned)(ntiles < resident ? ntiles : resident)), dim3(320), 0, s, b, ntiles, tiles_x, tiles_y);
 }
