@@ -11,7 +11,7 @@ The oracle (oracle/ref_cpu.py, fp32 torch on the CPU, bf16 rounding points of th
 batch: (a) as it is (direct convs), (b) conv2 / conv4 through the Winograd emulation, (c) the fp32 reference values from
 tests/golden/hkust_fullsize.npz.  Prints loss and per-tensor gradient distances (b)-(c) beside (a)-(c).
 
-    python tools/winograd_gate.py [--idim 80] [--B 16]
+    python tests/diag_winograd_gate.py [--idim 80] [--B 16]      (under tests/: like every checker script it imports oracle/)
 """
 import argparse
 import sys
