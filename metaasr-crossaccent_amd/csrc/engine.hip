@@ -1311,6 +1311,9 @@ int masr_test_gemm_epi(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
     g.C32 = C32; g.ldc = N; g.C16 = (bf16*)C16; g.ldc16 = N;
     return mk_gemm(g, (hipStream_t)stream);
 }
+int masr_test_conv1_fwd(const float* x, const float* w, const float* bias, uint16_t* out, uint64_t* relu_bits, int B, int H, int W, void* stream) {
+    return mk_conv1_fwd(x, w, bias, (bf16*)out, B, H, W, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(relu_bits));
+}
 int masr_test_conv3x3(const uint16_t* in, const uint16_t* wk, const float* bias, int relu, uint16_t* out, int B, int H, int W, int CIN,
                       int COUT, void* stream) {
     ConvArgs a{}; a.in = (const bf16*)in; a.wk = (const bf16*)wk; a.bias = bias; a.relu = relu; a.out = (bf16*)out;

@@ -247,6 +247,33 @@ def test_conv3x3_pool_codes_and_their_backward(L, B_, H, W, CIN, COUT):
     assert torch.equal(din.float()[:, :2 * H2, :2 * W2][u], ref[:, :2 * H2, :2 * W2][u])
 
 
+@pytest.mark.parametrize("B_,H,W", [(2, 37, 80), (1, 50, 83), (3, 16, 16), (1, 9, 5), (2, 64, 40), (16, 100, 80)])
+def test_conv1_forward_on_the_fp32_mfma(L, B_, H, W):
+    """The CIN = 1 conv of the VGG front-end (mono_transformer_torch.py:49-50) on v_mfma_f32_16x16x4_f32: fp32 arithmetic, one rounding to bf16.
+    Against F.conv2d in fp32 + ReLU rounded to bf16: equal up to the one-ulp flips an fp32 summation order can cause at a rounding boundary (at
+    most 0.1 % of the elements, each by one bf16 ulp); the ReLU sign word of every pixel is exactly (out > 0); widths that are not multiples of
+    16 and maps smaller than a segment included; a poisoned output buffer shows that every element is written."""
+    g = torch.Generator(device="cuda").manual_seed(H * 131 + W)
+    x = torch.randn(B_, H, W, device="cuda", generator=g)
+    w = torch.randn(64, 1, 3, 3, device="cuda", generator=g) * 0.3
+    b = torch.randn(64, device="cuda", generator=g) * 0.2
+    out = torch.full((B_, H, W, 64), float("nan"), device="cuda").bfloat16()
+    bits = torch.full((B_, H, W), -1, device="cuda", dtype=torch.int64)
+    _cabi.check(L.masr_test_conv1_fwd(P(x), P(w.reshape(64, 9).contiguous()), P(b), P(out), P(bits), B_, H, W, S()))
+    ref = torch.relu(torch.nn.functional.conv2d(x.unsqueeze(1), w, b, padding=1)).permute(0, 2, 3, 1)
+    refq = ref.bfloat16()
+    assert bool(torch.isfinite(out.float()).all())
+    diff = out != refq
+    assert float(diff.float().mean()) <= 1e-3, float(diff.float().mean())
+    torch.testing.assert_close(out.float(), ref, rtol=8e-3, atol=1e-6)                     # (bf16: 2^-8 relative)
+    want = ((out.float() > 0).to(torch.int64) << torch.arange(64, device="cuda").view(1, 1, 1, 64)).sum(-1)
+    assert torch.equal(bits, want)
+    # without the sign words (evaluation / the BLSTM front-end): same map
+    out2 = torch.zeros_like(out)
+    _cabi.check(L.masr_test_conv1_fwd(P(x), P(w.reshape(64, 9).contiguous()), P(b), P(out2), None, B_, H, W, S()))
+    assert torch.equal(out2, out)
+
+
 def _unpool(codes, gp, H, W):
     """MaxPool2d(2, 2) + ReLU backward from the pool codes (window position 0..3 of the first maximum, 4 = nothing passed the ReLU): the map
     [B][H][W][C] the dgrad / weight-gradient kernels expand in their staging -- pure indexing, exact."""
