@@ -1,6 +1,6 @@
 // Energy per instruction on gfx950, for the costing of DESIGN 6.2 (Winograd trades MFMAs for vector instructions under a board power cap):
-// back-to-back loops of (a) v_mfma_f32_16x16x32_bf16, (b) v_fma_f32, (c) one MFMA + 9 FMAs, on random register contents, one wave per SIMD on
-// every CU, each run for a few seconds while tools/energy/run.sh samples hwmon power1_average.  Not part of the product; nothing links it.
+// back-to-back loops of (0) v_mfma_f32_16x16x32_bf16, (1) v_fma_f32, (2) one MFMA + 9 FMAs, (3) ds_read_b128 (conflict-free, 1 KB per
+// wave-instruction), (4) one MFMA + one ds_read_b128 whose result is the MFMA's next A operand -- on random contents, one wave per SIMD on every CU, each run for a few seconds while tools/energy/run.sh samples hwmon power1_average.  Not part of the product; nothing links it.
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/energy_probe tools/energy/energy_probe.hip && /tmp/energy_probe <mode> <seconds>
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -20,7 +20,30 @@ __global__ __launch_bounds__(256) void burn(const float* __restrict__ seed, floa
     for (int i = 0; i < 16; ++i) v[i] = seed[(tid * 53 + i) & 65535];
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 8; ++j) { a[i][j] = (__bf16)seed[(tid * 11 + i * 8 + j) & 65535]; b[i][j] = (__bf16)seed[(tid * 7 + i * 8 + j + 99) & 65535]; }
     const float c0 = seed[tid & 1023] * 1e-3f + 0.999f, c1 = seed[(tid + 1) & 1023] * 1e-3f;
+    __shared__ __attribute__((aligned(16))) float lds[MODE >= 3 ? 16384 : 4];      // 64 KB of random bits: 16 x 1 KB rows per wave
+    if (MODE >= 3) { for (int i = threadIdx.x; i < 16384; i += 256) lds[i] = seed[(i * 3 + blockIdx.x) & 65535]; __syncthreads(); }
+    const unsigned lbase = (unsigned)(size_t)((__attribute__((address_space(3))) float*)lds) + (threadIdx.x >> 6) * 16384 + (threadIdx.x & 63) * 16;
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    u4 rd[8];
+    for (int i = 0; i < 8; ++i) rd[i] = u4{0u, 0u, 0u, 0u};
     for (int it = 0; it < iters; ++it) {
+        if (MODE == 3) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rd[i]) : "v"(lbase), "n"(i * 1024));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+        if (MODE == 4) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rd[i]) : "v"(lbase), "n"(i * 1024));
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, rd[(i + 4) & 7]), b[i & 1], acc[i], 0, 0, 0);
+                if (i == 3 || i == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if ((it & 63) == 63) for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) acc[i][j] *= 1e-3f;
+        }
         if (MODE == 0 || MODE == 2) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -43,6 +66,7 @@ __global__ __launch_bounds__(256) void burn(const float* __restrict__ seed, floa
     float s = 0.f;
     for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) s += acc[i][j];
     for (int i = 0; i < 16; ++i) s += v[i];
+    for (int i = 0; i < 8; ++i) s += __builtin_bit_cast(float, rd[i][0] & 0x3f800000u);
     if (s == 123.456f) sink[tid] = s;
 }
 
@@ -57,7 +81,9 @@ int main(int argc, char** argv) {
     auto launch = [&]() {
         if (mode == 0) hipLaunchKernelGGL(burn<0>, dim3(ncu), dim3(256), 0, 0, seed, sink, iters);
         else if (mode == 1) hipLaunchKernelGGL(burn<1>, dim3(ncu), dim3(256), 0, 0, seed, sink, iters);
-        else hipLaunchKernelGGL(burn<2>, dim3(ncu), dim3(256), 0, 0, seed, sink, iters);
+        else if (mode == 2) hipLaunchKernelGGL(burn<2>, dim3(ncu), dim3(256), 0, 0, seed, sink, iters);
+        else if (mode == 3) hipLaunchKernelGGL(burn<3>, dim3(ncu), dim3(256), 0, 0, seed, sink, iters);
+        else hipLaunchKernelGGL(burn<4>, dim3(ncu), dim3(256), 0, 0, seed, sink, iters);
     };
     launch(); hipDeviceSynchronize();
     const auto t0 = std::chrono::steady_clock::now();
@@ -65,7 +91,8 @@ int main(int argc, char** argv) {
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) { for (int k = 0; k < 4; ++k) launch(); hipDeviceSynchronize(); n += 4; }
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const double waves = (double)ncu * 4, per_wave_iter = (double)n * iters;
-    const double mfma = (mode == 1 ? 0.0 : 8.0) * per_wave_iter * waves, valu = (mode == 0 ? 0.0 : mode == 1 ? 128.0 : 72.0) * per_wave_iter * waves;
-    printf("mode %d: %.2f s, %.3e MFMA/s (16x16x32 bf16), %.3e vector instructions/s (wave64 v_fma_f32)\n", mode, dt, mfma / dt, valu / dt);
+    const double mfma = (mode == 1 || mode == 3 ? 0.0 : 8.0) * per_wave_iter * waves, valu = (mode == 1 ? 128.0 : mode == 2 ? 72.0 : 0.0) * per_wave_iter * waves;
+    const double lds = (mode == 3 ? 16.0 : mode == 4 ? 8.0 : 0.0) * per_wave_iter * waves;
+    printf("mode %d: %.2f s, %.3e MFMA/s (16x16x32 bf16), %.3e vector instructions/s (wave64 v_fma_f32), %.3e ds_read_b128/s (1 KB each)\n", mode, dt, mfma / dt, valu / dt, lds / dt);
     return 0;
 }
