@@ -143,6 +143,17 @@ class ClockSampler:
                 pass
         return None
 
+    @staticmethod
+    def _cap(dev):
+        """board power cap in W (hwmon power1_cap, microwatts): the four-slot headline runs AT it, so the line carries it beside the reading"""
+        import glob
+        for f in glob.glob(os.path.join(dev, "hwmon", "hwmon*", "power1_cap")):
+            try:
+                return float(open(f).read()) / 1e6
+            except Exception:
+                pass
+        return None
+
     def _read(self, dev):
         return (self._cur(os.path.join(dev, "pp_dpm_sclk")), self._cur(os.path.join(dev, "pp_dpm_mclk")), self._power(dev))
 
@@ -174,6 +185,7 @@ class ClockSampler:
             return {"available": False, "note": "pp_dpm_sclk not readable on this box"}
         return {"available": True, "samples": len(s_), "sclk_mhz_min": min(s_), "sclk_mhz_median": float(np.median(s_)), "sclk_mhz_max": max(s_),
                 "mclk_mhz_median": float(np.median(m_)) if m_ else None, "power_w_median": float(np.median(p_)) if p_ else None,
+                "power_cap_w": self._cap(self.dev or (self.cands[0] if self.cands else "")),
                 "card": getattr(self, "how", "busiest of %d cards (by power)" % len(self.cands)),
                 "source": "sysfs pp_dpm_sclk / pp_dpm_mclk (current DPM level) and hwmon power1_average, sampled every %.2f s during the leg" % self.period}
 
