@@ -51,9 +51,8 @@ __device__ __forceinline__ s16x2 lane_xor8(s16x2 v) { return __builtin_bit_cast(
 // ------------------------------------------------------------------ conv1 (CIN = 1), direct fp32
 // bits (optional): the ReLU mask of this map as one 64-bit word per pixel [B][H][W], bit c = (out[..][c] > 0) -- all the masked
 // dgrad of the NEXT conv needs of the map (conv3x3_resw_w1x_kernel, ConvArgs::mask_bits): 8 bytes per pixel instead of 128, and half
-// the vector-memory instructions that launch is bound by.  Here it costs ONE more store instruction per 16-pixel segment: a thread
-// owns 8 channels of two pixels, i.e. one byte of each pixel's word; the four bytes of a half-word sit in a quad of lanes and are
-// OR-ed together by two DPP moves; the lanes with (cg & 3) < 2 then store the segment's 32 dwords (128 contiguous bytes).
+// the vector-memory instructions that launch is bound by.  Here it costs ONE more store instruction per 16-pixel segment: a lane owns the
+// 16 channels 16 q .. 16 q + 15 of its pixel, i.e. one 16-bit piece of the pixel's word.
 // (Tried instead: the patch wave of conv2's forward launch derives the words from the patches it streams -- 32 LDS reads + ~500
 // VALU per tile on a wave that shares its SIMD with an MFMA wave: conv2 forward 93 -> 133 us.)
 // Round 6: the CIN = 1 layer on the fp32-input MFMA (v_mfma_f32_16x16x4_f32: exact fp32, a k-ordered fmaf chain -- the precision policy keeps
