@@ -163,6 +163,28 @@ def test_conv3x3_mask_and_pool(L, B_, H, W, CIN, COUT):
     assert torch.equal(pool.float(), pref)                       # pooling the stored map is exact
 
 
+@pytest.mark.parametrize("B_,H,W,CIN,COUT", [(2, 50, 42, 128, 256), (1, 37, 21, 256, 256), (2, 33, 42, 256, 128), (8, 200, 42, 256, 256)])
+def test_conv3x3_256_channels_as_passes_of_128(L, B_, H, W, CIN, COUT):
+    """The BLSTM front-end's convs (src/modules/encoder.py:215-298: 128 -> 256 -> 256 behind the first pool) run as passes of 128 OUTPUT
+    channels of the streaming kernel over the same patches (ConvArgs::out_cstride / out_coff): forward (bias + ReLU) and the dgrad flavour
+    through a bf16 ReLU mask with 256 channels per pixel, against torch; a poisoned output shows that both passes wrote their half of every
+    pixel and nothing else."""
+    g = torch.Generator(device="cuda").manual_seed(5 * CIN + COUT + H)
+    x = torch.randn(B_, H, W, CIN, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(COUT, CIN, 3, 3, device="cuda", generator=g) * 0.04).bfloat16()
+    bias = torch.randn(COUT, device="cuda", generator=g)
+    wk = w.permute(0, 2, 3, 1).reshape(COUT, 9 * CIN).contiguous()
+    conv = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float(), None, padding=1).permute(0, 2, 3, 1)
+    out = torch.full((B_ * H * W * COUT + 256,), float("nan"), device="cuda").bfloat16()          # (+ a guard zone behind the map)
+    _cabi.check(L.masr_test_conv3x3(P(x), P(wk), P(bias), 1, P(out), B_, H, W, CIN, COUT, S()))
+    assert bool(torch.isnan(out[-256:].float()).all())
+    torch.testing.assert_close(out[:-256].view(B_, H, W, COUT).float(), torch.relu(conv + bias), rtol=1e-2, atol=2e-2)
+    mask = torch.relu(torch.randn(B_, H, W, COUT, device="cuda", generator=g)).bfloat16()
+    out2 = torch.full((B_, H, W, COUT), float("nan"), device="cuda").bfloat16()
+    _cabi.check(L.masr_test_conv3x3_ex(P(x), P(wk), None, 0, P(mask), P(out2), None, B_, H, W, CIN, COUT, S()))
+    torch.testing.assert_close(out2.float(), torch.where(mask.float() > 0, conv, torch.zeros_like(conv)), rtol=1e-2, atol=2e-2)
+
+
 def _sign_words(m):
     """[B,H,W,128] map -> [B,H,W,4] dwords: dword q, byte h, bit j = (channel 32 h + 8 q + j > 0)"""
     B_, H, W, _ = m.shape
