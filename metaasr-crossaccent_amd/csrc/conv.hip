@@ -1964,7 +1964,11 @@ static int conv3x3_dispatch(const ConvArgs& a, hipStream_t s) {
     }
     if (a.mask && (a.bias || a.relu || a.pool_out)) { mk_set_error("mk_conv3x3", "a launch is a forward flavour (bias / ReLU / pool) or a dgrad flavour (mask), not both"); return -1; }
     if (a.CIN <= 128 && a.COUT <= 128) {
-        const int tiles_x = (a.W + 7) / 8, tiles_y = (a.H + 15) / 16, ty32 = (a.H + 31) / 32;
+        // a launch that stores only the pooled map (floor mode) has no use for the last row / column of an odd map: the shipped idim 83
+        // pools to 41 columns, and the 128 -> 128 forward on them needs 40 = five 8-wide tiles, not six
+        const bool pooled_only = !a.out && a.pool_out && !a.mask && a.W > 1 && a.H > 1;
+        const int We = pooled_only ? (a.W & ~1) : a.W, He = pooled_only ? (a.H & ~1) : a.H;
+        const int tiles_x = (We + 7) / 8, tiles_y = (He + 15) / 16, ty32 = (He + 31) / 32;
         // 64 -> 64 forward takes the resident-weight kernel with 16-wide tiles, also on widths that pad badly to 16 (W = 83: 0.100 ms
         // against 0.172 ms for the weight-ring kernel on 8-wide tiles).  32-row tiles where the registers allow: the per-tap weight slices
         // (the bulk of these kernels' vector-memory instructions) are amortised over twice the pixels -- not for 64 -> 128 (spills), nor
@@ -2001,22 +2005,40 @@ static int conv3x3_dispatch(const ConvArgs& a, hipStream_t s) {
 // ONE persistent workgroup per CU with the next tiles prefetched in registers (256 partial slabs: 37 MB written and read again per layer).
 // One configuration for every mode: the partition of the pixels into partial sums is part of the result's bits (slots = sequential run).
 static int wgrad2_nwg(int CIN, int COUT) { return W2_TOTAL_WG / ((CIN / 64) * (COUT / 64)); }
+// tile = 16 x 8 pixels (wide x tall), or 8 x 16 where the map's width pads better to eights (40 -> 40 instead of 48, 83 -> 88 instead of 96:
+// the 40-wide layers spent 20 % of their MFMAs on columns outside the map)
+static int wgrad2_we(int W, bool pooled) { return pooled && W > 1 ? (W & ~1) : W; }
+static int wgrad2_tw(int W) { return ((W + 7) / 8) * 8 < ((W + 15) / 16) * 16 ? 8 : 16; }
 long mk_conv3x3_wgrad_slab_floats(int B, int H, int W, int CIN, int COUT) {
     (void)B; (void)H; (void)W;
     return (long)wgrad2_nwg(CIN, COUT) * (COUT * 9 * CIN + COUT);
 }
-int mk_conv3x3_wgrad_nsplit(int B, int H, int W, int CIN, int COUT) {
-    const int ntiles = ((W + 15) / 16) * ((H + 7) / 8) * B, nwg = wgrad2_nwg(CIN, COUT);
-    return nwg < ntiles ? nwg : ntiles;
+// tiles and workgroups of a launch (one place: the fold launch that sums the partial slabs must count what the kernel wrote).  A pooled gradient
+// is zero on the row / column the floor-mode pool cropped: tiles cover the even part of the map only.
+struct Wgrad2Grid { int tw, tiles_x, tiles_y, ntiles, nwg; };
+static Wgrad2Grid wgrad2_grid(const ConvWgradArgs& a) {
+    const bool pooled = a.dy_pooled && a.pool_idx;
+    const int We = wgrad2_we(a.W, pooled), He = wgrad2_we(a.H, pooled);
+    Wgrad2Grid g;
+    g.tw = wgrad2_tw(We);
+    const int th = 128 / g.tw;
+    g.tiles_x = (We + g.tw - 1) / g.tw; g.tiles_y = (He + th - 1) / th; g.ntiles = g.tiles_x * g.tiles_y * a.B;
+    g.nwg = wgrad2_nwg(a.CIN, a.COUT);
+    if (g.nwg > g.ntiles) g.nwg = g.ntiles;
+    return g;
 }
+int mk_conv3x3_wgrad_nsplit(const ConvWgradArgs& a) { return wgrad2_grid(a).nwg; }
 int mk_conv1_wgrad_fused_rows(int B, int H, int W) { return resw_w1_rows(B, H, W); }
 int mk_conv3x3_wgrad(const ConvWgradArgs& a, hipStream_t s, int phase) {
     // phase 0: both launches; 1: the partial-slab kernel only; 2: the slab reduce only (the engine times them in separate slots)
-    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 7) / 8, ntiles = tiles_x * tiles_y * a.B;
-    int nwg = wgrad2_nwg(a.CIN, a.COUT);
-    if (nwg > ntiles) nwg = ntiles;
+    const Wgrad2Grid wg = wgrad2_grid(a);
+    const int tw = wg.tw, tiles_x = wg.tiles_x, tiles_y = wg.tiles_y, ntiles = wg.ntiles, nwg = wg.nwg;
     const dim3 grid(nwg, (a.CIN / 64) * (a.COUT / 64));
-#define W2(CI, CO, PL) hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CI, CO, 16, PL>), grid, dim3(512), 0, s, a, nwg, ntiles, tiles_x, tiles_y)
+#define W2(CI, CO, PL)                                                                                                                  \
+    do {                                                                                                                                \
+        if (tw == 8) hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CI, CO, 8, PL>), grid, dim3(512), 0, s, a, nwg, ntiles, tiles_x, tiles_y);  \
+        else hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CI, CO, 16, PL>), grid, dim3(512), 0, s, a, nwg, ntiles, tiles_x, tiles_y);         \
+    } while (0)
     const bool pooled = a.dy_pooled && a.pool_idx;
     if (!pooled && !a.dy) { mk_set_error("mk_conv3x3_wgrad", "dy missing"); return -1; }
     if (pooled && !((a.CIN == 64 && a.COUT == 64) || (a.CIN == 128 && a.COUT == 128))) { mk_set_error("mk_conv3x3_wgrad", "pooled dy: 64->64 and 128->128 only"); return -1; }

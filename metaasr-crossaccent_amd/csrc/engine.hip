@@ -841,7 +841,7 @@ static int backward(Ctx& c, const float* xs) {
         ConvWgradArgs wa{}; wa.in = in; wa.dy = dy; wa.dw = G + cv.w; wa.db = G + cv.b; wa.slab = a.cw_slab[k]; wa.B = B; wa.H = H; wa.W = W; wa.CIN = cv.CI; wa.COUT = cv.CO;
         wa.dy_pooled = dy_pooled; wa.pool_idx = idx;
         { Prof p(m, MASR_PROF_CONV2_WGRAD + k, s); CK(mk_conv3x3_wgrad(wa, s, 1)); }     // the partial slabs; their reduce rides in the fold launch below
-        folds.conv[folds.nconv++] = {a.cw_slab[k], mk_conv3x3_wgrad_nsplit(B, H, W, cv.CI, cv.CO), G + cv.w, G + cv.b, cv.CI, cv.CO};
+        folds.conv[folds.nconv++] = {a.cw_slab[k], mk_conv3x3_wgrad_nsplit(wa), G + cv.w, G + cv.b, cv.CI, cv.CO};
         return 0;
     };
     auto dgrad = [&](const bf16* dy, const Conv& cv, bf16* out, int H, int W, const bf16* dy_pooled = nullptr, const uint8_t* idx = nullptr) -> int {

@@ -177,7 +177,7 @@ struct FoldJobs {
     LnReduceGroup ln;
 };
 int mk_backward_folds(const FoldJobs& j, hipStream_t s);
-int mk_conv3x3_wgrad_nsplit(int B, int H, int W, int CIN, int COUT);      // the partial slabs mk_conv3x3_wgrad's phase 1 writes for this shape
+int mk_conv3x3_wgrad_nsplit(const ConvWgradArgs& a);                     // the partial slabs mk_conv3x3_wgrad's phase 1 writes for this launch
 int mk_conv1_wgrad_fused_rows(int B, int H, int W);                      // the 640-sum rows the fused conv1 weight gradient writes
 int mk_embed_fwd(const int* tok, const float* table, const float* pe, float* y32, bf16* y16,
                    int B, int L, int E, float drop_p, uint32_t seed, uint32_t site, hipStream_t s, const uint32_t* seed_ptr = nullptr);

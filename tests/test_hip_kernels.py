@@ -223,7 +223,8 @@ def test_conv3x3_relu_mask_as_sign_bits(L, B_, H, W):
 
 
 @pytest.mark.parametrize("B_,H,W,CIN,COUT", [(2, 38, 80, 64, 64), (3, 50, 40, 128, 128), (2, 301, 80, 64, 64), (1, 17, 48, 128, 128),
-                                             (2, 45, 83, 64, 64), (2, 27, 41, 64, 128), (2, 64, 40, 64, 128), (1, 33, 20, 128, 128)])
+                                             (2, 45, 83, 64, 64), (2, 27, 41, 64, 128), (2, 64, 40, 64, 128), (1, 33, 20, 128, 128),
+                                             (2, 33, 41, 128, 128)])      # (odd H and W: a launch that drops the map skips the cropped row / column's tiles)
 def test_conv3x3_pool_codes_and_their_backward(L, B_, H, W, CIN, COUT):
     """the pooling convs of the engine emit one byte per pooled element (which window position won / nothing passed the ReLU) and may
     drop the full-resolution map; the pool + ReLU backward runs from those bytes.  Codes are checked against the stored map of a second
@@ -323,11 +324,13 @@ def test_conv3x3_wgrad(L, B_, H, W, CIN, COUT):
     torch.testing.assert_close(dw, wref.grad, rtol=1e-3, atol=2e-2)
 
 
-@pytest.mark.parametrize("B_,H,W,C", [(2, 10, 9, 64), (2, 40, 20, 128), (1, 21, 47, 128), (1, 33, 80, 64), (3, 16, 32, 64)])
+@pytest.mark.parametrize("B_,H,W,C", [(2, 10, 9, 64), (2, 40, 20, 128), (1, 21, 47, 128), (1, 33, 80, 64), (3, 16, 32, 64), (2, 33, 41, 128), (1, 50, 83, 64)])
 def test_conv3x3_wgrad_from_pooled_gradient(L, B_, H, W, C):
     """ConvWgradArgs::dy_pooled: the weight-gradient kernel of the conv in FRONT of a MaxPool2d(2, 2) (mono_transformer_torch.py:49-60) expands
-    pooled gradient + pool codes itself.  Same bits as staging the expanded map (_unpool; the LDS tile is identical);
-    odd H / W: the cropped last row / column gets no gradient; the bias gradient (summed in another order) within rounding."""
+    pooled gradient + pool codes itself.  Even maps: same bits as staging the expanded map (_unpool; the LDS tile is identical).  Odd H / W: the
+    cropped last row / column gets no gradient, so the pooled launch tiles the even part of the map only (41 columns -> five 8-wide tiles of 40
+    instead of three 16-wide of 48) -- the same products summed over another partition: equal within fp32 rounding.  The bias gradient (summed in
+    another order) within rounding."""
     g = torch.Generator(device="cuda").manual_seed(C + H + W)
     x = torch.randn(B_, H, W, C, device="cuda", generator=g).bfloat16()
     H2, W2 = H // 2, W // 2
@@ -339,7 +342,10 @@ def test_conv3x3_wgrad_from_pooled_gradient(L, B_, H, W, C):
     dw0 = torch.zeros(C, C, 3, 3, device="cuda"); dw1 = torch.zeros_like(dw0); db = torch.zeros(C, device="cuda")
     _cabi.check(L.masr_test_conv3x3_wgrad(P(x), P(dy), P(dw0), P(slab), n, B_, H, W, C, C, S()))
     _cabi.check(L.masr_test_conv3x3_wgrad_pooled(P(x), P(dyp), P(codes), P(dw1), P(db), P(slab), n, B_, H, W, C, C, S()))
-    assert torch.equal(dw0, dw1)
+    if H % 2 == 0 and W % 2 == 0:
+        assert torch.equal(dw0, dw1)
+    else:
+        torch.testing.assert_close(dw1, dw0, rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(db, dy.float().sum((0, 1, 2)), rtol=1e-4, atol=1e-3)
     assert float(dw1.abs().max()) > 0
 
