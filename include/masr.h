@@ -120,6 +120,11 @@ int masr_clip_sgd_step(masr_model* m, float* momentum_buf, float max_norm, float
 int masr_clip_grads(masr_model* m, float max_norm, void* stream);
 /* _partial_meta_update after the val-batch clip (fo_meta_interface.py:148-154,180-198): updates += clip(grads) */
 int masr_clip_accumulate(masr_model* m, float* updates, float max_norm, void* stream);
+/* Quirk Q5 of the reference (fo_meta_interface.py:151-154): a val-batch gradient whose norm is NaN is only warned about and still accumulated, so
+   one bad batch turns the meta weights into NaNs.  Default (off) reproduces that.  On (pretrain.py --fix_nan_meta_grad): masr_clip_grads zeroes
+   such a gradient and masr_clip_accumulate leaves `updates` alone -- decided on the device from the norm both already form, no host sync; the
+   norm reported by masr_read_stats stays NaN, so the warning is still logged. */
+void masr_set_drop_nan_grads(masr_model* m, int on);
 /* buf[0..n) *= min(1, max_norm / (*norm + 1e-6)) with the norm read from device memory (what masr_allreduce applies chunk by chunk, as one
    pass: for transports that cannot pipeline it) */
 int masr_clip_scale_flat(float* buf, int64_t n, const float* norm, float max_norm, void* stream);

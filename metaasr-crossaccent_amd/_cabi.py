@@ -34,6 +34,7 @@ _SIGS = {
     "masr_set_step_graphs": (None, [vp, i32]),
     "masr_set_split_wgrad_launches": (None, [vp, i32]),
     "masr_set_ksplit": (None, [vp, i32]),
+    "masr_set_drop_nan_grads": (None, [vp, i32]),
     "masr_step_counters": (None, [vp, C.POINTER(i64)]),
     "masr_read_stats": (i32, [vp, C.POINTER(f32), vp]),
     "masr_stats_post": (i64, [vp, vp]),

@@ -107,6 +107,7 @@ struct masr_model {
     LnReduceGroup lng; int64_t ln_slab_used = 0;           // LayerNorm dgamma/dbeta partials, folded by one grouped launch
     bool split_wgrad = false;                              // masr_set_split_wgrad_launches
     int slots = 1;                                         // masr_set_concurrency: task slots sharing the GPU
+    int drop_nan_grads = 0;                                // masr_set_drop_nan_grads: masr_clip_grads / masr_clip_accumulate turn a NaN-norm gradient into zeros (opt-out of quirk Q5)
     bool ksplit = false;                                   // masr_set_ksplit: few-row long-reduction GEMMs k-split, partials summed by the LayerNorm behind them
     int64_t n_ksplit = 0;                                  // k-split GEMM launches of the last masr_run_batch (masr_step_counters out[3])
     WgradGroup wg, wge;                                    // decoder-row / encoder-row weight gradients collected for the grouped launch (lin_wgrad)
@@ -987,6 +988,7 @@ int masr_run_batch(masr_model* m, const float* xs, const int64_t* ilens, const i
 void masr_set_step_graphs(masr_model* m, int on) { m->step_graphs_on = on != 0; }
 void masr_set_split_wgrad_launches(masr_model* m, int on) { if ((on != 0) != m->split_wgrad) drop_step_graphs(m); m->split_wgrad = on != 0; }
 void masr_set_ksplit(masr_model* m, int on) { if ((on != 0) != m->ksplit) drop_step_graphs(m); m->ksplit = on != 0; }
+void masr_set_drop_nan_grads(masr_model* m, int on) { m->drop_nan_grads = on != 0; }
 void masr_step_counters(const masr_model* m, int64_t out[4]) { out[0] = m->n_direct; out[1] = m->n_captured; out[2] = m->n_replayed; out[3] = m->n_ksplit; }
 
 int masr_read_stats(masr_model* m, float out[4], void* stream) {
@@ -1046,14 +1048,14 @@ int masr_clip_sgd_step(masr_model* m, float* mom, float max_norm, float lr, floa
 }
 int masr_clip_grads(masr_model* m, float max_norm, void* stream) {
     CK(masr_grad_norm(m, stream));
-    return mk_clip_scale(m->G, m->nparams, m->stats + 3, max_norm, (hipStream_t)stream);
+    return mk_clip_scale(m->G, m->nparams, m->stats + 3, max_norm, (hipStream_t)stream, m->drop_nan_grads);
 }
 int masr_clip_scale_flat(float* buf, int64_t n, const float* norm, float max_norm, void* stream) {
     return mk_clip_scale(buf, n, norm, max_norm, (hipStream_t)stream);
 }
 int masr_clip_accumulate(masr_model* m, float* updates, float max_norm, void* stream) {
     CK(masr_grad_norm(m, stream));
-    return mk_clip_axpy(updates, m->G, m->nparams, m->stats + 3, max_norm, (hipStream_t)stream);
+    return mk_clip_axpy(updates, m->G, m->nparams, m->stats + 3, max_norm, (hipStream_t)stream, m->drop_nan_grads);
 }
 int masr_adam_step(float* p, const float* g, float* ea, float* eas, int64_t n, float lr, float b1, float b2, float eps, int step, void* stream) {
     return mk_adam(p, g, ea, eas, n, lr, b1, b2, eps, step, 0.f, 0, (hipStream_t)stream);

@@ -207,8 +207,9 @@ long mk_sumsq_slab_floats(long n);
 // norm == nullptr: plain SGD step without clipping
 int mk_clip_sgd(float* p, const float* g, float* mom, long n, const float* norm, float max_norm, float lr,
                   float momentum, int nesterov, int first_step, hipStream_t s);     // NaN norm -> step skipped
-int mk_clip_scale(float* g, long n, const float* norm, float max_norm, hipStream_t s);    // g *= coef
-int mk_clip_axpy(float* acc, const float* g, long n, const float* norm, float max_norm, hipStream_t s); // acc += coef*g
+// (nan_zero: a NaN norm zeroes g / leaves acc alone instead of spreading NaNs -- masr_set_drop_nan_grads)
+int mk_clip_scale(float* g, long n, const float* norm, float max_norm, hipStream_t s, int nan_zero = 0);    // g *= coef
+int mk_clip_axpy(float* acc, const float* g, long n, const float* norm, float max_norm, hipStream_t s, int nan_zero = 0); // acc += coef*g
 int mk_scale(float* x, long n, float a, hipStream_t s);
 // weight_decay: decoupled != 0 -> AdamW (p *= 1 - lr*wd first), else torch.optim.Adam's L2 term (g += wd*p); 0 = plain Adam
 int mk_adam_guarded(float* p, const float* g, float* m, float* v, long n, float lr_a, int t_a, float lr_b, int t_b, float b1, float b2, float eps,

@@ -108,14 +108,20 @@ __device__ __forceinline__ void flat_pass(long n, int vec, F1 body, F4 body4) {
 }
 #define F4P(ptr) reinterpret_cast<float4*>(ptr)
 #define F4C(ptr) reinterpret_cast<const float4*>(ptr)
-__global__ void clip_scale_kernel(float* __restrict__ g, long n, const float* __restrict__ norm, float max_norm, int vec) {
+// nan_zero (masr_set_drop_nan_grads, the opt-out of quirk Q5): a gradient whose norm is NaN becomes / contributes zeros instead of NaNs
+__global__ void clip_scale_kernel(float* __restrict__ g, long n, const float* __restrict__ norm, float max_norm, int vec, int nan_zero) {
     const float coef = clip_coef(norm[0], max_norm);
+    if (nan_zero && coef != coef) {
+        flat_pass(n, vec, [&](long i) { g[i] = 0.f; }, [&](long i) { F4P(g)[i] = float4{0.f, 0.f, 0.f, 0.f}; });
+        return;
+    }
     flat_pass(n, vec, [&](long i) { g[i] *= coef; },
               [&](long i) { float4 v = F4C(g)[i]; v.x *= coef; v.y *= coef; v.z *= coef; v.w *= coef; F4P(g)[i] = v; });
 }
 __global__ void clip_axpy_kernel(float* __restrict__ acc, const float* __restrict__ g, long n, const float* __restrict__ norm,
-                                 float max_norm, int vec) {
+                                 float max_norm, int vec, int nan_zero) {
     const float coef = clip_coef(norm[0], max_norm);
+    if (nan_zero && coef != coef) return;
     flat_pass(n, vec, [&](long i) { acc[i] += coef * g[i]; },
               [&](long i) { float4 a = F4C(acc)[i]; const float4 v = F4C(g)[i];
                             a.x += coef * v.x; a.y += coef * v.y; a.z += coef * v.z; a.w += coef * v.w; F4P(acc)[i] = a; });
@@ -365,12 +371,12 @@ int mk_clip_sgd(float* p, const float* g, float* mom, long n, const float* norm,
     hipLaunchKernelGGL(clip_sgd_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, s, p, g, mom, n, norm, max_norm, lr, momentum, nesterov, first_step, vec);
     return LAUNCH_OK();
 }
-int mk_clip_scale(float* g, long n, const float* norm, float max_norm, hipStream_t s) {
-    hipLaunchKernelGGL(clip_scale_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, s, g, n, norm, max_norm, aligned16(g));
+int mk_clip_scale(float* g, long n, const float* norm, float max_norm, hipStream_t s, int nan_zero) {
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, s, g, n, norm, max_norm, aligned16(g), nan_zero);
     return LAUNCH_OK();
 }
-int mk_clip_axpy(float* acc, const float* g, long n, const float* norm, float max_norm, hipStream_t s) {
-    hipLaunchKernelGGL(clip_axpy_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, s, acc, g, n, norm, max_norm, aligned16(acc, g));
+int mk_clip_axpy(float* acc, const float* g, long n, const float* norm, float max_norm, hipStream_t s, int nan_zero) {
+    hipLaunchKernelGGL(clip_axpy_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, s, acc, g, n, norm, max_norm, aligned16(acc, g), nan_zero);
     return LAUNCH_OK();
 }
 int mk_scale(float* x, long n, float a, hipStream_t s) {

@@ -256,6 +256,11 @@ class MasrEngine:
         loops (train.py: mono / multi interface) turn it on (+3 %); the FOMAML interface leaves it off for every --tasks_per_gpu."""
         self._l.masr_set_ksplit(self.h, int(bool(on)))
 
+    def set_drop_nan_grads(self, on: bool):
+        """clip_grads / clip_accumulate turn a gradient whose norm is NaN into zeros (include/masr.h masr_set_drop_nan_grads; pretrain.py
+        --fix_nan_meta_grad).  Default off: the reference accumulates the NaNs (fo_meta_interface.py:151-154)."""
+        self._l.masr_set_drop_nan_grads(self.h, int(bool(on)))
+
     def step_counters(self):
         """{'direct', 'captured', 'replayed'}: how run_batch calls reached the GPU (kernel by kernel / graph capture / graph replay);
         'ksplit_gemms': k-split GEMM launches of the last step launched or captured (0 = whole reductions: masr_set_ksplit off)"""

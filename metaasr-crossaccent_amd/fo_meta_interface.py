@@ -7,7 +7,7 @@ flat HBM buffers of the HIP engine.
   train     : per task run_task + val-batch gradient + clip + accumulate; then /= counter and Noam-Adam
 Multi-GPU: tasks of a meta-step are split round-robin over ranks and `_updates` is all-reduced (parallel.py).
 Reference quirks kept by default: snapshots hold the LAST TASK's adapted weights (Q1/F8),
-evaluation runs on them too (Q2), a NaN val gradient is still accumulated (Q5); --fix_* flags opt out."""
+evaluation runs on them too (Q2), a NaN val gradient is still accumulated (Q5); --fix_snapshot_meta_weights / --fix_nan_meta_grad opt out."""
 import contextlib
 import math
 import pickle
@@ -75,6 +75,10 @@ class FOMetaASRInterface(PretrainInterface):
         # --fix_reptile: the reference's `--algo reptile` dies with ValueError in _partial_meta_update (:197-198);
         # with the flag the published Reptile pseudo-gradient (theta_meta - theta_k) is used instead (parity unpinned)
         self.fix_reptile = bool(getattr(paras, 'fix_reptile', False))
+        # --fix_nan_meta_grad: the reference warns about a NaN val-batch gradient and accumulates it all the same (:151-154, quirk Q5): one bad
+        # batch and the meta weights are NaN for good.  With the flag the val-batch clip turns such a gradient into zeros on the device
+        # (include/masr.h masr_set_drop_nan_grads): the task still counts in the mean, the warning is still logged.
+        self.fix_nan = bool(getattr(paras, 'fix_nan_meta_grad', False))
         # MI355X extension: tasks of one meta-step are independent, so several of them can run CONCURRENTLY on one GPU
         # (one model replica + HIP stream + host thread per slot).  A B=16 inner step leaves ~40 % of the 256 CUs idle
         # (small decoder GEMMs, kernel tails); three concurrent tasks raise the throughput ~1.6x.  1 = reference order.
@@ -200,6 +204,8 @@ class FOMetaASRInterface(PretrainInterface):
             # fp32 summation order that pays for a lone task only; the engine's default is off) stays off in this interface whatever K is
             if hasattr(sl['engine'], 'set_ksplit'):
                 sl['engine'].set_ksplit(False)
+            if self.fix_nan:
+                sl['engine'].set_drop_nan_grads(True)
 
     def write_tr_logs(self):
         for k, v in self.train_info.items():
@@ -243,7 +249,8 @@ class FOMetaASRInterface(PretrainInterface):
 
     def _clip_on_the_wire(self, engine=None):
         sh = self.sharder
-        return (engine is None and getattr(sh, 'native', False) and self.tasks_per_gpu == 1 and self.paras.algo == 'fomaml'
+        # (--fix_nan_meta_grad: the clip stays in masr_clip_grads, which is where a NaN-norm gradient is zeroed)
+        return (engine is None and getattr(sh, 'native', False) and self.tasks_per_gpu == 1 and self.paras.algo == 'fomaml' and not self.fix_nan
                 and hasattr(self.asr_model.engine, 'grad_norm_device_ptr'))
 
     def _drain_stats(self, keep_steps=0):

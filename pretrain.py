@@ -56,6 +56,7 @@ def build_parser():
                    'task is queued (the reference\'s timing of its log lines); default: the host runs one meta-step ahead of the GPU and books '
                    'them then -- same numbers, same order')
     p.add_argument('--fix_snapshot_meta_weights', action='store_true', help='save the META weights in snapshots (reference saves the last task\'s adapted weights)')
+    p.add_argument('--fix_nan_meta_grad', action='store_true', help='a val-batch gradient with a NaN norm contributes zeros to the meta update (the reference accumulates the NaNs)')
     p.add_argument('--fix_reptile', action='store_true', help='run --algo reptile with the published pseudo-gradient (the reference raises ValueError for it)')
     return p
 

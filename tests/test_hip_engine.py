@@ -527,3 +527,39 @@ def test_sgd_step_with_nan_norm_is_skipped():
     before = eng.params.clone()
     eng.clip_sgd_step(torch.zeros_like(eng.params), 5.0, 0.05, 0.9, True, 3)
     assert torch.equal(eng.params, before)
+
+
+def test_nan_val_gradient_accumulates_by_default_and_is_dropped_on_request():
+    """Quirk Q5 (fo_meta_interface.py:151-154): the reference warns about a NaN val-batch gradient and adds it to `_updates` all the same.
+    Default = that; masr_set_drop_nan_grads (pretrain.py --fix_nan_meta_grad): the clip zeroes such a gradient / the accumulate leaves
+    `updates` alone, decided on the device; the reported norm stays NaN (the warning is still logged); a finite gradient is unaffected."""
+    cfg = dict(TINY)
+    eng = MasrEngine(cfg, ODIM, label_smoothing=0.1)
+    eng.load_state_dict(ref_cpu.deterministic_state_dict(cfg, ODIM, seed=8))
+    xs, il, ys, ol = synth_batch(22, [64, 52], [9, 7])
+
+    def fresh(poison):
+        eng.run_batch(xs, il, ys, ol.clone(), train=True)
+        if poison:
+            eng.grads[5] = float("nan")
+    # reference behaviour
+    fresh(True)
+    upd = torch.ones_like(eng.params)
+    eng.clip_accumulate(upd, 5.0)
+    assert bool(torch.isnan(upd).all())
+    fresh(True)
+    eng.clip_grads(5.0)
+    assert bool(torch.isnan(eng.grads).all()) and math.isnan(eng.read_stats()['grad_norm'])
+    # a finite gradient: the switch changes nothing
+    fresh(False); eng.clip_grads(5.0); want = eng.grads.clone()
+    eng.set_drop_nan_grads(True)
+    fresh(False); eng.clip_grads(5.0)
+    assert torch.equal(eng.grads, want) and float(want.abs().max()) > 0
+    # NaN norm with the switch on
+    fresh(True)
+    upd = torch.ones_like(eng.params)
+    eng.clip_accumulate(upd, 5.0)
+    assert bool((upd == 1).all())
+    fresh(True)
+    eng.clip_grads(5.0)
+    assert bool((eng.grads == 0).all()) and math.isnan(eng.read_stats()['grad_norm'])
