@@ -29,6 +29,10 @@ int masr_test_attention_dropout(const uint16_t* q, const uint16_t* k, const uint
 /* the NT GEMM with any combination of its fused epilogue stages (tools/bench_gemm_epi.py: what each stage costs per launch) */
 int masr_test_gemm_epi(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int K, const float* bias, int relu,
                        float drop_p, const float* residual, const uint16_t* mask, float* C32, uint16_t* C16, void* stream);
+/* the operand-shadow pass of masr_refresh on ONE Linear weight: W fp32 [N][K] at P + src (P 16-byte aligned, src any dword offset >= 4 with at
+ * least four floats of P behind the tensor -- in the flat parameter buffer the shadowed tensors are neither first nor last) -> k16 bf16 [N][K]
+ * and its transpose t16 bf16 [K][ldt] (ldt >= N; the pads of a row stay untouched) */
+int masr_test_linear_shadows(const float* P, int64_t src, int N, int K, int ldt, uint16_t* k16, uint16_t* t16, void* stream);
 /* the first conv of the VGG front-end (CIN = 1, 64 output channels; mono_transformer_torch.py:49-50) as the engine launches it: x fp32 [B][H][W],
  * w fp32 [64][9], bias fp32 [64] -> out bf16 [B][H][W][64] = ReLU(conv + bias) (fp32 arithmetic on the exact-fp32 MFMA, rounded once) and, when
  * relu_bits is given, one 64-bit word per pixel whose bit c says whether channel c passed the ReLU (what the fused dgrad of the second conv reads) */

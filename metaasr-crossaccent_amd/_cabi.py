@@ -97,6 +97,7 @@ _SIGS = {
     "masr_test_gemm_dropout": (i32, [vp, i64, vp, i64, i32, i32, i32, f32, C.c_uint32, C.c_uint32, vp, i64, vp]),
     "masr_test_attention_dropout": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, C.c_uint32, C.c_uint32, vp]),
     "masr_test_gemm_epi": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, i32, f32, vp, vp, vp, vp, vp]),
+    "masr_test_linear_shadows": (i32, [vp, i64, i32, i32, i32, vp, vp, vp]),
     "masr_test_conv1_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "masr_test_conv3x3": (i32, [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     "masr_test_conv3x3_ex": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -1313,6 +1313,15 @@ int masr_test_gemm_epi(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
     g.C32 = C32; g.ldc = N; g.C16 = (bf16*)C16; g.ldc16 = N;
     return mk_gemm(g, (hipStream_t)stream);
 }
+int masr_test_linear_shadows(const float* P, int64_t src, int N, int K, int ldt, uint16_t* k16, uint16_t* t16, void* stream) {
+    if (N <= 0 || K <= 0 || ldt < N || src < 4) { mk_set_error("masr_test_linear_shadows", "N, K > 0, ldt >= N, src >= 4 (the tile pass reads up to three floats in front of a row)"); return -1; }
+    ShadowJobs jobs{};
+    jobs.n = 1;
+    jobs.d[0] = ShadowDesc{src, SH_LINEAR, N, K, ldt, 0, 0, 0};
+    jobs.blocks = mk_shadow_blocks(jobs.d[0]);
+    jobs.p[0] = (bf16*)k16; jobs.p[1] = (bf16*)t16;
+    return mk_all_shadows(P, jobs, (hipStream_t)stream);
+}
 int masr_test_conv1_fwd(const float* x, const float* w, const float* bias, uint16_t* out, uint64_t* relu_bits, int B, int H, int W, void* stream) {
     return mk_conv1_fwd(x, w, bias, (bf16*)out, B, H, W, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(relu_bits));
 }

@@ -238,6 +238,70 @@ __global__ __launch_bounds__(256) void vgg2enc_unpermute_kernel(const float* __r
 
 // every operand shadow of the model, one job list, one launch (see kernels.h)
 constexpr int SH_TILE = 64;
+
+// One full-width 64 x 64 tile of a Linear weight whose rows are a multiple of four floats: fp32 rows in, bf16 out in BOTH layouts, 16 bytes per
+// lane and access on the global side although the tensor sits at an arbitrary dword offset of the flat buffer (P itself is 16-byte aligned).
+// Every row of the tile starts `mis` floats past a 16-byte boundary (the same for all rows) and spans 17 ALIGNED float4s; SEVENTEEN lanes per row
+// take one vector each (15 rows per pass, five passes), round it to bf16 and drop it into two LDS images of the tile -- A[row][col] and
+// At[col][row] -- at its tile columns.  Both images carry a margin (A: 8 columns in front, 8 behind, rows 64..74; At: 4 rows in front and behind,
+// columns 64..75) that takes what the first / 17th vector hold of the neighbouring tile and the rows the fifth pass reads past the tile, so that
+// no lane tests what it owns; the margins are never read.  The read side is one 16-byte LDS read and one 16-byte store per lane, pass and layout.
+// (Round 6: the fp32 tile with scalar LDS reads and a rotation against its bank conflicts executed 780 instructions per wave and tile and ran the
+// launch at 3.0 TB/s; this form ~170.)
+constexpr int SH_SA = 80, SH_ST = 76;                             // row strides (elements): 160 B (16-byte reads), 152 B (8-byte reads)
+constexpr int SH_LDS_BYTES = (75 * SH_SA + 72 * SH_ST) * 2;       // 22 944 B: both images (the generic tile's fp32 [64][65] = 16 640 B shares them)
+__device__ __forceinline__ void shadow_tile_aligned(const float* __restrict__ P, const ShadowDesc& d, bf16* __restrict__ p0, bf16* __restrict__ p1,
+                                                    int r0, int c0, bf16* lds) {
+    constexpr int SA = SH_SA, ST = SH_ST;
+    bf16* const A = lds;                                          // [row k][8 + col]
+    bf16* const At = lds + 75 * SA;                               // [4 + col][row k]
+    const int mis = (int)((d.src + (long)r0 * d.K + c0) & 3);
+    const int v = threadIdx.x % 17, rr = threadIdx.x / 17;
+    if (rr < 15) {                                                // (thread 255 sits out)
+        // mis == 0: the 17th vector lies behind the tile (possibly behind the tensor): the 16th is read again and lands in the margin
+        const int vec = (v == 16 && mis == 0) ? 15 : v;
+        const float* base = P + d.src + (long)r0 * d.K + c0 - mis + 4 * vec;
+        bf16* a = A + rr * SA + 8 + 4 * v - mis;
+        bf16* at = At + (4 + 4 * v - mis) * ST + rr;
+        // all five loads first: a workgroup that waited for each pass's vector before asking for the next spent five memory round trips per tile
+        // (the launch ran at the latency, 54 us for 200 MB, whatever its instruction count)
+        float4 qs[5];
+#pragma unroll
+        for (int pass = 0; pass < 5; ++pass) {
+            const int k = rr + 15 * pass;
+            const int kr = r0 + k < d.N ? k : 0;                   // rows behind the tensor: the tile's first row again (never stored)
+            qs[pass] = *reinterpret_cast<const float4*>(base + (long)kr * d.K);
+        }
+#pragma unroll
+        for (int pass = 0; pass < 5; ++pass) {
+            const float4 q = qs[pass];
+            const bf16 b0 = (bf16)q.x, b1 = (bf16)q.y, b2 = (bf16)q.z, b3 = (bf16)q.w;
+            bf16* ak = a + 15 * pass * SA;
+            if (mis == 0) {
+                *reinterpret_cast<bf16x4*>(ak) = bf16x4{b0, b1, b2, b3};
+            } else {
+                ak[0] = b0; ak[1] = b1; ak[2] = b2; ak[3] = b3;
+            }
+            bf16* atk = at + 15 * pass;
+            atk[0] = b0; atk[ST] = b1; atk[2 * ST] = b2; atk[3 * ST] = b3;
+        }
+    }
+    __syncthreads();
+    const int sub = threadIdx.x & 7, line = threadIdx.x >> 3;        // 8 lanes x 8 elements = one 64-element line
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int l = line + 32 * pass;
+        if (r0 + l < d.N) st8(p0 + (long)(r0 + l) * d.K + c0 + sub * 8, *reinterpret_cast<const bf16x8*>(A + l * SA + 8 + sub * 8));   // k16 [N][K]
+        const int r = r0 + sub * 8;                                  // t16 [K][ldt]: line = tile column, elements run over the tile's rows
+        if (r < d.N) {
+            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(At + (4 + l) * ST + sub * 8), hi = *reinterpret_cast<const bf16x4*>(At + (4 + l) * ST + sub * 8 + 4);
+            const bf16x8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            bf16* dst = p1 + (long)(c0 + l) * d.ldt + r;
+            if (r + 8 <= d.N) st8(dst, o);
+            else for (int e = 0; r + e < d.N; ++e) dst[e] = o[e];   // (pads of a padded row stay untouched)
+        }
+    }
+}
 __global__ __launch_bounds__(256) void all_shadows_kernel(const float* __restrict__ P, const ShadowJobs jobs) {
     auto elem = [&](long i) -> float { return P[i]; };
     int lo = 0, hi = jobs.n - 1;                                  // last job whose tile_start <= blockIdx.x (uniform: scalar ALU)
@@ -245,12 +309,20 @@ __global__ __launch_bounds__(256) void all_shadows_kernel(const float* __restric
         const int mid = (lo + hi + 1) >> 1;
         if ((int)blockIdx.x >= jobs.d[mid].tile_start) lo = mid; else hi = mid - 1;
     }
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SH_LDS_BYTES];
+    static_assert(SH_LDS_BYTES >= SH_TILE * (SH_TILE + 1) * 4, "the generic tile fits");
     const int e = lo;
     const ShadowDesc& d = jobs.d[e];
     const int blk = blockIdx.x - d.tile_start;
     const float* x = P + d.src;
     bf16* p0 = jobs.p[2 * e]; bf16* p1 = jobs.p[2 * e + 1];
+    if (d.type == SH_LINEAR && (d.K & 3) == 0) {
+        const int tc = (d.K + SH_TILE - 1) / SH_TILE;
+        const int r0 = (blk / tc) * SH_TILE, c0 = (blk % tc) * SH_TILE;
+        if (c0 + SH_TILE <= d.K) { shadow_tile_aligned(P, d, p0, p1, r0, c0, reinterpret_cast<bf16*>(lds_raw)); return; }
+    }
     if (d.type == SH_LINEAR || d.type == SH_VGG2ENC) {
+        // the remaining tiles (a ragged last tile column, rows that are no multiple of four floats, the vgg2enc gather):
         // 64 x 64 tile: fp32 rows in, through LDS, bf16 out as 16 bytes per lane in BOTH layouts -- the pass is bound by
         // vector-memory instructions: 4-byte loads and 2-byte stores made 48 of them per wave and tile where 9 suffice.
         // SH_VGG2ENC is the same tile pass with a column gather on the way in: output column fn = dd * C + c comes from source column
@@ -260,7 +332,7 @@ __global__ __launch_bounds__(256) void all_shadows_kernel(const float* __restric
         const int dK = vgg ? d.a0 * d.a1 : d.K, dldt = vgg ? d.N : d.ldt;
         const int tc = (dK + SH_TILE - 1) / SH_TILE;
         const int r0 = (blk / tc) * SH_TILE, c0 = (blk % tc) * SH_TILE;
-        __shared__ float t[SH_TILE][SH_TILE + 1];
+        float (*t)[SH_TILE + 1] = reinterpret_cast<float (*)[SH_TILE + 1]>(lds_raw);
         if (vgg) {
             const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 4 rows per pass, 64 consecutive OUTPUT columns per row
             const int fn = c0 + tx, C = d.a0, Dp = d.a1;
@@ -268,27 +340,6 @@ __global__ __launch_bounds__(256) void all_shadows_kernel(const float* __restric
             for (int k = ty; k < SH_TILE; k += 4) {
                 const bool ok = r0 + k < d.N && fn < dK;
                 t[k][tx] = ok ? elem(d.src + (long)(r0 + k) * dK + f) : 0.f;
-            }
-        } else if ((d.K & 3) == 0 && c0 + SH_TILE <= d.K) {
-            // 16-byte accesses although the tensor sits at an arbitrary dword offset of the flat buffer (P itself is 16-byte aligned):
-            // every row of the tile starts `mis` floats past a 16-byte boundary (K % 4 == 0: the same for all rows) and spans 17
-            // ALIGNED float4s, the first owned from element `mis` on, the 17th up to it.  SEVENTEEN lanes per row take one vector
-            // each (15 rows per pass, five passes) and drop its owned elements into the LDS tile at their tile columns: one load per
-            // array and pass, no realignment in registers (16 lanes per row took two loads each -- the 17th vector -- and eight
-            // shuffles).  What lies outside the tile belongs to a neighbouring tile or tensor of P (never past its ends: the shadowed
-            // tensors are neither the first nor the last): read and dropped.
-            const int mis = (int)((d.src + (long)r0 * d.K + c0) & 3);
-            const int v = threadIdx.x % 17, rr = threadIdx.x / 17;
-            const int lo = v == 0 ? mis : 0, hi = v == 16 ? mis : 4;              // owned elements of the vector: [lo, hi)
-#pragma unroll
-            for (int pass = 0; pass < 5; ++pass) {
-                const int k = rr + 15 * pass;
-                const bool in = rr < 15 && k < SH_TILE, ok = in && r0 + k < d.N;
-                const long aoff = d.src + (long)(ok ? r0 + k : r0) * d.K + c0 - mis + 4 * (hi > lo ? v : 15);
-                const float4 q = *reinterpret_cast<const float4*>(P + aoff);
-                const float qa[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (in && e >= lo && e < hi) t[k][4 * v - mis + e] = ok ? qa[e] : 0.f;
             }
         } else {
             const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 4 rows per pass, 64 consecutive columns per row

@@ -691,3 +691,23 @@ def test_gemm_wide_outputs(L, M, N, K, flavour):
         ref = ref * mask.float()
     torch.testing.assert_close(C16[:M].float(), ref, rtol=1e-2, atol=2e-2 * (K ** 0.5) / 8)
     assert torch.all(C16[M].float() == 3.0)
+
+
+@pytest.mark.parametrize("N,K,ldt,src", [(512, 512, 512, 4), (2048, 512, 2048, 5), (512, 2048, 512, 6), (367, 512, 384, 7), (1536, 512, 1536, 1001),
+                                         (100, 200, 104, 9), (70, 66, 72, 11), (64, 64, 64, 8), (592, 130, 592, 13)])
+def test_linear_operand_shadows(L, N, K, ldt, src):
+    """masr_refresh's shadow pass on one Linear weight (the operands of `F.linear` and of its input gradient, mono_transformer_torch.py:74-98): k16
+    = the weight rounded to bf16, t16 = its transpose with row pitch ldt; exact.  Every dword misalignment of the tensor inside the flat buffer,
+    ragged row counts (367 = odim), widths that are no multiple of 64 or of 4 (the generic tiles), padded transposed rows whose pads stay
+    untouched; what surrounds the tensor in the buffer is NaN (a tile that stored a neighbour's element would show)."""
+    g = torch.Generator(device="cuda").manual_seed(N + K + src)
+    P_ = torch.full((src + N * K + 64,), float("nan"), device="cuda")
+    W = torch.randn(N, K, device="cuda", generator=g)
+    P_[src:src + N * K] = W.reshape(-1)
+    k16 = torch.full((N, K), 7.0, device="cuda").bfloat16()
+    t16 = torch.full((K, ldt), 7.0, device="cuda").bfloat16()
+    _cabi.check(L.masr_test_linear_shadows(P(P_), src, N, K, ldt, P(k16), P(t16), S()))
+    want = W.bfloat16()
+    assert torch.equal(k16, want)
+    assert torch.equal(t16[:, :N], want.t())
+    assert bool((t16[:, N:].float() == 7.0).all())
