@@ -226,7 +226,7 @@ int mk_transpose_cast_bf16(const float* x /*[R][C]*/, bf16* y /*[C][ldy]*/, int 
 // conv weight shadows: w [CO][CI][3][3] fp32 -> wk [CO][tap*CI+ci] (fwd) and wd [CI][tap'*CO+co] = w[co][ci][8-tap'] (dgrad)
 int mk_conv_weight_shadows(const float* w, bf16* wk, bf16* wd, int CO, int CI, hipStream_t s);       // (BLSTM engine; the transformer uses mk_all_shadows)
 // EVERY bf16 operand shadow of the model in ONE launch (masr_refresh after each parameter update), descriptor driven:
-//   SH_LINEAR   weight [N][K] at P+src -> k16 [N][K] and its transpose t16 [K][ldt] (32x32 tiles); ptrs[2i] = k16, ptrs[2i+1] = t16
+//   SH_LINEAR   weight [N][K] at P+src -> k16 [N][K] and its transpose t16 [K][ldt] (64x64 tiles); ptrs[2i] = k16, ptrs[2i+1] = t16
 //   SH_CONV     w [CO=N][CI=K][3][3] -> wk [CO][tap*CI+ci] (forward) and wd [CI][tap'*CO+co] = w[co][ci][8-tap'] (dgrad)
 //   SH_VGG2ENC  w [E=N][a0*a1] with reference feature index c*Dp+d (a0 = C, a1 = Dp) -> wk [E][d*C+c] (NHWC order) and wt = wk^T
 //   SH_COPY32   N floats at P+src -> (float*)ptrs[2i]   (the cross-attention K/V biases gathered into one vector)
