@@ -242,14 +242,16 @@ constexpr int SH_TILE = 64;
 // One full-width 64 x 64 tile of a Linear weight whose rows are a multiple of four floats: fp32 rows in, bf16 out in BOTH layouts, 16 bytes per
 // lane and access on the global side although the tensor sits at an arbitrary dword offset of the flat buffer (P itself is 16-byte aligned).
 // Every row of the tile starts `mis` floats past a 16-byte boundary (the same for all rows) and spans 17 ALIGNED float4s; SEVENTEEN lanes per row
-// take one vector each (15 rows per pass, five passes), round it to bf16 and drop it into two LDS images of the tile -- A[row][col] and
+// take one vector each (15 rows per pass, five passes: thread group rr takes rows 5 rr .. 5 rr + 4), round it to bf16 and drop it into two LDS images of the tile -- A[row][col] and
 // At[col][row] -- at its tile columns.  Both images carry a margin (A: 8 columns in front, 8 behind, rows 64..74; At: 4 rows in front and behind,
-// columns 64..75) that takes what the first / 17th vector hold of the neighbouring tile and the rows the fifth pass reads past the tile, so that
-// no lane tests what it owns; the margins are never read.  The read side is one 16-byte LDS read and one 16-byte store per lane, pass and layout.
+// columns 64..77) that takes what the first / 17th vector hold of the neighbouring tile and the rows the fifth pass reads past the tile, so that
+// no lane tests what it owns; the margins are never read.  The read side is 16 bytes from LDS and one 16-byte store per lane, pass and layout.
 // (Round 6: the fp32 tile with scalar LDS reads and a rotation against its bank conflicts executed 780 instructions per wave and tile and ran the
 // launch at 3.0 TB/s; this form ~170.)
-constexpr int SH_SA = 80, SH_ST = 76;                             // row strides (elements): 160 B (16-byte reads), 152 B (8-byte reads)
-constexpr int SH_LDS_BYTES = (75 * SH_SA + 72 * SH_ST) * 2;       // 22 944 B: both images (the generic tile's fp32 [64][65] = 16 640 B shares them)
+// row strides (elements): A 160 B (16-byte reads); At 156 B = 39 dwords: the seventeen lanes of a row write column elements 4 x 39 dwords apart
+// = 28 banks apart mod 64, sixteen different banks (at 152 B they met in eight: SQ_LDS_BANK_CONFLICT 0.31 of the wave cycles), read back as dwords
+constexpr int SH_SA = 80, SH_ST = 78;
+constexpr int SH_LDS_BYTES = (75 * SH_SA + 72 * SH_ST) * 2;       // 23 232 B: both images (the generic tile's fp32 [64][65] = 16 640 B shares them)
 __device__ __forceinline__ void shadow_tile_aligned(const float* __restrict__ P, const ShadowDesc& d, bf16* __restrict__ p0, bf16* __restrict__ p1,
                                                     int r0, int c0, bf16* lds) {
     constexpr int SA = SH_SA, ST = SH_ST;
@@ -261,14 +263,16 @@ __device__ __forceinline__ void shadow_tile_aligned(const float* __restrict__ P,
         // mis == 0: the 17th vector lies behind the tile (possibly behind the tensor): the 16th is read again and lands in the margin
         const int vec = (v == 16 && mis == 0) ? 15 : v;
         const float* base = P + d.src + (long)r0 * d.K + c0 - mis + 4 * vec;
-        bf16* a = A + rr * SA + 8 + 4 * v - mis;
-        bf16* at = At + (4 + 4 * v - mis) * ST + rr;
+        // thread (rr, v) takes rows 5 rr + pass: the four rows a wave writes at a time are five apart (adjacent rows would be the two halves of
+        // one dword of an At line)
+        bf16* a = A + 5 * rr * SA + 8 + 4 * v - mis;
+        bf16* at = At + (4 + 4 * v - mis) * ST + 5 * rr;
         // all five loads first: a workgroup that waited for each pass's vector before asking for the next spent five memory round trips per tile
         // (the launch ran at the latency, 54 us for 200 MB, whatever its instruction count)
         float4 qs[5];
 #pragma unroll
         for (int pass = 0; pass < 5; ++pass) {
-            const int k = rr + 15 * pass;
+            const int k = 5 * rr + pass;
             const int kr = r0 + k < d.N ? k : 0;                   // rows behind the tensor: the tile's first row again (never stored)
             qs[pass] = *reinterpret_cast<const float4*>(base + (long)kr * d.K);
         }
@@ -276,13 +280,13 @@ __device__ __forceinline__ void shadow_tile_aligned(const float* __restrict__ P,
         for (int pass = 0; pass < 5; ++pass) {
             const float4 q = qs[pass];
             const bf16 b0 = (bf16)q.x, b1 = (bf16)q.y, b2 = (bf16)q.z, b3 = (bf16)q.w;
-            bf16* ak = a + 15 * pass * SA;
+            bf16* ak = a + pass * SA;
             if (mis == 0) {
                 *reinterpret_cast<bf16x4*>(ak) = bf16x4{b0, b1, b2, b3};
             } else {
                 ak[0] = b0; ak[1] = b1; ak[2] = b2; ak[3] = b3;
             }
-            bf16* atk = at + 15 * pass;
+            bf16* atk = at + pass;
             atk[0] = b0; atk[ST] = b1; atk[2 * ST] = b2; atk[3 * ST] = b3;
         }
     }
@@ -294,8 +298,9 @@ __device__ __forceinline__ void shadow_tile_aligned(const float* __restrict__ P,
         if (r0 + l < d.N) st8(p0 + (long)(r0 + l) * d.K + c0 + sub * 8, *reinterpret_cast<const bf16x8*>(A + l * SA + 8 + sub * 8));   // k16 [N][K]
         const int r = r0 + sub * 8;                                  // t16 [K][ldt]: line = tile column, elements run over the tile's rows
         if (r < d.N) {
-            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(At + (4 + l) * ST + sub * 8), hi = *reinterpret_cast<const bf16x4*>(At + (4 + l) * ST + sub * 8 + 4);
-            const bf16x8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            const unsigned* w = reinterpret_cast<const unsigned*>(At + (4 + l) * ST + sub * 8);          // (4-byte aligned lines)
+            const bf16x8 o = __builtin_bit_cast(bf16x8, u32x4{w[0], w[1], w[2], w[3]});
             bf16* dst = p1 + (long)(c0 + l) * d.ldt + r;
             if (r + 8 <= d.N) st8(dst, o);
             else for (int e = 0; r + e < d.N; ++e) dst[e] = o[e];   // (pads of a padded row stay untouched)
