@@ -1616,18 +1616,15 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad2_kernel(ConvWgradArgs a, in
     // wave w owns input channels 16w .. 16w+15 x all 64 output channels x 9 taps: the four dy fragments of a pixel slab are
     // tap-independent (read once per slab), only ONE x fragment is read per tap: 26 transposing reads per 36 MFMAs
     // (the 2 x 2 wave grid needed 40)
+    // The partial slab is written in REGISTER order -- element ((tap * 4 + fm) * 256 + thread) * 4 + r of this (64-ci, 64-co) block's 36 864 --
+    // 36 sixteen-byte stores per lane, a kilobyte per wave-instruction (in [co][tap][ci] order the same 147 KB left as 144 dword stores per
+    // lane in 64-byte pieces, at the end of the launch with every CU storing at once); conv3x3_wgrad_reduce_body un-permutes (folds.h)
     auto write_slab = [&](f32x4 (&acc)[9][4]) {
-        float* out = a.slab + (long)blockIdx.x * COUT * KTOT;
+        float* out = a.slab + (long)blockIdx.x * COUT * KTOT + (long)blockIdx.y * (64 * 9 * 64) + tid * 4;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-            for (int fm = 0; fm < 4; ++fm)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = ch * 64 + fm * 16 + (lane >> 4) * 4 + r;
-                    const int ci = cs * 64 + wave * 16 + (lane & 15);
-                    out[(long)co * KTOT + tap * CIN + ci] = acc[tap][fm][r];
-                }
+            for (int fm = 0; fm < 4; ++fm) *reinterpret_cast<f32x4*>(out + (tap * 4 + fm) * 1024) = acc[tap][fm];
     };
     auto fold_db = [&]() {                                       // threads with equal tid % 8 own the same 8 output channels
         const int rc = tid / 8, j = tid % 8;

@@ -8,12 +8,14 @@
 namespace {
 
 // dw[co][ci][3][3] = sum over the per-workgroup partial slabs; 64 outputs x 4 slab-lanes per workgroup, four independent partial sums
-// per thread (fixed order -> deterministic); the trailing COUT entries are the bias gradient
+// per thread (fixed order -> deterministic); the trailing COUT entries are the bias gradient.  A slab holds the weight part in the REGISTER order
+// of conv3x3_wgrad2_kernel (conv.hip write_slab): per (64-ci slab cs, 64-co half ch) block of 36 864 floats, element
+// ((tap * 4 + fm) * 256 + wave * 64 + lane) * 4 + r is output channel ch * 64 + fm * 16 + (lane >> 4) * 4 + r, input channel cs * 64 + wave * 16 + (lane & 15)
 __device__ __forceinline__ void conv3x3_wgrad_reduce_body(const float* __restrict__ slab, int nsplit, float* __restrict__ dw,
                                                           float* __restrict__ db, int CIN, int COUT, int bx) {
     const int KTOT = 9 * CIN, NW = COUT * KTOT;
     const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int i = bx * 64 + cl;                       // co*KTOT + tap*CIN + ci, then NW + co for the bias
+    const int i = bx * 64 + cl;                       // slab element (register order), then NW + co for the bias
     __shared__ float red[4][64];
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (i < NW + COUT) {
@@ -32,7 +34,9 @@ __device__ __forceinline__ void conv3x3_wgrad_reduce_body(const float* __restric
         const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
         if (i >= NW) { if (db) db[i - NW] = t; }
         else {
-            const int co = i / KTOT, rem = i % KTOT, tap = rem / CIN, ci = rem % CIN;
+            const int yb = i / 36864, rem = i % 36864, tf = rem >> 10, th = (rem & 1023) >> 2, r = rem & 3, lane = th & 63;
+            const int cs = yb % (CIN / 64), ch = yb / (CIN / 64), tap = tf >> 2, fm = tf & 3;
+            const int co = ch * 64 + fm * 16 + (lane >> 4) * 4 + r, ci = cs * 64 + (th >> 6) * 16 + (lane & 15);
             dw[((long)co * CIN + ci) * 9 + tap] = t;
         }
     }
